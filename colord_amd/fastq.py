@@ -1,0 +1,122 @@
+"""Host-side FASTQ/FASTA reading with the reference reader's semantics (plumbing, not the hot path).
+
+Follows src/colord/in_reads.cpp:24-42 (ACGTN -> 0..4, anything else is an error), :62-77 / :104-112
+(a pack closes once sum(len+1) >= 4 Mi, the +1 being the reference's guard byte) and :114-226
+(multi-line FASTA, CRLF tolerance).
+"""
+from __future__ import annotations
+import gzip
+from dataclasses import dataclass, field
+import numpy as np
+
+READS_PACK_SIZE = 2 << 21          # defs.h:45
+
+_CODE = np.full(256, 255, dtype=np.uint8)
+for _c, _v in zip(b"ACGTN", range(5)):
+    _CODE[_c] = _v
+    _CODE[ord(chr(_c).lower())] = _v     # SymbToBinMap accepts lower case as well (utils.h)
+
+
+@dataclass
+class ReadSet:
+    """Reads in file order: concatenated base codes (1 B/base, 0..4) + offsets, qualities, headers."""
+    bases: np.ndarray                      # uint8 codes
+    offsets: np.ndarray                    # int64, n_reads+1
+    quals: np.ndarray | None               # uint8 ASCII, same offsets (None for FASTA)
+    headers: list = field(default_factory=list)   # bytes, without '@'/'>'
+    plus_eq: list = field(default_factory=list)   # bool: '+' line repeats the header
+    is_fastq: bool = True
+
+    @property
+    def n_reads(self) -> int:
+        return len(self.offsets) - 1
+
+    def read(self, i: int) -> np.ndarray:
+        return self.bases[self.offsets[i]:self.offsets[i + 1]]
+
+    def qual(self, i: int) -> np.ndarray:
+        return self.quals[self.offsets[i]:self.offsets[i + 1]]
+
+    def has_n(self) -> np.ndarray:
+        isn = (self.bases == 4).astype(np.int64)
+        cs = np.concatenate([[0], np.cumsum(isn)])
+        return (cs[self.offsets[1:]] - cs[self.offsets[:-1]]) > 0
+
+    def pack_bounds(self) -> np.ndarray:
+        """Read index boundaries of the reference's packs (in_reads.cpp:62-77)."""
+        lens = np.diff(self.offsets) + 1
+        bounds = [0]
+        acc = 0
+        for i, l in enumerate(lens):
+            acc += int(l)
+            if acc >= READS_PACK_SIZE:
+                bounds.append(i + 1)
+                acc = 0
+        if bounds[-1] != self.n_reads:
+            bounds.append(self.n_reads)
+        return np.asarray(bounds, dtype=np.int64)
+
+
+def _open(path):
+    with open(path, "rb") as f:
+        magic = f.read(2)
+    return gzip.open(path, "rb") if magic == b"\x1f\x8b" else open(path, "rb")
+
+
+def read_fastx(path: str) -> ReadSet:
+    with _open(path) as f:
+        data = f.read()
+    lines = data.split(b"\n")
+    if lines and lines[-1] == b"":
+        lines.pop()
+    lines = [l[:-1] if l.endswith(b"\r") else l for l in lines]
+    if not lines:
+        return ReadSet(np.zeros(0, np.uint8), np.zeros(1, np.int64), np.zeros(0, np.uint8))
+    is_fastq = lines[0][:1] == b"@"
+    seqs, quals, headers, plus_eq = [], [], [], []
+    if is_fastq:
+        if len(lines) % 4:
+            raise ValueError("truncated FASTQ")
+        for i in range(0, len(lines), 4):
+            h, s, p, q = lines[i:i + 4]
+            headers.append(h[1:])
+            if len(p) > 1 and p[1:] != h[1:]:
+                raise ValueError("quality header not empty but different than read header")
+            plus_eq.append(len(p) > 1)
+            seqs.append(s)
+            quals.append(q)
+    else:
+        cur = None
+        for l in lines:
+            if l[:1] == b">":
+                if cur is not None:
+                    seqs.append(b"".join(cur))
+                headers.append(l[1:])
+                plus_eq.append(False)
+                cur = []
+            else:
+                cur.append(l)
+        if cur is not None:
+            seqs.append(b"".join(cur))
+    lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=len(seqs))
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    bases = _CODE[np.frombuffer(b"".join(seqs), dtype=np.uint8)]
+    if (bases == 255).any():
+        raise ValueError("Only ACGTN symbols supported inside a read")
+    q = np.frombuffer(b"".join(quals), dtype=np.uint8).copy() if is_fastq else None
+    if is_fastq and len(q) != len(bases):
+        raise ValueError("quality length differs from read length")
+    return ReadSet(bases, offsets, q, headers, plus_eq, is_fastq)
+
+
+def write_fastq(path: str, rs: ReadSet, quals: np.ndarray | None = None) -> None:
+    lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    q = rs.quals if quals is None else quals
+    with open(path, "wb") as f:
+        for i in range(rs.n_reads):
+            a, b = rs.offsets[i], rs.offsets[i + 1]
+            f.write(b"@" + rs.headers[i] + b"\n")
+            f.write(lut[rs.bases[a:b]].tobytes())
+            f.write(b"\n+" + (rs.headers[i] if rs.plus_eq[i] else b"") + b"\n")
+            f.write(q[a:b].tobytes())
+            f.write(b"\n")

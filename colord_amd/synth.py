@@ -1,0 +1,48 @@
+"""Seed-reproducible synthetic ONT-like reads (host generator; SURVEY.md §8d recipe).
+
+genome: G uniform random bases; read length clip(lognormal(ln 20000 - sigma^2, sigma=0.7), 200, 200000)
+(N50 ~ 20 kb), uniform start, fair strand; per-base errors 2 % deletion, 3 % substitution, 2 % insertion;
+qualities i.i.d. from {Q4,Q10,Q20,Q34} = '%+5C' with p = (.1,.2,.4,.3); header
+``read_<n> ch=<n%512> start_time=2020-01-01T00:00:<n%60>Z``; '+' line empty.
+"""
+from __future__ import annotations
+import numpy as np
+from .fastq import ReadSet
+
+_QV = np.frombuffer(b"%+5C", dtype=np.uint8)
+_COMP = np.array([3, 2, 1, 0], dtype=np.uint8)
+
+
+def make_reads(seed: int, genome_len: int, target_bases: int, mean_scale: float = 20000.0,
+               sigma: float = 0.7, n_frac: float = 0.0, max_len: int = 200000) -> ReadSet:
+    rng = np.random.default_rng(seed)
+    genome = rng.integers(0, 4, genome_len, dtype=np.uint8)
+    mu = np.log(mean_scale) - sigma * sigma
+    seqs, quals, headers = [], [], []
+    tot = 0
+    n = 0
+    while tot < target_bases:
+        ln = int(min(max(rng.lognormal(mu, sigma), 200), min(max_len, genome_len - 1)))
+        st = int(rng.integers(0, genome_len - ln))
+        s = genome[st:st + ln]
+        if rng.random() < 0.5:
+            s = _COMP[s[::-1]]
+        r = rng.random(ln)
+        sub = (r >= 0.02) & (r < 0.05)
+        s = s.copy()
+        s[sub] = (s[sub] + rng.integers(1, 4, int(sub.sum()))) % 4
+        s = s[r >= 0.02]
+        ins = np.nonzero(rng.random(len(s)) < 0.02)[0]
+        s = np.insert(s, ins, rng.integers(0, 4, len(ins)).astype(np.uint8))
+        if n_frac > 0 and rng.random() < n_frac:          # sprinkle a few N into some reads
+            pos = rng.integers(0, len(s), max(1, len(s) // 2000))
+            s[pos] = 4
+        q = _QV[rng.choice(4, len(s), p=[0.1, 0.2, 0.4, 0.3])]
+        seqs.append(s)
+        quals.append(q)
+        headers.append(b"read_%d ch=%d start_time=2020-01-01T00:00:%02dZ" % (n, n % 512, n % 60))
+        tot += len(s)
+        n += 1
+    lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=len(seqs))
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    return ReadSet(np.concatenate(seqs), offsets, np.concatenate(quals), headers, [False] * n, True)

@@ -1,0 +1,73 @@
+/* oracle.h — CPU restatement of the CoLoRd v1.2.1 hot path (TEST INFRASTRUCTURE ONLY).
+ *
+ * Plain C99 restatement, written from the behaviour of the reference sources; every function cites the
+ * reference file:line it follows (paths relative to /root/reference).  Nothing here is shipped or
+ * measured as the product: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load liboracle.so.  The product path (colord_amd/) never calls into it.
+ *
+ * Parity status: PINNED.  Each stage is checked in tests/ against golden vectors dumped from the
+ * unmodified reference objects by oracle/ref_harness/ref_dump.cpp (built by oracle/Makefile.ref into
+ * oracle/_ref/) on the reference's own fixtures test/M.bovis, A.thaliana, D.melanogaster (+ genome).
+ *
+ * Conventions: bases are one byte each, A=0 C=1 G=2 T=3 N=4 (in_reads.cpp:24-42); k-mers are uint64,
+ * first base in the most significant bits (in_reads.h:59-73).
+ */
+#ifndef COLORD_ORACLE_H
+#define COLORD_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- a1: canonical k-mer walk + murmur-modulo filter ------------------------------------------- */
+uint64_t orc_hash_mm(uint64_t x);                                   /* hash_filter.h:8-16 */
+/* Pass-1 (KMC) semantics: every N-free window of k bases (splitter.cpp:560-660), canonical form,
+ * kept iff hash_mm(kmer) % f == 0 (hash_filter.h:28-77).  Appends to out (capacity cap), returns count
+ * (or the count that would be needed when out==NULL). */
+size_t orc_kmer_scan(const uint8_t* bases, size_t len, uint32_t k, uint32_t f, uint64_t* out, size_t cap);
+
+/* ---- a2: exact count, threshold, saturation (kb_sorter.h:1000-1060, kmc.h:1428-1485) ------------ */
+typedef struct {
+	uint64_t n_reads;          /* filled by the caller */
+	uint64_t tot_kmers;        /* "#Total no. of k-mers": surviving instances */
+	uint64_t n_unique;         /* distinct surviving k-mers */
+	uint64_t n_unique_counted; /* "#Unique_counted_k-mers": count >= ci */
+	uint64_t total_count_filtered; /* sum of min(count,cs) over kept keys (filter_kmers.cpp:77) */
+} orc_kmer_stats;
+/* kmers is sorted in place. keys/counts need capacity n. returns number of kept keys (ascending). */
+size_t orc_count_filter(uint64_t* kmers, size_t n, uint32_t ci, uint32_t cs,
+                        uint64_t* keys, uint32_t* counts, orc_kmer_stats* st);
+
+/* ---- a4: accepted k-mers of one read (reads_sim_graph.cpp:128-169) ------------------------------ */
+/* kept = ascending array of kept keys.  hasN reads and reads shorter than k yield nothing.
+ * Output: distinct canonical k-mers passing the modulo test and present in kept, first-occurrence order. */
+size_t orc_accepted_kmers(const uint8_t* bases, size_t len, uint32_t k, uint32_t f,
+                          const uint64_t* kept, size_t n_kept, uint64_t* out, size_t cap);
+
+/* ---- a6: reference-read acceptor (ref_reads_accepter.h:23-58) ----------------------------------- */
+/* Replays std::mt19937 (default seed 5489) + std::uniform_real_distribution<double>(0,1) as libstdc++
+ * implements them (two 32-bit draws per double).  out[i] for i in [0, n_pseudo + n_reads). */
+void orc_ref_accept(uint32_t n_reads, uint32_t n_pseudo, uint32_t range, double exponent, uint8_t* out);
+
+/* ---- a5: streaming k-mer -> reads multimap and candidate selection (reads_sim_graph.cpp:324-528) - */
+typedef struct orc_graph orc_graph;
+orc_graph* orc_graph_new(uint32_t max_candidates, uint32_t max_kmer_count);
+void orc_graph_free(orc_graph*);
+/* pseudo-read from the reference genome: always a reference, list cap not applied (:295-322) */
+void orc_graph_add_pseudo(orc_graph*, const uint64_t* kmers, size_t n);
+/* one real read in file order. accept = !hasN && acceptor decision. out_refs capacity max_candidates.
+ * If out_common != NULL (HiFi, :429-528): out_common_off[i]..[i+1] delimit, in out_common, the k-mers
+ * shared with out_refs[i] in read order (out_common capacity max_candidates * n). returns #candidates. */
+uint32_t orc_graph_next_read(orc_graph*, const uint64_t* kmers, size_t n, int accept,
+                             uint32_t* out_refs, uint32_t* out_votes,
+                             uint64_t* out_common, uint32_t* out_common_off);
+uint32_t orc_graph_n_refs(const orc_graph*);
+
+/* ---- a7: 2-bit reference read store (reference_reads.h:35-72) ----------------------------------- */
+size_t orc_refread_compact(const uint8_t* bases, size_t len, uint8_t* out);   /* returns (len+3)/4 + 1 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif
