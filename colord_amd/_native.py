@@ -1,0 +1,92 @@
+"""ctypes binding of libcolord_hip.so (the C ABI in include/colord_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call fails, an exception is
+raised.  Device memory is supplied by the caller (torch CUDA tensors -> data_ptr()).
+"""
+from __future__ import annotations
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcolord_hip.so")
+
+CL_OK, CL_E_INVALID, CL_E_HIP, CL_E_CAPACITY, CL_E_NOMEM, CL_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+
+
+class ColordHipError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"colord_hip error {status}: {msg}")
+        self.status = status
+
+
+class KmerStats(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("tot_kmers", C.c_uint64), ("n_unique", C.c_uint64),
+                ("n_unique_counted", C.c_uint64), ("total_count_filtered", C.c_uint64)]
+
+
+_P = C.c_void_p
+_SIG = {
+    "cl_ctx_create": (C.c_int32, [C.c_int, C.POINTER(_P)]),
+    "cl_ctx_destroy": (None, [_P]),
+    "cl_last_error": (C.c_char_p, [_P]),
+    "cl_ctx_stream": (_P, [_P]),
+    "cl_ctx_last_kernel_ms": (C.c_int32, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
+    "cl_ctx_set_timing": (None, [_P, C.c_int]),
+    "cl_reads_pack": (C.c_int32, [_P, _P, _P, C.c_uint32, C.c_int, C.POINTER(_P)]),
+    "cl_reads_free": (None, [_P]),
+    "cl_reads_count": (C.c_uint32, [_P]),
+    "cl_reads_total_bases": (C.c_uint64, [_P]),
+    "cl_reads_total_words": (C.c_uint64, [_P]),
+    "cl_reads_packed": (_P, [_P]),
+    "cl_reads_invalid": (_P, [_P]),
+    "cl_reads_word_offsets": (_P, [_P]),
+    "cl_reads_lengths": (_P, [_P]),
+    "cl_reads_has_n": (_P, [_P]),
+    "cl_reads_compact": (C.c_int32, [_P, _P, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "cl_kmer_scan": (C.c_int32, [_P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "cl_kmer_count_filter": (C.c_int32, [_P, _P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_P), C.POINTER(KmerStats)]),
+    "cl_kmer_set_free": (None, [_P]),
+    "cl_kmer_set_size": (C.c_uint64, [_P]),
+    "cl_kmer_set_keys": (_P, [_P]),
+    "cl_kmer_set_counts": (_P, [_P]),
+    "cl_kmer_set_check": (C.c_int32, [_P, _P, _P, C.c_uint64, _P]),
+    "cl_accepted_kmers": (C.c_int32, [_P, _P, _P, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
+    "cl_kmer_lists_free": (None, [_P]),
+    "cl_kmer_lists_reads": (C.c_uint32, [_P]),
+    "cl_kmer_lists_total": (C.c_uint64, [_P]),
+    "cl_kmer_lists_offsets": (_P, [_P]),
+    "cl_kmer_lists_kmers": (_P, [_P]),
+    "cl_kmer_lists_ids": (_P, [_P]),
+    "cl_kmer_lists_pos": (_P, [_P]),
+    "cl_ref_accept": (C.c_int32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, _P]),
+    "cl_index_build": (C.c_int32, [_P, _P, _P, _P, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
+    "cl_index_free": (None, [_P]),
+    "cl_index_n_refs": (C.c_uint32, [_P]),
+    "cl_index_entries": (C.c_uint64, [_P]),
+    "cl_index_ref_rank": (_P, [_P]),
+    "cl_candidates": (C.c_int32, [_P, _P, _P, C.c_uint32, _P, _P, _P]),
+    "cl_candidates_common": (C.c_int32, [_P, _P, _P, C.c_uint32, _P, _P, _P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "cl_sort_u64": (C.c_int32, [_P, _P, C.c_uint64, C.c_uint32, C.c_uint32]),
+    "cl_sort_u64_u32": (C.c_int32, [_P, _P, _P, C.c_uint64, C.c_uint32, C.c_uint32]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libcolord_hip.so and declare every entry point of include/colord_hip.h.  Fails loudly."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ColordHipError(CL_E_HIP, f"{LIB_PATH} is missing: run `make -C colord_amd/csrc` "
+                                 "(or __graft_entry__.build()); there is no CPU fallback")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIG.items():
+            fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def exported_names():
+    return sorted(_SIG)

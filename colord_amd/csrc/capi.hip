@@ -1,0 +1,81 @@
+// capi.hip — context management, host-side acceptor (a6) and thin exported wrappers.
+#include "common.hpp"
+#include "objects.hpp"
+#include <cmath>
+#include <random>
+
+extern "C" cl_status cl_ctx_create(int device, cl_ctx** out)
+{
+	if (!out) return CL_E_INVALID;
+	*out = nullptr;
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess || n <= 0) { fprintf(stderr, "colord_hip: no HIP device available (%s)\n", hipGetErrorString(e)); return CL_E_HIP; }
+	if (device < 0 || device >= n) return CL_E_INVALID;
+	if (hipSetDevice(device) != hipSuccess) return CL_E_HIP;
+	cl_ctx* c = new cl_ctx(); c->device = device;
+	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return CL_E_HIP; }
+	hipDeviceProp_t p;
+	if (hipGetDeviceProperties(&p, device) == hipSuccess) c->n_cu = p.multiProcessorCount;
+	*out = c;
+	return CL_OK;
+}
+extern "C" void cl_ctx_destroy(cl_ctx* c)
+{
+	if (!c) return;
+	(void)hipSetDevice(c->device);
+	for (auto& p : c->pending) { (void)hipEventDestroy(p.second.first); (void)hipEventDestroy(p.second.second); }
+	for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+	if (c->stream) (void)hipStreamDestroy(c->stream);
+	delete c;
+}
+extern "C" const char* cl_last_error(const cl_ctx* c) { return c ? c->err.c_str() : "null context"; }
+extern "C" void* cl_ctx_stream(cl_ctx* c) { return c ? (void*)c->stream : nullptr; }
+extern "C" void cl_ctx_set_timing(cl_ctx* c, int on) { if (c) c->timing = on != 0; }
+extern "C" cl_status cl_ctx_last_kernel_ms(const cl_ctx* c, const char* kernel, double* ms, uint32_t* launches)
+{
+	if (!c || !kernel) return CL_E_INVALID;
+	auto it = c->times.find(kernel);
+	if (it == c->times.end()) { if (ms) *ms = 0; if (launches) *launches = 0; return CL_E_INVALID; }
+	if (ms) *ms = it->second.ms;
+	if (launches) *launches = it->second.launches;
+	return CL_OK;
+}
+
+// a6 — CRefReadsAccepter (ref_reads_accepter.h:23-58).  The decision stream is one sequential
+// std::mt19937 (default seed) feeding std::uniform_real_distribution<double>(0,1): the archive format
+// depends on libstdc++'s generate_canonical (two 32-bit draws per double), so the same library types are
+// used here on the host; cost is negligible (one draw per read).
+extern "C" cl_status cl_ref_accept(uint32_t n_reads, uint32_t n_pseudo, uint32_t range, double exponent, uint8_t* h_out)
+{
+	if (!h_out || range == 0) return CL_E_INVALID;
+	std::mt19937 mt;
+	std::uniform_real_distribution<double> dist(0.0, 1.0);
+	for (uint64_t i = 0; i < (uint64_t)n_reads + n_pseudo; ++i)
+	{
+		if (i < n_pseudo) { h_out[i] = 1; continue; }
+		uint32_t range_no = (uint32_t)((i - n_pseudo) / range);
+		double p = std::pow(1.0 / (range_no + 1ul), exponent);
+		h_out[i] = dist(mt) <= p;
+	}
+	return CL_OK;
+}
+
+extern "C" cl_status cl_sort_u64(cl_ctx* ctx, uint64_t* d_keys, uint64_t n, uint32_t begin_bit, uint32_t end_bit)
+{
+	if (!ctx || (!d_keys && n)) return cl_fail(ctx, CL_E_INVALID, "cl_sort_u64: null argument");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	cl_timing_begin(ctx);
+	cl_status s = dev_sort_pairs(ctx, d_keys, nullptr, n, begin_bit, end_bit);
+	cl_timing_collect(ctx);
+	return s;
+}
+extern "C" cl_status cl_sort_u64_u32(cl_ctx* ctx, uint64_t* d_keys, uint32_t* d_vals, uint64_t n, uint32_t begin_bit, uint32_t end_bit)
+{
+	if (!ctx || ((!d_keys || !d_vals) && n)) return cl_fail(ctx, CL_E_INVALID, "cl_sort_u64_u32: null argument");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	cl_timing_begin(ctx);
+	cl_status s = dev_sort_pairs(ctx, d_keys, d_vals, n, begin_bit, end_bit);
+	cl_timing_collect(ctx);
+	return s;
+}

@@ -1,0 +1,149 @@
+// common.hpp — context, device memory helpers and wave64 device primitives shared by the kernels.
+// gfx950 only: wavefront = 64 lanes, no dual paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <map>
+#include "../../include/colord_hip.h"
+
+#define CL_WAVE 64
+
+struct KernelTime { double ms = 0; uint32_t launches = 0; };
+
+struct cl_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	std::string err;
+	bool timing = false;
+	std::map<std::string, KernelTime> times;     // per-kernel accumulated HIP-event time of the last API call
+	std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
+	std::vector<hipEvent_t> ev_pool;
+	int n_cu = 256;
+};
+
+static inline cl_status cl_fail(cl_ctx* c, cl_status s, const std::string& msg)
+{
+	if (c) c->err = msg;
+	return s;
+}
+
+#define HIP_TRY(ctx, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \
+	return cl_fail((ctx), CL_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e) + " @" + __FILE__ + ":" + std::to_string(__LINE__)); } } while (0)
+#define CL_TRY(expr) do { cl_status _s = (expr); if (_s != CL_OK) return _s; } while (0)
+
+// ---- device buffers (RAII, freed with the owning object) -----------------------------------------
+template<typename T> struct DevBuf {
+	T* p = nullptr; uint64_t n = 0;
+	DevBuf() = default;
+	DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
+	DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+	DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
+	~DevBuf() { release(); }
+	void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+	hipError_t alloc(uint64_t count) { release(); n = count; if (!count) count = 1; return hipMalloc((void**)&p, count * sizeof(T)); }
+};
+#define DEV_ALLOC(ctx, buf, count) do { hipError_t _e = (buf).alloc(count); if (_e != hipSuccess) \
+	return cl_fail((ctx), CL_E_NOMEM, std::string("hipMalloc(" #buf ") of ") + std::to_string((uint64_t)(count)) + " elems: " + hipGetErrorString(_e)); } while (0)
+
+// ---- per-kernel timing with HIP events on the context stream -------------------------------------
+struct KernelTimer {
+	cl_ctx* c; const char* name; hipEvent_t a = nullptr, b = nullptr;
+	KernelTimer(cl_ctx* c_, const char* n) : c(c_), name(n)
+	{
+		if (!c->timing) return;
+		auto get = [&]() { hipEvent_t e; if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); } else (void)hipEventCreate(&e); return e; };
+		a = get(); b = get();
+		(void)hipEventRecord(a, c->stream);
+	}
+	~KernelTimer()
+	{
+		if (!c->timing) return;
+		(void)hipEventRecord(b, c->stream);
+		c->pending.push_back({ name, { a, b } });
+	}
+};
+static inline void cl_timing_begin(cl_ctx* c) { if (c->timing) c->times.clear(); }
+static inline void cl_timing_collect(cl_ctx* c)
+{
+	if (!c->timing) return;
+	for (auto& p : c->pending)
+	{
+		(void)hipEventSynchronize(p.second.second);
+		float ms = 0; (void)hipEventElapsedTime(&ms, p.second.first, p.second.second);
+		auto& t = c->times[p.first]; t.ms += ms; t.launches += 1;
+		c->ev_pool.push_back(p.second.first); c->ev_pool.push_back(p.second.second);
+	}
+	c->pending.clear();
+}
+
+// ---- device primitives ---------------------------------------------------------------------------
+// MurmurHash3 fmix64 — the reference's filter hash (filtering-KMC/hash_filter.h:8-16)
+__host__ __device__ static inline uint64_t hash_mm(uint64_t x)
+{
+	x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
+	x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;
+	x ^= x >> 33;
+	return x;
+}
+
+// Exact "h % f == 0" for a launch-constant f without a divide: f = 2^s * d (d odd);
+// h divisible by f  <=>  low s bits of h are zero  and  (h >> s) * inv(d) mod 2^64 <= (2^64-1)/d.
+struct ModTest { uint64_t low_mask, dinv, lim; uint32_t s; };
+static inline ModTest make_modtest(uint32_t f)
+{
+	ModTest m; uint32_t s = 0; uint64_t d = f;
+	while ((d & 1) == 0) { d >>= 1; ++s; }
+	uint64_t inv = d;                       // Newton iteration for the inverse of odd d modulo 2^64
+	for (int i = 0; i < 6; ++i) inv *= 2 - d * inv;
+	m.s = s; m.low_mask = (s ? ((1ULL << s) - 1) : 0); m.dinv = inv; m.lim = ~0ULL / d;
+	return m;
+}
+__device__ static inline bool mod_is_zero(uint64_t h, const ModTest& m)
+{
+	return ((h & m.low_mask) == 0) && (((h >> m.s) * m.dinv) <= m.lim);
+}
+
+__device__ static inline uint32_t lane_id() { return threadIdx.x & 63; }
+__device__ static inline uint64_t lanemask_lt() { return (1ULL << lane_id()) - 1; }
+
+// inclusive wave scan (sum) over 64 lanes
+__device__ static inline uint32_t wave_incl_scan(uint32_t v)
+{
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) { uint32_t t = __shfl_up(v, d, 64); if ((int)lane_id() >= d) v += t; }
+	return v;
+}
+__device__ static inline uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+	for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+	return v;
+}
+
+// Block-wide exclusive scan for blockDim.x == 256 (4 waves).  sh must hold 4 uint32.  Returns the
+// exclusive prefix of v; *total receives the block sum.
+__device__ static inline uint32_t block_excl_scan_256(uint32_t v, uint32_t* sh, uint32_t* total)
+{
+	uint32_t incl = wave_incl_scan(v);
+	uint32_t w = threadIdx.x >> 6;
+	__syncthreads();                       // protect sh from a previous use
+	if (lane_id() == 63) sh[w] = incl;
+	__syncthreads();
+	uint32_t base = 0, tot = 0;
+#pragma unroll
+	for (uint32_t i = 0; i < 4; ++i) { uint32_t s = sh[i]; if (i < w) base += s; tot += s; }
+	*total = tot;
+	return base + incl - v;
+}
+
+// device-wide primitives implemented in scan.hip / sort.hip
+cl_status dev_exclusive_scan_u32(cl_ctx* ctx, uint32_t* d_data, uint64_t n, uint64_t* h_total);   // in place
+cl_status dev_exclusive_scan_u64(cl_ctx* ctx, const uint32_t* d_in, uint64_t* d_out, uint64_t n, uint64_t* h_total); // d_out has n+1
+cl_status dev_sort_pairs(cl_ctx* ctx, uint64_t* d_keys, uint32_t* d_vals, uint64_t n, uint32_t begin_bit, uint32_t end_bit);
+cl_status dev_sort_keys32_pairs(cl_ctx* ctx, uint32_t* d_keys, uint32_t* d_vals, uint64_t n, uint32_t begin_bit, uint32_t end_bit);
+
+static inline uint32_t grid_for(uint64_t n, uint32_t per_block) { return (uint32_t)((n + per_block - 1) / per_block); }

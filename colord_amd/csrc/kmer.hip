@@ -1,0 +1,597 @@
+// kmer.hip — read arena, canonical k-mer scan (a1), exact count + filter (a2), membership table (a3),
+// accepted k-mers per read (a4).  Integer/bit work on 2-bit packed bases: coalesced 8-byte loads of the
+// arena, rolling forward/reverse-complement k-mers in registers, murmur fmix64 + divide-free modulo
+// test, ballot/prefix compaction.  No MFMA anywhere on this path.
+#include "common.hpp"
+#include "objects.hpp"
+
+// ======================================================================================================
+// arena
+// ======================================================================================================
+namespace {
+
+__global__ void k_read_geometry(const uint64_t* __restrict__ off, uint32_t n_reads, uint32_t* __restrict__ lens,
+                                uint32_t* __restrict__ words, uint32_t* __restrict__ err)
+{
+	uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_reads) return;
+	uint64_t l = off[r + 1] - off[r];
+	if (off[r + 1] < off[r] || l >= 0xfffffff0ull) { atomicOr(err, 1u); l = 0; }
+	lens[r] = (uint32_t)l;
+	words[r] = (uint32_t)(l / 32 + 1);          // always at least one pad base after the read
+}
+
+__device__ inline uint32_t base_code(uint8_t c, int ascii, uint32_t* bad)
+{
+	if (!ascii) { if (c > 4) *bad = 1; return c; }
+	switch (c | 0x20) { case 'a': return 0; case 'c': return 1; case 'g': return 2; case 't': return 3; case 'n': return 4; }
+	*bad = 1; return 4;
+}
+
+// one wave per read; lane = one 32-base word per iteration
+__global__ __launch_bounds__(256) void k_pack(const uint8_t* __restrict__ codes, const uint64_t* __restrict__ off,
+                                              const uint64_t* __restrict__ word_off, const uint32_t* __restrict__ lens,
+                                              uint32_t n_reads, int ascii, uint64_t* __restrict__ packed,
+                                              uint32_t* __restrict__ inv, uint8_t* __restrict__ has_n, uint32_t* __restrict__ err)
+{
+	uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (r >= n_reads) return;
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t len = lens[r];
+	const uint64_t src = off[r], wb = word_off[r];
+	const uint32_t nw = len / 32 + 1;
+	uint32_t bad = 0, anyn = 0;
+	for (uint32_t w = lane; w < nw; w += 64)
+	{
+		uint64_t pw = 0; uint32_t iv = 0;
+		uint32_t p0 = w * 32;
+#pragma unroll 4
+		for (uint32_t j = 0; j < 32; ++j)
+		{
+			uint32_t p = p0 + j;
+			uint32_t c = 4; bool pad = p >= len;
+			if (!pad) c = base_code(codes[src + p], ascii, &bad);
+			if (c > 3) { iv |= 1u << (31 - j); if (!pad) anyn = 1; c = 0; }
+			pw |= (uint64_t)c << (62 - 2 * j);
+		}
+		packed[wb + w] = pw; inv[wb + w] = iv;
+	}
+	uint64_t bn = __ballot(anyn != 0), bb = __ballot(bad != 0);
+	if (lane == 0) { has_n[r] = bn != 0; if (bb) atomicOr(err, 2u); }
+}
+
+__global__ void k_arena_tail(uint64_t* packed, uint32_t* inv, uint64_t total_words)
+{
+	packed[total_words] = 0; inv[total_words] = 0xffffffffu;
+}
+} // namespace
+
+extern "C" cl_status cl_reads_pack(cl_ctx* ctx, const uint8_t* d_codes, const uint64_t* d_offsets, uint32_t n_reads,
+                                   int ascii, cl_reads** out)
+{
+	if (!ctx || !out || (!d_offsets)) return cl_fail(ctx, CL_E_INVALID, "cl_reads_pack: null argument");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	cl_reads* R = new cl_reads(); R->ctx = ctx; R->n_reads = n_reads;
+	std::unique_ptr<cl_reads> guard(R);
+	DEV_ALLOC(ctx, R->lens, n_reads); DEV_ALLOC(ctx, R->word_off, (uint64_t)n_reads + 1); DEV_ALLOC(ctx, R->has_n, n_reads);
+	DevBuf<uint32_t> words; DEV_ALLOC(ctx, words, n_reads);
+	DevBuf<uint32_t> err; DEV_ALLOC(ctx, err, 1);
+	HIP_TRY(ctx, hipMemsetAsync(err.p, 0, 4, ctx->stream));
+	if (n_reads)
+	{
+		hipLaunchKernelGGL(k_read_geometry, dim3(grid_for(n_reads, 256)), dim3(256), 0, ctx->stream, d_offsets, n_reads, R->lens.p, words.p, err.p);
+		HIP_TRY(ctx, hipGetLastError());
+	}
+	CL_TRY(dev_exclusive_scan_u64(ctx, words.p, R->word_off.p, n_reads, &R->total_words));
+	uint64_t first = 0, last = 0;
+	if (n_reads)
+	{
+		HIP_TRY(ctx, hipMemcpyAsync(&first, d_offsets, 8, hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(ctx, hipMemcpyAsync(&last, d_offsets + n_reads, 8, hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	}
+	R->total_bases = last - first;
+	DEV_ALLOC(ctx, R->packed, R->total_words + 1); DEV_ALLOC(ctx, R->inv, R->total_words + 1);
+	if (n_reads)
+	{
+		KernelTimer t(ctx, "pack_reads");
+		hipLaunchKernelGGL(k_pack, dim3(grid_for(n_reads, 4)), dim3(256), 0, ctx->stream, d_codes, d_offsets, (const uint64_t*)R->word_off.p,
+			(const uint32_t*)R->lens.p, n_reads, ascii, R->packed.p, R->inv.p, R->has_n.p, err.p);
+	}
+	HIP_TRY(ctx, hipGetLastError());
+	hipLaunchKernelGGL(k_arena_tail, dim3(1), dim3(1), 0, ctx->stream, R->packed.p, R->inv.p, R->total_words);
+	uint32_t herr = 0;
+	HIP_TRY(ctx, hipMemcpyAsync(&herr, err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	cl_timing_collect(ctx);
+	if (herr & 1) return cl_fail(ctx, CL_E_INVALID, "cl_reads_pack: offsets not monotone or read too long");
+	if (herr & 2) return cl_fail(ctx, CL_E_INVALID, "Only ACGTN symbols supported inside a read");   // in_reads.cpp:31-35
+	*out = guard.release();
+	return CL_OK;
+}
+extern "C" void cl_reads_free(cl_reads* r) { delete r; }
+extern "C" uint32_t cl_reads_count(const cl_reads* r) { return r->n_reads; }
+extern "C" uint64_t cl_reads_total_bases(const cl_reads* r) { return r->total_bases; }
+extern "C" uint64_t cl_reads_total_words(const cl_reads* r) { return r->total_words; }
+extern "C" const uint64_t* cl_reads_packed(const cl_reads* r) { return r->packed.p; }
+extern "C" const uint32_t* cl_reads_invalid(const cl_reads* r) { return r->inv.p; }
+extern "C" const uint64_t* cl_reads_word_offsets(const cl_reads* r) { return r->word_off.p; }
+extern "C" const uint32_t* cl_reads_lengths(const cl_reads* r) { return r->lens.p; }
+extern "C" const uint8_t* cl_reads_has_n(const cl_reads* r) { return r->has_n.p; }
+
+extern "C" cl_status cl_reads_compact(cl_ctx* ctx, const cl_reads* R, uint32_t read, uint8_t* h_out, uint64_t cap, uint64_t* n_out)
+{
+	if (!ctx || !R || read >= R->n_reads) return cl_fail(ctx, CL_E_INVALID, "cl_reads_compact: bad read index");
+	uint32_t len = 0; uint64_t wo = 0;
+	HIP_TRY(ctx, hipMemcpy(&len, R->lens.p + read, 4, hipMemcpyDeviceToHost));
+	HIP_TRY(ctx, hipMemcpy(&wo, R->word_off.p + read, 8, hipMemcpyDeviceToHost));
+	uint64_t nb = ((uint64_t)len + 3) / 4;
+	if (n_out) *n_out = nb + 1;
+	if (cap < nb + 1) return cl_fail(ctx, CL_E_CAPACITY, "cl_reads_compact: buffer too small");
+	std::vector<uint64_t> w(len / 32 + 1);
+	HIP_TRY(ctx, hipMemcpy(w.data(), R->packed.p + wo, w.size() * 8, hipMemcpyDeviceToHost));
+	// arena words are MSB-first, i.e. the big-endian byte image of a word IS the reference's 4-bases/byte layout
+	for (uint64_t b = 0; b < nb; ++b) h_out[b] = (uint8_t)(w[b / 8] >> (56 - 8 * (b % 8)));
+	if (len % 4) h_out[nb - 1] &= (uint8_t)(0xff << (8 - 2 * (len % 4)));
+	h_out[nb] = (uint8_t)(len % 4);
+	return CL_OK;
+}
+
+// ======================================================================================================
+// a1: canonical k-mer scan of one 32-base word (positions p = 0..31 start in word w, may extend into w+1)
+// ======================================================================================================
+namespace {
+
+__device__ inline uint64_t revcomp_k(uint64_t x, uint32_t k)
+{
+	x = ~x;                                               // complement (A<->T, C<->G) of every 2-bit group
+	x = __brevll(x);                                      // reverse all bits: groups reversed, bits inside a group swapped
+	x = ((x >> 1) & 0x5555555555555555ULL) | ((x & 0x5555555555555555ULL) << 1);
+	return x >> (64 - 2 * k);
+}
+// forward k-mer starting at base p of the 64-base window (hi:lo)
+__device__ inline uint64_t fwd_at(uint64_t hi, uint64_t lo, uint32_t p, uint32_t k, uint64_t mask)
+{
+	uint32_t s = 128 - 2 * (p + k);                       // right shift of the 128-bit window
+	uint64_t v = (s >= 64) ? (hi >> (s - 64)) : ((hi << (64 - s)) | (lo >> s));
+	return v & mask;
+}
+__device__ inline bool window_valid(uint64_t inv64, uint32_t p, uint32_t k)
+{
+	return ((inv64 >> (64 - (p + k))) & ((1ULL << k) - 1)) == 0;
+}
+
+// Returns the 32-bit mask (bit p) of start positions whose canonical k-mer passes the modulo test.
+__device__ inline uint32_t scan_word(uint64_t hi, uint64_t lo, uint64_t inv64, uint32_t k, const ModTest& mt)
+{
+	if ((inv64 >> 32) == 0xffffffffull) return 0;
+	const uint64_t mask = (1ULL << (2 * k)) - 1;
+	const uint32_t roff = 2 * (k - 1);
+	uint64_t fwd = hi >> (64 - 2 * k);
+	uint64_t rev = revcomp_k(fwd, k);
+	uint32_t res = 0;
+#pragma unroll 8
+	for (uint32_t p = 0; p < 32; ++p)
+	{
+		if (window_valid(inv64, p, k))
+		{
+			uint64_t can = fwd < rev ? fwd : rev;
+			if (mod_is_zero(hash_mm(can), mt)) res |= 1u << p;
+		}
+		uint32_t j = p + k;                               // next base index in the window, < 64
+		uint64_t src = j < 32 ? hi : lo;
+		uint64_t b = (src >> (62 - 2 * (j & 31))) & 3;
+		fwd = ((fwd << 2) | b) & mask;
+		rev = (rev >> 2) | ((3 - b) << roff);
+	}
+	return res;
+}
+__device__ inline uint64_t canonical_at(uint64_t hi, uint64_t lo, uint32_t p, uint32_t k)
+{
+	const uint64_t mask = (1ULL << (2 * k)) - 1;
+	uint64_t f = fwd_at(hi, lo, p, k, mask);
+	uint64_t r = revcomp_k(f, k);
+	return f < r ? f : r;
+}
+
+__global__ __launch_bounds__(256) void k_kmer_scan(const uint64_t* __restrict__ packed, const uint32_t* __restrict__ inv,
+                                                   uint64_t total_words, uint32_t k, ModTest mt,
+                                                   uint64_t* __restrict__ out, uint64_t cap, unsigned long long* __restrict__ counter)
+{
+	__shared__ uint32_t sh[4];
+	__shared__ unsigned long long sbase;
+	uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	uint64_t hi = 0, lo = 0, inv64 = ~0ULL; uint32_t m = 0;
+	if (w < total_words)
+	{
+		hi = packed[w]; lo = packed[w + 1];
+		inv64 = ((uint64_t)inv[w] << 32) | inv[w + 1];
+		m = scan_word(hi, lo, inv64, k, mt);
+	}
+	uint32_t cnt = __popc(m), total;
+	uint32_t ex = block_excl_scan_256(cnt, sh, &total);
+	if (threadIdx.x == 0) sbase = total ? atomicAdd(counter, (unsigned long long)total) : 0ULL;
+	__syncthreads();
+	uint64_t o = sbase + ex;
+	while (m)
+	{
+		uint32_t p = __ffs(m) - 1; m &= m - 1;
+		if (o < cap) out[o] = canonical_at(hi, lo, p, k);
+		++o;
+	}
+}
+} // namespace
+
+extern "C" cl_status cl_kmer_scan(cl_ctx* ctx, const cl_reads* R, uint32_t k, uint32_t f, uint64_t* d_out, uint64_t cap, uint64_t* n_out)
+{
+	if (!ctx || !R || !n_out) return cl_fail(ctx, CL_E_INVALID, "cl_kmer_scan: null argument");
+	if (k < 1 || k > 28 || f < 1) return cl_fail(ctx, CL_E_INVALID, "cl_kmer_scan: need 1 <= k <= 28 and f >= 1");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	cl_timing_begin(ctx);
+	DevBuf<unsigned long long> counter; DEV_ALLOC(ctx, counter, 1);
+	HIP_TRY(ctx, hipMemsetAsync(counter.p, 0, 8, ctx->stream));
+	if (R->total_words)
+	{
+		KernelTimer t(ctx, "kmer_scan");
+		hipLaunchKernelGGL(k_kmer_scan, dim3(grid_for(R->total_words, 256)), dim3(256), 0, ctx->stream,
+			(const uint64_t*)R->packed.p, (const uint32_t*)R->inv.p, R->total_words, k, make_modtest(f), d_out, cap, counter.p);
+	}
+	HIP_TRY(ctx, hipGetLastError());
+	unsigned long long n = 0;
+	HIP_TRY(ctx, hipMemcpyAsync(&n, counter.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	cl_timing_collect(ctx);
+	*n_out = n;
+	if (n > cap) return cl_fail(ctx, CL_E_CAPACITY, "cl_kmer_scan: output capacity " + std::to_string(cap) + " < " + std::to_string(n));
+	return CL_OK;
+}
+
+// ======================================================================================================
+// a2: exact counts by sort + run lengths; a3: bucketed open-addressing membership table
+// ======================================================================================================
+namespace {
+
+__global__ void k_head_flags(const uint64_t* __restrict__ keys, uint64_t n, uint32_t* __restrict__ flags)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+// flags already exclusive-scanned in place: position i is a run head iff it is the last element or scan[i+1] != scan[i]
+__global__ void k_scatter_heads(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ scan, uint64_t n, uint64_t n_heads,
+                                uint32_t* __restrict__ head_pos)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	uint32_t s = scan[i];
+	uint32_t nx = (i + 1 < n) ? scan[i + 1] : (uint32_t)n_heads;
+	if (nx != s) head_pos[s] = (uint32_t)i;
+}
+__global__ void k_count_flags(const uint32_t* __restrict__ head_pos, uint64_t n_heads, uint64_t n, uint32_t ci,
+                              uint32_t* __restrict__ flags)
+{
+	uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= n_heads) return;
+	uint64_t end = (j + 1 < n_heads) ? head_pos[j + 1] : n;
+	flags[j] = (end - head_pos[j] >= ci) ? 1u : 0u;
+}
+__global__ void k_scatter_kept(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ head_pos, const uint32_t* __restrict__ scan,
+                               uint64_t n_heads, uint64_t n_kept, uint64_t n, uint32_t cs,
+                               uint64_t* __restrict__ kept_keys, uint32_t* __restrict__ kept_counts, unsigned long long* __restrict__ sum)
+{
+	uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t c = 0;
+	if (j < n_heads)
+	{
+		uint32_t s = scan[j];
+		uint32_t nx = (j + 1 < n_heads) ? scan[j + 1] : (uint32_t)n_kept;
+		if (nx != s)
+		{
+			uint64_t end = (j + 1 < n_heads) ? head_pos[j + 1] : n;
+			uint64_t cnt = end - head_pos[j];
+			c = cnt > cs ? cs : (uint32_t)cnt;             // saturating counter ("-cs", kb_sorter.h:1000-1060)
+			kept_keys[s] = keys[head_pos[j]]; kept_counts[s] = c;
+		}
+	}
+	uint32_t ws = wave_sum(c);
+	if ((threadIdx.x & 63) == 0 && ws) atomicAdd(sum, (unsigned long long)ws);
+}
+
+// ---- membership table: buckets of 4 x {key, value} = 64 bytes, load <= 0.5, linear probing over buckets
+struct Slot { uint64_t key, val; };
+constexpr uint64_t SLOT_EMPTY = ~0ULL;
+__device__ inline uint64_t bucket_of(uint64_t key, uint64_t bmask) { return (hash_mm(key) >> 20) & bmask; }
+
+__global__ void k_table_build(const uint64_t* __restrict__ keys, uint64_t n, Slot* __restrict__ slots, uint64_t bmask)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	uint64_t key = keys[i];
+	uint64_t b = bucket_of(key, bmask);
+	for (;;)
+	{
+		for (uint32_t s = 0; s < 4; ++s)
+		{
+			unsigned long long* kp = (unsigned long long*)&slots[b * 4 + s].key;
+			unsigned long long old = atomicCAS(kp, (unsigned long long)SLOT_EMPTY, (unsigned long long)key);
+			if (old == SLOT_EMPTY) { slots[b * 4 + s].val = i; return; }
+		}
+		b = (b + 1) & bmask;
+	}
+}
+} // namespace
+
+// returns rank of key in the sorted kept array, or ~0u
+__device__ uint32_t table_lookup(const void* slots_v, uint64_t bmask, uint64_t key)
+{
+	const Slot* slots = (const Slot*)slots_v;
+	uint64_t b = bucket_of(key, bmask);
+	for (;;)
+	{
+		const ulonglong2* bp = (const ulonglong2*)(slots + b * 4);
+		ulonglong2 s0 = bp[0], s1 = bp[1], s2 = bp[2], s3 = bp[3];
+		if (s0.x == key) return (uint32_t)s0.y;
+		if (s1.x == key) return (uint32_t)s1.y;
+		if (s2.x == key) return (uint32_t)s2.y;
+		if (s3.x == key) return (uint32_t)s3.y;
+		if (s0.x == SLOT_EMPTY || s1.x == SLOT_EMPTY || s2.x == SLOT_EMPTY || s3.x == SLOT_EMPTY) return ~0u;
+		b = (b + 1) & bmask;
+	}
+}
+
+namespace {
+__global__ void k_table_check(const void* slots, uint64_t bmask, const uint64_t* __restrict__ kmers, uint64_t n, uint8_t* __restrict__ found)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) found[i] = table_lookup(slots, bmask, kmers[i]) != ~0u;
+}
+} // namespace
+
+extern "C" cl_status cl_kmer_count_filter(cl_ctx* ctx, uint64_t* d_kmers, uint64_t n, uint32_t k, uint32_t ci, uint32_t cs,
+                                          cl_kmer_set** out, cl_kmer_stats* stats)
+{
+	if (!ctx || !out) return cl_fail(ctx, CL_E_INVALID, "cl_kmer_count_filter: null argument");
+	if (k < 1 || k > 28) return cl_fail(ctx, CL_E_INVALID, "cl_kmer_count_filter: need 1 <= k <= 28");
+	if (n >= (1ULL << 32)) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_kmer_count_filter: n must be < 2^32 per call");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	cl_timing_begin(ctx);
+	cl_kmer_set* S = new cl_kmer_set(); S->ctx = ctx; S->k = k;
+	std::unique_ptr<cl_kmer_set> guard(S);
+	uint64_t n_heads = 0, n_kept = 0; unsigned long long filt = 0;
+	if (n)
+	{
+		CL_TRY(dev_sort_pairs(ctx, d_kmers, nullptr, n, 0, 2 * k));
+		DevBuf<uint32_t> flags; DEV_ALLOC(ctx, flags, n);
+		{ KernelTimer t(ctx, "count_head_flags");
+		  hipLaunchKernelGGL(k_head_flags, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, (const uint64_t*)d_kmers, n, flags.p); }
+		HIP_TRY(ctx, hipGetLastError());
+		CL_TRY(dev_exclusive_scan_u32(ctx, flags.p, n, &n_heads));
+		DevBuf<uint32_t> head_pos; DEV_ALLOC(ctx, head_pos, n_heads);
+		{ KernelTimer t(ctx, "count_scatter_heads");
+		  hipLaunchKernelGGL(k_scatter_heads, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, (const uint64_t*)d_kmers, (const uint32_t*)flags.p, n, n_heads, head_pos.p); }
+		HIP_TRY(ctx, hipGetLastError());
+		DevBuf<uint32_t> kflags; DEV_ALLOC(ctx, kflags, n_heads);
+		hipLaunchKernelGGL(k_count_flags, dim3(grid_for(n_heads, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)head_pos.p, n_heads, n, ci, kflags.p);
+		HIP_TRY(ctx, hipGetLastError());
+		CL_TRY(dev_exclusive_scan_u32(ctx, kflags.p, n_heads, &n_kept));
+		DEV_ALLOC(ctx, S->keys, n_kept); DEV_ALLOC(ctx, S->counts, n_kept);
+		DevBuf<unsigned long long> sum; DEV_ALLOC(ctx, sum, 1);
+		HIP_TRY(ctx, hipMemsetAsync(sum.p, 0, 8, ctx->stream));
+		hipLaunchKernelGGL(k_scatter_kept, dim3(grid_for(n_heads, 256)), dim3(256), 0, ctx->stream, (const uint64_t*)d_kmers, (const uint32_t*)head_pos.p,
+			(const uint32_t*)kflags.p, n_heads, n_kept, n, cs, S->keys.p, S->counts.p, sum.p);
+		HIP_TRY(ctx, hipGetLastError());
+		HIP_TRY(ctx, hipMemcpyAsync(&filt, sum.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	}
+	else { DEV_ALLOC(ctx, S->keys, 0); DEV_ALLOC(ctx, S->counts, 0); }
+	S->n = n_kept;
+	// a3: table with >= 2 slots per key
+	uint64_t nbuckets = 16; while (nbuckets * 4 < 2 * n_kept) nbuckets <<= 1;
+	S->bmask = nbuckets - 1;
+	DEV_ALLOC(ctx, S->slots, nbuckets * 4 * 2);     // as uint64 pairs
+	HIP_TRY(ctx, hipMemsetAsync(S->slots.p, 0xff, nbuckets * 64, ctx->stream));
+	if (n_kept)
+	{
+		KernelTimer t(ctx, "table_build");
+		hipLaunchKernelGGL(k_table_build, dim3(grid_for(n_kept, 256)), dim3(256), 0, ctx->stream, (const uint64_t*)S->keys.p, n_kept, (Slot*)S->slots.p, S->bmask);
+	}
+	HIP_TRY(ctx, hipGetLastError());
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	cl_timing_collect(ctx);
+	if (stats) { stats->tot_kmers = n; stats->n_unique = n_heads; stats->n_unique_counted = n_kept; stats->total_count_filtered = filt; }
+	*out = guard.release();
+	return CL_OK;
+}
+extern "C" void cl_kmer_set_free(cl_kmer_set* s) { delete s; }
+extern "C" uint64_t cl_kmer_set_size(const cl_kmer_set* s) { return s->n; }
+extern "C" const uint64_t* cl_kmer_set_keys(const cl_kmer_set* s) { return s->keys.p; }
+extern "C" const uint32_t* cl_kmer_set_counts(const cl_kmer_set* s) { return s->counts.p; }
+extern "C" cl_status cl_kmer_set_check(cl_ctx* ctx, const cl_kmer_set* S, const uint64_t* d_kmers, uint64_t n, uint8_t* d_found)
+{
+	if (!ctx || !S) return cl_fail(ctx, CL_E_INVALID, "cl_kmer_set_check: null argument");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	if (n) hipLaunchKernelGGL(k_table_check, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, (const void*)S->slots.p, S->bmask, d_kmers, n, d_found);
+	HIP_TRY(ctx, hipGetLastError());
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return CL_OK;
+}
+
+// ======================================================================================================
+// a4: accepted k-mers per read
+// ======================================================================================================
+namespace {
+
+// phase A: per word, mask of start positions whose canonical k-mer passes the modulo test AND is in the set
+__global__ __launch_bounds__(256) void k_found_mask(const uint64_t* __restrict__ packed, const uint32_t* __restrict__ inv,
+                                                    uint64_t total_words, uint32_t k, ModTest mt, const void* slots, uint64_t bmask,
+                                                    uint32_t* __restrict__ fmask)
+{
+	uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	if (w >= total_words) return;
+	uint64_t hi = packed[w], lo = packed[w + 1];
+	uint64_t inv64 = ((uint64_t)inv[w] << 32) | inv[w + 1];
+	uint32_t m = scan_word(hi, lo, inv64, k, mt), res = 0;
+	while (m)
+	{
+		uint32_t p = __ffs(m) - 1; m &= m - 1;
+		if (table_lookup(slots, bmask, canonical_at(hi, lo, p, k)) != ~0u) res |= 1u << p;
+	}
+	fmask[w] = res;
+}
+// per read: number of records (one wave per read)
+__global__ __launch_bounds__(256) void k_read_counts(const uint32_t* __restrict__ fmask, const uint64_t* __restrict__ word_off,
+                                                     const uint32_t* __restrict__ lens, const uint8_t* __restrict__ has_n,
+                                                     uint32_t n_reads, uint32_t k, uint32_t* __restrict__ counts)
+{
+	uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (r >= n_reads) return;
+	uint32_t lane = threadIdx.x & 63, c = 0;
+	if (!has_n[r] && lens[r] >= k)                        // reads_sim_graph.cpp:142-146
+	{
+		uint64_t wb = word_off[r]; uint32_t nw = (uint32_t)(word_off[r + 1] - wb);
+		for (uint32_t w = lane; w < nw; w += 64) c += __popc(fmask[wb + w]);
+	}
+	c = wave_sum(c);
+	if (lane == 0) counts[r] = c;
+}
+// phase B: write records in (read, position) order
+__global__ __launch_bounds__(256) void k_emit_records(const uint64_t* __restrict__ packed, const uint32_t* __restrict__ fmask,
+                                                      const uint64_t* __restrict__ word_off, const uint64_t* __restrict__ rec_off,
+                                                      uint32_t n_reads, uint32_t k, const void* slots, uint64_t bmask,
+                                                      uint32_t* __restrict__ rec_id, uint32_t* __restrict__ rec_pos, uint32_t* __restrict__ rec_read)
+{
+	uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (r >= n_reads) return;
+	uint64_t o = rec_off[r];
+	if (rec_off[r + 1] == o) return;
+	uint32_t lane = threadIdx.x & 63;
+	uint64_t wb = word_off[r]; uint32_t nw = (uint32_t)(word_off[r + 1] - wb);
+	for (uint32_t w0 = 0; w0 < nw; w0 += 64)
+	{
+		uint32_t w = w0 + lane;
+		uint32_t m = (w < nw) ? fmask[wb + w] : 0u;
+		uint32_t cnt = __popc(m);
+		uint32_t incl = wave_incl_scan(cnt);
+		uint32_t tot = __shfl(incl, 63, 64);
+		uint64_t my = o + incl - cnt;
+		if (m)
+		{
+			uint64_t hi = packed[wb + w], lo = packed[wb + w + 1];
+			while (m)
+			{
+				uint32_t p = __ffs(m) - 1; m &= m - 1;
+				rec_id[my] = table_lookup(slots, bmask, canonical_at(hi, lo, p, k));
+				rec_pos[my] = w * 32 + p; rec_read[my] = r;
+				++my;
+			}
+		}
+		o += tot;
+	}
+}
+__global__ void k_iota(uint32_t* v, uint64_t n) { uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) v[i] = (uint32_t)i; }
+// sorted by id (stable): record j is a duplicate iff the previous record has the same id and the same read
+__global__ void k_flag_first(const uint32_t* __restrict__ sid, const uint32_t* __restrict__ sidx, const uint32_t* __restrict__ rec_read,
+                             uint64_t n, uint32_t* __restrict__ keep)
+{
+	uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= n) return;
+	uint32_t me = sidx[j];
+	bool dup = j > 0 && sid[j] == sid[j - 1] && rec_read[sidx[j - 1]] == rec_read[me];
+	keep[me] = dup ? 0u : 1u;
+}
+__global__ void k_compact_records(const uint32_t* __restrict__ scan, uint64_t n, uint64_t n_keep, const uint32_t* __restrict__ rec_id,
+                                  const uint32_t* __restrict__ rec_pos, const uint32_t* __restrict__ rec_read, const uint64_t* __restrict__ kept_keys,
+                                  uint32_t* __restrict__ o_id, uint32_t* __restrict__ o_pos, uint32_t* __restrict__ o_read, uint64_t* __restrict__ o_kmer)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	uint32_t s = scan[i];
+	uint32_t nx = (i + 1 < n) ? scan[i + 1] : (uint32_t)n_keep;
+	if (nx == s) return;
+	uint32_t id = rec_id[i];
+	o_id[s] = id; o_pos[s] = rec_pos[i]; o_read[s] = rec_read[i]; o_kmer[s] = kept_keys[id];
+}
+__global__ void k_remap_offsets(const uint64_t* __restrict__ rec_off, const uint32_t* __restrict__ scan, uint32_t n_reads, uint64_t n, uint64_t n_keep,
+                                uint64_t* __restrict__ out_off)
+{
+	uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r > n_reads) return;
+	uint64_t o = rec_off[r];
+	out_off[r] = (o < n) ? scan[o] : n_keep;
+}
+} // namespace
+
+extern "C" cl_status cl_accepted_kmers(cl_ctx* ctx, const cl_kmer_set* S, const cl_reads* R, uint32_t k, uint32_t f, cl_kmer_lists** out)
+{
+	if (!ctx || !S || !R || !out) return cl_fail(ctx, CL_E_INVALID, "cl_accepted_kmers: null argument");
+	if (k != S->k) return cl_fail(ctx, CL_E_INVALID, "cl_accepted_kmers: k differs from the set's k");
+	if (f < 1) return cl_fail(ctx, CL_E_INVALID, "cl_accepted_kmers: f >= 1");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	cl_timing_begin(ctx);
+	cl_kmer_lists* L = new cl_kmer_lists(); L->ctx = ctx; L->n_reads = R->n_reads;
+	std::unique_ptr<cl_kmer_lists> guard(L);
+	const uint32_t nr = R->n_reads;
+	DevBuf<uint32_t> fmask; DEV_ALLOC(ctx, fmask, R->total_words);
+	if (R->total_words)
+	{
+		KernelTimer t(ctx, "accepted_found_mask");
+		hipLaunchKernelGGL(k_found_mask, dim3(grid_for(R->total_words, 256)), dim3(256), 0, ctx->stream, (const uint64_t*)R->packed.p, (const uint32_t*)R->inv.p,
+			R->total_words, k, make_modtest(f), (const void*)S->slots.p, S->bmask, fmask.p);
+	}
+	HIP_TRY(ctx, hipGetLastError());
+	DevBuf<uint32_t> counts; DEV_ALLOC(ctx, counts, nr);
+	if (nr) hipLaunchKernelGGL(k_read_counts, dim3(grid_for(nr, 4)), dim3(256), 0, ctx->stream, (const uint32_t*)fmask.p, (const uint64_t*)R->word_off.p,
+		(const uint32_t*)R->lens.p, (const uint8_t*)R->has_n.p, nr, k, counts.p);
+	HIP_TRY(ctx, hipGetLastError());
+	DevBuf<uint64_t> rec_off; DEV_ALLOC(ctx, rec_off, (uint64_t)nr + 1);
+	uint64_t n_rec = 0;
+	CL_TRY(dev_exclusive_scan_u64(ctx, counts.p, rec_off.p, nr, &n_rec));
+	if (n_rec >= (1ULL << 32)) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_accepted_kmers: more than 2^32 records in one arena; split the batch");
+	DevBuf<uint32_t> rec_id, rec_pos, rec_read;
+	DEV_ALLOC(ctx, rec_id, n_rec); DEV_ALLOC(ctx, rec_pos, n_rec); DEV_ALLOC(ctx, rec_read, n_rec);
+	if (nr && n_rec)
+	{
+		KernelTimer t(ctx, "accepted_emit");
+		hipLaunchKernelGGL(k_emit_records, dim3(grid_for(nr, 4)), dim3(256), 0, ctx->stream, (const uint64_t*)R->packed.p, (const uint32_t*)fmask.p,
+			(const uint64_t*)R->word_off.p, (const uint64_t*)rec_off.p, nr, k, (const void*)S->slots.p, S->bmask, rec_id.p, rec_pos.p, rec_read.p);
+	}
+	HIP_TRY(ctx, hipGetLastError());
+	fmask.release();
+	// per-read dedup (first occurrence wins): stable sort of (id -> record index), flag repeats inside a read
+	uint64_t n_keep = 0;
+	DevBuf<uint32_t> keep; DEV_ALLOC(ctx, keep, n_rec);
+	if (n_rec)
+	{
+		DevBuf<uint32_t> sid, sidx; DEV_ALLOC(ctx, sid, n_rec); DEV_ALLOC(ctx, sidx, n_rec);
+		HIP_TRY(ctx, hipMemcpyAsync(sid.p, rec_id.p, n_rec * 4, hipMemcpyDeviceToDevice, ctx->stream));
+		hipLaunchKernelGGL(k_iota, dim3(grid_for(n_rec, 256)), dim3(256), 0, ctx->stream, sidx.p, n_rec);
+		uint32_t bits = 1; while (bits < 32 && (1ULL << bits) < S->n) ++bits;
+		CL_TRY(dev_sort_keys32_pairs(ctx, sid.p, sidx.p, n_rec, 0, bits));
+		hipLaunchKernelGGL(k_flag_first, dim3(grid_for(n_rec, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)sid.p, (const uint32_t*)sidx.p,
+			(const uint32_t*)rec_read.p, n_rec, keep.p);
+		HIP_TRY(ctx, hipGetLastError());
+		CL_TRY(dev_exclusive_scan_u32(ctx, keep.p, n_rec, &n_keep));
+	}
+	L->total = n_keep;
+	DEV_ALLOC(ctx, L->ids, n_keep); DEV_ALLOC(ctx, L->pos, n_keep); DEV_ALLOC(ctx, L->read, n_keep); DEV_ALLOC(ctx, L->kmers, n_keep);
+	DEV_ALLOC(ctx, L->off, (uint64_t)nr + 1);
+	if (n_rec)
+	{
+		hipLaunchKernelGGL(k_compact_records, dim3(grid_for(n_rec, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)keep.p, n_rec, n_keep,
+			(const uint32_t*)rec_id.p, (const uint32_t*)rec_pos.p, (const uint32_t*)rec_read.p, (const uint64_t*)S->keys.p, L->ids.p, L->pos.p, L->read.p, L->kmers.p);
+		HIP_TRY(ctx, hipGetLastError());
+	}
+	hipLaunchKernelGGL(k_remap_offsets, dim3(grid_for((uint64_t)nr + 1, 256)), dim3(256), 0, ctx->stream, (const uint64_t*)rec_off.p, (const uint32_t*)keep.p,
+		nr, n_rec, n_keep, L->off.p);
+	HIP_TRY(ctx, hipGetLastError());
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	cl_timing_collect(ctx);
+	*out = guard.release();
+	return CL_OK;
+}
+extern "C" void cl_kmer_lists_free(cl_kmer_lists* l) { delete l; }
+extern "C" uint32_t cl_kmer_lists_reads(const cl_kmer_lists* l) { return l->n_reads; }
+extern "C" uint64_t cl_kmer_lists_total(const cl_kmer_lists* l) { return l->total; }
+extern "C" const uint64_t* cl_kmer_lists_offsets(const cl_kmer_lists* l) { return l->off.p; }
+extern "C" const uint64_t* cl_kmer_lists_kmers(const cl_kmer_lists* l) { return l->kmers.p; }
+extern "C" const uint32_t* cl_kmer_lists_ids(const cl_kmer_lists* l) { return l->ids.p; }
+extern "C" const uint32_t* cl_kmer_lists_pos(const cl_kmer_lists* l) { return l->pos.p; }

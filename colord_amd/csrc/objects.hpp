@@ -1,0 +1,45 @@
+// objects.hpp — device-resident objects behind the opaque C-ABI handles.
+#pragma once
+#include "common.hpp"
+#include <memory>
+
+struct cl_reads {
+	cl_ctx* ctx = nullptr;
+	uint32_t n_reads = 0;
+	uint64_t total_bases = 0, total_words = 0;
+	DevBuf<uint64_t> packed;      // total_words + 1 (tail word), 32 bases per word, first base in bits 63..62
+	DevBuf<uint32_t> inv;         // total_words + 1, bit 31-j = base j invalid (N or pad)
+	DevBuf<uint64_t> word_off;    // n_reads + 1
+	DevBuf<uint32_t> lens;        // n_reads
+	DevBuf<uint8_t> has_n;        // n_reads
+};
+
+struct cl_kmer_set {
+	cl_ctx* ctx = nullptr;
+	uint32_t k = 0;
+	uint64_t n = 0;
+	DevBuf<uint64_t> keys;        // ascending
+	DevBuf<uint32_t> counts;      // min(count, cs)
+	DevBuf<uint64_t> slots;       // buckets of 4 x {key, rank}: 8 uint64 per bucket
+	uint64_t bmask = 0;
+};
+
+struct cl_kmer_lists {
+	cl_ctx* ctx = nullptr;
+	uint32_t n_reads = 0;
+	uint64_t total = 0;
+	DevBuf<uint64_t> off;         // n_reads + 1
+	DevBuf<uint64_t> kmers;       // k-mer values
+	DevBuf<uint32_t> ids;         // rank in the set
+	DevBuf<uint32_t> pos;         // start position in the read
+	DevBuf<uint32_t> read;        // owning read of each entry
+};
+
+struct cl_index {
+	cl_ctx* ctx = nullptr;
+	uint32_t n_reads = 0, n_refs = 0, n_pseudo = 0;
+	uint64_t n_keys = 0, n_entries = 0;
+	DevBuf<uint32_t> ref_rank;    // n_reads + 1: number of reference reads before read i
+	DevBuf<uint64_t> off;         // n_keys + 1 (CSR over set ranks)
+	DevBuf<uint32_t> refs;        // reference ids, ascending inside a list
+};

@@ -1,0 +1,133 @@
+// sort.hip — in-tree stable LSD radix sort (8-bit digits) for uint32/uint64 keys with an optional
+// uint32 payload.  Per pass: per-tile digit histogram -> device-wide exclusive scan (digit-major) ->
+// stable scatter.  Ranking inside a wavefront uses 64-lane ballots ("match-any" over the 8 digit bits)
+// so equal digits keep their input order without a second local sort.
+//
+// HBM roofline per pass: 2 key reads + 1 key write (+ payload read/write); n must be < 2^32.
+#include "common.hpp"
+
+namespace {
+constexpr uint32_t ST = 256;            // threads per block
+constexpr uint32_t SI = 16;             // keys per thread
+constexpr uint32_t STILE = ST * SI;     // 4096 keys per tile
+
+template<typename K>
+__global__ __launch_bounds__(ST) void k_sort_hist(const K* __restrict__ keys, uint64_t n, uint32_t shift,
+                                                  uint32_t* __restrict__ hist, uint32_t nb)
+{
+	__shared__ uint32_t h[256];
+	h[threadIdx.x] = 0;
+	__syncthreads();
+	uint64_t base = (uint64_t)blockIdx.x * STILE;
+#pragma unroll
+	for (uint32_t i = 0; i < SI; ++i)
+	{
+		uint64_t idx = base + (uint64_t)i * ST + threadIdx.x;
+		if (idx < n) atomicAdd(&h[(uint32_t)(keys[idx] >> shift) & 255u], 1u);
+	}
+	__syncthreads();
+	hist[(uint64_t)threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
+}
+
+template<typename K, bool HAS_V>
+__global__ __launch_bounds__(ST) void k_sort_scatter(const K* __restrict__ kin, const uint32_t* __restrict__ vin,
+                                                     K* __restrict__ kout, uint32_t* __restrict__ vout,
+                                                     uint64_t n, uint32_t shift, const uint32_t* __restrict__ offs, uint32_t nb)
+{
+	__shared__ uint32_t wh[4][256];
+	const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	for (uint32_t i = threadIdx.x; i < 4 * 256; i += ST) (&wh[0][0])[i] = 0;
+	__syncthreads();
+
+	const uint64_t wbase = (uint64_t)blockIdx.x * STILE + (uint64_t)w * (64 * SI);
+	K key[SI]; uint32_t rank[SI];
+	const uint64_t lt = (1ULL << lane) - 1;
+#pragma unroll
+	for (uint32_t r = 0; r < SI; ++r)
+	{
+		uint64_t idx = wbase + (uint64_t)r * 64 + lane;
+		bool valid = idx < n;
+		key[r] = valid ? kin[idx] : (K)0;
+		uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
+		uint64_t peers = __ballot(valid);
+#pragma unroll
+		for (uint32_t b = 0; b < 8; ++b)
+		{
+			bool bit = (d >> b) & 1u;
+			uint64_t m = __ballot(valid && bit);
+			peers &= bit ? m : ~m;
+		}
+		uint32_t prior = valid ? wh[w][d] : 0u;
+		rank[r] = prior + (uint32_t)__popcll(peers & lt);
+		__builtin_amdgcn_wave_barrier();
+		if (valid && (peers & lt) == 0) wh[w][d] = prior + (uint32_t)__popcll(peers);   // lowest peer lane
+		__builtin_amdgcn_wave_barrier();
+	}
+	__syncthreads();
+	{	// thread d: turn per-wave counts of digit d into global start offsets
+		uint32_t d = threadIdx.x;
+		uint32_t g = offs[(uint64_t)d * nb + blockIdx.x];
+#pragma unroll
+		for (uint32_t i = 0; i < 4; ++i) { uint32_t t = wh[i][d]; wh[i][d] = g; g += t; }
+	}
+	__syncthreads();
+#pragma unroll
+	for (uint32_t r = 0; r < SI; ++r)
+	{
+		uint64_t idx = wbase + (uint64_t)r * 64 + lane;
+		if (idx < n)
+		{
+			uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
+			uint32_t pos = wh[w][d] + rank[r];
+			kout[pos] = key[r];
+			if (HAS_V) vout[pos] = vin[idx];
+		}
+	}
+}
+
+template<typename K>
+cl_status sort_impl(cl_ctx* ctx, K* d_keys, uint32_t* d_vals, uint64_t n, uint32_t begin_bit, uint32_t end_bit)
+{
+	if (n <= 1 || end_bit <= begin_bit) return CL_OK;
+	if (n >= (1ULL << 32)) return cl_fail(ctx, CL_E_UNSUPPORTED, "radix sort: n must be < 2^32 per call");
+	const uint32_t nb = grid_for(n, STILE);
+	DevBuf<K> ktmp; DEV_ALLOC(ctx, ktmp, n);
+	DevBuf<uint32_t> vtmp; if (d_vals) DEV_ALLOC(ctx, vtmp, n);
+	DevBuf<uint32_t> hist; DEV_ALLOC(ctx, hist, (uint64_t)256 * nb);
+	K* kin = d_keys; K* kout = ktmp.p; uint32_t* vin = d_vals; uint32_t* vout = vtmp.p;
+	for (uint32_t shift = begin_bit; shift < end_bit; shift += 8)
+	{
+		{
+			KernelTimer t(ctx, "sort_hist");
+			hipLaunchKernelGGL((k_sort_hist<K>), dim3(nb), dim3(ST), 0, ctx->stream, (const K*)kin, n, shift, hist.p, nb);
+		}
+		HIP_TRY(ctx, hipGetLastError());
+		CL_TRY(dev_exclusive_scan_u32(ctx, hist.p, (uint64_t)256 * nb, nullptr));
+		{
+			KernelTimer t(ctx, "sort_scatter");
+			if (d_vals)
+				hipLaunchKernelGGL((k_sort_scatter<K, true>), dim3(nb), dim3(ST), 0, ctx->stream, (const K*)kin, (const uint32_t*)vin, kout, vout, n, shift, (const uint32_t*)hist.p, nb);
+			else
+				hipLaunchKernelGGL((k_sort_scatter<K, false>), dim3(nb), dim3(ST), 0, ctx->stream, (const K*)kin, (const uint32_t*)nullptr, kout, (uint32_t*)nullptr, n, shift, (const uint32_t*)hist.p, nb);
+		}
+		HIP_TRY(ctx, hipGetLastError());
+		std::swap(kin, kout); std::swap(vin, vout);
+	}
+	if (kin != d_keys)
+	{
+		HIP_TRY(ctx, hipMemcpyAsync(d_keys, kin, n * sizeof(K), hipMemcpyDeviceToDevice, ctx->stream));
+		if (d_vals) HIP_TRY(ctx, hipMemcpyAsync(d_vals, vin, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+	}
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return CL_OK;
+}
+} // namespace
+
+cl_status dev_sort_pairs(cl_ctx* ctx, uint64_t* d_keys, uint32_t* d_vals, uint64_t n, uint32_t begin_bit, uint32_t end_bit)
+{
+	return sort_impl<uint64_t>(ctx, d_keys, d_vals, n, begin_bit, end_bit);
+}
+cl_status dev_sort_keys32_pairs(cl_ctx* ctx, uint32_t* d_keys, uint32_t* d_vals, uint64_t n, uint32_t begin_bit, uint32_t end_bit)
+{
+	return sort_impl<uint32_t>(ctx, d_keys, d_vals, n, begin_bit, end_bit);
+}

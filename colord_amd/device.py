@@ -1,0 +1,219 @@
+"""Thin object layer over the C ABI for tests and bench.py: torch tensors own the caller-side device
+memory; everything computed comes from the HIP library (no CPU fallback anywhere)."""
+from __future__ import annotations
+import ctypes as C
+import numpy as np
+import torch
+from . import _native as N
+
+
+def _check(ctx, st):
+    if st != N.CL_OK:
+        msg = N.load().cl_last_error(ctx.h).decode() if ctx is not None and ctx.h else ""
+        raise N.ColordHipError(st, msg)
+
+
+def _view(ptr, n, dtype, device):
+    """Copy n elements of a library-owned device array into a new torch tensor."""
+    out = torch.empty(int(n), dtype=dtype, device=device)
+    if n:
+        torch.cuda.synchronize(device)
+        rc = _hip().hipMemcpy(C.c_void_p(out.data_ptr()), C.c_void_p(ptr), C.c_size_t(int(n) * out.element_size()), 3)  # D2D
+        if rc != 0:
+            raise N.ColordHipError(N.CL_E_HIP, f"hipMemcpy failed ({rc})")
+    return out
+
+
+_HIP = None
+
+
+def _hip():
+    global _HIP
+    if _HIP is None:
+        _HIP = C.CDLL("libamdhip64.so")
+        _HIP.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        _HIP.hipMemcpy.restype = C.c_int
+    return _HIP
+
+
+class Context:
+    def __init__(self, device: int = 0, timing: bool = False):
+        self.lib = N.load()
+        if not torch.cuda.is_available():
+            raise N.ColordHipError(N.CL_E_HIP, "no GPU visible: the HIP path cannot run (no CPU fallback)")
+        self.h = N._P()
+        st = self.lib.cl_ctx_create(device, C.byref(self.h))
+        if st != N.CL_OK:
+            raise N.ColordHipError(st, "cl_ctx_create failed")
+        self.device = torch.device("cuda", device)
+        if timing:
+            self.lib.cl_ctx_set_timing(self.h, 1)
+
+    def close(self):
+        if self.h:
+            self.lib.cl_ctx_destroy(self.h)
+            self.h = None
+
+    def kernel_ms(self, name: str):
+        ms, n = C.c_double(0), C.c_uint32(0)
+        self.lib.cl_ctx_last_kernel_ms(self.h, name.encode(), C.byref(ms), C.byref(n))
+        return ms.value, n.value
+
+    # ---- arena ----
+    def pack_reads(self, codes: torch.Tensor, offsets: torch.Tensor, ascii: bool = False) -> "Reads":
+        assert codes.dtype == torch.uint8 and offsets.dtype in (torch.int64, torch.uint64)
+        codes = codes.to(self.device).contiguous()
+        offsets = offsets.to(self.device).contiguous()
+        h = N._P()
+        _check(self, self.lib.cl_reads_pack(self.h, codes.data_ptr(), offsets.data_ptr(), offsets.numel() - 1, int(ascii), C.byref(h)))
+        return Reads(self, h)
+
+    def pack_readset(self, rs) -> "Reads":
+        return self.pack_reads(torch.from_numpy(rs.bases), torch.from_numpy(rs.offsets))
+
+    # ---- a1 ----
+    def kmer_scan(self, reads: "Reads", k: int, f: int, cap: int | None = None) -> torch.Tensor:
+        if cap is None:
+            cap = int(reads.total_bases // max(f, 1) * 1.3) + 4096 if f > 1 else int(reads.total_bases) + 64
+        while True:
+            out = torch.empty(cap, dtype=torch.int64, device=self.device)
+            n = C.c_uint64(0)
+            st = self.lib.cl_kmer_scan(self.h, reads.h, k, f, out.data_ptr(), cap, C.byref(n))
+            if st == N.CL_E_CAPACITY:
+                cap = int(n.value)
+                continue
+            _check(self, st)
+            return out[:n.value]
+
+    # ---- a2 + a3 ----
+    def count_filter(self, kmers: torch.Tensor, k: int, ci: int, cs: int):
+        kmers = kmers.contiguous()
+        h = N._P()
+        st = N.KmerStats()
+        _check(self, self.lib.cl_kmer_count_filter(self.h, kmers.data_ptr(), kmers.numel(), k, ci, cs, C.byref(h), C.byref(st)))
+        return KmerSet(self, h), st
+
+    # ---- a4 ----
+    def accepted_kmers(self, kset: "KmerSet", reads: "Reads", k: int, f: int) -> "KmerLists":
+        h = N._P()
+        _check(self, self.lib.cl_accepted_kmers(self.h, kset.h, reads.h, k, f, C.byref(h)))
+        return KmerLists(self, h)
+
+    # ---- a6 ----
+    def ref_accept(self, n_reads: int, n_pseudo: int, rng: int, exponent: float) -> np.ndarray:
+        out = np.zeros(n_reads + n_pseudo, np.uint8)
+        st = self.lib.cl_ref_accept(n_reads, n_pseudo, rng, exponent, out.ctypes.data)
+        _check(self, st)
+        return out
+
+    # ---- a5 ----
+    def index_build(self, kset, lists, accept: torch.Tensor, n_pseudo: int, max_kmer_count: int) -> "Index":
+        accept = accept.to(self.device).contiguous()
+        assert accept.dtype == torch.uint8 and accept.numel() == lists.n_reads
+        h = N._P()
+        _check(self, self.lib.cl_index_build(self.h, kset.h, lists.h, accept.data_ptr(), n_pseudo, max_kmer_count, C.byref(h)))
+        return Index(self, h)
+
+    def candidates(self, index, lists, c: int):
+        n = lists.n_reads
+        refs = torch.empty((n, c), dtype=torch.int32, device=self.device)
+        votes = torch.empty((n, c), dtype=torch.int32, device=self.device)
+        cnt = torch.empty(n, dtype=torch.int32, device=self.device)
+        _check(self, self.lib.cl_candidates(self.h, index.h, lists.h, c, refs.data_ptr(), votes.data_ptr(), cnt.data_ptr()))
+        return refs, votes, cnt
+
+    def candidates_common(self, index, lists, c: int, refs, cnt):
+        n = lists.n_reads
+        off = torch.empty(n * c + 1, dtype=torch.int64, device=self.device)
+        need = C.c_uint64(0)
+        st = self.lib.cl_candidates_common(self.h, index.h, lists.h, c, refs.data_ptr(), cnt.data_ptr(), off.data_ptr(), None, 0, C.byref(need))
+        if st not in (N.CL_OK, N.CL_E_CAPACITY):
+            _check(self, st)
+        common = torch.empty(max(1, need.value), dtype=torch.int64, device=self.device)
+        _check(self, self.lib.cl_candidates_common(self.h, index.h, lists.h, c, refs.data_ptr(), cnt.data_ptr(), off.data_ptr(),
+                                                   common.data_ptr(), need.value, C.byref(need)))
+        return off, common[:need.value]
+
+    def sort_u64(self, keys: torch.Tensor, vals: torch.Tensor | None = None, begin_bit=0, end_bit=64):
+        if vals is None:
+            _check(self, self.lib.cl_sort_u64(self.h, keys.data_ptr(), keys.numel(), begin_bit, end_bit))
+        else:
+            _check(self, self.lib.cl_sort_u64_u32(self.h, keys.data_ptr(), vals.data_ptr(), keys.numel(), begin_bit, end_bit))
+
+
+class _Obj:
+    _free = None
+
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+
+    def free(self):
+        if self.h:
+            getattr(self.ctx.lib, self._free)(self.h)
+            self.h = None
+
+    def _arr(self, getter, n, dtype):
+        ptr = getattr(self.ctx.lib, getter)(self.h)
+        return _view(ptr, n, dtype, self.ctx.device)
+
+
+class Reads(_Obj):
+    _free = "cl_reads_free"
+
+    @property
+    def n_reads(self): return self.ctx.lib.cl_reads_count(self.h)
+    @property
+    def total_bases(self): return self.ctx.lib.cl_reads_total_bases(self.h)
+    @property
+    def total_words(self): return self.ctx.lib.cl_reads_total_words(self.h)
+    def packed(self): return self._arr("cl_reads_packed", self.total_words + 1, torch.int64)
+    def invalid(self): return self._arr("cl_reads_invalid", self.total_words + 1, torch.int32)
+    def word_offsets(self): return self._arr("cl_reads_word_offsets", self.n_reads + 1, torch.int64)
+    def lengths(self): return self._arr("cl_reads_lengths", self.n_reads, torch.int32)
+    def has_n(self): return self._arr("cl_reads_has_n", self.n_reads, torch.uint8)
+
+    def compact(self, i: int) -> bytes:
+        buf = np.zeros(1 << 20, np.uint8)
+        n = C.c_uint64(0)
+        st = self.ctx.lib.cl_reads_compact(self.ctx.h, self.h, i, buf.ctypes.data, buf.size, C.byref(n))
+        if st == N.CL_E_CAPACITY:
+            buf = np.zeros(n.value, np.uint8)
+            st = self.ctx.lib.cl_reads_compact(self.ctx.h, self.h, i, buf.ctypes.data, buf.size, C.byref(n))
+        _check(self.ctx, st)
+        return bytes(buf[:n.value])
+
+
+class KmerSet(_Obj):
+    _free = "cl_kmer_set_free"
+
+    @property
+    def size(self): return self.ctx.lib.cl_kmer_set_size(self.h)
+    def keys(self): return self._arr("cl_kmer_set_keys", self.size, torch.int64)
+    def counts(self): return self._arr("cl_kmer_set_counts", self.size, torch.int32)
+
+    def check(self, kmers: torch.Tensor) -> torch.Tensor:
+        out = torch.empty(kmers.numel(), dtype=torch.uint8, device=self.ctx.device)
+        _check(self.ctx, self.ctx.lib.cl_kmer_set_check(self.ctx.h, self.h, kmers.data_ptr(), kmers.numel(), out.data_ptr()))
+        return out
+
+
+class KmerLists(_Obj):
+    _free = "cl_kmer_lists_free"
+
+    @property
+    def n_reads(self): return self.ctx.lib.cl_kmer_lists_reads(self.h)
+    @property
+    def total(self): return self.ctx.lib.cl_kmer_lists_total(self.h)
+    def offsets(self): return self._arr("cl_kmer_lists_offsets", self.n_reads + 1, torch.int64)
+    def kmers(self): return self._arr("cl_kmer_lists_kmers", self.total, torch.int64)
+    def ids(self): return self._arr("cl_kmer_lists_ids", self.total, torch.int32)
+    def pos(self): return self._arr("cl_kmer_lists_pos", self.total, torch.int32)
+
+
+class Index(_Obj):
+    _free = "cl_index_free"
+
+    @property
+    def n_refs(self): return self.ctx.lib.cl_index_n_refs(self.h)
+    @property
+    def entries(self): return self.ctx.lib.cl_index_entries(self.h)

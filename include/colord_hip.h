@@ -1,0 +1,153 @@
+/* colord_hip.h — C ABI of the MI355X-native CoLoRd hot path (libcolord_hip.so).
+ *
+ * The reference (refresh-bio/colord v1.2.1) has no FFI layer: its seams are the C++ stage objects that
+ * `runCompression` (src/colord/compression.cpp:344-785) wires together.  Every entry point below names
+ * the reference seam it replaces so that a host driver shaped like `runCompression` can call them 1:1.
+ * See INTEGRATION.md for the binding a reference maintainer would add.
+ *
+ * Conventions
+ *  - plain C, no C++/torch types; every function returns cl_status (0 = ok, <0 = error, text via
+ *    cl_last_error); nothing throws, nothing calls exit().
+ *  - pointers named d_* are DEVICE pointers (hipMalloc / torch CUDA tensor data_ptr), h_* are host.
+ *  - one cl_ctx per GPU; calls on different contexts are thread-safe, calls on one context are
+ *    serialised by the caller.  All kernels of a context run on the context's own HIP stream; a call
+ *    returns after its results are complete (it synchronises that stream).
+ *  - objects (cl_reads, cl_kmer_set, ...) are owned by the context and freed by their *_free or by
+ *    cl_ctx_destroy.
+ *  - bases are 2-bit codes A=0 C=1 G=2 T=3 (N=4 in the 1-byte input form), k-mers are uint64 with the
+ *    first base in the most significant used bits (src/colord/in_reads.h:30-74), k <= 28
+ *    (src/colord/arg_parse.cpp:471).
+ */
+#ifndef COLORD_HIP_H
+#define COLORD_HIP_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t cl_status;
+enum {
+	CL_OK = 0,
+	CL_E_INVALID = -1,      /* bad argument */
+	CL_E_HIP = -2,          /* HIP runtime error (text in cl_last_error) */
+	CL_E_CAPACITY = -3,     /* caller buffer too small; the needed element count was returned */
+	CL_E_NOMEM = -4,
+	CL_E_UNSUPPORTED = -5
+};
+
+typedef struct cl_ctx cl_ctx;
+typedef struct cl_reads cl_reads;         /* packed read arena on device */
+typedef struct cl_kmer_set cl_kmer_set;   /* filtered k-mer set (CKmerFilter) */
+typedef struct cl_kmer_lists cl_kmer_lists; /* per-read accepted k-mers (getAcceptedKmers) */
+typedef struct cl_index cl_index;         /* k-mer -> reference reads (CKmersToReads) */
+
+/* ---- context ---------------------------------------------------------------------------------- */
+cl_status cl_ctx_create(int device, cl_ctx** out);
+void cl_ctx_destroy(cl_ctx* ctx);
+const char* cl_last_error(const cl_ctx* ctx);
+/* HIP stream the context launches on (hipStream_t as void*), for callers that time with HIP events. */
+void* cl_ctx_stream(cl_ctx* ctx);
+/* Wall-clock free device timing of the LAST call's dominant kernel, measured with HIP events on the
+ * context stream: *ms = elapsed milliseconds, *launches = number of launches it covers. */
+cl_status cl_ctx_last_kernel_ms(const cl_ctx* ctx, const char* kernel, double* ms, uint32_t* launches);
+/* Enable/disable per-kernel HIP-event timing (off by default; on adds event records around kernels). */
+void cl_ctx_set_timing(cl_ctx* ctx, int on);
+
+/* ---- read arena: replaces read_t / read_pack_t (src/colord/utils.h:366-376, in_reads.cpp:24-42) -- */
+/* d_codes: concatenated bases, 1 byte per base; either codes 0..4 (ascii=0) or ASCII ACGTN/acgtn
+ * (ascii=1).  d_offsets: n_reads+1 base offsets into d_codes.  Builds the 2-bit arena: every read starts
+ * on a 32-base (uint64) word boundary and is followed by at least one pad base; a parallel bit mask
+ * marks N and pad bases invalid. */
+cl_status cl_reads_pack(cl_ctx* ctx, const uint8_t* d_codes, const uint64_t* d_offsets, uint32_t n_reads,
+                        int ascii, cl_reads** out);
+void cl_reads_free(cl_reads* r);
+uint32_t cl_reads_count(const cl_reads* r);
+uint64_t cl_reads_total_bases(const cl_reads* r);
+uint64_t cl_reads_total_words(const cl_reads* r);
+const uint64_t* cl_reads_packed(const cl_reads* r);     /* device: words, base j of a word in bits 63-2j..62-2j */
+const uint32_t* cl_reads_invalid(const cl_reads* r);    /* device: per word, bit 31-j set = base j is N/pad */
+const uint64_t* cl_reads_word_offsets(const cl_reads* r); /* device: n_reads+1 */
+const uint32_t* cl_reads_lengths(const cl_reads* r);    /* device: n_reads */
+const uint8_t* cl_reads_has_n(const cl_reads* r);       /* device: n_reads (1 = read contains N) */
+
+/* ---- a1: CKmerWalker + CHashModuloFilter (in_reads.h:30-74, filtering-KMC/hash_filter.h:8-77) ---- */
+/* Pass-1 scan: every N-free k-window of every read, canonical form, kept iff fmix64(kmer) % f == 0.
+ * Survivors are written unordered to d_out (capacity cap, in k-mers); *n_out = number produced
+ * (CL_E_CAPACITY if > cap; then only the first cap were written). */
+cl_status cl_kmer_scan(cl_ctx* ctx, const cl_reads* reads, uint32_t k, uint32_t f,
+                       uint64_t* d_out, uint64_t cap, uint64_t* n_out);
+
+/* ---- a2 + a3: run_filtering_kmc + CKmerFilter (filtering_kmc.h:5-18, count_kmers.cpp:57-93,
+ *      kmer_filter.h:30-167, filter_kmers.cpp:45-93) --------------------------------------------- */
+typedef struct {
+	uint64_t n_reads;              /* "#Total_reads" (caller-supplied read count is echoed) */
+	uint64_t tot_kmers;            /* "#Total no. of k-mers" */
+	uint64_t n_unique;             /* "#Unique_k-mers" */
+	uint64_t n_unique_counted;     /* "#Unique_counted_k-mers" */
+	uint64_t total_count_filtered; /* CKmerFilter::GetTotalKmers() */
+} cl_kmer_stats;
+/* d_kmers (n survivors of cl_kmer_scan, possibly from several arenas) is sorted in place; distinct
+ * k-mers with multiplicity >= ci are kept with counter min(count, cs).  Builds the membership table. */
+cl_status cl_kmer_count_filter(cl_ctx* ctx, uint64_t* d_kmers, uint64_t n, uint32_t k, uint32_t ci, uint32_t cs,
+                               cl_kmer_set** out, cl_kmer_stats* stats);
+void cl_kmer_set_free(cl_kmer_set* s);
+uint64_t cl_kmer_set_size(const cl_kmer_set* s);
+const uint64_t* cl_kmer_set_keys(const cl_kmer_set* s);   /* device, ascending */
+const uint32_t* cl_kmer_set_counts(const cl_kmer_set* s); /* device, saturated counters */
+/* CKmerFilter::Check for a batch of k-mers: d_found[i] = 1/0 */
+cl_status cl_kmer_set_check(cl_ctx* ctx, const cl_kmer_set* s, const uint64_t* d_kmers, uint64_t n, uint8_t* d_found);
+
+/* ---- a4: CReadsSimilarityGraph::getAcceptedKmers (reads_sim_graph.cpp:128-169, 221-228) ---------- */
+/* Per read without N and with len >= k: the distinct canonical k-mers that pass the modulo test and
+ * are in the set, in first-occurrence order. */
+cl_status cl_accepted_kmers(cl_ctx* ctx, const cl_kmer_set* set, const cl_reads* reads, uint32_t k, uint32_t f,
+                            cl_kmer_lists** out);
+void cl_kmer_lists_free(cl_kmer_lists* l);
+uint32_t cl_kmer_lists_reads(const cl_kmer_lists* l);
+uint64_t cl_kmer_lists_total(const cl_kmer_lists* l);
+const uint64_t* cl_kmer_lists_offsets(const cl_kmer_lists* l); /* device, n_reads+1 */
+const uint64_t* cl_kmer_lists_kmers(const cl_kmer_lists* l);   /* device, k-mer values */
+const uint32_t* cl_kmer_lists_ids(const cl_kmer_lists* l);     /* device, rank of each k-mer in the set */
+const uint32_t* cl_kmer_lists_pos(const cl_kmer_lists* l);     /* device, start position in the read */
+
+/* ---- a6: CRefReadsAccepter (ref_reads_accepter.h:23-58) ------------------------------------------ */
+/* Host function (one sequential mt19937 stream, negligible cost).  h_out[i], i < n_pseudo + n_reads. */
+cl_status cl_ref_accept(uint32_t n_reads, uint32_t n_pseudo, uint32_t range, double exponent, uint8_t* h_out);
+
+/* ---- a5: CKmersToReads + processReadsPack[HiFi] (reads_sim_graph.h:45-119, .cpp:295-528) --------- */
+/* d_accept[i] (n_reads bytes): read i becomes a reference read (acceptor decision AND no N).  The first
+ * n_pseudo reads of `lists` are reference-genome pseudo reads (always accepted, list cap not applied).
+ * Builds, for every k-mer of the set, the list of the first max_kmer_count reference ids containing it. */
+cl_status cl_index_build(cl_ctx* ctx, const cl_kmer_set* set, const cl_kmer_lists* lists, const uint8_t* d_accept,
+                         uint32_t n_pseudo, uint32_t max_kmer_count, cl_index** out);
+void cl_index_free(cl_index* ix);
+uint32_t cl_index_n_refs(const cl_index* ix);
+uint64_t cl_index_entries(const cl_index* ix);
+const uint32_t* cl_index_ref_rank(const cl_index* ix);   /* device, n_reads+1: #references before read i */
+/* For every read i: up to max_candidates earlier reference reads sharing most accepted k-mers, ordered
+ * by (votes desc, ref id asc).  d_refs / d_votes: n_reads * max_candidates (row-major, unused = ~0u / 0),
+ * d_n: n_reads. */
+cl_status cl_candidates(cl_ctx* ctx, const cl_index* ix, const cl_kmer_lists* lists, uint32_t max_candidates,
+                        uint32_t* d_refs, uint32_t* d_votes, uint32_t* d_n);
+/* HiFi variant (processReadsPackHiFi): additionally, per chosen candidate, the shared k-mers in read
+ * order.  d_common_off: n_reads*max_candidates+1 offsets into d_common (capacity cap k-mers);
+ * *n_common = needed size. */
+cl_status cl_candidates_common(cl_ctx* ctx, const cl_index* ix, const cl_kmer_lists* lists, uint32_t max_candidates,
+                               const uint32_t* d_refs, const uint32_t* d_n,
+                               uint64_t* d_common_off, uint64_t* d_common, uint64_t cap, uint64_t* n_common);
+
+/* ---- a7: CReferenceReads (reference_reads.h:27-259) ---------------------------------------------- */
+/* Byte image of one stored reference read (4 bases/byte MSB first + trailing count byte) produced from
+ * the arena; h_out needs (len+3)/4+1 bytes.  Used by the parity tests and by the host archive code. */
+cl_status cl_reads_compact(cl_ctx* ctx, const cl_reads* reads, uint32_t read, uint8_t* h_out, uint64_t cap, uint64_t* n_out);
+
+/* ---- utilities (device primitives exposed for tests/bench) -------------------------------------- */
+cl_status cl_sort_u64(cl_ctx* ctx, uint64_t* d_keys, uint64_t n, uint32_t begin_bit, uint32_t end_bit);
+cl_status cl_sort_u64_u32(cl_ctx* ctx, uint64_t* d_keys, uint32_t* d_vals, uint64_t n, uint32_t begin_bit, uint32_t end_bit);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,20 @@
+import os
+import sys
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    """One HIP context for the whole GPU session; fails loudly when the library or the GPU is missing."""
+    from colord_amd.device import Context
+    c = Context(0)
+    yield c
+    c.close()
