@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the MI355X-native CoLoRd hot path on synthetic ONT reads.
+
+One "step" = one pass of every hot-path stage built so far over one per-GPU shard of synthetic ONT reads
+that is already resident in HBM as a packed read arena (+ raw quality bytes):
+    a1 canonical k-mer scan + murmur-modulo filter  ->  a2 exact count/threshold (radix sort + RLE)
+    -> a3 membership table  ->  a4 accepted k-mers per read  ->  a6 acceptor  ->  a5 index + candidates
+Stages not yet on the GPU (a8-a15: anchors, edit scripts, DNA/quality range coders) are NOT in the timed
+region and the JSON line says so in config.stages; `value` is therefore a hot-path-prefix rate, not yet a
+whole-compressor rate.
+
+Contract: python bench.py --gpus N --steps K --warmup W   (N>1 via torch.distributed.run, one rank/GPU).
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--bases", type=float, default=2.0e9, help="synthetic bases per GPU (weak scaling)")
+    ap.add_argument("--coverage", type=float, default=16.7, help="genome = total bases / coverage (50 Gbases over 3 Gb)")
+    ap.add_argument("--k", type=int, default=25)           # compression.cpp:84-88 for a 50 Gbase input
+    ap.add_argument("--cpu-sample-bases", type=float, default=1.5e8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+# ONT default ("memory") preset: arg_parse.cpp:89-408 / SURVEY App. B
+PRESET = dict(f=12, ci=4, cs=80, c=5, g=1.0, exponent=1.0)
+
+
+class StepTimes:
+    def __init__(self):
+        self.ms = {}
+        self.launches = {}
+
+    def add(self, ctx, names):
+        for n in names:
+            ms, k = ctx.kernel_ms(n)
+            if k:
+                self.ms[n] = self.ms.get(n, 0.0) + ms
+                self.launches[n] = self.launches.get(n, 0) + k
+
+
+def hot_path_step(ctx, reads, k, times: StepTimes | None):
+    """One pass of the stages built so far (single- or multi-GPU).  Returns sizes for reporting."""
+    from colord_amd import parallel as par
+    p = PRESET
+    w, rank = par.world(), par.rank()
+    km = ctx.kmer_scan(reads, k, p["f"])
+    if times is not None:
+        times.add(ctx, ["kmer_scan"])
+    n_surv = km.numel()
+    km = par.exchange_kmers(km)                            # exchange 1a: k-mers to the owner of their key
+    kset, st = ctx.count_filter(km, k, p["ci"], p["cs"])
+    if times is not None:
+        times.add(ctx, ["sort_hist", "sort_scatter", "count_head_flags", "count_scatter_heads", "table_build"])
+    tot_kmers, n_unique, n_reads_total = par.all_reduce_sum_ints(st.tot_kmers, st.n_unique_counted, reads.n_reads)
+    if w > 1:                                              # exchange 1b: replicate the filtered set
+        allk = torch.cat(par.all_gather_v(kset.keys()))
+        allc = torch.cat(par.all_gather_v(kset.counts()))
+        kset.free()
+        kset = ctx.kmer_set_from_keys(allk, allc, k)
+    lists = ctx.accepted_kmers(kset, reads, k, p["f"])
+    if times is not None:
+        times.add(ctx, ["accepted_found_mask", "accepted_emit", "sort_hist", "sort_scatter"])
+    # host scalars exactly as compression.cpp:443,501 derives them
+    mean_read_len = int(float(tot_kmers * p["f"]) / n_reads_total + k - 1)
+    sparse_range = max(1, int((p["g"] * n_unique * p["f"]) / mean_read_len))
+    first_read, _ = par.exclusive_prefix(reads.n_reads, ctx.device)
+    acc_all = ctx.ref_accept(n_reads_total, 0, sparse_range, p["exponent"])    # same stream on every rank
+    acc = acc_all[first_read:first_read + reads.n_reads]
+    accept = torch.from_numpy(acc.copy()).to(ctx.device) & (reads.has_n() == 0).to(torch.uint8)
+    ref_base, n_refs_total = par.exclusive_prefix(int(accept.sum().item()), ctx.device)
+    ids, refs, bounds, _ = ctx.index_entries(lists, accept, ref_base)
+    if w > 1:                                              # exchange 2: replicate the k-mer -> reference reads index
+        ids = torch.cat(par.all_gather_v(ids))
+        refs = torch.cat(par.all_gather_v(refs))
+    index = ctx.index_build_pairs(kset, ids, refs, bounds, n_refs_total, 0, p["cs"])
+    crefs, votes, cnt = ctx.candidates(index, lists, p["c"])
+    if times is not None:
+        times.add(ctx, ["cand_pair_counts", "cand_pair_fill", "cand_top", "sort_hist", "sort_scatter"])
+    out = dict(survivors=n_surv, tot_kmers=tot_kmers, kept=kset.size, accepted=lists.total, refs=n_refs_total,
+               index_entries=index.entries, with_candidates=int((cnt > 0).sum().item()))
+    index.free(); lists.free(); kset.free()
+    return out
+
+
+def cpu_baseline(sample_bases: float, k_hint: int):
+    """The UNMODIFIED reference binary (oracle/_ref/colord, built by oracle/Makefile.ref) timed on this
+    host's cores on a bounded sample of the same synthetic recipe.  It runs the WHOLE compressor."""
+    from colord_amd.synth import make_reads
+    from colord_amd.fastq import write_fastq
+    ref = os.path.join(ROOT, "oracle", "_ref", "colord")
+    if not os.path.exists(ref):
+        return None
+    cores = os.cpu_count() or 1
+    rs = make_reads(seed=101, genome_len=int(sample_bases / 16.7), target_bases=int(sample_bases))
+    with tempfile.TemporaryDirectory() as tmp:
+        fq = os.path.join(tmp, "sample.fastq")
+        write_fastq(fq, rs)
+        t0 = time.time()
+        subprocess.check_call([ref, "compress-ont", "-t", str(cores), fq, os.path.join(tmp, "o.colord")],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        dt = time.time() - t0
+        size = os.path.getsize(os.path.join(tmp, "o.colord"))
+    return {"value": len(rs.bases) / dt / 1e9, "unit": "Gbases/s", "cores": cores, "kind": "reference",
+            "sample": f"oracle/_ref/colord compress-ont -t {cores} on {len(rs.bases)} synthetic ONT bases ({rs.n_reads} reads), "
+                      f"whole compressor incl. stages not yet on the GPU; {dt:.2f} s wall, archive {size} B"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print("bench.py: launch with torch.distributed.run for --gpus > 1", file=sys.stderr)
+            sys.exit(2)
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from colord_amd.device import Context
+    from colord_amd.synth_device import make_reads_device
+
+    ctx = Context(local, timing=True)
+    bases = int(args.bases)
+    genome_len = max(1_000_000, int(bases * world / args.coverage))
+    # same genome on every rank (seed), different reads per rank
+    codes, offsets, quals = make_reads_device(ctx.device, seed=1234, genome_len=genome_len, target_bases=bases,
+                                              with_quals=True, read_seed=1000 + rank)
+    n_reads_local = offsets.numel() - 1
+    reads = ctx.pack_reads(codes, offsets)
+    local_bases = reads.total_bases
+    del codes
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        hot_path_step(ctx, reads, args.k, None)
+    times = StepTimes()
+    sync()
+    t0 = time.perf_counter()
+    info = None
+    for _ in range(args.steps):
+        info = hot_path_step(ctx, reads, args.k, times)
+    sync()
+    dt = time.perf_counter() - t0
+    tdev = torch.tensor([dt], dtype=torch.float64, device=ctx.device)
+    tb = torch.tensor([local_bases], dtype=torch.int64, device=ctx.device)
+    if world > 1:
+        dist.all_reduce(tdev, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tb)
+    dt = float(tdev.item())
+    total_bases = int(tb.item())
+
+    if rank == 0:
+        # dominant kernel (by measured HIP-event time on the context stream) and its algorithmic bytes
+        dom = max(times.ms, key=times.ms.get)
+        K = info["survivors"]
+        alg_bytes_per_launch = {
+            # k-mer scan reads N/4 packed bases and writes 8 B per surviving k-mer
+            "kmer_scan": local_bases / 4 + 8 * K,
+            "accepted_found_mask": local_bases / 4 + 4 * K + 4 * (local_bases / 32),
+        }
+        launches = times.launches[dom]
+        avg_ms = times.ms[dom] / launches
+        if dom in alg_bytes_per_launch:
+            per_launch = alg_bytes_per_launch[dom]
+        elif dom in ("sort_scatter", "sort_hist"):
+            per_launch = None                              # depends on the array being sorted; see DESIGN.md
+        else:
+            per_launch = None
+        roof = {"bound": "hbm", "kernel": dom, "avg_ms": avg_ms, "launches_per_step": launches / args.steps,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
+        if per_launch is not None:
+            ach = per_launch / (avg_ms * 1e-3) / 1e9
+            roof.update({"achieved": ach, "frac": ach / HBM_PEAK_GBS, "alg_bytes_per_launch": per_launch})
+        else:
+            roof.update({"achieved": None, "frac": None})
+        roof["kernel_ms_per_step"] = {n: times.ms[n] / args.steps for n in sorted(times.ms, key=times.ms.get, reverse=True)}
+        cb = None if args.no_cpu_baseline else cpu_baseline(args.cpu_sample_bases, args.k)
+        line = {
+            "metric": "input Gbases/s, synthetic ONT (hot-path stages built so far)", "value": total_bases * args.steps / dt / 1e9,
+            "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"synthetic ONT, {local_bases} bases/GPU ({n_reads_local} reads, N50~20kb), genome {genome_len} bp, "
+                                   f"k={args.k} f={PRESET['f']} ci={PRESET['ci']} cs={PRESET['cs']} c={PRESET['c']} (ONT default preset)",
+                       "stages": "a1 k-mer scan, a2 count/filter, a3 set build, a4 accepted k-mers, a6 acceptor, a5 index+candidates; "
+                                 "a8-a15 (anchors, edit scripts, DNA/quality coders) not yet on GPU, not timed",
+                       "parallelism": f"reads sharded x{world}, k-mer set replicated" if world > 1 else "single GPU",
+                       "sizes": info},
+            "roofline": roof, "cpu_baseline": cb,
+        }
+        print(json.dumps(line))
+    reads.free()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

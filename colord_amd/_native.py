@@ -45,6 +45,7 @@ _SIG = {
     "cl_reads_compact": (C.c_int32, [_P, _P, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "cl_kmer_scan": (C.c_int32, [_P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "cl_kmer_count_filter": (C.c_int32, [_P, _P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_P), C.POINTER(KmerStats)]),
+    "cl_kmer_set_create": (C.c_int32, [_P, _P, _P, C.c_uint64, C.c_uint32, C.POINTER(_P)]),
     "cl_kmer_set_free": (None, [_P]),
     "cl_kmer_set_size": (C.c_uint64, [_P]),
     "cl_kmer_set_keys": (_P, [_P]),
@@ -60,6 +61,8 @@ _SIG = {
     "cl_kmer_lists_pos": (_P, [_P]),
     "cl_ref_accept": (C.c_int32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, _P]),
     "cl_index_build": (C.c_int32, [_P, _P, _P, _P, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
+    "cl_index_entries_of": (C.c_int32, [_P, _P, _P, C.c_uint32, _P, _P, C.c_uint64, C.POINTER(C.c_uint64), _P, C.POINTER(C.c_uint32)]),
+    "cl_index_build_pairs": (C.c_int32, [_P, _P, _P, _P, C.c_uint64, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
     "cl_index_free": (None, [_P]),
     "cl_index_n_refs": (C.c_uint32, [_P]),
     "cl_index_entries": (C.c_uint64, [_P]),

@@ -30,6 +30,7 @@ __global__ void k_gather_ref_entries(const uint32_t* __restrict__ scan, uint64_t
 	if (nx == s) return;
 	o_id[s] = ids[e]; o_ref[s] = ref_rank[entry_read[e]];
 }
+__global__ void k_add_const(uint32_t* v, uint64_t n, uint32_t c) { uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) v[i] += c; }
 __global__ void k_head_flags32(const uint32_t* __restrict__ keys, uint64_t n, uint32_t* __restrict__ flags)
 {
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -157,58 +158,77 @@ __global__ __launch_bounds__(256) void k_top_candidates(const uint64_t* __restri
 }
 } // namespace
 
-extern "C" cl_status cl_index_build(cl_ctx* ctx, const cl_kmer_set* S, const cl_kmer_lists* L, const uint8_t* d_accept,
-                                    uint32_t n_pseudo, uint32_t max_kmer_count, cl_index** out)
+// (id, ref) pairs of the accepted reads of `lists`, in read order; ref = ref_base + rank among accepted
+extern "C" cl_status cl_index_entries_of(cl_ctx* ctx, const cl_kmer_lists* L, const uint8_t* d_accept, uint32_t ref_base,
+                                         uint32_t* d_ids, uint32_t* d_refs, uint64_t cap, uint64_t* n_out,
+                                         uint32_t* d_bounds, uint32_t* n_accepted)
 {
-	if (!ctx || !S || !L || !d_accept || !out) return cl_fail(ctx, CL_E_INVALID, "cl_index_build: null argument");
+	if (!ctx || !L || !d_accept || !n_out) return cl_fail(ctx, CL_E_INVALID, "cl_index_entries_of: null argument");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
-	cl_timing_begin(ctx);
-	cl_index* X = new cl_index(); X->ctx = ctx; X->n_reads = L->n_reads; X->n_pseudo = n_pseudo; X->n_keys = S->n;
-	std::unique_ptr<cl_index> guard(X);
 	const uint32_t nr = L->n_reads; const uint64_t ne = L->total;
-	// reference rank of every read
-	DEV_ALLOC(ctx, X->ref_rank, (uint64_t)nr + 1);
+	DevBuf<uint32_t> rank; DEV_ALLOC(ctx, rank, (uint64_t)nr + 1);
 	uint64_t n_refs = 0;
-	if (nr) hipLaunchKernelGGL(k_flags_from_bytes, dim3(grid_for(nr, 256)), dim3(256), 0, ctx->stream, d_accept, nr, X->ref_rank.p);
+	if (nr) hipLaunchKernelGGL(k_flags_from_bytes, dim3(grid_for(nr, 256)), dim3(256), 0, ctx->stream, d_accept, nr, rank.p);
 	HIP_TRY(ctx, hipGetLastError());
-	CL_TRY(dev_exclusive_scan_u32(ctx, X->ref_rank.p, nr, &n_refs));
-	{ uint32_t t = (uint32_t)n_refs; HIP_TRY(ctx, hipMemcpyAsync(X->ref_rank.p + nr, &t, 4, hipMemcpyHostToDevice, ctx->stream)); HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); }
-	X->n_refs = (uint32_t)n_refs;
-	// entries of accepted reads -> (id, ref) pairs in read order
-	uint64_t n_sel = 0, n_keep = 0;
-	DevBuf<uint32_t> sid, sref;
+	CL_TRY(dev_exclusive_scan_u32(ctx, rank.p, nr, &n_refs));
+	{ uint32_t t = (uint32_t)n_refs; HIP_TRY(ctx, hipMemcpyAsync(rank.p + nr, &t, 4, hipMemcpyHostToDevice, ctx->stream)); }
+	if (ref_base) hipLaunchKernelGGL(k_add_const, dim3(grid_for((uint64_t)nr + 1, 256)), dim3(256), 0, ctx->stream, rank.p, (uint64_t)nr + 1, ref_base);
+	HIP_TRY(ctx, hipGetLastError());
+	if (n_accepted) *n_accepted = (uint32_t)n_refs;
+	if (d_bounds) HIP_TRY(ctx, hipMemcpyAsync(d_bounds, rank.p, ((uint64_t)nr + 1) * 4, hipMemcpyDeviceToDevice, ctx->stream));
+	uint64_t n_sel = 0;
 	if (ne)
 	{
 		DevBuf<uint32_t> ef; DEV_ALLOC(ctx, ef, ne);
 		hipLaunchKernelGGL(k_entry_flags, dim3(grid_for(ne, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)L->read.p, d_accept, ne, ef.p);
 		HIP_TRY(ctx, hipGetLastError());
 		CL_TRY(dev_exclusive_scan_u32(ctx, ef.p, ne, &n_sel));
-		DEV_ALLOC(ctx, sid, n_sel); DEV_ALLOC(ctx, sref, n_sel);
+		*n_out = n_sel;
+		if (n_sel > cap || (n_sel && (!d_ids || !d_refs))) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); return cl_fail(ctx, CL_E_CAPACITY, "cl_index_entries_of: need " + std::to_string(n_sel) + " entries"); }
 		hipLaunchKernelGGL(k_gather_ref_entries, dim3(grid_for(ne, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)ef.p, ne, n_sel,
-			(const uint32_t*)L->ids.p, (const uint32_t*)L->read.p, (const uint32_t*)X->ref_rank.p, sid.p, sref.p);
+			(const uint32_t*)L->ids.p, (const uint32_t*)L->read.p, (const uint32_t*)rank.p, d_ids, d_refs);
 		HIP_TRY(ctx, hipGetLastError());
-		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	}
+	*n_out = n_sel;
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return CL_OK;
+}
+
+// Index from explicit (id, ref) pairs listed in ascending ref order (e.g. the all-gathered entries of every
+// rank).  d_bounds[i] (n_reads+1) = number of reference reads that precede local read i in the global order.
+// d_ids / d_refs are sorted in place.
+extern "C" cl_status cl_index_build_pairs(cl_ctx* ctx, const cl_kmer_set* S, uint32_t* d_ids, uint32_t* d_refs, uint64_t n_sel,
+                                          const uint32_t* d_bounds, uint32_t n_reads, uint32_t n_refs_total,
+                                          uint32_t n_pseudo, uint32_t max_kmer_count, cl_index** out)
+{
+	if (!ctx || !S || !d_bounds || !out) return cl_fail(ctx, CL_E_INVALID, "cl_index_build_pairs: null argument");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	cl_timing_begin(ctx);
+	cl_index* X = new cl_index(); X->ctx = ctx; X->n_reads = n_reads; X->n_pseudo = n_pseudo; X->n_keys = S->n; X->n_refs = n_refs_total;
+	std::unique_ptr<cl_index> guard(X);
+	DEV_ALLOC(ctx, X->ref_rank, (uint64_t)n_reads + 1);
+	HIP_TRY(ctx, hipMemcpyAsync(X->ref_rank.p, d_bounds, ((uint64_t)n_reads + 1) * 4, hipMemcpyDeviceToDevice, ctx->stream));
+	uint64_t n_keep = 0;
 	DevBuf<uint32_t> id_counts; DEV_ALLOC(ctx, id_counts, S->n + 1);
 	HIP_TRY(ctx, hipMemsetAsync(id_counts.p, 0, (S->n + 1) * 4, ctx->stream));
 	if (n_sel)
 	{
 		uint32_t bits = 1; while (bits < 32 && (1ULL << bits) < S->n) ++bits;
-		CL_TRY(dev_sort_keys32_pairs(ctx, sid.p, sref.p, n_sel, 0, bits));      // stable: refs stay ascending inside a k-mer
+		CL_TRY(dev_sort_keys32_pairs(ctx, d_ids, d_refs, n_sel, 0, bits));      // stable: refs stay ascending inside a k-mer
 		DevBuf<uint32_t> hf; DEV_ALLOC(ctx, hf, n_sel);
-		hipLaunchKernelGGL(k_head_flags32, dim3(grid_for(n_sel, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)sid.p, n_sel, hf.p);
+		hipLaunchKernelGGL(k_head_flags32, dim3(grid_for(n_sel, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_ids, n_sel, hf.p);
 		uint64_t n_heads = 0;
 		CL_TRY(dev_exclusive_scan_u32(ctx, hf.p, n_sel, &n_heads));
 		DevBuf<uint32_t> head_pos; DEV_ALLOC(ctx, head_pos, n_heads);
 		hipLaunchKernelGGL(k_scatter_head_pos, dim3(grid_for(n_sel, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)hf.p, n_sel, n_heads, head_pos.p);
 		DevBuf<uint32_t> keep; DEV_ALLOC(ctx, keep, n_sel);
-		hipLaunchKernelGGL(k_cap_flags, dim3(grid_for(n_sel, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)sid.p, (const uint32_t*)sref.p, (const uint32_t*)hf.p,
+		hipLaunchKernelGGL(k_cap_flags, dim3(grid_for(n_sel, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_ids, (const uint32_t*)d_refs, (const uint32_t*)hf.p,
 			(const uint32_t*)head_pos.p, n_sel, n_heads, n_pseudo, max_kmer_count, keep.p);
 		HIP_TRY(ctx, hipGetLastError());
 		CL_TRY(dev_exclusive_scan_u32(ctx, keep.p, n_sel, &n_keep));
 		DEV_ALLOC(ctx, X->refs, n_keep);
 		hipLaunchKernelGGL(k_compact_index, dim3(grid_for(n_sel, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)keep.p, n_sel, n_keep,
-			(const uint32_t*)sid.p, (const uint32_t*)sref.p, X->refs.p, id_counts.p);
+			(const uint32_t*)d_ids, (const uint32_t*)d_refs, X->refs.p, id_counts.p);
 		HIP_TRY(ctx, hipGetLastError());
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	}
@@ -219,6 +239,20 @@ extern "C" cl_status cl_index_build(cl_ctx* ctx, const cl_kmer_set* S, const cl_
 	cl_timing_collect(ctx);
 	*out = guard.release();
 	return CL_OK;
+}
+
+extern "C" cl_status cl_index_build(cl_ctx* ctx, const cl_kmer_set* S, const cl_kmer_lists* L, const uint8_t* d_accept,
+                                    uint32_t n_pseudo, uint32_t max_kmer_count, cl_index** out)
+{
+	if (!ctx || !S || !L || !d_accept || !out) return cl_fail(ctx, CL_E_INVALID, "cl_index_build: null argument");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	uint64_t n_sel = 0; uint32_t n_refs = 0;
+	DevBuf<uint32_t> bounds; DEV_ALLOC(ctx, bounds, (uint64_t)L->n_reads + 1);
+	cl_status st = cl_index_entries_of(ctx, L, d_accept, 0, nullptr, nullptr, 0, &n_sel, bounds.p, &n_refs);
+	if (st != CL_OK && st != CL_E_CAPACITY) return st;
+	DevBuf<uint32_t> sid, sref; DEV_ALLOC(ctx, sid, n_sel); DEV_ALLOC(ctx, sref, n_sel);
+	if (n_sel) CL_TRY(cl_index_entries_of(ctx, L, d_accept, 0, sid.p, sref.p, n_sel, &n_sel, nullptr, nullptr));
+	return cl_index_build_pairs(ctx, S, sid.p, sref.p, n_sel, bounds.p, L->n_reads, n_refs, n_pseudo, max_kmer_count, out);
 }
 extern "C" void cl_index_free(cl_index* ix) { delete ix; }
 extern "C" uint32_t cl_index_n_refs(const cl_index* ix) { return ix->n_refs; }

@@ -346,6 +346,8 @@ __global__ void k_table_check(const void* slots, uint64_t bmask, const uint64_t*
 }
 } // namespace
 
+static cl_status build_table(cl_ctx* ctx, cl_kmer_set* S);
+
 extern "C" cl_status cl_kmer_count_filter(cl_ctx* ctx, uint64_t* d_kmers, uint64_t n, uint32_t k, uint32_t ci, uint32_t cs,
                                           cl_kmer_set** out, cl_kmer_stats* stats)
 {
@@ -384,20 +386,45 @@ extern "C" cl_status cl_kmer_count_filter(cl_ctx* ctx, uint64_t* d_kmers, uint64
 	}
 	else { DEV_ALLOC(ctx, S->keys, 0); DEV_ALLOC(ctx, S->counts, 0); }
 	S->n = n_kept;
-	// a3: table with >= 2 slots per key
-	uint64_t nbuckets = 16; while (nbuckets * 4 < 2 * n_kept) nbuckets <<= 1;
+	CL_TRY(build_table(ctx, S));          // a3: table with >= 2 slots per key
+	cl_timing_collect(ctx);
+	if (stats) { stats->tot_kmers = n; stats->n_unique = n_heads; stats->n_unique_counted = n_kept; stats->total_count_filtered = filt; }
+	*out = guard.release();
+	return CL_OK;
+}
+// Builds a set object from already counted keys (ascending, distinct) — used to replicate the filtered set
+// on every GPU after the all-gather of the per-rank partitions.
+static cl_status build_table(cl_ctx* ctx, cl_kmer_set* S)
+{
+	uint64_t nbuckets = 16; while (nbuckets * 4 < 2 * S->n) nbuckets <<= 1;
 	S->bmask = nbuckets - 1;
-	DEV_ALLOC(ctx, S->slots, nbuckets * 4 * 2);     // as uint64 pairs
+	DEV_ALLOC(ctx, S->slots, nbuckets * 4 * 2);
 	HIP_TRY(ctx, hipMemsetAsync(S->slots.p, 0xff, nbuckets * 64, ctx->stream));
-	if (n_kept)
+	if (S->n)
 	{
 		KernelTimer t(ctx, "table_build");
-		hipLaunchKernelGGL(k_table_build, dim3(grid_for(n_kept, 256)), dim3(256), 0, ctx->stream, (const uint64_t*)S->keys.p, n_kept, (Slot*)S->slots.p, S->bmask);
+		hipLaunchKernelGGL(k_table_build, dim3(grid_for(S->n, 256)), dim3(256), 0, ctx->stream, (const uint64_t*)S->keys.p, S->n, (Slot*)S->slots.p, S->bmask);
 	}
 	HIP_TRY(ctx, hipGetLastError());
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return CL_OK;
+}
+extern "C" cl_status cl_kmer_set_create(cl_ctx* ctx, const uint64_t* d_keys, const uint32_t* d_counts, uint64_t n, uint32_t k, cl_kmer_set** out)
+{
+	if (!ctx || !out || (n && (!d_keys || !d_counts))) return cl_fail(ctx, CL_E_INVALID, "cl_kmer_set_create: null argument");
+	if (k < 1 || k > 28 || n >= (1ULL << 32)) return cl_fail(ctx, CL_E_INVALID, "cl_kmer_set_create: need 1 <= k <= 28, n < 2^32");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	cl_timing_begin(ctx);
+	cl_kmer_set* S = new cl_kmer_set(); S->ctx = ctx; S->k = k; S->n = n;
+	std::unique_ptr<cl_kmer_set> guard(S);
+	DEV_ALLOC(ctx, S->keys, n); DEV_ALLOC(ctx, S->counts, n);
+	if (n)
+	{
+		HIP_TRY(ctx, hipMemcpyAsync(S->keys.p, d_keys, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+		HIP_TRY(ctx, hipMemcpyAsync(S->counts.p, d_counts, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+	}
+	CL_TRY(build_table(ctx, S));
 	cl_timing_collect(ctx);
-	if (stats) { stats->tot_kmers = n; stats->n_unique = n_heads; stats->n_unique_counted = n_kept; stats->total_count_filtered = filt; }
 	*out = guard.release();
 	return CL_OK;
 }

@@ -93,6 +93,16 @@ class Context:
         _check(self, self.lib.cl_kmer_count_filter(self.h, kmers.data_ptr(), kmers.numel(), k, ci, cs, C.byref(h), C.byref(st)))
         return KmerSet(self, h), st
 
+    def kmer_set_from_keys(self, keys: torch.Tensor, counts: torch.Tensor, k: int) -> "KmerSet":
+        """Replicated set from gathered per-rank partitions: sort by key on device, then build the table."""
+        keys = keys.contiguous().clone()
+        idx = torch.arange(keys.numel(), dtype=torch.int32, device=self.device)
+        self.sort_u64(keys, idx, 0, 2 * k)
+        counts = counts.contiguous()[idx.long()].contiguous()
+        h = N._P()
+        _check(self, self.lib.cl_kmer_set_create(self.h, keys.data_ptr(), counts.data_ptr(), keys.numel(), k, C.byref(h)))
+        return KmerSet(self, h)
+
     # ---- a4 ----
     def accepted_kmers(self, kset: "KmerSet", reads: "Reads", k: int, f: int) -> "KmerLists":
         h = N._P()
@@ -112,6 +122,26 @@ class Context:
         assert accept.dtype == torch.uint8 and accept.numel() == lists.n_reads
         h = N._P()
         _check(self, self.lib.cl_index_build(self.h, kset.h, lists.h, accept.data_ptr(), n_pseudo, max_kmer_count, C.byref(h)))
+        return Index(self, h)
+
+    def index_entries(self, lists, accept: torch.Tensor, ref_base: int):
+        accept = accept.to(self.device).contiguous()
+        bounds = torch.empty(lists.n_reads + 1, dtype=torch.int32, device=self.device)
+        n, nacc = C.c_uint64(0), C.c_uint32(0)
+        st = self.lib.cl_index_entries_of(self.h, lists.h, accept.data_ptr(), ref_base, None, None, 0, C.byref(n), bounds.data_ptr(), C.byref(nacc))
+        if st not in (N.CL_OK, N.CL_E_CAPACITY):
+            _check(self, st)
+        ids = torch.empty(max(1, n.value), dtype=torch.int32, device=self.device)
+        refs = torch.empty(max(1, n.value), dtype=torch.int32, device=self.device)
+        if n.value:
+            _check(self, self.lib.cl_index_entries_of(self.h, lists.h, accept.data_ptr(), ref_base, ids.data_ptr(), refs.data_ptr(), n.value, C.byref(n), None, None))
+        return ids[:n.value], refs[:n.value], bounds, nacc.value
+
+    def index_build_pairs(self, kset, ids, refs, bounds, n_refs_total: int, n_pseudo: int, max_kmer_count: int) -> "Index":
+        ids, refs = ids.contiguous().clone(), refs.contiguous().clone()
+        h = N._P()
+        _check(self, self.lib.cl_index_build_pairs(self.h, kset.h, ids.data_ptr(), refs.data_ptr(), ids.numel(), bounds.data_ptr(),
+                                                   bounds.numel() - 1, n_refs_total, n_pseudo, max_kmer_count, C.byref(h)))
         return Index(self, h)
 
     def candidates(self, index, lists, c: int):

@@ -11,9 +11,11 @@ import torch
 
 
 def make_reads_device(device, seed: int, genome_len: int, target_bases: int, mean_scale: float = 20000.0,
-                      sigma: float = 0.7, chunk_bases: int = 64_000_000, with_quals: bool = False):
+                      sigma: float = 0.7, chunk_bases: int = 64_000_000, with_quals: bool = False, read_seed: int | None = None):
     g = torch.Generator(device=device).manual_seed(seed)
     genome = torch.randint(0, 4, (genome_len,), generator=g, device=device, dtype=torch.uint8)
+    if read_seed is not None:                  # same genome on every rank, different reads
+        g = torch.Generator(device=device).manual_seed(read_seed)
     mu = math.log(mean_scale) - sigma * sigma
     mean_len = math.exp(mu + sigma * sigma / 2)
     out_codes, out_lens, out_quals = [], [], []

@@ -92,6 +92,9 @@ typedef struct {
  * k-mers with multiplicity >= ci are kept with counter min(count, cs).  Builds the membership table. */
 cl_status cl_kmer_count_filter(cl_ctx* ctx, uint64_t* d_kmers, uint64_t n, uint32_t k, uint32_t ci, uint32_t cs,
                                cl_kmer_set** out, cl_kmer_stats* stats);
+/* Set object from keys that are already counted/filtered (ascending, distinct) — used to replicate the
+ * set on every GPU after the all-gather of the per-rank key partitions (SURVEY §8e exchange 1). */
+cl_status cl_kmer_set_create(cl_ctx* ctx, const uint64_t* d_keys, const uint32_t* d_counts, uint64_t n, uint32_t k, cl_kmer_set** out);
 void cl_kmer_set_free(cl_kmer_set* s);
 uint64_t cl_kmer_set_size(const cl_kmer_set* s);
 const uint64_t* cl_kmer_set_keys(const cl_kmer_set* s);   /* device, ascending */
@@ -122,6 +125,17 @@ cl_status cl_ref_accept(uint32_t n_reads, uint32_t n_pseudo, uint32_t range, dou
  * Builds, for every k-mer of the set, the list of the first max_kmer_count reference ids containing it. */
 cl_status cl_index_build(cl_ctx* ctx, const cl_kmer_set* set, const cl_kmer_lists* lists, const uint8_t* d_accept,
                          uint32_t n_pseudo, uint32_t max_kmer_count, cl_index** out);
+/* Multi-GPU form of the same build (SURVEY §8e exchange 2).  cl_index_entries_of lists the (k-mer id,
+ * reference id) pairs of this rank's accepted reads in read order, reference ids starting at ref_base;
+ * d_bounds (n_reads+1, optional) receives ref_base + number of accepted reads before each local read.
+ * After an all-gather in rank order the concatenated pairs (ascending reference id) go to
+ * cl_index_build_pairs, which sorts d_ids/d_refs in place. */
+cl_status cl_index_entries_of(cl_ctx* ctx, const cl_kmer_lists* lists, const uint8_t* d_accept, uint32_t ref_base,
+                              uint32_t* d_ids, uint32_t* d_refs, uint64_t cap, uint64_t* n_out,
+                              uint32_t* d_bounds, uint32_t* n_accepted);
+cl_status cl_index_build_pairs(cl_ctx* ctx, const cl_kmer_set* set, uint32_t* d_ids, uint32_t* d_refs, uint64_t n,
+                               const uint32_t* d_bounds, uint32_t n_reads, uint32_t n_refs_total,
+                               uint32_t n_pseudo, uint32_t max_kmer_count, cl_index** out);
 void cl_index_free(cl_index* ix);
 uint32_t cl_index_n_refs(const cl_index* ix);
 uint64_t cl_index_entries(const cl_index* ix);
