@@ -50,31 +50,21 @@ PRESET = dict(f=12, ci=4, cs=80, c=5, g=1.0, exponent=1.0)
 
 
 class StepTimes:
-    def __init__(self):
-        self.ms = {}
-        self.launches = {}
-
-    def add(self, ctx, names):
-        for n in names:
-            ms, k = ctx.kernel_ms(n)
-            if k:
-                self.ms[n] = self.ms.get(n, 0.0) + ms
-                self.launches[n] = self.launches.get(n, 0) + k
+    """Per-kernel HIP-event times (context stream) accumulated by colord_amd.device.Context."""
+    def __init__(self, ctx):
+        self.ms = {n: v[0] for n, v in ctx.acc.items()}
+        self.launches = {n: v[1] for n, v in ctx.acc.items()}
 
 
-def hot_path_step(ctx, reads, k, times: StepTimes | None):
+def hot_path_step(ctx, reads, k):
     """One pass of the stages built so far (single- or multi-GPU).  Returns sizes for reporting."""
     from colord_amd import parallel as par
     p = PRESET
     w, rank = par.world(), par.rank()
     km = ctx.kmer_scan(reads, k, p["f"])
-    if times is not None:
-        times.add(ctx, ["kmer_scan"])
     n_surv = km.numel()
     km = par.exchange_kmers(km)                            # exchange 1a: k-mers to the owner of their key
     kset, st = ctx.count_filter(km, k, p["ci"], p["cs"])
-    if times is not None:
-        times.add(ctx, ["sort_hist", "sort_scatter", "count_head_flags", "count_scatter_heads", "table_build"])
     tot_kmers, n_unique, n_reads_total = par.all_reduce_sum_ints(st.tot_kmers, st.n_unique_counted, reads.n_reads)
     if w > 1:                                              # exchange 1b: replicate the filtered set
         allk = torch.cat(par.all_gather_v(kset.keys()))
@@ -82,8 +72,6 @@ def hot_path_step(ctx, reads, k, times: StepTimes | None):
         kset.free()
         kset = ctx.kmer_set_from_keys(allk, allc, k)
     lists = ctx.accepted_kmers(kset, reads, k, p["f"])
-    if times is not None:
-        times.add(ctx, ["accepted_found_mask", "accepted_emit", "sort_hist", "sort_scatter"])
     # host scalars exactly as compression.cpp:443,501 derives them
     mean_read_len = int(float(tot_kmers * p["f"]) / n_reads_total + k - 1)
     sparse_range = max(1, int((p["g"] * n_unique * p["f"]) / mean_read_len))
@@ -98,8 +86,6 @@ def hot_path_step(ctx, reads, k, times: StepTimes | None):
         refs = torch.cat(par.all_gather_v(refs))
     index = ctx.index_build_pairs(kset, ids, refs, bounds, n_refs_total, 0, p["cs"])
     crefs, votes, cnt = ctx.candidates(index, lists, p["c"])
-    if times is not None:
-        times.add(ctx, ["cand_pair_counts", "cand_pair_fill", "cand_top", "sort_hist", "sort_scatter"])
     out = dict(survivors=n_surv, tot_kmers=tot_kmers, kept=kset.size, accepted=lists.total, refs=n_refs_total,
                index_entries=index.entries, with_candidates=int((cnt > 0).sum().item()))
     index.free(); lists.free(); kset.free()
@@ -163,13 +149,13 @@ def main():
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        hot_path_step(ctx, reads, args.k, None)
-    times = StepTimes()
+        hot_path_step(ctx, reads, args.k)
+    ctx.acc.clear()
     sync()
     t0 = time.perf_counter()
     info = None
     for _ in range(args.steps):
-        info = hot_path_step(ctx, reads, args.k, times)
+        info = hot_path_step(ctx, reads, args.k)
     sync()
     dt = time.perf_counter() - t0
     tdev = torch.tensor([dt], dtype=torch.float64, device=ctx.device)
@@ -180,21 +166,20 @@ def main():
     dt = float(tdev.item())
     total_bases = int(tb.item())
 
+    times = StepTimes(ctx)
     if rank == 0:
         # dominant kernel (by measured HIP-event time on the context stream) and its algorithmic bytes
         dom = max(times.ms, key=times.ms.get)
         K = info["survivors"]
         alg_bytes_per_launch = {
             # k-mer scan reads N/4 packed bases and writes 8 B per surviving k-mer
-            "kmer_scan": local_bases / 4 + 8 * K,
-            "accepted_found_mask": local_bases / 4 + 4 * K + 4 * (local_bases / 32),
+            "k_kmer_scan": local_bases / 4 + 8 * K,
+            "k_found_mask": local_bases / 4 + 4 * K + 4 * (local_bases / 32),
         }
         launches = times.launches[dom]
         avg_ms = times.ms[dom] / launches
         if dom in alg_bytes_per_launch:
             per_launch = alg_bytes_per_launch[dom]
-        elif dom in ("sort_scatter", "sort_hist"):
-            per_launch = None                              # depends on the array being sorted; see DESIGN.md
         else:
             per_launch = None
         roof = {"bound": "hbm", "kernel": dom, "avg_ms": avg_ms, "launches_per_step": launches / args.steps,

@@ -32,6 +32,7 @@ _SIG = {
     "cl_ctx_stream": (_P, [_P]),
     "cl_ctx_last_kernel_ms": (C.c_int32, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
     "cl_ctx_set_timing": (None, [_P, C.c_int]),
+    "cl_ctx_kernel_times": (C.c_int32, [_P, C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "cl_reads_pack": (C.c_int32, [_P, _P, _P, C.c_uint32, C.c_int, C.POINTER(_P)]),
     "cl_reads_free": (None, [_P]),
     "cl_reads_count": (C.c_uint32, [_P]),

@@ -27,6 +27,7 @@ extern "C" void cl_ctx_destroy(cl_ctx* c)
 	for (auto& p : c->pending) { (void)hipEventDestroy(p.second.first); (void)hipEventDestroy(p.second.second); }
 	for (auto e : c->ev_pool) (void)hipEventDestroy(e);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
+	c->pool.trim();
 	delete c;
 }
 extern "C" const char* cl_last_error(const cl_ctx* c) { return c ? c->err.c_str() : "null context"; }
@@ -39,6 +40,18 @@ extern "C" cl_status cl_ctx_last_kernel_ms(const cl_ctx* c, const char* kernel, 
 	if (it == c->times.end()) { if (ms) *ms = 0; if (launches) *launches = 0; return CL_E_INVALID; }
 	if (ms) *ms = it->second.ms;
 	if (launches) *launches = it->second.launches;
+	return CL_OK;
+}
+
+extern "C" cl_status cl_ctx_kernel_times(cl_ctx* c, char* buf, uint64_t cap, uint64_t* needed)
+{
+	if (!c) return CL_E_INVALID;
+	std::string out;
+	for (auto& kv : c->times) out += kv.first + "\t" + std::to_string(kv.second.ms) + "\t" + std::to_string(kv.second.launches) + "\n";
+	if (needed) *needed = out.size() + 1;
+	if (!buf || cap < out.size() + 1) return CL_E_CAPACITY;
+	memcpy(buf, out.c_str(), out.size() + 1);
+	c->times.clear();
 	return CL_OK;
 }
 

@@ -14,7 +14,33 @@
 
 struct KernelTime { double ms = 0; uint32_t launches = 0; };
 
+// Grow-only caching device allocator: hipMalloc/hipFree cost ~0.1-1 ms each and synchronise the device,
+// which dominated short calls.  Blocks are binned by rounded size and reused across calls.
+struct DevPool {
+	std::multimap<uint64_t, void*> free_blocks;
+	uint64_t cached_bytes = 0;
+	static uint64_t round_size(uint64_t bytes)
+	{
+		if (bytes < 256) return 256;
+		if (bytes < (1ull << 21)) { uint64_t p = 256; while (p < bytes) p <<= 1; return p; }
+		const uint64_t g = 1ull << 21; return (bytes + g - 1) / g * g;
+	}
+	hipError_t get(uint64_t bytes, void** out, uint64_t* got)
+	{
+		uint64_t r = round_size(bytes);
+		auto it = free_blocks.find(r);
+		if (it != free_blocks.end()) { *out = it->second; *got = r; cached_bytes -= r; free_blocks.erase(it); return hipSuccess; }
+		hipError_t e = hipMalloc(out, r);
+		if (e != hipSuccess) { (void)hipGetLastError(); trim(); e = hipMalloc(out, r); }
+		*got = r;
+		return e;
+	}
+	void put(void* p, uint64_t r) { free_blocks.emplace(r, p); cached_bytes += r; }
+	void trim() { for (auto& b : free_blocks) (void)hipFree(b.second); free_blocks.clear(); cached_bytes = 0; }
+};
+
 struct cl_ctx {
+	DevPool pool;
 	int device = 0;
 	hipStream_t stream = nullptr;
 	std::string err;
@@ -37,16 +63,27 @@ static inline cl_status cl_fail(cl_ctx* c, cl_status s, const std::string& msg)
 
 // ---- device buffers (RAII, freed with the owning object) -----------------------------------------
 template<typename T> struct DevBuf {
-	T* p = nullptr; uint64_t n = 0;
+	T* p = nullptr; uint64_t n = 0; uint64_t bytes = 0; DevPool* pool = nullptr;
 	DevBuf() = default;
 	DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
-	DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
-	DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
+	DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n), bytes(o.bytes), pool(o.pool) { o.p = nullptr; o.n = 0; }
+	DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; bytes = o.bytes; pool = o.pool; o.p = nullptr; o.n = 0; } return *this; }
 	~DevBuf() { release(); }
-	void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
-	hipError_t alloc(uint64_t count) { release(); n = count; if (!count) count = 1; return hipMalloc((void**)&p, count * sizeof(T)); }
+	void release() { if (p) { if (pool) pool->put(p, bytes); else (void)hipFree(p); } p = nullptr; n = 0; }
+	hipError_t alloc(cl_ctx* c, uint64_t count);
 };
-#define DEV_ALLOC(ctx, buf, count) do { hipError_t _e = (buf).alloc(count); if (_e != hipSuccess) \
+template<typename T> hipError_t DevBuf<T>::alloc(cl_ctx* c, uint64_t count)
+{
+	release(); n = count; if (!count) count = 1;
+	pool = &c->pool;
+	void* q = nullptr;
+	hipError_t e = pool->get(count * sizeof(T), &q, &bytes);
+	p = (T*)q;
+	if (e != hipSuccess) { p = nullptr; n = 0; }
+	return e;
+}
+
+#define DEV_ALLOC(ctx, buf, count) do { hipError_t _e = (buf).alloc((ctx), count); if (_e != hipSuccess) \
 	return cl_fail((ctx), CL_E_NOMEM, std::string("hipMalloc(" #buf ") of ") + std::to_string((uint64_t)(count)) + " elems: " + hipGetErrorString(_e)); } while (0)
 
 // ---- per-kernel timing with HIP events on the context stream -------------------------------------
@@ -66,7 +103,10 @@ struct KernelTimer {
 		c->pending.push_back({ name, { a, b } });
 	}
 };
-static inline void cl_timing_begin(cl_ctx* c) { if (c->timing) c->times.clear(); }
+// every kernel launch goes through LAUNCH so that per-kernel HIP-event times are complete
+#define LAUNCH(ctx, kernel, grid, block, ...) do { KernelTimer _kt((ctx), #kernel); \
+	hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (ctx)->stream, __VA_ARGS__); } while (0)
+static inline void cl_timing_begin(cl_ctx*) {}   // times accumulate until cl_ctx_kernel_times reports them
 static inline void cl_timing_collect(cl_ctx* c)
 {
 	if (!c->timing) return;
@@ -74,7 +114,9 @@ static inline void cl_timing_collect(cl_ctx* c)
 	{
 		(void)hipEventSynchronize(p.second.second);
 		float ms = 0; (void)hipEventElapsedTime(&ms, p.second.first, p.second.second);
-		auto& t = c->times[p.first]; t.ms += ms; t.launches += 1;
+		std::string nm = p.first;
+		if (!nm.empty() && nm.front() == '(' && nm.back() == ')') nm = nm.substr(1, nm.size() - 2);
+		auto& t = c->times[nm]; t.ms += ms; t.launches += 1;
 		c->ev_pool.push_back(p.second.first); c->ev_pool.push_back(p.second.second);
 	}
 	c->pending.clear();

@@ -168,11 +168,11 @@ extern "C" cl_status cl_index_entries_of(cl_ctx* ctx, const cl_kmer_lists* L, co
 	const uint32_t nr = L->n_reads; const uint64_t ne = L->total;
 	DevBuf<uint32_t> rank; DEV_ALLOC(ctx, rank, (uint64_t)nr + 1);
 	uint64_t n_refs = 0;
-	if (nr) hipLaunchKernelGGL(k_flags_from_bytes, dim3(grid_for(nr, 256)), dim3(256), 0, ctx->stream, d_accept, nr, rank.p);
+	if (nr) LAUNCH(ctx, k_flags_from_bytes, grid_for(nr, 256), 256, d_accept, nr, rank.p);
 	HIP_TRY(ctx, hipGetLastError());
 	CL_TRY(dev_exclusive_scan_u32(ctx, rank.p, nr, &n_refs));
 	{ uint32_t t = (uint32_t)n_refs; HIP_TRY(ctx, hipMemcpyAsync(rank.p + nr, &t, 4, hipMemcpyHostToDevice, ctx->stream)); }
-	if (ref_base) hipLaunchKernelGGL(k_add_const, dim3(grid_for((uint64_t)nr + 1, 256)), dim3(256), 0, ctx->stream, rank.p, (uint64_t)nr + 1, ref_base);
+	if (ref_base) LAUNCH(ctx, k_add_const, grid_for((uint64_t)nr + 1, 256), 256, rank.p, (uint64_t)nr + 1, ref_base);
 	HIP_TRY(ctx, hipGetLastError());
 	if (n_accepted) *n_accepted = (uint32_t)n_refs;
 	if (d_bounds) HIP_TRY(ctx, hipMemcpyAsync(d_bounds, rank.p, ((uint64_t)nr + 1) * 4, hipMemcpyDeviceToDevice, ctx->stream));
@@ -180,12 +180,12 @@ extern "C" cl_status cl_index_entries_of(cl_ctx* ctx, const cl_kmer_lists* L, co
 	if (ne)
 	{
 		DevBuf<uint32_t> ef; DEV_ALLOC(ctx, ef, ne);
-		hipLaunchKernelGGL(k_entry_flags, dim3(grid_for(ne, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)L->read.p, d_accept, ne, ef.p);
+		LAUNCH(ctx, k_entry_flags, grid_for(ne, 256), 256, (const uint32_t*)L->read.p, d_accept, ne, ef.p);
 		HIP_TRY(ctx, hipGetLastError());
 		CL_TRY(dev_exclusive_scan_u32(ctx, ef.p, ne, &n_sel));
 		*n_out = n_sel;
 		if (n_sel > cap || (n_sel && (!d_ids || !d_refs))) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); return cl_fail(ctx, CL_E_CAPACITY, "cl_index_entries_of: need " + std::to_string(n_sel) + " entries"); }
-		hipLaunchKernelGGL(k_gather_ref_entries, dim3(grid_for(ne, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)ef.p, ne, n_sel,
+		LAUNCH(ctx, k_gather_ref_entries, grid_for(ne, 256), 256, (const uint32_t*)ef.p, ne, n_sel,
 			(const uint32_t*)L->ids.p, (const uint32_t*)L->read.p, (const uint32_t*)rank.p, d_ids, d_refs);
 		HIP_TRY(ctx, hipGetLastError());
 	}
@@ -216,18 +216,18 @@ extern "C" cl_status cl_index_build_pairs(cl_ctx* ctx, const cl_kmer_set* S, uin
 		uint32_t bits = 1; while (bits < 32 && (1ULL << bits) < S->n) ++bits;
 		CL_TRY(dev_sort_keys32_pairs(ctx, d_ids, d_refs, n_sel, 0, bits));      // stable: refs stay ascending inside a k-mer
 		DevBuf<uint32_t> hf; DEV_ALLOC(ctx, hf, n_sel);
-		hipLaunchKernelGGL(k_head_flags32, dim3(grid_for(n_sel, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_ids, n_sel, hf.p);
+		LAUNCH(ctx, k_head_flags32, grid_for(n_sel, 256), 256, (const uint32_t*)d_ids, n_sel, hf.p);
 		uint64_t n_heads = 0;
 		CL_TRY(dev_exclusive_scan_u32(ctx, hf.p, n_sel, &n_heads));
 		DevBuf<uint32_t> head_pos; DEV_ALLOC(ctx, head_pos, n_heads);
-		hipLaunchKernelGGL(k_scatter_head_pos, dim3(grid_for(n_sel, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)hf.p, n_sel, n_heads, head_pos.p);
+		LAUNCH(ctx, k_scatter_head_pos, grid_for(n_sel, 256), 256, (const uint32_t*)hf.p, n_sel, n_heads, head_pos.p);
 		DevBuf<uint32_t> keep; DEV_ALLOC(ctx, keep, n_sel);
-		hipLaunchKernelGGL(k_cap_flags, dim3(grid_for(n_sel, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_ids, (const uint32_t*)d_refs, (const uint32_t*)hf.p,
+		LAUNCH(ctx, k_cap_flags, grid_for(n_sel, 256), 256, (const uint32_t*)d_ids, (const uint32_t*)d_refs, (const uint32_t*)hf.p,
 			(const uint32_t*)head_pos.p, n_sel, n_heads, n_pseudo, max_kmer_count, keep.p);
 		HIP_TRY(ctx, hipGetLastError());
 		CL_TRY(dev_exclusive_scan_u32(ctx, keep.p, n_sel, &n_keep));
 		DEV_ALLOC(ctx, X->refs, n_keep);
-		hipLaunchKernelGGL(k_compact_index, dim3(grid_for(n_sel, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)keep.p, n_sel, n_keep,
+		LAUNCH(ctx, k_compact_index, grid_for(n_sel, 256), 256, (const uint32_t*)keep.p, n_sel, n_keep,
 			(const uint32_t*)d_ids, (const uint32_t*)d_refs, X->refs.p, id_counts.p);
 		HIP_TRY(ctx, hipGetLastError());
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -274,8 +274,7 @@ extern "C" cl_status cl_candidates(cl_ctx* ctx, const cl_index* X, const cl_kmer
 	uint64_t n_pairs = 0;
 	if (ne)
 	{
-		KernelTimer t(ctx, "cand_pair_counts");
-		hipLaunchKernelGGL(k_pair_counts, dim3(grid_for(ne, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)L->ids.p, (const uint32_t*)L->read.p, ne,
+		LAUNCH(ctx, k_pair_counts, grid_for(ne, 256), 256, (const uint32_t*)L->ids.p, (const uint32_t*)L->read.p, ne,
 			(const uint32_t*)X->ref_rank.p, (const uint64_t*)X->off.p, (const uint32_t*)X->refs.p, cnt.p);
 	}
 	HIP_TRY(ctx, hipGetLastError());
@@ -311,21 +310,19 @@ extern "C" cl_status cl_candidates(cl_ctx* ctx, const cl_index* X, const cl_kmer
 		{
 			if (np >= (1ULL << 32)) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_candidates: a single read produces >= 2^32 vote pairs");
 			if (pairs.n < np) { DEV_ALLOC(ctx, pairs, np); DEV_ALLOC(ctx, hf, np); }
-			{ KernelTimer t(ctx, "cand_pair_fill");
-			  hipLaunchKernelGGL(k_pair_fill, dim3(grid_for(e1 - e0, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)L->ids.p, (const uint32_t*)L->read.p, e0, e1,
+			{ LAUNCH(ctx, k_pair_fill, grid_for(e1 - e0, 256), 256, (const uint32_t*)L->ids.p, (const uint32_t*)L->read.p, e0, e1,
 				(const uint32_t*)cnt.p, (const uint64_t*)poff.p, p0, (const uint64_t*)X->off.p, (const uint32_t*)X->refs.p, r0, ref_bits, pairs.p); }
 			HIP_TRY(ctx, hipGetLastError());
 			uint32_t rb = 1; while ((1ULL << rb) < (uint64_t)(r1 - r0)) ++rb;
 			CL_TRY(dev_sort_pairs(ctx, pairs.p, nullptr, np, 0, ref_bits + rb));
-			hipLaunchKernelGGL(k_head_flags64, dim3(grid_for(np, 256)), dim3(256), 0, ctx->stream, (const uint64_t*)pairs.p, np, hf.p);
+			LAUNCH(ctx, k_head_flags64, grid_for(np, 256), 256, (const uint64_t*)pairs.p, np, hf.p);
 			CL_TRY(dev_exclusive_scan_u32(ctx, hf.p, np, &n_u));
 			if (head_pos.n < n_u) { DEV_ALLOC(ctx, head_pos, n_u); DEV_ALLOC(ctx, votes, n_u); DEV_ALLOC(ctx, ukey, n_u); }
-			hipLaunchKernelGGL(k_scatter_head_pos, dim3(grid_for(np, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)hf.p, np, n_u, head_pos.p);
-			hipLaunchKernelGGL(k_pair_votes, dim3(grid_for(n_u, 256)), dim3(256), 0, ctx->stream, (const uint64_t*)pairs.p, (const uint32_t*)head_pos.p, n_u, np, ukey.p, votes.p);
+			LAUNCH(ctx, k_scatter_head_pos, grid_for(np, 256), 256, (const uint32_t*)hf.p, np, n_u, head_pos.p);
+			LAUNCH(ctx, k_pair_votes, grid_for(n_u, 256), 256, (const uint64_t*)pairs.p, (const uint32_t*)head_pos.p, n_u, np, ukey.p, votes.p);
 			HIP_TRY(ctx, hipGetLastError());
 		}
-		{ KernelTimer t(ctx, "cand_top");
-		  hipLaunchKernelGGL(k_top_candidates, dim3(grid_for(r1 - r0, 4)), dim3(256), 0, ctx->stream, (const uint64_t*)ukey.p, (const uint32_t*)votes.p, n_u,
+		{ LAUNCH(ctx, k_top_candidates, grid_for(r1 - r0, 4), 256, (const uint64_t*)ukey.p, (const uint32_t*)votes.p, n_u,
 			r0, r1, ref_bits, c, d_refs, d_votes, d_n); }
 		HIP_TRY(ctx, hipGetLastError());
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -383,14 +380,14 @@ extern "C" cl_status cl_candidates_common(cl_ctx* ctx, const cl_index* X, const 
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	const uint32_t nr = L->n_reads; const uint64_t nslots = (uint64_t)nr * c;
 	DevBuf<uint32_t> counts; DEV_ALLOC(ctx, counts, nslots);
-	if (nr) hipLaunchKernelGGL((k_common<0>), dim3(grid_for(nr, 4)), dim3(256), 0, ctx->stream, (const uint64_t*)L->off.p, (const uint32_t*)L->ids.p, (const uint64_t*)L->kmers.p,
+	if (nr) LAUNCH(ctx, (k_common<0>), grid_for(nr, 4), 256, (const uint64_t*)L->off.p, (const uint32_t*)L->ids.p, (const uint64_t*)L->kmers.p,
 		(const uint64_t*)X->off.p, (const uint32_t*)X->refs.p, d_refs, d_n, nr, c, counts.p, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t)0);
 	HIP_TRY(ctx, hipGetLastError());
 	uint64_t total = 0;
 	CL_TRY(dev_exclusive_scan_u64(ctx, counts.p, d_common_off, nslots, &total));
 	*n_common = total;
 	if (total > cap || (total && !d_common)) return cl_fail(ctx, CL_E_CAPACITY, "cl_candidates_common: need " + std::to_string(total) + " k-mers");
-	if (nr && total) hipLaunchKernelGGL((k_common<1>), dim3(grid_for(nr, 4)), dim3(256), 0, ctx->stream, (const uint64_t*)L->off.p, (const uint32_t*)L->ids.p, (const uint64_t*)L->kmers.p,
+	if (nr && total) LAUNCH(ctx, (k_common<1>), grid_for(nr, 4), 256, (const uint64_t*)L->off.p, (const uint32_t*)L->ids.p, (const uint64_t*)L->kmers.p,
 		(const uint64_t*)X->off.p, (const uint32_t*)X->refs.p, d_refs, d_n, nr, c, (uint32_t*)nullptr, (const uint64_t*)d_common_off, d_common, cap);
 	HIP_TRY(ctx, hipGetLastError());
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -4,6 +4,7 @@
 // test, ballot/prefix compaction.  No MFMA anywhere on this path.
 #include "common.hpp"
 #include "objects.hpp"
+#include <algorithm>
 
 // ======================================================================================================
 // arena
@@ -79,7 +80,7 @@ extern "C" cl_status cl_reads_pack(cl_ctx* ctx, const uint8_t* d_codes, const ui
 	HIP_TRY(ctx, hipMemsetAsync(err.p, 0, 4, ctx->stream));
 	if (n_reads)
 	{
-		hipLaunchKernelGGL(k_read_geometry, dim3(grid_for(n_reads, 256)), dim3(256), 0, ctx->stream, d_offsets, n_reads, R->lens.p, words.p, err.p);
+		LAUNCH(ctx, k_read_geometry, grid_for(n_reads, 256), 256, d_offsets, n_reads, R->lens.p, words.p, err.p);
 		HIP_TRY(ctx, hipGetLastError());
 	}
 	CL_TRY(dev_exclusive_scan_u64(ctx, words.p, R->word_off.p, n_reads, &R->total_words));
@@ -94,12 +95,11 @@ extern "C" cl_status cl_reads_pack(cl_ctx* ctx, const uint8_t* d_codes, const ui
 	DEV_ALLOC(ctx, R->packed, R->total_words + 1); DEV_ALLOC(ctx, R->inv, R->total_words + 1);
 	if (n_reads)
 	{
-		KernelTimer t(ctx, "pack_reads");
-		hipLaunchKernelGGL(k_pack, dim3(grid_for(n_reads, 4)), dim3(256), 0, ctx->stream, d_codes, d_offsets, (const uint64_t*)R->word_off.p,
+		LAUNCH(ctx, k_pack, grid_for(n_reads, 4), 256, d_codes, d_offsets, (const uint64_t*)R->word_off.p,
 			(const uint32_t*)R->lens.p, n_reads, ascii, R->packed.p, R->inv.p, R->has_n.p, err.p);
 	}
 	HIP_TRY(ctx, hipGetLastError());
-	hipLaunchKernelGGL(k_arena_tail, dim3(1), dim3(1), 0, ctx->stream, R->packed.p, R->inv.p, R->total_words);
+	LAUNCH(ctx, k_arena_tail, 1, 1, R->packed.p, R->inv.p, R->total_words);
 	uint32_t herr = 0;
 	HIP_TRY(ctx, hipMemcpyAsync(&herr, err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -232,8 +232,7 @@ extern "C" cl_status cl_kmer_scan(cl_ctx* ctx, const cl_reads* R, uint32_t k, ui
 	HIP_TRY(ctx, hipMemsetAsync(counter.p, 0, 8, ctx->stream));
 	if (R->total_words)
 	{
-		KernelTimer t(ctx, "kmer_scan");
-		hipLaunchKernelGGL(k_kmer_scan, dim3(grid_for(R->total_words, 256)), dim3(256), 0, ctx->stream,
+		LAUNCH(ctx, k_kmer_scan, grid_for(R->total_words, 256), 256,
 			(const uint64_t*)R->packed.p, (const uint32_t*)R->inv.p, R->total_words, k, make_modtest(f), d_out, cap, counter.p);
 	}
 	HIP_TRY(ctx, hipGetLastError());
@@ -276,7 +275,7 @@ __global__ void k_count_flags(const uint32_t* __restrict__ head_pos, uint64_t n_
 }
 __global__ void k_scatter_kept(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ head_pos, const uint32_t* __restrict__ scan,
                                uint64_t n_heads, uint64_t n_kept, uint64_t n, uint32_t cs,
-                               uint64_t* __restrict__ kept_keys, uint32_t* __restrict__ kept_counts, unsigned long long* __restrict__ sum)
+                               uint64_t* __restrict__ kept_keys, uint32_t* __restrict__ kept_counts)
 {
 	uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	uint32_t c = 0;
@@ -292,8 +291,18 @@ __global__ void k_scatter_kept(const uint64_t* __restrict__ keys, const uint32_t
 			kept_keys[s] = keys[head_pos[j]]; kept_counts[s] = c;
 		}
 	}
-	uint32_t ws = wave_sum(c);
-	if ((threadIdx.x & 63) == 0 && ws) atomicAdd(sum, (unsigned long long)ws);
+}
+// grid-stride sum of a uint32 array into one uint64 (one atomic per block)
+__global__ __launch_bounds__(256) void k_sum_u32(const uint32_t* __restrict__ v, uint64_t n, unsigned long long* __restrict__ sum)
+{
+	__shared__ unsigned long long sh[4];
+	unsigned long long s = 0;
+	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) s += v[i];
+#pragma unroll
+	for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+	if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+	__syncthreads();
+	if (threadIdx.x == 0) atomicAdd(sum, sh[0] + sh[1] + sh[2] + sh[3]);
 }
 
 // ---- membership table: buckets of 4 x {key, value} = 64 bytes, load <= 0.5, linear probing over buckets
@@ -363,23 +372,23 @@ extern "C" cl_status cl_kmer_count_filter(cl_ctx* ctx, uint64_t* d_kmers, uint64
 	{
 		CL_TRY(dev_sort_pairs(ctx, d_kmers, nullptr, n, 0, 2 * k));
 		DevBuf<uint32_t> flags; DEV_ALLOC(ctx, flags, n);
-		{ KernelTimer t(ctx, "count_head_flags");
-		  hipLaunchKernelGGL(k_head_flags, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, (const uint64_t*)d_kmers, n, flags.p); }
+		{ LAUNCH(ctx, k_head_flags, grid_for(n, 256), 256, (const uint64_t*)d_kmers, n, flags.p); }
 		HIP_TRY(ctx, hipGetLastError());
 		CL_TRY(dev_exclusive_scan_u32(ctx, flags.p, n, &n_heads));
 		DevBuf<uint32_t> head_pos; DEV_ALLOC(ctx, head_pos, n_heads);
-		{ KernelTimer t(ctx, "count_scatter_heads");
-		  hipLaunchKernelGGL(k_scatter_heads, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, (const uint64_t*)d_kmers, (const uint32_t*)flags.p, n, n_heads, head_pos.p); }
+		{ LAUNCH(ctx, k_scatter_heads, grid_for(n, 256), 256, (const uint64_t*)d_kmers, (const uint32_t*)flags.p, n, n_heads, head_pos.p); }
 		HIP_TRY(ctx, hipGetLastError());
 		DevBuf<uint32_t> kflags; DEV_ALLOC(ctx, kflags, n_heads);
-		hipLaunchKernelGGL(k_count_flags, dim3(grid_for(n_heads, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)head_pos.p, n_heads, n, ci, kflags.p);
+		LAUNCH(ctx, k_count_flags, grid_for(n_heads, 256), 256, (const uint32_t*)head_pos.p, n_heads, n, ci, kflags.p);
 		HIP_TRY(ctx, hipGetLastError());
 		CL_TRY(dev_exclusive_scan_u32(ctx, kflags.p, n_heads, &n_kept));
 		DEV_ALLOC(ctx, S->keys, n_kept); DEV_ALLOC(ctx, S->counts, n_kept);
 		DevBuf<unsigned long long> sum; DEV_ALLOC(ctx, sum, 1);
 		HIP_TRY(ctx, hipMemsetAsync(sum.p, 0, 8, ctx->stream));
-		hipLaunchKernelGGL(k_scatter_kept, dim3(grid_for(n_heads, 256)), dim3(256), 0, ctx->stream, (const uint64_t*)d_kmers, (const uint32_t*)head_pos.p,
-			(const uint32_t*)kflags.p, n_heads, n_kept, n, cs, S->keys.p, S->counts.p, sum.p);
+		LAUNCH(ctx, k_scatter_kept, grid_for(n_heads, 256), 256, (const uint64_t*)d_kmers, (const uint32_t*)head_pos.p,
+			(const uint32_t*)kflags.p, n_heads, n_kept, n, cs, S->keys.p, S->counts.p);
+		HIP_TRY(ctx, hipGetLastError());
+		if (n_kept) LAUNCH(ctx, k_sum_u32, (uint32_t)std::min<uint64_t>(1024, grid_for(n_kept, 256)), 256, (const uint32_t*)S->counts.p, n_kept, sum.p);
 		HIP_TRY(ctx, hipGetLastError());
 		HIP_TRY(ctx, hipMemcpyAsync(&filt, sum.p, 8, hipMemcpyDeviceToHost, ctx->stream));
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -402,8 +411,7 @@ static cl_status build_table(cl_ctx* ctx, cl_kmer_set* S)
 	HIP_TRY(ctx, hipMemsetAsync(S->slots.p, 0xff, nbuckets * 64, ctx->stream));
 	if (S->n)
 	{
-		KernelTimer t(ctx, "table_build");
-		hipLaunchKernelGGL(k_table_build, dim3(grid_for(S->n, 256)), dim3(256), 0, ctx->stream, (const uint64_t*)S->keys.p, S->n, (Slot*)S->slots.p, S->bmask);
+		LAUNCH(ctx, k_table_build, grid_for(S->n, 256), 256, (const uint64_t*)S->keys.p, S->n, (Slot*)S->slots.p, S->bmask);
 	}
 	HIP_TRY(ctx, hipGetLastError());
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -436,7 +444,7 @@ extern "C" cl_status cl_kmer_set_check(cl_ctx* ctx, const cl_kmer_set* S, const 
 {
 	if (!ctx || !S) return cl_fail(ctx, CL_E_INVALID, "cl_kmer_set_check: null argument");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
-	if (n) hipLaunchKernelGGL(k_table_check, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, (const void*)S->slots.p, S->bmask, d_kmers, n, d_found);
+	if (n) LAUNCH(ctx, k_table_check, grid_for(n, 256), 256, (const void*)S->slots.p, S->bmask, d_kmers, n, d_found);
 	HIP_TRY(ctx, hipGetLastError());
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	return CL_OK;
@@ -560,13 +568,12 @@ extern "C" cl_status cl_accepted_kmers(cl_ctx* ctx, const cl_kmer_set* S, const 
 	DevBuf<uint32_t> fmask; DEV_ALLOC(ctx, fmask, R->total_words);
 	if (R->total_words)
 	{
-		KernelTimer t(ctx, "accepted_found_mask");
-		hipLaunchKernelGGL(k_found_mask, dim3(grid_for(R->total_words, 256)), dim3(256), 0, ctx->stream, (const uint64_t*)R->packed.p, (const uint32_t*)R->inv.p,
+		LAUNCH(ctx, k_found_mask, grid_for(R->total_words, 256), 256, (const uint64_t*)R->packed.p, (const uint32_t*)R->inv.p,
 			R->total_words, k, make_modtest(f), (const void*)S->slots.p, S->bmask, fmask.p);
 	}
 	HIP_TRY(ctx, hipGetLastError());
 	DevBuf<uint32_t> counts; DEV_ALLOC(ctx, counts, nr);
-	if (nr) hipLaunchKernelGGL(k_read_counts, dim3(grid_for(nr, 4)), dim3(256), 0, ctx->stream, (const uint32_t*)fmask.p, (const uint64_t*)R->word_off.p,
+	if (nr) LAUNCH(ctx, k_read_counts, grid_for(nr, 4), 256, (const uint32_t*)fmask.p, (const uint64_t*)R->word_off.p,
 		(const uint32_t*)R->lens.p, (const uint8_t*)R->has_n.p, nr, k, counts.p);
 	HIP_TRY(ctx, hipGetLastError());
 	DevBuf<uint64_t> rec_off; DEV_ALLOC(ctx, rec_off, (uint64_t)nr + 1);
@@ -577,8 +584,7 @@ extern "C" cl_status cl_accepted_kmers(cl_ctx* ctx, const cl_kmer_set* S, const 
 	DEV_ALLOC(ctx, rec_id, n_rec); DEV_ALLOC(ctx, rec_pos, n_rec); DEV_ALLOC(ctx, rec_read, n_rec);
 	if (nr && n_rec)
 	{
-		KernelTimer t(ctx, "accepted_emit");
-		hipLaunchKernelGGL(k_emit_records, dim3(grid_for(nr, 4)), dim3(256), 0, ctx->stream, (const uint64_t*)R->packed.p, (const uint32_t*)fmask.p,
+		LAUNCH(ctx, k_emit_records, grid_for(nr, 4), 256, (const uint64_t*)R->packed.p, (const uint32_t*)fmask.p,
 			(const uint64_t*)R->word_off.p, (const uint64_t*)rec_off.p, nr, k, (const void*)S->slots.p, S->bmask, rec_id.p, rec_pos.p, rec_read.p);
 	}
 	HIP_TRY(ctx, hipGetLastError());
@@ -590,10 +596,10 @@ extern "C" cl_status cl_accepted_kmers(cl_ctx* ctx, const cl_kmer_set* S, const 
 	{
 		DevBuf<uint32_t> sid, sidx; DEV_ALLOC(ctx, sid, n_rec); DEV_ALLOC(ctx, sidx, n_rec);
 		HIP_TRY(ctx, hipMemcpyAsync(sid.p, rec_id.p, n_rec * 4, hipMemcpyDeviceToDevice, ctx->stream));
-		hipLaunchKernelGGL(k_iota, dim3(grid_for(n_rec, 256)), dim3(256), 0, ctx->stream, sidx.p, n_rec);
+		LAUNCH(ctx, k_iota, grid_for(n_rec, 256), 256, sidx.p, n_rec);
 		uint32_t bits = 1; while (bits < 32 && (1ULL << bits) < S->n) ++bits;
 		CL_TRY(dev_sort_keys32_pairs(ctx, sid.p, sidx.p, n_rec, 0, bits));
-		hipLaunchKernelGGL(k_flag_first, dim3(grid_for(n_rec, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)sid.p, (const uint32_t*)sidx.p,
+		LAUNCH(ctx, k_flag_first, grid_for(n_rec, 256), 256, (const uint32_t*)sid.p, (const uint32_t*)sidx.p,
 			(const uint32_t*)rec_read.p, n_rec, keep.p);
 		HIP_TRY(ctx, hipGetLastError());
 		CL_TRY(dev_exclusive_scan_u32(ctx, keep.p, n_rec, &n_keep));
@@ -603,11 +609,11 @@ extern "C" cl_status cl_accepted_kmers(cl_ctx* ctx, const cl_kmer_set* S, const 
 	DEV_ALLOC(ctx, L->off, (uint64_t)nr + 1);
 	if (n_rec)
 	{
-		hipLaunchKernelGGL(k_compact_records, dim3(grid_for(n_rec, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)keep.p, n_rec, n_keep,
+		LAUNCH(ctx, k_compact_records, grid_for(n_rec, 256), 256, (const uint32_t*)keep.p, n_rec, n_keep,
 			(const uint32_t*)rec_id.p, (const uint32_t*)rec_pos.p, (const uint32_t*)rec_read.p, (const uint64_t*)S->keys.p, L->ids.p, L->pos.p, L->read.p, L->kmers.p);
 		HIP_TRY(ctx, hipGetLastError());
 	}
-	hipLaunchKernelGGL(k_remap_offsets, dim3(grid_for((uint64_t)nr + 1, 256)), dim3(256), 0, ctx->stream, (const uint64_t*)rec_off.p, (const uint32_t*)keep.p,
+	LAUNCH(ctx, k_remap_offsets, grid_for((uint64_t)nr + 1, 256), 256, (const uint64_t*)rec_off.p, (const uint32_t*)keep.p,
 		nr, n_rec, n_keep, L->off.p);
 	HIP_TRY(ctx, hipGetLastError());
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

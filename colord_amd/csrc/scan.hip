@@ -62,15 +62,15 @@ cl_status scan_impl(cl_ctx* ctx, const TIn* d_in, TOut* d_out, uint64_t n)
 	uint32_t tiles = grid_for(n, SCAN_TILE);
 	if (tiles == 1)
 	{
-		hipLaunchKernelGGL((k_tile_scan<TIn, TOut>), dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, d_in, n, (const TOut*)nullptr, d_out);
+		LAUNCH(ctx, (k_tile_scan<TIn, TOut>), 1, SCAN_THREADS, d_in, n, (const TOut*)nullptr, d_out);
 		HIP_TRY(ctx, hipGetLastError());
 		return CL_OK;
 	}
 	DevBuf<TOut> sums; DEV_ALLOC(ctx, sums, tiles);
-	hipLaunchKernelGGL((k_tile_reduce<TIn, TOut>), dim3(tiles), dim3(SCAN_THREADS), 0, ctx->stream, d_in, n, sums.p);
+	LAUNCH(ctx, (k_tile_reduce<TIn, TOut>), tiles, SCAN_THREADS, d_in, n, sums.p);
 	HIP_TRY(ctx, hipGetLastError());
 	CL_TRY((scan_impl<TOut, TOut>(ctx, sums.p, sums.p, tiles)));
-	hipLaunchKernelGGL((k_tile_scan<TIn, TOut>), dim3(tiles), dim3(SCAN_THREADS), 0, ctx->stream, d_in, n, (const TOut*)sums.p, d_out);
+	LAUNCH(ctx, (k_tile_scan<TIn, TOut>), tiles, SCAN_THREADS, d_in, n, (const TOut*)sums.p, d_out);
 	HIP_TRY(ctx, hipGetLastError());
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // sums is freed on return
 	return CL_OK;

@@ -98,17 +98,15 @@ cl_status sort_impl(cl_ctx* ctx, K* d_keys, uint32_t* d_vals, uint64_t n, uint32
 	for (uint32_t shift = begin_bit; shift < end_bit; shift += 8)
 	{
 		{
-			KernelTimer t(ctx, "sort_hist");
-			hipLaunchKernelGGL((k_sort_hist<K>), dim3(nb), dim3(ST), 0, ctx->stream, (const K*)kin, n, shift, hist.p, nb);
+			LAUNCH(ctx, (k_sort_hist<K>), nb, ST, (const K*)kin, n, shift, hist.p, nb);
 		}
 		HIP_TRY(ctx, hipGetLastError());
 		CL_TRY(dev_exclusive_scan_u32(ctx, hist.p, (uint64_t)256 * nb, nullptr));
 		{
-			KernelTimer t(ctx, "sort_scatter");
 			if (d_vals)
-				hipLaunchKernelGGL((k_sort_scatter<K, true>), dim3(nb), dim3(ST), 0, ctx->stream, (const K*)kin, (const uint32_t*)vin, kout, vout, n, shift, (const uint32_t*)hist.p, nb);
+				LAUNCH(ctx, (k_sort_scatter<K, true>), nb, ST, (const K*)kin, (const uint32_t*)vin, kout, vout, n, shift, (const uint32_t*)hist.p, nb);
 			else
-				hipLaunchKernelGGL((k_sort_scatter<K, false>), dim3(nb), dim3(ST), 0, ctx->stream, (const K*)kin, (const uint32_t*)nullptr, kout, (uint32_t*)nullptr, n, shift, (const uint32_t*)hist.p, nb);
+				LAUNCH(ctx, (k_sort_scatter<K, false>), nb, ST, (const K*)kin, (const uint32_t*)nullptr, kout, (uint32_t*)nullptr, n, shift, (const uint32_t*)hist.p, nb);
 		}
 		HIP_TRY(ctx, hipGetLastError());
 		std::swap(kin, kout); std::swap(vin, vout);

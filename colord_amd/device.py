@@ -8,6 +8,11 @@ from . import _native as N
 
 
 def _check(ctx, st):
+    if ctx is not None and getattr(ctx, "timing", False):
+        for n, (ms, k) in ctx.kernel_times().items():
+            a = ctx.acc.setdefault(n, [0.0, 0])
+            a[0] += ms
+            a[1] += k
     if st != N.CL_OK:
         msg = N.load().cl_last_error(ctx.h).decode() if ctx is not None and ctx.h else ""
         raise N.ColordHipError(st, msg)
@@ -46,6 +51,8 @@ class Context:
         if st != N.CL_OK:
             raise N.ColordHipError(st, "cl_ctx_create failed")
         self.device = torch.device("cuda", device)
+        self.timing = timing
+        self.acc = {}                  # {kernel: [ms, launches]} accumulated over API calls while timing is on
         if timing:
             self.lib.cl_ctx_set_timing(self.h, 1)
 
@@ -58,6 +65,18 @@ class Context:
         ms, n = C.c_double(0), C.c_uint32(0)
         self.lib.cl_ctx_last_kernel_ms(self.h, name.encode(), C.byref(ms), C.byref(n))
         return ms.value, n.value
+
+    def kernel_times(self) -> dict:
+        """{kernel: (ms, launches)} of the last API call (timing must be on)."""
+        buf = C.create_string_buffer(1 << 16)
+        need = C.c_uint64(0)
+        if self.lib.cl_ctx_kernel_times(self.h, buf, len(buf), C.byref(need)) != N.CL_OK:
+            return {}
+        out = {}
+        for line in buf.value.decode().splitlines():
+            n, ms, k = line.split("\t")
+            out[n] = (float(ms), int(k))
+        return out
 
     # ---- arena ----
     def pack_reads(self, codes: torch.Tensor, offsets: torch.Tensor, ascii: bool = False) -> "Reads":

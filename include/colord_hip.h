@@ -52,6 +52,9 @@ void* cl_ctx_stream(cl_ctx* ctx);
 /* Wall-clock free device timing of the LAST call's dominant kernel, measured with HIP events on the
  * context stream: *ms = elapsed milliseconds, *launches = number of launches it covers. */
 cl_status cl_ctx_last_kernel_ms(const cl_ctx* ctx, const char* kernel, double* ms, uint32_t* launches);
+/* Kernel times recorded since the previous report, as text lines "name\tms\tlaunches\n" (needs timing on);
+ * a successful report clears the record. */
+cl_status cl_ctx_kernel_times(cl_ctx* ctx, char* buf, uint64_t cap, uint64_t* needed);
 /* Enable/disable per-kernel HIP-event timing (off by default; on adds event records around kernels). */
 void cl_ctx_set_timing(cl_ctx* ctx, int on);
 
