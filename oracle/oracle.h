@@ -67,6 +67,19 @@ uint32_t orc_graph_n_refs(const orc_graph*);
 /* ---- a7: 2-bit reference read store (reference_reads.h:35-72) ----------------------------------- */
 size_t orc_refread_compact(const uint8_t* bases, size_t len, uint8_t* out);   /* returns (len+3)/4 + 1 */
 
+/* ---- a13 + a15: range coder, models, quality coder (sub_rc.h, rc.h, quality_coder*.cpp) --------- */
+typedef struct orc_qual orc_qual;
+/* mode: QualityComprMode (params.h:33-43), source: DataSource (0 ONT, 1 PBRaw, 2 PBHiFi), level 1..3 */
+orc_qual* orc_qual_new(int compress, int mode, int source, int level, const uint32_t* fwd_thr, int n_fwd, const uint32_t* rev_thr, int n_rev);
+void orc_qual_free(orc_qual*);
+void orc_qual_encode(orc_qual*, const uint8_t* bases, const uint8_t* qual, uint32_t len, const uint8_t* flags);
+/* closes the current part (Finish/GetOutput/Restart, entr_qual.h:68-79); dst==NULL only returns the size */
+size_t orc_qual_finish_part(orc_qual*, uint8_t* dst, size_t cap);
+void orc_qual_set_input(orc_qual*, const uint8_t* data, size_t n);
+void orc_qual_decode(orc_qual*, const uint8_t* bases, uint32_t len, const uint8_t* flags, uint8_t* qual_out);
+/* per-base 'A'/'M'/' '/'P' classes from a read's tuple stream (quality_coder_impl.cpp:25-75) */
+void orc_es_flags(const uint8_t* es, size_t n, uint32_t read_len, uint8_t* flags);
+
 #ifdef __cplusplus
 }
 #endif

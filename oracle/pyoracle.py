@@ -46,6 +46,15 @@ def lib():
         L.orc_graph_n_refs.argtypes = [C.c_void_p]
         L.orc_refread_compact.restype = C.c_size_t
         L.orc_refread_compact.argtypes = [u8p, C.c_size_t, u8p]
+        L.orc_qual_new.restype = C.c_void_p
+        L.orc_qual_new.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orc_qual_free.argtypes = [C.c_void_p]
+        L.orc_qual_encode.argtypes = [C.c_void_p, u8p, u8p, C.c_uint32, C.c_void_p]
+        L.orc_qual_finish_part.restype = C.c_size_t
+        L.orc_qual_finish_part.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.orc_qual_set_input.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.orc_qual_decode.argtypes = [C.c_void_p, u8p, C.c_uint32, C.c_void_p, u8p]
+        L.orc_es_flags.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, u8p]
         _LIB = L
     return _LIB
 
@@ -109,3 +118,61 @@ class Graph:
             return refs[:n].copy(), votes[:n].copy(), [common[off[i]:off[i + 1]].copy() for i in range(n)]
         n = lib().orc_graph_next_read(self.h, k, len(k), int(accept), refs, votes, None, None)
         return refs[:n].copy(), votes[:n].copy(), None
+
+
+# QualityComprMode (params.h:33-43) and the default thresholds / representatives (arg_parse.cpp:32-84)
+QM = dict(org=0, avg5=1, avg4=2, avg2=3, fix5=4, fix4=5, fix2=6, avg=7, none=8)
+QUAL_DEFAULTS = {
+    0: ((), ()), 7: ((), ()), 8: ((), (0,)),
+    1: ((7, 14, 26, 93), ()), 2: ((7, 14, 26), ()), 3: ((7,), ()),
+    4: ((7, 14, 26, 93), (3, 10, 18, 35, 93)), 5: ((7, 14, 26), (3, 10, 18, 35)), 6: ((7,), (1, 13)),
+}
+
+
+def es_flags(es: bytes, read_len: int) -> np.ndarray:
+    out = np.zeros(max(read_len, 1), np.uint8)
+    buf = (C.c_char * len(es)).from_buffer_copy(es)
+    lib().orc_es_flags(buf, len(es), read_len, out)
+    return out[:read_len]
+
+
+class QualCoder:
+    """CQualityCoder + the per-pack part framing of CEntrComprQuals / CEntrDecomprQuals."""
+    def __init__(self, compress: bool, mode: int, source: int, level: int, fwd=None, rev=None):
+        d = QUAL_DEFAULTS[mode]
+        fwd = np.asarray(d[0] if fwd is None else fwd, np.uint32)
+        rev = np.asarray(d[1] if rev is None else rev, np.uint32)
+        self.h = lib().orc_qual_new(int(compress), mode, source, level, fwd.ctypes.data, len(fwd), rev.ctypes.data, len(rev))
+        self._keep = None
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_qual_free(self.h)
+            self.h = None
+
+    def encode(self, bases, qual, flags=None):
+        b = np.ascontiguousarray(bases, np.uint8)
+        q = np.ascontiguousarray(qual, np.uint8)
+        f = None if flags is None else np.ascontiguousarray(flags, np.uint8)
+        if len(b) == 0:
+            b = np.zeros(1, np.uint8); q = np.zeros(1, np.uint8)
+        lib().orc_qual_encode(self.h, b, q, len(bases), None if f is None else f.ctypes.data)
+
+    def finish_part(self) -> bytes:
+        n = lib().orc_qual_finish_part(self.h, None, 0)
+        buf = np.zeros(n, np.uint8)
+        m = lib().orc_qual_finish_part(self.h, buf.ctypes.data, n)
+        return buf[:m].tobytes()
+
+    def set_input(self, data: bytes):
+        self._keep = (C.c_char * max(1, len(data))).from_buffer_copy(data or b"\0")
+        lib().orc_qual_set_input(self.h, self._keep, len(data))
+
+    def decode(self, bases, flags=None) -> np.ndarray:
+        b = np.ascontiguousarray(bases, np.uint8)
+        out = np.zeros(max(1, len(b)), np.uint8)
+        f = None if flags is None else np.ascontiguousarray(flags, np.uint8)
+        if len(b) == 0:
+            b = np.zeros(1, np.uint8)
+        lib().orc_qual_decode(self.h, b, len(bases), None if f is None else f.ctypes.data, out)
+        return out[:len(bases)]
