@@ -19,6 +19,11 @@ class ColordHipError(RuntimeError):
         self.status = status
 
 
+class QualParams(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("source", C.c_int32), ("level", C.c_int32), ("n_fwd", C.c_uint32), ("fwd", C.c_uint32 * 8),
+                ("n_rev", C.c_uint32), ("rev", C.c_uint32 * 8)]
+
+
 class KmerStats(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("tot_kmers", C.c_uint64), ("n_unique", C.c_uint64),
                 ("n_unique_counted", C.c_uint64), ("total_count_filtered", C.c_uint64)]
@@ -70,6 +75,9 @@ _SIG = {
     "cl_index_ref_rank": (_P, [_P]),
     "cl_candidates": (C.c_int32, [_P, _P, _P, C.c_uint32, _P, _P, _P]),
     "cl_candidates_common": (C.c_int32, [_P, _P, _P, C.c_uint32, _P, _P, _P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "cl_qual_coder_create": (C.c_int32, [_P, C.POINTER(QualParams), C.POINTER(_P)]),
+    "cl_qual_coder_free": (None, [_P]),
+    "cl_qual_encode": (C.c_int32, [_P, _P, _P, _P, _P, _P, _P, C.c_uint32, _P, C.c_uint64, _P, C.POINTER(C.c_uint64)]),
     "cl_sort_u64": (C.c_int32, [_P, _P, C.c_uint64, C.c_uint32, C.c_uint32]),
     "cl_sort_u64_u32": (C.c_int32, [_P, _P, _P, C.c_uint64, C.c_uint32, C.c_uint32]),
 }

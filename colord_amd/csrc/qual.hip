@@ -1,0 +1,563 @@
+// qual.hip — quality stream coder (a13 + a15 + a16 framing) on the GPU, bit-identical to the reference's
+// sequential adaptive coder.
+//
+// The reference codes one symbol per base through ONE adaptive model set that lives for the whole file
+// (entr_qual.h:100-135).  Two facts make that parallel without changing a single output byte:
+//   1. contexts depend only on INPUT data (previous quality values, neighbouring bases, edit-script
+//      flags), never on coder state, so (context, symbol) of every position is computed independently;
+//   2. a model is touched only by the symbols of its own context (basic_coder.h:116-137) and its update
+//      is "+ADDER, halve-round-up when total >= MAX_TOTAL" (rc.h:233-244,347-358), so after a STABLE sort by
+//      context each model is evolved by one wavefront over its own contiguous run, with 64 symbols
+//      ranked per step by ballot + popcount prefixes.
+// That yields for every coded symbol the exact triple (cumulative, frequency, total) the sequential coder
+// would have used.  The interval arithmetic itself (sub_rc.h:83-100) is a dependent chain; it restarts
+// per part (entr_qual.h:68-79), so one lane codes one part and all parts of a batch run concurrently.
+#include "common.hpp"
+#include "objects.hpp"
+#include <algorithm>
+
+namespace {
+
+enum { QM_ORIGINAL = 0, QM_QUINARY_AVG, QM_QUAD_AVG, QM_BINARY_AVG, QM_QUINARY_THR, QM_QUAD_THR, QM_BINARY_THR, QM_AVERAGE, QM_NONE };
+
+struct QualCfg {
+	int32_t mode, level;
+	uint32_t bits_per_sym, n_ctx_sym, ctx_bits;   // previous-symbol history
+	uint32_t base_bits;                            // neighbouring-base part of the context
+	uint32_t n_sym, sym_bits;                      // alphabet of the per-base family
+	uint32_t n_bins, navg;                         // *-avg: bins and coded bytes per read (2 per bin; avg: 2)
+	uint32_t max_total, adder;
+	uint32_t n_ctx;                                // dense context count of the per-base family
+	uint32_t is_avg, is_thr;
+	uint8_t map_fwd[96], quant[96];
+};
+
+} // namespace
+
+struct cl_qual_coder {
+	cl_ctx* ctx = nullptr;
+	QualCfg cfg;
+	DevBuf<QualCfg> d_cfg;
+	DevBuf<uint32_t> state;       // per-base family: n_ctx * (n_sym + 1)  (counters..., total)
+	DevBuf<uint32_t> bstate;      // byte family: 896 * 257
+	uint64_t symbols_coded = 0;
+};
+
+namespace {
+constexpr uint32_t BYTE_CTX = 5 * 128 + 256;      // (bin, floor(prev avg)) and 0x100 + high byte (quality_coder_impl.cpp:821-834)
+
+__device__ inline uint32_t arena_base(const uint64_t* __restrict__ packed, uint64_t wb, uint32_t p)
+{
+	return (uint32_t)(packed[wb + (p >> 5)] >> (62 - 2 * (p & 31))) & 3u;
+}
+
+// ---- Q1: (context, symbol) of every coded symbol, in stream order ---------------------------------
+// one wave per read.  key32 = ctx << sym_bits | sym ; byte family: bkey = ctx << 8 | byte
+__global__ __launch_bounds__(256) void k_qual_symbols(const QualCfg* __restrict__ cfgp, const uint64_t* __restrict__ packed,
+                                                     const uint64_t* __restrict__ word_off, const uint8_t* __restrict__ quals,
+                                                     const uint64_t* __restrict__ qoff, const uint8_t* __restrict__ flags,
+                                                     uint32_t r0, uint32_t r1, uint64_t q0,
+                                                     uint32_t* __restrict__ key, uint32_t* __restrict__ sidx_out, uint64_t* __restrict__ n_key,
+                                                     uint32_t* __restrict__ bkey, uint32_t* __restrict__ bsidx)
+{
+	__shared__ QualCfg cfg;
+	for (uint32_t i = threadIdx.x; i < sizeof(QualCfg) / 4; i += blockDim.x) ((uint32_t*)&cfg)[i] = ((const uint32_t*)cfgp)[i];
+	__syncthreads();
+	const uint32_t r = r0 + blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (r >= r1) return;
+	const uint32_t lane = threadIdx.x & 63;
+	const uint64_t qb = qoff[r]; const uint32_t len = (uint32_t)(qoff[r + 1] - qb);
+	const uint64_t wb = word_off[r];
+	const uint32_t navg = cfg.navg;
+	// position of this read's first symbol in the batch's symbol stream, and of its first per-base key
+	const uint64_t s_read = (qb - q0) + (uint64_t)(r - r0) * navg;
+	const uint64_t k_read = qb - q0;
+
+	if (navg)
+	{	// per-read averages: integer sums are exact, so sum/cnt in double equals the reference's accumulation
+		uint32_t sum[5] = { 0, 0, 0, 0, 0 }, cnt[5] = { 0, 0, 0, 0, 0 };
+		for (uint32_t i = lane; i < len; i += 64)
+		{
+			uint32_t q = quals[qb + i] - 33u;
+			uint32_t b = cfg.mode == QM_AVERAGE ? 0u : cfg.map_fwd[q];
+#pragma unroll
+			for (uint32_t t = 0; t < 5; ++t) if (b == t) { sum[t] += q; cnt[t] += 1; }
+		}
+#pragma unroll
+		for (uint32_t t = 0; t < 5; ++t) { sum[t] = wave_sum(sum[t]); cnt[t] = wave_sum(cnt[t]); }
+		if (lane == 0)
+		{
+			const uint64_t bo = (uint64_t)(r - r0) * navg;
+			if (cfg.mode == QM_AVERAGE)
+			{
+				double avg = (double)sum[0] / (double)len;            // quality_coder_impl.cpp:438-450 (0/0 -> NaN -> cast 0 on x86: len==0 unsupported)
+				uint32_t a = (uint32_t)(avg * 256), a1 = a >> 8, a2 = a & 0xff;
+				bkey[bo] = (0u << 8) | a1; bsidx[bo] = (uint32_t)s_read;
+				bkey[bo + 1] = ((640u + a1) << 8) | a2; bsidx[bo + 1] = (uint32_t)s_read + 1;
+			}
+			else
+			{
+				uint32_t ctx_p = 0;
+				for (uint32_t t = 0; t < cfg.n_bins; ++t)
+				{
+					double avg = cnt[t] ? (double)sum[t] / (double)cnt[t] : 0.0;
+					uint32_t a = (uint32_t)(avg * 256), a1 = a >> 8, a2 = a & 0xff;
+					bkey[bo + 2 * t] = ((t * 128u + ctx_p) << 8) | a1; bsidx[bo + 2 * t] = (uint32_t)(s_read + 2 * t);
+					bkey[bo + 2 * t + 1] = ((640u + a1) << 8) | a2; bsidx[bo + 2 * t + 1] = (uint32_t)(s_read + 2 * t + 1);
+					ctx_p = (uint32_t)avg;
+				}
+			}
+		}
+	}
+	if (cfg.mode == QM_AVERAGE || cfg.mode == QM_NONE) return;
+
+	const uint32_t sym_mask = (1u << cfg.bits_per_sym) - 1;
+	for (uint32_t i = lane; i < len; i += 64)
+	{
+		uint32_t qv = quals[qb + i] - 33u;
+		uint32_t sym = cfg.map_fwd[qv];
+		// history: context values of positions i-1 .. i-n (missing = all ones)
+		uint32_t hist = 0;
+		for (uint32_t t = 1; t <= cfg.n_ctx_sym; ++t)
+		{
+			uint32_t v = sym_mask;
+			if (i >= t)
+			{
+				uint32_t s = cfg.map_fwd[quals[qb + i - t] - 33u];
+				v = cfg.mode == QM_ORIGINAL ? cfg.quant[s] : s;
+			}
+			hist |= (v & sym_mask) << ((t - 1) * cfg.bits_per_sym);
+		}
+		uint32_t b0 = arena_base(packed, wb, i);
+		uint32_t bm1 = i > 0 ? arena_base(packed, wb, i - 1) : 0;
+		uint32_t bm2 = i > 1 ? arena_base(packed, wb, i - 2) : 0;
+		uint32_t bp1 = i + 1 < len ? arena_base(packed, wb, i + 1) : 0;
+		uint32_t bctx;
+		if (cfg.is_avg) bctx = (bm2 << 6) | (bm1 << 4) | (b0 << 2) | bp1;                       // :203-210
+		else if (cfg.is_thr) bctx = b0 | (bm1 << 2) | (bm2 << 4) | (bp1 << 6);                  // :323-339
+		else if (cfg.level == 3) bctx = b0 | (bm1 << 2) | (bm2 << 4) | (bp1 << 6);              // :88-108
+		else bctx = b0 | (bm1 << 2) | ((uint32_t)(i > 1 && bm2 == bm1) << 4) | (bp1 << 5);
+		uint32_t fl = 0;
+		if (cfg.level > 1 && flags) { uint8_t c = flags[qb + i]; fl = (c == 'M' ? 1u : 0u) | (c == 'A' ? 2u : 0u); }
+		uint32_t ctx = hist | (bctx << cfg.ctx_bits) | (fl << (cfg.ctx_bits + cfg.base_bits));
+		key[k_read + i] = (ctx << cfg.sym_bits) | sym;
+		sidx_out[k_read + i] = (uint32_t)(s_read + navg + i);
+	}
+}
+
+// ---- Q3: run bounds of every context in the sorted key array --------------------------------------
+__global__ void k_seg_bounds(const uint32_t* __restrict__ skey, uint64_t n, uint32_t shift, uint32_t* __restrict__ seg_start, uint32_t* __restrict__ seg_end)
+{
+	uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= n) return;
+	uint32_t c = skey[j] >> shift;
+	if (j == 0 || (skey[j - 1] >> shift) != c) seg_start[c] = (uint32_t)j;
+	if (j + 1 == n || (skey[j + 1] >> shift) != c) seg_end[c] = (uint32_t)j + 1;
+}
+
+__device__ inline uint64_t pack_triple(uint32_t cum, uint32_t freq, uint32_t tot) { return ((uint64_t)cum << 42) | ((uint64_t)freq << 21) | tot; }
+
+// ---- Q4a: model evolution for alphabets of <= 5 symbols: one wave per context ----------------------
+// 64 symbols per step: per-class ballots give every lane the number of earlier same-class symbols of the
+// step; the rescale instant follows from the total alone.
+template<uint32_t A>
+__global__ __launch_bounds__(256) void k_evolve_small(const uint32_t* __restrict__ skey, const uint32_t* __restrict__ sval,
+                                                     const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ seg_end,
+                                                     uint32_t n_ctx, uint32_t sym_bits, uint32_t max_total, uint32_t adder,
+                                                     uint32_t* __restrict__ state, uint64_t* __restrict__ trip)
+{
+	const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (c >= n_ctx) return;
+	const uint32_t s = seg_start[c], e = seg_end[c];
+	if (e <= s) return;
+	const uint32_t lane = threadIdx.x & 63;
+	const uint64_t lt = (1ULL << lane) - 1;
+	uint32_t st[A]; uint32_t tot;
+#pragma unroll
+	for (uint32_t a = 0; a < A; ++a) st[a] = state[(uint64_t)c * (A + 1) + a];
+	tot = state[(uint64_t)c * (A + 1) + A];
+	const uint32_t smask = (1u << sym_bits) - 1;
+	for (uint32_t j0 = s; j0 < e; j0 += 64)
+	{
+		const uint32_t j = j0 + lane;
+		const bool valid = j < e;
+		const uint32_t sym = valid ? (skey[j] & smask) : 0xffu;
+		const uint32_t dst = valid ? sval[j] : 0u;
+		uint64_t m[A];
+#pragma unroll
+		for (uint32_t a = 0; a < A; ++a) m[a] = __ballot(valid && sym == a);
+		const uint32_t cnt = (e - j0) < 64 ? (e - j0) : 64;
+		uint32_t start = 0;
+		while (start < cnt)
+		{
+			// number of updates the current state absorbs before a rescale: the r-th update makes total >= max_total
+			uint32_t r = (max_total - tot + adder - 1) / adder;
+			uint32_t now = (cnt - start) < r ? (cnt - start) : r;
+			uint64_t win = (now == 64 ? ~0ULL : ((1ULL << now) - 1)) << start;       // lanes [start, start+now)
+			if (lane >= start && lane < start + now)
+			{
+				uint64_t before = lt & win;
+				uint32_t cum = 0, freq = 0;
+#pragma unroll
+				for (uint32_t a = 0; a < A; ++a)
+				{
+					uint32_t v = st[a] + adder * (uint32_t)__popcll(m[a] & before);
+					if (a < sym) cum += v;
+					if (a == sym) freq = v;
+				}
+				trip[dst] = pack_triple(cum, freq, tot + adder * (lane - start));
+			}
+#pragma unroll
+			for (uint32_t a = 0; a < A; ++a) st[a] += adder * (uint32_t)__popcll(m[a] & win);
+			tot += adder * now;
+			while (tot >= max_total)                                                   // rc.h:233-244
+			{
+				tot = 0;
+#pragma unroll
+				for (uint32_t a = 0; a < A; ++a) { st[a] = (st[a] + 1) / 2; tot += st[a]; }
+			}
+			start += now;
+		}
+	}
+	if (lane == 0)
+	{
+#pragma unroll
+		for (uint32_t a = 0; a < A; ++a) state[(uint64_t)c * (A + 1) + a] = st[a];
+		state[(uint64_t)c * (A + 1) + A] = tot;
+	}
+}
+
+// ---- Q4b: model evolution for large alphabets (96 / 256): counters spread over the lanes, symbols taken
+// one at a time (cumulative = masked wave sum).  NS = counters per lane (2 for 96, 4 for 256).
+template<uint32_t NS>
+__global__ __launch_bounds__(256) void k_evolve_large(const uint32_t* __restrict__ skey, const uint32_t* __restrict__ sval,
+                                                     const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ seg_end,
+                                                     uint32_t n_ctx, uint32_t n_sym, uint32_t sym_bits, uint32_t max_total, uint32_t adder,
+                                                     uint32_t* __restrict__ state, uint64_t* __restrict__ trip)
+{
+	const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (c >= n_ctx) return;
+	const uint32_t s = seg_start[c], e = seg_end[c];
+	if (e <= s) return;
+	const uint32_t lane = threadIdx.x & 63;
+	uint32_t* sp = state + (uint64_t)c * (n_sym + 1);
+	uint32_t cn[NS];                                       // symbol a lives in lane a % 64, slot a / 64
+#pragma unroll
+	for (uint32_t t = 0; t < NS; ++t) { uint32_t a = t * 64 + lane; cn[t] = a < n_sym ? sp[a] : 0u; }
+	uint32_t tot = sp[n_sym];
+	const uint32_t smask = (1u << sym_bits) - 1;
+	for (uint32_t j0 = s; j0 < e; j0 += 64)
+	{
+		const uint32_t j = j0 + lane;
+		const bool valid = j < e;
+		const uint32_t my_sym = valid ? (skey[j] & smask) : 0u;
+		const uint32_t my_dst = valid ? sval[j] : 0u;
+		const uint32_t cnt = (e - j0) < 64 ? (e - j0) : 64;
+		uint32_t my_cum = 0, my_freq = 0, my_tot = 0;
+		for (uint32_t l = 0; l < cnt; ++l)
+		{
+			const uint32_t sym = __shfl(my_sym, l, 64);
+			const uint32_t slot = sym >> 6, ln = sym & 63;
+			uint32_t part = 0, mine = 0;
+#pragma unroll
+			for (uint32_t t = 0; t < NS; ++t)
+			{
+				if (t < slot) part += cn[t];
+				else if (t == slot) { if (lane < ln) part += cn[t]; mine = cn[t]; }
+			}
+			const uint32_t cum = wave_sum(part);
+			const uint32_t freq = __shfl(mine, ln, 64);
+			if (lane == l) { my_cum = cum; my_freq = freq; my_tot = tot; }
+#pragma unroll
+			for (uint32_t t = 0; t < NS; ++t) if (t == slot && lane == ln) cn[t] += adder;
+			tot += adder;
+			while (tot >= max_total)
+			{
+				uint32_t sum = 0;
+#pragma unroll
+				for (uint32_t t = 0; t < NS; ++t) { uint32_t a = t * 64 + lane; if (a < n_sym) { cn[t] = (cn[t] + 1) / 2; sum += cn[t]; } }
+				tot = wave_sum(sum);
+			}
+		}
+		if (valid) trip[my_dst] = pack_triple(my_cum, my_freq, my_tot);
+	}
+#pragma unroll
+	for (uint32_t t = 0; t < NS; ++t) { uint32_t a = t * 64 + lane; if (a < n_sym) sp[a] = cn[t]; }
+	if (lane == 0) sp[n_sym] = tot;
+}
+
+// ---- Q5: interval arithmetic, one lane per part (sub_rc.h:72-100,203-210) ---------------------------
+// range / tot with tot < 2^21: two exact double divisions (operands < 2^53) instead of a 64-bit divide.
+__device__ inline uint64_t div_u64_small(uint64_t x, uint32_t d)
+{
+	const double dd = (double)d;
+	uint32_t hi = (uint32_t)(x >> 32), lo = (uint32_t)x;
+	uint32_t q1 = (uint32_t)((double)hi / dd);            // hi < 2^32: exact operands
+	if ((uint64_t)q1 * d > hi) --q1;                      // guard the (unreachable for d < 2^21) round-up case
+	uint32_t r1 = hi - q1 * d;
+	if (r1 >= d) { ++q1; r1 -= d; }
+	uint64_t rest = ((uint64_t)r1 << 32) | lo;            // < d * 2^32 <= 2^53
+	uint64_t q2 = (uint64_t)((double)rest / dd);
+	// the double quotient of exactly representable operands is correctly rounded, truncation can be off by one
+	uint64_t prod = q2 * d;
+	if (prod > rest) { --q2; } else if (rest - prod >= d) { ++q2; }
+	return ((uint64_t)q1 << 32) + q2;
+}
+
+struct ByteSink {
+	uint8_t* p; uint64_t n; uint64_t acc; uint32_t fill; uint64_t cap; bool overflow;
+	__device__ inline void put(uint8_t b)
+	{
+		acc |= (uint64_t)b << (8 * fill);
+		if (++fill == 8)
+		{
+			if (n + 8 <= cap) *(uint64_t*)(p + n) = acc; else overflow = true;
+			n += 8; acc = 0; fill = 0;
+		}
+	}
+	__device__ inline void flush()
+	{
+		if (n + fill <= cap) { for (uint32_t i = 0; i < fill; ++i) p[n + i] = (uint8_t)(acc >> (8 * i)); } else overflow = true;
+		n += fill; fill = 0; acc = 0;
+	}
+};
+
+__global__ __launch_bounds__(64) void k_range_code(const uint64_t* __restrict__ trip, const uint64_t* __restrict__ part_sym_off, uint32_t n_parts,
+                                                  uint8_t* __restrict__ out, const uint64_t* __restrict__ part_out_off, uint64_t* __restrict__ part_size)
+{
+	const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= n_parts) return;
+	const uint64_t TOP = 0x00ffffffffffffULL, MASK = 0xff00000000000000ULL;
+	uint64_t low = 0, range = MASK;
+	ByteSink sink{ out + part_out_off[p], 0, 0, 0, part_out_off[p + 1] - part_out_off[p], false };
+	const uint64_t a = part_sym_off[p], b = part_sym_off[p + 1];
+	for (uint64_t i = a; i < b; ++i)
+	{
+		const uint64_t t = trip[i];
+		const uint32_t tot = (uint32_t)(t & 0x1fffff), freq = (uint32_t)((t >> 21) & 0x1fffff), cum = (uint32_t)(t >> 42);
+		range = div_u64_small(range, tot);
+		low += range * cum;
+		range *= freq;
+		while (range <= TOP)
+		{
+			if ((low ^ (low + range)) & MASK) { uint64_t r = low; range = (r | TOP) - r; }
+			sink.put((uint8_t)(low >> 56));
+			low <<= 8; range <<= 8;
+		}
+	}
+	for (int i = 0; i < 8; ++i) { sink.put((uint8_t)(low >> 56)); low <<= 8; }
+	sink.flush();
+	part_size[p] = sink.overflow ? ~0ULL : sink.n;
+}
+
+__global__ void k_gather_u64(const uint64_t* __restrict__ src, const uint32_t* __restrict__ idx, uint64_t n, uint64_t* __restrict__ dst)
+{ uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) dst[i] = src[idx[i]]; }
+__global__ void k_fill_u32(uint32_t* v, uint64_t n, uint32_t x) { uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) v[i] = x; }
+// state tables: counters 1, total = n_sym
+__global__ void k_init_state(uint32_t* st, uint64_t n_ctx, uint32_t n_sym)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_ctx * (n_sym + 1)) return;
+	st[i] = (i % (n_sym + 1)) == n_sym ? n_sym : 1u;
+}
+__global__ void k_gather_bytes(const uint8_t* __restrict__ src, const uint64_t* __restrict__ src_off, const uint64_t* __restrict__ dst_off,
+                               const uint64_t* __restrict__ size, uint8_t* __restrict__ dst)
+{
+	const uint32_t p = blockIdx.x;
+	const uint64_t n = size[p]; const uint8_t* s = src + src_off[p]; uint8_t* d = dst + dst_off[p];
+	for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
+}
+
+void fill_range(uint8_t* a, int lo, int hi, uint8_t v) { for (int i = lo; i < hi; ++i) a[i] = v; }
+} // namespace
+
+// CQualityCoder::Init (quality_coder.cpp:26-247): mode tables; adjust_quality_map_* (:250-525)
+extern "C" cl_status cl_qual_coder_create(cl_ctx* ctx, const cl_qual_params* prm, cl_qual_coder** out)
+{
+	if (!ctx || !prm || !out) return cl_fail(ctx, CL_E_INVALID, "cl_qual_coder_create: null argument");
+	if (prm->mode < 0 || prm->mode > QM_NONE || prm->source < 0 || prm->source > 2 || prm->level < 1 || prm->level > 3)
+		return cl_fail(ctx, CL_E_INVALID, "cl_qual_coder_create: mode 0..8, source 0..2, level 1..3");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	cl_qual_coder* Q = new cl_qual_coder(); Q->ctx = ctx;
+	std::unique_ptr<cl_qual_coder> guard(Q);
+	QualCfg& c = Q->cfg; memset(&c, 0, sizeof(c));
+	c.mode = prm->mode; c.level = prm->level;
+	c.max_total = 1u << 18; c.adder = 8;                                    // quality_coder.h:37-41
+	auto bins = [&](uint32_t n) -> cl_status {
+		if (prm->n_fwd != n - 1) return cl_fail(ctx, CL_E_INVALID, "cl_qual_coder_create: need " + std::to_string(n - 1) + " thresholds");
+		for (uint32_t i = 0; i + 1 < n - 1; ++i) if (prm->fwd[i] > prm->fwd[i + 1]) return cl_fail(ctx, CL_E_INVALID, "thresholds must ascend");
+		if (prm->fwd[n - 2] > 96) return cl_fail(ctx, CL_E_INVALID, "threshold > 96");
+		fill_range(c.map_fwd, 0, (int)prm->fwd[0], 0);
+		for (uint32_t b = 1; b + 1 < n; ++b) fill_range(c.map_fwd, (int)prm->fwd[b - 1], (int)prm->fwd[b], (uint8_t)b);
+		fill_range(c.map_fwd, (int)prm->fwd[n - 2], 96, (uint8_t)(n - 1));
+		c.n_bins = n; c.n_sym = n;
+		return CL_OK;
+	};
+	switch (prm->mode)
+	{
+	case QM_ORIGINAL:
+	{
+		for (int i = 0; i < 96; ++i) c.map_fwd[i] = (uint8_t)i;
+		static const int ont3[] = { 0, 1, 2, 4, 7, 11, 16, 22, 29, 37, 46, 56, 67, 79, 90, 96 };
+		static const int ont12[] = { 0, 1, 2, 5, 10, 15, 20, 25, 35, 50, 70, 96 };
+		static const int pb3[] = { 0, 1, 10, 20, 30, 39, 45, 51, 57, 63, 69, 75, 81, 87, 93, 94 };
+		static const int pb12[] = { 0, 1, 15, 29, 41, 53, 63, 72, 80, 87, 93, 94 };
+		const int* t; int n;
+		if (prm->source == 0) { if (prm->level == 3) { t = ont3; n = 15; } else { t = ont12; n = 11; } }
+		else { if (prm->level == 3) { t = pb3; n = 15; } else { t = pb12; n = 11; } }
+		for (int b = 0; b < n; ++b) fill_range(c.quant, t[b], t[b + 1], (uint8_t)b);
+		if (prm->source == 2) { for (int i = 0; i < 93; ++i) c.quant[i] += 1; c.quant[93] = 0; }
+		c.bits_per_sym = 4; c.n_ctx_sym = 2; c.n_sym = 96; c.max_total = 1u << 20; c.adder = 32;   // quality_coder.h:36
+		c.base_bits = prm->level == 3 ? 8 : 7;
+		break;
+	}
+	case QM_QUINARY_AVG: CL_TRY(bins(5)); c.bits_per_sym = 3; c.n_ctx_sym = 3; c.is_avg = 1; c.navg = 10; c.base_bits = 8; break;
+	case QM_QUAD_AVG: CL_TRY(bins(4)); c.bits_per_sym = 3; c.n_ctx_sym = 3; c.is_avg = 1; c.navg = 8; c.base_bits = 8; break;
+	case QM_BINARY_AVG: CL_TRY(bins(2)); c.bits_per_sym = 2; c.n_ctx_sym = 6; c.is_avg = 1; c.navg = 4; c.base_bits = 8; break;
+	case QM_QUINARY_THR: CL_TRY(bins(5)); c.bits_per_sym = 3; c.n_ctx_sym = 3; c.is_thr = 1; c.base_bits = 8; break;
+	case QM_QUAD_THR: CL_TRY(bins(4)); c.bits_per_sym = 3; c.n_ctx_sym = 3; c.is_thr = 1; c.base_bits = 8; break;
+	case QM_BINARY_THR: CL_TRY(bins(2)); c.bits_per_sym = 2; c.n_ctx_sym = 6; c.is_thr = 1; c.base_bits = 8; break;
+	case QM_AVERAGE: c.navg = 2; c.n_sym = 2; break;
+	case QM_NONE: c.n_sym = 2; break;
+	}
+	c.ctx_bits = c.bits_per_sym * c.n_ctx_sym;
+	c.sym_bits = 1; while ((1u << c.sym_bits) < c.n_sym) ++c.sym_bits;
+	uint32_t total_ctx_bits = c.ctx_bits + c.base_bits + (c.level > 1 ? 2 : 0);
+	if (total_ctx_bits + c.sym_bits > 32) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_qual_coder_create: context does not fit 32-bit keys");
+	c.n_ctx = (c.mode == QM_AVERAGE || c.mode == QM_NONE) ? 1u : (1u << total_ctx_bits);
+	DEV_ALLOC(ctx, Q->d_cfg, 1);
+	HIP_TRY(ctx, hipMemcpyAsync(Q->d_cfg.p, &c, sizeof(c), hipMemcpyHostToDevice, ctx->stream));
+	DEV_ALLOC(ctx, Q->state, (uint64_t)c.n_ctx * (c.n_sym + 1));
+	LAUNCH(ctx, k_init_state, grid_for((uint64_t)c.n_ctx * (c.n_sym + 1), 256), 256, Q->state.p, (uint64_t)c.n_ctx, c.n_sym);
+	DEV_ALLOC(ctx, Q->bstate, (uint64_t)BYTE_CTX * 257);
+	LAUNCH(ctx, k_init_state, grid_for((uint64_t)BYTE_CTX * 257, 256), 256, Q->bstate.p, (uint64_t)BYTE_CTX, 256u);
+	HIP_TRY(ctx, hipGetLastError());
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	*out = guard.release();
+	return CL_OK;
+}
+extern "C" void cl_qual_coder_free(cl_qual_coder* q) { delete q; }
+
+// CEntrComprQuals::Compress for a batch of whole parts (entr_qual.h:100-135).  Models persist across calls.
+extern "C" cl_status cl_qual_encode(cl_ctx* ctx, cl_qual_coder* Q, const cl_reads* R, const uint8_t* d_quals, const uint64_t* d_qual_off,
+                                    const uint8_t* d_flags, const uint32_t* h_part_bounds, uint32_t n_parts,
+                                    uint8_t* d_out, uint64_t cap, uint64_t* h_part_sizes, uint64_t* n_out)
+{
+	if (!ctx || !Q || !R || !d_qual_off || !h_part_bounds || !h_part_sizes || !n_out) return cl_fail(ctx, CL_E_INVALID, "cl_qual_encode: null argument");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	const QualCfg& c = Q->cfg;
+	for (uint32_t p = 0; p < n_parts; ++p) if (h_part_bounds[p] > h_part_bounds[p + 1]) return cl_fail(ctx, CL_E_INVALID, "cl_qual_encode: part bounds must ascend");
+	if (n_parts && h_part_bounds[n_parts] > R->n_reads) return cl_fail(ctx, CL_E_INVALID, "cl_qual_encode: part bound beyond the arena");
+	*n_out = 0;
+	if (!n_parts) return CL_OK;
+	if (c.mode == QM_NONE)
+	{	// nothing is coded: every part is the 8 flush bytes of an untouched coder (zeros)
+		if (cap < 8ull * n_parts) { *n_out = 8ull * n_parts; return cl_fail(ctx, CL_E_CAPACITY, "cl_qual_encode: output capacity"); }
+		HIP_TRY(ctx, hipMemsetAsync(d_out, 0, 8ull * n_parts, ctx->stream));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		for (uint32_t p = 0; p < n_parts; ++p) h_part_sizes[p] = 8;
+		*n_out = 8ull * n_parts;
+		return CL_OK;
+	}
+	// host copy of the quality offsets at part boundaries
+	std::vector<uint64_t> qo(n_parts + 1);
+	{
+		DevBuf<uint32_t> d_pb; DEV_ALLOC(ctx, d_pb, (uint64_t)n_parts + 1);
+		DevBuf<uint64_t> d_qo; DEV_ALLOC(ctx, d_qo, (uint64_t)n_parts + 1);
+		HIP_TRY(ctx, hipMemcpyAsync(d_pb.p, h_part_bounds, ((uint64_t)n_parts + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+		LAUNCH(ctx, k_gather_u64, grid_for((uint64_t)n_parts + 1, 256), 256, d_qual_off, (const uint32_t*)d_pb.p, (uint64_t)n_parts + 1, d_qo.p);
+		HIP_TRY(ctx, hipMemcpyAsync(qo.data(), d_qo.p, ((uint64_t)n_parts + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	}
+	const uint32_t bits_max = c.max_total == (1u << 20) ? 20 : 18;
+	uint64_t written = 0;
+	// process groups of parts so that one group's symbol stream stays below 2^31
+	const uint64_t GROUP_SYMS = 1ull << 29;
+	uint32_t p0 = 0;
+	while (p0 < n_parts)
+	{
+		uint32_t p1 = p0 + 1;
+		auto syms_of = [&](uint32_t a, uint32_t b) { return (qo[b] - qo[a]) + (uint64_t)(h_part_bounds[b] - h_part_bounds[a]) * c.navg; };
+		while (p1 < n_parts && syms_of(p0, p1 + 1) <= GROUP_SYMS) ++p1;
+		const uint32_t r0 = h_part_bounds[p0], r1 = h_part_bounds[p1];
+		const uint64_t n_base = qo[p1] - qo[p0], n_syms = syms_of(p0, p1), n_byte = (uint64_t)(r1 - r0) * c.navg;
+		if (n_syms >= (1ull << 32)) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_qual_encode: a single part has >= 2^32 symbols");
+		const uint32_t np = p1 - p0;
+		DevBuf<uint64_t> trip; DEV_ALLOC(ctx, trip, n_syms);
+		const bool per_base = !(c.mode == QM_AVERAGE);
+		{
+			DevBuf<uint32_t> key, sidx, bkey, bsidx;
+			DEV_ALLOC(ctx, key, per_base ? n_base : 0); DEV_ALLOC(ctx, sidx, per_base ? n_base : 0);
+			DEV_ALLOC(ctx, bkey, n_byte); DEV_ALLOC(ctx, bsidx, n_byte);
+			if (r1 > r0)
+				LAUNCH(ctx, k_qual_symbols, grid_for(r1 - r0, 4), 256, (const QualCfg*)Q->d_cfg.p, (const uint64_t*)R->packed.p, (const uint64_t*)R->word_off.p,
+					d_quals, d_qual_off, d_flags, r0, r1, qo[p0], key.p, sidx.p, (uint64_t*)nullptr, bkey.p, bsidx.p);
+			HIP_TRY(ctx, hipGetLastError());
+			const uint32_t total_ctx_bits = c.ctx_bits + c.base_bits + (c.level > 1 ? 2 : 0);
+			if (per_base && n_base)
+			{
+				CL_TRY(dev_sort_keys32_pairs(ctx, key.p, sidx.p, n_base, c.sym_bits, c.sym_bits + total_ctx_bits));
+				DevBuf<uint32_t> ss, se; DEV_ALLOC(ctx, ss, c.n_ctx); DEV_ALLOC(ctx, se, c.n_ctx);
+				HIP_TRY(ctx, hipMemsetAsync(ss.p, 0, (uint64_t)c.n_ctx * 4, ctx->stream));
+				HIP_TRY(ctx, hipMemsetAsync(se.p, 0, (uint64_t)c.n_ctx * 4, ctx->stream));
+				LAUNCH(ctx, k_seg_bounds, grid_for(n_base, 256), 256, (const uint32_t*)key.p, n_base, c.sym_bits, ss.p, se.p);
+				const uint32_t g = grid_for(c.n_ctx, 4);
+				switch (c.n_sym)
+				{
+				case 2: LAUNCH(ctx, (k_evolve_small<2>), g, 256, (const uint32_t*)key.p, (const uint32_t*)sidx.p, (const uint32_t*)ss.p, (const uint32_t*)se.p, c.n_ctx, c.sym_bits, c.max_total, c.adder, Q->state.p, trip.p); break;
+				case 4: LAUNCH(ctx, (k_evolve_small<4>), g, 256, (const uint32_t*)key.p, (const uint32_t*)sidx.p, (const uint32_t*)ss.p, (const uint32_t*)se.p, c.n_ctx, c.sym_bits, c.max_total, c.adder, Q->state.p, trip.p); break;
+				case 5: LAUNCH(ctx, (k_evolve_small<5>), g, 256, (const uint32_t*)key.p, (const uint32_t*)sidx.p, (const uint32_t*)ss.p, (const uint32_t*)se.p, c.n_ctx, c.sym_bits, c.max_total, c.adder, Q->state.p, trip.p); break;
+				default: LAUNCH(ctx, (k_evolve_large<2>), g, 256, (const uint32_t*)key.p, (const uint32_t*)sidx.p, (const uint32_t*)ss.p, (const uint32_t*)se.p, c.n_ctx, c.n_sym, c.sym_bits, c.max_total, c.adder, Q->state.p, trip.p); break;
+				}
+				HIP_TRY(ctx, hipGetLastError());
+				HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+			}
+			if (n_byte)
+			{
+				CL_TRY(dev_sort_keys32_pairs(ctx, bkey.p, bsidx.p, n_byte, 8, 8 + 10));
+				DevBuf<uint32_t> ss, se; DEV_ALLOC(ctx, ss, BYTE_CTX); DEV_ALLOC(ctx, se, BYTE_CTX);
+				HIP_TRY(ctx, hipMemsetAsync(ss.p, 0, BYTE_CTX * 4, ctx->stream));
+				HIP_TRY(ctx, hipMemsetAsync(se.p, 0, BYTE_CTX * 4, ctx->stream));
+				LAUNCH(ctx, k_seg_bounds, grid_for(n_byte, 256), 256, (const uint32_t*)bkey.p, n_byte, 8u, ss.p, se.p);
+				LAUNCH(ctx, (k_evolve_large<4>), grid_for(BYTE_CTX, 4), 256, (const uint32_t*)bkey.p, (const uint32_t*)bsidx.p, (const uint32_t*)ss.p, (const uint32_t*)se.p,
+					BYTE_CTX, 256u, 8u, 1u << 18, 8u, Q->bstate.p, trip.p);
+				HIP_TRY(ctx, hipGetLastError());
+				HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+			}
+		}
+		// range coding: worst case bits_max bits per symbol + 8 flush bytes, rounded to 8-byte aligned regions
+		std::vector<uint64_t> sym_off(np + 1), out_off(np + 1);
+		sym_off[0] = 0; out_off[0] = 0;
+		for (uint32_t p = 0; p < np; ++p)
+		{
+			uint64_t s = syms_of(p0 + p, p0 + p + 1);
+			sym_off[p + 1] = sym_off[p] + s;
+			out_off[p + 1] = out_off[p] + ((s * bits_max + 7) / 8 + s / 16 + 64 + 7) / 8 * 8;
+		}
+		DevBuf<uint8_t> tmp; DEV_ALLOC(ctx, tmp, out_off[np]);
+		DevBuf<uint64_t> d_sym_off, d_out_off, d_size, d_dst_off;
+		DEV_ALLOC(ctx, d_sym_off, np + 1); DEV_ALLOC(ctx, d_out_off, np + 1); DEV_ALLOC(ctx, d_size, np); DEV_ALLOC(ctx, d_dst_off, np);
+		HIP_TRY(ctx, hipMemcpyAsync(d_sym_off.p, sym_off.data(), (np + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(ctx, hipMemcpyAsync(d_out_off.p, out_off.data(), (np + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+		LAUNCH(ctx, k_range_code, grid_for(np, 64), 64, (const uint64_t*)trip.p, (const uint64_t*)d_sym_off.p, np, tmp.p, (const uint64_t*)d_out_off.p, d_size.p);
+		HIP_TRY(ctx, hipGetLastError());
+		HIP_TRY(ctx, hipMemcpyAsync(h_part_sizes + p0, d_size.p, np * 8, hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		for (uint32_t p = 0; p < np; ++p) if (h_part_sizes[p0 + p] == ~0ULL)
+			return cl_fail(ctx, CL_E_CAPACITY, "cl_qual_encode: internal part buffer overflow (pathological interval clamping)");
+		std::vector<uint64_t> dst_off(np);
+		uint64_t w = written;
+		for (uint32_t p = 0; p < np; ++p) { dst_off[p] = w; w += h_part_sizes[p0 + p]; }
+		if (w > cap) { *n_out = w; return cl_fail(ctx, CL_E_CAPACITY, "cl_qual_encode: output capacity " + std::to_string(cap) + " too small"); }
+		HIP_TRY(ctx, hipMemcpyAsync(d_dst_off.p, dst_off.data(), np * 8, hipMemcpyHostToDevice, ctx->stream));
+		LAUNCH(ctx, k_gather_bytes, np, 256, (const uint8_t*)tmp.p, (const uint64_t*)d_out_off.p, (const uint64_t*)d_dst_off.p, (const uint64_t*)d_size.p, d_out);
+		HIP_TRY(ctx, hipGetLastError());
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		written = w;
+		Q->symbols_coded += n_syms;
+		p0 = p1;
+	}
+	cl_timing_collect(ctx);
+	*n_out = written;
+	return CL_OK;
+}

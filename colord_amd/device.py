@@ -183,6 +183,19 @@ class Context:
                                                    common.data_ptr(), need.value, C.byref(need)))
         return off, common[:need.value]
 
+    # ---- a13 + a15 ----
+    def qual_coder(self, mode: int, source: int, level: int, fwd=(), rev=()) -> "QualCoder":
+        prm = N.QualParams()
+        prm.mode, prm.source, prm.level = mode, source, level
+        prm.n_fwd, prm.n_rev = len(fwd), len(rev)
+        for i, v in enumerate(fwd):
+            prm.fwd[i] = v
+        for i, v in enumerate(rev):
+            prm.rev[i] = v
+        h = N._P()
+        _check(self, self.lib.cl_qual_coder_create(self.h, C.byref(prm), C.byref(h)))
+        return QualCoder(self, h)
+
     def sort_u64(self, keys: torch.Tensor, vals: torch.Tensor | None = None, begin_bit=0, end_bit=64):
         if vals is None:
             _check(self, self.lib.cl_sort_u64(self.h, keys.data_ptr(), keys.numel(), begin_bit, end_bit))
@@ -266,3 +279,25 @@ class Index(_Obj):
     def n_refs(self): return self.ctx.lib.cl_index_n_refs(self.h)
     @property
     def entries(self): return self.ctx.lib.cl_index_entries(self.h)
+
+
+class QualCoder(_Obj):
+    _free = "cl_qual_coder_free"
+
+    def encode(self, reads: "Reads", quals: torch.Tensor, qual_off: torch.Tensor, part_bounds, flags: torch.Tensor | None = None):
+        """Returns (payload bytes tensor on device, list of part sizes)."""
+        ctx = self.ctx
+        pb = np.ascontiguousarray(part_bounds, dtype=np.uint32)
+        n_parts = len(pb) - 1
+        sizes = np.zeros(max(n_parts, 1), np.uint64)
+        cap = max(1024, int(quals.numel() * 0.6) + 64 * n_parts)
+        while True:
+            out = torch.empty(cap, dtype=torch.uint8, device=ctx.device)
+            n = C.c_uint64(0)
+            st = ctx.lib.cl_qual_encode(ctx.h, self.h, reads.h, quals.data_ptr(), qual_off.data_ptr(),
+                                        None if flags is None else flags.data_ptr(), pb.ctypes.data, n_parts,
+                                        out.data_ptr(), cap, sizes.ctypes.data, C.byref(n))
+            if st == N.CL_E_CAPACITY and n.value > cap:
+                raise N.ColordHipError(st, "qual output capacity exceeded after models advanced; retry with a larger cap")
+            _check(ctx, st)
+            return out[:n.value], [int(x) for x in sizes[:n_parts]]

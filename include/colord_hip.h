@@ -155,6 +155,31 @@ cl_status cl_candidates_common(cl_ctx* ctx, const cl_index* ix, const cl_kmer_li
                                const uint32_t* d_refs, const uint32_t* d_n,
                                uint64_t* d_common_off, uint64_t* d_common, uint64_t cap, uint64_t* n_common);
 
+/* ---- a13 + a15 + a16: CQualityCoder / CEntrComprQuals (quality_coder.{h,cpp}, quality_coder_impl.cpp,
+ *      entr_qual.h:100-135; range coder sub_rc.h:44-212; models rc.h) ---------------------------------- */
+typedef struct cl_qual_coder cl_qual_coder;
+typedef struct {
+	int32_t mode;        /* QualityComprMode (params.h:33-43): 0 org, 1 5-avg, 2 4-avg, 3 2-avg, 4 5-fix, 5 4-fix, 6 2-fix, 7 avg, 8 none */
+	int32_t source;      /* DataSource: 0 ONT, 1 PBRaw, 2 PBHiFi */
+	int32_t level;       /* compression level 1..3 */
+	uint32_t n_fwd;      /* -T thresholds (bins - 1 values) */
+	uint32_t fwd[8];
+	uint32_t n_rev;      /* -D representatives (decoder side only; carried for completeness) */
+	uint32_t rev[8];
+} cl_qual_params;
+/* CQualityCoder::Init(true, ...): one adaptive model set that persists across cl_qual_encode calls. */
+cl_status cl_qual_coder_create(cl_ctx* ctx, const cl_qual_params* params, cl_qual_coder** out);
+void cl_qual_coder_free(cl_qual_coder* q);
+/* CEntrComprQuals::Compress for a batch of whole parts.  Reads [h_part_bounds[p], h_part_bounds[p+1]) of the
+ * arena form part p (the reference cuts parts where sum(len+1) >= 4 Mi, in_reads.cpp:62-77; any cut at read
+ * boundaries yields a valid archive).  d_quals: ASCII quality bytes, d_qual_off: n_reads+1 offsets into it
+ * (read i has the same length as in the arena).  d_flags (level > 1 only, else NULL): per-base class bytes
+ * 'A' / 'M' / other (quality_coder_impl.cpp:25-75), same offsets.  Output: part payloads back to back in
+ * d_out (capacity cap), h_part_sizes[n_parts]; *n_out = total bytes. */
+cl_status cl_qual_encode(cl_ctx* ctx, cl_qual_coder* q, const cl_reads* reads, const uint8_t* d_quals, const uint64_t* d_qual_off,
+                         const uint8_t* d_flags, const uint32_t* h_part_bounds, uint32_t n_parts,
+                         uint8_t* d_out, uint64_t cap, uint64_t* h_part_sizes, uint64_t* n_out);
+
 /* ---- a7: CReferenceReads (reference_reads.h:27-259) ---------------------------------------------- */
 /* Byte image of one stored reference read (4 bases/byte MSB first + trailing count byte) produced from
  * the arena; h_out needs (len+3)/4+1 bytes.  Used by the parity tests and by the host archive code. */
