@@ -70,7 +70,8 @@ __global__ __launch_bounds__(256) void k_qual_symbols(const QualCfg* __restrict_
 	const uint64_t wb = word_off[r];
 	const uint32_t navg = cfg.navg;
 	// position of this read's first symbol in the batch's symbol stream, and of its first per-base key
-	const uint64_t s_read = (qb - q0) + (uint64_t)(r - r0) * navg;
+	const bool per_base = !(cfg.mode == QM_AVERAGE || cfg.mode == QM_NONE);     // 'avg' codes two bytes per read and nothing per base
+	const uint64_t s_read = (per_base ? (qb - q0) : 0) + (uint64_t)(r - r0) * navg;
 	const uint64_t k_read = qb - q0;
 
 	if (navg)
@@ -335,6 +336,7 @@ __global__ __launch_bounds__(64) void k_range_code(const uint64_t* __restrict__ 
 	{
 		const uint64_t t = trip[i];
 		const uint32_t tot = (uint32_t)(t & 0x1fffff), freq = (uint32_t)((t >> 21) & 0x1fffff), cum = (uint32_t)(t >> 42);
+		if (freq == 0 || tot == 0 || cum + freq > tot) { sink.overflow = true; break; }   // never happens with valid triples; guards against a hang
 		range = div_u64_small(range, tot);
 		low += range * cum;
 		range *= freq;
@@ -477,14 +479,14 @@ extern "C" cl_status cl_qual_encode(cl_ctx* ctx, cl_qual_coder* Q, const cl_read
 	while (p0 < n_parts)
 	{
 		uint32_t p1 = p0 + 1;
-		auto syms_of = [&](uint32_t a, uint32_t b) { return (qo[b] - qo[a]) + (uint64_t)(h_part_bounds[b] - h_part_bounds[a]) * c.navg; };
+		const bool per_base = !(c.mode == QM_AVERAGE);
+		auto syms_of = [&](uint32_t a, uint32_t b) { return (per_base ? (qo[b] - qo[a]) : 0) + (uint64_t)(h_part_bounds[b] - h_part_bounds[a]) * c.navg; };
 		while (p1 < n_parts && syms_of(p0, p1 + 1) <= GROUP_SYMS) ++p1;
 		const uint32_t r0 = h_part_bounds[p0], r1 = h_part_bounds[p1];
 		const uint64_t n_base = qo[p1] - qo[p0], n_syms = syms_of(p0, p1), n_byte = (uint64_t)(r1 - r0) * c.navg;
 		if (n_syms >= (1ull << 32)) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_qual_encode: a single part has >= 2^32 symbols");
 		const uint32_t np = p1 - p0;
 		DevBuf<uint64_t> trip; DEV_ALLOC(ctx, trip, n_syms);
-		const bool per_base = !(c.mode == QM_AVERAGE);
 		{
 			DevBuf<uint32_t> key, sidx, bkey, bsidx;
 			DEV_ALLOC(ctx, key, per_base ? n_base : 0); DEV_ALLOC(ctx, sidx, per_base ? n_base : 0);
