@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--coverage", type=float, default=16.7, help="genome = total bases / coverage (50 Gbases over 3 Gb)")
     ap.add_argument("--k", type=int, default=25)           # compression.cpp:84-88 for a 50 Gbase input
     ap.add_argument("--cpu-sample-bases", type=float, default=1.5e8)
+    XX
+    ap.add_argument("--no-qual", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -56,7 +58,23 @@ class StepTimes:
         self.launches = {n: v[1] for n, v in ctx.acc.items()}
 
 
-def hot_path_step(ctx, reads, k):
+def reference_part_bounds(lengths: np.ndarray, pack_symbols: int) -> np.ndarray:
+    """Greedy part cut of the reference reader: a pack closes once sum(len+1) >= pack_symbols (in_reads.cpp:62-77)."""
+    acc = np.cumsum(lengths.astype(np.int64) + 1)
+    bounds = [0]
+    base = 0
+    while True:
+        i = int(np.searchsorted(acc, base + pack_symbols, side="left"))
+        if i >= len(acc):
+            break
+        bounds.append(i + 1)
+        base = int(acc[i])
+    if bounds[-1] != len(lengths):
+        bounds.append(len(lengths))
+    return np.asarray(bounds, dtype=np.uint32)
+
+
+def hot_path_step(ctx, reads, k, quals=None, qual_off=None, part_bounds=None):
     """One pass of the stages built so far (single- or multi-GPU).  Returns sizes for reporting."""
     from colord_amd import parallel as par
     p = PRESET
@@ -88,6 +106,13 @@ def hot_path_step(ctx, reads, k):
     crefs, votes, cnt = ctx.candidates(index, lists, p["c"])
     out = dict(survivors=n_surv, tot_kmers=tot_kmers, kept=kset.size, accepted=lists.total, refs=n_refs_total,
                index_entries=index.entries, with_candidates=int((cnt > 0).sum().item()))
+    if quals is not None:
+        # a13+a15: quality stream, ONT default 4-avg at level 1 (contexts do not need the edit script at level 1).
+        # One model domain per GPU (the adaptive models live for the whole shard), parts cut like the reference's packs.
+        qc = ctx.qual_coder(2, 0, 1, (7, 14, 26), ())
+        payload, sizes = qc.encode(reads, quals, qual_off, part_bounds)
+        qc.free()
+        out.update(qual_bytes=int(payload.numel()), qual_parts=len(sizes))
     index.free(); lists.free(); kset.free()
     return out
 
@@ -141,6 +166,9 @@ def main():
     reads = ctx.pack_reads(codes, offsets)
     local_bases = reads.total_bases
     del codes
+    qual_off = offsets.contiguous()
+    part_bounds = reference_part_bounds(reads.lengths().cpu().numpy().view(np.uint32), args.pack_symbols)
+    qargs = {} if args.no_qual else dict(quals=quals, qual_off=qual_off, part_bounds=part_bounds)
 
     def sync():
         torch.cuda.synchronize()
@@ -149,13 +177,13 @@ def main():
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        hot_path_step(ctx, reads, args.k)
+        hot_path_step(ctx, reads, args.k, **qargs)
     ctx.acc.clear()
     sync()
     t0 = time.perf_counter()
     info = None
     for _ in range(args.steps):
-        info = hot_path_step(ctx, reads, args.k)
+        info = hot_path_step(ctx, reads, args.k, **qargs)
     sync()
     dt = time.perf_counter() - t0
     tdev = torch.tensor([dt], dtype=torch.float64, device=ctx.device)
@@ -197,8 +225,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"synthetic ONT, {local_bases} bases/GPU ({n_reads_local} reads, N50~20kb), genome {genome_len} bp, "
                                    f"k={args.k} f={PRESET['f']} ci={PRESET['ci']} cs={PRESET['cs']} c={PRESET['c']} (ONT default preset)",
-                       "stages": "a1 k-mer scan, a2 count/filter, a3 set build, a4 accepted k-mers, a6 acceptor, a5 index+candidates; "
-                                 "a8-a15 (anchors, edit scripts, DNA/quality coders) not yet on GPU, not timed",
+                       "stages": "a1 k-mer scan, a2 count/filter, a3 set build, a4 accepted k-mers, a6 acceptor, a5 index+candidates"
+                                 + ("" if args.no_qual else f", a13+a15 quality stream (4-avg, level 1, parts of {args.pack_symbols} symbols)")
+                                 + "; a8-a12 + a14 (anchors, edit scripts, DNA coder) not yet on GPU, not timed",
                        "parallelism": f"reads sharded x{world}, k-mer set replicated" if world > 1 else "single GPU",
                        "sizes": info},
             "roofline": roof, "cpu_baseline": cb,

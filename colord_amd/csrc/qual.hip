@@ -14,6 +14,7 @@
 // per part (entr_qual.h:68-79), so one lane codes one part and all parts of a batch run concurrently.
 #include "common.hpp"
 #include "objects.hpp"
+#include "rc_dev.hpp"
 #include <algorithm>
 
 namespace {
@@ -56,8 +57,8 @@ __device__ inline uint32_t arena_base(const uint64_t* __restrict__ packed, uint6
 __global__ __launch_bounds__(256) void k_qual_symbols(const QualCfg* __restrict__ cfgp, const uint64_t* __restrict__ packed,
                                                      const uint64_t* __restrict__ word_off, const uint8_t* __restrict__ quals,
                                                      const uint64_t* __restrict__ qoff, const uint8_t* __restrict__ flags,
-                                                     uint32_t r0, uint32_t r1, uint64_t q0,
-                                                     uint32_t* __restrict__ key, uint32_t* __restrict__ sidx_out, uint64_t* __restrict__ n_key,
+                                                     uint32_t r0, uint32_t r1, uint64_t q0, TripLayoutDev lay,
+                                                     uint32_t* __restrict__ key, uint32_t* __restrict__ sidx_out,
                                                      uint32_t* __restrict__ bkey, uint32_t* __restrict__ bsidx)
 {
 	__shared__ QualCfg cfg;
@@ -73,6 +74,7 @@ __global__ __launch_bounds__(256) void k_qual_symbols(const QualCfg* __restrict_
 	const bool per_base = !(cfg.mode == QM_AVERAGE || cfg.mode == QM_NONE);     // 'avg' codes two bytes per read and nothing per base
 	const uint64_t s_read = (per_base ? (qb - q0) : 0) + (uint64_t)(r - r0) * navg;
 	const uint64_t k_read = qb - q0;
+	const uint32_t part = part_of_read(lay, r);
 
 	if (navg)
 	{	// per-read averages: integer sums are exact, so sum/cnt in double equals the reference's accumulation
@@ -93,8 +95,8 @@ __global__ __launch_bounds__(256) void k_qual_symbols(const QualCfg* __restrict_
 			{
 				double avg = (double)sum[0] / (double)len;            // quality_coder_impl.cpp:438-450 (0/0 -> NaN -> cast 0 on x86: len==0 unsupported)
 				uint32_t a = (uint32_t)(avg * 256), a1 = a >> 8, a2 = a & 0xff;
-				bkey[bo] = (0u << 8) | a1; bsidx[bo] = (uint32_t)s_read;
-				bkey[bo + 1] = ((640u + a1) << 8) | a2; bsidx[bo + 1] = (uint32_t)s_read + 1;
+				bkey[bo] = (0u << 8) | a1; bsidx[bo] = trip_index(lay, part, s_read);
+				bkey[bo + 1] = ((640u + a1) << 8) | a2; bsidx[bo + 1] = trip_index(lay, part, s_read + 1);
 			}
 			else
 			{
@@ -103,8 +105,8 @@ __global__ __launch_bounds__(256) void k_qual_symbols(const QualCfg* __restrict_
 				{
 					double avg = cnt[t] ? (double)sum[t] / (double)cnt[t] : 0.0;
 					uint32_t a = (uint32_t)(avg * 256), a1 = a >> 8, a2 = a & 0xff;
-					bkey[bo + 2 * t] = ((t * 128u + ctx_p) << 8) | a1; bsidx[bo + 2 * t] = (uint32_t)(s_read + 2 * t);
-					bkey[bo + 2 * t + 1] = ((640u + a1) << 8) | a2; bsidx[bo + 2 * t + 1] = (uint32_t)(s_read + 2 * t + 1);
+					bkey[bo + 2 * t] = ((t * 128u + ctx_p) << 8) | a1; bsidx[bo + 2 * t] = trip_index(lay, part, s_read + 2 * t);
+					bkey[bo + 2 * t + 1] = ((640u + a1) << 8) | a2; bsidx[bo + 2 * t + 1] = trip_index(lay, part, s_read + 2 * t + 1);
 					ctx_p = (uint32_t)avg;
 				}
 			}
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(256) void k_qual_symbols(const QualCfg* __restrict_
 		if (cfg.level > 1 && flags) { uint8_t c = flags[qb + i]; fl = (c == 'M' ? 1u : 0u) | (c == 'A' ? 2u : 0u); }
 		uint32_t ctx = hist | (bctx << cfg.ctx_bits) | (fl << (cfg.ctx_bits + cfg.base_bits));
 		key[k_read + i] = (ctx << cfg.sym_bits) | sym;
-		sidx_out[k_read + i] = (uint32_t)(s_read + navg + i);
+		sidx_out[k_read + i] = trip_index(lay, part, s_read + navg + i);
 	}
 }
 
@@ -156,8 +158,6 @@ __global__ void k_seg_bounds(const uint32_t* __restrict__ skey, uint64_t n, uint
 	if (j + 1 == n || (skey[j + 1] >> shift) != c) seg_end[c] = (uint32_t)j + 1;
 }
 
-__device__ inline uint64_t pack_triple(uint32_t cum, uint32_t freq, uint32_t tot) { return ((uint64_t)cum << 42) | ((uint64_t)freq << 21) | tot; }
-
 // ---- Q4a: model evolution for alphabets of <= 5 symbols: one wave per context ----------------------
 // 64 symbols per step: per-class ballots give every lane the number of earlier same-class symbols of the
 // step; the rescale instant follows from the total alone.
@@ -165,7 +165,7 @@ template<uint32_t A>
 __global__ __launch_bounds__(256) void k_evolve_small(const uint32_t* __restrict__ skey, const uint32_t* __restrict__ sval,
                                                      const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ seg_end,
                                                      uint32_t n_ctx, uint32_t sym_bits, uint32_t max_total, uint32_t adder,
-                                                     uint32_t* __restrict__ state, uint64_t* __restrict__ trip)
+                                                     uint32_t* __restrict__ state, triple_t* __restrict__ trip)
 {
 	const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6);
 	if (c >= n_ctx) return;
@@ -228,128 +228,76 @@ __global__ __launch_bounds__(256) void k_evolve_small(const uint32_t* __restrict
 	}
 }
 
-// ---- Q4b: model evolution for large alphabets (96 / 256): counters spread over the lanes, symbols taken
-// one at a time (cumulative = masked wave sum).  NS = counters per lane (2 for 96, 4 for 256).
-template<uint32_t NS>
+// ---- Q4b: model evolution for large alphabets (96 / 256 symbols): one wave per context, counters and
+// their exclusive prefix in LDS, 64 symbols per step.  Inside a step lane l needs, besides the table
+// values, the number of earlier lanes of the step with a smaller / an equal symbol (uniform readlane loop).
 __global__ __launch_bounds__(256) void k_evolve_large(const uint32_t* __restrict__ skey, const uint32_t* __restrict__ sval,
                                                      const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ seg_end,
                                                      uint32_t n_ctx, uint32_t n_sym, uint32_t sym_bits, uint32_t max_total, uint32_t adder,
-                                                     uint32_t* __restrict__ state, uint64_t* __restrict__ trip)
+                                                     uint32_t* __restrict__ state, triple_t* __restrict__ trip)
 {
-	const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6);
+	__shared__ uint32_t s_cnt[4][256];
+	__shared__ uint32_t s_pre[4][256];
+	const uint32_t w = threadIdx.x >> 6;
+	const uint32_t c = blockIdx.x * 4 + w;
 	if (c >= n_ctx) return;
 	const uint32_t s = seg_start[c], e = seg_end[c];
 	if (e <= s) return;
 	const uint32_t lane = threadIdx.x & 63;
 	uint32_t* sp = state + (uint64_t)c * (n_sym + 1);
-	uint32_t cn[NS];                                       // symbol a lives in lane a % 64, slot a / 64
+	uint32_t* cnt = s_cnt[w]; uint32_t* pre = s_pre[w];
 #pragma unroll
-	for (uint32_t t = 0; t < NS; ++t) { uint32_t a = t * 64 + lane; cn[t] = a < n_sym ? sp[a] : 0u; }
+	for (uint32_t t = 0; t < 4; ++t) { uint32_t a = lane * 4 + t; cnt[a] = a < n_sym ? sp[a] : 0u; }
 	uint32_t tot = sp[n_sym];
+	auto rebuild_prefix = [&]() {
+		uint32_t v0 = cnt[lane * 4], v1 = cnt[lane * 4 + 1], v2 = cnt[lane * 4 + 2], v3 = cnt[lane * 4 + 3];
+		uint32_t sum = v0 + v1 + v2 + v3;
+		uint32_t ex = wave_incl_scan(sum) - sum;
+		pre[lane * 4] = ex; pre[lane * 4 + 1] = ex + v0; pre[lane * 4 + 2] = ex + v0 + v1; pre[lane * 4 + 3] = ex + v0 + v1 + v2;
+		__builtin_amdgcn_wave_barrier();
+	};
+	__builtin_amdgcn_wave_barrier();
+	rebuild_prefix();
 	const uint32_t smask = (1u << sym_bits) - 1;
 	for (uint32_t j0 = s; j0 < e; j0 += 64)
 	{
 		const uint32_t j = j0 + lane;
 		const bool valid = j < e;
-		const uint32_t my_sym = valid ? (skey[j] & smask) : 0u;
-		const uint32_t my_dst = valid ? sval[j] : 0u;
-		const uint32_t cnt = (e - j0) < 64 ? (e - j0) : 64;
-		uint32_t my_cum = 0, my_freq = 0, my_tot = 0;
-		for (uint32_t l = 0; l < cnt; ++l)
+		const uint32_t sym = valid ? (skey[j] & smask) : 0u;
+		const uint32_t dst = valid ? sval[j] : 0u;
+		const uint32_t n_here = (e - j0) < 64 ? (e - j0) : 64;
+		uint32_t start = 0;
+		while (start < n_here)
 		{
-			const uint32_t sym = __shfl(my_sym, l, 64);
-			const uint32_t slot = sym >> 6, ln = sym & 63;
-			uint32_t part = 0, mine = 0;
-#pragma unroll
-			for (uint32_t t = 0; t < NS; ++t)
+			const uint32_t r = (max_total - tot + adder - 1) / adder;          // updates absorbed before the next rescale
+			const uint32_t now = (n_here - start) < r ? (n_here - start) : r;
+			uint32_t less = 0, eq = 0;
+			for (uint32_t l = start; l < start + now; ++l)
 			{
-				if (t < slot) part += cn[t];
-				else if (t == slot) { if (lane < ln) part += cn[t]; mine = cn[t]; }
+				const uint32_t o = __builtin_amdgcn_readlane(sym, l);
+				if (l < lane) { less += (o < sym) ? 1u : 0u; eq += (o == sym) ? 1u : 0u; }
 			}
-			const uint32_t cum = wave_sum(part);
-			const uint32_t freq = __shfl(mine, ln, 64);
-			if (lane == l) { my_cum = cum; my_freq = freq; my_tot = tot; }
-#pragma unroll
-			for (uint32_t t = 0; t < NS; ++t) if (t == slot && lane == ln) cn[t] += adder;
-			tot += adder;
-			while (tot >= max_total)
+			const bool mine = lane >= start && lane < start + now;
+			if (mine) trip[dst] = pack_triple(pre[sym] + adder * less, cnt[sym] + adder * eq, tot + adder * (lane - start));
+			__builtin_amdgcn_wave_barrier();
+			if (mine) atomicAdd(&cnt[sym], adder);
+			__builtin_amdgcn_wave_barrier();
+			tot += adder * now;
+			while (tot >= max_total)                                               // rc.h:233-244 / 661-676
 			{
 				uint32_t sum = 0;
 #pragma unroll
-				for (uint32_t t = 0; t < NS; ++t) { uint32_t a = t * 64 + lane; if (a < n_sym) { cn[t] = (cn[t] + 1) / 2; sum += cn[t]; } }
+				for (uint32_t t = 0; t < 4; ++t) { uint32_t a = lane * 4 + t; if (a < n_sym) { uint32_t v = (cnt[a] + 1) / 2; cnt[a] = v; sum += v; } }
 				tot = wave_sum(sum);
 			}
+			__builtin_amdgcn_wave_barrier();
+			rebuild_prefix();
+			start += now;
 		}
-		if (valid) trip[my_dst] = pack_triple(my_cum, my_freq, my_tot);
 	}
 #pragma unroll
-	for (uint32_t t = 0; t < NS; ++t) { uint32_t a = t * 64 + lane; if (a < n_sym) sp[a] = cn[t]; }
+	for (uint32_t t = 0; t < 4; ++t) { uint32_t a = lane * 4 + t; if (a < n_sym) sp[a] = cnt[a]; }
 	if (lane == 0) sp[n_sym] = tot;
-}
-
-// ---- Q5: interval arithmetic, one lane per part (sub_rc.h:72-100,203-210) ---------------------------
-// range / tot with tot < 2^21: two exact double divisions (operands < 2^53) instead of a 64-bit divide.
-__device__ inline uint64_t div_u64_small(uint64_t x, uint32_t d)
-{
-	const double dd = (double)d;
-	uint32_t hi = (uint32_t)(x >> 32), lo = (uint32_t)x;
-	uint32_t q1 = (uint32_t)((double)hi / dd);            // hi < 2^32: exact operands
-	if ((uint64_t)q1 * d > hi) --q1;                      // guard the (unreachable for d < 2^21) round-up case
-	uint32_t r1 = hi - q1 * d;
-	if (r1 >= d) { ++q1; r1 -= d; }
-	uint64_t rest = ((uint64_t)r1 << 32) | lo;            // < d * 2^32 <= 2^53
-	uint64_t q2 = (uint64_t)((double)rest / dd);
-	// the double quotient of exactly representable operands is correctly rounded, truncation can be off by one
-	uint64_t prod = q2 * d;
-	if (prod > rest) { --q2; } else if (rest - prod >= d) { ++q2; }
-	return ((uint64_t)q1 << 32) + q2;
-}
-
-struct ByteSink {
-	uint8_t* p; uint64_t n; uint64_t acc; uint32_t fill; uint64_t cap; bool overflow;
-	__device__ inline void put(uint8_t b)
-	{
-		acc |= (uint64_t)b << (8 * fill);
-		if (++fill == 8)
-		{
-			if (n + 8 <= cap) *(uint64_t*)(p + n) = acc; else overflow = true;
-			n += 8; acc = 0; fill = 0;
-		}
-	}
-	__device__ inline void flush()
-	{
-		if (n + fill <= cap) { for (uint32_t i = 0; i < fill; ++i) p[n + i] = (uint8_t)(acc >> (8 * i)); } else overflow = true;
-		n += fill; fill = 0; acc = 0;
-	}
-};
-
-__global__ __launch_bounds__(64) void k_range_code(const uint64_t* __restrict__ trip, const uint64_t* __restrict__ part_sym_off, uint32_t n_parts,
-                                                  uint8_t* __restrict__ out, const uint64_t* __restrict__ part_out_off, uint64_t* __restrict__ part_size)
-{
-	const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-	if (p >= n_parts) return;
-	const uint64_t TOP = 0x00ffffffffffffULL, MASK = 0xff00000000000000ULL;
-	uint64_t low = 0, range = MASK;
-	ByteSink sink{ out + part_out_off[p], 0, 0, 0, part_out_off[p + 1] - part_out_off[p], false };
-	const uint64_t a = part_sym_off[p], b = part_sym_off[p + 1];
-	for (uint64_t i = a; i < b; ++i)
-	{
-		const uint64_t t = trip[i];
-		const uint32_t tot = (uint32_t)(t & 0x1fffff), freq = (uint32_t)((t >> 21) & 0x1fffff), cum = (uint32_t)(t >> 42);
-		if (freq == 0 || tot == 0 || cum + freq > tot) { sink.overflow = true; break; }   // never happens with valid triples; guards against a hang
-		range = div_u64_small(range, tot);
-		low += range * cum;
-		range *= freq;
-		while (range <= TOP)
-		{
-			if ((low ^ (low + range)) & MASK) { uint64_t r = low; range = (r | TOP) - r; }
-			sink.put((uint8_t)(low >> 56));
-			low <<= 8; range <<= 8;
-		}
-	}
-	for (int i = 0; i < 8; ++i) { sink.put((uint8_t)(low >> 56)); low <<= 8; }
-	sink.flush();
-	part_size[p] = sink.overflow ? ~0ULL : sink.n;
 }
 
 __global__ void k_gather_u64(const uint64_t* __restrict__ src, const uint32_t* __restrict__ idx, uint64_t n, uint64_t* __restrict__ dst)
@@ -486,14 +434,41 @@ extern "C" cl_status cl_qual_encode(cl_ctx* ctx, cl_qual_coder* Q, const cl_read
 		const uint64_t n_base = qo[p1] - qo[p0], n_syms = syms_of(p0, p1), n_byte = (uint64_t)(r1 - r0) * c.navg;
 		if (n_syms >= (1ull << 32)) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_qual_encode: a single part has >= 2^32 symbols");
 		const uint32_t np = p1 - p0;
-		DevBuf<uint64_t> trip; DEV_ALLOC(ctx, trip, n_syms);
+		// interleaved triple layout: groups of 64 parts, padded to the longest part of the group
+		const uint32_t ng = (np + 63) / 64;
+		std::vector<uint64_t> sym_start(np + 1), gbase(ng + 1);
+		std::vector<uint32_t> plen(np), pfirst(np + 1);
+		sym_start[0] = 0;
+		for (uint32_t p = 0; p < np; ++p)
+		{
+			uint64_t sl = syms_of(p0 + p, p0 + p + 1);
+			if (sl >= (1ull << 31)) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_qual_encode: a part has >= 2^31 symbols");
+			plen[p] = (uint32_t)sl; sym_start[p + 1] = sym_start[p] + sl; pfirst[p] = h_part_bounds[p0 + p];
+		}
+		pfirst[np] = h_part_bounds[p1];
+		gbase[0] = 0;
+		for (uint32_t g = 0; g < ng; ++g)
+		{
+			uint32_t lm = 0;
+			for (uint32_t p = g * 64; p < std::min(np, g * 64 + 64); ++p) lm = std::max(lm, plen[p]);
+			gbase[g + 1] = gbase[g] + (uint64_t)lm * 64;
+		}
+		if (gbase[ng] >= (1ull << 32)) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_qual_encode: group too large for 32-bit triple indices");
+		DevBuf<uint64_t> d_sym_start, d_gbase; DevBuf<uint32_t> d_plen, d_pfirst;
+		DEV_ALLOC(ctx, d_sym_start, np + 1); DEV_ALLOC(ctx, d_gbase, ng + 1); DEV_ALLOC(ctx, d_plen, np); DEV_ALLOC(ctx, d_pfirst, np + 1);
+		HIP_TRY(ctx, hipMemcpyAsync(d_sym_start.p, sym_start.data(), (np + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(ctx, hipMemcpyAsync(d_gbase.p, gbase.data(), (ng + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(ctx, hipMemcpyAsync(d_plen.p, plen.data(), np * 4, hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(ctx, hipMemcpyAsync(d_pfirst.p, pfirst.data(), (np + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+		TripLayoutDev lay{ d_pfirst.p, d_sym_start.p, d_gbase.p, np };
+		DevBuf<triple_t> trip; DEV_ALLOC(ctx, trip, gbase[ng]);
 		{
 			DevBuf<uint32_t> key, sidx, bkey, bsidx;
 			DEV_ALLOC(ctx, key, per_base ? n_base : 0); DEV_ALLOC(ctx, sidx, per_base ? n_base : 0);
 			DEV_ALLOC(ctx, bkey, n_byte); DEV_ALLOC(ctx, bsidx, n_byte);
 			if (r1 > r0)
 				LAUNCH(ctx, k_qual_symbols, grid_for(r1 - r0, 4), 256, (const QualCfg*)Q->d_cfg.p, (const uint64_t*)R->packed.p, (const uint64_t*)R->word_off.p,
-					d_quals, d_qual_off, d_flags, r0, r1, qo[p0], key.p, sidx.p, (uint64_t*)nullptr, bkey.p, bsidx.p);
+					d_quals, d_qual_off, d_flags, r0, r1, qo[p0], lay, key.p, sidx.p, bkey.p, bsidx.p);
 			HIP_TRY(ctx, hipGetLastError());
 			const uint32_t total_ctx_bits = c.ctx_bits + c.base_bits + (c.level > 1 ? 2 : 0);
 			if (per_base && n_base)
@@ -509,7 +484,7 @@ extern "C" cl_status cl_qual_encode(cl_ctx* ctx, cl_qual_coder* Q, const cl_read
 				case 2: LAUNCH(ctx, (k_evolve_small<2>), g, 256, (const uint32_t*)key.p, (const uint32_t*)sidx.p, (const uint32_t*)ss.p, (const uint32_t*)se.p, c.n_ctx, c.sym_bits, c.max_total, c.adder, Q->state.p, trip.p); break;
 				case 4: LAUNCH(ctx, (k_evolve_small<4>), g, 256, (const uint32_t*)key.p, (const uint32_t*)sidx.p, (const uint32_t*)ss.p, (const uint32_t*)se.p, c.n_ctx, c.sym_bits, c.max_total, c.adder, Q->state.p, trip.p); break;
 				case 5: LAUNCH(ctx, (k_evolve_small<5>), g, 256, (const uint32_t*)key.p, (const uint32_t*)sidx.p, (const uint32_t*)ss.p, (const uint32_t*)se.p, c.n_ctx, c.sym_bits, c.max_total, c.adder, Q->state.p, trip.p); break;
-				default: LAUNCH(ctx, (k_evolve_large<2>), g, 256, (const uint32_t*)key.p, (const uint32_t*)sidx.p, (const uint32_t*)ss.p, (const uint32_t*)se.p, c.n_ctx, c.n_sym, c.sym_bits, c.max_total, c.adder, Q->state.p, trip.p); break;
+				default: LAUNCH(ctx, k_evolve_large, g, 256, (const uint32_t*)key.p, (const uint32_t*)sidx.p, (const uint32_t*)ss.p, (const uint32_t*)se.p, c.n_ctx, c.n_sym, c.sym_bits, c.max_total, c.adder, Q->state.p, trip.p); break;
 				}
 				HIP_TRY(ctx, hipGetLastError());
 				HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -521,27 +496,25 @@ extern "C" cl_status cl_qual_encode(cl_ctx* ctx, cl_qual_coder* Q, const cl_read
 				HIP_TRY(ctx, hipMemsetAsync(ss.p, 0, BYTE_CTX * 4, ctx->stream));
 				HIP_TRY(ctx, hipMemsetAsync(se.p, 0, BYTE_CTX * 4, ctx->stream));
 				LAUNCH(ctx, k_seg_bounds, grid_for(n_byte, 256), 256, (const uint32_t*)bkey.p, n_byte, 8u, ss.p, se.p);
-				LAUNCH(ctx, (k_evolve_large<4>), grid_for(BYTE_CTX, 4), 256, (const uint32_t*)bkey.p, (const uint32_t*)bsidx.p, (const uint32_t*)ss.p, (const uint32_t*)se.p,
+				LAUNCH(ctx, k_evolve_large, grid_for(BYTE_CTX, 4), 256, (const uint32_t*)bkey.p, (const uint32_t*)bsidx.p, (const uint32_t*)ss.p, (const uint32_t*)se.p,
 					BYTE_CTX, 256u, 8u, 1u << 18, 8u, Q->bstate.p, trip.p);
 				HIP_TRY(ctx, hipGetLastError());
 				HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 			}
 		}
 		// range coding: worst case bits_max bits per symbol + 8 flush bytes, rounded to 8-byte aligned regions
-		std::vector<uint64_t> sym_off(np + 1), out_off(np + 1);
-		sym_off[0] = 0; out_off[0] = 0;
+		std::vector<uint64_t> out_off(np + 1);
+		out_off[0] = 0;
 		for (uint32_t p = 0; p < np; ++p)
 		{
-			uint64_t s = syms_of(p0 + p, p0 + p + 1);
-			sym_off[p + 1] = sym_off[p] + s;
+			uint64_t s = plen[p];
 			out_off[p + 1] = out_off[p] + ((s * bits_max + 7) / 8 + s / 16 + 64 + 7) / 8 * 8;
 		}
 		DevBuf<uint8_t> tmp; DEV_ALLOC(ctx, tmp, out_off[np]);
-		DevBuf<uint64_t> d_sym_off, d_out_off, d_size, d_dst_off;
-		DEV_ALLOC(ctx, d_sym_off, np + 1); DEV_ALLOC(ctx, d_out_off, np + 1); DEV_ALLOC(ctx, d_size, np); DEV_ALLOC(ctx, d_dst_off, np);
-		HIP_TRY(ctx, hipMemcpyAsync(d_sym_off.p, sym_off.data(), (np + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+		DevBuf<uint64_t> d_out_off, d_size, d_dst_off;
+		DEV_ALLOC(ctx, d_out_off, np + 1); DEV_ALLOC(ctx, d_size, np); DEV_ALLOC(ctx, d_dst_off, np);
 		HIP_TRY(ctx, hipMemcpyAsync(d_out_off.p, out_off.data(), (np + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-		LAUNCH(ctx, k_range_code, grid_for(np, 64), 64, (const uint64_t*)trip.p, (const uint64_t*)d_sym_off.p, np, tmp.p, (const uint64_t*)d_out_off.p, d_size.p);
+		LAUNCH(ctx, k_range_code, ng, 64, (const triple_t*)trip.p, (const uint64_t*)d_gbase.p, (const uint32_t*)d_plen.p, np, tmp.p, (const uint64_t*)d_out_off.p, d_size.p);
 		HIP_TRY(ctx, hipGetLastError());
 		HIP_TRY(ctx, hipMemcpyAsync(h_part_sizes + p0, d_size.p, np * 8, hipMemcpyDeviceToHost, ctx->stream));
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
