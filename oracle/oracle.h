@@ -80,6 +80,15 @@ void orc_qual_decode(orc_qual*, const uint8_t* bases, uint32_t len, const uint8_
 /* per-base 'A'/'M'/' '/'P' classes from a read's tuple stream (quality_coder_impl.cpp:25-75) */
 void orc_es_flags(const uint8_t* es, size_t n, uint32_t read_len, uint8_t* flags);
 
+/* ---- a14: DNA coder (dna_coder.{h,cpp}, entr_read.h:56-80) ---------------------------------------- */
+typedef struct orc_dna orc_dna;
+orc_dna* orc_dna_new(int compress, int max_alt_refs, int level, uint32_t start_read_id);
+void orc_dna_free(orc_dna*);
+void orc_dna_add_ref(orc_dna*, const uint8_t* bases, uint32_t len);      /* CReferenceReads::Add, in reference-id order */
+/* one read: its tuple stream in the App. A byte layout and the tuple count (es_t::size()) */
+void orc_dna_encode(orc_dna*, const uint8_t* es, size_t n_bytes, uint32_t n_tuples);
+size_t orc_dna_finish_part(orc_dna*, uint8_t* dst, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,6 +55,13 @@ def lib():
         L.orc_qual_set_input.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.orc_qual_decode.argtypes = [C.c_void_p, u8p, C.c_uint32, C.c_void_p, u8p]
         L.orc_es_flags.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, u8p]
+        L.orc_dna_new.restype = C.c_void_p
+        L.orc_dna_new.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32]
+        L.orc_dna_free.argtypes = [C.c_void_p]
+        L.orc_dna_add_ref.argtypes = [C.c_void_p, u8p, C.c_uint32]
+        L.orc_dna_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32]
+        L.orc_dna_finish_part.restype = C.c_size_t
+        L.orc_dna_finish_part.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         _LIB = L
     return _LIB
 
@@ -176,3 +183,28 @@ class QualCoder:
             b = np.zeros(1, np.uint8)
         lib().orc_qual_decode(self.h, b, len(bases), None if f is None else f.ctypes.data, out)
         return out[:len(bases)]
+
+
+class DnaCoder:
+    """CDNACoder + the part framing of CEntrComprReads."""
+    def __init__(self, max_alt_refs: int, level: int, start_read_id: int = 0):
+        self.h = lib().orc_dna_new(1, max_alt_refs, level, start_read_id)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_dna_free(self.h)
+            self.h = None
+
+    def add_ref(self, bases):
+        b = np.ascontiguousarray(bases, np.uint8)
+        lib().orc_dna_add_ref(self.h, b if len(b) else np.zeros(1, np.uint8), len(b))
+
+    def encode(self, es: bytes, n_tuples: int):
+        buf = (C.c_char * len(es)).from_buffer_copy(es)
+        lib().orc_dna_encode(self.h, buf, len(es), n_tuples)
+
+    def finish_part(self) -> bytes:
+        n = lib().orc_dna_finish_part(self.h, None, 0)
+        buf = np.zeros(n, np.uint8)
+        m = lib().orc_dna_finish_part(self.h, buf.ctypes.data, n)
+        return buf[:m].tobytes()
