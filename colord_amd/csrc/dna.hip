@@ -1,0 +1,689 @@
+// dna.hip — DNA stream coder (a14 + a16 framing) on the GPU, bit-identical to CDNACoder
+// (src/colord/dna_coder.{h,cpp}) driven by CEntrComprReads (entr_read.h:56-80).
+//
+// Same decomposition as the quality coder (qual.hip): every coded symbol's (model family, context, symbol,
+// exclusions) is a function of INPUT data only — the read's tuple stream, the reference reads it points
+// to and the types of the previous four reads — so symbols are generated independently per read (one
+// lane walks one tuple stream; plain reads are expanded one lane per base), grouped by (family, context)
+// with a stable sort, each model is evolved by one wavefront over its own run, and the interval
+// arithmetic runs one lane per part (rc_dev.hpp).
+#include "common.hpp"
+#include "objects.hpp"
+#include "rc_dev.hpp"
+#include <algorithm>
+
+namespace {
+enum { T_INS = 0, T_DEL, T_MATCH, T_SUBST, T_ANCHOR, T_SKIP, T_ALT_ID, T_MAIN_REF, T_PLAIN, T_START_PLAIN, T_START_ES, T_START_PLAIN_N, T_NONE };
+enum { F_READ_TYPE = 0, F_REV_COMP, F_SEEN, F_LEN_BITS, F_LEN_DATA, F_SYMBOLS, F_SYMBOLS_N, F_READ_ID, F_READ_ID_SHORT,
+       F_ANCHOR_LEN, F_SKIP_LOCAL, F_SKIP_DISTANT, F_TUPLE_TYPE, N_FAM };
+constexpr uint32_t MAX_ALT = 64;
+
+struct FamTab {
+	uint32_t n_sym[N_FAM], max_total[N_FAM], adder[N_FAM];
+	uint32_t ctx_base[N_FAM + 1];       // dense global context ids
+	uint64_t state_base[N_FAM + 1];     // offsets into the state array (u32 units)
+	uint32_t n_ctx[N_FAM];
+	int32_t level, T, S;                // tuple / symbol history lengths (dna_coder.cpp:1253-1280)
+	uint32_t sym_B;                     // bit width of the regular symbols-family contexts
+	uint32_t max_alt;
+};
+
+struct RefStore { const uint64_t* packed; const uint64_t* word_off; const uint32_t* lens; uint32_t n; };
+// GetRefRead(id, rev)[pos] including the trailing guard 255 (reference_reads.h:142-207)
+__device__ inline uint32_t ref_at(const RefStore& R, uint32_t id, bool rev, int64_t pos)
+{
+	if (id >= R.n) return 255;
+	const uint32_t len = R.lens[id];
+	if (pos < 0 || pos >= (int64_t)len) return 255;
+	const uint32_t p = rev ? (len - 1 - (uint32_t)pos) : (uint32_t)pos;
+	const uint32_t b = (uint32_t)(R.packed[R.word_off[id] + (p >> 5)] >> (62 - 2 * (p & 31))) & 3u;
+	return rev ? 3u - b : b;
+}
+__device__ inline uint32_t ilog2_(uint64_t x) { return x ? 64u - (uint32_t)__clzll((long long)x) : 0u; }     // bit length (basic_coder.h:39-47)
+__device__ inline uint32_t no_bytes_(uint64_t x) { uint32_t r = 1; x >>= 8; for (; x; ++r) x >>= 8; return r; }
+
+struct Emitter {
+	bool write; uint64_t* key; uint32_t* sidx; uint64_t off; uint32_t count; const FamTab* ft; TripLayoutDev lay; uint32_t part;
+	__device__ inline void operator()(int fam, uint32_t ctx, uint32_t sym, int e1 = 15, int e2 = 15)
+	{
+		if (write)
+		{
+			key[off + count] = ((uint64_t)(ft->ctx_base[fam] + ctx) << 16) | ((uint64_t)(e1 & 15) << 12) | ((uint64_t)(e2 & 15) << 8) | sym;
+			sidx[off + count] = trip_index(lay, part, off + count);
+		}
+		++count;
+	}
+};
+
+struct EsReader {
+	const uint8_t* p; const uint8_t* e;
+	__device__ inline bool next(uint32_t& type, uint32_t& v1, uint32_t& v2)
+	{
+		if (p >= e) return false;
+		const uint32_t t = p[0] >> 4; type = t;
+		switch (t)
+		{
+		case T_INS: case T_SUBST: case T_PLAIN: v1 = p[0] & 0xf; p += 1; break;
+		case T_ANCHOR: case T_SKIP: v2 = ((uint32_t)(p[0] & 0xf) << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; p += 4; break;
+		case T_ALT_ID: case T_START_ES: v2 = p[0] & 0xf; v1 = ((uint32_t)p[1] << 24) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 8) | p[4]; p += 5; break;
+		default: p += 1;
+		}
+		return true;
+	}
+};
+
+__device__ inline void emit_read_len(Emitter& em, uint32_t len)                  // dna_coder.cpp:1004-1056
+{
+	int nb = (int)ilog2_(len);
+	em(F_LEN_BITS, 0, (uint32_t)nb);
+	if (nb < 2) return;
+	uint32_t ctx = (uint32_t)nb << 3;
+	len -= 1u << (nb - 1);
+	uint32_t prefix, suffix;
+	if (nb <= 9) { prefix = len; suffix = 0; }
+	else { prefix = len >> (nb - 9); suffix = len - (prefix << (nb - 9)); }
+	em(F_LEN_DATA, ctx, prefix);
+	if (nb <= 9) return;
+	nb -= 9; ctx += 4;
+	for (; nb > 0; nb -= 8) { em(F_LEN_DATA, ctx, suffix & 0xff); suffix >>= 8; ++ctx; }
+}
+__device__ inline void emit_read_id(Emitter& em, uint32_t id, uint32_t cur_read_id)   // :535-551
+{
+	const int n = (int)no_bytes_(cur_read_id);
+	for (int i = n - 1; i >= 0; --i)
+	{
+		uint32_t add = (i == n - 2) ? ((id >> (8 * (n - 1))) & 0xff) : 0;
+		em(F_READ_ID, (uint32_t)i + (add << 3), (id >> (8 * i)) & 0xff);
+	}
+}
+__device__ inline void emit_anchor_len(Emitter& em, uint32_t len)                // :958-978
+{
+	for (uint32_t part = 0; len; ++part)
+	{
+		if (len < 23) { em(F_ANCHOR_LEN, part, len); break; }
+		em(F_ANCHOR_LEN, part, 23);
+		len -= 22;
+	}
+}
+__device__ inline void emit_skip_len(Emitter& em, uint32_t len, bool local)      // :1109-1137
+{
+	if (local)
+	{
+		for (uint32_t part = 0; len; ++part)
+		{
+			if (len < 255) { em(F_SKIP_LOCAL, part, len); break; }
+			em(F_SKIP_LOCAL, part, 255);
+			len -= 254;
+		}
+		return;
+	}
+	uint32_t encoded = 0;
+	for (int i = 3; i >= 0; --i)
+	{
+		uint32_t x = (len >> (8 * i)) & 0xff;
+		em(F_SKIP_DISTANT, (uint32_t)i * 64 + ilog2_(encoded), x);
+		encoded = (encoded << 8) + x;
+	}
+}
+
+// ---- D1: one lane per read walks the tuple stream (CDNACoder::Encode, dna_coder.cpp:26-231) ----------
+// WRITE = false: only counts the symbols of each read.  Bases of plain reads are left to k_dna_plain.
+template<bool WRITE>
+__global__ __launch_bounds__(64) void k_dna_walk(const FamTab* __restrict__ ftp, RefStore R, const uint8_t* __restrict__ es, const uint64_t* __restrict__ es_off,
+                                                const uint32_t* __restrict__ es_ntup, const uint8_t* __restrict__ read_flag,
+                                                uint32_t r0, uint32_t r1, uint32_t prev_types, uint32_t cur_read_id0, TripLayoutDev lay,
+                                                uint32_t* __restrict__ counts, uint32_t* __restrict__ hdr_counts, const uint64_t* __restrict__ sym_off,
+                                                uint64_t* __restrict__ key, uint32_t* __restrict__ sidx, uint32_t* __restrict__ err)
+{
+	__shared__ FamTab ft;
+	for (uint32_t i = threadIdx.x; i < sizeof(FamTab) / 4; i += blockDim.x) ((uint32_t*)&ft)[i] = ((const uint32_t*)ftp)[i];
+	__syncthreads();
+	const uint32_t r = r0 + blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= r1) return;
+	Emitter em{ WRITE, key, sidx, WRITE ? sym_off[r - r0] : 0, 0, &ft, lay, WRITE ? part_of_read(lay, r) : 0 };
+	EsReader rd{ es + es_off[r], es + es_off[r + 1] };
+	uint32_t type = T_NONE, v1 = 0, v2 = 0;
+	rd.next(type, v1, v2);
+	// read-type history: types of the four previous reads, also across calls (dna_coder.cpp:440-463)
+	uint32_t ctx_rt = 0;
+	for (uint32_t t = 1; t <= 4; ++t)
+	{
+		uint32_t f = (r >= r0 + t) ? read_flag[r - t - r0] : ((prev_types >> (2 * (t - 1 - (r - r0)))) & 3u);
+		ctx_rt |= f << (2 * (t - 1));
+	}
+	const uint32_t flag = type == T_START_PLAIN ? 0u : type == T_START_PLAIN_N ? 1u : 2u;
+	em(F_READ_TYPE, ctx_rt, flag);
+	const uint32_t ntup = es_ntup[r];
+	emit_read_len(em, ntup - 1);
+	const uint32_t cur_read_id = cur_read_id0 + (r - r0);
+	if (type == T_START_PLAIN || type == T_START_PLAIN_N)
+	{
+		if (!WRITE) { hdr_counts[r - r0] = em.count; counts[r - r0] = em.count + (ntup - 1); }
+		return;
+	}
+	const uint64_t mask_tuple = (1ULL << (3 * ft.T)) - 1, mask_symbol = (1ULL << (2 * ft.S)) - 1;
+	uint64_t ctx_tuple = mask_tuple, ctx_symbol = mask_symbol; uint32_t ctx_rev = 0xf;
+	int32_t rc_ids[MAX_ALT + 1]; uint32_t n_rc = 0;                               // uo_rev_comp keys (values are not needed to encode)
+	int32_t alt_ids[MAX_ALT], alt_pos_of[MAX_ALT]; uint8_t alt_rev_of[MAX_ALT]; uint32_t n_alt = 0;
+	const uint32_t ref_id = v1; const bool ref_rev = v2 != 0;
+	uint32_t alt_id = 0; bool alt_rev = false; int32_t alt_slot = -1;
+	int64_t ref_pos = 0, alt_pos = 0; int32_t delta = 0;
+	uint32_t last_type = T_NONE, last_flag = T_NONE; bool is_main = true, first = true;
+	auto rev_comp_flag = [&](uint32_t id, bool rc) {                                 // :489-509
+		for (uint32_t i = 0; i < n_rc; ++i) if (rc_ids[i] == (int32_t)id) return;
+		em(F_REV_COMP, ctx_rev, rc ? 1u : 0u);
+		if (n_rc < MAX_ALT + 1) rc_ids[n_rc++] = (int32_t)id;
+		ctx_rev = ((ctx_rev << 2) + (rc ? 1u : 0u)) & 0xf;
+	};
+	emit_read_id(em, ref_id, cur_read_id);
+	rev_comp_flag(ref_id, ref_rev);
+	const uint32_t s3 = 3 * ft.T;
+	while (rd.next(type, v1, v2))
+	{
+		const uint32_t ref_symbol = is_main ? ref_at(R, ref_id, ref_rev, ref_pos) : ref_at(R, alt_id, alt_rev, alt_pos);
+		{	// encode_tuple_type (:651-710) with the guard case moved to its own dense region
+			uint32_t cls = delta < -10 ? 1u : delta < -1 ? 2u : delta > 10 ? 3u : delta > 1 ? 4u : 0u;
+			uint32_t c = (uint32_t)ctx_tuple | ((uint32_t)(ctx_symbol & 0xf) << s3);
+			if (ref_symbol <= 3) c |= (ref_symbol << (s3 + 4)) | (cls << (s3 + 6));
+			else c = (1u << (s3 + 9)) + (c | (cls << (s3 + 4)));
+			int e1 = 15, e2 = 15;
+			if (!first)
+				switch (last_flag)
+				{
+				case T_MATCH: e1 = T_ANCHOR; break;
+				case T_DEL: e1 = T_SKIP; break;
+				case T_ANCHOR: e1 = T_ANCHOR; e2 = T_MATCH; break;
+				case T_SKIP: e1 = T_DEL; e2 = T_SKIP; break;
+				case T_MAIN_REF: case T_ALT_ID: e1 = T_ALT_ID; e2 = T_MAIN_REF; break;
+				default: break;
+				}
+			em(F_TUPLE_TYPE, c, type, e1, e2);
+			ctx_tuple = ((ctx_tuple << 3) + type) & mask_tuple;
+		}
+		first = false; last_flag = type;
+		switch (type)
+		{
+		case T_ALT_ID:
+		{
+			if (!is_main && alt_slot >= 0) alt_pos_of[alt_slot] = (int32_t)alt_pos;
+			bool is_new = false; int32_t slot = -1;
+			if (n_alt == 0) { emit_read_id(em, v1, cur_read_id); alt_ids[0] = (int32_t)v1; alt_pos_of[0] = 0; n_alt = 1; slot = 0; is_new = true; }
+			else
+			{
+				const uint32_t seen = n_alt;
+				for (uint32_t i = 0; i < n_alt; ++i) if (alt_ids[i] == (int32_t)v1) slot = (int32_t)i;
+				const int32_t short_id = slot;
+				if (slot < 0)
+				{
+					if (n_alt >= MAX_ALT) { if (err) atomicOr(err, 1u); return; }
+					slot = (int32_t)n_alt; alt_ids[n_alt] = (int32_t)v1; alt_pos_of[n_alt] = 0; ++n_alt; is_new = true;
+				}
+				em(F_SEEN, seen, short_id >= 0 ? 1u : 0u);
+				if (short_id < 0) emit_read_id(em, v1, cur_read_id);
+				else em(F_READ_ID_SHORT, seen, (uint32_t)short_id);
+			}
+			if (is_new) alt_rev_of[slot] = (uint8_t)v2;
+			rev_comp_flag(v1, v2 != 0);
+			alt_id = v1; alt_slot = slot; alt_rev = alt_rev_of[slot] != 0;
+			alt_pos = 0; is_main = false; delta = 0;
+			break;
+		}
+		case T_ANCHOR:
+			emit_anchor_len(em, v2);
+			if (is_main) ref_pos += v2; else alt_pos += v2;
+			for (int i = ft.S; i > 0; --i)
+				ctx_symbol = (ctx_symbol << 2) + (is_main ? ref_at(R, ref_id, ref_rev, ref_pos - i) : ref_at(R, alt_id, alt_rev, alt_pos - i));
+			ctx_symbol &= mask_symbol;
+			delta = 0;
+			break;
+		case T_MATCH:
+			ctx_symbol = ((ctx_symbol << 2) + ref_symbol) & mask_symbol;
+			if (is_main) ++ref_pos; else ++alt_pos;
+			break;
+		case T_INS:
+		{	// encode_insertion (:772-811)
+			uint32_t shift = 2, c = 2;
+			if (ft.level == 1) { c += (uint32_t)(ctx_symbol & 0xff) << shift; shift += 8; }
+			else if (ft.level == 2) { c += (uint32_t)(ctx_symbol & 0x3ff) << shift; shift += 10; }
+			else { c += (uint32_t)(ctx_symbol & 0x3ff) << shift; shift += 10; c += (uint32_t)(((ctx_symbol >> 10) & 3) == ((ctx_symbol >> 8) & 3)) << shift; ++shift; }
+			const bool guard = ref_symbol > 3;
+			c += (guard ? 0u : ref_symbol) << shift; shift += 2;
+			c += (uint32_t)(ctx_tuple & 0777) << shift;
+			if (guard) c += 1u << ft.sym_B;
+			em(F_SYMBOLS, c, v1);
+			ctx_symbol = ((ctx_symbol << 2) + v1) & mask_symbol;
+			++delta;
+			break;
+		}
+		case T_DEL:
+			if (is_main) ++ref_pos; else ++alt_pos;
+			--delta;
+			break;
+		case T_SUBST:
+		{	// encode_substitution (:889-922); the coded symbol is the new base, the reference base is excluded
+			const uint32_t rs = ref_symbol & 3;
+			const uint32_t sym = (rs == 0) ? (v1 == 0 ? 1u : v1 == 1 ? 2u : 3u) : (rs == 1) ? (v1 == 0 ? 0u : v1 == 1 ? 2u : 3u)
+			                   : (rs == 2) ? (v1 == 0 ? 0u : v1 == 1 ? 1u : 3u) : (v1 == 0 ? 0u : v1 == 1 ? 1u : 2u);   // subst_to_code (dna_coder.h:37)
+			uint32_t shift = 2, c = 1;
+			c += (uint32_t)(ctx_symbol & 0x3f) << shift; shift += 6;
+			if (ft.level == 3) { c += (uint32_t)(((ctx_symbol >> 6) & 3) == ((ctx_symbol >> 4) & 3)) << shift; ++shift; }
+			c += rs << shift; shift += 2;
+			c += (uint32_t)(ctx_tuple & 07777) << shift;
+			em(F_SYMBOLS, c, sym, (int)rs);
+			ctx_symbol = ((ctx_symbol << 2) + sym) & mask_symbol;
+			if (is_main) ++ref_pos; else ++alt_pos;
+			break;
+		}
+		case T_SKIP:
+		{
+			const int32_t skip_len = (int32_t)v2;
+			delta -= skip_len;
+			if (!is_main && last_type == T_ALT_ID)                               // :187-201
+			{
+				const int32_t mod = skip_len - (alt_slot >= 0 ? alt_pos_of[alt_slot] : 0);
+				if (mod > 0) emit_skip_len(em, (uint32_t)mod, false);
+				else { emit_skip_len(em, 0, false); emit_skip_len(em, (uint32_t)(-mod), false); }
+			}
+			else emit_skip_len(em, (uint32_t)skip_len, last_type != T_ALT_ID && last_type != T_NONE);
+			if (is_main) ref_pos += v2; else alt_pos += v2;
+			break;
+		}
+		case T_MAIN_REF:
+			is_main = true;
+			if (alt_slot >= 0) alt_pos_of[alt_slot] = (int32_t)alt_pos;
+			delta = 0;
+			break;
+		default: break;
+		}
+		last_type = type;
+	}
+	if (!WRITE) { hdr_counts[r - r0] = em.count; counts[r - r0] = em.count; }
+}
+
+// first tuple of every read -> read-type flag (0 plain, 1 plain with N, 2 edit script)
+__global__ void k_read_flags(const uint8_t* __restrict__ es, const uint64_t* __restrict__ es_off, uint32_t r0, uint32_t r1, uint8_t* __restrict__ flag)
+{
+	uint32_t r = r0 + blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= r1) return;
+	uint32_t t = es[es_off[r]] >> 4;
+	flag[r - r0] = t == T_START_PLAIN ? 0 : t == T_START_PLAIN_N ? 1 : 2;
+}
+
+// ---- D1b: bases of plain reads, one wave per read, one lane per base (dna_coder.cpp:1178-1227) ----------
+__global__ __launch_bounds__(256) void k_dna_plain(const FamTab* __restrict__ ftp, const uint8_t* __restrict__ es, const uint64_t* __restrict__ es_off,
+                                                  const uint32_t* __restrict__ es_ntup, const uint8_t* __restrict__ read_flag, const uint32_t* __restrict__ hdr_counts,
+                                                  const uint64_t* __restrict__ sym_off, uint32_t r0, uint32_t r1, TripLayoutDev lay,
+                                                  uint64_t* __restrict__ key, uint32_t* __restrict__ sidx)
+{
+	const uint32_t r = r0 + blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (r >= r1) return;
+	const uint32_t fl = read_flag[r - r0];
+	if (fl == 2) return;
+	const FamTab& ft = *ftp;
+	const uint32_t lane = threadIdx.x & 63;
+	const uint8_t* b = es + es_off[r] + 1;                    // one byte per base after the start tuple (low nibble = base)
+	const uint32_t len = es_ntup[r] - 1;
+	const uint64_t off = sym_off[r - r0] + hdr_counts[r - r0];
+	const uint32_t part = part_of_read(lay, r);
+	const uint32_t S2 = 2 * ft.S; const uint32_t mask = (1u << S2) - 1;
+	const uint32_t fam = fl == 0 ? F_SYMBOLS : F_SYMBOLS_N;
+	const uint32_t cbase = ft.ctx_base[fam];
+	for (uint32_t i = lane; i < len; i += 64)
+	{
+		uint32_t ctx = mask;
+		if (fl == 0)
+		{
+			const uint32_t n = i < (uint32_t)ft.S ? i : (uint32_t)ft.S;
+			for (uint32_t t = n; t >= 1; --t) ctx = ((ctx << 2) + (b[i - t] & 3u)) & mask;
+			ctx <<= 2;                                                         // plain marker 0
+		}
+		else
+		{
+			const uint32_t n = i < 4 ? i : 4;
+			for (uint32_t t = n; t >= 1; --t) ctx = ((ctx << 4) + (b[i - t] & 0xfu)) & mask;
+		}
+		key[off + i] = ((uint64_t)(cbase + ctx) << 16) | (15u << 12) | (15u << 8) | (b[i] & 0xfu);
+		sidx[off + i] = trip_index(lay, part, off + i);
+	}
+}
+
+// ---- D3: runs of equal context in the sorted keys --------------------------------------------------------
+__global__ void k_ctx_heads(const uint64_t* __restrict__ skey, uint64_t n, uint32_t* __restrict__ flags)
+{
+	uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j < n) flags[j] = (j == 0 || (skey[j - 1] >> 16) != (skey[j] >> 16)) ? 1u : 0u;
+}
+__global__ void k_seg_starts(const uint32_t* __restrict__ scan, uint64_t n, uint64_t n_heads, uint32_t* __restrict__ seg_start)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	uint32_t s = scan[i];
+	uint32_t nx = (i + 1 < n) ? scan[i + 1] : (uint32_t)n_heads;
+	if (nx != s) seg_start[s] = (uint32_t)i;
+	if (i == 0) seg_start[n_heads] = (uint32_t)n;
+}
+
+// ---- D4: model evolution, one wave per non-empty (family, context) run ---------------------------------
+// alphabets <= 8: per-class ballots (with the two optional exclusions of rc.h:316-341); larger: LDS counters.
+__global__ __launch_bounds__(256) void k_dna_evolve(const FamTab* __restrict__ ftp, const uint64_t* __restrict__ skey, const uint32_t* __restrict__ sval,
+                                                   const uint32_t* __restrict__ seg_start, uint32_t n_seg, uint32_t* __restrict__ state, triple_t* __restrict__ trip)
+{
+	__shared__ uint32_t s_cnt[4][256];
+	__shared__ uint32_t s_pre[4][256];
+	const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const uint32_t sg = blockIdx.x * 4 + w;
+	if (sg >= n_seg) return;
+	const uint32_t s = seg_start[sg], e = seg_start[sg + 1];
+	const FamTab& ft = *ftp;
+	const uint32_t gctx = (uint32_t)(skey[s] >> 16);
+	uint32_t fam = 0;
+	for (uint32_t f = 1; f < N_FAM; ++f) if (gctx >= ft.ctx_base[f]) fam = f;
+	const uint32_t n_sym = ft.n_sym[fam], max_total = ft.max_total[fam], adder = ft.adder[fam];
+	uint32_t* sp = state + ft.state_base[fam] + (uint64_t)(gctx - ft.ctx_base[fam]) * (n_sym + 1);
+	const uint64_t lt = (1ULL << lane) - 1;
+	if (n_sym <= 8)
+	{
+		uint32_t st[8]; uint32_t tot = sp[n_sym];
+#pragma unroll
+		for (uint32_t a = 0; a < 8; ++a) st[a] = a < n_sym ? sp[a] : 0u;
+		for (uint32_t j0 = s; j0 < e; j0 += 64)
+		{
+			const uint32_t j = j0 + lane; const bool valid = j < e;
+			const uint64_t k = valid ? skey[j] : 0;
+			const uint32_t sym = valid ? (uint32_t)(k & 0xff) : 0xffu, e1 = (uint32_t)(k >> 12) & 15u, e2 = (uint32_t)(k >> 8) & 15u;
+			const uint32_t dst = valid ? sval[j] : 0u;
+			uint64_t m[8];
+#pragma unroll
+			for (uint32_t a = 0; a < 8; ++a) m[a] = __ballot(valid && sym == a);
+			const uint32_t cnt = (e - j0) < 64 ? (e - j0) : 64;
+			uint32_t start = 0;
+			while (start < cnt)
+			{
+				const uint32_t r = (max_total - tot + adder - 1) / adder;
+				const uint32_t now = (cnt - start) < r ? (cnt - start) : r;
+				const uint64_t win = (now == 64 ? ~0ULL : ((1ULL << now) - 1)) << start;
+				if (lane >= start && lane < start + now)
+				{
+					const uint64_t before = lt & win;
+					uint32_t cum = 0, freq = 0, excl = 0;
+#pragma unroll
+					for (uint32_t a = 0; a < 8; ++a)
+					{
+						const uint32_t v = st[a] + adder * (uint32_t)__popcll(m[a] & before);
+						const bool ex = a == e1 || a == e2;
+						if (ex) excl += v;
+						if (a < sym && !ex) cum += v;
+						if (a == sym) freq = v;
+					}
+					trip[dst] = pack_triple(cum, freq, tot + adder * (lane - start) - excl);
+				}
+#pragma unroll
+				for (uint32_t a = 0; a < 8; ++a) st[a] += adder * (uint32_t)__popcll(m[a] & win);
+				tot += adder * now;
+				while (tot >= max_total)
+				{
+					tot = 0;
+#pragma unroll
+					for (uint32_t a = 0; a < 8; ++a) { st[a] = (st[a] + 1) / 2; tot += st[a]; }   // unused classes stay 0
+				}
+				start += now;
+			}
+		}
+		if (lane == 0)
+		{
+			for (uint32_t a = 0; a < n_sym; ++a) sp[a] = st[a];
+			sp[n_sym] = tot;
+		}
+		return;
+	}
+	uint32_t* cnt = s_cnt[w]; uint32_t* pre = s_pre[w];
+#pragma unroll
+	for (uint32_t t = 0; t < 4; ++t) { uint32_t a = lane * 4 + t; cnt[a] = a < n_sym ? sp[a] : 0u; }
+	uint32_t tot = sp[n_sym];
+	auto rebuild_prefix = [&]() {
+		uint32_t v0 = cnt[lane * 4], v1 = cnt[lane * 4 + 1], v2 = cnt[lane * 4 + 2], v3 = cnt[lane * 4 + 3];
+		uint32_t sum = v0 + v1 + v2 + v3;
+		uint32_t ex = wave_incl_scan(sum) - sum;
+		pre[lane * 4] = ex; pre[lane * 4 + 1] = ex + v0; pre[lane * 4 + 2] = ex + v0 + v1; pre[lane * 4 + 3] = ex + v0 + v1 + v2;
+		__builtin_amdgcn_wave_barrier();
+	};
+	__builtin_amdgcn_wave_barrier();
+	rebuild_prefix();
+	for (uint32_t j0 = s; j0 < e; j0 += 64)
+	{
+		const uint32_t j = j0 + lane; const bool valid = j < e;
+		const uint32_t sym = valid ? (uint32_t)(skey[j] & 0xff) : 0u;
+		const uint32_t dst = valid ? sval[j] : 0u;
+		const uint32_t n_here = (e - j0) < 64 ? (e - j0) : 64;
+		uint32_t start = 0;
+		while (start < n_here)
+		{
+			const uint32_t r = (max_total - tot + adder - 1) / adder;
+			const uint32_t now = (n_here - start) < r ? (n_here - start) : r;
+			uint32_t less = 0, eq = 0;
+			for (uint32_t l = start; l < start + now; ++l)
+			{
+				const uint32_t o = __builtin_amdgcn_readlane(sym, l);
+				if (l < lane) { less += (o < sym) ? 1u : 0u; eq += (o == sym) ? 1u : 0u; }
+			}
+			const bool mine = lane >= start && lane < start + now;
+			if (mine) trip[dst] = pack_triple(pre[sym] + adder * less, cnt[sym] + adder * eq, tot + adder * (lane - start));
+			__builtin_amdgcn_wave_barrier();
+			if (mine) atomicAdd(&cnt[sym], adder);
+			__builtin_amdgcn_wave_barrier();
+			tot += adder * now;
+			while (tot >= max_total)
+			{
+				uint32_t sum = 0;
+#pragma unroll
+				for (uint32_t t = 0; t < 4; ++t) { uint32_t a = lane * 4 + t; if (a < n_sym) { uint32_t v = (cnt[a] + 1) / 2; cnt[a] = v; sum += v; } }
+				tot = wave_sum(sum);
+			}
+			__builtin_amdgcn_wave_barrier();
+			rebuild_prefix();
+			start += now;
+		}
+	}
+#pragma unroll
+	for (uint32_t t = 0; t < 4; ++t) { uint32_t a = lane * 4 + t; if (a < n_sym) sp[a] = cnt[a]; }
+	if (lane == 0) sp[n_sym] = tot;
+}
+
+__global__ void k_init_fam_state(const FamTab* __restrict__ ftp, uint32_t fam, uint32_t* __restrict__ state)
+{
+	const FamTab& ft = *ftp;
+	const uint32_t ns = ft.n_sym[fam];
+	const uint64_t n = (uint64_t)ft.n_ctx[fam] * (ns + 1);
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+		state[ft.state_base[fam] + i] = (i % (ns + 1)) == ns ? ns : 1u;
+}
+__global__ void k_gather_bytes2(const uint8_t* __restrict__ src, const uint64_t* __restrict__ src_off, const uint64_t* __restrict__ dst_off,
+                                const uint64_t* __restrict__ size, uint8_t* __restrict__ dst)
+{
+	const uint32_t p = blockIdx.x;
+	const uint64_t n = size[p]; const uint8_t* s = src + src_off[p]; uint8_t* d = dst + dst_off[p];
+	for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
+}
+__global__ void k_last_types(const uint8_t* __restrict__ flag, uint32_t n, uint32_t prev, uint32_t* __restrict__ out)
+{
+	// types of the last four reads, most recent in the low bits (as ctx_read_type keeps them)
+	uint32_t v = prev;
+	uint32_t start = n > 4 ? n - 4 : 0;
+	for (uint32_t i = start; i < n; ++i) v = ((v << 2) + flag[i]) & 0xff;
+	*out = v;
+}
+} // namespace
+
+struct cl_dna_coder {
+	cl_ctx* ctx = nullptr;
+	FamTab ft;
+	DevBuf<FamTab> d_ft;
+	DevBuf<uint32_t> state;
+	uint32_t cur_read_id = 0;        // CDNACoder::cur_read_id
+	uint32_t prev_types = 0;         // ctx_read_type (types of the last four reads)
+};
+
+// CDNACoder::Init(true, max_no_alt_refs, level, ., start_read_id) (dna_coder.cpp:1242-1340)
+extern "C" cl_status cl_dna_coder_create(cl_ctx* ctx, uint32_t max_alt_refs, int32_t level, uint32_t start_read_id, cl_dna_coder** out)
+{
+	if (!ctx || !out) return cl_fail(ctx, CL_E_INVALID, "cl_dna_coder_create: null argument");
+	if (level < 1 || level > 3 || max_alt_refs < 1 || max_alt_refs > MAX_ALT) return cl_fail(ctx, CL_E_INVALID, "cl_dna_coder_create: level 1..3, 1 <= max_alt_refs <= 64");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	cl_dna_coder* D = new cl_dna_coder(); D->ctx = ctx; D->cur_read_id = start_read_id;
+	std::unique_ptr<cl_dna_coder> guard(D);
+	FamTab& f = D->ft; memset(&f, 0, sizeof(f));
+	f.level = level; f.max_alt = max_alt_refs;
+	f.T = level == 3 ? 4 : level == 2 ? 3 : 2;
+	f.S = level == 3 ? 8 : level == 2 ? 7 : 5;
+	f.sym_B = level == 3 ? 24 : level == 2 ? 23 : 22;
+	auto set = [&](int i, uint32_t ns, uint32_t mt, uint32_t ad, uint32_t nc) { f.n_sym[i] = ns; f.max_total[i] = mt; f.adder[i] = ad; f.n_ctx[i] = nc; };
+	set(F_READ_TYPE, 3, 1u << 15, 1, 256);                  // dna_coder.h:48-60
+	set(F_REV_COMP, 2, 1u << 15, 1, 16);
+	set(F_SEEN, 2, 1u << 15, 1, MAX_ALT + 1);
+	set(F_LEN_BITS, 32, 1u << 18, 8, 1);
+	set(F_LEN_DATA, 256, 1u << 18, 8, 512);
+	set(F_SYMBOLS, 4, 1u << 10, 1, 1u << (f.sym_B + 1));
+	set(F_SYMBOLS_N, 5, 1u << 10, 1, 1u << 16);
+	set(F_READ_ID, 256, 1u << 13, 1, 2048);
+	set(F_READ_ID_SHORT, max_alt_refs, 1u << 13, 1, MAX_ALT + 1);
+	set(F_ANCHOR_LEN, 24, 1u << 15, 1, 1u << 17);
+	set(F_SKIP_LOCAL, 256, 1u << 15, 1, 1u << 14);
+	set(F_SKIP_DISTANT, 256, 1u << 15, 1, 256);
+	set(F_TUPLE_TYPE, 8, 1u << 15, 1, 1u << (3 * f.T + 10));
+	uint64_t cb = 0, sb = 0;
+	for (int i = 0; i < N_FAM; ++i) { f.ctx_base[i] = (uint32_t)cb; f.state_base[i] = sb; cb += f.n_ctx[i]; sb += (uint64_t)f.n_ctx[i] * (f.n_sym[i] + 1); }
+	f.ctx_base[N_FAM] = (uint32_t)cb; f.state_base[N_FAM] = sb;
+	if (cb >= (1ull << 32)) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_dna_coder_create: context space too large");
+	DEV_ALLOC(ctx, D->d_ft, 1);
+	HIP_TRY(ctx, hipMemcpyAsync(D->d_ft.p, &f, sizeof(f), hipMemcpyHostToDevice, ctx->stream));
+	DEV_ALLOC(ctx, D->state, sb);
+	for (uint32_t i = 0; i < N_FAM; ++i) LAUNCH(ctx, k_init_fam_state, 2048, 256, (const FamTab*)D->d_ft.p, i, D->state.p);
+	HIP_TRY(ctx, hipGetLastError());
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	*out = guard.release();
+	return CL_OK;
+}
+extern "C" void cl_dna_coder_free(cl_dna_coder* d) { delete d; }
+
+// CEntrComprReads::Compress for a batch of whole parts (entr_read.h:56-80)
+extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads* refs, const uint8_t* d_es, const uint64_t* d_es_off,
+                                   const uint32_t* d_es_ntuples, uint32_t n_reads, const uint32_t* h_part_bounds, uint32_t n_parts,
+                                   uint8_t* d_out, uint64_t cap, uint64_t* h_part_sizes, uint64_t* n_out)
+{
+	if (!ctx || !D || !refs || !d_es || !d_es_off || !d_es_ntuples || !h_part_bounds || !h_part_sizes || !n_out) return cl_fail(ctx, CL_E_INVALID, "cl_dna_encode: null argument");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	for (uint32_t p = 0; p < n_parts; ++p) if (h_part_bounds[p] > h_part_bounds[p + 1]) return cl_fail(ctx, CL_E_INVALID, "cl_dna_encode: part bounds must ascend");
+	if (n_parts && (h_part_bounds[0] != 0 || h_part_bounds[n_parts] != n_reads)) return cl_fail(ctx, CL_E_INVALID, "cl_dna_encode: parts must cover reads [0, n_reads)");
+	*n_out = 0;
+	if (!n_parts) return CL_OK;
+	const FamTab& f = D->ft;
+	RefStore R{ refs->packed.p, refs->word_off.p, refs->lens.p, refs->n_reads };
+	uint64_t written = 0;
+	// tuple counts bound the number of symbols: group parts so that a group stays below ~2^28 tuples
+	std::vector<uint32_t> h_ntup(n_reads);
+	HIP_TRY(ctx, hipMemcpy(h_ntup.data(), d_es_ntuples, (uint64_t)n_reads * 4, hipMemcpyDeviceToHost));
+	std::vector<uint64_t> tup_prefix(n_reads + 1, 0);
+	for (uint32_t i = 0; i < n_reads; ++i) tup_prefix[i + 1] = tup_prefix[i] + h_ntup[i];
+	const uint64_t GROUP_TUPLES = 1ull << 28;
+	uint32_t p0 = 0;
+	while (p0 < n_parts)
+	{
+		uint32_t p1 = p0 + 1;
+		while (p1 < n_parts && tup_prefix[h_part_bounds[p1 + 1]] - tup_prefix[h_part_bounds[p0]] <= GROUP_TUPLES) ++p1;
+		const uint32_t r0 = h_part_bounds[p0], r1 = h_part_bounds[p1], nr = r1 - r0, np = p1 - p0, ng = (np + 63) / 64;
+		DevBuf<uint8_t> rflag; DEV_ALLOC(ctx, rflag, nr);
+		DevBuf<uint32_t> counts, hdr; DEV_ALLOC(ctx, counts, nr); DEV_ALLOC(ctx, hdr, nr);
+		DevBuf<uint64_t> sym_off; DEV_ALLOC(ctx, sym_off, (uint64_t)nr + 1);
+		DevBuf<uint32_t> err; DEV_ALLOC(ctx, err, 1);
+		HIP_TRY(ctx, hipMemsetAsync(err.p, 0, 4, ctx->stream));
+		TripLayoutDev nolay{ nullptr, nullptr, nullptr, 0 };
+		uint64_t n_syms = 0;
+		if (nr)
+		{
+			LAUNCH(ctx, k_read_flags, grid_for(nr, 256), 256, d_es, d_es_off, r0, r1, rflag.p);
+			LAUNCH(ctx, (k_dna_walk<false>), grid_for(nr, 64), 64, (const FamTab*)D->d_ft.p, R, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, r0, r1,
+				D->prev_types, D->cur_read_id, nolay, counts.p, hdr.p, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, err.p);
+			HIP_TRY(ctx, hipGetLastError());
+		}
+		CL_TRY(dev_exclusive_scan_u64(ctx, counts.p, sym_off.p, nr, &n_syms));
+		if (n_syms >= (1ull << 31)) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_dna_encode: group has >= 2^31 symbols");
+		// part geometry
+		std::vector<uint64_t> h_sym_off((size_t)nr + 1);
+		HIP_TRY(ctx, hipMemcpy(h_sym_off.data(), sym_off.p, ((uint64_t)nr + 1) * 8, hipMemcpyDeviceToHost));
+		std::vector<uint64_t> sym_start(np + 1), gbase(ng + 1);
+		std::vector<uint32_t> plen(np), pfirst(np + 1);
+		for (uint32_t p = 0; p <= np; ++p) { pfirst[p] = h_part_bounds[p0 + p]; sym_start[p] = h_sym_off[pfirst[p] - r0]; }
+		for (uint32_t p = 0; p < np; ++p) plen[p] = (uint32_t)(sym_start[p + 1] - sym_start[p]);
+		gbase[0] = 0;
+		for (uint32_t g = 0; g < ng; ++g)
+		{
+			uint32_t lm = 0;
+			for (uint32_t p = g * 64; p < std::min(np, g * 64 + 64); ++p) lm = std::max(lm, plen[p]);
+			gbase[g + 1] = gbase[g] + (uint64_t)lm * 64;
+		}
+		if (gbase[ng] >= (1ull << 32)) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_dna_encode: group too large for 32-bit triple indices");
+		DevBuf<uint64_t> d_sym_start, d_gbase; DevBuf<uint32_t> d_plen, d_pfirst;
+		DEV_ALLOC(ctx, d_sym_start, np + 1); DEV_ALLOC(ctx, d_gbase, ng + 1); DEV_ALLOC(ctx, d_plen, np); DEV_ALLOC(ctx, d_pfirst, np + 1);
+		HIP_TRY(ctx, hipMemcpyAsync(d_sym_start.p, sym_start.data(), (np + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(ctx, hipMemcpyAsync(d_gbase.p, gbase.data(), (ng + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(ctx, hipMemcpyAsync(d_plen.p, plen.data(), np * 4, hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(ctx, hipMemcpyAsync(d_pfirst.p, pfirst.data(), (np + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+		TripLayoutDev lay{ d_pfirst.p, d_sym_start.p, d_gbase.p, np };
+		DevBuf<triple_t> trip; DEV_ALLOC(ctx, trip, gbase[ng]);
+		if (n_syms)
+		{
+			DevBuf<uint64_t> key; DevBuf<uint32_t> sidx; DEV_ALLOC(ctx, key, n_syms); DEV_ALLOC(ctx, sidx, n_syms);
+			LAUNCH(ctx, (k_dna_walk<true>), grid_for(nr, 64), 64, (const FamTab*)D->d_ft.p, R, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, r0, r1,
+				D->prev_types, D->cur_read_id, lay, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint64_t*)sym_off.p, key.p, sidx.p, err.p);
+			LAUNCH(ctx, k_dna_plain, grid_for(nr, 4), 256, (const FamTab*)D->d_ft.p, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, (const uint32_t*)hdr.p,
+				(const uint64_t*)sym_off.p, r0, r1, lay, key.p, sidx.p);
+			HIP_TRY(ctx, hipGetLastError());
+			uint32_t cbits = 1; while ((1ull << cbits) < f.ctx_base[N_FAM]) ++cbits;
+			CL_TRY(dev_sort_pairs(ctx, key.p, sidx.p, n_syms, 16, 16 + cbits));
+			DevBuf<uint32_t> hf; DEV_ALLOC(ctx, hf, n_syms);
+			LAUNCH(ctx, k_ctx_heads, grid_for(n_syms, 256), 256, (const uint64_t*)key.p, n_syms, hf.p);
+			uint64_t n_seg = 0;
+			CL_TRY(dev_exclusive_scan_u32(ctx, hf.p, n_syms, &n_seg));
+			DevBuf<uint32_t> seg; DEV_ALLOC(ctx, seg, n_seg + 1);
+			LAUNCH(ctx, k_seg_starts, grid_for(n_syms, 256), 256, (const uint32_t*)hf.p, n_syms, n_seg, seg.p);
+			LAUNCH(ctx, k_dna_evolve, grid_for(n_seg, 4), 256, (const FamTab*)D->d_ft.p, (const uint64_t*)key.p, (const uint32_t*)sidx.p, (const uint32_t*)seg.p,
+				(uint32_t)n_seg, D->state.p, trip.p);
+			HIP_TRY(ctx, hipGetLastError());
+			HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		}
+		uint32_t herr = 0;
+		HIP_TRY(ctx, hipMemcpy(&herr, err.p, 4, hipMemcpyDeviceToHost));
+		if (herr) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_dna_encode: a read uses more than 64 alternative references");
+		// interval arithmetic per part
+		std::vector<uint64_t> out_off(np + 1);
+		out_off[0] = 0;
+		for (uint32_t p = 0; p < np; ++p) { uint64_t s = plen[p]; out_off[p + 1] = out_off[p] + ((s * 18 + 7) / 8 + s / 16 + 64 + 7) / 8 * 8; }
+		DevBuf<uint8_t> tmp; DEV_ALLOC(ctx, tmp, out_off[np]);
+		DevBuf<uint64_t> d_out_off, d_size, d_dst_off;
+		DEV_ALLOC(ctx, d_out_off, np + 1); DEV_ALLOC(ctx, d_size, np); DEV_ALLOC(ctx, d_dst_off, np);
+		HIP_TRY(ctx, hipMemcpyAsync(d_out_off.p, out_off.data(), (np + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+		LAUNCH(ctx, k_range_code, ng, 64, (const triple_t*)trip.p, (const uint64_t*)d_gbase.p, (const uint32_t*)d_plen.p, np, tmp.p, (const uint64_t*)d_out_off.p, d_size.p);
+		HIP_TRY(ctx, hipGetLastError());
+		HIP_TRY(ctx, hipMemcpyAsync(h_part_sizes + p0, d_size.p, np * 8, hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		for (uint32_t p = 0; p < np; ++p) if (h_part_sizes[p0 + p] == ~0ULL) return cl_fail(ctx, CL_E_CAPACITY, "cl_dna_encode: internal part buffer overflow");
+		std::vector<uint64_t> dst_off(np);
+		uint64_t w = written;
+		for (uint32_t p = 0; p < np; ++p) { dst_off[p] = w; w += h_part_sizes[p0 + p]; }
+		if (w > cap) { *n_out = w; return cl_fail(ctx, CL_E_CAPACITY, "cl_dna_encode: output capacity " + std::to_string(cap) + " too small"); }
+		HIP_TRY(ctx, hipMemcpyAsync(d_dst_off.p, dst_off.data(), np * 8, hipMemcpyHostToDevice, ctx->stream));
+		LAUNCH(ctx, k_gather_bytes2, np, 256, (const uint8_t*)tmp.p, (const uint64_t*)d_out_off.p, (const uint64_t*)d_dst_off.p, (const uint64_t*)d_size.p, d_out);
+		// carry the coder state to the next group / call
+		DevBuf<uint32_t> lt; DEV_ALLOC(ctx, lt, 1);
+		LAUNCH(ctx, k_last_types, 1, 1, (const uint8_t*)rflag.p, nr, D->prev_types, lt.p);
+		HIP_TRY(ctx, hipGetLastError());
+		HIP_TRY(ctx, hipMemcpyAsync(&D->prev_types, lt.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		D->cur_read_id += nr;
+		written = w;
+		p0 = p1;
+	}
+	cl_timing_collect(ctx);
+	*n_out = written;
+	return CL_OK;
+}

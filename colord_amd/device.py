@@ -196,6 +196,12 @@ class Context:
         _check(self, self.lib.cl_qual_coder_create(self.h, C.byref(prm), C.byref(h)))
         return QualCoder(self, h)
 
+    # ---- a14 ----
+    def dna_coder(self, max_alt_refs: int, level: int, start_read_id: int = 0) -> "DnaCoder":
+        h = N._P()
+        _check(self, self.lib.cl_dna_coder_create(self.h, max_alt_refs, level, start_read_id, C.byref(h)))
+        return DnaCoder(self, h)
+
     def sort_u64(self, keys: torch.Tensor, vals: torch.Tensor | None = None, begin_bit=0, end_bit=64):
         if vals is None:
             _check(self, self.lib.cl_sort_u64(self.h, keys.data_ptr(), keys.numel(), begin_bit, end_bit))
@@ -301,3 +307,22 @@ class QualCoder(_Obj):
                 raise N.ColordHipError(st, "qual output capacity exceeded after models advanced; retry with a larger cap")
             _check(ctx, st)
             return out[:n.value], [int(x) for x in sizes[:n_parts]]
+
+
+class DnaCoder(_Obj):
+    _free = "cl_dna_coder_free"
+
+    def encode(self, refs: "Reads", es: torch.Tensor, es_off: torch.Tensor, es_ntuples: torch.Tensor, part_bounds):
+        """Returns (payload bytes tensor on device, list of part sizes)."""
+        ctx = self.ctx
+        pb = np.ascontiguousarray(part_bounds, dtype=np.uint32)
+        n_parts = len(pb) - 1
+        n_reads = es_off.numel() - 1
+        sizes = np.zeros(max(n_parts, 1), np.uint64)
+        cap = max(4096, int(es.numel() * 0.6) + 64 * n_parts)
+        out = torch.empty(cap, dtype=torch.uint8, device=ctx.device)
+        n = C.c_uint64(0)
+        st = ctx.lib.cl_dna_encode(ctx.h, self.h, refs.h, es.data_ptr(), es_off.data_ptr(), es_ntuples.data_ptr(), n_reads,
+                                   pb.ctypes.data, n_parts, out.data_ptr(), cap, sizes.ctypes.data, C.byref(n))
+        _check(ctx, st)
+        return out[:n.value], [int(x) for x in sizes[:n_parts]]

@@ -180,6 +180,21 @@ cl_status cl_qual_encode(cl_ctx* ctx, cl_qual_coder* q, const cl_reads* reads, c
                          const uint8_t* d_flags, const uint32_t* h_part_bounds, uint32_t n_parts,
                          uint8_t* d_out, uint64_t cap, uint64_t* h_part_sizes, uint64_t* n_out);
 
+/* ---- a14 + a16: CDNACoder / CEntrComprReads (dna_coder.{h,cpp}, entr_read.h:56-80) --------------------- */
+typedef struct cl_dna_coder cl_dna_coder;
+/* CDNACoder::Init(true, maxCandidates, level, ., n_ref_genome_pseudo_reads): one adaptive model set that
+ * persists across cl_dna_encode calls; start_read_id seeds cur_read_id. */
+cl_status cl_dna_coder_create(cl_ctx* ctx, uint32_t max_alt_refs, int32_t level, uint32_t start_read_id, cl_dna_coder** out);
+void cl_dna_coder_free(cl_dna_coder* d);
+/* CEntrComprReads::Compress for a batch of whole parts.  d_es: the reads' tuple streams (es_t byte layout,
+ * utils.h:56-273) back to back, d_es_off: n_reads+1 byte offsets, d_es_ntuples: es_t::size() per read.
+ * refs: arena whose read i is reference read i (CReferenceReads order).  Parts [h_part_bounds[p],
+ * h_part_bounds[p+1]) must cover [0, n_reads).  Output as for cl_qual_encode; the archive metadata of
+ * part p is its read count. */
+cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* d, const cl_reads* refs, const uint8_t* d_es, const uint64_t* d_es_off,
+                        const uint32_t* d_es_ntuples, uint32_t n_reads, const uint32_t* h_part_bounds, uint32_t n_parts,
+                        uint8_t* d_out, uint64_t cap, uint64_t* h_part_sizes, uint64_t* n_out);
+
 /* ---- a7: CReferenceReads (reference_reads.h:27-259) ---------------------------------------------- */
 /* Byte image of one stored reference read (4 bases/byte MSB first + trailing count byte) produced from
  * the arena; h_out needs (len+3)/4+1 bytes.  Used by the parity tests and by the host archive code. */
