@@ -113,6 +113,14 @@ def hot_path_step(ctx, reads, k, quals=None, qual_off=None, part_bounds=None):
         payload, sizes = qc.encode(reads, quals, qual_off, part_bounds)
         qc.free()
         out.update(qual_bytes=int(payload.numel()), qual_parts=len(sizes))
+        # a12 (plain form) + a14: DNA stream.  The anchor / edit-script encoder (a8-a11) is not on the GPU yet, so every
+        # read is emitted verbatim (what the reference does for a read without usable candidates) and coded with the
+        # real DNA coder at level 1; same parts as the quality stream (the decoder requires that, entr_qual.h:150-170).
+        es, es_off, es_nt = ctx.encode_plain(reads)
+        dc = ctx.dna_coder(p["c"], 1, 0)
+        dpayload, dsizes = dc.encode(reads, es, es_off, es_nt, part_bounds)
+        dc.free()
+        out.update(dna_bytes_all_plain=int(dpayload.numel()))
     index.free(); lists.free(); kset.free()
     return out
 
@@ -227,7 +235,8 @@ def main():
                                    f"k={args.k} f={PRESET['f']} ci={PRESET['ci']} cs={PRESET['cs']} c={PRESET['c']} (ONT default preset)",
                        "stages": "a1 k-mer scan, a2 count/filter, a3 set build, a4 accepted k-mers, a6 acceptor, a5 index+candidates"
                                  + ("" if args.no_qual else f", a13+a15 quality stream (4-avg, level 1, parts of {args.pack_symbols} symbols)")
-                                 + "; a8-a12 + a14 (anchors, edit scripts, DNA coder) not yet on GPU, not timed",
+                                 + ("" if args.no_qual else ", a12 plain tuple streams + a14 DNA stream coder (all reads verbatim)")
+                                 + "; a8-a11 (anchors, alignment, edit-script decisions) not yet on GPU, not timed: the DNA stream is valid but ~2x the reference's size",
                        "parallelism": f"reads sharded x{world}, k-mer set replicated" if world > 1 else "single GPU",
                        "sizes": info},
             "roofline": roof, "cpu_baseline": cb,

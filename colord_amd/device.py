@@ -196,6 +196,17 @@ class Context:
         _check(self, self.lib.cl_qual_coder_create(self.h, C.byref(prm), C.byref(h)))
         return QualCoder(self, h)
 
+    # ---- a12 (plain forms) ----
+    def encode_plain(self, reads: "Reads"):
+        n = reads.n_reads
+        cap = int(reads.total_bases) + n
+        es = torch.empty(max(cap, 1), dtype=torch.uint8, device=self.device)
+        off = torch.empty(n + 1, dtype=torch.int64, device=self.device)
+        nt = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        need = C.c_uint64(0)
+        _check(self, self.lib.cl_encode_plain(self.h, reads.h, es.data_ptr(), cap, off.data_ptr(), nt.data_ptr(), C.byref(need)))
+        return es[:need.value], off, nt[:n]
+
     # ---- a14 ----
     def dna_coder(self, max_alt_refs: int, level: int, start_read_id: int = 0) -> "DnaCoder":
         h = N._P()

@@ -180,6 +180,14 @@ cl_status cl_qual_encode(cl_ctx* ctx, cl_qual_coder* q, const cl_reads* reads, c
                          const uint8_t* d_flags, const uint32_t* h_part_bounds, uint32_t n_parts,
                          uint8_t* d_out, uint64_t cap, uint64_t* h_part_sizes, uint64_t* n_out);
 
+/* ---- a12 (plain forms): CEncoder::AddPlainRead / AddPlainReadWithN (encoder.cpp:663-681) --------------- */
+/* Tuple streams that store every read of the arena verbatim: `start_plain` (`start_plain_with_Ns` for reads
+ * containing N) + one `plain` tuple per base.  d_es needs total_bases + n_reads bytes (cap), d_es_off
+ * n_reads+1, d_es_ntuples n_reads.  This is what the reference emits for a read without usable candidates;
+ * the anchor / edit-script forms are not on the GPU yet. */
+cl_status cl_encode_plain(cl_ctx* ctx, const cl_reads* reads, uint8_t* d_es, uint64_t cap, uint64_t* d_es_off,
+                          uint32_t* d_es_ntuples, uint64_t* n_out);
+
 /* ---- a14 + a16: CDNACoder / CEntrComprReads (dna_coder.{h,cpp}, entr_read.h:56-80) --------------------- */
 typedef struct cl_dna_coder cl_dna_coder;
 /* CDNACoder::Init(true, maxCandidates, level, ., n_ref_genome_pseudo_reads): one adaptive model set that

@@ -78,3 +78,18 @@ def test_ragged_parts_and_state_across_calls_equal_oracle(ctx, cfg):
         exp.append(dc.finish_part())
     assert gpu_dna(ctx, g, bounds) == exp
     assert gpu_dna(ctx, g, bounds, split=3) == exp
+
+
+def test_plain_tuple_streams_match_reference(ctx):
+    """a12 plain forms: c1 (every read stored plain by the reference) and a set with N reads."""
+    for cfg in ("c1_ont_default", "s3m_ont_n_ratio"):
+        g = golden(cfg)
+        rs = g.reads
+        reads = ctx.pack_readset(rs)
+        es, off, nt = ctx.encode_plain(reads)
+        es, off, nt = es.cpu().numpy().tobytes(), off.cpu().numpy(), nt.cpu().numpy()
+        for i in range(rs.n_reads):
+            pack, ntup, raw = g.es[i]
+            if raw[0] >> 4 in (9, 11):                 # reads the reference stored plain
+                assert es[off[i]:off[i + 1]] == raw and nt[i] == ntup, (cfg, i)
+        reads.free()
