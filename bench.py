@@ -41,7 +41,10 @@ def parse():
     ap.add_argument("--coverage", type=float, default=16.7, help="genome = total bases / coverage (50 Gbases over 3 Gb)")
     ap.add_argument("--k", type=int, default=25)           # compression.cpp:84-88 for a 50 Gbase input
     ap.add_argument("--cpu-sample-bases", type=float, default=1.5e8)
-    XX
+    ap.add_argument("--pack-symbols", type=int, default=1 << 16,
+                    help="part (= range-coder restart) size in symbols.  4194304 reproduces the reference's packs (defs.h:45) and its exact "
+                         "bytes; smaller parts are equally valid archives (the reference decoder follows the part table), cost 8 flush "
+                         "bytes each (+0.04 %% at 64 Ki) and expose the parallelism the per-part dependent chain needs")
     ap.add_argument("--no-qual", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
