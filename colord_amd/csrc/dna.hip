@@ -584,7 +584,7 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 	HIP_TRY(ctx, hipMemcpy(h_ntup.data(), d_es_ntuples, (uint64_t)n_reads * 4, hipMemcpyDeviceToHost));
 	std::vector<uint64_t> tup_prefix(n_reads + 1, 0);
 	for (uint32_t i = 0; i < n_reads; ++i) tup_prefix[i + 1] = tup_prefix[i] + h_ntup[i];
-	const uint64_t GROUP_TUPLES = 1ull << 28;
+	const uint64_t GROUP_TUPLES = 3ull << 29;       // as few launches as 32-bit symbol indices allow (see qual.hip)
 	uint32_t p0 = 0;
 	while (p0 < n_parts)
 	{

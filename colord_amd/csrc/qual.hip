@@ -422,7 +422,10 @@ extern "C" cl_status cl_qual_encode(cl_ctx* ctx, cl_qual_coder* Q, const cl_read
 	const uint32_t bits_max = c.max_total == (1u << 20) ? 20 : 18;
 	uint64_t written = 0;
 	// process groups of parts so that one group's symbol stream stays below 2^31
-	const uint64_t GROUP_SYMS = 1ull << 29;
+	// One group of parts = one sort + one range-coding launch.  The per-part interval chain is latency bound (its
+	// duration is set by the longest part, not by the number of parts), so groups are made as large as 32-bit
+	// symbol indices allow: every extra launch would pay that latency again.
+	const uint64_t GROUP_SYMS = (1ull << 31) - (1ull << 24);
 	uint32_t p0 = 0;
 	while (p0 < n_parts)
 	{
