@@ -46,8 +46,9 @@ extern "C" cl_status cl_ctx_last_kernel_ms(const cl_ctx* c, const char* kernel, 
 extern "C" cl_status cl_ctx_kernel_times(cl_ctx* c, char* buf, uint64_t cap, uint64_t* needed)
 {
 	if (!c) return CL_E_INVALID;
+	cl_timing_collect(c);
 	std::string out;
-	for (auto& kv : c->times) out += kv.first + "\t" + std::to_string(kv.second.ms) + "\t" + std::to_string(kv.second.launches) + "\n";
+	for (auto& kv : c->times) out += kv.first + "\t" + std::to_string(kv.second.ms) + "\t" + std::to_string(kv.second.launches) + "\t" + std::to_string(kv.second.bytes) + "\n";
 	if (needed) *needed = out.size() + 1;
 	if (!buf || cap < out.size() + 1) return CL_E_CAPACITY;
 	memcpy(buf, out.c_str(), out.size() + 1);

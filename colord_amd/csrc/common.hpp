@@ -12,7 +12,7 @@
 
 #define CL_WAVE 64
 
-struct KernelTime { double ms = 0; uint32_t launches = 0; };
+struct KernelTime { double ms = 0; uint32_t launches = 0; double bytes = 0; };   // bytes = algorithmic HBM bytes of the timed launches
 
 // Grow-only caching device allocator: hipMalloc/hipFree cost ~0.1-1 ms each and synchronise the device,
 // which dominated short calls.  Blocks are binned by rounded size and reused across calls.
@@ -47,6 +47,8 @@ struct cl_ctx {
 	bool timing = false;
 	std::map<std::string, KernelTime> times;     // per-kernel accumulated HIP-event time of the last API call
 	std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
+	std::vector<double> pending_bytes;
+	double next_bytes = 0;                       // algorithmic bytes of the next LAUNCH (set by LAUNCHB)
 	std::vector<hipEvent_t> ev_pool;
 	int n_cu = 256;
 };
@@ -101,25 +103,29 @@ struct KernelTimer {
 		if (!c->timing) return;
 		(void)hipEventRecord(b, c->stream);
 		c->pending.push_back({ name, { a, b } });
+		c->pending_bytes.push_back(c->next_bytes); c->next_bytes = 0;
 	}
 };
 // every kernel launch goes through LAUNCH so that per-kernel HIP-event times are complete
 #define LAUNCH(ctx, kernel, grid, block, ...) do { KernelTimer _kt((ctx), #kernel); \
 	hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (ctx)->stream, __VA_ARGS__); } while (0)
+// LAUNCH with the algorithmic HBM byte count of this launch (for achieved-GB/s reporting)
+#define LAUNCHB(ctx, bytes, kernel, grid, block, ...) do { (ctx)->next_bytes = (double)(bytes); LAUNCH(ctx, kernel, grid, block, __VA_ARGS__); } while (0)
 static inline void cl_timing_begin(cl_ctx*) {}   // times accumulate until cl_ctx_kernel_times reports them
 static inline void cl_timing_collect(cl_ctx* c)
 {
 	if (!c->timing) return;
+	size_t pi = 0;
 	for (auto& p : c->pending)
 	{
 		(void)hipEventSynchronize(p.second.second);
 		float ms = 0; (void)hipEventElapsedTime(&ms, p.second.first, p.second.second);
 		std::string nm = p.first;
 		if (!nm.empty() && nm.front() == '(' && nm.back() == ')') nm = nm.substr(1, nm.size() - 2);
-		auto& t = c->times[nm]; t.ms += ms; t.launches += 1;
+		auto& t = c->times[nm]; t.ms += ms; t.launches += 1; t.bytes += c->pending_bytes[pi++];
 		c->ev_pool.push_back(p.second.first); c->ev_pool.push_back(p.second.second);
 	}
-	c->pending.clear();
+	c->pending.clear(); c->pending_bytes.clear();
 }
 
 // ---- device primitives ---------------------------------------------------------------------------

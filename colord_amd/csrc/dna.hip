@@ -646,7 +646,7 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 			CL_TRY(dev_exclusive_scan_u32(ctx, hf.p, n_syms, &n_seg));
 			DevBuf<uint32_t> seg; DEV_ALLOC(ctx, seg, n_seg + 1);
 			LAUNCH(ctx, k_seg_starts, grid_for(n_syms, 256), 256, (const uint32_t*)hf.p, n_syms, n_seg, seg.p);
-			LAUNCH(ctx, k_dna_evolve, grid_for(n_seg, 4), 256, (const FamTab*)D->d_ft.p, (const uint64_t*)key.p, (const uint32_t*)sidx.p, (const uint32_t*)seg.p,
+			LAUNCHB(ctx, n_syms * 28.0, k_dna_evolve, grid_for(n_seg, 4), 256, (const FamTab*)D->d_ft.p, (const uint64_t*)key.p, (const uint32_t*)sidx.p, (const uint32_t*)seg.p,
 				(uint32_t)n_seg, D->state.p, trip.p);
 			HIP_TRY(ctx, hipGetLastError());
 			HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -662,7 +662,7 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 		DevBuf<uint64_t> d_out_off, d_size, d_dst_off;
 		DEV_ALLOC(ctx, d_out_off, np + 1); DEV_ALLOC(ctx, d_size, np); DEV_ALLOC(ctx, d_dst_off, np);
 		HIP_TRY(ctx, hipMemcpyAsync(d_out_off.p, out_off.data(), (np + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-		LAUNCH(ctx, k_range_code, ng, 64, (const triple_t*)trip.p, (const uint64_t*)d_gbase.p, (const uint32_t*)d_plen.p, np, tmp.p, (const uint64_t*)d_out_off.p, d_size.p);
+		LAUNCHB(ctx, n_syms * 16.0, k_range_code, ng, 64, (const triple_t*)trip.p, (const uint64_t*)d_gbase.p, (const uint32_t*)d_plen.p, np, tmp.p, (const uint64_t*)d_out_off.p, d_size.p);
 		HIP_TRY(ctx, hipGetLastError());
 		HIP_TRY(ctx, hipMemcpyAsync(h_part_sizes + p0, d_size.p, np * 8, hipMemcpyDeviceToHost, ctx->stream));
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

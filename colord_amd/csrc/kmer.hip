@@ -4,6 +4,7 @@
 // test, ballot/prefix compaction.  No MFMA anywhere on this path.
 #include "common.hpp"
 #include "objects.hpp"
+static inline double cap_hint(uint64_t bases, uint32_t f) { return (double)bases / (f ? f : 1); }   // expected survivors, N/f
 #include <algorithm>
 
 // ======================================================================================================
@@ -232,7 +233,7 @@ extern "C" cl_status cl_kmer_scan(cl_ctx* ctx, const cl_reads* R, uint32_t k, ui
 	HIP_TRY(ctx, hipMemsetAsync(counter.p, 0, 8, ctx->stream));
 	if (R->total_words)
 	{
-		LAUNCH(ctx, k_kmer_scan, grid_for(R->total_words, 256), 256,
+		LAUNCHB(ctx, R->total_bases / 4.0 + R->total_bases / 8.0 + 8.0 * cap_hint(R->total_bases, f), k_kmer_scan, grid_for(R->total_words, 256), 256,
 			(const uint64_t*)R->packed.p, (const uint32_t*)R->inv.p, R->total_words, k, make_modtest(f), d_out, cap, counter.p);
 	}
 	HIP_TRY(ctx, hipGetLastError());
@@ -568,7 +569,7 @@ extern "C" cl_status cl_accepted_kmers(cl_ctx* ctx, const cl_kmer_set* S, const 
 	DevBuf<uint32_t> fmask; DEV_ALLOC(ctx, fmask, R->total_words);
 	if (R->total_words)
 	{
-		LAUNCH(ctx, k_found_mask, grid_for(R->total_words, 256), 256, (const uint64_t*)R->packed.p, (const uint32_t*)R->inv.p,
+		LAUNCHB(ctx, R->total_bases / 4.0 + R->total_bases / 8.0 + 4.0 * (R->total_bases / 32.0) + 64.0 * R->total_bases / f, k_found_mask, grid_for(R->total_words, 256), 256, (const uint64_t*)R->packed.p, (const uint32_t*)R->inv.p,
 			R->total_words, k, make_modtest(f), (const void*)S->slots.p, S->bmask, fmask.p);
 	}
 	HIP_TRY(ctx, hipGetLastError());

@@ -470,7 +470,7 @@ extern "C" cl_status cl_qual_encode(cl_ctx* ctx, cl_qual_coder* Q, const cl_read
 			DEV_ALLOC(ctx, key, per_base ? n_base : 0); DEV_ALLOC(ctx, sidx, per_base ? n_base : 0);
 			DEV_ALLOC(ctx, bkey, n_byte); DEV_ALLOC(ctx, bsidx, n_byte);
 			if (r1 > r0)
-				LAUNCH(ctx, k_qual_symbols, grid_for(r1 - r0, 4), 256, (const QualCfg*)Q->d_cfg.p, (const uint64_t*)R->packed.p, (const uint64_t*)R->word_off.p,
+				LAUNCHB(ctx, n_base * (1.0 + 0.25 + 8.0) + n_byte * 8.0, k_qual_symbols, grid_for(r1 - r0, 4), 256, (const QualCfg*)Q->d_cfg.p, (const uint64_t*)R->packed.p, (const uint64_t*)R->word_off.p,
 					d_quals, d_qual_off, d_flags, r0, r1, qo[p0], lay, key.p, sidx.p, bkey.p, bsidx.p);
 			HIP_TRY(ctx, hipGetLastError());
 			const uint32_t total_ctx_bits = c.ctx_bits + c.base_bits + (c.level > 1 ? 2 : 0);
@@ -484,10 +484,10 @@ extern "C" cl_status cl_qual_encode(cl_ctx* ctx, cl_qual_coder* Q, const cl_read
 				const uint32_t g = grid_for(c.n_ctx, 4);
 				switch (c.n_sym)
 				{
-				case 2: LAUNCH(ctx, (k_evolve_small<2>), g, 256, (const uint32_t*)key.p, (const uint32_t*)sidx.p, (const uint32_t*)ss.p, (const uint32_t*)se.p, c.n_ctx, c.sym_bits, c.max_total, c.adder, Q->state.p, trip.p); break;
-				case 4: LAUNCH(ctx, (k_evolve_small<4>), g, 256, (const uint32_t*)key.p, (const uint32_t*)sidx.p, (const uint32_t*)ss.p, (const uint32_t*)se.p, c.n_ctx, c.sym_bits, c.max_total, c.adder, Q->state.p, trip.p); break;
-				case 5: LAUNCH(ctx, (k_evolve_small<5>), g, 256, (const uint32_t*)key.p, (const uint32_t*)sidx.p, (const uint32_t*)ss.p, (const uint32_t*)se.p, c.n_ctx, c.sym_bits, c.max_total, c.adder, Q->state.p, trip.p); break;
-				default: LAUNCH(ctx, k_evolve_large, g, 256, (const uint32_t*)key.p, (const uint32_t*)sidx.p, (const uint32_t*)ss.p, (const uint32_t*)se.p, c.n_ctx, c.n_sym, c.sym_bits, c.max_total, c.adder, Q->state.p, trip.p); break;
+				case 2: LAUNCHB(ctx, n_base * 24.0, (k_evolve_small<2>), g, 256, (const uint32_t*)key.p, (const uint32_t*)sidx.p, (const uint32_t*)ss.p, (const uint32_t*)se.p, c.n_ctx, c.sym_bits, c.max_total, c.adder, Q->state.p, trip.p); break;
+				case 4: LAUNCHB(ctx, n_base * 24.0, (k_evolve_small<4>), g, 256, (const uint32_t*)key.p, (const uint32_t*)sidx.p, (const uint32_t*)ss.p, (const uint32_t*)se.p, c.n_ctx, c.sym_bits, c.max_total, c.adder, Q->state.p, trip.p); break;
+				case 5: LAUNCHB(ctx, n_base * 24.0, (k_evolve_small<5>), g, 256, (const uint32_t*)key.p, (const uint32_t*)sidx.p, (const uint32_t*)ss.p, (const uint32_t*)se.p, c.n_ctx, c.sym_bits, c.max_total, c.adder, Q->state.p, trip.p); break;
+				default: LAUNCHB(ctx, n_base * 24.0, k_evolve_large, g, 256, (const uint32_t*)key.p, (const uint32_t*)sidx.p, (const uint32_t*)ss.p, (const uint32_t*)se.p, c.n_ctx, c.n_sym, c.sym_bits, c.max_total, c.adder, Q->state.p, trip.p); break;
 				}
 				HIP_TRY(ctx, hipGetLastError());
 				HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -517,7 +517,7 @@ extern "C" cl_status cl_qual_encode(cl_ctx* ctx, cl_qual_coder* Q, const cl_read
 		DevBuf<uint64_t> d_out_off, d_size, d_dst_off;
 		DEV_ALLOC(ctx, d_out_off, np + 1); DEV_ALLOC(ctx, d_size, np); DEV_ALLOC(ctx, d_dst_off, np);
 		HIP_TRY(ctx, hipMemcpyAsync(d_out_off.p, out_off.data(), (np + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-		LAUNCH(ctx, k_range_code, ng, 64, (const triple_t*)trip.p, (const uint64_t*)d_gbase.p, (const uint32_t*)d_plen.p, np, tmp.p, (const uint64_t*)d_out_off.p, d_size.p);
+		LAUNCHB(ctx, n_syms * 16.0, k_range_code, ng, 64, (const triple_t*)trip.p, (const uint64_t*)d_gbase.p, (const uint32_t*)d_plen.p, np, tmp.p, (const uint64_t*)d_out_off.p, d_size.p);
 		HIP_TRY(ctx, hipGetLastError());
 		HIP_TRY(ctx, hipMemcpyAsync(h_part_sizes + p0, d_size.p, np * 8, hipMemcpyDeviceToHost, ctx->stream));
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

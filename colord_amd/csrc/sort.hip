@@ -98,15 +98,15 @@ cl_status sort_impl(cl_ctx* ctx, K* d_keys, uint32_t* d_vals, uint64_t n, uint32
 	for (uint32_t shift = begin_bit; shift < end_bit; shift += 8)
 	{
 		{
-			LAUNCH(ctx, (k_sort_hist<K>), nb, ST, (const K*)kin, n, shift, hist.p, nb);
+			LAUNCHB(ctx, n * sizeof(K), (k_sort_hist<K>), nb, ST, (const K*)kin, n, shift, hist.p, nb);
 		}
 		HIP_TRY(ctx, hipGetLastError());
 		CL_TRY(dev_exclusive_scan_u32(ctx, hist.p, (uint64_t)256 * nb, nullptr));
 		{
 			if (d_vals)
-				LAUNCH(ctx, (k_sort_scatter<K, true>), nb, ST, (const K*)kin, (const uint32_t*)vin, kout, vout, n, shift, (const uint32_t*)hist.p, nb);
+				LAUNCHB(ctx, n * (2 * sizeof(K) + 8), (k_sort_scatter<K, true>), nb, ST, (const K*)kin, (const uint32_t*)vin, kout, vout, n, shift, (const uint32_t*)hist.p, nb);
 			else
-				LAUNCH(ctx, (k_sort_scatter<K, false>), nb, ST, (const K*)kin, (const uint32_t*)nullptr, kout, (uint32_t*)nullptr, n, shift, (const uint32_t*)hist.p, nb);
+				LAUNCHB(ctx, n * 2 * sizeof(K), (k_sort_scatter<K, false>), nb, ST, (const K*)kin, (const uint32_t*)nullptr, kout, (uint32_t*)nullptr, n, shift, (const uint32_t*)hist.p, nb);
 		}
 		HIP_TRY(ctx, hipGetLastError());
 		std::swap(kin, kout); std::swap(vin, vout);

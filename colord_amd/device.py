@@ -9,10 +9,11 @@ from . import _native as N
 
 def _check(ctx, st):
     if ctx is not None and getattr(ctx, "timing", False):
-        for n, (ms, k) in ctx.kernel_times().items():
-            a = ctx.acc.setdefault(n, [0.0, 0])
+        for n, (ms, k, b) in ctx.kernel_times().items():
+            a = ctx.acc.setdefault(n, [0.0, 0, 0.0])
             a[0] += ms
             a[1] += k
+            a[2] += b
     if st != N.CL_OK:
         msg = N.load().cl_last_error(ctx.h).decode() if ctx is not None and ctx.h else ""
         raise N.ColordHipError(st, msg)
@@ -74,8 +75,8 @@ class Context:
             return {}
         out = {}
         for line in buf.value.decode().splitlines():
-            n, ms, k = line.split("\t")
-            out[n] = (float(ms), int(k))
+            n, ms, k, b = line.split("\t")
+            out[n] = (float(ms), int(k), float(b))
         return out
 
     # ---- arena ----
