@@ -89,6 +89,18 @@ void orc_dna_add_ref(orc_dna*, const uint8_t* bases, uint32_t len);      /* CRef
 void orc_dna_encode(orc_dna*, const uint8_t* es, size_t n_bytes, uint32_t n_tuples);
 size_t orc_dna_finish_part(orc_dna*, uint8_t* dst, size_t cap);
 
+/* ---- a8-a12: CEncoder (encoder.{h,cpp}, edit_script.h, libs/edlib, utils.h:700-1131) ---------------- */
+typedef struct orc_encoder orc_encoder;
+orc_encoder* orc_encoder_new(uint32_t anchor_len, uint32_t kmer_len, uint32_t modulo, int source, double frac_always, double frac_min,
+                             double max_matches_mult, double cost_mult, uint32_t min_part_alt, uint32_t max_rec, uint32_t min_anchors);
+void orc_encoder_free(orc_encoder*);
+void orc_encoder_add_ref(orc_encoder*, const uint8_t* bases, uint32_t len);     /* CReferenceReads::Add */
+void orc_encoder_new_pack(orc_encoder*);                                          /* entropyEstimator.Reset() (encoder.cpp:1677) */
+/* processComprElem for one read; common/common_off (HiFi) may be NULL.  Returns the byte size of the tuple stream
+ * (written to out when cap suffices), *n_tuples = es_t::size(). */
+size_t orc_encoder_encode(orc_encoder*, const uint8_t* read, uint32_t len, int has_n, const uint32_t* neighbours, uint32_t n_nb,
+                          const uint64_t* common, const uint32_t* common_off, uint8_t* out, size_t cap, uint32_t* n_tuples);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,6 +62,13 @@ def lib():
         L.orc_dna_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32]
         L.orc_dna_finish_part.restype = C.c_size_t
         L.orc_dna_finish_part.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.orc_encoder_new.restype = C.c_void_p
+        L.orc_encoder_new.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.orc_encoder_free.argtypes = [C.c_void_p]
+        L.orc_encoder_add_ref.argtypes = [C.c_void_p, u8p, C.c_uint32]
+        L.orc_encoder_new_pack.argtypes = [C.c_void_p]
+        L.orc_encoder_encode.restype = C.c_size_t
+        L.orc_encoder_encode.argtypes = [C.c_void_p, u8p, C.c_uint32, C.c_int, u32p, C.c_uint32, C.c_void_p, C.c_void_p, u8p, C.c_size_t, C.POINTER(C.c_uint32)]
         _LIB = L
     return _LIB
 
@@ -208,3 +215,38 @@ class DnaCoder:
         buf = np.zeros(n, np.uint8)
         m = lib().orc_dna_finish_part(self.h, buf.ctypes.data, n)
         return buf[:m].tobytes()
+
+
+class Encoder:
+    """CEncoder for one encoder thread: per-pack estimator, reference reads added in reference-id order."""
+    def __init__(self, a, k, f, source, frac_always=0.9, frac_min=0.5, max_matches_mult=10.0, cost_mult=1.0, min_part_alt=64, max_rec=3, min_anchors=1):
+        self.h = lib().orc_encoder_new(a, k, f, source, frac_always, frac_min, max_matches_mult, cost_mult, min_part_alt, max_rec, min_anchors)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_encoder_free(self.h)
+            self.h = None
+
+    def add_ref(self, bases):
+        b = np.ascontiguousarray(bases, np.uint8)
+        lib().orc_encoder_add_ref(self.h, b if len(b) else np.zeros(1, np.uint8), len(b))
+
+    def new_pack(self):
+        lib().orc_encoder_new_pack(self.h)
+
+    def encode(self, read, has_n, neighbours, common=None):
+        r = np.ascontiguousarray(read, np.uint8)
+        nb = np.ascontiguousarray(neighbours, np.uint32)
+        if len(nb) == 0:
+            nb = np.zeros(1, np.uint32)
+        cptr = coff_ptr = None
+        if common is not None:
+            coff = np.concatenate([[0], np.cumsum([len(c) for c in common])]).astype(np.uint32)
+            call = np.concatenate(list(common) + [np.zeros(0, np.uint64)]).astype(np.uint64)
+            if len(call) == 0:
+                call = np.zeros(1, np.uint64)
+            cptr, coff_ptr = call.ctypes.data, coff.ctypes.data
+        out = np.zeros(2 * len(r) + 64, np.uint8)
+        nt = C.c_uint32(0)
+        n = lib().orc_encoder_encode(self.h, r if len(r) else np.zeros(1, np.uint8), len(r), int(has_n), nb, len(neighbours), cptr, coff_ptr, out, len(out), C.byref(nt))
+        return out[:n].tobytes(), nt.value
