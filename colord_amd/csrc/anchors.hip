@@ -1,0 +1,419 @@
+// anchors.hip — m-mer anchors between a read and its candidate reference reads (a8):
+// CMmers / AnalyseRefRead / get_aligned_mmers_LIS / MergeAnchors / MmerBasedAnchors / prepareEncodeCandidates /
+// fixOverlaping* (src/colord/encoder.cpp:291-493,617-776,1016-1111,1149-1192,1577-1622).
+//
+// Only SETS matter up to the LIS, so the per-read hash map with its duplicate side vectors
+// and the Bloom filter are replaced by:
+//   1. one open-addressing table per read in HBM: m-mer -> chain of its positions (built by all positions in
+//      parallel with CAS / exchange);
+//   2. one task per (read, candidate, orientation): every reference position looks its m-mer up and emits the
+//      (enc position, ref position) pairs — their number is exactly the reference's match count used for the
+//      "too many matches" veto;
+//   3. a device-wide radix sort of the pairs by (task, enc position asc, ref position desc) — the order in
+//      which the reference feeds its LIS;
+//   4. one lane per task replays the reference's patience LIS (same tie-breaking), its map-back scan and the
+//      merge of consecutive hits into anchors;
+//   5. per read: orientation choice (reverse complement wins ties), stable sort by total anchor length,
+//      overlap trimming in reference then in read coordinates.
+#include "common.hpp"
+#include "objects.hpp"
+#include <algorithm>
+
+struct cl_anchors {
+	cl_ctx* ctx = nullptr;
+	uint32_t n_reads = 0, c = 0;
+	uint64_t n_anchors = 0;
+	DevBuf<uint32_t> n_cands;     // n_reads
+	DevBuf<uint32_t> cand;        // n_reads * c * 4: ref_id, rev, tot_anchor_len, n_anchors
+	DevBuf<uint64_t> cand_off;    // n_reads * c + 1: first anchor of each candidate slot
+	DevBuf<uint32_t> anchors;     // n_anchors * 3: len, pos_enc, pos_ref
+};
+
+namespace {
+constexpr uint32_t POS_BITS = 20;                 // reads < 2^20 bases in this kernel family
+constexpr uint64_t POS_MASK = (1ull << POS_BITS) - 1;
+
+struct Arena { const uint64_t* packed; const uint64_t* word_off; const uint32_t* lens; };
+
+// m-mer (m <= 28) starting at base p of read r
+__device__ inline uint64_t mmer_at(const Arena& A, uint64_t wb, uint32_t p, uint32_t m)
+{
+	const uint64_t* w = A.packed + wb + (p >> 5);
+	const uint32_t j = p & 31;                     // first base inside word
+	const uint64_t hi = w[0], lo = w[1];
+	const uint32_t s = 128 - 2 * (j + m);
+	const uint64_t v = (s >= 64) ? (hi >> (s - 64)) : ((hi << (64 - s)) | (lo >> s));
+	return v & ((1ULL << (2 * m)) - 1);
+}
+__device__ inline uint64_t revcomp_m(uint64_t x, uint32_t m)
+{
+	x = ~x; x = __brevll(x);
+	x = ((x >> 1) & 0x5555555555555555ULL) | ((x & 0x5555555555555555ULL) << 1);
+	return x >> (64 - 2 * m);
+}
+// m-mer at position q of the oriented reference read (rev: reverse complement of the stored read)
+__device__ inline uint64_t ref_mmer(const Arena& R, uint32_t id, bool rev, uint32_t q, uint32_t m)
+{
+	const uint32_t len = R.lens[id];
+	const uint64_t wb = R.word_off[id];
+	return rev ? revcomp_m(mmer_at(R, wb, len - m - q, m), m) : mmer_at(R, wb, q, m);
+}
+
+struct EncTable { uint64_t* keys; uint32_t* heads; const uint64_t* toff; uint32_t* next; const uint64_t* noff; };
+constexpr uint64_t KEY_EMPTY = ~0ULL;
+constexpr uint32_t NIL = 0xffffffffu;
+
+// ---- A1: table sizes; one wave per read inserts every position --------------------------------------------
+__global__ void k_table_sizes(const uint32_t* __restrict__ lens, const uint8_t* __restrict__ has_n, const uint32_t* __restrict__ ncand,
+                              uint32_t r0, uint32_t r1, uint32_t m, uint32_t* __restrict__ tsize, uint32_t* __restrict__ nsize, uint32_t* __restrict__ err)
+{
+	uint32_t r = r0 + blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= r1) return;
+	uint32_t len = lens[r];
+	bool active = ncand[r] > 0 && !has_n[r] && len >= m;
+	if (active && len >= (1u << POS_BITS)) { atomicOr(err, 1u); active = false; }
+	uint32_t n = active ? len - m + 1 : 0;
+	uint32_t t = 0;
+	if (n) { t = 16; while (t < 2 * n + n / 2) t <<= 1; }
+	tsize[r - r0] = t; nsize[r - r0] = n;
+}
+__global__ __launch_bounds__(256) void k_table_insert(Arena A, uint32_t r0, uint32_t r1, uint32_t m, EncTable T, uint32_t* __restrict__ n_distinct)
+{
+	const uint32_t r = r0 + blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (r >= r1) return;
+	const uint64_t t0 = T.toff[r - r0]; const uint32_t tsz = (uint32_t)(T.toff[r - r0 + 1] - t0);
+	if (!tsz) return;
+	const uint64_t n0 = T.noff[r - r0]; const uint32_t n = (uint32_t)(T.noff[r - r0 + 1] - n0);
+	const uint64_t wb = A.word_off[r];
+	const uint32_t lane = threadIdx.x & 63;
+	uint32_t fresh = 0;
+	for (uint32_t p = lane; p < n; p += 64)
+	{
+		const uint64_t x = mmer_at(A, wb, p, m);
+		uint32_t h = (uint32_t)(hash_mm(x) >> 17) & (tsz - 1);
+		for (;;)
+		{
+			unsigned long long old = atomicCAS((unsigned long long*)&T.keys[t0 + h], (unsigned long long)KEY_EMPTY, (unsigned long long)x);
+			if (old == KEY_EMPTY) { ++fresh; break; }
+			if (old == x) break;
+			h = (h + 1) & (tsz - 1);
+		}
+		T.next[n0 + p] = atomicExch(&T.heads[t0 + h], p);
+	}
+	fresh = wave_sum(fresh);
+	if (lane == 0) n_distinct[r - r0] = fresh;
+}
+__device__ inline uint32_t table_head(const EncTable& T, uint64_t t0, uint32_t tsz, uint64_t x)
+{
+	uint32_t h = (uint32_t)(hash_mm(x) >> 17) & (tsz - 1);
+	for (;;)
+	{
+		const uint64_t k = T.keys[t0 + h];
+		if (k == x) return T.heads[t0 + h];
+		if (k == KEY_EMPTY) return NIL;
+		h = (h + 1) & (tsz - 1);
+	}
+}
+
+// ---- A2 / A3: one wave per task (read, candidate slot, orientation): count, then emit the match pairs ----------
+// task id t -> read r0 + t / (2c), slot (t / 2) % c, orientation t & 1 (0 = reverse complement, analysed first)
+struct TaskCfg { uint32_t r0, r1, c, m; float pad; double frac_always, frac_min, max_mult; };
+
+template<bool EMIT>
+__global__ __launch_bounds__(256) void k_match(Arena A, Arena R, EncTable T, TaskCfg cfg, const uint32_t* __restrict__ cand_refs, const uint32_t* __restrict__ cand_n,
+                                              const uint32_t* __restrict__ n_distinct, uint32_t n_tasks,
+                                              uint32_t* __restrict__ counts, const uint64_t* __restrict__ pair_off, uint64_t* __restrict__ pairs)
+{
+	const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (t >= n_tasks) return;
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t rl = t / (2 * cfg.c), slot = (t / 2) % cfg.c; const bool rev = (t & 1) == 0;
+	const uint32_t r = cfg.r0 + rl;
+	const uint64_t t0 = T.toff[rl]; const uint32_t tsz = (uint32_t)(T.toff[rl + 1] - t0);
+	uint32_t total = 0;
+	bool active = tsz != 0 && slot < cand_n[r];
+	uint32_t elen = 0;
+	if (active)
+	{	// read-level decision (encoder.cpp:1069-1078): refuse when too few distinct m-mers
+		elen = A.lens[r];
+		if ((double)n_distinct[rl] < cfg.frac_min * (double)elen && !((double)n_distinct[rl] > cfg.frac_always * (double)elen)) active = false;
+	}
+	uint32_t id = 0, rlen = 0;
+	if (active) { id = cand_refs[(uint64_t)r * cfg.c + slot]; rlen = R.lens[id]; if (rlen < cfg.m) active = false; }
+	if (!active) { if (!EMIT && lane == 0) counts[t] = 0; return; }
+	if (EMIT && pair_off[t + 1] == pair_off[t]) return;
+	const uint64_t n0 = T.noff[rl];
+	const uint32_t nq = rlen - cfg.m + 1;
+	uint64_t base = EMIT ? pair_off[t] : 0;
+	for (uint32_t q0 = 0; q0 < nq; q0 += 64)
+	{
+		const uint32_t q = q0 + lane;
+		uint32_t head = NIL, cnt = 0;
+		if (q < nq)
+		{
+			head = table_head(T, t0, tsz, ref_mmer(R, id, rev, q, cfg.m));
+			for (uint32_t p = head; p != NIL; p = T.next[n0 + p]) ++cnt;
+		}
+		if (!EMIT) { total += cnt; continue; }
+		const uint32_t incl = wave_incl_scan(cnt);
+		uint64_t o = base + incl - cnt;
+		for (uint32_t p = head; p != NIL; p = T.next[n0 + p])
+			pairs[o++] = ((uint64_t)t << (2 * POS_BITS)) | ((uint64_t)p << POS_BITS) | (uint64_t)(~q & (uint32_t)POS_MASK);
+		base += __shfl(incl, 63, 64);
+	}
+	if (!EMIT)
+	{
+		total = wave_sum(total);
+		if (lane == 0)
+		{	// "too many matches" veto unless the read is always encoded (encoder.cpp:1034-1042; enc_read.size() counts the guard)
+			bool always = (double)n_distinct[rl] > cfg.frac_always * (double)elen;
+			if (!always && (double)total > cfg.max_mult * (double)(elen + 1)) total = 0;
+			counts[t] = total;
+		}
+	}
+}
+
+// ---- A5: one lane per task: LIS (utils.cpp:157-209), map-back (encoder.cpp:644-658), MergeAnchors (:731-776) ----
+__device__ inline int lis_search(const int* __restrict__ tf, int size, int value)
+{
+	int low = 0;
+	while (size > 0)
+	{
+		const int half = size / 2, other_half = size - half, probe = low + half, other_low = low + other_half;
+		const int v = tf[probe];
+		size = half;
+		low = value > v ? other_low : low;
+	}
+	return low;
+}
+__global__ __launch_bounds__(64) void k_lis_anchors(Arena A, Arena R, TaskCfg cfg, const uint32_t* __restrict__ cand_refs, uint32_t n_tasks,
+                                                   const uint64_t* __restrict__ pair_off, const uint64_t* __restrict__ pairs,
+                                                   int* __restrict__ tf, int* __restrict__ ts, int* __restrict__ pred,
+                                                   uint32_t* __restrict__ anch, uint32_t* __restrict__ t_nanch, uint32_t* __restrict__ t_tot)
+{
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= n_tasks) return;
+	const uint64_t a = pair_off[t], b = pair_off[t + 1];
+	uint32_t n_anch = 0, tot = 0;
+	if (b > a)
+	{
+		const uint32_t n = (uint32_t)(b - a);
+		const uint64_t* P = pairs + a;
+		int* F = tf + a; int* S = ts + a; int* PR = pred + a;
+		auto ref_pos = [&](uint32_t i) -> int { return (int)(~(uint32_t)P[i] & (uint32_t)POS_MASK); };
+		auto enc_pos = [&](uint32_t i) -> uint32_t { return (uint32_t)(P[i] >> POS_BITS) & (uint32_t)POS_MASK; };
+		F[0] = ref_pos(0); S[0] = 0; PR[0] = -1;
+		int out_len = 1;
+		for (int i = 1; i < (int)n; ++i)
+		{
+			const int x = ref_pos((uint32_t)i);
+			int pos;
+			if (F[out_len - 1] < x) pos = out_len; else pos = lis_search(F, out_len, x);
+			if (pos == out_len) ++out_len;
+			F[pos] = x; S[pos] = i;
+			PR[i] = pos > 0 ? S[pos - 1] : -1;
+		}
+		// chain in increasing order: walk the predecessor links backwards, storing the pair indices in S (reused)
+		int cur = S[out_len - 1];
+		for (int i = out_len - 1; i >= 0; --i) { F[i] = cur; cur = PR[cur]; }       // F[i] = pair index of chain element i
+		// map-back + merge.  The reference re-derives the enc position by scanning the distinct enc positions forward for
+		// the next one that carries the chain element's m-mer.
+		const uint32_t rl = t / (2 * cfg.c), slot = (t / 2) % cfg.c; const bool rev = (t & 1) == 0;
+		const uint32_t r = cfg.r0 + rl;
+		const uint32_t id = cand_refs[(uint64_t)r * cfg.c + slot];
+		const uint64_t ewb = A.word_off[r];
+		uint32_t* out = anch + 3 * a;
+		uint32_t ep = 0;                                   // index into the pairs, positioned on the first pair of a distinct enc position
+		uint32_t run = 0, start_e = 0, start_r = 0, prev_e = 0, prev_r = 0;
+		for (int i = 0; i < out_len; ++i)
+		{
+			const uint32_t pr = (uint32_t)ref_pos((uint32_t)F[i]);
+			const uint64_t mm = ref_mmer(R, id, rev, pr, cfg.m);
+			uint32_t pe;
+			for (;;)
+			{
+				pe = enc_pos(ep);
+				const bool hit = mmer_at(A, ewb, pe, cfg.m) == mm;
+				do { ++ep; } while (ep < n && enc_pos(ep) == pe);      // advance to the next distinct enc position
+				if (hit || ep >= n) break;                              // (the scan always hits before the end; the bound only guards against a hang)
+			}
+			if (run && prev_e == pe - 1 && prev_r == pr - 1) ++run;
+			else
+			{
+				if (run) { out[3 * n_anch] = run + cfg.m - 1; out[3 * n_anch + 1] = start_e; out[3 * n_anch + 2] = start_r; tot += run + cfg.m - 1; ++n_anch; }
+				run = 1; start_e = pe; start_r = pr;
+			}
+			prev_e = pe; prev_r = pr;
+		}
+		if (run) { out[3 * n_anch] = run + cfg.m - 1; out[3 * n_anch + 1] = start_e; out[3 * n_anch + 2] = start_r; tot += run + cfg.m - 1; ++n_anch; }
+	}
+	t_nanch[t] = n_anch; t_tot[t] = tot;
+}
+
+// ---- A6: per read: orientation choice, stable sort by total anchor length (encoder.cpp:1106-1108,1157-1191) --------
+__global__ void k_select(TaskCfg cfg, const uint32_t* __restrict__ cand_refs, const uint32_t* __restrict__ cand_n, uint32_t min_anchors,
+                         const uint32_t* __restrict__ t_nanch, const uint32_t* __restrict__ t_tot,
+                         uint32_t* __restrict__ o_ncand, uint32_t* __restrict__ o_cand, uint32_t* __restrict__ o_task, uint32_t* __restrict__ o_count)
+{
+	const uint32_t r = cfg.r0 + blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= cfg.r1) return;
+	const uint32_t rl = r - cfg.r0, c = cfg.c;
+	uint32_t n = 0;
+	uint32_t sel_task[16], sel_tot[16];
+	const uint32_t nc = cand_n[r] < c ? cand_n[r] : c;
+	for (uint32_t j = 0; j < nc && j < 16; ++j)
+	{
+		const uint32_t trc = (rl * c + j) * 2, tfw = trc + 1;
+		const bool arc = t_nanch[trc] >= min_anchors && t_nanch[trc] > 0, afw = t_nanch[tfw] >= min_anchors && t_nanch[tfw] > 0;
+		int pick = -1;
+		if (arc && afw) pick = t_tot[tfw] > t_tot[trc] ? 1 : 0;       // reverse complement wins ties
+		else if (arc) pick = 0;
+		else if (afw) pick = 1;
+		if (pick >= 0) { sel_task[n] = trc + (uint32_t)pick; sel_tot[n] = t_tot[trc + pick]; ++n; }
+	}
+	for (uint32_t i = 1; i < n; ++i)                                 // insertion sort = libstdc++ std::sort on <= 16 elements, stable
+	{
+		uint32_t xt = sel_task[i], xv = sel_tot[i]; uint32_t j = i;
+		while (j > 0 && xv > sel_tot[j - 1]) { sel_task[j] = sel_task[j - 1]; sel_tot[j] = sel_tot[j - 1]; --j; }
+		sel_task[j] = xt; sel_tot[j] = xv;
+	}
+	o_ncand[r] = n;
+	for (uint32_t i = 0; i < c; ++i)
+	{
+		const uint64_t s = (uint64_t)r * c + i;
+		if (i < n)
+		{
+			const uint32_t t = sel_task[i], slot = (t / 2) % c;
+			o_cand[4 * s] = cand_refs[(uint64_t)r * c + slot]; o_cand[4 * s + 1] = (t & 1) == 0 ? 1u : 0u;
+			o_cand[4 * s + 2] = sel_tot[i]; o_cand[4 * s + 3] = t_nanch[t];
+			o_task[(uint64_t)rl * c + i] = t; o_count[(uint64_t)rl * c + i] = t_nanch[t];
+		}
+		else { o_cand[4 * s] = ~0u; o_cand[4 * s + 1] = 0; o_cand[4 * s + 2] = 0; o_cand[4 * s + 3] = 0; o_task[(uint64_t)rl * c + i] = ~0u; o_count[(uint64_t)rl * c + i] = 0; }
+	}
+}
+// ---- A7: copy the chosen anchors, trimming overlaps in reference then read coordinates (encoder.cpp:1577-1622) ------
+__global__ void k_copy_fix(const uint32_t* __restrict__ o_task, const uint64_t* __restrict__ slot_off, uint64_t n_slots,
+                           const uint64_t* __restrict__ pair_off, const uint32_t* __restrict__ anch, uint64_t dst_base, uint32_t* __restrict__ out)
+{
+	const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= n_slots) return;
+	const uint32_t t = o_task[s];
+	if (t == ~0u) return;
+	const uint32_t n = (uint32_t)(slot_off[s + 1] - slot_off[s]);
+	const uint32_t* src = anch + 3 * pair_off[t];
+	uint32_t* dst = out + 3 * (dst_base + slot_off[s]);
+	for (uint32_t i = 0; i < 3 * n; ++i) dst[i] = src[i];
+	for (uint32_t i = 0; i + 1 < n; ++i)
+	{
+		const uint32_t end = dst[3 * i + 2] + dst[3 * i];
+		if (dst[3 * (i + 1) + 2] < end) { const uint32_t d = end - dst[3 * (i + 1) + 2]; dst[3 * (i + 1) + 2] += d; dst[3 * (i + 1)] -= d; dst[3 * (i + 1) + 1] += d; }
+	}
+	for (uint32_t i = 0; i + 1 < n; ++i)
+	{
+		const uint32_t end = dst[3 * i + 1] + dst[3 * i];
+		if (dst[3 * (i + 1) + 1] < end) { const uint32_t d = end - dst[3 * (i + 1) + 1]; dst[3 * (i + 1) + 1] += d; dst[3 * (i + 1)] -= d; dst[3 * (i + 1) + 2] += d; }
+	}
+}
+__global__ void k_add_u64(uint64_t* v, uint64_t n, uint64_t c) { uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) v[i] += c; }
+} // namespace
+
+extern "C" cl_status cl_anchor_candidates(cl_ctx* ctx, const cl_reads* reads, const cl_reads* refs, const uint32_t* d_cand_refs, const uint32_t* d_cand_n,
+                                          uint32_t c, uint32_t anchor_len, double frac_always, double frac_min, double max_matches_mult,
+                                          uint32_t min_anchors, cl_anchors** out)
+{
+	if (!ctx || !reads || !refs || !d_cand_refs || !d_cand_n || !out) return cl_fail(ctx, CL_E_INVALID, "cl_anchor_candidates: null argument");
+	if (c == 0 || c > 16 || anchor_len < 2 || anchor_len > 28) return cl_fail(ctx, CL_E_INVALID, "cl_anchor_candidates: 1 <= c <= 16, 2 <= anchor_len <= 28");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	const uint32_t nr = reads->n_reads, m = anchor_len;
+	cl_anchors* X = new cl_anchors(); X->ctx = ctx; X->n_reads = nr; X->c = c;
+	std::unique_ptr<cl_anchors> guard(X);
+	DEV_ALLOC(ctx, X->n_cands, nr); DEV_ALLOC(ctx, X->cand, (uint64_t)nr * c * 4); DEV_ALLOC(ctx, X->cand_off, (uint64_t)nr * c + 1);
+	Arena A{ reads->packed.p, reads->word_off.p, reads->lens.p }, R{ refs->packed.p, refs->word_off.p, refs->lens.p };
+	std::vector<uint32_t> h_len(nr);
+	if (nr) HIP_TRY(ctx, hipMemcpy(h_len.data(), reads->lens.p, (uint64_t)nr * 4, hipMemcpyDeviceToHost));
+	// batches of reads: bounded by bases (tables) — the pair count is checked per batch
+	const uint64_t BATCH_BASES = 1ull << 28;
+	std::vector<DevBuf<uint32_t>> chunks; std::vector<uint64_t> chunk_n;
+	uint64_t total_anchors = 0;
+	uint32_t r0 = 0;
+	while (r0 < nr)
+	{
+		uint32_t r1 = r0; uint64_t acc = 0;
+		while (r1 < nr && (r1 == r0 || acc + h_len[r1] <= BATCH_BASES) && (uint64_t)(r1 - r0 + 1) * 2 * c < (1ull << 24)) { acc += h_len[r1]; ++r1; }
+		const uint32_t nb = r1 - r0, n_tasks = nb * 2 * c;
+		TaskCfg cfg{ r0, r1, c, m, 0.f, frac_always, frac_min, max_matches_mult };
+		DevBuf<uint32_t> tsize, nsize, err, n_distinct; DEV_ALLOC(ctx, tsize, nb); DEV_ALLOC(ctx, nsize, nb); DEV_ALLOC(ctx, err, 1); DEV_ALLOC(ctx, n_distinct, nb);
+		HIP_TRY(ctx, hipMemsetAsync(err.p, 0, 4, ctx->stream));
+		HIP_TRY(ctx, hipMemsetAsync(n_distinct.p, 0, (uint64_t)nb * 4, ctx->stream));
+		LAUNCH(ctx, k_table_sizes, grid_for(nb, 256), 256, (const uint32_t*)reads->lens.p, (const uint8_t*)reads->has_n.p, d_cand_n, r0, r1, m, tsize.p, nsize.p, err.p);
+		DevBuf<uint64_t> toff, noff; DEV_ALLOC(ctx, toff, (uint64_t)nb + 1); DEV_ALLOC(ctx, noff, (uint64_t)nb + 1);
+		uint64_t tsum = 0, nsum = 0;
+		CL_TRY(dev_exclusive_scan_u64(ctx, tsize.p, toff.p, nb, &tsum));
+		CL_TRY(dev_exclusive_scan_u64(ctx, nsize.p, noff.p, nb, &nsum));
+		uint32_t herr = 0; HIP_TRY(ctx, hipMemcpy(&herr, err.p, 4, hipMemcpyDeviceToHost));
+		if (herr) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_anchor_candidates: reads of 2^20 bases or more are not supported yet");
+		DevBuf<uint64_t> keys; DevBuf<uint32_t> heads, next; DEV_ALLOC(ctx, keys, tsum); DEV_ALLOC(ctx, heads, tsum); DEV_ALLOC(ctx, next, nsum);
+		HIP_TRY(ctx, hipMemsetAsync(keys.p, 0xff, tsum * 8, ctx->stream));
+		HIP_TRY(ctx, hipMemsetAsync(heads.p, 0xff, tsum * 4, ctx->stream));
+		EncTable T{ keys.p, heads.p, toff.p, next.p, noff.p };
+		LAUNCHB(ctx, nsum * (0.25 + 16.0), k_table_insert, grid_for(nb, 4), 256, A, r0, r1, m, T, n_distinct.p);
+		DevBuf<uint32_t> counts; DEV_ALLOC(ctx, counts, n_tasks);
+		DevBuf<uint64_t> pair_off; DEV_ALLOC(ctx, pair_off, (uint64_t)n_tasks + 1);
+		LAUNCH(ctx, (k_match<false>), grid_for(n_tasks, 4), 256, A, R, T, cfg, d_cand_refs, d_cand_n, (const uint32_t*)n_distinct.p, n_tasks, counts.p, (const uint64_t*)nullptr, (uint64_t*)nullptr);
+		HIP_TRY(ctx, hipGetLastError());
+		uint64_t n_pairs = 0;
+		CL_TRY(dev_exclusive_scan_u64(ctx, counts.p, pair_off.p, n_tasks, &n_pairs));
+		if (n_pairs >= (1ull << 32)) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_anchor_candidates: batch produces >= 2^32 match pairs");
+		DevBuf<uint64_t> pairs; DEV_ALLOC(ctx, pairs, n_pairs);
+		DevBuf<int> tf, ts, pred; DEV_ALLOC(ctx, tf, n_pairs); DEV_ALLOC(ctx, ts, n_pairs); DEV_ALLOC(ctx, pred, n_pairs);
+		DevBuf<uint32_t> anch; DEV_ALLOC(ctx, anch, 3 * n_pairs);
+		DevBuf<uint32_t> t_nanch, t_tot; DEV_ALLOC(ctx, t_nanch, n_tasks); DEV_ALLOC(ctx, t_tot, n_tasks);
+		if (n_pairs)
+		{
+			LAUNCHB(ctx, n_pairs * 8.0, (k_match<true>), grid_for(n_tasks, 4), 256, A, R, T, cfg, d_cand_refs, d_cand_n, (const uint32_t*)n_distinct.p, n_tasks, (uint32_t*)nullptr, (const uint64_t*)pair_off.p, pairs.p);
+			HIP_TRY(ctx, hipGetLastError());
+			uint32_t tb = 1; while ((1ull << tb) < n_tasks) ++tb;
+			CL_TRY(dev_sort_pairs(ctx, pairs.p, nullptr, n_pairs, 0, 2 * POS_BITS + tb));
+		}
+		LAUNCHB(ctx, n_pairs * 32.0, k_lis_anchors, grid_for(n_tasks, 64), 64, A, R, cfg, d_cand_refs, n_tasks, (const uint64_t*)pair_off.p, (const uint64_t*)pairs.p,
+			tf.p, ts.p, pred.p, anch.p, t_nanch.p, t_tot.p);
+		HIP_TRY(ctx, hipGetLastError());
+		const uint64_t n_slots = (uint64_t)nb * c;
+		DevBuf<uint32_t> o_task, o_count; DEV_ALLOC(ctx, o_task, n_slots); DEV_ALLOC(ctx, o_count, n_slots);
+		LAUNCH(ctx, k_select, grid_for(nb, 128), 128, cfg, d_cand_refs, d_cand_n, min_anchors, (const uint32_t*)t_nanch.p, (const uint32_t*)t_tot.p,
+			X->n_cands.p, X->cand.p, o_task.p, o_count.p);
+		DevBuf<uint64_t> slot_off; DEV_ALLOC(ctx, slot_off, n_slots + 1);
+		uint64_t n_here = 0;
+		CL_TRY(dev_exclusive_scan_u64(ctx, o_count.p, slot_off.p, n_slots, &n_here));
+		DevBuf<uint32_t> chunk; DEV_ALLOC(ctx, chunk, 3 * n_here);
+		LAUNCH(ctx, k_copy_fix, grid_for(n_slots, 128), 128, (const uint32_t*)o_task.p, (const uint64_t*)slot_off.p, n_slots, (const uint64_t*)pair_off.p,
+			(const uint32_t*)anch.p, (uint64_t)0, chunk.p);
+		// global candidate offsets of this batch
+		HIP_TRY(ctx, hipMemcpyAsync(X->cand_off.p + (uint64_t)r0 * c, slot_off.p, n_slots * 8, hipMemcpyDeviceToDevice, ctx->stream));
+		if (total_anchors) LAUNCH(ctx, k_add_u64, grid_for(n_slots, 256), 256, X->cand_off.p + (uint64_t)r0 * c, n_slots, total_anchors);
+		HIP_TRY(ctx, hipGetLastError());
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		chunks.push_back(std::move(chunk)); chunk_n.push_back(n_here);
+		total_anchors += n_here;
+		r0 = r1;
+	}
+	X->n_anchors = total_anchors;
+	DEV_ALLOC(ctx, X->anchors, 3 * total_anchors);
+	uint64_t o = 0;
+	for (size_t i = 0; i < chunks.size(); ++i)
+	{
+		if (chunk_n[i]) HIP_TRY(ctx, hipMemcpyAsync(X->anchors.p + 3 * o, chunks[i].p, chunk_n[i] * 12, hipMemcpyDeviceToDevice, ctx->stream));
+		o += chunk_n[i];
+	}
+	HIP_TRY(ctx, hipMemcpyAsync(X->cand_off.p + (uint64_t)nr * c, &total_anchors, 8, hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	cl_timing_collect(ctx);
+	*out = guard.release();
+	return CL_OK;
+}
+extern "C" void cl_anchors_free(cl_anchors* a) { delete a; }
+extern "C" uint64_t cl_anchors_total(const cl_anchors* a) { return a->n_anchors; }
+extern "C" const uint32_t* cl_anchors_n_cands(const cl_anchors* a) { return a->n_cands.p; }
+extern "C" const uint32_t* cl_anchors_cands(const cl_anchors* a) { return a->cand.p; }
+extern "C" const uint64_t* cl_anchors_cand_offsets(const cl_anchors* a) { return a->cand_off.p; }
+extern "C" const uint32_t* cl_anchors_data(const cl_anchors* a) { return a->anchors.p; }

@@ -197,6 +197,15 @@ class Context:
         _check(self, self.lib.cl_qual_coder_create(self.h, C.byref(prm), C.byref(h)))
         return QualCoder(self, h)
 
+    # ---- a8 ----
+    def anchor_candidates(self, reads: "Reads", refs: "Reads", cand_refs: torch.Tensor, cand_n: torch.Tensor, anchor_len: int,
+                          frac_always=0.9, frac_min=0.5, max_matches_mult=10.0, min_anchors=1) -> "Anchors":
+        c = cand_refs.shape[1]
+        h = N._P()
+        _check(self, self.lib.cl_anchor_candidates(self.h, reads.h, refs.h, cand_refs.contiguous().data_ptr(), cand_n.contiguous().data_ptr(), c, anchor_len,
+                                                   frac_always, frac_min, max_matches_mult, min_anchors, C.byref(h)))
+        return Anchors(self, h, reads.n_reads, c)
+
     # ---- a12 (plain forms) ----
     def encode_plain(self, reads: "Reads"):
         n = reads.n_reads
@@ -338,3 +347,18 @@ class DnaCoder(_Obj):
                                    pb.ctypes.data, n_parts, out.data_ptr(), cap, sizes.ctypes.data, C.byref(n))
         _check(ctx, st)
         return out[:n.value], [int(x) for x in sizes[:n_parts]]
+
+
+class Anchors(_Obj):
+    _free = "cl_anchors_free"
+
+    def __init__(self, ctx, h, n_reads, c):
+        super().__init__(ctx, h)
+        self.n_reads, self.c = n_reads, c
+
+    @property
+    def total(self): return self.ctx.lib.cl_anchors_total(self.h)
+    def n_cands(self): return self._arr("cl_anchors_n_cands", self.n_reads, torch.int32)
+    def cands(self): return self._arr("cl_anchors_cands", self.n_reads * self.c * 4, torch.int32).view(self.n_reads, self.c, 4)
+    def cand_offsets(self): return self._arr("cl_anchors_cand_offsets", self.n_reads * self.c + 1, torch.int64)
+    def data(self): return self._arr("cl_anchors_data", self.total * 3, torch.int32).view(-1, 3)

@@ -180,6 +180,24 @@ cl_status cl_qual_encode(cl_ctx* ctx, cl_qual_coder* q, const cl_reads* reads, c
                          const uint8_t* d_flags, const uint32_t* h_part_bounds, uint32_t n_parts,
                          uint8_t* d_out, uint64_t cap, uint64_t* h_part_sizes, uint64_t* n_out);
 
+/* ---- a8: m-mer anchors (encoder.cpp:291-493,617-776,1016-1111,1149-1192,1577-1622) ------------------------ */
+typedef struct cl_anchors cl_anchors;
+/* prepareEncodeCandidates + fixOverlaping* for every read of `reads` (non-HiFi path): for each of its <= c candidate
+ * reference ids (d_cand_refs row-major n_reads*c, d_cand_n per read — the output of cl_candidates; ids index `refs`,
+ * the arena of reference reads) both orientations are analysed: shared m-mers (m = anchor_len, not canonical), "too
+ * many matches" veto, LIS chain, merge into anchors; the better orientation is kept (reverse complement wins ties),
+ * candidates are sorted by total anchor length (stable) and overlaps trimmed.  Reads with N, shorter than m or with
+ * too few distinct m-mers get no candidates (they are stored plain). */
+cl_status cl_anchor_candidates(cl_ctx* ctx, const cl_reads* reads, const cl_reads* refs, const uint32_t* d_cand_refs, const uint32_t* d_cand_n,
+                               uint32_t c, uint32_t anchor_len, double frac_always, double frac_min, double max_matches_mult,
+                               uint32_t min_anchors, cl_anchors** out);
+void cl_anchors_free(cl_anchors* a);
+uint64_t cl_anchors_total(const cl_anchors* a);
+const uint32_t* cl_anchors_n_cands(const cl_anchors* a);        /* device, n_reads */
+const uint32_t* cl_anchors_cands(const cl_anchors* a);          /* device, n_reads*c*4: ref_id, rev, tot_anchor_len, n_anchors */
+const uint64_t* cl_anchors_cand_offsets(const cl_anchors* a);   /* device, n_reads*c+1: first anchor of each slot */
+const uint32_t* cl_anchors_data(const cl_anchors* a);           /* device, 3 per anchor: len, pos_in_enc, pos_in_ref */
+
 /* ---- a12 (plain forms): CEncoder::AddPlainRead / AddPlainReadWithN (encoder.cpp:663-681) --------------- */
 /* Tuple streams that store every read of the arena verbatim: `start_plain` (`start_plain_with_Ns` for reads
  * containing N) + one `plain` tuple per base.  d_es needs total_bases + n_reads bytes (cap), d_es_off

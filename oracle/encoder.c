@@ -810,6 +810,82 @@ static void add_encoded(orc_encoder* e, const uint8_t* enc, uint32_t enc_len, ca
 	str_free(&big); free(ref_read);
 }
 
+/* prepareEncodeCandidates[HiFi] (encoder.cpp:1058-1111,1194-1253) + fixOverlaping* (:1651-1655).
+ * Returns the number of candidates (0 = the read is stored plain). */
+static uint32_t prepare_candidates(orc_encoder* e, const uint8_t* read, uint32_t len, const uint32_t* neighbours, uint32_t n_nb,
+                                   const uint64_t* common, const uint32_t* common_off, cand_t** out)
+{
+	cand_t* cands = NULL; uint32_t n_cands = 0;
+	*out = NULL;
+	if (n_nb == 0) return 0;
+	mindex_t ix; mindex_build(&ix, read, len, e->m);
+	int decision = -1;
+	if ((double)ix.n_uniq > e->frac_always * (double)len) decision = 0;
+	else if ((double)ix.n_uniq < e->frac_min * (double)len) decision = 1;
+	if (decision != 1)
+	{
+		cands = (cand_t*)calloc(n_nb, sizeof(cand_t));
+		for (uint32_t i = 0; i < n_nb; ++i)
+		{
+			const uint32_t id = neighbours[i];
+			uint8_t* fwd = ref_oriented(e, id, 0); uint8_t* rc = ref_oriented(e, id, 1); const uint32_t rl = e->refs[id].len;
+			cand_t cf, cr; memset(&cf, 0, sizeof(cf)); memset(&cr, 0, sizeof(cr));
+			cf.ref_id = cr.ref_id = id; cr.rev = 1;
+			int chosen = -1;                           /* 0 fwd, 1 rc */
+			if (e->source == 2 && common)
+			{	/* KmerBasedAnchors (:1113-1147) */
+				uint32_t nc = common_off[i + 1] - common_off[i];
+				uint64_t* cs = (uint64_t*)malloc((nc ? nc : 1) * 8); memcpy(cs, common + common_off[i], nc * 8);
+				qsort(cs, nc, 8, cmp_u64);
+				int rr = analyse_ref_kmers(e, read, len, rc, rl, cs, nc, &cr);
+				int rf = analyse_ref_kmers(e, read, len, fwd, rl, cs, nc, &cf);
+				free(cs);
+				if (rr == KR_ACCEPT && rf == KR_ACCEPT) chosen = cf.tot > cr.tot ? 0 : 1;
+				else if (rr == KR_ACCEPT) chosen = 1;
+				else if (rf == KR_ACCEPT) chosen = 0;
+			}
+			if (chosen < 0)
+			{	/* MmerBasedAnchors (:1149-1192): reverse complement analysed first, wins ties */
+				int rr = analyse_ref(e, &ix, len, rc, rl, &cr, decision);
+				int rf = analyse_ref(e, &ix, len, fwd, rl, &cf, decision);
+				if (rr == AR_ACCEPT && rf == AR_ACCEPT) chosen = cf.tot > cr.tot ? 0 : 1;
+				else if (rr == AR_ACCEPT) chosen = 1;
+				else if (rf == AR_ACCEPT) chosen = 0;
+			}
+			if (chosen == 0) { cands[n_cands++] = cf; free(cr.a); }
+			else if (chosen == 1) { cands[n_cands++] = cr; free(cf.a); }
+			else { free(cf.a); free(cr.a); }
+			free(fwd); free(rc);
+		}
+		sort_cands_desc(cands, n_cands);
+	}
+	mindex_free(&ix);
+	for (uint32_t i = 0; i < n_cands; ++i) fix_overlaps(&cands[i]);
+	if (n_cands == 0) { free(cands); cands = NULL; }
+	*out = cands;
+	return n_cands;
+}
+
+/* The candidates of one read as the encoder will use them (after orientation choice, sort and overlap fixing):
+ * out_cand[i] = {ref_id, rev, tot_anchor_len, n_anchors}, anchors appended to out_anchors as {len, pos_enc, pos_ref}. */
+uint32_t orc_encoder_candidates(orc_encoder* e, const uint8_t* read, uint32_t len, const uint32_t* neighbours, uint32_t n_nb,
+                                const uint64_t* common, const uint32_t* common_off, uint32_t* out_cand, uint32_t* out_anchors, size_t cap_anchors, size_t* n_anchors)
+{
+	cand_t* c = NULL;
+	uint32_t n = prepare_candidates(e, read, len, neighbours, n_nb, common, common_off, &c);
+	size_t na = 0;
+	for (uint32_t i = 0; i < n; ++i)
+	{
+		out_cand[4 * i] = c[i].ref_id; out_cand[4 * i + 1] = (uint32_t)c[i].rev; out_cand[4 * i + 2] = c[i].tot; out_cand[4 * i + 3] = c[i].n;
+		for (uint32_t j = 0; j < c[i].n; ++j, ++na)
+			if (na < cap_anchors) { out_anchors[3 * na] = c[i].a[j].len; out_anchors[3 * na + 1] = c[i].a[j].pos_enc; out_anchors[3 * na + 2] = c[i].a[j].pos_ref; }
+		free(c[i].a);
+	}
+	free(c);
+	*n_anchors = na;
+	return n;
+}
+
 /* processComprElem (encoder.cpp:1625-1661) for one read.  neighbours: candidate reference ids from the graph;
  * common / common_off: HiFi shared k-mers per neighbour (NULL otherwise).  Returns the tuple stream. */
 size_t orc_encoder_encode(orc_encoder* e, const uint8_t* read, uint32_t len, int has_n, const uint32_t* neighbours, uint32_t n_nb,
@@ -820,57 +896,11 @@ size_t orc_encoder_encode(orc_encoder* e, const uint8_t* read, uint32_t len, int
 	cand_t* cands = NULL; uint32_t n_cands = 0;
 	if (has_n) { esb_t1(&b, 11, 0); for (uint32_t i = 0; i < len; ++i) esb_t1(&b, 8, read[i]); goto done; }
 	est_log_read(&e->est, read, len);
-	if (n_nb == 0) plain = 1;
-	else
-	{	/* prepareEncodeCandidates[HiFi] (:1058-1111,1194-1253) */
-		mindex_t ix; mindex_build(&ix, read, len, e->m);
-		int decision = -1;
-		if ((double)ix.n_uniq > e->frac_always * (double)len) decision = 0;
-		else if ((double)ix.n_uniq < e->frac_min * (double)len) decision = 1;
-		if (decision != 1)
-		{
-			cands = (cand_t*)calloc(n_nb, sizeof(cand_t));
-			for (uint32_t i = 0; i < n_nb; ++i)
-			{
-				const uint32_t id = neighbours[i];
-				uint8_t* fwd = ref_oriented(e, id, 0); uint8_t* rc = ref_oriented(e, id, 1); const uint32_t rl = e->refs[id].len;
-				cand_t cf, cr; memset(&cf, 0, sizeof(cf)); memset(&cr, 0, sizeof(cr));
-				cf.ref_id = cr.ref_id = id; cr.rev = 1;
-				int chosen = -1;                           /* 0 fwd, 1 rc */
-				if (e->source == 2 && common)
-				{	/* KmerBasedAnchors (:1113-1147) */
-					uint32_t nc = common_off[i + 1] - common_off[i];
-					uint64_t* cs = (uint64_t*)malloc((nc ? nc : 1) * 8); memcpy(cs, common + common_off[i], nc * 8);
-					qsort(cs, nc, 8, cmp_u64);
-					int rr = analyse_ref_kmers(e, read, len, rc, rl, cs, nc, &cr);
-					int rf = analyse_ref_kmers(e, read, len, fwd, rl, cs, nc, &cf);
-					free(cs);
-					if (rr == KR_ACCEPT && rf == KR_ACCEPT) chosen = cf.tot > cr.tot ? 0 : 1;
-					else if (rr == KR_ACCEPT) chosen = 1;
-					else if (rf == KR_ACCEPT) chosen = 0;
-				}
-				if (chosen < 0)
-				{	/* MmerBasedAnchors (:1149-1192): reverse complement analysed first, wins ties */
-					int rr = analyse_ref(e, &ix, len, rc, rl, &cr, decision);
-					int rf = analyse_ref(e, &ix, len, fwd, rl, &cf, decision);
-					if (rr == AR_ACCEPT && rf == AR_ACCEPT) chosen = cf.tot > cr.tot ? 0 : 1;
-					else if (rr == AR_ACCEPT) chosen = 1;
-					else if (rf == AR_ACCEPT) chosen = 0;
-				}
-				if (chosen == 0) { cands[n_cands++] = cf; free(cr.a); }
-				else if (chosen == 1) { cands[n_cands++] = cr; free(cf.a); }
-				else { free(cf.a); free(cr.a); }
-				free(fwd); free(rc);
-			}
-			sort_cands_desc(cands, n_cands);
-		}
-		mindex_free(&ix);
-		if (n_cands == 0) plain = 1;
-	}
+	n_cands = prepare_candidates(e, read, len, neighbours, n_nb, common, common_off, &cands);
+	if (n_cands == 0) plain = 1;
 	if (plain) { esb_t1(&b, 9, 0); for (uint32_t i = 0; i < len; ++i) esb_t1(&b, 8, read[i]); }
 	else
 	{
-		for (uint32_t i = 0; i < n_cands; ++i) fix_overlaps(&cands[i]);
 		int first = 1;
 		add_encoded(e, read, len, cands, n_cands, 0, &b, cands[0].ref_id, &first);
 	}

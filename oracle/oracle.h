@@ -98,6 +98,10 @@ void orc_encoder_add_ref(orc_encoder*, const uint8_t* bases, uint32_t len);     
 void orc_encoder_new_pack(orc_encoder*);                                          /* entropyEstimator.Reset() (encoder.cpp:1677) */
 /* processComprElem for one read; common/common_off (HiFi) may be NULL.  Returns the byte size of the tuple stream
  * (written to out when cap suffices), *n_tuples = es_t::size(). */
+/* a8/a9 only: the final candidate list of one read: out_cand[4*i..] = {ref_id, rev, tot_anchor_len, n_anchors},
+ * anchors {len, pos_enc, pos_ref} appended to out_anchors (capacity in anchors). */
+uint32_t orc_encoder_candidates(orc_encoder*, const uint8_t* read, uint32_t len, const uint32_t* neighbours, uint32_t n_nb,
+                                const uint64_t* common, const uint32_t* common_off, uint32_t* out_cand, uint32_t* out_anchors, size_t cap_anchors, size_t* n_anchors);
 size_t orc_encoder_encode(orc_encoder*, const uint8_t* read, uint32_t len, int has_n, const uint32_t* neighbours, uint32_t n_nb,
                           const uint64_t* common, const uint32_t* common_off, uint8_t* out, size_t cap, uint32_t* n_tuples);
 

@@ -67,6 +67,8 @@ def lib():
         L.orc_encoder_free.argtypes = [C.c_void_p]
         L.orc_encoder_add_ref.argtypes = [C.c_void_p, u8p, C.c_uint32]
         L.orc_encoder_new_pack.argtypes = [C.c_void_p]
+        L.orc_encoder_candidates.restype = C.c_uint32
+        L.orc_encoder_candidates.argtypes = [C.c_void_p, u8p, C.c_uint32, u32p, C.c_uint32, C.c_void_p, C.c_void_p, u32p, u32p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.orc_encoder_encode.restype = C.c_size_t
         L.orc_encoder_encode.argtypes = [C.c_void_p, u8p, C.c_uint32, C.c_int, u32p, C.c_uint32, C.c_void_p, C.c_void_p, u8p, C.c_size_t, C.POINTER(C.c_uint32)]
         _LIB = L
@@ -233,6 +235,30 @@ class Encoder:
 
     def new_pack(self):
         lib().orc_encoder_new_pack(self.h)
+
+    def candidates(self, read, neighbours, common=None):
+        """[(ref_id, rev, tot_anchor_len, [(len, pos_enc, pos_ref), ...]), ...] as the encoder will use them."""
+        r = np.ascontiguousarray(read, np.uint8)
+        nb = np.ascontiguousarray(neighbours, np.uint32)
+        if len(nb) == 0:
+            return []
+        cptr = coff_ptr = None
+        if common is not None:
+            coff = np.concatenate([[0], np.cumsum([len(c) for c in common])]).astype(np.uint32)
+            call = np.concatenate(list(common) + [np.zeros(0, np.uint64)]).astype(np.uint64)
+            if len(call) == 0:
+                call = np.zeros(1, np.uint64)
+            cptr, coff_ptr = call.ctypes.data, coff.ctypes.data
+        oc = np.zeros(4 * len(nb), np.uint32)
+        oa = np.zeros(3 * (len(r) + 16) * 2, np.uint32)
+        na = C.c_size_t(0)
+        n = lib().orc_encoder_candidates(self.h, r, len(r), nb, len(nb), cptr, coff_ptr, oc, oa, len(oa) // 3, C.byref(na))
+        out, o = [], 0
+        for i in range(n):
+            k = int(oc[4 * i + 3])
+            out.append((int(oc[4 * i]), int(oc[4 * i + 1]), int(oc[4 * i + 2]), [tuple(int(x) for x in oa[3 * (o + j):3 * (o + j) + 3]) for j in range(k)]))
+            o += k
+        return out
 
     def encode(self, read, has_n, neighbours, common=None):
         r = np.ascontiguousarray(read, np.uint8)
