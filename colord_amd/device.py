@@ -217,6 +217,28 @@ class Context:
         _check(self, self.lib.cl_encode_plain(self.h, reads.h, es.data_ptr(), cap, off.data_ptr(), nt.data_ptr(), C.byref(need)))
         return es[:need.value], off, nt[:n]
 
+    # ---- a10-a12 ----
+    def encode_reads(self, reads: "Reads", refs: "Reads", anchors: "Anchors", anchor_len: int, min_part_alt: int, max_rec: int, cost_mult: float,
+                     pack_bounds=None):
+        """CEncoder::Encode over the arena: returns (tuple bytes, byte offsets [n+1], tuple counts [n])."""
+        import numpy as np
+        n = reads.n_reads
+        pb = np.ascontiguousarray(np.asarray([0, n] if pack_bounds is None else pack_bounds, dtype=np.uint32))
+        off = torch.empty(n + 1, dtype=torch.int64, device=self.device)
+        nt = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        need = C.c_uint64(0)
+        cap = int(reads.total_bases) // 2 + 8 * n + 4096
+        for _ in range(2):
+            es = torch.empty(max(cap, 1), dtype=torch.uint8, device=self.device)
+            st = self.lib.cl_encode_reads(self.h, reads.h, refs.h, anchors.h, anchors.c, anchor_len, min_part_alt, max_rec, cost_mult,
+                                          pb.ctypes.data, len(pb) - 1, es.data_ptr(), cap, off.data_ptr(), nt.data_ptr(), C.byref(need))
+            if st == N.CL_E_CAPACITY and need.value > cap:
+                cap = need.value
+                continue
+            _check(self, st)
+            break
+        return es[:need.value], off, nt[:n]
+
     # ---- a14 ----
     def dna_coder(self, max_alt_refs: int, level: int, start_read_id: int = 0) -> "DnaCoder":
         h = N._P()

@@ -201,10 +201,22 @@ const uint32_t* cl_anchors_data(const cl_anchors* a);           /* device, 3 per
 /* ---- a12 (plain forms): CEncoder::AddPlainRead / AddPlainReadWithN (encoder.cpp:663-681) --------------- */
 /* Tuple streams that store every read of the arena verbatim: `start_plain` (`start_plain_with_Ns` for reads
  * containing N) + one `plain` tuple per base.  d_es needs total_bases + n_reads bytes (cap), d_es_off
- * n_reads+1, d_es_ntuples n_reads.  This is what the reference emits for a read without usable candidates;
- * the anchor / edit-script forms are not on the GPU yet. */
+ * n_reads+1, d_es_ntuples n_reads.  This is what the reference emits for a read without usable candidates. */
 cl_status cl_encode_plain(cl_ctx* ctx, const cl_reads* reads, uint8_t* d_es, uint64_t cap, uint64_t* d_es_off,
                           uint32_t* d_es_ntuples, uint64_t* n_out);
+
+/* ---- a10 + a11 + a12: CEncoder::Encode (encoder.cpp:1672-1691) on anchored candidates ------------------- */
+/* Every read of `reads` is encoded against its candidates from cl_anchor_candidates (same arena, same c):
+ * gaps between anchors are aligned with edlib's observable behaviour (edit_script.h:156-419), indels canonicalised
+ * (refactor_edit_script), each gap kept as edit script or replaced by literals / an alternative reference
+ * (EncodePart, EncodeWithAlternativeRead up to max_rec levels), and the result written as es_t tuple bytes
+ * (utils.h:56-273).  h_pack_bounds (n_packs+1 read indices, first 0, last n_reads) are the reader packs: the
+ * adaptive cost estimator (CEntropyEstimator, utils.h:877-1130) is reset at each of them (encoder.cpp:1677).
+ * Reads without candidates and reads with N are stored plain.  d_es (cap bytes) receives the streams back to back,
+ * d_es_off n_reads+1 byte offsets, d_es_ntuples n_reads tuple counts; *n_out = bytes needed (CL_E_CAPACITY if > cap). */
+cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const cl_reads* refs, const cl_anchors* anchors, uint32_t c, uint32_t anchor_len,
+                          uint32_t min_part_alt, uint32_t max_rec, double cost_mult, const uint32_t* h_pack_bounds, uint32_t n_packs,
+                          uint8_t* d_es, uint64_t cap, uint64_t* d_es_off, uint32_t* d_es_ntuples, uint64_t* n_out);
 
 /* ---- a14 + a16: CDNACoder / CEntrComprReads (dna_coder.{h,cpp}, entr_read.h:56-80) --------------------- */
 typedef struct cl_dna_coder cl_dna_coder;
