@@ -14,19 +14,19 @@
 #include "common.hpp"
 
 struct LanePool {
-	uint8_t* base; uint64_t cap, top; bool overflow;
-	__device__ inline void* alloc(uint64_t bytes)
+	uint8_t* base; uint64_t cap, top; bool overflow; uint32_t why;
+	CL_DEV inline void* alloc(uint64_t bytes)
 	{
 		bytes = (bytes + 15) & ~15ull;
-		if (top + bytes > cap) { overflow = true; return base; }      // keeps running on garbage; the read is redone with a larger pool
+		if (top + bytes > cap) { overflow = true; why |= 1u; return base; }      // keeps running on garbage; the read is redone with a larger pool
 		void* p = base + top; top += bytes; return p;
 	}
-	__device__ inline uint64_t mark() const { return top; }
-	__device__ inline void release(uint64_t m) { top = m; }
+	CL_DEV inline uint64_t mark() const { return top; }
+	CL_DEV inline void release(uint64_t m) { top = m; }
 };
 
 // ---- Myers block step (Myers 1999 / Hyyro): vertical deltas Pv/Mv of the previous column -> this column --------
-__device__ inline int myers_block(uint64_t Pv, uint64_t Mv, uint64_t Eq, int hin, uint64_t& PvOut, uint64_t& MvOut)
+CL_DEV inline int myers_block(uint64_t Pv, uint64_t Mv, uint64_t Eq, int hin, uint64_t& PvOut, uint64_t& MvOut)
 {
 	const uint64_t hneg = hin < 0 ? 1ull : 0ull;
 	const uint64_t Xv = Eq | Mv;
@@ -43,10 +43,10 @@ __device__ inline int myers_block(uint64_t Pv, uint64_t Mv, uint64_t Eq, int hin
 }
 
 struct Seq { const uint8_t* p; int32_t step; };                       // element i = p[i * step] (step = -1: reversed view)
-__device__ inline uint8_t seq_at(const Seq& s, uint32_t i) { return s.p[(int64_t)i * s.step]; }
+CL_DEV inline uint8_t seq_at(const Seq& s, uint32_t i) { return s.p[(int64_t)i * s.step]; }
 
 // match masks of the query: peq[sym * nb + b]
-__device__ inline uint64_t* build_peq(LanePool& pool, const Seq& q, uint32_t n, uint32_t nb)
+CL_DEV inline uint64_t* build_peq(LanePool& pool, const Seq& q, uint32_t n, uint32_t nb)
 {
 	uint64_t* peq = (uint64_t*)pool.alloc((uint64_t)4 * nb * 8);
 	if (pool.overflow) return peq;
@@ -58,26 +58,26 @@ __device__ inline uint64_t* build_peq(LanePool& pool, const Seq& q, uint32_t n, 
 // Column state of the global (NW) matrix: per block vertical deltas and the score at the block's last row.
 struct ColState { uint64_t* P; uint64_t* M; int32_t* S; };
 
-__device__ inline void col_init(ColState& c, uint32_t nb)
+CL_DEV inline void col_init(ColState& c, uint32_t nb)
 {
 	for (uint32_t b = 0; b < nb; ++b) { c.P[b] = ~0ull; c.M[b] = 0; c.S[b] = (int32_t)((b + 1) * 64); }   // D[i][0] = i
 }
-__device__ inline void col_step(ColState& c, const uint64_t* peq_sym, uint32_t nb)
+CL_DEV inline void col_step(ColState& c, const uint64_t* peq_sym, uint32_t nb)
 {
 	int h = 1;                                                    // D[0][j] - D[0][j-1] = +1
 	for (uint32_t b = 0; b < nb; ++b) { h = myers_block(c.P[b], c.M[b], peq_sym[b], h, c.P[b], c.M[b]); c.S[b] += h; }
 }
 // D[i][j] for row i (1-based, 1..n) given the column's words; i = 0 -> boundary j
-__device__ inline int32_t col_value(const uint64_t* P, const uint64_t* M, const int32_t* S, uint32_t i, uint32_t j)
+CL_DEV inline int32_t col_value(const uint64_t* P, const uint64_t* M, const int32_t* S, uint32_t i, uint32_t j)
 {
 	if (i == 0) return (int32_t)j;
 	const uint32_t r = i - 1, b = r >> 6, l = r & 63;
 	const uint64_t above = l == 63 ? 0ull : (~0ull << (l + 1));            // rows of the block below row r (bits l+1..63)
-	return S[b] - (int32_t)__popcll(P[b] & above) + (int32_t)__popcll(M[b] & above);
+	return S[b] - (int32_t)__builtin_popcountll(P[b] & above) + (int32_t)__builtin_popcountll(M[b] & above);
 }
 
 // D[n][m] only
-__device__ inline uint32_t nw_distance(LanePool& pool, const Seq& q, uint32_t n, const Seq& t, uint32_t m)
+CL_DEV inline uint32_t nw_distance(LanePool& pool, const Seq& q, uint32_t n, const Seq& t, uint32_t m)
 {
 	const uint64_t mk = pool.mark();
 	const uint32_t nb = (n + 63) / 64;
@@ -91,7 +91,7 @@ __device__ inline uint32_t nw_distance(LanePool& pool, const Seq& q, uint32_t n,
 	return d;
 }
 // last column of the NW matrix: out[i] = D[i][m], i = 0..n
-__device__ inline void nw_last_column(LanePool& pool, const Seq& q, uint32_t n, const Seq& t, uint32_t m, int32_t* out)
+CL_DEV inline void nw_last_column(LanePool& pool, const Seq& q, uint32_t n, const Seq& t, uint32_t m, int32_t* out)
 {
 	const uint64_t mk = pool.mark();
 	const uint32_t nb = (n + 63) / 64;
@@ -110,7 +110,7 @@ __device__ inline void nw_last_column(LanePool& pool, const Seq& q, uint32_t n, 
 	pool.release(mk);
 }
 // SHW: best = min_j D[n][j], end = first such j-1, with end = -1 (score n) considered first when n % 64 != 0
-__device__ inline void shw_distance(LanePool& pool, const Seq& q, uint32_t n, const Seq& t, uint32_t m, uint32_t* best_out, int64_t* end_out)
+CL_DEV inline void shw_distance(LanePool& pool, const Seq& q, uint32_t n, const Seq& t, uint32_t m, uint32_t* best_out, int64_t* end_out)
 {
 	const uint64_t mk = pool.mark();
 	const uint32_t nb = (n + 63) / 64;
@@ -133,7 +133,7 @@ __device__ inline void shw_distance(LanePool& pool, const Seq& q, uint32_t n, co
 struct OpsOut { uint8_t* p; uint64_t n; };                               // 0 match, 1 consume query, 2 consume target, 3 mismatch
 
 // traceback on stored columns (forward sequences only)
-__device__ inline void nw_traceback(LanePool& pool, const uint8_t* q, uint32_t n, const uint8_t* t, uint32_t m, OpsOut& out)
+CL_DEV inline void nw_traceback(LanePool& pool, const uint8_t* q, uint32_t n, const uint8_t* t, uint32_t m, OpsOut& out)
 {
 	const uint64_t mk = pool.mark();
 	const uint32_t nb = (n + 63) / 64;
@@ -173,7 +173,7 @@ __device__ inline void nw_traceback(LanePool& pool, const uint8_t* q, uint32_t n
 }
 
 // obtainAlignment: optimal path of q (rows) against t (columns) given the optimal score
-__device__ inline void nw_path(LanePool& pool, const uint8_t* q, uint32_t n, const uint8_t* t, uint32_t m, uint32_t best, OpsOut& out)
+CL_DEV inline void nw_path(LanePool& pool, const uint8_t* q, uint32_t n, const uint8_t* t, uint32_t m, uint32_t best, OpsOut& out)
 {
 	struct Job { uint32_t qo, n, to, m, best; };
 	const uint64_t mk0 = pool.mark();
@@ -201,8 +201,8 @@ __device__ inline void nw_path(LanePool& pool, const uint8_t* q, uint32_t n, con
 		if (found < 0 && L + (uint32_t)right[jb.n] == jb.best) { found = 0; ls = L; rs = (uint32_t)right[jb.n]; }
 		if (found < 0 && (uint32_t)left[jb.n] + R == jb.best) { found = jb.n; ls = (uint32_t)left[jb.n]; rs = R; }
 		pool.release(mk);
-		if (found < 0) { pool.overflow = true; found = 0; ls = L; rs = jb.best > L ? jb.best - L : 0; }      // cannot happen with a correct optimum
-		if (sp + 2 > 96) { pool.overflow = true; continue; }
+		if (found < 0) { pool.overflow = true; pool.why |= 2u; found = 0; ls = L; rs = jb.best > L ? jb.best - L : 0; }      // cannot happen with a correct optimum
+		if (sp + 2 > 96) { pool.overflow = true; pool.why |= 4u; continue; }
 		// lower-right half first on the stack so that the upper-left half is emitted first
 		stack[sp++] = Job{ jb.qo + (uint32_t)found, jb.n - (uint32_t)found, jb.to + L, R, rs };
 		stack[sp++] = Job{ jb.qo, (uint32_t)found, jb.to, L, ls };

@@ -1,6 +1,12 @@
 // common.hpp — context, device memory helpers and wave64 device primitives shared by the kernels.
 // gfx950 only: wavefront = 64 lanes, no dual paths.
 #pragma once
+// device functions that a debugging build (tests/tools, -DCL_HOST_DEBUG) also compiles for the host; the library never does
+#ifdef CL_HOST_DEBUG
+#define CL_DEV __host__ __device__
+#else
+#define CL_DEV __device__
+#endif
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
