@@ -51,7 +51,7 @@ def parse():
 
 
 # ONT default ("memory") preset: arg_parse.cpp:89-408 / SURVEY App. B
-PRESET = dict(f=12, ci=4, cs=80, c=5, g=1.0, exponent=1.0)
+PRESET = dict(f=12, ci=4, cs=80, c=5, g=1.0, exponent=1.0, a=22, min_part_alt=64, max_rec=3)   # a: compression.cpp:84-88 with k=25
 
 
 class StepTimes:
@@ -78,7 +78,7 @@ def reference_part_bounds(lengths: np.ndarray, pack_symbols: int) -> np.ndarray:
     return np.asarray(bounds, dtype=np.uint32)
 
 
-def hot_path_step(ctx, reads, k, quals=None, qual_off=None, part_bounds=None):
+def hot_path_step(ctx, reads, k, quals=None, qual_off=None, part_bounds=None, est_bounds=None):
     """One pass of the stages built so far (single- or multi-GPU).  Returns sizes for reporting."""
     from colord_amd import parallel as par
     p = PRESET
@@ -117,14 +117,25 @@ def hot_path_step(ctx, reads, k, quals=None, qual_off=None, part_bounds=None):
         payload, sizes = qc.encode(reads, quals, qual_off, part_bounds)
         qc.free()
         out.update(qual_bytes=int(payload.numel()), qual_parts=len(sizes))
-        # a12 (plain form) + a14: DNA stream.  The anchor / edit-script encoder (a8-a11) is not on the GPU yet, so every
-        # read is emitted verbatim (what the reference does for a read without usable candidates) and coded with the
-        # real DNA coder at level 1; same parts as the quality stream (the decoder requires that, entr_qual.h:150-170).
-        es, es_off, es_nt = ctx.encode_plain(reads)
+        # a8 + a10-a12 + a14: DNA stream.  Reference reads = the accepted reads of all ranks (CReferenceReads is one
+        # process-wide store in the reference; each rank replicates it), anchors against the candidates, edit scripts,
+        # tuple streams, DNA coder at level 1.  The estimator packs are the reference's reader packs (4 Mi symbols,
+        # defs.h:45); the coder parts are the same as the quality stream's (the decoder requires that, entr_qual.h:150-170).
+        my_refs = ctx.select_reads(reads, accept)
+        if w > 1:                                          # exchange 3: replicate the reference reads
+            pk = torch.cat(par.all_gather_v(my_refs.packed()[:my_refs.total_words]))
+            iv = torch.cat(par.all_gather_v(my_refs.invalid()[:my_refs.total_words]))
+            ln = torch.cat(par.all_gather_v(my_refs.lengths()))
+            my_refs.free()
+            my_refs = ctx.reads_from_arena(pk, iv, ln)
+        anc = ctx.anchor_candidates(reads, my_refs, crefs, cnt, p["a"])
+        es, es_off, es_nt = ctx.encode_reads(reads, my_refs, anc, p["a"], p["min_part_alt"], p["max_rec"], 1.0, est_bounds)
+        n_plain = int((es[es_off[:-1]] >> 4 != 10).sum().item())
         dc = ctx.dna_coder(p["c"], 1, 0)
-        dpayload, dsizes = dc.encode(reads, es, es_off, es_nt, part_bounds)
+        dpayload, dsizes = dc.encode(my_refs, es, es_off, es_nt, part_bounds)
         dc.free()
-        out.update(dna_bytes_all_plain=int(dpayload.numel()))
+        out.update(dna_bytes=int(dpayload.numel()), tuple_bytes=int(es.numel()), reads_stored_plain=n_plain, anchors=int(anc.total))
+        anc.free(); my_refs.free()
     index.free(); lists.free(); kset.free()
     return out
 
@@ -180,7 +191,8 @@ def main():
     del codes
     qual_off = offsets.contiguous()
     part_bounds = reference_part_bounds(reads.lengths().cpu().numpy().view(np.uint32), args.pack_symbols)
-    qargs = {} if args.no_qual else dict(quals=quals, qual_off=qual_off, part_bounds=part_bounds)
+    est_bounds = reference_part_bounds(reads.lengths().cpu().numpy().view(np.uint32), 1 << 22)      # reader packs (defs.h:45)
+    qargs = {} if args.no_qual else dict(quals=quals, qual_off=qual_off, part_bounds=part_bounds, est_bounds=est_bounds)
 
     def sync():
         torch.cuda.synchronize()
@@ -232,8 +244,7 @@ def main():
                                    f"k={args.k} f={PRESET['f']} ci={PRESET['ci']} cs={PRESET['cs']} c={PRESET['c']} (ONT default preset)",
                        "stages": "a1 k-mer scan, a2 count/filter, a3 set build, a4 accepted k-mers, a6 acceptor, a5 index+candidates"
                                  + ("" if args.no_qual else f", a13+a15 quality stream (4-avg, level 1, parts of {args.pack_symbols} symbols)")
-                                 + ("" if args.no_qual else ", a12 plain tuple streams + a14 DNA stream coder (all reads verbatim)")
-                                 + "; a8-a11 (anchors, alignment, edit-script decisions) not yet on GPU, not timed: the DNA stream is valid but ~2x the reference's size",
+                                 + ("" if args.no_qual else ", a8 m-mer anchors, a10-a12 gap alignment + cost decisions + tuple streams, a14+a16 DNA stream coder"),
                        "parallelism": f"reads sharded x{world}, k-mer set replicated" if world > 1 else "single GPU",
                        "sizes": info},
             "roofline": roof, "cpu_baseline": cb,

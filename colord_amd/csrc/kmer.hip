@@ -120,6 +120,131 @@ extern "C" const uint64_t* cl_reads_word_offsets(const cl_reads* r) { return r->
 extern "C" const uint32_t* cl_reads_lengths(const cl_reads* r) { return r->lens.p; }
 extern "C" const uint8_t* cl_reads_has_n(const cl_reads* r) { return r->has_n.p; }
 
+// CReferenceReads (reference_reads.h): the arena of the reads the acceptor kept, in reference-id order
+namespace {
+__global__ void k_select_geometry(const uint8_t* __restrict__ keep, const uint32_t* __restrict__ lens, uint32_t n, uint32_t* __restrict__ flag, uint32_t* __restrict__ words)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t kp = keep[i] ? 1u : 0u;
+	flag[i] = kp; words[i] = kp ? (lens[i] + 31) / 32 : 0u;
+}
+__global__ void k_select_copy(const uint8_t* __restrict__ keep, const uint32_t* __restrict__ rank, const uint64_t* __restrict__ new_off, const uint64_t* __restrict__ old_off,
+                              const uint32_t* __restrict__ lens, const uint8_t* __restrict__ has_n, const uint64_t* __restrict__ packed, const uint32_t* __restrict__ inv, uint32_t n,
+                              uint64_t* __restrict__ o_off, uint32_t* __restrict__ o_lens, uint8_t* __restrict__ o_has_n, uint64_t* __restrict__ o_packed, uint32_t* __restrict__ o_inv)
+{	// one wave per read
+	const uint32_t r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+	if (r >= n || !keep[r]) return;
+	const uint32_t j = rank[r]; const uint64_t so = old_off[r], d = new_off[r]; const uint32_t w = (lens[r] + 31) / 32;
+	if (lane == 0) { o_off[j] = d; o_lens[j] = lens[r]; o_has_n[j] = has_n[r]; }
+	for (uint32_t i = lane; i < w; i += 64) { o_packed[d + i] = packed[so + i]; o_inv[d + i] = inv[so + i]; }
+}
+} // namespace
+extern "C" cl_status cl_reads_select(cl_ctx* ctx, const cl_reads* src, const uint8_t* d_keep, cl_reads** out)
+{
+	if (!ctx || !src || !d_keep || !out) return cl_fail(ctx, CL_E_INVALID, "cl_reads_select: null argument");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	const uint32_t n = src->n_reads;
+	cl_reads* R = new cl_reads(); R->ctx = ctx;
+	std::unique_ptr<cl_reads> guard(R);
+	DevBuf<uint32_t> flag, words; DEV_ALLOC(ctx, flag, (uint64_t)n + 1); DEV_ALLOC(ctx, words, (uint64_t)n + 1);
+	DevBuf<uint64_t> new_off; DEV_ALLOC(ctx, new_off, (uint64_t)n + 1);
+	uint64_t kept = 0;
+	if (n)
+	{
+		LAUNCH(ctx, k_select_geometry, grid_for(n, 256), 256, d_keep, (const uint32_t*)src->lens.p, n, flag.p, words.p);
+		HIP_TRY(ctx, hipGetLastError());
+	}
+	CL_TRY(dev_exclusive_scan_u64(ctx, words.p, new_off.p, n, &R->total_words));
+	CL_TRY(dev_exclusive_scan_u32(ctx, flag.p, n, &kept));
+	R->n_reads = (uint32_t)kept;
+	DEV_ALLOC(ctx, R->lens, kept); DEV_ALLOC(ctx, R->word_off, kept + 1); DEV_ALLOC(ctx, R->has_n, kept);
+	DEV_ALLOC(ctx, R->packed, R->total_words + 1); DEV_ALLOC(ctx, R->inv, R->total_words + 1);
+	if (n)
+	{
+		LAUNCHB(ctx, R->total_words * 24.0, k_select_copy, grid_for((uint64_t)n * 64, 256), 256, d_keep, (const uint32_t*)flag.p, (const uint64_t*)new_off.p, (const uint64_t*)src->word_off.p,
+			(const uint32_t*)src->lens.p, (const uint8_t*)src->has_n.p, (const uint64_t*)src->packed.p, (const uint32_t*)src->inv.p, n,
+			R->word_off.p, R->lens.p, R->has_n.p, R->packed.p, R->inv.p);
+		HIP_TRY(ctx, hipGetLastError());
+	}
+	HIP_TRY(ctx, hipMemcpyAsync(R->word_off.p + kept, &R->total_words, 8, hipMemcpyHostToDevice, ctx->stream));
+	LAUNCH(ctx, k_arena_tail, 1, 1, R->packed.p, R->inv.p, R->total_words);
+	if (kept)
+	{	// total bases = sum of the kept lengths
+		std::vector<uint32_t> h(kept);
+		HIP_TRY(ctx, hipMemcpyAsync(h.data(), R->lens.p, kept * 4, hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		uint64_t tb = 0; for (uint32_t l : h) tb += l;
+		R->total_bases = tb;
+	}
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	cl_timing_collect(ctx);
+	*out = guard.release();
+	return CL_OK;
+}
+
+namespace {
+__global__ void k_arena_geometry(const uint32_t* __restrict__ lens, uint32_t n, uint32_t* __restrict__ words)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) words[i] = (lens[i] + 31) / 32;
+}
+__global__ void k_arena_has_n(const uint64_t* __restrict__ off, const uint32_t* __restrict__ lens, const uint32_t* __restrict__ inv, uint32_t n, uint8_t* __restrict__ has_n)
+{	// one wave per read: any invalid bit inside the read's length
+	const uint32_t r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+	if (r >= n) return;
+	const uint32_t len = lens[r], w = (len + 31) / 32; const uint64_t o = off[r];
+	bool any = false;
+	for (uint32_t i = lane; i < w; i += 64)
+	{
+		uint32_t m = inv[o + i];
+		if (i == w - 1 && (len & 31)) m &= ~0u << (32 - (len & 31));          // ignore the pad bits of the last word
+		any |= m != 0;
+	}
+	const uint64_t b = __ballot(any);
+	if (lane == 0) has_n[r] = b ? 1 : 0;
+}
+} // namespace
+// An arena from packed words that already have the arena layout (word-aligned reads back to back), e.g. the
+// concatenation of the reference-read arenas of several ranks.
+extern "C" cl_status cl_reads_from_arena(cl_ctx* ctx, const uint64_t* d_packed, const uint32_t* d_inv, const uint32_t* d_lens, uint32_t n_reads, cl_reads** out)
+{
+	if (!ctx || !out || (n_reads && (!d_packed || !d_inv || !d_lens))) return cl_fail(ctx, CL_E_INVALID, "cl_reads_from_arena: null argument");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	cl_reads* R = new cl_reads(); R->ctx = ctx; R->n_reads = n_reads;
+	std::unique_ptr<cl_reads> guard(R);
+	DEV_ALLOC(ctx, R->lens, n_reads); DEV_ALLOC(ctx, R->word_off, (uint64_t)n_reads + 1); DEV_ALLOC(ctx, R->has_n, n_reads);
+	DevBuf<uint32_t> words; DEV_ALLOC(ctx, words, (uint64_t)n_reads + 1);
+	if (n_reads)
+	{
+		HIP_TRY(ctx, hipMemcpyAsync(R->lens.p, d_lens, (uint64_t)n_reads * 4, hipMemcpyDeviceToDevice, ctx->stream));
+		LAUNCH(ctx, k_arena_geometry, grid_for(n_reads, 256), 256, d_lens, n_reads, words.p);
+		HIP_TRY(ctx, hipGetLastError());
+	}
+	CL_TRY(dev_exclusive_scan_u64(ctx, words.p, R->word_off.p, n_reads, &R->total_words));
+	DEV_ALLOC(ctx, R->packed, R->total_words + 1); DEV_ALLOC(ctx, R->inv, R->total_words + 1);
+	if (R->total_words)
+	{
+		HIP_TRY(ctx, hipMemcpyAsync(R->packed.p, d_packed, R->total_words * 8, hipMemcpyDeviceToDevice, ctx->stream));
+		HIP_TRY(ctx, hipMemcpyAsync(R->inv.p, d_inv, R->total_words * 4, hipMemcpyDeviceToDevice, ctx->stream));
+	}
+	LAUNCH(ctx, k_arena_tail, 1, 1, R->packed.p, R->inv.p, R->total_words);
+	if (n_reads)
+	{
+		LAUNCH(ctx, k_arena_has_n, grid_for((uint64_t)n_reads * 64, 256), 256, (const uint64_t*)R->word_off.p, (const uint32_t*)R->lens.p, (const uint32_t*)R->inv.p, n_reads, R->has_n.p);
+		HIP_TRY(ctx, hipGetLastError());
+		std::vector<uint32_t> h(n_reads);
+		HIP_TRY(ctx, hipMemcpyAsync(h.data(), R->lens.p, (uint64_t)n_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		uint64_t tb = 0; for (uint32_t l : h) tb += l;
+		R->total_bases = tb;
+	}
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	cl_timing_collect(ctx);
+	*out = guard.release();
+	return CL_OK;
+}
+
 extern "C" cl_status cl_reads_compact(cl_ctx* ctx, const cl_reads* R, uint32_t read, uint8_t* h_out, uint64_t cap, uint64_t* n_out)
 {
 	if (!ctx || !R || read >= R->n_reads) return cl_fail(ctx, CL_E_INVALID, "cl_reads_compact: bad read index");

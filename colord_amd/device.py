@@ -88,6 +88,21 @@ class Context:
         _check(self, self.lib.cl_reads_pack(self.h, codes.data_ptr(), offsets.data_ptr(), offsets.numel() - 1, int(ascii), C.byref(h)))
         return Reads(self, h)
 
+    def select_reads(self, reads: "Reads", keep: torch.Tensor) -> "Reads":
+        """CReferenceReads: the arena of the reads with keep[i] != 0 (reference id = rank among the kept reads)."""
+        assert keep.dtype == torch.uint8 and keep.numel() == reads.n_reads
+        h = N._P()
+        _check(self, self.lib.cl_reads_select(self.h, reads.h, keep.contiguous().data_ptr(), C.byref(h)))
+        return Reads(self, h)
+
+    def reads_from_arena(self, packed: torch.Tensor, inv: torch.Tensor, lens: torch.Tensor) -> "Reads":
+        """Arena from already packed words (word-aligned reads back to back), e.g. gathered from all ranks."""
+        h = N._P()
+        n = lens.numel()
+        _check(self, self.lib.cl_reads_from_arena(self.h, packed.contiguous().data_ptr() if n else None, inv.contiguous().data_ptr() if n else None,
+                                                  lens.contiguous().data_ptr() if n else None, n, C.byref(h)))
+        return Reads(self, h)
+
     def pack_readset(self, rs) -> "Reads":
         return self.pack_reads(torch.from_numpy(rs.bases), torch.from_numpy(rs.offsets))
 

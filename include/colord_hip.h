@@ -233,6 +233,14 @@ cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* d, const cl_reads* refs, cons
                         const uint32_t* d_es_ntuples, uint32_t n_reads, const uint32_t* h_part_bounds, uint32_t n_parts,
                         uint8_t* d_out, uint64_t cap, uint64_t* h_part_sizes, uint64_t* n_out);
 
+/* CReferenceReads (reference_reads.h:24-80): the arena of the reads with d_keep[i] != 0, in order — reference id r is
+ * the r-th kept read.  The result is an independent arena (free with cl_reads_free). */
+cl_status cl_reads_select(cl_ctx* ctx, const cl_reads* src, const uint8_t* d_keep, cl_reads** out);
+/* An arena from words that already have the arena layout (word-aligned reads back to back; see cl_reads_packed /
+ * cl_reads_invalid), e.g. the concatenation of the reference-read arenas of all ranks (the reference's
+ * CReferenceReads is one process-wide store; with reads sharded over GPUs each rank replicates it). */
+cl_status cl_reads_from_arena(cl_ctx* ctx, const uint64_t* d_packed, const uint32_t* d_inv, const uint32_t* d_lens, uint32_t n_reads, cl_reads** out);
+
 /* ---- a7: CReferenceReads (reference_reads.h:27-259) ---------------------------------------------- */
 /* Byte image of one stored reference read (4 bases/byte MSB first + trailing count byte) produced from
  * the arena; h_out needs (len+3)/4+1 bytes.  Used by the parity tests and by the host archive code. */

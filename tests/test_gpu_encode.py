@@ -48,3 +48,56 @@ def test_tuple_streams_equal_reference(ctx, cfg):
     assert not bad, f"{len(bad)} of {g.reads.n_reads} reads differ, first {bad[:10]}"
     if cfg in ("c3_clr_ratio", "s6m_ont", "s3m_ont_n_ratio"):
         assert n_es > 10                                    # the edit-script path is really exercised
+
+
+@pytest.mark.parametrize("cfg", ["c3_clr_ratio", "s6m_ont", "s3m_ont_n_ratio", "c1_ont_default"])
+def test_whole_dna_path_byte_identical_to_reference(ctx, cfg):
+    """Read bases in, `dna` stream parts out, every stage on the GPU (a1-a8, a10-a12, a14, a16): the parts must have the
+    sizes and SHA-256 of the parts the unmodified reference wrote for the same file."""
+    import hashlib
+    g = golden(cfg)
+    rs = g.reads
+    k, f, c = g.p("k"), g.p("f"), g.p("c")
+    reads = ctx.pack_readset(rs)
+    kset, st = ctx.count_filter(ctx.kmer_scan(reads, k, f), k, g.p("ci"), g.p("cs"))
+    lists = ctx.accepted_kmers(kset, reads, k, f)
+    acc = ctx.ref_accept(g.p("n_reads"), g.p("n_pseudo"), g.p("sparse_range"), g.p("sparse_exp")) if g.p("sparse") else np.ones(rs.n_reads, np.uint8)
+    accept = torch.from_numpy(acc.copy()).to(ctx.device) & (reads.has_n() == 0).to(torch.uint8)
+    index = ctx.index_build(kset, lists, accept, 0, g.p("cs"))
+    crefs, votes, cnt = ctx.candidates(index, lists, c)
+    refs = ctx.select_reads(reads, accept)
+    assert refs.n_reads == int(accept.sum().item())
+    anc = ctx.anchor_candidates(reads, refs, crefs, cnt, g.p("a"))
+    min_alt, max_rec = PRESET_BY_LEVEL[g.p("level")]
+    bounds = rs.pack_bounds()
+    es, off, nt = ctx.encode_reads(reads, refs, anc, g.p("a"), min_alt, max_rec, 1.0, bounds)
+    dc = ctx.dna_coder(c, g.p("level"), g.p("n_pseudo"))
+    out, sizes = dc.encode(refs, es, off, nt, np.asarray(bounds))
+    raw = out.cpu().numpy().tobytes()
+    got, o = [], 0
+    for i, s in enumerate(sizes):
+        got.append([int(bounds[i + 1] - bounds[i]), int(s), hashlib.sha256(raw[o:o + s]).hexdigest()])
+        o += s
+    assert got == g.spec["streams"]["dna"]["parts"]
+    dc.free(); anc.free(); refs.free(); index.free(); lists.free(); kset.free(); reads.free()
+
+
+def test_select_reads_and_arena_concat(ctx):
+    g = golden("s3m_ont_n_ratio")
+    rs = g.reads
+    reads = ctx.pack_readset(rs)
+    keep = (np.arange(rs.n_reads) % 3 != 1).astype(np.uint8)
+    sub = ctx.select_reads(reads, torch.from_numpy(keep).to(ctx.device))
+    exp = ctx.pack_readset(ref_subset(rs, keep.astype(bool)))
+    for a, b in ((sub, exp),):
+        assert a.n_reads == b.n_reads and a.total_words == b.total_words and a.total_bases == b.total_bases
+        assert torch.equal(a.packed(), b.packed()) and torch.equal(a.invalid(), b.invalid())
+        assert torch.equal(a.word_offsets(), b.word_offsets()) and torch.equal(a.lengths(), b.lengths()) and torch.equal(a.has_n(), b.has_n())
+    # concatenation of two arenas (what the ranks do with their reference reads)
+    both = ctx.reads_from_arena(torch.cat([sub.packed()[:sub.total_words], reads.packed()[:reads.total_words]]),
+                                torch.cat([sub.invalid()[:sub.total_words], reads.invalid()[:reads.total_words]]),
+                                torch.cat([sub.lengths(), reads.lengths()]))
+    assert both.n_reads == sub.n_reads + reads.n_reads and both.total_bases == sub.total_bases + reads.total_bases
+    assert torch.equal(both.has_n(), torch.cat([sub.has_n(), reads.has_n()]))
+    assert torch.equal(both.word_offsets()[sub.n_reads:], reads.word_offsets() + sub.total_words)
+    both.free(); exp.free(); sub.free(); reads.free()
