@@ -117,6 +117,9 @@ struct KernelTimer {
 	hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (ctx)->stream, __VA_ARGS__); } while (0)
 // LAUNCH with the algorithmic HBM byte count of this launch (for achieved-GB/s reporting)
 #define LAUNCHB(ctx, bytes, kernel, grid, block, ...) do { (ctx)->next_bytes = (double)(bytes); LAUNCH(ctx, kernel, grid, block, __VA_ARGS__); } while (0)
+// the same with dynamic LDS
+#define LAUNCHB_SHM(ctx, bytes, kernel, grid, block, shm, ...) do { (ctx)->next_bytes = (double)(bytes); KernelTimer _kt((ctx), #kernel); \
+	hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (shm), (ctx)->stream, __VA_ARGS__); } while (0)
 static inline void cl_timing_begin(cl_ctx*) {}   // times accumulate until cl_ctx_kernel_times reports them
 static inline void cl_timing_collect(cl_ctx* c)
 {

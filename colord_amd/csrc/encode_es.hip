@@ -1,24 +1,17 @@
-// encode_es.hip — edit-script encoding of reads against their anchored candidates (a10 + a11 + a12):
-// CEncoder::AddEncodedReadWithCandidates / EncodePart / GetEditDist / EncodeWithEditScript /
-// EncodeWithAlternativeRead / AdjustAnchors / StoreFrag / bigEditScriptToTuples (src/colord/encoder.cpp:778-868,
-// 1255-1575), refactor_edit_script (edit_script.h:416-446,591-671), CEntropy / CEntropyEstimator
-// (utils.h:700-1131).
+// encode_es.hip — kernels and host driver of the edit-script encoder (a10 + a11 + a12); the algorithm, its data
+// model (frames, gaps, levels) and the reference citations are in encode_core.hpp.
 //
-// Three passes, because the only cross-read state of the reference encoder is the adaptive cost estimator, and it
-// is consulted only for gaps shorter than minPartLenToConsiderAltRead, whose outcome never changes WHICH work
-// exists (no recursion starts from a short gap):
-//   pass 1 (one lane per read, all reads concurrently): walks the fragment tree of the read — anchors, gaps,
-//           recursion into alternative references for rejected long gaps (static entropy test) — aligns every gap
-//           (align_dev.hpp), canonicalises indels, and records an ordered item list plus, for every short gap, the
-//           statistics the estimator needs;
-//   pass 2 (one lane per reader pack, the estimator's reset domain, encoder.cpp:1677): replays the estimator over
-//           the short gaps in encoding order and decides edit script vs literal;
-//   pass 3 (one lane per read): interprets the item list with those decisions into the tuple stream (run-length
-//           rules of singleEditScriptSymbolStore, segment headers of StoreFrag).
-#include "common.hpp"
+// Per recursion level L (host loop, <= maxRecurence + 1 iterations, each a handful of launches over ALL level-L gaps):
+//   k_frame_gap_counts -> scan -> k_gap_geometry -> scans (script capacity, pending slots) -> sort gaps by size class
+//   -> k_align_small<NB> (one lane per gap, rows <= 64*NB, columns <= 256: Myers' recurrence in registers, sequences and
+//      the script in LDS, per-column history lane-interleaved in HBM) / k_align_large (the rest: lane pool, Hirschberg)
+//   -> k_gap_stats (estimator statistics or the static entropy decision) -> k_spawn_mark -> scans -> k_spawn_fill.
+// Then k_estimator (one lane per reader pack) and k_emit_tuples (one lane per read, count pass + write pass).
 #include "objects.hpp"
-#include "align_dev.hpp"
+#include "encode_core.hpp"
 #include <algorithm>
+#include <memory>
+#include <vector>
 
 struct cl_anchors;   // anchors.hip
 extern "C" const uint32_t* cl_anchors_n_cands(const cl_anchors* a);
@@ -26,622 +19,198 @@ extern "C" const uint32_t* cl_anchors_cands(const cl_anchors* a);
 extern "C" const uint64_t* cl_anchors_cand_offsets(const cl_anchors* a);
 extern "C" const uint32_t* cl_anchors_data(const cl_anchors* a);
 
-namespace {
-struct ArenaV { const uint64_t* packed; const uint64_t* word_off; const uint32_t* lens; };
-CL_DEV inline uint32_t arena_base_at(const ArenaV& A, uint64_t wb, uint32_t p) { return (uint32_t)(A.packed[wb + (p >> 5)] >> (62 - 2 * (p & 31))) & 3u; }
-CL_DEV inline uint32_t ref_base_at(const ArenaV& R, uint32_t id, bool rev, uint32_t pos)
-{
-	const uint32_t len = R.lens[id];
-	const uint32_t p = rev ? len - 1 - pos : pos;
-	const uint32_t b = arena_base_at(R, R.word_off[id], p);
-	return rev ? 3u - b : b;
-}
+using namespace enc;
 
-struct EncCfg {
-	uint32_t c, m, min_part_alt, max_rec; double cost_mult; uint32_t scale, max_ref_len;
-};
+namespace {
 struct AnchorsV { const uint32_t* n_cands; const uint32_t* cand; const uint64_t* cand_off; const uint32_t* data; };
 
-// item kinds (top 4 bits of a 64-bit item)
-enum : uint64_t { IT_RUN = 1, IT_GAP = 2, IT_STORE = 3, IT_STORE2 = 4, IT_BEGIN = 5, IT_END = 6 };
-CL_DEV inline uint64_t it_run(char sym, uint32_t n) { return (IT_RUN << 60) | ((uint64_t)(uint8_t)sym << 32) | n; }
-struct GapRec { uint32_t es_off, es_len, enc_start, ne, d_after, state, pend, d_before; };   // script = d_before x 'D' + es   // state: 0 edit script, 1 literal, 2 pending (estimator)
-struct PendRec { uint32_t rd[12]; uint32_t len_cost; uint32_t pl[4]; uint32_t ref_len; };
-
-struct ReadOut {          // per-read chunk bookkeeping (filled at the end of pass 1)
-	uint64_t item_off, gap_off, pend_off, es_off;
-	uint32_t n_items, n_gaps, n_pend, es_len;
-	uint32_t dna[4];      // base counts (estimator LogRead)
-	uint32_t plain;       // 1: stored plain (no candidates), 2: plain with N
-	uint32_t pad;
-};
-
-struct Frame {
-	uint32_t level, enc_off, enc_len, n_cands;
-	uint32_t* a_len; uint32_t* a_pe; uint32_t* a_pr;      // anchors of all candidates, concatenated
-	uint32_t* c_first; uint32_t* c_n; uint32_t* c_tot; uint32_t* c_ref; uint8_t* c_rev;
-	uint32_t i, n_frag, anch, cur_ref, cur_enc, after_child, a_span;   // a_span: length of the anchor arrays (slots keep their offsets)
-	uint64_t pool_mark;
-};
-
-struct Sink {            // lane-local growing outputs in the lane pool's tail region
-	uint64_t* items; uint32_t n_items, cap_items;
-	GapRec* gaps; uint32_t n_gaps, cap_gaps;
-	PendRec* pend; uint32_t n_pend, cap_pend;
-	char* es; uint32_t n_es, cap_es;
-	bool overflow; uint32_t why;
-	CL_DEV inline void item(uint64_t v) { if (n_items < cap_items) items[n_items++] = v; else { overflow = true; why |= 8u; } }
-};
-
-CL_DEV inline char mismatch_sym(uint32_t ref, uint32_t nw)            // utils.h:341-352
-{
-	const uint32_t rank = nw - (nw > ref ? 1u : 0u);                      // rank of the new base among the three others
-	return (char)('X' + rank);
-}
-CL_DEV inline bool is_mismatch(char c) { return c == 'X' || c == 'Y' || c == 'Z'; }
-CL_DEV inline char base_letter(uint32_t b) { return b == 0 ? 'A' : b == 1 ? 'C' : b == 2 ? 'G' : 'T'; }
-
-// refactor_edit_script (edit_script.h:416-446,591-671)
-CL_DEV inline void fix_in_range(char* es, uint64_t start, uint64_t end)
-{
-	if (end < start + 2) return;
-	--end;
-	for (;;)
-	{
-		while (start < end && es[start] == 'M') ++start;
-		while (start < end && es[end] != 'M') --end;
-		if (start == end) break;
-		const char t = es[start]; es[start] = es[end]; es[end] = t;
-	}
-}
-CL_DEV inline void refactor_es(const uint8_t* ref, const uint8_t* enc, char* s, uint32_t n)
-{
-	uint32_t st = 0, pos = 0, es_start = 0;
-	for (uint32_t p = 0; p < n; ++p)
-	{
-		const char c = s[p];
-		const bool mis = is_mismatch(c), ins = c == 'A' || c == 'C' || c == 'G' || c == 'T';
-		if (ins || mis || ref[st] != ref[pos]) { fix_in_range(s, es_start, p); es_start = p; if (ins || mis) ++es_start; st = pos; }
-		if (!ins) ++pos;
-	}
-	fix_in_range(s, es_start, n);
-	st = 0; pos = 0; es_start = 0;
-	for (uint32_t p = 0; p < n; ++p)
-	{
-		const char c = s[p];
-		const bool mis = is_mismatch(c), del = c == 'D';
-		if (del || mis || enc[st] != enc[pos]) { fix_in_range(s, es_start, p); es_start = p; if (del || mis) ++es_start; st = pos; }
-		if (!del) ++pos;
-	}
-	fix_in_range(s, es_start, n);
-}
-
-// edit script of one gap into dst (capacity >= nr + ne + 2); returns its length.  GetEditDist (encoder.cpp:1255-1283)
-// rbuf: the reference symbols the alignment can touch — the whole part for an inner gap, its first `use` symbols for
-// the right flank, its LAST `use` symbols for the left flank (use = min(2*ne, nr)).
-CL_DEV uint32_t gap_edit_script(LanePool& pool, const uint8_t* rbuf, uint32_t nr, const uint8_t* enc, uint32_t ne, uint32_t frag, uint32_t n_frag, char* dst, uint32_t* d_before)
-{
-	uint32_t n = 0;
-	const uint8_t* ref = rbuf;
-	*d_before = 0;
-	if (nr == 0 || ne == 0)                                                    // get_edit_dist_on_seq_empty (edit_script.h:250-267)
-	{
-		if (nr == 0) for (uint32_t i = 0; i < ne; ++i) dst[n++] = base_letter(enc[i]);
-		else *d_before = nr;
-		return n;
-	}
-	const uint64_t mk = pool.mark();
-	const bool inner = frag != 0 && frag != n_frag - 1;
-	const uint32_t use = inner ? nr : (2 * ne < nr ? 2 * ne : nr);
-	uint8_t* opsbuf = (uint8_t*)pool.alloc((uint64_t)use + ne + 16);
-	uint8_t* r2 = (uint8_t*)pool.alloc(use + 16ull); uint8_t* e2 = (uint8_t*)pool.alloc(ne + 16ull);
-	if (pool.overflow) { pool.release(mk); return 0; }
-	OpsOut ops{ opsbuf, 0 };
-	const bool left = frag == 0, right = !left && frag == n_frag - 1;
-	if (!left && !right)
-	{	// find_edit_dist_with_edlib_ex: query = ref, target = enc, global.  (The small-input DP of the reference has the
-		// same move preference in this orientation, edit_script.h:156-239, so one code path covers both.)
-		const uint32_t best = nw_distance(pool, Seq{ ref, 1 }, nr, Seq{ enc, 1 }, ne);
-		nw_path(pool, ref, nr, enc, ne, best, ops);
-		uint32_t pr = 0, pe = 0;
-		for (uint64_t i = 0; i < ops.n; ++i)
-			switch (ops.p[i])
-			{
-			case 0: dst[n++] = 'M'; ++pr; ++pe; break;
-			case 1: dst[n++] = 'D'; ++pr; break;
-			case 2: dst[n++] = base_letter(enc[pe++]); break;
-			default: dst[n++] = mismatch_sym(ref[pr], enc[pe]); ++pr; ++pe;
-			}
-		refactor_es(ref, enc, dst, n);
-		pool.release(mk);
-		return n;
-	}
-	// flanks: prefix-free alignment of the whole read part against <= 2*|enc| reference symbols
-	if (left) { for (uint32_t i = 0; i < use; ++i) r2[i] = rbuf[use - 1 - i]; for (uint32_t i = 0; i < ne; ++i) e2[i] = enc[ne - 1 - i]; }
-	else { for (uint32_t i = 0; i < use; ++i) r2[i] = ref[i]; for (uint32_t i = 0; i < ne; ++i) e2[i] = enc[i]; }
-	uint32_t ref_end;
-	if (use < 2 || ne < 2)
-	{	// find_edit_dist (edit_script.h:156-239): global, rows = ref: prefers deleting a reference symbol
-		const uint32_t best = nw_distance(pool, Seq{ r2, 1 }, use, Seq{ e2, 1 }, ne);
-		nw_path(pool, r2, use, e2, ne, best, ops);
-		uint32_t pr = 0, pe = 0;
-		for (uint64_t i = 0; i < ops.n; ++i)
-			switch (ops.p[i])
-			{
-			case 0: dst[n++] = 'M'; ++pr; ++pe; break;
-			case 1: dst[n++] = 'D'; ++pr; break;
-			case 2: dst[n++] = base_letter(e2[pe++]); break;
-			default: dst[n++] = mismatch_sym(r2[pr], e2[pe]); ++pr; ++pe;
-			}
-		ref_end = use - 1;
-	}
-	else
-	{	// edlib SHW, query = enc, target = ref (edit_script.h:341-400)
-		uint32_t best; int64_t end;
-		shw_distance(pool, Seq{ e2, 1 }, ne, Seq{ r2, 1 }, use, &best, &end);
-		ref_end = (uint32_t)end;
-		nw_path(pool, e2, ne, r2, (uint32_t)(end + 1), best, ops);
-		uint32_t pr = 0, pe = 0;
-		for (uint64_t i = 0; i < ops.n; ++i)
-			switch (ops.p[i])
-			{
-			case 0: dst[n++] = 'M'; ++pr; ++pe; break;
-			case 1: dst[n++] = base_letter(e2[pe++]); break;
-			case 2: dst[n++] = 'D'; ++pr; break;
-			default: dst[n++] = mismatch_sym(r2[pr], e2[pe]); ++pr; ++pe;
-			}
-	}
-	if (left)
-	{	// find_edit_dist_with_edlib_ex_odwr_reverse (edit_script.h:405-419) + the D prefix (encoder.cpp:1263-1269)
-		for (uint32_t a = 0, b = n; a + 1 < b; ++a) { --b; const char t = dst[a]; dst[a] = dst[b]; dst[b] = t; }
-		const uint32_t ref_offset = (nr - 1) - ref_end;                       // uint32 wrap for end = -1, as in the reference
-		refactor_es(rbuf + (ref_offset - (nr - use)), enc, dst, n);      // = ref part + ref_offset
-		*d_before = ref_offset;
-	}
-	else refactor_es(ref, enc, dst, n);
-	pool.release(mk);
-	return n;
-}
-
-// static entropies (utils.h:706-752)
-CL_DEV inline double entropy_dna_dev(const uint8_t* s, uint32_t n)
-{
-	uint32_t h[4] = { 0, 0, 0, 0 };
-	for (uint32_t i = 0; i < n; ++i) ++h[s[i]];
-	double sum = 0; for (int i = 0; i < 4; ++i) sum += h[i];
-	const double rec = 1.0 / sum; double e = 0;
-	for (int c = 0; c < 4; ++c) if (h[c]) { const double p = (double)h[c] * rec; e += log2(p) * p; }
-	return -e;
-}
-CL_DEV inline uint32_t es_class(char c)       // order of CEntropy::es_sym = A C D G M T X Y Z (S, R never occur in a script)
-{
-	switch (c) { case 'A': return 0; case 'C': return 1; case 'D': return 2; case 'G': return 3; case 'M': return 4; case 'T': return 5; case 'X': return 6; case 'Y': return 7; default: return 8; }
-}
-CL_DEV inline double entropy_es_dev(const char* s, uint32_t n, uint32_t extra_d)
-{
-	uint32_t h[9] = { 0, 0, extra_d, 0, 0, 0, 0, 0, 0 };
-	for (uint32_t i = 0; i < n; ++i) ++h[es_class(s[i])];
-	double sum = 0; for (int i = 0; i < 9; ++i) sum += h[i];
-	const double rec = 1.0 / sum; double e = 0;
-	for (int c = 0; c < 9; ++c) if (h[c]) { const double p = (double)h[c] * rec; e += log2(p) * p; }
-	return -e;
-}
-CL_DEV inline uint32_t bitlen32(uint64_t x) { return x ? 64u - (uint32_t)__builtin_clzll(x) : 0u; }
-// estimator alphabet (utils.h:914-930): A C G T D M X Y Z S R
-CL_DEV inline uint32_t est_code(char c)
-{
-	switch (c) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; case 'D': return 4; case 'M': return 5; case 'X': return 6; case 'Y': return 7; case 'Z': return 8; default: return 11; }
-}
-// analyze_es (utils.h:819-874) reduced to what EncodeWithEditScript consumes
-CL_DEV inline void analyze_es_dev(const char* es, uint32_t n, uint32_t d_before, PendRec& p)
-{
-	for (int i = 0; i < 12; ++i) p.rd[i] = 0;
-	p.len_cost = 0;
-	char c = d_before ? 'D' : ' '; uint32_t len = d_before;
-	for (uint32_t i = 0; i <= n; ++i)
-	{
-		const char x = i < n ? es[i] : ' ';
-		if (x == c) { ++len; continue; }
-		if (c == 'D') { if (len >= 10) { ++p.rd[9]; p.len_cost += bitlen32(len) + 1; } else p.rd[4] += len; }
-		else if (c == 'M') { if (len >= 15) { ++p.rd[10]; p.len_cost += bitlen32(len) + 1; } else p.rd[5] += len; }
-		else if (c != ' ') ++p.rd[est_code(c)];
-		c = x; len = 1;
-	}
-}
-
-// AdjustAnchors (encoder.cpp:778-868) on one candidate's anchors (arrays of length *n), returns total length
-CL_DEV uint32_t adjust_anchors(uint32_t* al, uint32_t* ape, uint32_t* apr, uint32_t* n_io, uint32_t ns, uint32_t ne, uint32_t m)
-{
-	uint32_t n = *n_io; const uint32_t G = 0xffffffffu; uint32_t first = G, last = G, tot = 0;
-	for (uint32_t i = 0; i < n; ++i) if (ape[i] + al[i] > ns) { first = i; break; }
-	if (first == G) { *n_io = 0; return 0; }
-	if (ape[first] < ns && (ape[first] + al[first]) - ns < m) ++first;
-	for (int32_t i = (int32_t)n - 1; i >= 0; --i) if (ape[i] < ne) { last = (uint32_t)i; break; }
-	if (last == G) { *n_io = 0; return 0; }
-	if (last < n && ape[last] + al[last] > ne && ne - ape[last] < m) { if (last == 0) { *n_io = 0; return 0; } --last; }
-	if (first > last) { *n_io = 0; return 0; }
-	n = last + 1 - first;
-	for (uint32_t i = 0; i < n; ++i) { al[i] = al[first + i]; ape[i] = ape[first + i]; apr[i] = apr[first + i]; }
-	if (!n) { *n_io = 0; return 0; }
-	if (ape[n - 1] + al[n - 1] > ne) al[n - 1] -= (ape[n - 1] + al[n - 1] - ne);
-	for (uint32_t i = 0; i < n; ++i)
-	{
-		if (i == 0 && ape[0] < ns) { const uint32_t d = ns - ape[0]; al[0] -= d; ape[0] = 0; apr[0] += d; }
-		else ape[i] -= ns;
-		tot += al[i];
-	}
-	*n_io = n;
-	return tot;
-}
-
-// ---- pass 1 ---------------------------------------------------------------------------------------------------
-// One read: fills ro (always) and the lane-local sink (when the read has candidates).  Returns true when the sink
-// holds the read's items; false for plain reads or when the lane's pool / sink ran out (pool.overflow / sk.overflow).
-CL_DEV bool expand_read(LanePool& pool, const ArenaV& A, const ArenaV& R, const AnchorsV& AV, const EncCfg& cfg, const uint8_t* has_n, uint32_t r, ReadOut& ro, Sink& sk)
-{
-	memset(&ro, 0, sizeof(ro));
-	const uint32_t len = A.lens[r]; const uint64_t wb = A.word_off[r];
-	if (has_n[r]) { ro.plain = 2; return false; }
-	for (uint32_t i = 0; i < len; ++i) ++ro.dna[arena_base_at(A, wb, i)];
-	const uint32_t nc = AV.n_cands[r];
-	if (nc == 0) { ro.plain = 1; return false; }
-	// lane-local output areas (generous: a read's scripts cannot exceed a few times its length)
-	memset(&sk, 0, sizeof(sk));
-	uint32_t tot_anch = 0;
-	for (uint32_t j = 0; j < nc; ++j) tot_anch += AV.cand[((uint64_t)r * cfg.c + j) * 4 + 3];
-	uint32_t max_anch = 0;
-	for (uint32_t j = 0; j < nc; ++j) { const uint32_t a = AV.cand[((uint64_t)r * cfg.c + j) * 4 + 3]; max_anch = a > max_anch ? a : max_anch; }
-	sk.cap_gaps = ((max_anch + 2) * (cfg.max_rec + 1) + len / 64 + 16) * cfg.scale;
-	sk.cap_items = sk.cap_gaps * 4 + 64;
-	sk.cap_pend = sk.cap_gaps;
-	sk.cap_es = (4 * len + 4096) * cfg.scale;
-	sk.items = (uint64_t*)pool.alloc((uint64_t)sk.cap_items * 8); sk.gaps = (GapRec*)pool.alloc((uint64_t)sk.cap_gaps * sizeof(GapRec));
-	sk.pend = (PendRec*)pool.alloc((uint64_t)sk.cap_pend * sizeof(PendRec)); sk.es = (char*)pool.alloc(sk.cap_es);
-	uint8_t* encb = (uint8_t*)pool.alloc(len + 16ull);
-	Frame* frames = (Frame*)pool.alloc(sizeof(Frame) * 10);
-	uint32_t* f0 = (uint32_t*)pool.alloc((tot_anch * 3ull + nc * 5ull + 16) * 4);
-	int fp = 0;
-	if (pool.overflow) fp = -1;
-	else
-	{	// level-0 frame: the candidates as the anchor stage delivered them
-		for (uint32_t i = 0; i < len; ++i) encb[i] = (uint8_t)arena_base_at(A, wb, i);
-		Frame& F = frames[0]; memset(&F, 0, sizeof(F));
-		F.level = 0; F.enc_off = 0; F.enc_len = len; F.n_cands = nc; F.a_span = tot_anch;
-		F.a_len = f0; F.a_pe = f0 + tot_anch; F.a_pr = f0 + 2ull * tot_anch;
-		F.c_first = f0 + 3ull * tot_anch; F.c_n = F.c_first + nc; F.c_tot = F.c_n + nc; F.c_ref = F.c_tot + nc; F.c_rev = (uint8_t*)(F.c_ref + nc);
-		uint32_t o = 0;
-		for (uint32_t j = 0; j < nc; ++j)
-		{
-			const uint64_t s = (uint64_t)r * cfg.c + j;
-			F.c_ref[j] = AV.cand[s * 4]; F.c_rev[j] = (uint8_t)AV.cand[s * 4 + 1]; F.c_tot[j] = AV.cand[s * 4 + 2]; F.c_n[j] = AV.cand[s * 4 + 3]; F.c_first[j] = o;
-			const uint64_t a0 = AV.cand_off[s];
-			for (uint32_t t = 0; t < F.c_n[j]; ++t, ++o) { F.a_len[o] = AV.data[3 * (a0 + t)]; F.a_pe[o] = AV.data[3 * (a0 + t) + 1]; F.a_pr[o] = AV.data[3 * (a0 + t) + 2]; }
-		}
-		F.n_frag = F.c_n[0] * 2 + 1;
-		F.pool_mark = pool.mark();
-		sk.item((IT_BEGIN << 60) | ((uint64_t)0 << 56) | ((uint64_t)F.c_rev[0] << 32) | F.c_ref[0]);
-	}
-	while (fp >= 0 && !pool.overflow && !sk.overflow)
-	{
-		Frame& F = frames[fp];
-		const uint32_t lv = F.level;
-		const uint32_t ref_id = F.c_ref[lv]; const bool rev = F.c_rev[lv] != 0;
-		const uint32_t ref_len = R.lens[ref_id];
-		if (F.i == F.n_frag)
-		{	// end of AddEncodedReadWithCandidates: final StoreFrag (encoder.cpp:1574)
-			sk.item((IT_STORE << 60) | ((uint64_t)lv << 56) | ((uint64_t)(rev ? 1 : 0) << 32) | ref_id);
-			sk.item((IT_STORE2 << 60) | F.cur_ref);
-			sk.item(IT_END << 60);
-			pool.release(F.pool_mark);
-			--fp;
-			if (fp >= 0)
-			{
-				Frame& Pf = frames[fp];
-				pool.release(Pf.pool_mark);
-				if (Pf.after_child) sk.item(it_run('D', Pf.after_child));
-				Pf.after_child = 0;
-			}
-			continue;
-		}
-		const uint32_t* al = F.a_len + F.c_first[lv]; const uint32_t* ape = F.a_pe + F.c_first[lv]; const uint32_t* apr = F.a_pr + F.c_first[lv];
-		if (F.i & 1)
-		{	// anchor
-			sk.item(it_run('M', al[F.anch]));
-			F.cur_ref = apr[F.anch] + al[F.anch]; F.cur_enc = ape[F.anch] + al[F.anch];
-			++F.anch; ++F.i;
-			continue;
-		}
-		// gap (EncodePart, encoder.cpp:1445-1511)
-		const bool last_frag = F.i == F.n_frag - 1;
-		const uint32_t end_enc = last_frag ? F.enc_len : ape[F.anch];
-		const uint32_t end_ref = last_frag ? ref_len : apr[F.anch];
-		const uint32_t want = end_ref - F.cur_ref, avail = ref_len - F.cur_ref;
-		const uint32_t nr = want < avail ? want : avail;
-		const uint32_t ne = end_enc - F.cur_enc;
-		if (end_enc < F.cur_enc || end_enc > F.enc_len || F.cur_ref > ref_len) { sk.overflow = true; sk.why |= 64u; break; }   // inconsistent anchors: refuse rather than run away
-		const uint64_t mk = pool.mark();
-		const bool flank = F.i == 0 || last_frag;
-		const uint32_t use = flank ? (2 * ne < nr ? 2 * ne : nr) : nr;          // reference symbols an alignment of this gap can touch
-		const uint32_t lo = F.i == 0 ? nr - use : 0;
-		uint8_t* refp = (uint8_t*)pool.alloc(use + 16ull);
-		if (!pool.overflow) for (uint32_t i = 0; i < use; ++i) refp[i] = (uint8_t)ref_base_at(R, ref_id, rev, F.cur_ref + lo + i);
-		const uint8_t* encp = encb + F.enc_off + F.cur_enc;
-		if (pool.overflow || sk.n_es + (uint64_t)use + ne + 8 > sk.cap_es || sk.n_gaps >= sk.cap_gaps || sk.n_pend >= sk.cap_pend) {
-#ifdef CL_HOST_DEBUG
-			printf("read %u: sink full at level %u frag %u/%u: nr %u ne %u use %u n_es %u/%u gaps %u/%u pend %u/%u cur_ref %u cur_enc %u end_ref %u end_enc %u ref_len %u\n", r, lv, F.i, F.n_frag, nr, ne, use, sk.n_es, sk.cap_es, sk.n_gaps, sk.cap_gaps, sk.n_pend, sk.cap_pend, F.cur_ref, F.cur_enc, end_ref, end_enc, ref_len);
-#endif
-			sk.overflow = true; sk.why |= 16u; break;
-		}
-		char* es = sk.es + sk.n_es;
-		uint32_t d_before;
-		const uint32_t n_es = gap_edit_script(pool, refp, nr, encp, ne, F.i, F.n_frag, es, &d_before);
-		GapRec g; memset(&g, 0, sizeof(g));
-		g.es_off = sk.n_es; g.es_len = n_es; g.enc_start = F.enc_off + F.cur_enc; g.ne = ne; g.d_after = last_frag ? 0 : end_ref - F.cur_ref; g.d_before = d_before;
-		sk.n_es += n_es;
-		bool accept = false, pending = false;
-		if (ne < cfg.min_part_alt)
-		{	// adaptive estimator decides in pass 2
-			pending = true;
-			PendRec& p = sk.pend[sk.n_pend];
-			analyze_es_dev(es, n_es, d_before, p);
-			p.pl[0] = p.pl[1] = p.pl[2] = p.pl[3] = 0;
-			for (uint32_t i = 0; i < ne; ++i) ++p.pl[encp[i]];
-			p.ref_len = nr;
-			g.pend = sk.n_pend++;
-		}
-		else
-		{	// EncodeWithEditScript (encoder.cpp:1315-1327) with GetEditScriptEntropyInput (:1299-1311)
-			uint32_t nd = 0; while (nd < n_es && es[nd] == 'D') ++nd;
-			const char* p = es; uint32_t n = n_es, extra = d_before;
-			if (nd + d_before >= 10) { p += nd; n -= nd; extra = 0; }
-			accept = entropy_es_dev(p, n, extra) * (double)(n + extra) * cfg.cost_mult < entropy_dna_dev(encp, ne) * (double)ne;
-		}
-		pool.release(mk);
-		if (pending || accept)
-		{
-			g.state = pending ? 2u : 0u;
-			sk.gaps[sk.n_gaps] = g; sk.item((IT_GAP << 60) | sk.n_gaps); ++sk.n_gaps;
-			++F.i;
-			continue;
-		}
-		// rejected long gap: EncodeWithAlternativeRead (encoder.cpp:1329-1346)
-		bool use_alt = false;
-		if (!(F.n_cands <= lv + 1 || ne < cfg.min_part_alt || lv >= cfg.max_rec) && fp + 1 < 10)
-		{
-			Frame& C = frames[fp + 1]; memset(&C, 0, sizeof(C));
-			F.pool_mark = pool.mark();
-			const uint32_t nc2 = F.n_cands;
-			const uint32_t tot_a = F.a_span;
-			uint32_t* f1 = (uint32_t*)pool.alloc((tot_a * 3ull + nc2 * 5ull + 16) * 4);
-			if (pool.overflow) break;
-			C.a_len = f1; C.a_pe = f1 + tot_a; C.a_pr = f1 + 2ull * tot_a;
-			C.c_first = f1 + 3ull * tot_a; C.c_n = C.c_first + nc2; C.c_tot = C.c_n + nc2; C.c_ref = C.c_tot + nc2; C.c_rev = (uint8_t*)(C.c_ref + nc2);
-			for (uint32_t j = 0; j < nc2; ++j) { C.c_first[j] = F.c_first[j]; C.c_n[j] = F.c_n[j]; C.c_tot[j] = F.c_tot[j]; C.c_ref[j] = F.c_ref[j]; C.c_rev[j] = F.c_rev[j]; }
-			for (uint32_t t = 0; t < tot_a; ++t) { C.a_len[t] = F.a_len[t]; C.a_pe[t] = F.a_pe[t]; C.a_pr[t] = F.a_pr[t]; }
-			for (uint32_t j = lv + 1; j < nc2; ++j)
-				C.c_tot[j] = adjust_anchors(C.a_len + C.c_first[j], C.a_pe + C.c_first[j], C.a_pr + C.c_first[j], &C.c_n[j], F.cur_enc, end_enc, cfg.m);
-			// stable insertion sort of candidates lv+1.. by total anchor length (libstdc++ std::sort on <= 16 elements)
-			for (uint32_t i = lv + 2; i < nc2; ++i)
-			{
-				const uint32_t xf = C.c_first[i], xn = C.c_n[i], xt = C.c_tot[i], xr = C.c_ref[i]; const uint8_t xv = C.c_rev[i];
-				uint32_t j = i;
-				while (j > lv + 1 && xt > C.c_tot[j - 1]) { C.c_first[j] = C.c_first[j - 1]; C.c_n[j] = C.c_n[j - 1]; C.c_tot[j] = C.c_tot[j - 1]; C.c_ref[j] = C.c_ref[j - 1]; C.c_rev[j] = C.c_rev[j - 1]; --j; }
-				C.c_first[j] = xf; C.c_n[j] = xn; C.c_tot[j] = xt; C.c_ref[j] = xr; C.c_rev[j] = xv;
-			}
-			use_alt = C.c_tot[lv + 1] != 0;
-			if (use_alt)
-			{
-				sk.item((IT_STORE << 60) | ((uint64_t)lv << 56) | ((uint64_t)(rev ? 1 : 0) << 32) | ref_id);
-				sk.item((IT_STORE2 << 60) | F.cur_ref);
-				C.a_span = tot_a; C.level = lv + 1; C.enc_off = F.enc_off + F.cur_enc; C.enc_len = ne; C.n_cands = nc2;
-				C.n_frag = C.c_n[lv + 1] * 2 + 1;
-				C.pool_mark = pool.mark();
-				sk.item((IT_BEGIN << 60) | ((uint64_t)(lv + 1) << 56) | ((uint64_t)C.c_rev[lv + 1] << 32) | C.c_ref[lv + 1]);
-				F.after_child = last_frag ? 0 : end_ref - F.cur_ref;
-				++F.i;
-				++fp;
-				continue;
-			}
-			pool.release(F.pool_mark);
-		}
-		// literal: the read part as insertions, then the reference part skipped (encoder.cpp:1497-1508)
-		g.state = 1;
-		sk.gaps[sk.n_gaps] = g; sk.item((IT_GAP << 60) | sk.n_gaps); ++sk.n_gaps;
-		++F.i;
-	}
-	return !(pool.overflow || sk.overflow);
-}
-
-__global__ __launch_bounds__(64) void k_encode_expand(ArenaV A, ArenaV R, AnchorsV AV, EncCfg cfg, const uint8_t* __restrict__ has_n, uint32_t n_reads,
-                                                     const uint32_t* __restrict__ todo, uint32_t n_todo, uint32_t* __restrict__ redo, unsigned int* __restrict__ n_redo,
-                                                     uint8_t* __restrict__ scratch, uint64_t scratch_per_lane, unsigned int* __restrict__ next_read,
-                                                     ReadOut* __restrict__ rout, uint64_t* __restrict__ g_items, uint64_t cap_items, GapRec* __restrict__ g_gaps, uint64_t cap_gaps,
-                                                     PendRec* __restrict__ g_pend, uint64_t cap_pend, char* __restrict__ g_es, uint64_t cap_es,
-                                                     unsigned long long* __restrict__ counters /* items, gaps, pend, es */, uint32_t* __restrict__ err)
-{
-	const uint32_t lane_id_g = blockIdx.x * blockDim.x + threadIdx.x;
-	LanePool pool{ scratch + (uint64_t)lane_id_g * scratch_per_lane, scratch_per_lane, 0, false, 0 };
-	for (;;)
-	{
-		const uint32_t slot = atomicAdd(next_read, 1u);
-		if (slot >= n_todo) break;
-		const uint32_t r = todo ? todo[slot] : slot;
-		pool.top = 0; pool.overflow = false; pool.why = 0;
-		ReadOut ro; Sink sk;
-		const bool have = expand_read(pool, A, R, AV, cfg, has_n, r, ro, sk);
-		if (!have && !pool.overflow && !sk.overflow) { rout[r] = ro; continue; }
-		if (pool.overflow || sk.overflow) { redo[atomicAdd(n_redo, 1u)] = r; atomicOr(err, 1u | ((pool.why | sk.why) << 8)); ro.plain = 1; rout[r] = ro; continue; }
-		// publish the read's chunks
-		ro.n_items = sk.n_items; ro.n_gaps = sk.n_gaps; ro.n_pend = sk.n_pend; ro.es_len = sk.n_es;
-		ro.item_off = atomicAdd(&counters[0], (unsigned long long)sk.n_items); ro.gap_off = atomicAdd(&counters[1], (unsigned long long)sk.n_gaps);
-		ro.pend_off = atomicAdd(&counters[2], (unsigned long long)sk.n_pend); ro.es_off = atomicAdd(&counters[3], (unsigned long long)sk.n_es);
-		if (ro.item_off + sk.n_items > cap_items || ro.gap_off + sk.n_gaps > cap_gaps || ro.pend_off + sk.n_pend > cap_pend || ro.es_off + sk.n_es > cap_es)
-		{ atomicOr(err, 2u); ro.plain = 1; ro.n_items = ro.n_gaps = ro.n_pend = ro.es_len = 0; rout[r] = ro; continue; }
-		for (uint32_t i = 0; i < sk.n_items; ++i) g_items[ro.item_off + i] = sk.items[i];
-		for (uint32_t i = 0; i < sk.n_gaps; ++i) g_gaps[ro.gap_off + i] = sk.gaps[i];
-		for (uint32_t i = 0; i < sk.n_pend; ++i) g_pend[ro.pend_off + i] = sk.pend[i];
-		for (uint32_t i = 0; i < sk.n_es; ++i) g_es[ro.es_off + i] = sk.es[i];
-		rout[r] = ro;
-	}
-}
-
-// ---- pass 2: the adaptive estimator, one lane per reader pack (utils.h:877-1130) ---------------------------------
-struct Estim { uint32_t dna[4], es[12], dec[2]; double dna_logs[4], es_logs[12], dec_logs[2]; uint32_t dna_sum, es_sum, dec_sum; };
-CL_DEV inline void est_rescale(uint32_t* a, int n, uint32_t& sum, uint32_t mx) { while (sum > mx) { sum = 0; for (int i = 0; i < n; ++i) { a[i] = (a[i] + 1) / 2; sum += a[i]; } } }
-CL_DEV inline void est_logs(const uint32_t* st, double* lg, int n, uint32_t sum)
-{
-	const double rec = 1.0 / sum;
-	for (int i = 0; i < n; ++i) lg[i] = st[i] ? -log2((double)st[i] * rec) : 0.0;
-}
-CL_DEV void estimate_pack(const ReadOut* rout, const PendRec* pend, uint32_t r_begin, uint32_t r_end, const uint32_t* lens, uint8_t* decisions)
-{
-	Estim e;
-	for (int i = 0; i < 4; ++i) e.dna[i] = 1;
-	e.dna_sum = 4;
-	for (int i = 0; i < 12; ++i) e.es[i] = 1;
-	e.es_sum = 12;
-	e.dec[0] = e.dec[1] = 1; e.dec_sum = 2;
-	est_logs(e.dna, e.dna_logs, 4, e.dna_sum); est_logs(e.es, e.es_logs, 12, e.es_sum); est_logs(e.dec, e.dec_logs, 2, e.dec_sum);
-	for (uint32_t r = r_begin; r < r_end; ++r)
-	{
-		const ReadOut ro = rout[r];
-		if (ro.plain == 2) continue;                                               // reads with N never reach the estimator (encoder.cpp:1629-1633)
-		for (int i = 0; i < 4; ++i) e.dna[i] += ro.dna[i];                           // LogRead (utils.h:946-955)
-		e.dna_sum += lens[r];
-		est_rescale(e.dna, 4, e.dna_sum, 1u << 20);
-		est_logs(e.dna, e.dna_logs, 4, e.dna_sum);
-		for (uint32_t k = 0; k < ro.n_pend; ++k)
-		{	// EncodeWithEditScript (utils.h:1060-1130)
-			const PendRec p = pend[ro.pend_off + k];
-			uint32_t loc[12]; uint32_t loc_sum = e.es_sum;
-			for (int i = 0; i < 12; ++i) { loc[i] = e.es[i] + p.rd[i]; loc_sum += p.rd[i]; }
-			double es_cost = e.dec_logs[0], plain_cost = e.dec_logs[1];
-			est_logs(loc, e.es_logs, 12, loc_sum);
-			for (int i = 0; i < 12; ++i) es_cost += p.rd[i] * e.es_logs[i];
-			es_cost += p.len_cost;
-			for (int i = 0; i < 4; ++i) plain_cost += p.pl[i] * e.dna_logs[i];
-			plain_cost += bitlen32(p.ref_len) + 1;
-			const bool choose_plain = plain_cost < es_cost;
-			if (choose_plain) { ++e.dec[1]; est_rescale(e.es, 12, e.es_sum, 1u << 20); }
-			else { ++e.dec[0]; for (int i = 0; i < 12; ++i) e.es[i] = loc[i]; e.es_sum = loc_sum; est_rescale(e.es, 12, e.es_sum, 1u << 20); }
-			++e.dec_sum;
-			est_rescale(e.dec, 2, e.dec_sum, 1u << 20);
-			est_logs(e.dec, e.dec_logs, 2, e.dec_sum);
-			decisions[ro.pend_off + k] = choose_plain ? 0 : 1;
-		}
-	}
-}
-
-__global__ void k_estimator(const ReadOut* __restrict__ rout, const PendRec* __restrict__ pend, const uint32_t* __restrict__ pack_bounds, uint32_t n_packs,
-                            const uint32_t* __restrict__ lens, uint8_t* __restrict__ decisions)
-{
-	const uint32_t pk = blockIdx.x * blockDim.x + threadIdx.x;
-	if (pk < n_packs) estimate_pack(rout, pend, pack_bounds[pk], pack_bounds[pk + 1], lens, decisions);
-}
-
-// ---- pass 3: tuple emission (encoder.cpp:1348-1443) ---------------------------------------------------------------
-struct TupleOut {
-	uint8_t* p; uint64_t n; uint32_t n_tuples; bool write;
-	CL_DEV inline void byte(uint8_t v) { if (write) p[n] = v; ++n; }
-	CL_DEV inline void t1(uint32_t type, uint32_t val) { byte((uint8_t)((type << 4) + val)); ++n_tuples; }
-	CL_DEV inline void t28(uint32_t type, uint32_t v) { byte((uint8_t)((type << 4) + (v >> 24))); byte((v >> 16) & 0xff); byte((v >> 8) & 0xff); byte(v & 0xff); ++n_tuples; }
-	CL_DEV inline void tid(uint32_t type, uint32_t id, uint32_t rev) { byte((uint8_t)((type << 4) + rev)); byte(id >> 24); byte((id >> 16) & 0xff); byte((id >> 8) & 0xff); byte(id & 0xff); ++n_tuples; }
-};
-struct RunState {
-	char sym; uint32_t rep; TupleOut* o;
-	CL_DEV inline void flush()
-	{
-		if (!rep) return;
-		if (sym == 'M') { if (rep >= 15) o->t28(4, rep); else for (uint32_t i = 0; i < rep; ++i) o->t1(2, 0); }
-		else if (sym == 'D') { if (rep > 16) o->t28(5, rep); else for (uint32_t i = 0; i < rep; ++i) o->t1(1, 0); }
-		else if (sym == 'X' || sym == 'Y' || sym == 'Z') { for (uint32_t i = 0; i < rep; ++i) o->t1(3, (uint32_t)(sym - 'X')); }
-		else { const uint32_t code = sym == 'A' ? 0 : sym == 'C' ? 1 : sym == 'G' ? 2 : 3; for (uint32_t i = 0; i < rep; ++i) o->t1(0, code); }
-		rep = 0;
-	}
-	CL_DEV inline void add(char s, uint32_t n) { if (!n) return; if (rep && s == sym) { rep += n; return; } flush(); sym = s; rep = n; }
-};
-
-template<bool WRITE>
-CL_DEV void emit_read(const ArenaV& A, const uint32_t* inv, uint32_t r, const ReadOut* rout, const uint64_t* g_items, const GapRec* g_gaps, const char* g_es,
-                      const uint8_t* decisions, uint32_t* sizes, uint32_t* ntuples, const uint64_t* es_off, uint8_t* out)
-{
-	const ReadOut ro = rout[r];
-	const uint32_t len = A.lens[r]; const uint64_t wb = A.word_off[r];
-	TupleOut o{ WRITE ? out + es_off[r] : nullptr, 0, 0, WRITE };
-	if (ro.plain)
-	{	// AddPlainRead / AddPlainReadWithN (encoder.cpp:663-681)
-		o.t1(ro.plain == 2 ? 11 : 9, 0);
-		for (uint32_t i = 0; i < len; ++i)
-		{
-			const bool isn = (inv[wb + (i >> 5)] >> (31 - (i & 31))) & 1u;
-			o.t1(8, isn ? 4u : arena_base_at(A, wb, i));
-		}
-		if (!WRITE) { sizes[r] = (uint32_t)o.n; ntuples[r] = o.n_tuples; }
-		return;
-	}
-	const uint64_t* items = g_items + ro.item_off;
-	const GapRec* gaps = g_gaps + ro.gap_off;
-	const char* es = g_es + ro.es_off;
-	auto gap_accepted = [&](const GapRec& g) -> bool { return g.state == 0 || (g.state == 2 && decisions[ro.pend_off + g.pend] != 0); };
-	auto gap_len = [&](const GapRec& g) -> uint64_t { return gap_accepted(g) ? (uint64_t)g.d_before + g.es_len : (uint64_t)g.ne + g.d_after; };
-	uint32_t last_pos[10]; int depth = -1;
-	bool first = true; uint32_t main_id = 0;
-	RunState rs{ 'M', 0, &o };
-	uint32_t i = 0;
-	while (i < ro.n_items)
-	{
-		const uint64_t it = items[i]; const uint64_t kind = it >> 60;
-		if (kind == IT_BEGIN)
-		{
-			++depth; last_pos[depth] = 0;
-			if (depth == 0) { main_id = (uint32_t)it; o.tid(10, main_id, (uint32_t)(it >> 32) & 1u); }     // start_es (encoder.cpp:1523-1527)
-			++i; continue;
-		}
-		if (kind == IT_END) { --depth; ++i; continue; }
-		// a segment: items up to and including the next IT_STORE/IT_STORE2 pair
-		uint32_t j = i; bool nonempty = false;
-		while ((items[j] >> 60) != IT_STORE)
-		{
-			const uint64_t x = items[j];
-			if ((x >> 60) == IT_RUN) nonempty |= (uint32_t)x != 0;
-			else nonempty |= gap_len(gaps[(uint32_t)x]) != 0;
-			++j;
-		}
-		const uint64_t st = items[j], st2 = items[j + 1];
-		const uint32_t level = (uint32_t)(st >> 56) & 15u, rev = (uint32_t)(st >> 32) & 1u, ref_id = (uint32_t)st, cur_ref = (uint32_t)st2;
-		if (nonempty)
-		{	// StoreFrag (encoder.cpp:1414-1443)
-			if (level == 0) { if (ref_id != main_id) o.tid(6, ref_id, rev); else if (!first) o.t1(7, 0); }
-			else { if (ref_id != main_id) o.tid(6, ref_id, rev); else o.t1(7, 0); rs.add('D', last_pos[depth]); }
-			for (uint32_t t = i; t < j; ++t)
-			{
-				const uint64_t x = items[t];
-				if ((x >> 60) == IT_RUN) { rs.add((char)((x >> 32) & 0xff), (uint32_t)x); continue; }
-				const GapRec g = gaps[(uint32_t)x];
-				if (gap_accepted(g)) { rs.add('D', g.d_before); for (uint32_t q = 0; q < g.es_len; ++q) rs.add(es[g.es_off + q], 1); }
-				else
-				{
-					for (uint32_t q = 0; q < g.ne; ++q) rs.add(base_letter(arena_base_at(A, wb, g.enc_start + q)), 1);
-					rs.add('D', g.d_after);
-				}
-			}
-			rs.flush();
-			last_pos[depth] = cur_ref;
-			first = false;
-		}
-		i = j + 2;
-	}
-	if (!WRITE) { sizes[r] = (uint32_t)o.n; ntuples[r] = o.n_tuples; }
-}
-template<bool WRITE>
-__global__ __launch_bounds__(64) void k_emit_tuples(ArenaV A, const uint32_t* __restrict__ inv, uint32_t n_reads, const ReadOut* __restrict__ rout,
-                                                   const uint64_t* __restrict__ g_items, const GapRec* __restrict__ g_gaps, const char* __restrict__ g_es,
-                                                   const uint8_t* __restrict__ decisions, uint32_t* __restrict__ sizes, uint32_t* __restrict__ ntuples,
-                                                   const uint64_t* __restrict__ es_off, uint8_t* __restrict__ out)
+// ---- level 0: one frame per read that has candidates ---------------------------------------------------------------
+__global__ void k_read_flags(const uint32_t* __restrict__ n_cands, const uint8_t* __restrict__ has_n, uint32_t n, uint32_t* __restrict__ flag, uint32_t* __restrict__ ncand)
 {
 	const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-	if (r < n_reads) emit_read<WRITE>(A, inv, r, rout, g_items, g_gaps, g_es, decisions, sizes, ntuples, es_off, out);
+	if (r >= n) return;
+	const uint32_t nc = has_n[r] ? 0u : n_cands[r];
+	flag[r] = nc ? 1u : 0u; ncand[r] = nc;
 }
+__global__ void k_frames_level0(ArenaV A, AnchorsV AV, uint32_t c, const uint8_t* __restrict__ has_n, uint32_t n, const uint32_t* __restrict__ frame_idx, const uint64_t* __restrict__ cand_base,
+                                FrameRec* __restrict__ frames, CandEnt* __restrict__ cands, uint32_t* __restrict__ frame_of_read)
+{
+	const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n) return;
+	const uint32_t nc = has_n[r] ? 0u : AV.n_cands[r];
+	if (!nc) { frame_of_read[r] = 0xffffffffu; return; }
+	const uint32_t f = frame_idx[r];
+	frame_of_read[r] = f;
+	FrameRec F; F.read = r; F.level = 0; F.enc_off = 0; F.enc_len = A.lens[r]; F.n_cands = nc; F.first_gap = 0; F.n_gaps = 0; F.pad = 0; F.cand_base = cand_base[r];
+	frames[f] = F;
+	for (uint32_t j = 0; j < nc; ++j) cands[F.cand_base + j] = cand_level0(AV.cand + ((uint64_t)r * c + j) * 4, AV.cand_off[(uint64_t)r * c + j], AV.data);
+}
+
+// ---- per level ---------------------------------------------------------------------------------------------------
+__global__ void k_frame_gap_counts(const FrameRec* __restrict__ frames, const CandEnt* __restrict__ cands, uint32_t n, uint32_t* __restrict__ counts)
+{
+	const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+	if (f < n) counts[f] = cands[frames[f].cand_base + frames[f].level].n + 1;
+}
+__global__ void k_frame_first_gaps(FrameRec* __restrict__ frames, const uint32_t* __restrict__ first, uint32_t n, uint32_t n_gaps)
+{
+	const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+	if (f >= n) return;
+	frames[f].first_gap = first[f];
+	frames[f].n_gaps = (f + 1 < n ? first[f + 1] : n_gaps) - first[f];
+}
+__global__ void k_gap_geometry(LevelV L, ArenaV R, const uint32_t* __restrict__ data, uint32_t min_part_alt, const uint32_t* __restrict__ first_gap,
+                               uint32_t* __restrict__ cap, uint32_t* __restrict__ pend_flag, uint32_t* __restrict__ keys, uint32_t* __restrict__ ids, uint32_t* __restrict__ err)
+{
+	const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
+	if (gi >= L.n_gaps) return;
+	uint32_t lo = 0, hi = L.n_frames;                                        // the frame that owns gap gi: last f with first_gap[f] <= gi
+	while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (first_gap[mid] <= gi) lo = mid; else hi = mid; }
+	GapRec g;
+	if (!gap_init(L, lo, gi - first_gap[lo], data, R, g)) atomicOr(err, 4u);
+	L.gaps[gi] = g;
+	cap[gi] = gap_es_capacity(g);
+	pend_flag[gi] = g.ne < min_part_alt ? 1u : 0u;
+	keys[gi] = gap_sort_key(g);
+	ids[gi] = gi;
+}
+__global__ void k_gap_offsets(GapRec* __restrict__ gaps, const uint64_t* __restrict__ es_off, uint32_t n)
+{
+	const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
+	if (gi < n) gaps[gi].es_off = es_off[gi];
+}
+__global__ void k_class_bounds(const uint32_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ bounds /* 7 */)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i > n) return;
+	const uint32_t a = i == 0 ? 0u : (keys[i - 1] >> 10) + 1, b = i == n ? 7u : (keys[i] >> 10) + 1;   // classes [a, b) start at i
+	for (uint32_t c = a; c < b && c < 7; ++c) bounds[c] = i;
+}
+
+// lane-private staging memory in LDS (word w of a lane at lds[w * 64 + lane]) + column history in HBM (lane-interleaved)
+template<int NB>
+struct LdsMem {
+	static constexpr uint32_t QW = 16 * NB, TW = 64;                          // words: rows, columns; then the script (16*NB + 64)
+	uint8_t* base; uint64_t* hist; uint32_t lane;
+	__device__ inline uint32_t addr(uint32_t w0, uint32_t b) const { return ((w0 + (b >> 2)) * 64 + lane) * 4 + (b & 3); }
+	__device__ inline uint32_t q(uint32_t i) const { return base[addr(0, i)]; }
+	__device__ inline uint32_t t(uint32_t j) const { return base[addr(QW, j)]; }
+	__device__ inline void q_set(uint32_t i, uint32_t v) { base[addr(0, i)] = (uint8_t)v; }
+	__device__ inline void t_set(uint32_t j, uint32_t v) { base[addr(QW, j)] = (uint8_t)v; }
+	__device__ inline char es_get(uint32_t k) const { return (char)base[addr(QW + TW, k)]; }
+	__device__ inline void es_set(uint32_t k, char c) { base[addr(QW + TW, k)] = (uint8_t)c; }
+	__device__ inline uint32_t es_word(uint32_t w) const { return ((const uint32_t*)base)[(QW + TW + w) * 64 + lane]; }
+	__device__ inline void hist_put(uint32_t j, uint32_t b, uint64_t P, uint64_t Ph) { uint64_t* h = hist + ((uint64_t)(j * NB + b) * 2) * 64 + lane; h[0] = P; h[64] = Ph; }
+	__device__ inline void hist_get(uint32_t j, uint32_t b, uint64_t& P, uint64_t& Ph) const { const uint64_t* h = hist + ((uint64_t)(j * NB + b) * 2) * 64 + lane; P = h[0]; Ph = h[64]; }
+};
+
+template<int NB>
+__global__ __launch_bounds__(64) void k_align_small(const uint32_t* __restrict__ list, uint32_t n_list, GapRec* __restrict__ gaps, char* __restrict__ es_pool,
+                                                   ArenaV A, ArenaV R, uint64_t* __restrict__ hist_all)
+{
+	extern __shared__ uint32_t lds_raw[];
+	LdsMem<NB> mem{ (uint8_t*)lds_raw, hist_all + (uint64_t)blockIdx.x * (256ull * NB * 2 * 64), threadIdx.x };
+	for (uint32_t chunk = blockIdx.x; (uint64_t)chunk * 64 < n_list; chunk += gridDim.x)
+	{
+		const uint32_t idx = chunk * 64 + threadIdx.x;
+		if (idx >= n_list) continue;
+		const uint32_t gi = list[idx];
+		const GapRec g = gaps[gi];
+		uint32_t n, m;
+		stage_small(mem, g, A, R, n, m);
+		uint32_t d_before;
+		const uint32_t k = align_small<NB>(mem, n, m, g.kind, g.left != 0, g.nr, g.use, &d_before);
+		uint32_t* dst = (uint32_t*)(es_pool + g.es_off);
+		for (uint32_t w = 0; w * 4 < k; ++w) dst[w] = mem.es_word(w);
+		gaps[gi].es_len = k; gaps[gi].d_before = d_before;
+	}
+}
+
+// the rest: one lane per gap, lane pool in HBM; gaps whose lane ran out of pool are redone with larger pools
+__global__ __launch_bounds__(64) void k_align_large(const uint32_t* __restrict__ list, uint32_t n_list, GapRec* __restrict__ gaps, char* __restrict__ es_pool, ArenaV A, ArenaV R,
+                                                   uint8_t* __restrict__ scratch, uint64_t per_lane, unsigned int* __restrict__ next, uint32_t* __restrict__ redo, unsigned int* __restrict__ n_redo)
+{
+	LanePool pool{ scratch + (uint64_t)(blockIdx.x * blockDim.x + threadIdx.x) * per_lane, per_lane, 0, false, 0 };
+	for (;;)
+	{
+		const uint32_t slot = atomicAdd(next, 1u);
+		if (slot >= n_list) break;
+		const uint32_t gi = list[n_list - 1 - slot];                            // the list is ascending by size: largest first
+		pool.top = 0; pool.overflow = false; pool.why = 0;
+		GapRec g = gaps[gi];
+		if (!align_large_gap(pool, g, A, R, es_pool + g.es_off)) { redo[atomicAdd(n_redo, 1u)] = gi; continue; }
+		gaps[gi].es_len = g.es_len; gaps[gi].d_before = g.d_before;
+	}
+}
+
+__global__ void k_gap_stats(LevelV L, ArenaV A, EncCfg cfg, const uint32_t* __restrict__ pend_idx, uint32_t* __restrict__ spawn_flag)
+{
+	const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
+	if (gi < L.n_gaps) spawn_flag[gi] = gap_finish(L, gi, A, cfg, pend_idx[gi]) ? 1u : 0u;
+}
+// rejected long gaps: continue in a child frame when an alternative candidate still has anchors there, else literal
+__global__ void k_spawn_mark(LevelV L, const uint32_t* __restrict__ data, EncCfg cfg, uint32_t* __restrict__ flag, uint32_t* __restrict__ ncand)
+{
+	const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
+	if (gi >= L.n_gaps) return;
+	ncand[gi] = 0;
+	if (!flag[gi]) return;
+	const GapRec g = L.gaps[gi];
+	const FrameRec F = L.frames[g.frame];
+	CandEnt out[16];
+	const bool alt = spawn_cands(F, L.cands + F.cand_base, data, g, cfg, out);
+	flag[gi] = alt ? 1u : 0u;
+	ncand[gi] = alt ? F.n_cands : 0u;
+	if (!alt) L.gaps[gi].state = GS_LITERAL;
+}
+__global__ void k_spawn_fill(LevelV L, const uint32_t* __restrict__ data, EncCfg cfg, const uint32_t* __restrict__ flag_scan, const uint64_t* __restrict__ cand_base,
+                             FrameRec* __restrict__ frames_next, CandEnt* __restrict__ cands_next)
+{
+	const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
+	if (gi >= L.n_gaps) return;
+	if (cand_base[gi + 1] == cand_base[gi]) return;
+	spawn_child(L, gi, data, cfg, flag_scan[gi], cand_base[gi], frames_next, cands_next);
+}
+
+// ---- estimator and emission -------------------------------------------------------------------------------------------
+__global__ void k_read_base_counts(ArenaV A, const uint8_t* __restrict__ has_n, uint32_t n, uint32_t* __restrict__ counts /* 4 per read */)
+{	// one wave per read
+	const uint32_t r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+	if (r >= n) return;
+	uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+	if (!has_n[r])
+	{
+		const uint32_t len = A.lens[r]; const uint64_t wb = A.word_off[r];
+		for (uint32_t w = lane; w * 32 < len; w += 64)
+		{
+			const uint64_t x = A.packed[wb + w]; const uint32_t cnt = len - w * 32 < 32 ? len - w * 32 : 32;
+			const uint64_t lo = x & 0x5555555555555555ull, hi = (x >> 1) & 0x5555555555555555ull;
+			const uint64_t valid = cnt == 32 ? 0x5555555555555555ull : (0x5555555555555555ull & ~((1ull << (64 - 2 * cnt)) - 1));
+			c0 += __popcll(~hi & ~lo & valid); c1 += __popcll(~hi & lo & valid); c2 += __popcll(hi & ~lo & valid); c3 += __popcll(hi & lo & valid);
+		}
+	}
+	for (int o = 32; o; o >>= 1) { c0 += __shfl_xor(c0, o); c1 += __shfl_xor(c1, o); c2 += __shfl_xor(c2, o); c3 += __shfl_xor(c3, o); }
+	if (lane == 0) { counts[4 * r] = c0; counts[4 * r + 1] = c1; counts[4 * r + 2] = c2; counts[4 * r + 3] = c3; }
+}
+__global__ void k_estimator(TreeV T, const uint32_t* __restrict__ pack_bounds, uint32_t n_packs, const uint32_t* __restrict__ lens, const uint8_t* __restrict__ has_n,
+                            const uint32_t* __restrict__ base_counts)
+{
+	const uint32_t pk = blockIdx.x * blockDim.x + threadIdx.x;
+	if (pk < n_packs) est_pack(T, pack_bounds[pk], pack_bounds[pk + 1], lens, has_n, base_counts);
+}
+template<bool WRITE>
+__global__ __launch_bounds__(64) void k_emit_tuples(ArenaV A, const uint32_t* __restrict__ inv, const uint8_t* __restrict__ has_n, TreeV T, uint32_t n_reads, const uint32_t* __restrict__ data,
+                                                   uint32_t* __restrict__ sizes, uint32_t* __restrict__ ntuples, const uint64_t* __restrict__ es_off, uint8_t* __restrict__ out)
+{
+	const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r < n_reads) emit_read<WRITE>(A, inv, has_n, T, r, data, sizes, ntuples, es_off, out);
+}
+
+struct LevelBufs {
+	DevBuf<FrameRec> frames; DevBuf<CandEnt> cands; DevBuf<GapRec> gaps; DevBuf<char> es; DevBuf<PendRec> pend; DevBuf<uint8_t> dec;
+	uint32_t n_frames = 0, n_gaps = 0; uint64_t n_cands = 0;
+	LevelV view() { return LevelV{ frames.p, cands.p, gaps.p, es.p, pend.p, dec.p, n_frames, n_gaps }; }
+};
 } // namespace
 
 // CEncoder::Encode for all reads of the arena (encoder.cpp:1672-1691).  h_pack_bounds: the reader packs (the
@@ -659,71 +228,155 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 	if (!nr) return CL_OK;
 	ArenaV A{ reads->packed.p, reads->word_off.p, reads->lens.p }, R{ refs->packed.p, refs->word_off.p, refs->lens.p };
 	AnchorsV AV{ cl_anchors_n_cands(anchors), cl_anchors_cands(anchors), cl_anchors_cand_offsets(anchors), cl_anchors_data(anchors) };
-	uint32_t maxlen = 0, max_ref = 0;
-	{
-		std::vector<uint32_t> h(std::max(nr, refs->n_reads));
-		HIP_TRY(ctx, hipMemcpy(h.data(), reads->lens.p, (uint64_t)nr * 4, hipMemcpyDeviceToHost));
-		for (uint32_t i = 0; i < nr; ++i) maxlen = std::max(maxlen, h[i]);
-		if (refs->n_reads) HIP_TRY(ctx, hipMemcpy(h.data(), refs->lens.p, (uint64_t)refs->n_reads * 4, hipMemcpyDeviceToHost));
-		for (uint32_t i = 0; i < refs->n_reads; ++i) max_ref = std::max(max_ref, h[i]);
-	}
-	const uint64_t cap_items = 16ull * nr + reads->total_bases / 4 + 1024, cap_gaps = cap_items / 2, cap_pend = cap_gaps, cap_es = 3 * reads->total_bases + 4096ull * 64 + 2ull * max_ref;
-	DevBuf<ReadOut> rout; DEV_ALLOC(ctx, rout, nr);
-	DevBuf<uint64_t> items; DEV_ALLOC(ctx, items, cap_items);
-	DevBuf<GapRec> gaps; DEV_ALLOC(ctx, gaps, cap_gaps);
-	DevBuf<PendRec> pend; DEV_ALLOC(ctx, pend, cap_pend);
-	DevBuf<char> esb; DEV_ALLOC(ctx, esb, cap_es);
-	DevBuf<unsigned long long> counters; DEV_ALLOC(ctx, counters, 4);
+	const EncCfg cfg{ c, anchor_len, min_part_alt, max_rec, cost_mult };
+	const uint8_t* has_n = reads->has_n.p;
+	hipStream_t st = ctx->stream;
+
+	std::vector<std::unique_ptr<LevelBufs>> levels;
+	DevBuf<uint32_t> frame_of_read; DEV_ALLOC(ctx, frame_of_read, nr);
 	DevBuf<uint32_t> err; DEV_ALLOC(ctx, err, 1);
-	DevBuf<unsigned int> cnt; DEV_ALLOC(ctx, cnt, 2);                    // next slot, number of reads to redo
-	DevBuf<uint32_t> todo, redo; DEV_ALLOC(ctx, todo, nr); DEV_ALLOC(ctx, redo, nr);
-	HIP_TRY(ctx, hipMemsetAsync(counters.p, 0, 32, ctx->stream));
-	// Pass 1 in rounds: many lanes with small pools first; the reads whose lane ran out of pool (long gaps need up to
-	// 1 MiB of traceback state, edlib's own threshold, plus Hirschberg columns) are redone by fewer lanes with larger pools.
-	uint32_t n_todo = nr; bool have_list = false;
-	uint64_t per_lane = (256ull << 10) + 24ull * std::min<uint32_t>(maxlen, 65536);
-	uint32_t n_lanes = 32768, scale = 1, last_err = 0;
-	for (int round = 0; n_todo; ++round)
-	{
-		if (round == 4) return cl_fail(ctx, CL_E_NOMEM, "cl_encode_reads: lane pool exhausted after 4 rounds (reasons " + std::to_string(last_err >> 8) + ", " + std::to_string(n_todo) + " reads)");
-		const uint32_t lanes = (uint32_t)std::min<uint64_t>(((uint64_t)n_todo + 63) / 64 * 64, n_lanes);
-		DevBuf<uint8_t> scratch; DEV_ALLOC(ctx, scratch, per_lane * lanes);
-		EncCfg cfg{ c, anchor_len, min_part_alt, max_rec, cost_mult, scale, max_ref };
-		HIP_TRY(ctx, hipMemsetAsync(cnt.p, 0, 8, ctx->stream));
-		HIP_TRY(ctx, hipMemsetAsync(err.p, 0, 4, ctx->stream));
-		LAUNCHB(ctx, reads->total_bases * 3.0, k_encode_expand, lanes / 64, 64, A, R, AV, cfg, (const uint8_t*)reads->has_n.p, nr,
-			have_list ? (const uint32_t*)todo.p : (const uint32_t*)nullptr, n_todo, redo.p, cnt.p + 1, scratch.p, per_lane, cnt.p,
-			rout.p, items.p, cap_items, gaps.p, cap_gaps, pend.p, cap_pend, esb.p, cap_es, counters.p, err.p);
+	HIP_TRY(ctx, hipMemsetAsync(err.p, 0, 4, st));
+	{	// level 0
+		auto L = std::make_unique<LevelBufs>();
+		DevBuf<uint32_t> flag, ncand; DEV_ALLOC(ctx, flag, (uint64_t)nr + 1); DEV_ALLOC(ctx, ncand, (uint64_t)nr + 1);
+		DevBuf<uint64_t> cbase; DEV_ALLOC(ctx, cbase, (uint64_t)nr + 1);
+		LAUNCH(ctx, k_read_flags, grid_for(nr, 256), 256, AV.n_cands, has_n, nr, flag.p, ncand.p);
+		uint64_t nf = 0;
+		CL_TRY(dev_exclusive_scan_u64(ctx, ncand.p, cbase.p, nr, &L->n_cands));
+		CL_TRY(dev_exclusive_scan_u32(ctx, flag.p, nr, &nf));
+		L->n_frames = (uint32_t)nf;
+		DEV_ALLOC(ctx, L->frames, nf + 1); DEV_ALLOC(ctx, L->cands, L->n_cands + 1);
+		LAUNCH(ctx, k_frames_level0, grid_for(nr, 256), 256, A, AV, c, has_n, nr, (const uint32_t*)flag.p, (const uint64_t*)cbase.p, L->frames.p, L->cands.p, frame_of_read.p);
 		HIP_TRY(ctx, hipGetLastError());
-		uint32_t herr = 0; unsigned int hcnt[2];
-		HIP_TRY(ctx, hipMemcpyAsync(&herr, err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-		HIP_TRY(ctx, hipMemcpyAsync(hcnt, cnt.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-		if (herr & 2) return cl_fail(ctx, CL_E_NOMEM, "cl_encode_reads: intermediate buffers too small");
-		n_todo = hcnt[1]; last_err = herr;
-		if (n_todo) { HIP_TRY(ctx, hipMemcpyAsync(todo.p, redo.p, (uint64_t)n_todo * 4, hipMemcpyDeviceToDevice, ctx->stream)); have_list = true; }
-		per_lane = per_lane * 8 + 96ull * maxlen; n_lanes = std::max<uint32_t>(n_lanes / 8, 64); scale *= 4;
+		HIP_TRY(ctx, hipStreamSynchronize(st));
+		levels.push_back(std::move(L));
 	}
-	unsigned long long hc[4];
-	HIP_TRY(ctx, hipMemcpy(hc, counters.p, 32, hipMemcpyDeviceToHost));
-	// pass 2
-	DevBuf<uint8_t> decisions; DEV_ALLOC(ctx, decisions, hc[2] + 1);
+	const uint32_t n_cu = 256;
+	for (uint32_t lv = 0; lv < levels.size(); ++lv)
+	{
+		LevelBufs& L = *levels[lv];
+		if (!L.n_frames) break;
+		// gaps of the level
+		DevBuf<uint32_t> first; DEV_ALLOC(ctx, first, (uint64_t)L.n_frames + 1);
+		LAUNCH(ctx, k_frame_gap_counts, grid_for(L.n_frames, 256), 256, (const FrameRec*)L.frames.p, (const CandEnt*)L.cands.p, L.n_frames, first.p);
+		uint64_t ng = 0;
+		CL_TRY(dev_exclusive_scan_u32(ctx, first.p, L.n_frames, &ng));
+		if (ng >= (1ull << 32)) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_encode_reads: more than 2^32 gaps in one call");
+		L.n_gaps = (uint32_t)ng;
+		LAUNCH(ctx, k_frame_first_gaps, grid_for(L.n_frames, 256), 256, L.frames.p, (const uint32_t*)first.p, L.n_frames, L.n_gaps);
+		DEV_ALLOC(ctx, L.gaps, ng + 1);
+		DevBuf<uint32_t> capw, pflag, keys, ids; DEV_ALLOC(ctx, capw, ng + 1); DEV_ALLOC(ctx, pflag, ng + 1); DEV_ALLOC(ctx, keys, ng + 1); DEV_ALLOC(ctx, ids, ng + 1);
+		LevelV V = L.view();
+		LAUNCH(ctx, k_gap_geometry, grid_for(ng, 256), 256, V, R, AV.data, min_part_alt, (const uint32_t*)first.p, capw.p, pflag.p, keys.p, ids.p, err.p);
+		DevBuf<uint64_t> es_off; DEV_ALLOC(ctx, es_off, ng + 1);
+		uint64_t es_total = 0, n_pend = 0;
+		CL_TRY(dev_exclusive_scan_u64(ctx, capw.p, es_off.p, ng, &es_total));
+		CL_TRY(dev_exclusive_scan_u32(ctx, pflag.p, ng, &n_pend));
+		LAUNCH(ctx, k_gap_offsets, grid_for(ng, 256), 256, L.gaps.p, (const uint64_t*)es_off.p, L.n_gaps);
+		DEV_ALLOC(ctx, L.es, es_total + 16); DEV_ALLOC(ctx, L.pend, n_pend + 1); DEV_ALLOC(ctx, L.dec, n_pend + 1);
+		V = L.view();
+		// size classes
+		CL_TRY(dev_sort_keys32_pairs(ctx, keys.p, ids.p, ng, 0, 13));
+		DevBuf<uint32_t> bounds; DEV_ALLOC(ctx, bounds, 8);
+		LAUNCH(ctx, k_class_bounds, grid_for(ng + 1, 256), 256, (const uint32_t*)keys.p, L.n_gaps, bounds.p);
+		uint32_t hb[7];
+		HIP_TRY(ctx, hipMemcpyAsync(hb, bounds.p, 28, hipMemcpyDeviceToHost, st));
+		HIP_TRY(ctx, hipStreamSynchronize(st));
+		// small gaps
+		{
+			uint32_t max_blocks = 1;
+			for (int nb = 1; nb <= 4; ++nb) max_blocks = std::max(max_blocks, std::min<uint32_t>(grid_for(hb[nb + 1] - hb[nb], 64), n_cu * 4));
+			DevBuf<uint64_t> hist; DEV_ALLOC(ctx, hist, (uint64_t)max_blocks * 256 * 4 * 2 * 64);
+			for (int nb = 1; nb <= 4; ++nb)
+			{
+				const uint32_t n_list = hb[nb + 1] - hb[nb];
+				if (!n_list) continue;
+				const uint32_t blocks = std::min<uint32_t>(grid_for(n_list, 64), n_cu * 4);
+				const uint32_t lds = (16 * nb + 64 + 16 * nb + 64) * 64 * 4;
+				const double bytes = (double)n_list * 64;
+				const uint32_t* list = ids.p + hb[nb];
+				switch (nb)
+				{
+				case 1: LAUNCHB_SHM(ctx, bytes, (k_align_small<1>), blocks, 64, lds, list, n_list, L.gaps.p, L.es.p, A, R, hist.p); break;
+				case 2: LAUNCHB_SHM(ctx, bytes, (k_align_small<2>), blocks, 64, lds, list, n_list, L.gaps.p, L.es.p, A, R, hist.p); break;
+				case 3: LAUNCHB_SHM(ctx, bytes, (k_align_small<3>), blocks, 64, lds, list, n_list, L.gaps.p, L.es.p, A, R, hist.p); break;
+				default: LAUNCHB_SHM(ctx, bytes, (k_align_small<4>), blocks, 64, lds, list, n_list, L.gaps.p, L.es.p, A, R, hist.p); break;
+				}
+				HIP_TRY(ctx, hipGetLastError());
+			}
+			HIP_TRY(ctx, hipStreamSynchronize(st));
+		}
+		// large gaps, in rounds of growing lane pools
+		{
+			uint32_t n_list = hb[6] - hb[5];
+			DevBuf<uint32_t> todo, redo; DEV_ALLOC(ctx, todo, (uint64_t)n_list + 1); DEV_ALLOC(ctx, redo, (uint64_t)n_list + 1);
+			DevBuf<unsigned int> cnt; DEV_ALLOC(ctx, cnt, 2);
+			const uint32_t* list = ids.p + hb[5];
+			uint64_t per_lane = 2ull << 20; uint32_t max_lanes = 16384;
+			for (int round = 0; n_list; ++round)
+			{
+				if (round == 5) return cl_fail(ctx, CL_E_NOMEM, "cl_encode_reads: lane pool exhausted (" + std::to_string(n_list) + " gaps left)");
+				const uint32_t lanes = (uint32_t)std::min<uint64_t>(((uint64_t)n_list + 63) / 64 * 64, max_lanes);
+				DevBuf<uint8_t> scratch; DEV_ALLOC(ctx, scratch, per_lane * lanes);
+				HIP_TRY(ctx, hipMemsetAsync(cnt.p, 0, 8, st));
+				LAUNCH(ctx, k_align_large, lanes / 64, 64, list, n_list, L.gaps.p, L.es.p, A, R, scratch.p, per_lane, cnt.p, redo.p, cnt.p + 1);
+				HIP_TRY(ctx, hipGetLastError());
+				unsigned int hc[2];
+				HIP_TRY(ctx, hipMemcpyAsync(hc, cnt.p, 8, hipMemcpyDeviceToHost, st));
+				HIP_TRY(ctx, hipStreamSynchronize(st));
+				n_list = hc[1];
+				if (n_list)
+				{
+					HIP_TRY(ctx, hipMemcpyAsync(todo.p, redo.p, (uint64_t)n_list * 4, hipMemcpyDeviceToDevice, st));
+					HIP_TRY(ctx, hipStreamSynchronize(st));
+					list = todo.p;
+				}
+				per_lane *= 8; max_lanes = std::max<uint32_t>(max_lanes / 8, 64);
+			}
+		}
+		// statistics / decisions, children
+		DevBuf<uint32_t> sflag, sncand; DEV_ALLOC(ctx, sflag, ng + 1); DEV_ALLOC(ctx, sncand, ng + 1);
+		LAUNCH(ctx, k_gap_stats, grid_for(ng, 64), 64, V, A, cfg, (const uint32_t*)pflag.p, sflag.p);
+		LAUNCH(ctx, k_spawn_mark, grid_for(ng, 64), 64, V, AV.data, cfg, sflag.p, sncand.p);      // refuses beyond max_rec: those gaps become literals
+		HIP_TRY(ctx, hipGetLastError());
+		if (lv >= max_rec || lv + 1 >= 10) { HIP_TRY(ctx, hipStreamSynchronize(st)); break; }
+		auto N = std::make_unique<LevelBufs>();
+		DevBuf<uint64_t> cbase; DEV_ALLOC(ctx, cbase, ng + 1);
+		uint64_t nf = 0;
+		CL_TRY(dev_exclusive_scan_u64(ctx, sncand.p, cbase.p, ng, &N->n_cands));
+		CL_TRY(dev_exclusive_scan_u32(ctx, sflag.p, ng, &nf));
+		N->n_frames = (uint32_t)nf;
+		if (!nf) break;
+		DEV_ALLOC(ctx, N->frames, nf + 1); DEV_ALLOC(ctx, N->cands, N->n_cands + 1);
+		LAUNCH(ctx, k_spawn_fill, grid_for(ng, 64), 64, V, AV.data, cfg, (const uint32_t*)sflag.p, (const uint64_t*)cbase.p, N->frames.p, N->cands.p);
+		HIP_TRY(ctx, hipGetLastError());
+		HIP_TRY(ctx, hipStreamSynchronize(st));
+		levels.push_back(std::move(N));
+	}
+	uint32_t herr = 0;
+	HIP_TRY(ctx, hipMemcpyAsync(&herr, err.p, 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(ctx, hipStreamSynchronize(st));
+	if (herr) return cl_fail(ctx, CL_E_INVALID, "cl_encode_reads: inconsistent anchors");
+
+	TreeV T; memset(&T, 0, sizeof(T));
+	for (size_t i = 0; i < levels.size() && i < 10; ++i) T.lv[i] = levels[i]->view();
+	T.frame_of_read = frame_of_read.p;
+	// estimator (per reader pack), then tuples: sizes, offsets, bytes
+	DevBuf<uint32_t> base_counts; DEV_ALLOC(ctx, base_counts, 4ull * nr);
+	LAUNCHB(ctx, reads->total_bases / 4.0, k_read_base_counts, grid_for((uint64_t)nr * 64, 256), 256, A, has_n, nr, base_counts.p);
 	DevBuf<uint32_t> d_pb; DEV_ALLOC(ctx, d_pb, (uint64_t)n_packs + 1);
-	HIP_TRY(ctx, hipMemcpyAsync(d_pb.p, h_pack_bounds, ((uint64_t)n_packs + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-	LAUNCH(ctx, k_estimator, grid_for(n_packs, 64), 64, (const ReadOut*)rout.p, (const PendRec*)pend.p, (const uint32_t*)d_pb.p, n_packs, (const uint32_t*)reads->lens.p, decisions.p);
-	// pass 3: sizes, offsets, bytes
+	HIP_TRY(ctx, hipMemcpyAsync(d_pb.p, h_pack_bounds, ((uint64_t)n_packs + 1) * 4, hipMemcpyHostToDevice, st));
+	LAUNCH(ctx, k_estimator, grid_for(n_packs, 64), 64, T, (const uint32_t*)d_pb.p, n_packs, (const uint32_t*)reads->lens.p, has_n, (const uint32_t*)base_counts.p);
 	DevBuf<uint32_t> sizes; DEV_ALLOC(ctx, sizes, nr);
-	LAUNCH(ctx, (k_emit_tuples<false>), grid_for(nr, 64), 64, A, (const uint32_t*)reads->inv.p, nr, (const ReadOut*)rout.p, (const uint64_t*)items.p,
-		(const GapRec*)gaps.p, (const char*)esb.p, (const uint8_t*)decisions.p, sizes.p, d_es_ntuples, (const uint64_t*)nullptr, (uint8_t*)nullptr);
+	LAUNCH(ctx, (k_emit_tuples<false>), grid_for(nr, 64), 64, A, (const uint32_t*)reads->inv.p, has_n, T, nr, AV.data, sizes.p, d_es_ntuples, (const uint64_t*)nullptr, (uint8_t*)nullptr);
 	HIP_TRY(ctx, hipGetLastError());
 	uint64_t total = 0;
 	CL_TRY(dev_exclusive_scan_u64(ctx, sizes.p, d_es_off, nr, &total));
 	*n_out = total;
 	if (total > cap || (total && !d_es)) return cl_fail(ctx, CL_E_CAPACITY, "cl_encode_reads: need " + std::to_string(total) + " bytes");
-	LAUNCH(ctx, (k_emit_tuples<true>), grid_for(nr, 64), 64, A, (const uint32_t*)reads->inv.p, nr, (const ReadOut*)rout.p, (const uint64_t*)items.p,
-		(const GapRec*)gaps.p, (const char*)esb.p, (const uint8_t*)decisions.p, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint64_t*)d_es_off, d_es);
+	LAUNCH(ctx, (k_emit_tuples<true>), grid_for(nr, 64), 64, A, (const uint32_t*)reads->inv.p, has_n, T, nr, AV.data, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint64_t*)d_es_off, d_es);
 	HIP_TRY(ctx, hipGetLastError());
-	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(st));
 	cl_timing_collect(ctx);
 	return CL_OK;
 }

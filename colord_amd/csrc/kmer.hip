@@ -127,7 +127,7 @@ __global__ void k_select_geometry(const uint8_t* __restrict__ keep, const uint32
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	const uint32_t kp = keep[i] ? 1u : 0u;
-	flag[i] = kp; words[i] = kp ? (lens[i] + 31) / 32 : 0u;
+	flag[i] = kp; words[i] = kp ? lens[i] / 32 + 1 : 0u;       // arena layout: len/32 + 1 words per read (cl_reads_pack)
 }
 __global__ void k_select_copy(const uint8_t* __restrict__ keep, const uint32_t* __restrict__ rank, const uint64_t* __restrict__ new_off, const uint64_t* __restrict__ old_off,
                               const uint32_t* __restrict__ lens, const uint8_t* __restrict__ has_n, const uint64_t* __restrict__ packed, const uint32_t* __restrict__ inv, uint32_t n,
@@ -135,7 +135,7 @@ __global__ void k_select_copy(const uint8_t* __restrict__ keep, const uint32_t* 
 {	// one wave per read
 	const uint32_t r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
 	if (r >= n || !keep[r]) return;
-	const uint32_t j = rank[r]; const uint64_t so = old_off[r], d = new_off[r]; const uint32_t w = (lens[r] + 31) / 32;
+	const uint32_t j = rank[r]; const uint64_t so = old_off[r], d = new_off[r]; const uint32_t w = lens[r] / 32 + 1;
 	if (lane == 0) { o_off[j] = d; o_lens[j] = lens[r]; o_has_n[j] = has_n[r]; }
 	for (uint32_t i = lane; i < w; i += 64) { o_packed[d + i] = packed[so + i]; o_inv[d + i] = inv[so + i]; }
 }
@@ -187,18 +187,18 @@ namespace {
 __global__ void k_arena_geometry(const uint32_t* __restrict__ lens, uint32_t n, uint32_t* __restrict__ words)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n) words[i] = (lens[i] + 31) / 32;
+	if (i < n) words[i] = lens[i] / 32 + 1;
 }
 __global__ void k_arena_has_n(const uint64_t* __restrict__ off, const uint32_t* __restrict__ lens, const uint32_t* __restrict__ inv, uint32_t n, uint8_t* __restrict__ has_n)
 {	// one wave per read: any invalid bit inside the read's length
 	const uint32_t r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
 	if (r >= n) return;
-	const uint32_t len = lens[r], w = (len + 31) / 32; const uint64_t o = off[r];
+	const uint32_t len = lens[r], w = len / 32 + 1; const uint64_t o = off[r];
 	bool any = false;
 	for (uint32_t i = lane; i < w; i += 64)
 	{
 		uint32_t m = inv[o + i];
-		if (i == w - 1 && (len & 31)) m &= ~0u << (32 - (len & 31));          // ignore the pad bits of the last word
+		if (i == w - 1) m &= (len & 31) ? ~0u << (32 - (len & 31)) : 0u;       // ignore the pad bits of the last word
 		any |= m != 0;
 	}
 	const uint64_t b = __ballot(any);

@@ -31,7 +31,7 @@ def pack(reads_list):
     return packed, woff, lens, inv
 
 
-def main(cfg, only=None):
+def main(cfg, force_large=0):
     g = golden(cfg)
     rs = g.reads
     c = g.p("c")
@@ -63,14 +63,14 @@ def main(cfg, only=None):
     min_alt, max_rec = PRESET_BY_LEVEL[g.p("level")]
     pb = np.asarray(rs.pack_bounds(), np.uint32)
     cap = int(rl.sum()) + 64 * rs.n_reads
-    out = np.zeros(cap, np.uint8); off = np.zeros(rs.n_reads + 1, np.uint64); nt = np.zeros(rs.n_reads, np.uint32); why = np.zeros(rs.n_reads, np.uint32)
+    out = np.zeros(cap, np.uint8); off = np.zeros(rs.n_reads + 1, np.uint64); nt = np.zeros(rs.n_reads, np.uint32); why = np.zeros(32, np.uint32)
     P = lambda a: a.ctypes.data_as(C.c_void_p)
     hn = has_n.astype(np.uint8)
     lib.dbg_encode.restype = C.c_int
     rc = lib.dbg_encode(P(rp), P(rw), P(rl), P(rinv), P(hn), C.c_uint32(rs.n_reads), P(fp), P(fw), P(fl), P(n_c), P(cand), P(coff), P(data),
                         C.c_uint32(c), C.c_uint32(g.p("a")), C.c_uint32(min_alt), C.c_uint32(max_rec), C.c_double(1.0), P(pb), C.c_uint32(len(pb) - 1),
-                        C.c_uint64(512 << 20), C.c_uint32(16), P(out), C.c_uint64(cap), P(off), P(nt), P(why))
-    print("rc", rc, "failed reads", [(i, hex(w)) for i, w in enumerate(why) if w][:20])
+                        C.c_uint64(1024 << 20), C.c_uint32(force_large), P(out), C.c_uint64(cap), P(off), P(nt), P(why))
+    print("rc", rc, "gaps per class [trivial, nb1..4, large]", list(why[:6]), "frames per level", [int(x) for x in why[8:18] if x])
     bad = []
     for i in range(rs.n_reads):
         got = out[int(off[i]):int(off[i + 1])].tobytes()
@@ -85,4 +85,4 @@ def main(cfg, only=None):
 
 
 if __name__ == "__main__":
-    sys.exit(1 if main(sys.argv[1]) else 0)
+    sys.exit(1 if main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 0) else 0)
