@@ -258,6 +258,95 @@ CL_DEV inline uint32_t align_small(MEM& mem, uint32_t n, uint32_t m, uint32_t ki
 	return k;
 }
 
+// ---- mid-size gaps: the same recurrence with the state in the lane's memory (rows * columns / 64 <= MID_CELLS) --------
+// MEM additionally provides peq / peq_set (symbol, block), pv / mv get + set (block).  Same observable behaviour as
+// align_small (and as edlib below its 1 MiB traceback budget: 20 bytes * blocks * columns stays under it).
+constexpr uint32_t MID_CELLS = 16384, MID_ROWS = 16384, MID_COLS = 4096;
+template<class MEM>
+CL_DEV inline uint32_t align_mid(MEM& mem, uint32_t n, uint32_t m, uint32_t kind, bool left, uint32_t nr, uint32_t use, uint32_t* d_before)
+{
+	const uint32_t nb = (n + 63) / 64;
+	for (uint32_t b = 0; b < nb; ++b)
+	{
+		uint64_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+		const uint32_t lo = b * 64, hi = n < lo + 64 ? n : lo + 64;
+		for (uint32_t i = lo; i < hi; ++i)
+		{
+			const uint32_t s = mem.q(i); const uint64_t bit = 1ull << (i - lo);
+			e0 |= s == 0 ? bit : 0; e1 |= s == 1 ? bit : 0; e2 |= s == 2 ? bit : 0; e3 |= s == 3 ? bit : 0;
+		}
+		mem.peq_set(0, b, e0); mem.peq_set(1, b, e1); mem.peq_set(2, b, e2); mem.peq_set(3, b, e3);
+		mem.pv_set(b, ~0ull); mem.mv_set(b, 0);
+	}
+	const bool shw = kind == GK_FLANK;
+	const uint32_t lastbit = (n - 1) & 63;
+	uint32_t score = n, best = 0xffffffffu; int32_t end = (int32_t)m - 1;
+	if (shw && (n & 63)) { best = n; end = -1; }
+	for (uint32_t j = 0; j < m; ++j)
+	{
+		const uint32_t c = mem.t(j);
+		int hin = 1;
+		for (uint32_t b = 0; b < nb; ++b)
+		{
+			uint64_t Eq = mem.peq(c, b); const uint64_t Pv = mem.pv(b), Mv = mem.mv(b);
+			const uint64_t hneg = hin < 0 ? 1ull : 0ull;
+			const uint64_t Xv = Eq | Mv;
+			Eq |= hneg;
+			const uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+			uint64_t Ph = Mv | ~(Xh | Pv);
+			uint64_t Mh = Pv & Xh;
+			if (b == nb - 1) score += (uint32_t)((Ph >> lastbit) & 1) - (uint32_t)((Mh >> lastbit) & 1);
+			const uint64_t ph_rows = Ph;
+			const int hout = (int)(Ph >> 63) - (int)(Mh >> 63);
+			Ph <<= 1; Mh <<= 1;
+			Mh |= hneg; Ph |= hin > 0 ? 1ull : 0ull;
+			const uint64_t Pn = Mh | ~(Xv | Ph);
+			mem.pv_set(b, Pn); mem.mv_set(b, Ph & Xv);
+			mem.hist_put(j, b, Pn, ph_rows);
+			hin = hout;
+		}
+		if (shw && score < best) { best = score; end = (int32_t)j; }
+	}
+	uint32_t i = n, j = shw ? (uint32_t)(end + 1) : m, k = 0;
+	const uint32_t t_used = j;
+	uint64_t P = 0, Ph = 0; uint32_t cj = 0xffffffffu, cb = 0xffffffffu;
+	while (i > 0 && j > 0)
+	{
+		const uint32_t r = i - 1, b = r >> 6;
+		if (cj != j || cb != b) { mem.hist_get(j - 1, b, P, Ph); cj = j; cb = b; }
+		const uint64_t bit = 1ull << (r & 63);
+		const uint32_t qs = mem.q(r), ts = mem.t(j - 1);
+		char ch;
+		if (P & bit) { ch = shw ? base_letter(qs) : 'D'; --i; }
+		else if (Ph & bit) { ch = shw ? 'D' : base_letter(ts); --j; }
+		else { ch = qs == ts ? 'M' : (shw ? mismatch_sym(ts, qs) : mismatch_sym(qs, ts)); --i; --j; }
+		mem.es_set(k++, ch);
+	}
+	while (i > 0) { --i; mem.es_set(k++, shw ? base_letter(mem.q(i)) : 'D'); }
+	while (j > 0) { --j; mem.es_set(k++, shw ? 'D' : base_letter(mem.t(j))); }
+	if (!left) for (uint32_t a = 0, z = k; a + 1 < z; ++a) { --z; const char t = mem.es_get(a); mem.es_set(a, mem.es_get(z)); mem.es_set(z, t); }
+	*d_before = 0;
+	struct ES { MEM& m; CL_DEV char get(uint32_t p) const { return m.es_get(p); } CL_DEV void set(uint32_t p, char c) { m.es_set(p, c); } } es{ mem };
+	const bool rows_ref = !shw;
+	if (left)
+	{
+		const uint32_t ref_end = shw ? (uint32_t)end : use - 1;
+		const uint32_t ref_offset = (nr - 1) - ref_end;
+		const uint32_t r_used = shw ? t_used : n, e_len = shw ? n : m;
+		auto ref = [&](uint32_t x) -> uint32_t { const uint32_t idx = r_used - 1 - x; return rows_ref ? mem.q(idx) : mem.t(idx); };
+		auto encf = [&](uint32_t x) -> uint32_t { const uint32_t idx = e_len - 1 - x; return rows_ref ? mem.t(idx) : mem.q(idx); };
+		refactor_es(es, k, ref, encf);
+		*d_before = ref_offset;
+	}
+	else
+	{
+		auto ref = [&](uint32_t x) -> uint32_t { return rows_ref ? mem.q(x) : mem.t(x); };
+		auto encf = [&](uint32_t x) -> uint32_t { return rows_ref ? mem.t(x) : mem.q(x); };
+		refactor_es(es, k, ref, encf);
+	}
+	return k;
+}
+
 // ---- large gaps: generic path, all working memory from the lane's pool (align_dev.hpp), Hirschberg when edlib would ---
 // rbuf: the reference symbols the alignment can touch (forward order): the whole part for an inner gap, its first `use`
 // symbols for the right flank, its LAST `use` symbols for the left flank.  enc: the read part, forward.  dst: >= use + ne chars.
@@ -604,19 +693,24 @@ CL_DEV inline bool gap_init(const LevelV& L, uint32_t frame, uint32_t g_idx, con
 	return false;
 }
 CL_DEV inline uint32_t gap_es_capacity(const GapRec& g) { return ((g.kind == GK_TRIVIAL ? (g.nr == 0 ? g.ne : 0u) : g.use + g.ne) + 3u) & ~3u; }   // dword-aligned script slots
-// size class of a gap: 0 trivial, 1..4 small with that many 64-row blocks, 5 large; key = class << 10 | size
+// size class of a gap: 0 trivial, 1..4 small with that many 64-row blocks, 5 mid, 6 large
+// sort key = class << 17 | row blocks (9 bits) << 8 | columns / 16 (8 bits): lanes of a wave get gaps of like shape
+constexpr uint32_t N_CLASSES = 7, KEY_BITS = 20;
 CL_DEV inline uint32_t gap_class(const GapRec& g, uint32_t& rows, uint32_t& cols)
 {
 	if (g.kind == GK_TRIVIAL) { rows = cols = 0; return 0; }
 	if (g.kind == GK_FLANK) { rows = g.ne; cols = g.use; } else { rows = g.use; cols = g.ne; }
 	if (rows <= 256 && cols <= 256) return (rows + 63) / 64;
-	return 5;
+	if (rows <= MID_ROWS && cols <= MID_COLS && (uint64_t)((rows + 63) / 64) * cols <= MID_CELLS) return 5;
+	return 6;
 }
 CL_DEV inline uint32_t gap_sort_key(const GapRec& g)
 {
 	uint32_t rows, cols; const uint32_t cls = gap_class(g, rows, cols);
-	const uint32_t sz = cls == 5 ? ((rows > cols ? rows : cols) >> 6) : cols;
-	return (cls << 10) | (sz > 1023 ? 1023u : sz);
+	uint32_t a, b;
+	if (cls == 6) { const uint64_t w = (uint64_t)((rows + 63) / 64) * cols; a = 0; b = 0; uint64_t x = w >> 8; while (x) { ++b; x >>= 1; } a = b; b = 0; }   // log2 of the work
+	else { a = (rows + 63) / 64; b = cols >> 4; }
+	return (cls << 17) | ((a > 511 ? 511u : a) << 8) | (b > 255 ? 255u : b);
 }
 // sequences of a small gap into the lane's staging memory, in alignment orientation (reversed for the left flank)
 template<class MEM>

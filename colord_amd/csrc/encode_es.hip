@@ -79,12 +79,12 @@ __global__ void k_gap_offsets(GapRec* __restrict__ gaps, const uint64_t* __restr
 	const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
 	if (gi < n) gaps[gi].es_off = es_off[gi];
 }
-__global__ void k_class_bounds(const uint32_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ bounds /* 7 */)
+__global__ void k_class_bounds(const uint32_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ bounds /* N_CLASSES + 1 */)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i > n) return;
-	const uint32_t a = i == 0 ? 0u : (keys[i - 1] >> 10) + 1, b = i == n ? 7u : (keys[i] >> 10) + 1;   // classes [a, b) start at i
-	for (uint32_t c = a; c < b && c < 7; ++c) bounds[c] = i;
+	const uint32_t a = i == 0 ? 0u : (keys[i - 1] >> 17) + 1, b = i == n ? N_CLASSES + 1 : (keys[i] >> 17) + 1;   // classes [a, b) start at i
+	for (uint32_t c = a; c < b && c <= N_CLASSES; ++c) bounds[c] = i;
 }
 
 // lane-private staging memory in LDS (word w of a lane at lds[w * 64 + lane]) + column history in HBM (lane-interleaved)
@@ -122,6 +122,50 @@ __global__ __launch_bounds__(64) void k_align_small(const uint32_t* __restrict__
 		const uint32_t k = align_small<NB>(mem, n, m, g.kind, g.left != 0, g.nr, g.use, &d_before);
 		uint32_t* dst = (uint32_t*)(es_pool + g.es_off);
 		for (uint32_t w = 0; w * 4 < k; ++w) dst[w] = mem.es_word(w);
+		gaps[gi].es_len = k; gaps[gi].d_before = d_before;
+	}
+}
+
+// mid-size gaps: one lane per gap, all state lane-interleaved in HBM (element e of a lane's array at (e * 64 + lane)):
+// the lanes of a wave walk in lockstep over gaps of like shape, so every access of the wave is one contiguous 512-byte line
+struct HbmMem {
+	static constexpr uint64_t HIST_W = 2ull * MID_CELLS, PEQ_W = 4ull * 256, ST_W = 256, Q_W = MID_ROWS / 8, T_W = MID_COLS / 8, ES_W = (MID_ROWS + MID_COLS) / 8;   // 64-bit words per lane
+	static constexpr uint64_t WORDS = HIST_W + PEQ_W + 2 * ST_W + Q_W + T_W + ES_W;
+	uint64_t* base; uint32_t lane, nb;
+	__device__ inline uint64_t* w(uint64_t region, uint64_t e) const { return base + (region + e) * 64 + lane; }
+	__device__ inline uint8_t* byte(uint64_t region, uint32_t b) const { return (uint8_t*)(base + (region + (b >> 3)) * 64 + lane) + (b & 7); }
+	__device__ inline void hist_put(uint32_t j, uint32_t b, uint64_t P, uint64_t Ph) { const uint64_t e = ((uint64_t)j * nb + b) * 2; *w(0, e) = P; *w(0, e + 1) = Ph; }
+	__device__ inline void hist_get(uint32_t j, uint32_t b, uint64_t& P, uint64_t& Ph) const { const uint64_t e = ((uint64_t)j * nb + b) * 2; P = *w(0, e); Ph = *w(0, e + 1); }
+	__device__ inline uint64_t peq(uint32_t s, uint32_t b) const { return *w(HIST_W, s * 256 + b); }
+	__device__ inline void peq_set(uint32_t s, uint32_t b, uint64_t v) { *w(HIST_W, s * 256 + b) = v; }
+	__device__ inline uint64_t pv(uint32_t b) const { return *w(HIST_W + PEQ_W, b); }
+	__device__ inline uint64_t mv(uint32_t b) const { return *w(HIST_W + PEQ_W + ST_W, b); }
+	__device__ inline void pv_set(uint32_t b, uint64_t v) { *w(HIST_W + PEQ_W, b) = v; }
+	__device__ inline void mv_set(uint32_t b, uint64_t v) { *w(HIST_W + PEQ_W + ST_W, b) = v; }
+	__device__ inline uint32_t q(uint32_t i) const { return *byte(HIST_W + PEQ_W + 2 * ST_W, i); }
+	__device__ inline uint32_t t(uint32_t j) const { return *byte(HIST_W + PEQ_W + 2 * ST_W + Q_W, j); }
+	__device__ inline void q_set(uint32_t i, uint32_t v) { *byte(HIST_W + PEQ_W + 2 * ST_W, i) = (uint8_t)v; }
+	__device__ inline void t_set(uint32_t j, uint32_t v) { *byte(HIST_W + PEQ_W + 2 * ST_W + Q_W, j) = (uint8_t)v; }
+	__device__ inline char es_get(uint32_t k) const { return (char)*byte(HIST_W + PEQ_W + 2 * ST_W + Q_W + T_W, k); }
+	__device__ inline void es_set(uint32_t k, char c) { *byte(HIST_W + PEQ_W + 2 * ST_W + Q_W + T_W, k) = (uint8_t)c; }
+	__device__ inline uint32_t es_word(uint32_t wi) const { return ((const uint32_t*)w(HIST_W + PEQ_W + 2 * ST_W + Q_W + T_W, wi >> 1))[wi & 1]; }
+};
+__global__ __launch_bounds__(64) void k_align_mid(const uint32_t* __restrict__ list, uint32_t n_list, GapRec* __restrict__ gaps, char* __restrict__ es_pool, ArenaV A, ArenaV R, uint64_t* __restrict__ scratch)
+{
+	HbmMem mem{ scratch + (uint64_t)blockIdx.x * HbmMem::WORDS * 64, threadIdx.x, 0 };
+	for (uint32_t chunk = blockIdx.x; (uint64_t)chunk * 64 < n_list; chunk += gridDim.x)
+	{
+		const uint32_t idx = chunk * 64 + threadIdx.x;
+		if (idx >= n_list) continue;
+		const uint32_t gi = list[idx];
+		const GapRec g = gaps[gi];
+		uint32_t n, m;
+		stage_small(mem, g, A, R, n, m);
+		mem.nb = (n + 63) / 64;
+		uint32_t d_before;
+		const uint32_t k = align_mid(mem, n, m, g.kind, g.left != 0, g.nr, g.use, &d_before);
+		uint32_t* dst = (uint32_t*)(es_pool + g.es_off);
+		for (uint32_t wi = 0; wi * 4 < k; ++wi) dst[wi] = mem.es_word(wi);
 		gaps[gi].es_len = k; gaps[gi].d_before = d_before;
 	}
 }
@@ -276,11 +320,11 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 		DEV_ALLOC(ctx, L.es, es_total + 16); DEV_ALLOC(ctx, L.pend, n_pend + 1); DEV_ALLOC(ctx, L.dec, n_pend + 1);
 		V = L.view();
 		// size classes
-		CL_TRY(dev_sort_keys32_pairs(ctx, keys.p, ids.p, ng, 0, 13));
-		DevBuf<uint32_t> bounds; DEV_ALLOC(ctx, bounds, 8);
+		CL_TRY(dev_sort_keys32_pairs(ctx, keys.p, ids.p, ng, 0, KEY_BITS));
+		DevBuf<uint32_t> bounds; DEV_ALLOC(ctx, bounds, N_CLASSES + 1);
 		LAUNCH(ctx, k_class_bounds, grid_for(ng + 1, 256), 256, (const uint32_t*)keys.p, L.n_gaps, bounds.p);
-		uint32_t hb[7];
-		HIP_TRY(ctx, hipMemcpyAsync(hb, bounds.p, 28, hipMemcpyDeviceToHost, st));
+		uint32_t hb[N_CLASSES + 1];
+		HIP_TRY(ctx, hipMemcpyAsync(hb, bounds.p, 4 * (N_CLASSES + 1), hipMemcpyDeviceToHost, st));
 		HIP_TRY(ctx, hipStreamSynchronize(st));
 		// small gaps
 		{
@@ -306,12 +350,22 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 			}
 			HIP_TRY(ctx, hipStreamSynchronize(st));
 		}
+		// mid-size gaps
+		if (hb[6] > hb[5])
+		{
+			const uint32_t n_list = hb[6] - hb[5];
+			const uint32_t blocks = std::min<uint32_t>(grid_for(n_list, 64), n_cu * 2);
+			DevBuf<uint64_t> scratch; DEV_ALLOC(ctx, scratch, (uint64_t)blocks * HbmMem::WORDS * 64);
+			LAUNCHB(ctx, (double)n_list * 64, k_align_mid, blocks, 64, (const uint32_t*)ids.p + hb[5], n_list, L.gaps.p, L.es.p, A, R, scratch.p);
+			HIP_TRY(ctx, hipGetLastError());
+			HIP_TRY(ctx, hipStreamSynchronize(st));
+		}
 		// large gaps, in rounds of growing lane pools
 		{
-			uint32_t n_list = hb[6] - hb[5];
+			uint32_t n_list = hb[7] - hb[6];
 			DevBuf<uint32_t> todo, redo; DEV_ALLOC(ctx, todo, (uint64_t)n_list + 1); DEV_ALLOC(ctx, redo, (uint64_t)n_list + 1);
 			DevBuf<unsigned int> cnt; DEV_ALLOC(ctx, cnt, 2);
-			const uint32_t* list = ids.p + hb[5];
+			const uint32_t* list = ids.p + hb[6];
 			uint64_t per_lane = 2ull << 20; uint32_t max_lanes = 16384;
 			for (int round = 0; n_list; ++round)
 			{

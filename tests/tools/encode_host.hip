@@ -13,7 +13,10 @@
 using namespace enc;
 
 struct HostMem {
-	uint8_t qb[256], tb[256]; char esb[512]; std::vector<uint64_t> hist; uint32_t nb;
+	uint8_t qb[MID_ROWS], tb[MID_COLS]; char esb[MID_ROWS + MID_COLS]; std::vector<uint64_t> hist; uint32_t nb;
+	uint64_t peq_[4][256], pv_[256], mv_[256];
+	uint64_t peq(uint32_t s, uint32_t b) const { return peq_[s][b]; } void peq_set(uint32_t s, uint32_t b, uint64_t v) { peq_[s][b] = v; }
+	uint64_t pv(uint32_t b) const { return pv_[b]; } uint64_t mv(uint32_t b) const { return mv_[b]; } void pv_set(uint32_t b, uint64_t v) { pv_[b] = v; } void mv_set(uint32_t b, uint64_t v) { mv_[b] = v; }
 	uint32_t q(uint32_t i) const { return qb[i]; } uint32_t t(uint32_t j) const { return tb[j]; }
 	void q_set(uint32_t i, uint32_t v) { qb[i] = (uint8_t)v; } void t_set(uint32_t j, uint32_t v) { tb[j] = (uint8_t)v; }
 	char es_get(uint32_t k) const { return esb[k]; } void es_set(uint32_t k, char c) { esb[k] = c; }
@@ -70,11 +73,22 @@ extern "C" int dbg_encode(const uint64_t* r_packed, const uint64_t* r_woff, cons
 			GapRec& g = L.gaps[gi];
 			uint32_t rows, cols; uint32_t cls = gap_class(g, rows, cols);
 			if (cls == 0) continue;
-			if (force_large) cls = 5;
+			if (force_large == 1) cls = 6;
+			if (force_large == 2 && cls <= 4) cls = 5;                           // everything alignable through the mid path
 			stats[cls]++;
-			if (cls <= 4)
+			if (cls == 5)
 			{
-				HostMem hm; hm.nb = cls; hm.hist.assign(256 * cls * 2, 0);
+				static HostMem hm;
+				uint32_t n, mm, d_before;
+				stage_small(hm, g, A, R, n, mm);
+				hm.nb = (n + 63) / 64; hm.hist.assign(2ull * hm.nb * mm + 2, 0);
+				const uint32_t k = align_mid(hm, n, mm, g.kind, g.left != 0, g.nr, g.use, &d_before);
+				memcpy(L.es.data() + g.es_off, hm.esb, k);
+				g.es_len = k; g.d_before = d_before;
+			}
+			else if (cls <= 4)
+			{
+				static HostMem hm; hm.nb = cls; hm.hist.assign(256 * cls * 2, 0);
 				uint32_t n, mm, d_before, k = 0;
 				stage_small(hm, g, A, R, n, mm);
 				switch (cls)
