@@ -1,0 +1,257 @@
+// align_wave.hpp — one WAVE aligns one large gap (device only).  Same observable behaviour as align_dev.hpp (edlib as
+// the reference calls it, edit_script.h:272-413; edlib.cpp:141-296,547-700,945-1400), organised for a 64-wide wavefront:
+//   * the 64-row blocks of Myers' recurrence are spread over the lanes and swept along the anti-diagonals: at step s
+//     lane l advances block l of the current 64-block tile through column s - l; the horizontal delta leaving a block
+//     reaches the lane below with one DPP shift, the column symbol travels the same way; tiles hand their last block's
+//     deltas over through a byte array;
+//   * the traceback (up, then left, then diagonal, edlib.cpp:1021-1147) is sequential by nature; the wave fetches the
+//     history words of 64 consecutive columns at once and walks them with lane reads;
+//   * Hirschberg (edlib.cpp:1230-1400) when the history would exceed edlib's 1 MiB budget: both half sweeps deliver their
+//     last column, the split row is found with a ballot.
+// All control flow is wave-uniform; memory comes from a per-wave bump pool in HBM.
+#pragma once
+#include "common.hpp"
+
+namespace wv {
+
+struct WavePool {
+	uint8_t* base; uint64_t cap, top; bool overflow;
+	__device__ inline void* alloc(uint64_t bytes)
+	{
+		bytes = (bytes + 255) & ~255ull;
+		if (top + bytes > cap) { overflow = true; return base; }
+		void* p = base + top; top += bytes; return p;
+	}
+	__device__ inline uint64_t mark() const { return top; }
+	__device__ inline void release(uint64_t m) { top = m; }
+};
+
+__device__ inline uint32_t lane_id() { return threadIdx.x & 63; }
+template<class T> __device__ inline T bcast(T v, uint32_t src) { return __shfl(v, (int)src); }
+__device__ inline uint32_t bcast_first(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+struct Hist { uint64_t* P; uint64_t* H; uint32_t W, m; };       // cell (tile, s, lane) at ((tile * (m + 64)) + s) * W + lane
+__device__ inline uint64_t hist_words(uint32_t nb, uint32_t m) { const uint32_t tiles = (nb + 63) / 64, W = nb < 64 ? nb : 64; return (uint64_t)tiles * (m + 64) * W; }
+
+struct Sweep { uint32_t score; uint32_t best; int32_t end; };
+// Sweeps all columns.  q/t: byte sequences with steps +-1.  hist: where to keep (vertical +1, horizontal +1) bit-vectors
+// per cell, or null.  lastcol: n + 1 values D[i][m], or null.  shw: track min over columns of D[n][j] (first minimum;
+// end = -1 a candidate when n % 64 != 0).  score = D[n][m].
+__device__ inline Sweep wave_sweep(WavePool& pool, const uint8_t* q, int qstep, uint32_t n, const uint8_t* t, int tstep, uint32_t m, bool shw, const Hist* hist, int32_t* lastcol)
+{
+	const uint32_t lane = lane_id();
+	const uint32_t nb = (n + 63) / 64, tiles = (nb + 63) / 64;
+	const uint64_t mk = pool.mark();
+	int8_t* hb_a = (int8_t*)pool.alloc(m + 64ull); int8_t* hb_b = (int8_t*)pool.alloc(m + 64ull);
+	Sweep out{ n, 0xffffffffu, (int32_t)m - 1 };
+	if (pool.overflow) { pool.release(mk); return out; }
+	if (shw && (n & 63)) { out.best = n; out.end = -1; }
+	const uint32_t lastbit = (n - 1) & 63;
+	uint32_t sc = n, best = out.best; int32_t end = out.end;             // meaningful in the lane that owns the last block
+	if (lastcol && lane == 0) lastcol[0] = (int32_t)m;
+	for (uint32_t tile = 0; tile < tiles; ++tile)
+	{
+		const uint32_t b = tile * 64 + lane; const bool act = b < nb;
+		const uint32_t W = nb - tile * 64 < 64 ? nb - tile * 64 : 64;
+		uint64_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+		if (act)
+		{
+			const uint32_t lo = b * 64, hi = n < lo + 64 ? n : lo + 64;
+			for (uint32_t i = lo; i < hi; ++i)
+			{
+				const uint32_t s = q[(int64_t)i * qstep] & 3; const uint64_t bit = 1ull << (i - lo);
+				e0 |= s == 0 ? bit : 0; e1 |= s == 1 ? bit : 0; e2 |= s == 2 ? bit : 0; e3 |= s == 3 ? bit : 0;
+			}
+		}
+		uint64_t Pv = ~0ull, Mv = 0; int32_t S = (int32_t)((b + 1) * 64);
+		const int8_t* hin_arr = tile ? hb_a : nullptr; int8_t* hout_arr = tile + 1 < tiles ? hb_b : nullptr;
+		const bool owner = act && b == nb - 1;
+		uint32_t c = 0; int hout = 0; uint32_t tchunk = 0; int hchunk = 1;
+		const uint32_t steps = m + W - 1;
+		for (uint32_t s = 0; s < steps; ++s)
+		{
+			if ((s & 63) == 0)
+			{
+				const uint32_t j0 = s + lane;
+				tchunk = j0 < m ? (uint32_t)(t[(int64_t)j0 * tstep] & 3) : 0u;
+				hchunk = hin_arr ? (j0 < m ? (int)hin_arr[j0] : 0) : 1;
+			}
+			const uint32_t c_new = bcast(tchunk, s & 63); const int h_new = bcast(hchunk, s & 63);
+			uint32_t c_up = __shfl_up(c, 1); int h_up = __shfl_up(hout, 1);
+			c = lane == 0 ? c_new : c_up;
+			const int hin = lane == 0 ? h_new : h_up;
+			const bool valid = act && s >= lane && s - lane < m;
+			hout = 0;
+			if (valid)
+			{
+				uint64_t Eq = c == 0 ? e0 : c == 1 ? e1 : c == 2 ? e2 : e3;
+				const uint64_t hneg = hin < 0 ? 1ull : 0ull;
+				const uint64_t Xv = Eq | Mv;
+				Eq |= hneg;
+				const uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+				uint64_t Ph = Mv | ~(Xh | Pv);
+				uint64_t Mh = Pv & Xh;
+				const uint64_t ph_rows = Ph;
+				if (owner)
+				{
+					sc += (uint32_t)((Ph >> lastbit) & 1) - (uint32_t)((Mh >> lastbit) & 1);
+					if (shw && sc < best) { best = sc; end = (int32_t)(s - lane); }
+				}
+				hout = (int)(Ph >> 63) - (int)(Mh >> 63);
+				Ph <<= 1; Mh <<= 1;
+				Mh |= hneg; Ph |= hin > 0 ? 1ull : 0ull;
+				Pv = Mh | ~(Xv | Ph);
+				Mv = Ph & Xv;
+				S += hout;
+				if (hist) { const uint64_t idx = ((uint64_t)tile * (m + 64) + s) * hist->W + lane; hist->P[idx] = Pv; hist->H[idx] = ph_rows; }
+				if (hout_arr && lane == W - 1) hout_arr[s - lane] = (int8_t)hout;
+			}
+		}
+		if (lastcol && act)
+		{	// column m of this block, bottom row upwards
+			const uint32_t lo = b * 64; int32_t v = S;
+			for (int r = 63; r >= 0; --r)
+			{
+				const uint32_t i = lo + (uint32_t)r + 1;
+				if (i <= n) lastcol[i] = v;
+				v -= (int32_t)((Pv >> r) & 1); v += (int32_t)((Mv >> r) & 1);
+			}
+		}
+		{ int8_t* x = hb_a; hb_a = hb_b; hb_b = x; }
+		__builtin_amdgcn_s_waitcnt(0);          // the next tile reads what this one wrote
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	}
+	const uint32_t own_lane = (nb - 1) & 63;
+	out.score = bcast(sc, own_lane); out.best = bcast(best, own_lane); out.end = bcast(end, own_lane);
+	pool.release(mk);
+	return out;
+}
+
+struct Ops { uint8_t* p; uint64_t n; };                   // 0 match, 1 consume query, 2 consume target, 3 mismatch (forward order)
+
+// traceback of q[0..n) x t[0..m) (forward byte sequences) on a fresh history; appends n..n+m ops
+__device__ inline void wave_traceback(WavePool& pool, const uint8_t* q, uint32_t n, const uint8_t* t, uint32_t m, Ops& out)
+{
+	const uint32_t lane = lane_id();
+	const uint64_t mk = pool.mark();
+	const uint32_t nb = (n + 63) / 64;
+	const uint64_t hw = hist_words(nb, m);
+	Hist h{ (uint64_t*)pool.alloc(hw * 8), (uint64_t*)pool.alloc(hw * 8), nb < 64 ? nb : 64, m };
+	uint8_t* rev = (uint8_t*)pool.alloc((uint64_t)n + m + 64);
+	if (pool.overflow) { pool.release(mk); return; }
+	wave_sweep(pool, q, 1, n, t, 1, m, false, &h, nullptr);
+	if (pool.overflow) { pool.release(mk); return; }
+	__builtin_amdgcn_s_waitcnt(0);
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	uint32_t i = n, j = m; uint64_t k = 0;
+	// window: lanes hold (P, H) of block wb for columns wj0 - lane (1-based column wj0 at lane 0, descending)
+	uint32_t wb = 0xffffffffu, wj0 = 0; uint64_t wP = 0, wH = 0; uint32_t wt = 0;
+	uint32_t wi0 = 0, wq = 0;                                                // lanes hold q[wi0 - 1 - lane]
+	while (i > 0 && j > 0)
+	{
+		const uint32_t r = i - 1, b = r >> 6;
+		if (b != wb || j > wj0 || wj0 - j >= 64)
+		{
+			wb = b; wj0 = j;
+			const uint32_t jj = j > lane ? j - lane : 0;                      // this lane's column (1-based), 0 = none
+			if (jj)
+			{
+				const uint32_t tile = b >> 6, bl = b & 63;
+				const uint64_t idx = ((uint64_t)tile * (m + 64) + (jj - 1) + bl) * h.W + bl;
+				wP = h.P[idx]; wH = h.H[idx]; wt = t[jj - 1];
+			}
+		}
+		const uint32_t src = wj0 - j;
+		const uint64_t P = bcast(wP, src), H = bcast(wH, src);
+		const uint32_t ts = bcast(wt, src);
+		const uint64_t bit = 1ull << (r & 63);
+		uint8_t op;
+		if (P & bit) { op = 1; --i; }
+		else if (H & bit) { op = 2; --j; }
+		else
+		{
+			if (i > wi0 || wi0 - i >= 64) { wi0 = i; wq = i > lane ? q[i - 1 - lane] : 0u; }
+			op = bcast(wq, wi0 - i) == ts ? 0 : 3; --i; --j;
+		}
+		if (lane == 0) rev[k] = op;
+		++k;
+	}
+	__builtin_amdgcn_s_waitcnt(0);
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	// out = [2 x j] [1 x i] reversed(rev)  in forward order: leading target consumption first?  No: the walk ended at (i, j)
+	// with i == 0 or j == 0; the remaining prefix is consumed first in forward order.
+	uint8_t* dst = out.p + out.n;
+	const uint64_t pre = (uint64_t)i + j; const uint8_t pre_op = i ? 1 : 2;
+	for (uint64_t x = lane; x < pre; x += 64) dst[x] = pre_op;
+	for (uint64_t x = lane; x < k; x += 64) dst[pre + x] = rev[k - 1 - x];
+	out.n += pre + k;
+	__builtin_amdgcn_s_waitcnt(0);
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	pool.release(mk);
+}
+
+// obtainAlignment (edlib.cpp:1164-1215): optimal path of q (rows) against t (columns) given the optimal score
+__device__ inline void wave_path(WavePool& pool, const uint8_t* q, uint32_t n, const uint8_t* t, uint32_t m, uint32_t best, Ops& out)
+{
+	struct Job { uint32_t qo, n, to, m, best; };
+	const uint32_t lane = lane_id();
+	const uint64_t mk0 = pool.mark();
+	Job* stack = (Job*)pool.alloc(sizeof(Job) * 128);
+	if (pool.overflow) return;
+	uint32_t sp = 0;
+	if (lane == 0) stack[0] = Job{ 0, n, 0, m, best };
+	sp = 1;
+	__builtin_amdgcn_s_waitcnt(0);
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	while (sp && !pool.overflow)
+	{
+		--sp;
+		Job jb;
+		jb.qo = bcast_first(stack[sp].qo); jb.n = bcast_first(stack[sp].n); jb.to = bcast_first(stack[sp].to); jb.m = bcast_first(stack[sp].m); jb.best = bcast_first(stack[sp].best);
+		if (jb.n == 0 || jb.m == 0)
+		{
+			const uint8_t op = jb.n == 0 ? 2 : 1;
+			for (uint64_t x = lane; x < (uint64_t)jb.n + jb.m; x += 64) out.p[out.n + x] = op;
+			out.n += (uint64_t)jb.n + jb.m;
+			continue;
+		}
+		const long long blocks = (jb.n + 63) / 64;
+		const long long sz = (2ll * 8 + 4) * blocks * jb.m + 2ll * 4 * jb.m;
+		if (sz < 1024 * 1024) { wave_traceback(pool, q + jb.qo, jb.n, t + jb.to, jb.m, out); continue; }
+		const uint32_t L = jb.m / 2, R = jb.m - L;
+		const uint64_t mk = pool.mark();
+		int32_t* left = (int32_t*)pool.alloc(((uint64_t)jb.n + 1) * 4);
+		int32_t* right = (int32_t*)pool.alloc(((uint64_t)jb.n + 1) * 4);
+		if (pool.overflow) break;
+		wave_sweep(pool, q + jb.qo, 1, jb.n, t + jb.to, 1, L, false, nullptr, left);
+		wave_sweep(pool, q + jb.qo + jb.n - 1, -1, jb.n, t + jb.to + jb.m - 1, -1, R, false, nullptr, right);
+		if (pool.overflow) break;
+		__builtin_amdgcn_s_waitcnt(0);
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		// smallest i in 1..n-1 with left[i] + right[n - i] == best, else the empty prefix, else the whole query
+		int64_t found = -1; uint32_t ls = 0, rs = 0;
+		for (uint32_t base = 1; base + 1 <= jb.n && found < 0; base += 64)
+		{
+			const uint32_t i = base + lane;
+			const bool hit = i + 1 <= jb.n && (uint32_t)(left[i] + right[jb.n - i]) == jb.best;
+			const uint64_t bal = __ballot(hit);
+			if (bal) { const uint32_t f = (uint32_t)__builtin_ctzll(bal); found = base + f; }
+		}
+		if (found >= 0) { ls = bcast_first((uint32_t)left[found]); rs = bcast_first((uint32_t)right[jb.n - (uint32_t)found]); }
+		if (found < 0 && L + (uint32_t)bcast_first((uint32_t)right[jb.n]) == jb.best) { found = 0; ls = L; rs = bcast_first((uint32_t)right[jb.n]); }
+		if (found < 0 && (uint32_t)bcast_first((uint32_t)left[jb.n]) + R == jb.best) { found = jb.n; ls = bcast_first((uint32_t)left[jb.n]); rs = R; }
+		pool.release(mk);
+		if (found < 0 || sp + 2 > 128) { pool.overflow = true; break; }
+		if (lane == 0)
+		{	// lower-right half first on the stack so that the upper-left half is emitted first
+			stack[sp] = Job{ jb.qo + (uint32_t)found, jb.n - (uint32_t)found, jb.to + L, R, rs };
+			stack[sp + 1] = Job{ jb.qo, (uint32_t)found, jb.to, L, ls };
+		}
+		sp += 2;
+		__builtin_amdgcn_s_waitcnt(0);
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	}
+	pool.release(mk0);
+}
+
+} // namespace wv

@@ -92,7 +92,24 @@ struct GapRec {
 	uint32_t kind, left;                         // left: the frame's first gap (aligned on reversed sequences)
 	uint32_t read, ref_rev;                      // ref_rev: reference id | rev << 31
 };
-struct PendRec { uint32_t rd[12]; uint32_t len_cost; uint32_t pl[4]; uint32_t ref_len; };
+// statistics of one short gap for the estimator.  lens: the (ilog2(run)+1) terms of the long D / M runs IN ORDER, 6 bits
+// each, count in the top 4 bits (the reference adds them to a double one by one, utils.h:1103-1104); more than 10 runs:
+// count = 15 and the low 32 bits hold their sum.
+struct PendRec { uint32_t rd[12]; uint32_t pl[4]; uint32_t ref_len; uint32_t pad; uint64_t lens; };
+CL_DEV inline void lens_push(uint64_t& lens, uint32_t v)
+{
+	const uint32_t cnt = (uint32_t)(lens >> 60);
+	if (cnt < 10) lens = (lens & 0x0fffffffffffffffull) | ((uint64_t)v << (6 * cnt)) | ((uint64_t)(cnt + 1) << 60);
+	else if (cnt == 10) { uint32_t sum = v; for (uint32_t i = 0; i < 10; ++i) sum += (uint32_t)(lens >> (6 * i)) & 63u; lens = (15ull << 60) | sum; }
+	else lens = (15ull << 60) | (uint32_t)((uint32_t)lens + v);
+}
+CL_DEV inline double lens_add(double cost, uint64_t lens)
+{
+	const uint32_t cnt = (uint32_t)(lens >> 60);
+	if (cnt == 15) return cost + (double)(uint32_t)lens;
+	for (uint32_t i = 0; i < cnt; ++i) cost += (double)((uint32_t)(lens >> (6 * i)) & 63u);
+	return cost;
+}
 struct LevelV { FrameRec* frames; CandEnt* cands; GapRec* gaps; char* es; PendRec* pend; uint8_t* dec; uint32_t n_frames, n_gaps; };
 struct TreeV { LevelV lv[10]; const uint32_t* frame_of_read; };     // frame_of_read: level-0 frame of a read or ~0
 
@@ -440,14 +457,14 @@ CL_DEV inline uint32_t est_code(char c)       // estimator alphabet (utils.h:914
 CL_DEV inline void analyze_es(const char* es, uint32_t n, uint32_t d_before, PendRec& p)
 {
 	for (int i = 0; i < 12; ++i) p.rd[i] = 0;
-	p.len_cost = 0;
+	p.lens = 0; p.pad = 0;
 	char c = d_before ? 'D' : ' '; uint32_t len = d_before;
 	for (uint32_t i = 0; i <= n; ++i)
 	{
 		const char x = i < n ? es[i] : ' ';
 		if (x == c) { ++len; continue; }
-		if (c == 'D') { if (len >= 10) { ++p.rd[9]; p.len_cost += bitlen32(len) + 1; } else p.rd[4] += len; }
-		else if (c == 'M') { if (len >= 15) { ++p.rd[10]; p.len_cost += bitlen32(len) + 1; } else p.rd[5] += len; }
+		if (c == 'D') { if (len >= 10) { ++p.rd[9]; lens_push(p.lens, bitlen32(len) + 1); } else p.rd[4] += len; }
+		else if (c == 'M') { if (len >= 15) { ++p.rd[10]; lens_push(p.lens, bitlen32(len) + 1); } else p.rd[5] += len; }
 		else if (c != ' ') ++p.rd[est_code(c)];
 		c = x; len = 1;
 	}
@@ -532,7 +549,7 @@ CL_DEV inline bool est_decide(Estim& e, const PendRec& p)                       
 	double es_cost = e.dec_logs[0], plain_cost = e.dec_logs[1];
 	est_logs(loc, e.es_logs, 12, loc_sum);
 	for (int i = 0; i < 12; ++i) es_cost += p.rd[i] * e.es_logs[i];
-	es_cost += p.len_cost;
+	es_cost = lens_add(es_cost, p.lens);
 	for (int i = 0; i < 4; ++i) plain_cost += p.pl[i] * e.dna_logs[i];
 	plain_cost += bitlen32(p.ref_len) + 1;
 	const bool choose_plain = plain_cost < es_cost;
@@ -557,6 +574,23 @@ CL_DEV inline void est_read(Estim& e, const TreeV& T, uint32_t frame0)
 		if (g.state == GS_PENDING) L.dec[g.aux] = est_decide(e, L.pend[g.aux]) ? 1 : 0;
 		else if (g.state == GS_CHILD) { ++sp; sf[sp] = g.aux; sg[sp] = 0; }
 	}
+}
+
+// the pending gaps of a read in encoding order as (level << 28 | pending index); out == nullptr: count only
+CL_DEV inline uint32_t pend_walk(const TreeV& T, uint32_t frame0, uint32_t* out)
+{
+	uint32_t sf[10], sg[10], n = 0; int sp = 0;
+	sf[0] = frame0; sg[0] = 0;
+	while (sp >= 0)
+	{
+		const LevelV& L = T.lv[sp];
+		const FrameRec& F = L.frames[sf[sp]];
+		if (sg[sp] == F.n_gaps) { --sp; continue; }
+		const GapRec& g = L.gaps[F.first_gap + sg[sp]++];
+		if (g.state == GS_PENDING) { if (out) out[n] = ((uint32_t)sp << 28) | g.aux; ++n; }
+		else if (g.state == GS_CHILD) { ++sp; sf[sp] = g.aux; sg[sp] = 0; }
+	}
+	return n;
 }
 
 // ---- tuple emission (encoder.cpp:1348-1443) -------------------------------------------------------------------------

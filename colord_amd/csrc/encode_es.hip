@@ -9,6 +9,7 @@
 // Then k_estimator (one lane per reader pack) and k_emit_tuples (one lane per read, count pass + write pass).
 #include "objects.hpp"
 #include "encode_core.hpp"
+#include "align_wave.hpp"
 #include <algorithm>
 #include <memory>
 #include <vector>
@@ -170,6 +171,111 @@ __global__ __launch_bounds__(64) void k_align_mid(const uint32_t* __restrict__ l
 	}
 }
 
+// large gaps: one WAVE per gap (align_wave.hpp); waves pull gaps from a queue, largest first
+__device__ inline bool align_wave_gap(wv::WavePool& pool, GapRec& g, const ArenaV& A, const ArenaV& R, char* dst)
+{
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t ref_id = g.ref_rev & 0x7fffffffu; const bool rev = g.ref_rev >> 31;
+	const uint64_t rwb = R.word_off[ref_id], ewb = A.word_off[g.read]; const uint32_t rlen = R.lens[ref_id];
+	const bool left = g.left != 0;
+	uint8_t* rbuf = (uint8_t*)pool.alloc(g.use + 64ull); uint8_t* ebuf = (uint8_t*)pool.alloc(g.ne + 64ull);
+	uint8_t* r2 = (uint8_t*)pool.alloc(g.use + 64ull); uint8_t* e2 = (uint8_t*)pool.alloc(g.ne + 64ull);
+	uint8_t* opsbuf = (uint8_t*)pool.alloc((uint64_t)g.use + g.ne + 64);
+	if (pool.overflow) return false;
+	const uint32_t lo = left ? g.nr - g.use : 0;
+	for (uint32_t i = lane; i < g.use; i += 64) { const uint8_t v = (uint8_t)ref_sym(R, rwb, rlen, rev, g.cur_ref + lo + i); rbuf[i] = v; r2[left ? g.use - 1 - i : i] = v; }
+	for (uint32_t i = lane; i < g.ne; i += 64) { const uint8_t v = (uint8_t)arena_base_at(A, ewb, g.enc_start + i); ebuf[i] = v; e2[left ? g.ne - 1 - i : i] = v; }
+	__builtin_amdgcn_s_waitcnt(0);
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	wv::Ops ops{ opsbuf, 0 };
+	const uint8_t* Q; const uint8_t* T; uint32_t n, m; bool rows_ref; uint32_t ref_end = 0;
+	if (g.kind == GK_INNER)
+	{
+		Q = rbuf; n = g.nr; T = ebuf; m = g.ne; rows_ref = true;
+		const wv::Sweep sw = wv::wave_sweep(pool, Q, 1, n, T, 1, m, false, nullptr, nullptr);
+		if (pool.overflow) return false;
+		wv::wave_path(pool, Q, n, T, m, sw.score, ops);
+	}
+	else if (g.kind == GK_FLANK_TINY)
+	{
+		Q = r2; n = g.use; T = e2; m = g.ne; rows_ref = true; ref_end = g.use - 1;
+		const wv::Sweep sw = wv::wave_sweep(pool, Q, 1, n, T, 1, m, false, nullptr, nullptr);
+		if (pool.overflow) return false;
+		wv::wave_path(pool, Q, n, T, m, sw.score, ops);
+	}
+	else
+	{
+		Q = e2; n = g.ne; T = r2; rows_ref = false;
+		const wv::Sweep sw = wv::wave_sweep(pool, Q, 1, n, T, 1, g.use, true, nullptr, nullptr);
+		if (pool.overflow) return false;
+		ref_end = (uint32_t)sw.end; m = (uint32_t)(sw.end + 1);
+		wv::wave_path(pool, Q, n, T, m, sw.best, ops);
+	}
+	if (pool.overflow) return false;
+	__builtin_amdgcn_s_waitcnt(0);
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	// operations -> script symbols, 64 at a time; for the left flank the script of the reversed sequences is written reversed
+	const uint32_t k = (uint32_t)ops.n;
+	uint32_t pq = 0, pt = 0;
+	for (uint32_t x0 = 0; x0 < k; x0 += 64)
+	{
+		const uint32_t x = x0 + lane; const bool in = x < k;
+		const uint32_t op = in ? ops.p[x] : 4u;
+		const uint64_t cq = __ballot(in && op != 2), ct = __ballot(in && op != 1);
+		const uint64_t lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+		const uint32_t myq = pq + (uint32_t)__popcll(cq & lt), myt = pt + (uint32_t)__popcll(ct & lt);
+		if (in)
+		{
+			char ch;
+			if (op == 0) ch = 'M';
+			else if (op == 1) ch = rows_ref ? 'D' : base_letter(Q[myq]);
+			else if (op == 2) ch = rows_ref ? base_letter(T[myt]) : 'D';
+			else ch = rows_ref ? mismatch_sym(Q[myq], T[myt]) : mismatch_sym(T[myt], Q[myq]);
+			dst[left ? k - 1 - x : x] = ch;
+		}
+		pq += (uint32_t)__popcll(cq); pt += (uint32_t)__popcll(ct);
+	}
+	__builtin_amdgcn_s_waitcnt(0);
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	// canonical indel placement (sequential; every lane runs the same walk, lane 0's stores count)
+	uint32_t d_before = 0;
+	struct WES { char* p; uint32_t lane; __device__ char get(uint32_t i) const { return p[i]; } __device__ void set(uint32_t i, char c) { if (lane == 0) p[i] = c; __builtin_amdgcn_s_waitcnt(0); } } es{ dst, lane };
+	if (left && g.kind != GK_INNER)
+	{
+		const uint32_t ref_offset = (g.nr - 1) - ref_end;                      // uint32 wrap for end = -1, as in the reference
+		const uint8_t* rf = rbuf + (ref_offset - (g.nr - g.use));
+		refactor_es(es, k, [&](uint32_t i) -> uint32_t { return rf[i]; }, [&](uint32_t i) -> uint32_t { return ebuf[i]; });
+		d_before = ref_offset;
+	}
+	else refactor_es(es, k, [&](uint32_t i) -> uint32_t { return rbuf[i]; }, [&](uint32_t i) -> uint32_t { return ebuf[i]; });
+	__builtin_amdgcn_s_waitcnt(0);
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	g.es_len = k; g.d_before = d_before;
+	return true;
+}
+__global__ __launch_bounds__(64) void k_align_wave(const uint32_t* __restrict__ list, uint32_t n_list, GapRec* __restrict__ gaps, char* __restrict__ es_pool, ArenaV A, ArenaV R,
+                                                  uint8_t* __restrict__ scratch, uint64_t per_wave, unsigned int* __restrict__ next, uint32_t* __restrict__ redo, unsigned int* __restrict__ n_redo)
+{
+	wv::WavePool pool{ scratch + (uint64_t)blockIdx.x * per_wave, per_wave, 0, false };
+	const uint32_t lane = threadIdx.x;
+	for (;;)
+	{
+		uint32_t slot = 0;
+		if (lane == 0) slot = atomicAdd(next, 1u);
+		slot = __builtin_amdgcn_readfirstlane(slot);
+		if (slot >= n_list) break;
+		const uint32_t gi = list[n_list - 1 - slot];                            // the list is ascending by size: largest first
+		pool.top = 0; pool.overflow = false;
+		GapRec g = gaps[gi];
+		if (!align_wave_gap(pool, g, A, R, es_pool + g.es_off))
+		{
+			if (lane == 0) redo[atomicAdd(n_redo, 1u)] = gi;
+			continue;
+		}
+		if (lane == 0) { gaps[gi].es_len = g.es_len; gaps[gi].d_before = g.d_before; }
+	}
+}
+
 // the rest: one lane per gap, lane pool in HBM; gaps whose lane ran out of pool are redone with larger pools
 __global__ __launch_bounds__(64) void k_align_large(const uint32_t* __restrict__ list, uint32_t n_list, GapRec* __restrict__ gaps, char* __restrict__ es_pool, ArenaV A, ArenaV R,
                                                    uint8_t* __restrict__ scratch, uint64_t per_lane, unsigned int* __restrict__ next, uint32_t* __restrict__ redo, unsigned int* __restrict__ n_redo)
@@ -236,11 +342,108 @@ __global__ void k_read_base_counts(ArenaV A, const uint8_t* __restrict__ has_n, 
 	for (int o = 32; o; o >>= 1) { c0 += __shfl_xor(c0, o); c1 += __shfl_xor(c1, o); c2 += __shfl_xor(c2, o); c3 += __shfl_xor(c3, o); }
 	if (lane == 0) { counts[4 * r] = c0; counts[4 * r + 1] = c1; counts[4 * r + 2] = c2; counts[4 * r + 3] = c3; }
 }
-__global__ void k_estimator(TreeV T, const uint32_t* __restrict__ pack_bounds, uint32_t n_packs, const uint32_t* __restrict__ lens, const uint8_t* __restrict__ has_n,
-                            const uint32_t* __restrict__ base_counts)
+// events of the estimator: the pending gaps of every read in encoding order (depth-first over its frames)
+__global__ void k_pend_count(TreeV T, uint32_t n_reads, uint32_t* __restrict__ cnt)
 {
-	const uint32_t pk = blockIdx.x * blockDim.x + threadIdx.x;
-	if (pk < n_packs) est_pack(T, pack_bounds[pk], pack_bounds[pk + 1], lens, has_n, base_counts);
+	const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_reads) return;
+	const uint32_t f0 = T.frame_of_read[r];
+	cnt[r] = f0 == 0xffffffffu ? 0u : pend_walk(T, f0, nullptr);
+}
+__global__ void k_pend_list(TreeV T, uint32_t n_reads, const uint64_t* __restrict__ off, uint32_t* __restrict__ events)
+{
+	const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_reads) return;
+	const uint32_t f0 = T.frame_of_read[r];
+	if (f0 != 0xffffffffu && off[r + 1] > off[r]) pend_walk(T, f0, events + off[r]);
+}
+// CEntropyEstimator over one reader pack by one wave (utils.h:877-1130): the events are inherently sequential, the work
+// inside one event is not — lanes 0..11 hold the 12 edit-script counters and take the logarithms in parallel, lanes
+// 12..15 precompute the decision logarithms of both outcomes; sums are then accumulated in the reference's order.
+__global__ __launch_bounds__(64) void k_estimator(TreeV T, const uint32_t* __restrict__ pack_bounds, uint32_t n_packs, const uint32_t* __restrict__ lens, const uint8_t* __restrict__ has_n,
+                                                 const uint32_t* __restrict__ base_counts, const uint64_t* __restrict__ ev_off, const uint32_t* __restrict__ events)
+{
+	__shared__ PendRec recs[64];
+	__shared__ uint32_t ev_id[64];
+	const uint32_t pk = blockIdx.x, lane = threadIdx.x;
+	if (pk >= n_packs) return;
+	const uint32_t MX = 1u << 20;
+	uint32_t es_l = lane < 12 ? 1u : 0u, es_sum = 12;
+	uint32_t dna0 = 1, dna1 = 1, dna2 = 1, dna3 = 1, dna_sum = 4, dec0 = 1, dec1 = 1, dec_sum = 2;
+	double dl0, dl1, dl2, dl3, dcl0, dcl1;
+	{ const double r4 = 1.0 / 4, r2 = 1.0 / 2; dl0 = dl1 = dl2 = dl3 = -log2(1.0 * r4); dcl0 = dcl1 = -log2(1.0 * r2); }
+	for (uint32_t r = pack_bounds[pk]; r < pack_bounds[pk + 1]; ++r)
+	{
+		if (has_n[r]) continue;                                                  // reads with N never reach the estimator (encoder.cpp:1629-1633)
+		{	// LogRead (utils.h:946-955)
+			dna0 += base_counts[4 * r]; dna1 += base_counts[4 * r + 1]; dna2 += base_counts[4 * r + 2]; dna3 += base_counts[4 * r + 3];
+			dna_sum += lens[r];
+			while (dna_sum > MX) { dna0 = (dna0 + 1) / 2; dna1 = (dna1 + 1) / 2; dna2 = (dna2 + 1) / 2; dna3 = (dna3 + 1) / 2; dna_sum = dna0 + dna1 + dna2 + dna3; }
+			const double rec = 1.0 / dna_sum;
+			const uint32_t x = lane == 0 ? dna0 : lane == 1 ? dna1 : lane == 2 ? dna2 : dna3;
+			const double lg = x ? -log2((double)x * rec) : 0.0;
+			dl0 = __shfl(lg, 0); dl1 = __shfl(lg, 1); dl2 = __shfl(lg, 2); dl3 = __shfl(lg, 3);
+		}
+		for (uint64_t e0 = ev_off[r]; e0 < ev_off[r + 1]; e0 += 64)
+		{
+			const uint32_t cnt = (uint32_t)(ev_off[r + 1] - e0 < 64 ? ev_off[r + 1] - e0 : 64);
+			__syncthreads();
+			if (lane < cnt)
+			{
+				const uint32_t ev = events[e0 + lane];
+				ev_id[lane] = ev;
+				recs[lane] = T.lv[ev >> 28].pend[ev & 0x0fffffffu];
+			}
+			__syncthreads();
+			for (uint32_t k = 0; k < cnt; ++k)
+			{	// EncodeWithEditScript (utils.h:1060-1130)
+				const PendRec& p = recs[k];
+				const uint32_t rd_l = lane < 12 ? p.rd[lane] : 0u;
+				uint32_t rd_sum = rd_l;
+				for (int o = 8; o; o >>= 1) rd_sum += __shfl_xor(rd_sum, o);              // lanes 0..15 (12..15 hold 0)
+				rd_sum = __shfl(rd_sum, 0);
+				const uint32_t loc_l = es_l + rd_l, loc_sum = es_sum + rd_sum;
+				const bool dec_resc = dec_sum + 1 > MX;
+				uint32_t x = loc_l; double rec = 1.0 / loc_sum;
+				if (lane >= 12 && lane < 16)
+				{	// decision logarithms after this event: lanes 12, 13 if the edit script wins, 14, 15 if the literal wins
+					x = lane == 12 ? dec0 + 1 : lane == 13 ? dec1 : lane == 14 ? dec0 : dec1 + 1;
+					rec = 1.0 / (dec_sum + 1);
+				}
+				const double lg = x ? -log2((double)x * rec) : 0.0;
+				const double term = (double)rd_l * lg;
+				double es_cost = dcl0;
+#pragma unroll
+				for (int i = 0; i < 12; ++i) es_cost += __shfl(term, i);
+				es_cost = lens_add(es_cost, p.lens);
+				double plain_cost = dcl1;
+				plain_cost += p.pl[0] * dl0; plain_cost += p.pl[1] * dl1; plain_cost += p.pl[2] * dl2; plain_cost += p.pl[3] * dl3;
+				plain_cost += bitlen32(p.ref_len) + 1;
+				const bool choose_plain = plain_cost < es_cost;
+				if (choose_plain) ++dec1;
+				else
+				{
+					++dec0; es_l = loc_l; es_sum = loc_sum;
+					while (es_sum > MX)
+					{
+						es_l = (es_l + 1) / 2;
+						uint32_t sm = lane < 12 ? es_l : 0u;
+						for (int o = 8; o; o >>= 1) sm += __shfl_xor(sm, o);
+						es_sum = __shfl(sm, 0);
+					}
+				}
+				++dec_sum;
+				if (!dec_resc) { dcl0 = __shfl(lg, choose_plain ? 14 : 12); dcl1 = __shfl(lg, choose_plain ? 15 : 13); }
+				else
+				{
+					while (dec_sum > MX) { dec0 = (dec0 + 1) / 2; dec1 = (dec1 + 1) / 2; dec_sum = dec0 + dec1; }
+					const double rc = 1.0 / dec_sum;
+					dcl0 = dec0 ? -log2((double)dec0 * rc) : 0.0; dcl1 = dec1 ? -log2((double)dec1 * rc) : 0.0;
+				}
+				if (lane == 0) { const uint32_t ev = ev_id[k]; T.lv[ev >> 28].dec[ev & 0x0fffffffu] = choose_plain ? 0 : 1; }
+			}
+		}
+	}
 }
 template<bool WRITE>
 __global__ __launch_bounds__(64) void k_emit_tuples(ArenaV A, const uint32_t* __restrict__ inv, const uint8_t* __restrict__ has_n, TreeV T, uint32_t n_reads, const uint32_t* __restrict__ data,
@@ -366,14 +569,16 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 			DevBuf<uint32_t> todo, redo; DEV_ALLOC(ctx, todo, (uint64_t)n_list + 1); DEV_ALLOC(ctx, redo, (uint64_t)n_list + 1);
 			DevBuf<unsigned int> cnt; DEV_ALLOC(ctx, cnt, 2);
 			const uint32_t* list = ids.p + hb[6];
-			uint64_t per_lane = 2ull << 20; uint32_t max_lanes = 16384;
+			uint64_t per_lane = 6ull << 20; uint32_t max_lanes = 2048;           // waves (k_align_wave) / lanes (k_align_large)
+			const bool use_wave = getenv("COLORD_HIP_NO_WAVE_ALIGN") == nullptr;
 			for (int round = 0; n_list; ++round)
 			{
 				if (round == 5) return cl_fail(ctx, CL_E_NOMEM, "cl_encode_reads: lane pool exhausted (" + std::to_string(n_list) + " gaps left)");
-				const uint32_t lanes = (uint32_t)std::min<uint64_t>(((uint64_t)n_list + 63) / 64 * 64, max_lanes);
+				const uint32_t lanes = use_wave ? std::min<uint32_t>(n_list, max_lanes) : (uint32_t)std::min<uint64_t>(((uint64_t)n_list + 63) / 64 * 64, max_lanes);
 				DevBuf<uint8_t> scratch; DEV_ALLOC(ctx, scratch, per_lane * lanes);
 				HIP_TRY(ctx, hipMemsetAsync(cnt.p, 0, 8, st));
-				LAUNCH(ctx, k_align_large, lanes / 64, 64, list, n_list, L.gaps.p, L.es.p, A, R, scratch.p, per_lane, cnt.p, redo.p, cnt.p + 1);
+				if (use_wave) LAUNCH(ctx, k_align_wave, lanes, 64, list, n_list, L.gaps.p, L.es.p, A, R, scratch.p, per_lane, cnt.p, redo.p, cnt.p + 1);
+				else LAUNCH(ctx, k_align_large, lanes / 64, 64, list, n_list, L.gaps.p, L.es.p, A, R, scratch.p, per_lane, cnt.p, redo.p, cnt.p + 1);
 				HIP_TRY(ctx, hipGetLastError());
 				unsigned int hc[2];
 				HIP_TRY(ctx, hipMemcpyAsync(hc, cnt.p, 8, hipMemcpyDeviceToHost, st));
@@ -420,7 +625,14 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 	LAUNCHB(ctx, reads->total_bases / 4.0, k_read_base_counts, grid_for((uint64_t)nr * 64, 256), 256, A, has_n, nr, base_counts.p);
 	DevBuf<uint32_t> d_pb; DEV_ALLOC(ctx, d_pb, (uint64_t)n_packs + 1);
 	HIP_TRY(ctx, hipMemcpyAsync(d_pb.p, h_pack_bounds, ((uint64_t)n_packs + 1) * 4, hipMemcpyHostToDevice, st));
-	LAUNCH(ctx, k_estimator, grid_for(n_packs, 64), 64, T, (const uint32_t*)d_pb.p, n_packs, (const uint32_t*)reads->lens.p, has_n, (const uint32_t*)base_counts.p);
+	DevBuf<uint32_t> ev_cnt; DEV_ALLOC(ctx, ev_cnt, (uint64_t)nr + 1);
+	DevBuf<uint64_t> ev_off; DEV_ALLOC(ctx, ev_off, (uint64_t)nr + 1);
+	LAUNCH(ctx, k_pend_count, grid_for(nr, 64), 64, T, nr, ev_cnt.p);
+	uint64_t n_events = 0;
+	CL_TRY(dev_exclusive_scan_u64(ctx, ev_cnt.p, ev_off.p, nr, &n_events));
+	DevBuf<uint32_t> events; DEV_ALLOC(ctx, events, n_events + 1);
+	LAUNCH(ctx, k_pend_list, grid_for(nr, 64), 64, T, nr, (const uint64_t*)ev_off.p, events.p);
+	if (n_packs) LAUNCH(ctx, k_estimator, n_packs, 64, T, (const uint32_t*)d_pb.p, n_packs, (const uint32_t*)reads->lens.p, has_n, (const uint32_t*)base_counts.p, (const uint64_t*)ev_off.p, (const uint32_t*)events.p);
 	DevBuf<uint32_t> sizes; DEV_ALLOC(ctx, sizes, nr);
 	LAUNCH(ctx, (k_emit_tuples<false>), grid_for(nr, 64), 64, A, (const uint32_t*)reads->inv.p, has_n, T, nr, AV.data, sizes.p, d_es_ntuples, (const uint64_t*)nullptr, (uint8_t*)nullptr);
 	HIP_TRY(ctx, hipGetLastError());
