@@ -15,7 +15,8 @@
 namespace wv {
 
 struct WavePool {
-	uint8_t* base; uint64_t cap, top; bool overflow;
+	uint8_t* base; uint64_t cap, top; bool overflow; volatile uint32_t* hb;       // hb: optional host-visible progress word (debugging)
+	__device__ inline void beat(uint32_t code) { if (hb && (threadIdx.x & 63) == 0) *hb = code; }
 	__device__ inline void* alloc(uint64_t bytes)
 	{
 		bytes = (bytes + 255) & ~255ull;

@@ -13,6 +13,8 @@
 #include <algorithm>
 #include <memory>
 #include <vector>
+#include <thread>
+#include <chrono>
 
 struct cl_anchors;   // anchors.hip
 extern "C" const uint32_t* cl_anchors_n_cands(const cl_anchors* a);
@@ -172,8 +174,9 @@ __global__ __launch_bounds__(64) void k_align_mid(const uint32_t* __restrict__ l
 }
 
 // large gaps: one WAVE per gap (align_wave.hpp); waves pull gaps from a queue, largest first
-__device__ inline bool align_wave_gap(wv::WavePool& pool, GapRec& g, const ArenaV& A, const ArenaV& R, char* dst)
+__device__ inline bool align_wave_gap(wv::WavePool& pool, GapRec& g, const ArenaV& A, const ArenaV& R, char* dst, uint32_t dbg_stage)
 {
+	g.es_len = 0; g.d_before = 0;
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t ref_id = g.ref_rev & 0x7fffffffu; const bool rev = g.ref_rev >> 31;
 	const uint64_t rwb = R.word_off[ref_id], ewb = A.word_off[g.read]; const uint32_t rlen = R.lens[ref_id];
@@ -182,11 +185,14 @@ __device__ inline bool align_wave_gap(wv::WavePool& pool, GapRec& g, const Arena
 	uint8_t* r2 = (uint8_t*)pool.alloc(g.use + 64ull); uint8_t* e2 = (uint8_t*)pool.alloc(g.ne + 64ull);
 	uint8_t* opsbuf = (uint8_t*)pool.alloc((uint64_t)g.use + g.ne + 64);
 	if (pool.overflow) return false;
+	pool.beat(4);
 	const uint32_t lo = left ? g.nr - g.use : 0;
 	for (uint32_t i = lane; i < g.use; i += 64) { const uint8_t v = (uint8_t)ref_sym(R, rwb, rlen, rev, g.cur_ref + lo + i); rbuf[i] = v; r2[left ? g.use - 1 - i : i] = v; }
 	for (uint32_t i = lane; i < g.ne; i += 64) { const uint8_t v = (uint8_t)arena_base_at(A, ewb, g.enc_start + i); ebuf[i] = v; e2[left ? g.ne - 1 - i : i] = v; }
 	__builtin_amdgcn_s_waitcnt(0);
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	pool.beat(5);
+	if (dbg_stage == 1) return true;
 	wv::Ops ops{ opsbuf, 0 };
 	const uint8_t* Q; const uint8_t* T; uint32_t n, m; bool rows_ref; uint32_t ref_end = 0;
 	if (g.kind == GK_INNER)
@@ -194,6 +200,7 @@ __device__ inline bool align_wave_gap(wv::WavePool& pool, GapRec& g, const Arena
 		Q = rbuf; n = g.nr; T = ebuf; m = g.ne; rows_ref = true;
 		const wv::Sweep sw = wv::wave_sweep(pool, Q, 1, n, T, 1, m, false, nullptr, nullptr);
 		if (pool.overflow) return false;
+		if (dbg_stage == 2) return true;
 		wv::wave_path(pool, Q, n, T, m, sw.score, ops);
 	}
 	else if (g.kind == GK_FLANK_TINY)
@@ -209,11 +216,14 @@ __device__ inline bool align_wave_gap(wv::WavePool& pool, GapRec& g, const Arena
 		const wv::Sweep sw = wv::wave_sweep(pool, Q, 1, n, T, 1, g.use, true, nullptr, nullptr);
 		if (pool.overflow) return false;
 		ref_end = (uint32_t)sw.end; m = (uint32_t)(sw.end + 1);
+		if (dbg_stage == 2) return true;
 		wv::wave_path(pool, Q, n, T, m, sw.best, ops);
 	}
 	if (pool.overflow) return false;
 	__builtin_amdgcn_s_waitcnt(0);
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	pool.beat(6);
+	if (dbg_stage == 3) return true;
 	// operations -> script symbols, 64 at a time; for the left flank the script of the reversed sequences is written reversed
 	const uint32_t k = (uint32_t)ops.n;
 	uint32_t pq = 0, pt = 0;
@@ -237,9 +247,11 @@ __device__ inline bool align_wave_gap(wv::WavePool& pool, GapRec& g, const Arena
 	}
 	__builtin_amdgcn_s_waitcnt(0);
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-	// canonical indel placement (sequential; every lane runs the same walk, lane 0's stores count)
+	pool.beat(7);
+	if (dbg_stage == 4) return true;
+	// canonical indel placement (sequential; every lane runs the same walk and issues the same stores)
 	uint32_t d_before = 0;
-	struct WES { char* p; uint32_t lane; __device__ char get(uint32_t i) const { return p[i]; } __device__ void set(uint32_t i, char c) { if (lane == 0) p[i] = c; __builtin_amdgcn_s_waitcnt(0); } } es{ dst, lane };
+	struct WES { char* p; uint32_t lane; __device__ char get(uint32_t i) const { return p[i]; } __device__ void set(uint32_t i, char c) { p[i] = c; } } es{ dst, lane };   // every lane stores the same byte: each thread then reads back its own store
 	if (left && g.kind != GK_INNER)
 	{
 		const uint32_t ref_offset = (g.nr - 1) - ref_end;                      // uint32 wrap for end = -1, as in the reference
@@ -254,26 +266,27 @@ __device__ inline bool align_wave_gap(wv::WavePool& pool, GapRec& g, const Arena
 	return true;
 }
 __global__ __launch_bounds__(64) void k_align_wave(const uint32_t* __restrict__ list, uint32_t n_list, GapRec* __restrict__ gaps, char* __restrict__ es_pool, ArenaV A, ArenaV R,
-                                                  uint8_t* __restrict__ scratch, uint64_t per_wave, unsigned int* __restrict__ next, uint32_t* __restrict__ redo, unsigned int* __restrict__ n_redo)
+                                                  uint8_t* __restrict__ scratch, uint64_t per_wave, unsigned int* __restrict__ next, uint32_t* __restrict__ redo, unsigned int* __restrict__ n_redo, uint32_t dbg_stage, uint32_t* hbt)
 {
-	wv::WavePool pool{ scratch + (uint64_t)blockIdx.x * per_wave, per_wave, 0, false };
+	wv::WavePool pool{ scratch + (uint64_t)blockIdx.x * per_wave, per_wave, 0, false, hbt ? hbt + blockIdx.x : nullptr };
+	pool.beat(1);
 	const uint32_t lane = threadIdx.x;
-	for (;;)
-	{
-		uint32_t slot = 0;
-		if (lane == 0) slot = atomicAdd(next, 1u);
-		slot = __builtin_amdgcn_readfirstlane(slot);
-		if (slot >= n_list) break;
-		const uint32_t gi = list[n_list - 1 - slot];                            // the list is ascending by size: largest first
+	for (uint32_t slot = blockIdx.x; slot < n_list; slot += gridDim.x)
+	{	// static round-robin over the list in descending size (the list is ascending): balanced enough, no queue
+		pool.beat(2);
+		const uint32_t gi = list[n_list - 1 - slot];
 		pool.top = 0; pool.overflow = false;
 		GapRec g = gaps[gi];
-		if (!align_wave_gap(pool, g, A, R, es_pool + g.es_off))
+		pool.beat(3);
+		if (!align_wave_gap(pool, g, A, R, es_pool + g.es_off, dbg_stage))
 		{
 			if (lane == 0) redo[atomicAdd(n_redo, 1u)] = gi;
 			continue;
 		}
+		pool.beat(8);
 		if (lane == 0) { gaps[gi].es_len = g.es_len; gaps[gi].d_before = g.d_before; }
 	}
+	pool.beat(9);
 }
 
 // the rest: one lane per gap, lane pool in HBM; gaps whose lane ran out of pool are redone with larger pools
@@ -571,13 +584,23 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 			const uint32_t* list = ids.p + hb[6];
 			uint64_t per_lane = 6ull << 20; uint32_t max_lanes = 2048;           // waves (k_align_wave) / lanes (k_align_large)
 			const bool use_wave = getenv("COLORD_HIP_NO_WAVE_ALIGN") == nullptr;
+			uint32_t* hbt_host = nullptr; uint32_t* hbt_dev = nullptr;
+			if (use_wave && n_list && getenv("COLORD_HIP_WAVE_HEARTBEAT"))
+			{	// debugging: host-visible progress words, dumped by a watchdog thread if the kernel is still running after a while
+				HIP_TRY(ctx, hipHostMalloc((void**)&hbt_host, 4096 * 4, hipHostMallocMapped));
+				memset(hbt_host, 0, 4096 * 4);
+				HIP_TRY(ctx, hipHostGetDevicePointer((void**)&hbt_dev, hbt_host, 0));
+				std::thread([hbt_host]() { for (int t = 0; t < 3; ++t) { std::this_thread::sleep_for(std::chrono::seconds(8)); fprintf(stderr, "[heartbeat]");
+					for (int i = 0; i < 24; ++i) fprintf(stderr, " %u", hbt_host[i]); fprintf(stderr, "\n"); fflush(stderr); } }).detach();
+			}
 			for (int round = 0; n_list; ++round)
 			{
 				if (round == 5) return cl_fail(ctx, CL_E_NOMEM, "cl_encode_reads: lane pool exhausted (" + std::to_string(n_list) + " gaps left)");
 				const uint32_t lanes = use_wave ? std::min<uint32_t>(n_list, max_lanes) : (uint32_t)std::min<uint64_t>(((uint64_t)n_list + 63) / 64 * 64, max_lanes);
 				DevBuf<uint8_t> scratch; DEV_ALLOC(ctx, scratch, per_lane * lanes);
 				HIP_TRY(ctx, hipMemsetAsync(cnt.p, 0, 8, st));
-				if (use_wave) LAUNCH(ctx, k_align_wave, lanes, 64, list, n_list, L.gaps.p, L.es.p, A, R, scratch.p, per_lane, cnt.p, redo.p, cnt.p + 1);
+				if (use_wave) LAUNCH(ctx, k_align_wave, lanes, 64, list, n_list, L.gaps.p, L.es.p, A, R, scratch.p, per_lane, cnt.p, redo.p, cnt.p + 1,
+					(uint32_t)(getenv("COLORD_HIP_WAVE_DEBUG_STAGE") ? atoi(getenv("COLORD_HIP_WAVE_DEBUG_STAGE")) : 0), hbt_dev);
 				else LAUNCH(ctx, k_align_large, lanes / 64, 64, list, n_list, L.gaps.p, L.es.p, A, R, scratch.p, per_lane, cnt.p, redo.p, cnt.p + 1);
 				HIP_TRY(ctx, hipGetLastError());
 				unsigned int hc[2];
