@@ -83,6 +83,15 @@ def hot_path_step(ctx, reads, k, quals=None, qual_off=None, part_bounds=None, es
     from colord_amd import parallel as par
     p = PRESET
     w, rank = par.world(), par.rank()
+    stage_t = {} if os.environ.get("BENCH_STAGE_TIMES") else None
+    t_last = [time.perf_counter()]
+
+    def lap(name):                                         # wall time per stage (diagnostic; adds syncs)
+        if stage_t is not None:
+            torch.cuda.synchronize()
+            now = time.perf_counter()
+            stage_t[name] = stage_t.get(name, 0.0) + (now - t_last[0]) * 1e3
+            t_last[0] = now
     km = ctx.kmer_scan(reads, k, p["f"])
     n_surv = km.numel()
     km = par.exchange_kmers(km)                            # exchange 1a: k-mers to the owner of their key
@@ -108,6 +117,7 @@ def hot_path_step(ctx, reads, k, quals=None, qual_off=None, part_bounds=None, es
         refs = torch.cat(par.all_gather_v(refs))
     index = ctx.index_build_pairs(kset, ids, refs, bounds, n_refs_total, 0, p["cs"])
     crefs, votes, cnt = ctx.candidates(index, lists, p["c"])
+    lap("a1-a7 k-mers, index, candidates")
     out = dict(survivors=n_surv, tot_kmers=tot_kmers, kept=kset.size, accepted=lists.total, refs=n_refs_total,
                index_entries=index.entries, with_candidates=int((cnt > 0).sum().item()))
     if quals is not None:
@@ -116,6 +126,7 @@ def hot_path_step(ctx, reads, k, quals=None, qual_off=None, part_bounds=None, es
         qc = ctx.qual_coder(2, 0, 1, (7, 14, 26), ())
         payload, sizes = qc.encode(reads, quals, qual_off, part_bounds)
         qc.free()
+        lap("a13+a15 quality stream")
         out.update(qual_bytes=int(payload.numel()), qual_parts=len(sizes))
         # a8 + a10-a12 + a14: DNA stream.  Reference reads = the accepted reads of all ranks (CReferenceReads is one
         # process-wide store in the reference; each rank replicates it), anchors against the candidates, edit scripts,
@@ -128,15 +139,21 @@ def hot_path_step(ctx, reads, k, quals=None, qual_off=None, part_bounds=None, es
             ln = torch.cat(par.all_gather_v(my_refs.lengths()))
             my_refs.free()
             my_refs = ctx.reads_from_arena(pk, iv, ln)
+        lap("reference reads")
         anc = ctx.anchor_candidates(reads, my_refs, crefs, cnt, p["a"])
+        lap("a8 anchors")
         es, es_off, es_nt = ctx.encode_reads(reads, my_refs, anc, p["a"], p["min_part_alt"], p["max_rec"], 1.0, est_bounds)
+        lap("a10-a12 encoder")
         n_plain = int((es[es_off[:-1]] >> 4 != 10).sum().item())
         dc = ctx.dna_coder(p["c"], 1, 0)
         dpayload, dsizes = dc.encode(my_refs, es, es_off, es_nt, part_bounds)
         dc.free()
+        lap("a14 DNA stream")
         out.update(dna_bytes=int(dpayload.numel()), tuple_bytes=int(es.numel()), reads_stored_plain=n_plain, anchors=int(anc.total))
         anc.free(); my_refs.free()
     index.free(); lists.free(); kset.free()
+    if stage_t is not None:
+        print("stage wall ms:", {k_: round(v, 1) for k_, v in stage_t.items()}, file=sys.stderr)
     return out
 
 

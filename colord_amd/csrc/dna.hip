@@ -590,7 +590,7 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 	{
 		uint32_t p1 = p0 + 1;
 		while (p1 < n_parts && tup_prefix[h_part_bounds[p1 + 1]] - tup_prefix[h_part_bounds[p0]] <= GROUP_TUPLES) ++p1;
-		const uint32_t r0 = h_part_bounds[p0], r1 = h_part_bounds[p1], nr = r1 - r0, np = p1 - p0, ng = (np + 63) / 64;
+		uint32_t r0 = h_part_bounds[p0], r1 = h_part_bounds[p1], nr = r1 - r0, np = p1 - p0, ng = (np + 63) / 64;
 		DevBuf<uint8_t> rflag; DEV_ALLOC(ctx, rflag, nr);
 		DevBuf<uint32_t> counts, hdr; DEV_ALLOC(ctx, counts, nr); DEV_ALLOC(ctx, hdr, nr);
 		DevBuf<uint64_t> sym_off; DEV_ALLOC(ctx, sym_off, (uint64_t)nr + 1);
@@ -598,15 +598,21 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 		HIP_TRY(ctx, hipMemsetAsync(err.p, 0, 4, ctx->stream));
 		TripLayoutDev nolay{ nullptr, nullptr, nullptr, 0 };
 		uint64_t n_syms = 0;
-		if (nr)
-		{
-			LAUNCH(ctx, k_read_flags, grid_for(nr, 256), 256, d_es, d_es_off, r0, r1, rflag.p);
-			LAUNCH(ctx, (k_dna_walk<false>), grid_for(nr, 64), 64, (const FamTab*)D->d_ft.p, R, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, r0, r1,
-				D->prev_types, D->cur_read_id, nolay, counts.p, hdr.p, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, err.p);
-			HIP_TRY(ctx, hipGetLastError());
+		for (;;)
+		{	// a tuple can take several symbols: shrink the group until its symbols fit 31-bit indices
+			if (nr)
+			{
+				LAUNCH(ctx, k_read_flags, grid_for(nr, 256), 256, d_es, d_es_off, r0, r1, rflag.p);
+				LAUNCH(ctx, (k_dna_walk<false>), grid_for(nr, 64), 64, (const FamTab*)D->d_ft.p, R, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, r0, r1,
+					D->prev_types, D->cur_read_id, nolay, counts.p, hdr.p, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, err.p);
+				HIP_TRY(ctx, hipGetLastError());
+			}
+			CL_TRY(dev_exclusive_scan_u64(ctx, counts.p, sym_off.p, nr, &n_syms));
+			if (n_syms < (1ull << 31)) break;
+			if (np == 1) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_dna_encode: one part has >= 2^31 symbols");
+			p1 = p0 + np / 2;
+			r1 = h_part_bounds[p1]; nr = r1 - r0; np = p1 - p0; ng = (np + 63) / 64;
 		}
-		CL_TRY(dev_exclusive_scan_u64(ctx, counts.p, sym_off.p, nr, &n_syms));
-		if (n_syms >= (1ull << 31)) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_dna_encode: group has >= 2^31 symbols");
 		// part geometry
 		std::vector<uint64_t> h_sym_off((size_t)nr + 1);
 		HIP_TRY(ctx, hipMemcpy(h_sym_off.data(), sym_off.p, ((uint64_t)nr + 1) * 8, hipMemcpyDeviceToHost));

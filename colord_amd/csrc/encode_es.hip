@@ -306,10 +306,62 @@ __global__ __launch_bounds__(64) void k_align_large(const uint32_t* __restrict__
 	}
 }
 
-__global__ void k_gap_stats(LevelV L, ArenaV A, EncCfg cfg, const uint32_t* __restrict__ pend_idx, uint32_t* __restrict__ spawn_flag)
+// short gaps (the estimator decides them later): one lane per gap; long gaps are listed for k_gap_stats_long
+__global__ void k_gap_stats(LevelV L, ArenaV A, EncCfg cfg, const uint32_t* __restrict__ pend_idx, uint32_t* __restrict__ spawn_flag, uint32_t* __restrict__ long_list)
 {
 	const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
-	if (gi < L.n_gaps) spawn_flag[gi] = gap_finish(L, gi, A, cfg, pend_idx[gi]) ? 1u : 0u;
+	if (gi >= L.n_gaps) return;
+	if (L.gaps[gi].ne >= cfg.min_part_alt) { long_list[gi - pend_idx[gi]] = gi; return; }      // pend_idx = number of short gaps before gi
+	spawn_flag[gi] = gap_finish(L, gi, A, cfg, pend_idx[gi]) ? 1u : 0u;
+}
+// long gaps: the static entropy test (EncodeWithEditScript, encoder.cpp:1315-1327; CEntropy, utils.h:706-752) by one wave
+__global__ __launch_bounds__(256) void k_gap_stats_long(LevelV L, ArenaV A, EncCfg cfg, const uint32_t* __restrict__ long_list, uint32_t n_long, uint32_t* __restrict__ spawn_flag)
+{
+	const uint32_t wi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+	if (wi >= n_long) return;
+	const uint32_t gi = long_list[wi];
+	GapRec g = L.gaps[gi];
+	char* es = L.es + g.es_off;
+	const uint64_t ewb = A.word_off[g.read];
+	if (g.kind == GK_TRIVIAL)
+	{	// get_edit_dist_on_seq_empty (edit_script.h:250-267)
+		if (g.nr == 0) { for (uint32_t i = lane; i < g.ne; i += 64) es[i] = base_letter(arena_base_at(A, ewb, g.enc_start + i)); g.es_len = g.ne; }
+		else g.d_before = g.nr;
+		__builtin_amdgcn_s_waitcnt(0);
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	}
+	// leading deletions (GetEditScriptEntropyInput, encoder.cpp:1299-1311)
+	uint32_t nd = 0;
+	for (uint32_t i0 = 0; i0 < g.es_len; i0 += 64)
+	{
+		const uint32_t i = i0 + lane;
+		const uint64_t notd = __ballot(i < g.es_len && es[i] != 'D');
+		if (notd) { nd = i0 + (uint32_t)__builtin_ctzll(notd); break; }
+		nd = i0 + 64 < g.es_len ? i0 + 64 : g.es_len;
+	}
+	uint32_t h[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, hd[4] = { 0, 0, 0, 0 };
+	for (uint32_t i = lane; i < g.es_len; i += 64)
+	{
+		const uint32_t c = es_class(es[i]);
+#pragma unroll
+		for (int k = 0; k < 9; ++k) h[k] += c == (uint32_t)k;
+	}
+	for (uint32_t i = lane; i < g.ne; i += 64)
+	{
+		const uint32_t c = arena_base_at(A, ewb, g.enc_start + i);
+#pragma unroll
+		for (int k = 0; k < 4; ++k) hd[k] += c == (uint32_t)k;
+	}
+#pragma unroll
+	for (int k = 0; k < 9; ++k) for (int o = 32; o; o >>= 1) h[k] += __shfl_xor(h[k], o);
+#pragma unroll
+	for (int k = 0; k < 4; ++k) for (int o = 32; o; o >>= 1) hd[k] += __shfl_xor(hd[k], o);
+	uint32_t n = g.es_len, extra = g.d_before;
+	if (nd + g.d_before >= 10) { h[2] -= nd; n -= nd; extra = 0; }                 // the script is scored without its leading deletions
+	h[2] += extra;
+	const bool accept = entropy_hist(h, 9) * (double)(n + extra) * cfg.cost_mult < entropy_hist(hd, 4) * (double)g.ne;
+	g.state = accept ? GS_ES : GS_REJECTED;
+	if (lane == 0) { L.gaps[gi] = g; spawn_flag[gi] = accept ? 0u : 1u; }
 }
 // rejected long gaps: continue in a child frame when an alternative candidate still has anchors there, else literal
 __global__ void k_spawn_mark(LevelV L, const uint32_t* __restrict__ data, EncCfg cfg, uint32_t* __restrict__ flag, uint32_t* __restrict__ ncand)
@@ -618,7 +670,10 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 		}
 		// statistics / decisions, children
 		DevBuf<uint32_t> sflag, sncand; DEV_ALLOC(ctx, sflag, ng + 1); DEV_ALLOC(ctx, sncand, ng + 1);
-		LAUNCH(ctx, k_gap_stats, grid_for(ng, 64), 64, V, A, cfg, (const uint32_t*)pflag.p, sflag.p);
+		const uint32_t n_long = (uint32_t)(ng - n_pend);
+		DevBuf<uint32_t> long_list; DEV_ALLOC(ctx, long_list, (uint64_t)n_long + 1);
+		LAUNCH(ctx, k_gap_stats, grid_for(ng, 64), 64, V, A, cfg, (const uint32_t*)pflag.p, sflag.p, long_list.p);
+		if (n_long) LAUNCH(ctx, k_gap_stats_long, grid_for((uint64_t)n_long * 64, 256), 256, V, A, cfg, (const uint32_t*)long_list.p, n_long, sflag.p);
 		LAUNCH(ctx, k_spawn_mark, grid_for(ng, 64), 64, V, AV.data, cfg, sflag.p, sncand.p);      // refuses beyond max_rec: those gaps become literals
 		HIP_TRY(ctx, hipGetLastError());
 		if (lv >= max_rec || lv + 1 >= 10) { HIP_TRY(ctx, hipStreamSynchronize(st)); break; }
