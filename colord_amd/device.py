@@ -242,7 +242,7 @@ class Context:
         off = torch.empty(n + 1, dtype=torch.int64, device=self.device)
         nt = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
         need = C.c_uint64(0)
-        cap = int(reads.total_bases) // 2 + 8 * n + 4096
+        cap = int(reads.total_bases) + 16 * n + 4096       # a stream never exceeds the plain form (1 B per base + header) by more than its headers
         for _ in range(2):
             es = torch.empty(max(cap, 1), dtype=torch.uint8, device=self.device)
             st = self.lib.cl_encode_reads(self.h, reads.h, refs.h, anchors.h, anchors.c, anchor_len, min_part_alt, max_rec, cost_mult,
