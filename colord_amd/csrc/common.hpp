@@ -34,10 +34,19 @@ struct DevPool {
 	hipError_t get(uint64_t bytes, void** out, uint64_t* got)
 	{
 		uint64_t r = round_size(bytes);
-		auto it = free_blocks.find(r);
-		if (it != free_blocks.end()) { *out = it->second; *got = r; cached_bytes -= r; free_blocks.erase(it); return hipSuccess; }
+		// best fit: the smallest cached block that holds r without wasting more than half of it (hipMalloc of tens of GB
+		// costs around a second, and a cache of exact sizes only would outgrow HBM over one pass of the pipeline)
+		auto it = free_blocks.lower_bound(r);
+		if (it != free_blocks.end() && it->first <= r + r / 2 + (64ull << 20))
+		{ *out = it->second; *got = it->first; cached_bytes -= it->first; free_blocks.erase(it); return hipSuccess; }
 		hipError_t e = hipMalloc(out, r);
-		if (e != hipSuccess) { (void)hipGetLastError(); trim(); e = hipMalloc(out, r); }
+		while (e != hipSuccess && !free_blocks.empty())
+		{	// out of memory: give back cached blocks, largest first, until the request fits
+			(void)hipGetLastError();
+			auto last = std::prev(free_blocks.end());
+			(void)hipFree(last->second); cached_bytes -= last->first; free_blocks.erase(last);
+			e = hipMalloc(out, r);
+		}
 		*got = r;
 		return e;
 	}
