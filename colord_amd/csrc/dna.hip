@@ -26,6 +26,7 @@ struct FamTab {
 	int32_t level, T, S;                // tuple / symbol history lengths (dna_coder.cpp:1253-1280)
 	uint32_t sym_B;                     // bit width of the regular symbols-family contexts
 	uint32_t max_alt;
+	uint32_t long_run;                  // runs of a small-alphabet model at least this long take the k_long_* path
 };
 
 struct RefStore { const uint64_t* packed; const uint64_t* word_off; const uint32_t* lens; uint32_t n; };
@@ -363,6 +364,208 @@ __global__ void k_seg_starts(const uint32_t* __restrict__ scan, uint64_t n, uint
 	if (i == 0) seg_start[n_heads] = (uint32_t)n;
 }
 
+// ---- D4': LONG runs of a small-alphabet model (e.g. the tuple-type context "match after match" holds a third of all
+// symbols).  The counters of a model between two rescales are its state at the last rescale + ADDER x (occurrences
+// since), and `total` grows by ADDER per symbol whatever the symbol: the rescale instants form a short sequential
+// chain (one every (MAX_TOTAL - total) / ADDER symbols) once class counts of arbitrary prefixes are available.  So:
+//   k_long_hist    per 64-symbol step: class histogram -> prefix inside its 64-step group, group totals      (parallel)
+//   k_long_groups  exclusive scan of the group totals of each run                                            (1 wave/run)
+//   k_long_epochs  walk the rescale chain: epoch records {start, total, counters, prefix counts at start}    (1 wave/run)
+//   k_long_apply   every symbol: counters = epoch state + ADDER x (prefix(j) - prefix(epoch start))          (parallel)
+// Bit-identical to the sequential model (rc.h:233-244,316-358): same counters, same rescale instants.
+constexpr uint32_t LONG_RUN = 1u << 19;                  // default of FamTab::long_run (COLORD_HIP_LONG_RUN overrides it, for tests)
+struct LongRun { uint32_t s, e, fam, gctx; uint64_t step0, group0, epoch0; uint32_t epoch_cap, pad; };
+struct EpochRec { uint32_t start, tot; uint32_t st[8]; uint32_t cnt0[8]; };
+__device__ inline uint32_t find_run(const LongRun* runs, uint32_t n_runs, uint64_t step)
+{
+	uint32_t lo = 0, hi = n_runs;
+	while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (runs[mid].step0 <= step) lo = mid; else hi = mid; }
+	return lo;
+}
+__global__ void k_long_find(const uint32_t* __restrict__ seg_start, uint32_t n_seg, const uint64_t* __restrict__ skey, const FamTab* __restrict__ ftp, LongRun* __restrict__ runs, uint32_t cap, uint32_t* __restrict__ n_runs)
+{
+	const uint32_t sg = blockIdx.x * blockDim.x + threadIdx.x;
+	if (sg >= n_seg) return;
+	const uint32_t s = seg_start[sg], e = seg_start[sg + 1];
+	const FamTab& ft = *ftp;
+	if (e - s < ft.long_run) return;
+	const uint32_t gctx = (uint32_t)(skey[s] >> 16);
+	uint32_t fam = 0;
+	for (uint32_t f = 1; f < N_FAM; ++f) if (gctx >= ft.ctx_base[f]) fam = f;
+	if (ft.n_sym[fam] > 8) return;
+	const uint32_t i = atomicAdd(n_runs, 1u);
+	if (i < cap) { LongRun r; r.s = s; r.e = e; r.fam = fam; r.gctx = gctx; r.step0 = r.group0 = r.epoch0 = 0; r.epoch_cap = 0; r.pad = 0; runs[i] = r; }
+}
+// one wave per group of 64 steps (4096 symbols)
+__global__ __launch_bounds__(256) void k_long_hist(const LongRun* __restrict__ runs, uint32_t n_runs, uint64_t n_groups, const uint64_t* __restrict__ skey,
+                                                  uint32_t* __restrict__ step_pfx, uint32_t* __restrict__ group_tot)
+{
+	const uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; const uint32_t lane = threadIdx.x & 63;
+	if (g >= n_groups) return;
+	uint32_t lo = 0, hi = n_runs;
+	while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (runs[mid].group0 <= g) lo = mid; else hi = mid; }
+	const LongRun R = runs[lo];
+	const uint64_t gl = g - R.group0;                                          // group inside the run
+	uint32_t c[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+	for (uint32_t k = 0; k < 64; ++k)
+	{
+		const uint64_t j = (uint64_t)R.s + (gl * 64 + k) * 64 + lane;
+		const bool valid = j < R.e;
+		const uint32_t sym = valid ? (uint32_t)(skey[j] & 0xff) : 0xffu;
+#pragma unroll
+		for (uint32_t a = 0; a < 8; ++a) { const uint32_t n = (uint32_t)__popcll(__ballot(sym == a)); if (lane == k) c[a] = n; }
+	}
+	const uint64_t n_steps = ((uint64_t)(R.e - R.s) + 63) / 64;
+	const uint64_t step = R.step0 + gl * 64 + lane;
+#pragma unroll
+	for (uint32_t a = 0; a < 8; ++a)
+	{
+		const uint32_t incl = wave_incl_scan(c[a]);
+		if (gl * 64 + lane < n_steps) step_pfx[step * 8 + a] = incl - c[a];     // the steps of the next run follow immediately
+		if (lane == 63) group_tot[g * 8 + a] = incl;
+	}
+}
+__global__ __launch_bounds__(64) void k_long_groups(const LongRun* __restrict__ runs, uint32_t n_runs, uint32_t* __restrict__ group_tot /* in: totals, out: exclusive prefix */)
+{
+	const uint32_t r = blockIdx.x, lane = threadIdx.x;
+	if (r >= n_runs) return;
+	const LongRun R = runs[r];
+	const uint64_t n_steps = ((uint64_t)(R.e - R.s) + 63) / 64, n_groups = (n_steps + 63) / 64;
+	uint32_t carry[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+	for (uint64_t g0 = 0; g0 < n_groups; g0 += 64)
+	{
+		const uint64_t g = g0 + lane; const bool valid = g < n_groups;
+#pragma unroll
+		for (uint32_t a = 0; a < 8; ++a)
+		{
+			const uint32_t v = valid ? group_tot[(R.group0 + g) * 8 + a] : 0u;
+			const uint32_t incl = wave_incl_scan(v);
+			if (valid) group_tot[(R.group0 + g) * 8 + a] = carry[a] + incl - v;
+			carry[a] += __shfl(incl, 63);
+		}
+	}
+}
+// occurrences of each class among the first x symbols of the run: lane a (< 8) returns class a
+__device__ inline uint32_t long_prefix(const LongRun& R, const uint64_t* skey, const uint32_t* step_pfx, const uint32_t* group_pfx, uint32_t x, uint32_t lane)
+{
+	const uint64_t step = x >> 6; const uint32_t off = x & 63;
+	const uint32_t a = lane & 7;
+	uint32_t v = group_pfx[(R.group0 + (step >> 6)) * 8 + a] + (step * 64 < (uint64_t)(R.e - R.s) || off ? step_pfx[(R.step0 + step) * 8 + a] : 0u);
+	if (x == R.e - R.s && off == 0)
+	{	// exactly at the end on a step boundary: the last step's prefix + its own histogram = prefix of a virtual next step
+		const uint64_t last = step - 1;
+		const uint64_t j = (uint64_t)R.s + last * 64 + lane; const uint32_t sym = j < R.e ? (uint32_t)(skey[j] & 0xff) : 0xffu;
+		uint32_t mine = 0;
+#pragma unroll
+		for (uint32_t b = 0; b < 8; ++b) { const uint32_t n = (uint32_t)__popcll(__ballot(sym == b)); if (a == b) mine = n; }
+		return group_pfx[(R.group0 + (last >> 6)) * 8 + a] + step_pfx[(R.step0 + last) * 8 + a] + mine;
+	}
+	if (off)
+	{
+		const uint64_t j = (uint64_t)R.s + step * 64 + lane; const uint32_t sym = j < R.e ? (uint32_t)(skey[j] & 0xff) : 0xffu;
+		const uint64_t below = (1ULL << off) - 1;
+		uint32_t mine = 0;
+#pragma unroll
+		for (uint32_t b = 0; b < 8; ++b) { const uint32_t n = (uint32_t)__popcll(__ballot(sym == b) & below); if (a == b) mine = n; }
+		v += mine;
+	}
+	return v;
+}
+__global__ __launch_bounds__(64) void k_long_epochs(const FamTab* __restrict__ ftp, const LongRun* __restrict__ runs, uint32_t n_runs, const uint64_t* __restrict__ skey,
+                                                   const uint32_t* __restrict__ step_pfx, const uint32_t* __restrict__ group_pfx, uint32_t* __restrict__ state,
+                                                   EpochRec* __restrict__ epochs, uint32_t* __restrict__ n_epochs, uint32_t* __restrict__ group_epoch, uint32_t* __restrict__ err)
+{
+	const uint32_t r = blockIdx.x, lane = threadIdx.x;
+	if (r >= n_runs) return;
+	const LongRun R = runs[r];
+	const FamTab& ft = *ftp;
+	const uint32_t n_sym = ft.n_sym[R.fam], max_total = ft.max_total[R.fam], adder = ft.adder[R.fam];
+	uint32_t* sp = state + ft.state_base[R.fam] + (uint64_t)(R.gctx - ft.ctx_base[R.fam]) * (n_sym + 1);
+	const uint32_t L = R.e - R.s;
+	uint32_t st = lane < n_sym ? sp[lane] : 0u, tot = sp[n_sym];               // lane a: counter of class a
+	uint32_t cnt0 = 0, p = 0, ne = 0;
+	EpochRec* E = epochs + R.epoch0;
+	for (;;)
+	{
+		if (ne >= R.epoch_cap) { if (lane == 0) atomicOr(err, 8u); break; }
+		if (lane < 8) { E[ne].st[lane] = st; E[ne].cnt0[lane] = cnt0; }
+		if (lane == 0) { E[ne].start = p; E[ne].tot = tot; }
+		++ne;
+		const uint32_t rr = (max_total - tot + adder - 1) / adder;              // symbols until total reaches MAX_TOTAL
+		if ((uint64_t)p + rr > L) break;
+		p += rr;
+		const uint32_t c1 = long_prefix(R, skey, step_pfx, group_pfx, p, lane);
+		st += adder * (c1 - cnt0); cnt0 = c1;
+		tot += adder * rr;
+		while (tot >= max_total)
+		{
+			st = (st + 1) / 2;
+			uint32_t sm = lane < 8 ? st : 0u;
+			for (int o = 4; o; o >>= 1) sm += __shfl_xor(sm, o);
+			tot = __shfl(sm, 0);
+		}
+		if (p == L) { if (lane < 8 && ne < R.epoch_cap) { E[ne].st[lane] = st; E[ne].cnt0[lane] = cnt0; } if (lane == 0 && ne < R.epoch_cap) { E[ne].start = p; E[ne].tot = tot; } ++ne; break; }
+	}
+	// final state of the model
+	const uint32_t cl = long_prefix(R, skey, step_pfx, group_pfx, L, lane);
+	if (p < L) { st += adder * (cl - cnt0); tot += adder * (L - p); }
+	if (lane < n_sym) sp[lane] = st;
+	if (lane == 0) { sp[n_sym] = tot; n_epochs[r] = ne; }
+	__builtin_amdgcn_s_waitcnt(0);
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	// epoch in force at the first symbol of every group
+	const uint64_t n_groups = (((uint64_t)L + 63) / 64 + 63) / 64;
+	for (uint64_t g0 = 0; g0 < n_groups; g0 += 64)
+	{
+		const uint64_t g = g0 + lane;
+		if (g >= n_groups) continue;
+		const uint32_t pos = (uint32_t)(g * 4096);
+		uint32_t lo = 0, hi = ne;
+		while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (E[mid].start <= pos) lo = mid; else hi = mid; }
+		group_epoch[R.group0 + g] = lo;
+	}
+}
+// one wave per step
+__global__ __launch_bounds__(256) void k_long_apply(const LongRun* __restrict__ runs, uint32_t n_runs, uint64_t n_steps, const uint64_t* __restrict__ skey, const uint32_t* __restrict__ sval,
+                                                   const uint32_t* __restrict__ step_pfx, const uint32_t* __restrict__ group_pfx, const EpochRec* __restrict__ epochs,
+                                                   const uint32_t* __restrict__ n_epochs, const uint32_t* __restrict__ group_epoch, const FamTab* __restrict__ ftp, triple_t* __restrict__ trip)
+{
+	const uint64_t step = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; const uint32_t lane = threadIdx.x & 63;
+	if (step >= n_steps) return;
+	const uint32_t ri = find_run(runs, n_runs, step);
+	const LongRun R = runs[ri];
+	const uint32_t adder = ftp->adder[R.fam];
+	const uint64_t sl = step - R.step0;                                        // step inside the run
+	const uint32_t x0 = (uint32_t)(sl * 64), x = x0 + lane;
+	const uint64_t j = (uint64_t)R.s + x; const bool valid = j < R.e;
+	const uint64_t k = valid ? skey[j] : 0;
+	const uint32_t sym = valid ? (uint32_t)(k & 0xff) : 0xffu, e1 = (uint32_t)(k >> 12) & 15u, e2 = (uint32_t)(k >> 8) & 15u;
+	uint64_t m[8];
+#pragma unroll
+	for (uint32_t a = 0; a < 8; ++a) m[a] = __ballot(sym == a);
+	// epoch of this lane's symbol: the one in force at the step's first symbol or a later one starting inside the step
+	const EpochRec* E = epochs + R.epoch0; const uint32_t ne = n_epochs[ri];
+	uint32_t e = group_epoch[R.group0 + (sl >> 6)];
+	while (e + 1 < ne && E[e + 1].start <= x0) ++e;
+	uint32_t me = e;
+	while (me + 1 < ne && E[me + 1].start <= x) ++me;
+	if (!valid) return;
+	const EpochRec ep = E[me];
+	const uint64_t lt = (1ULL << lane) - 1;
+	uint32_t cum = 0, freq = 0, excl = 0;
+#pragma unroll
+	for (uint32_t a = 0; a < 8; ++a)
+	{
+		const uint32_t pre = group_pfx[(R.group0 + (sl >> 6)) * 8 + a] + step_pfx[step * 8 + a] + (uint32_t)__popcll(m[a] & lt);
+		const uint32_t v = ep.st[a] + adder * (pre - ep.cnt0[a]);
+		const bool ex = a == e1 || a == e2;
+		if (ex) excl += v;
+		if (a < sym && !ex) cum += v;
+		if (a == sym) freq = v;
+	}
+	trip[sval[j]] = pack_triple(cum, freq, ep.tot + adder * (x - ep.start) - excl);
+}
+
 // ---- D4: model evolution, one wave per non-empty (family, context) run ---------------------------------
 // alphabets <= 8: per-class ballots (with the two optional exclusions of rc.h:316-341); larger: LDS counters.
 __global__ __launch_bounds__(256) void k_dna_evolve(const FamTab* __restrict__ ftp, const uint64_t* __restrict__ skey, const uint32_t* __restrict__ sval,
@@ -383,6 +586,7 @@ __global__ __launch_bounds__(256) void k_dna_evolve(const FamTab* __restrict__ f
 	const uint64_t lt = (1ULL << lane) - 1;
 	if (n_sym <= 8)
 	{
+		if (e - s >= ft.long_run) return;                                      // k_long_* below
 		uint32_t st[8]; uint32_t tot = sp[n_sym];
 #pragma unroll
 		for (uint32_t a = 0; a < 8; ++a) st[a] = a < n_sym ? sp[a] : 0u;
@@ -536,6 +740,8 @@ extern "C" cl_status cl_dna_coder_create(cl_ctx* ctx, uint32_t max_alt_refs, int
 	f.T = level == 3 ? 4 : level == 2 ? 3 : 2;
 	f.S = level == 3 ? 8 : level == 2 ? 7 : 5;
 	f.sym_B = level == 3 ? 24 : level == 2 ? 23 : 22;
+	f.long_run = LONG_RUN;
+	if (const char* lr = getenv("COLORD_HIP_LONG_RUN")) f.long_run = (uint32_t)std::max(64, atoi(lr));
 	auto set = [&](int i, uint32_t ns, uint32_t mt, uint32_t ad, uint32_t nc) { f.n_sym[i] = ns; f.max_total[i] = mt; f.adder[i] = ad; f.n_ctx[i] = nc; };
 	set(F_READ_TYPE, 3, 1u << 15, 1, 256);                  // dna_coder.h:48-60
 	set(F_REV_COMP, 2, 1u << 15, 1, 16);
@@ -655,10 +861,47 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 			LAUNCHB(ctx, n_syms * 28.0, k_dna_evolve, grid_for(n_seg, 4), 256, (const FamTab*)D->d_ft.p, (const uint64_t*)key.p, (const uint32_t*)sidx.p, (const uint32_t*)seg.p,
 				(uint32_t)n_seg, D->state.p, trip.p);
 			HIP_TRY(ctx, hipGetLastError());
+			{	// long runs of the small-alphabet models (k_dna_evolve skipped them)
+				const uint32_t RUN_CAP = 4096;
+				DevBuf<LongRun> runs; DEV_ALLOC(ctx, runs, RUN_CAP);
+				DevBuf<uint32_t> n_runs; DEV_ALLOC(ctx, n_runs, 1);
+				HIP_TRY(ctx, hipMemsetAsync(n_runs.p, 0, 4, ctx->stream));
+				LAUNCH(ctx, k_long_find, grid_for(n_seg, 256), 256, (const uint32_t*)seg.p, (uint32_t)n_seg, (const uint64_t*)key.p, (const FamTab*)D->d_ft.p, runs.p, RUN_CAP, n_runs.p);
+				uint32_t nlr = 0;
+				HIP_TRY(ctx, hipMemcpyAsync(&nlr, n_runs.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+				HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+				if (nlr > RUN_CAP) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_dna_encode: more than 4096 long context runs in one group");
+				if (nlr)
+				{
+					std::vector<LongRun> h(nlr);
+					HIP_TRY(ctx, hipMemcpy(h.data(), runs.p, nlr * sizeof(LongRun), hipMemcpyDeviceToHost));
+					std::sort(h.begin(), h.end(), [](const LongRun& a, const LongRun& b) { return a.s < b.s; });
+					uint64_t steps = 0, groups = 0, eps = 0;
+					for (auto& r : h)
+					{
+						const uint64_t L = r.e - r.s, ns = (L + 63) / 64, ngp = (ns + 63) / 64;
+						const uint64_t half = f.max_total[r.fam] / 2 / f.adder[r.fam];
+						r.step0 = steps; r.group0 = groups; r.epoch0 = eps; r.epoch_cap = (uint32_t)(L / (half > 16 ? half - 8 : 1) + 8);
+						steps += ns; groups += ngp; eps += r.epoch_cap;
+					}
+					HIP_TRY(ctx, hipMemcpyAsync(runs.p, h.data(), nlr * sizeof(LongRun), hipMemcpyHostToDevice, ctx->stream));
+					DevBuf<uint32_t> step_pfx, group_pfx, d_ne, group_epoch; DevBuf<EpochRec> epochs;
+					DEV_ALLOC(ctx, step_pfx, steps * 8 + 8); DEV_ALLOC(ctx, group_pfx, groups * 8 + 8); DEV_ALLOC(ctx, d_ne, nlr); DEV_ALLOC(ctx, group_epoch, groups + 1); DEV_ALLOC(ctx, epochs, eps + 1);
+					LAUNCHB(ctx, steps * 64 * 8.0, k_long_hist, grid_for(groups * 64, 256), 256, (const LongRun*)runs.p, nlr, groups, (const uint64_t*)key.p, step_pfx.p, group_pfx.p);
+					LAUNCH(ctx, k_long_groups, nlr, 64, (const LongRun*)runs.p, nlr, group_pfx.p);
+					LAUNCH(ctx, k_long_epochs, nlr, 64, (const FamTab*)D->d_ft.p, (const LongRun*)runs.p, nlr, (const uint64_t*)key.p, (const uint32_t*)step_pfx.p, (const uint32_t*)group_pfx.p,
+						D->state.p, epochs.p, d_ne.p, group_epoch.p, err.p);
+					LAUNCHB(ctx, steps * 64 * 28.0, k_long_apply, grid_for(steps * 64, 256), 256, (const LongRun*)runs.p, nlr, steps, (const uint64_t*)key.p, (const uint32_t*)sidx.p,
+						(const uint32_t*)step_pfx.p, (const uint32_t*)group_pfx.p, (const EpochRec*)epochs.p, (const uint32_t*)d_ne.p, (const uint32_t*)group_epoch.p, (const FamTab*)D->d_ft.p, trip.p);
+					HIP_TRY(ctx, hipGetLastError());
+					HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+				}
+			}
 			HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 		}
 		uint32_t herr = 0;
 		HIP_TRY(ctx, hipMemcpy(&herr, err.p, 4, hipMemcpyDeviceToHost));
+		if (herr & 8) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_dna_encode: epoch table of a long context run too small");
 		if (herr) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_dna_encode: a read uses more than 64 alternative references");
 		// interval arithmetic per part
 		std::vector<uint64_t> out_off(np + 1);

@@ -93,3 +93,16 @@ def test_plain_tuple_streams_match_reference(ctx):
             if raw[0] >> 4 in (9, 11):                 # reads the reference stored plain
                 assert es[off[i]:off[i + 1]] == raw and nt[i] == ntup, (cfg, i)
         reads.free()
+
+
+@pytest.mark.parametrize("cfg", ["s6m_ont", "c3_clr_ratio", "s5m_hifi"])
+@pytest.mark.parametrize("long_run", ["4096", "50000"])
+def test_long_context_runs_take_the_parallel_path(ctx, cfg, long_run, monkeypatch):
+    """Long runs of one context are evolved by the prefix-count + rescale-chain kernels (k_long_*); with the threshold
+    lowered the golden streams run through that path and must still be byte-identical to the reference."""
+    monkeypatch.setenv("COLORD_HIP_LONG_RUN", long_run)
+    g = golden(cfg)
+    bounds = g.reads.pack_bounds()
+    parts = gpu_dna(ctx, g, bounds)
+    got = [[int(bounds[i + 1] - bounds[i]), len(p), hashlib.sha256(p).hexdigest()] for i, p in enumerate(parts)]
+    assert got == g.spec["streams"]["dna"]["parts"]
