@@ -375,14 +375,14 @@ __global__ void k_seg_starts(const uint32_t* __restrict__ scan, uint64_t n, uint
 // Bit-identical to the sequential model (rc.h:233-244,316-358): same counters, same rescale instants.
 constexpr uint32_t LONG_RUN = 1u << 19;                  // default of FamTab::long_run (COLORD_HIP_LONG_RUN overrides it, for tests)
 struct LongRun { uint32_t s, e, fam, gctx; uint64_t step0, group0, epoch0; uint32_t epoch_cap, pad; };
-struct EpochRec { uint32_t start, tot; uint32_t st[8]; uint32_t cnt0[8]; };
+template<int NS> struct EpochRec { uint32_t start, tot; uint32_t st[NS]; uint32_t cnt0[NS]; };       // NS = 8 or 32 classes
 __device__ inline uint32_t find_run(const LongRun* runs, uint32_t n_runs, uint64_t step)
 {
 	uint32_t lo = 0, hi = n_runs;
 	while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (runs[mid].step0 <= step) lo = mid; else hi = mid; }
 	return lo;
 }
-__global__ void k_long_find(const uint32_t* __restrict__ seg_start, uint32_t n_seg, const uint64_t* __restrict__ skey, const FamTab* __restrict__ ftp, LongRun* __restrict__ runs, uint32_t cap, uint32_t* __restrict__ n_runs)
+__global__ void k_long_find(const uint32_t* __restrict__ seg_start, uint32_t n_seg, const uint64_t* __restrict__ skey, const FamTab* __restrict__ ftp, LongRun* __restrict__ runs /* 2 lists of cap */, uint32_t cap, uint32_t* __restrict__ n_runs /* 2 */)
 {
 	const uint32_t sg = blockIdx.x * blockDim.x + threadIdx.x;
 	if (sg >= n_seg) return;
@@ -392,11 +392,13 @@ __global__ void k_long_find(const uint32_t* __restrict__ seg_start, uint32_t n_s
 	const uint32_t gctx = (uint32_t)(skey[s] >> 16);
 	uint32_t fam = 0;
 	for (uint32_t f = 1; f < N_FAM; ++f) if (gctx >= ft.ctx_base[f]) fam = f;
-	if (ft.n_sym[fam] > 8) return;
-	const uint32_t i = atomicAdd(n_runs, 1u);
-	if (i < cap) { LongRun r; r.s = s; r.e = e; r.fam = fam; r.gctx = gctx; r.step0 = r.group0 = r.epoch0 = 0; r.epoch_cap = 0; r.pad = 0; runs[i] = r; }
+	if (ft.n_sym[fam] > 32) return;
+	const uint32_t which = ft.n_sym[fam] > 8 ? 1u : 0u;
+	const uint32_t i = atomicAdd(n_runs + which, 1u);
+	if (i < cap) { LongRun r; r.s = s; r.e = e; r.fam = fam; r.gctx = gctx; r.step0 = r.group0 = r.epoch0 = 0; r.epoch_cap = 0; r.pad = 0; runs[which * cap + i] = r; }
 }
 // one wave per group of 64 steps (4096 symbols)
+template<int NS>
 __global__ __launch_bounds__(256) void k_long_hist(const LongRun* __restrict__ runs, uint32_t n_runs, uint64_t n_groups, const uint64_t* __restrict__ skey,
                                                   uint32_t* __restrict__ step_pfx, uint32_t* __restrict__ group_tot)
 {
@@ -406,59 +408,65 @@ __global__ __launch_bounds__(256) void k_long_hist(const LongRun* __restrict__ r
 	while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (runs[mid].group0 <= g) lo = mid; else hi = mid; }
 	const LongRun R = runs[lo];
 	const uint64_t gl = g - R.group0;                                          // group inside the run
-	uint32_t c[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+	uint32_t c[NS];
+#pragma unroll
+	for (int a = 0; a < NS; ++a) c[a] = 0;
 	for (uint32_t k = 0; k < 64; ++k)
 	{
 		const uint64_t j = (uint64_t)R.s + (gl * 64 + k) * 64 + lane;
 		const bool valid = j < R.e;
 		const uint32_t sym = valid ? (uint32_t)(skey[j] & 0xff) : 0xffu;
 #pragma unroll
-		for (uint32_t a = 0; a < 8; ++a) { const uint32_t n = (uint32_t)__popcll(__ballot(sym == a)); if (lane == k) c[a] = n; }
+		for (uint32_t a = 0; a < NS; ++a) { const uint32_t n = (uint32_t)__popcll(__ballot(sym == a)); if (lane == k) c[a] = n; }
 	}
 	const uint64_t n_steps = ((uint64_t)(R.e - R.s) + 63) / 64;
 	const uint64_t step = R.step0 + gl * 64 + lane;
 #pragma unroll
-	for (uint32_t a = 0; a < 8; ++a)
+	for (uint32_t a = 0; a < NS; ++a)
 	{
 		const uint32_t incl = wave_incl_scan(c[a]);
-		if (gl * 64 + lane < n_steps) step_pfx[step * 8 + a] = incl - c[a];     // the steps of the next run follow immediately
-		if (lane == 63) group_tot[g * 8 + a] = incl;
+		if (gl * 64 + lane < n_steps) step_pfx[step * NS + a] = incl - c[a];    // the steps of the next run follow immediately
+		if (lane == 63) group_tot[g * NS + a] = incl;
 	}
 }
+template<int NS>
 __global__ __launch_bounds__(64) void k_long_groups(const LongRun* __restrict__ runs, uint32_t n_runs, uint32_t* __restrict__ group_tot /* in: totals, out: exclusive prefix */)
 {
 	const uint32_t r = blockIdx.x, lane = threadIdx.x;
 	if (r >= n_runs) return;
 	const LongRun R = runs[r];
 	const uint64_t n_steps = ((uint64_t)(R.e - R.s) + 63) / 64, n_groups = (n_steps + 63) / 64;
-	uint32_t carry[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+	uint32_t carry[NS];
+#pragma unroll
+	for (int a = 0; a < NS; ++a) carry[a] = 0;
 	for (uint64_t g0 = 0; g0 < n_groups; g0 += 64)
 	{
 		const uint64_t g = g0 + lane; const bool valid = g < n_groups;
 #pragma unroll
-		for (uint32_t a = 0; a < 8; ++a)
+		for (uint32_t a = 0; a < NS; ++a)
 		{
-			const uint32_t v = valid ? group_tot[(R.group0 + g) * 8 + a] : 0u;
+			const uint32_t v = valid ? group_tot[(R.group0 + g) * NS + a] : 0u;
 			const uint32_t incl = wave_incl_scan(v);
-			if (valid) group_tot[(R.group0 + g) * 8 + a] = carry[a] + incl - v;
+			if (valid) group_tot[(R.group0 + g) * NS + a] = carry[a] + incl - v;
 			carry[a] += __shfl(incl, 63);
 		}
 	}
 }
-// occurrences of each class among the first x symbols of the run: lane a (< 8) returns class a
+// occurrences of each class among the first x symbols of the run: lane a (< NS) returns class a
+template<int NS>
 __device__ inline uint32_t long_prefix(const LongRun& R, const uint64_t* skey, const uint32_t* step_pfx, const uint32_t* group_pfx, uint32_t x, uint32_t lane)
 {
 	const uint64_t step = x >> 6; const uint32_t off = x & 63;
-	const uint32_t a = lane & 7;
-	uint32_t v = group_pfx[(R.group0 + (step >> 6)) * 8 + a] + (step * 64 < (uint64_t)(R.e - R.s) || off ? step_pfx[(R.step0 + step) * 8 + a] : 0u);
+	const uint32_t a = lane & (NS - 1);
+	uint32_t v = group_pfx[(R.group0 + (step >> 6)) * NS + a] + (step * 64 < (uint64_t)(R.e - R.s) || off ? step_pfx[(R.step0 + step) * NS + a] : 0u);
 	if (x == R.e - R.s && off == 0)
 	{	// exactly at the end on a step boundary: the last step's prefix + its own histogram = prefix of a virtual next step
 		const uint64_t last = step - 1;
 		const uint64_t j = (uint64_t)R.s + last * 64 + lane; const uint32_t sym = j < R.e ? (uint32_t)(skey[j] & 0xff) : 0xffu;
 		uint32_t mine = 0;
 #pragma unroll
-		for (uint32_t b = 0; b < 8; ++b) { const uint32_t n = (uint32_t)__popcll(__ballot(sym == b)); if (a == b) mine = n; }
-		return group_pfx[(R.group0 + (last >> 6)) * 8 + a] + step_pfx[(R.step0 + last) * 8 + a] + mine;
+		for (uint32_t b = 0; b < NS; ++b) { const uint32_t n = (uint32_t)__popcll(__ballot(sym == b)); if (a == b) mine = n; }
+		return group_pfx[(R.group0 + (last >> 6)) * NS + a] + step_pfx[(R.step0 + last) * NS + a] + mine;
 	}
 	if (off)
 	{
@@ -466,14 +474,15 @@ __device__ inline uint32_t long_prefix(const LongRun& R, const uint64_t* skey, c
 		const uint64_t below = (1ULL << off) - 1;
 		uint32_t mine = 0;
 #pragma unroll
-		for (uint32_t b = 0; b < 8; ++b) { const uint32_t n = (uint32_t)__popcll(__ballot(sym == b) & below); if (a == b) mine = n; }
+		for (uint32_t b = 0; b < NS; ++b) { const uint32_t n = (uint32_t)__popcll(__ballot(sym == b) & below); if (a == b) mine = n; }
 		v += mine;
 	}
 	return v;
 }
+template<int NS>
 __global__ __launch_bounds__(64) void k_long_epochs(const FamTab* __restrict__ ftp, const LongRun* __restrict__ runs, uint32_t n_runs, const uint64_t* __restrict__ skey,
                                                    const uint32_t* __restrict__ step_pfx, const uint32_t* __restrict__ group_pfx, uint32_t* __restrict__ state,
-                                                   EpochRec* __restrict__ epochs, uint32_t* __restrict__ n_epochs, uint32_t* __restrict__ group_epoch, uint32_t* __restrict__ err)
+                                                   EpochRec<NS>* __restrict__ epochs, uint32_t* __restrict__ n_epochs, uint32_t* __restrict__ group_epoch, uint32_t* __restrict__ err)
 {
 	const uint32_t r = blockIdx.x, lane = threadIdx.x;
 	if (r >= n_runs) return;
@@ -484,30 +493,30 @@ __global__ __launch_bounds__(64) void k_long_epochs(const FamTab* __restrict__ f
 	const uint32_t L = R.e - R.s;
 	uint32_t st = lane < n_sym ? sp[lane] : 0u, tot = sp[n_sym];               // lane a: counter of class a
 	uint32_t cnt0 = 0, p = 0, ne = 0;
-	EpochRec* E = epochs + R.epoch0;
+	EpochRec<NS>* E = epochs + R.epoch0;
 	for (;;)
 	{
 		if (ne >= R.epoch_cap) { if (lane == 0) atomicOr(err, 8u); break; }
-		if (lane < 8) { E[ne].st[lane] = st; E[ne].cnt0[lane] = cnt0; }
+		if (lane < NS) { E[ne].st[lane] = st; E[ne].cnt0[lane] = cnt0; }
 		if (lane == 0) { E[ne].start = p; E[ne].tot = tot; }
 		++ne;
 		const uint32_t rr = (max_total - tot + adder - 1) / adder;              // symbols until total reaches MAX_TOTAL
 		if ((uint64_t)p + rr > L) break;
 		p += rr;
-		const uint32_t c1 = long_prefix(R, skey, step_pfx, group_pfx, p, lane);
+		const uint32_t c1 = long_prefix<NS>(R, skey, step_pfx, group_pfx, p, lane);
 		st += adder * (c1 - cnt0); cnt0 = c1;
 		tot += adder * rr;
 		while (tot >= max_total)
 		{
 			st = (st + 1) / 2;
-			uint32_t sm = lane < 8 ? st : 0u;
-			for (int o = 4; o; o >>= 1) sm += __shfl_xor(sm, o);
+			uint32_t sm = lane < NS ? st : 0u;
+			for (int o = NS / 2; o; o >>= 1) sm += __shfl_xor(sm, o);
 			tot = __shfl(sm, 0);
 		}
-		if (p == L) { if (lane < 8 && ne < R.epoch_cap) { E[ne].st[lane] = st; E[ne].cnt0[lane] = cnt0; } if (lane == 0 && ne < R.epoch_cap) { E[ne].start = p; E[ne].tot = tot; } ++ne; break; }
+		if (p == L) { if (lane < NS && ne < R.epoch_cap) { E[ne].st[lane] = st; E[ne].cnt0[lane] = cnt0; } if (lane == 0 && ne < R.epoch_cap) { E[ne].start = p; E[ne].tot = tot; } ++ne; break; }
 	}
 	// final state of the model
-	const uint32_t cl = long_prefix(R, skey, step_pfx, group_pfx, L, lane);
+	const uint32_t cl = long_prefix<NS>(R, skey, step_pfx, group_pfx, L, lane);
 	if (p < L) { st += adder * (cl - cnt0); tot += adder * (L - p); }
 	if (lane < n_sym) sp[lane] = st;
 	if (lane == 0) { sp[n_sym] = tot; n_epochs[r] = ne; }
@@ -526,8 +535,9 @@ __global__ __launch_bounds__(64) void k_long_epochs(const FamTab* __restrict__ f
 	}
 }
 // one wave per step
+template<int NS>
 __global__ __launch_bounds__(256) void k_long_apply(const LongRun* __restrict__ runs, uint32_t n_runs, uint64_t n_steps, const uint64_t* __restrict__ skey, const uint32_t* __restrict__ sval,
-                                                   const uint32_t* __restrict__ step_pfx, const uint32_t* __restrict__ group_pfx, const EpochRec* __restrict__ epochs,
+                                                   const uint32_t* __restrict__ step_pfx, const uint32_t* __restrict__ group_pfx, const EpochRec<NS>* __restrict__ epochs,
                                                    const uint32_t* __restrict__ n_epochs, const uint32_t* __restrict__ group_epoch, const FamTab* __restrict__ ftp, triple_t* __restrict__ trip)
 {
 	const uint64_t step = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; const uint32_t lane = threadIdx.x & 63;
@@ -540,25 +550,25 @@ __global__ __launch_bounds__(256) void k_long_apply(const LongRun* __restrict__ 
 	const uint64_t j = (uint64_t)R.s + x; const bool valid = j < R.e;
 	const uint64_t k = valid ? skey[j] : 0;
 	const uint32_t sym = valid ? (uint32_t)(k & 0xff) : 0xffu, e1 = (uint32_t)(k >> 12) & 15u, e2 = (uint32_t)(k >> 8) & 15u;
-	uint64_t m[8];
+	uint64_t m[NS];
 #pragma unroll
-	for (uint32_t a = 0; a < 8; ++a) m[a] = __ballot(sym == a);
+	for (uint32_t a = 0; a < NS; ++a) m[a] = __ballot(sym == a);
 	// epoch of this lane's symbol: the one in force at the step's first symbol or a later one starting inside the step
-	const EpochRec* E = epochs + R.epoch0; const uint32_t ne = n_epochs[ri];
+	const EpochRec<NS>* E = epochs + R.epoch0; const uint32_t ne = n_epochs[ri];
 	uint32_t e = group_epoch[R.group0 + (sl >> 6)];
 	while (e + 1 < ne && E[e + 1].start <= x0) ++e;
 	uint32_t me = e;
 	while (me + 1 < ne && E[me + 1].start <= x) ++me;
 	if (!valid) return;
-	const EpochRec ep = E[me];
+	const EpochRec<NS>& ep = E[me];
 	const uint64_t lt = (1ULL << lane) - 1;
 	uint32_t cum = 0, freq = 0, excl = 0;
 #pragma unroll
-	for (uint32_t a = 0; a < 8; ++a)
+	for (uint32_t a = 0; a < NS; ++a)
 	{
-		const uint32_t pre = group_pfx[(R.group0 + (sl >> 6)) * 8 + a] + step_pfx[step * 8 + a] + (uint32_t)__popcll(m[a] & lt);
+		const uint32_t pre = group_pfx[(R.group0 + (sl >> 6)) * NS + a] + step_pfx[step * NS + a] + (uint32_t)__popcll(m[a] & lt);
 		const uint32_t v = ep.st[a] + adder * (pre - ep.cnt0[a]);
-		const bool ex = a == e1 || a == e2;
+		const bool ex = NS <= 8 && (a == e1 || a == e2);                         // exclusions exist only in the small models (15 = none)
 		if (ex) excl += v;
 		if (a < sym && !ex) cum += v;
 		if (a == sym) freq = v;
@@ -640,6 +650,7 @@ __global__ __launch_bounds__(256) void k_dna_evolve(const FamTab* __restrict__ f
 		}
 		return;
 	}
+	if (n_sym <= 32 && e - s >= ft.long_run) return;                          // k_long_*<32>
 	uint32_t* cnt = s_cnt[w]; uint32_t* pre = s_pre[w];
 #pragma unroll
 	for (uint32_t t = 0; t < 4; ++t) { uint32_t a = lane * 4 + t; cnt[a] = a < n_sym ? sp[a] : 0u; }
@@ -861,38 +872,55 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 			LAUNCHB(ctx, n_syms * 28.0, k_dna_evolve, grid_for(n_seg, 4), 256, (const FamTab*)D->d_ft.p, (const uint64_t*)key.p, (const uint32_t*)sidx.p, (const uint32_t*)seg.p,
 				(uint32_t)n_seg, D->state.p, trip.p);
 			HIP_TRY(ctx, hipGetLastError());
-			{	// long runs of the small-alphabet models (k_dna_evolve skipped them)
+			{	// long runs of the models with up to 32 symbols (k_dna_evolve skipped them)
 				const uint32_t RUN_CAP = 4096;
-				DevBuf<LongRun> runs; DEV_ALLOC(ctx, runs, RUN_CAP);
-				DevBuf<uint32_t> n_runs; DEV_ALLOC(ctx, n_runs, 1);
-				HIP_TRY(ctx, hipMemsetAsync(n_runs.p, 0, 4, ctx->stream));
+				DevBuf<LongRun> runs; DEV_ALLOC(ctx, runs, 2 * RUN_CAP);
+				DevBuf<uint32_t> n_runs; DEV_ALLOC(ctx, n_runs, 2);
+				HIP_TRY(ctx, hipMemsetAsync(n_runs.p, 0, 8, ctx->stream));
 				LAUNCH(ctx, k_long_find, grid_for(n_seg, 256), 256, (const uint32_t*)seg.p, (uint32_t)n_seg, (const uint64_t*)key.p, (const FamTab*)D->d_ft.p, runs.p, RUN_CAP, n_runs.p);
-				uint32_t nlr = 0;
-				HIP_TRY(ctx, hipMemcpyAsync(&nlr, n_runs.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+				uint32_t nlr2[2] = { 0, 0 };
+				HIP_TRY(ctx, hipMemcpyAsync(nlr2, n_runs.p, 8, hipMemcpyDeviceToHost, ctx->stream));
 				HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-				if (nlr > RUN_CAP) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_dna_encode: more than 4096 long context runs in one group");
-				if (nlr)
+				if (nlr2[0] > RUN_CAP || nlr2[1] > RUN_CAP) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_dna_encode: more than 4096 long context runs in one group");
+				for (int which = 0; which < 2; ++which)
 				{
+					const uint32_t nlr = nlr2[which], NS = which ? 32 : 8;
+					if (!nlr) continue;
+					LongRun* d_runs = runs.p + (uint64_t)which * RUN_CAP;
 					std::vector<LongRun> h(nlr);
-					HIP_TRY(ctx, hipMemcpy(h.data(), runs.p, nlr * sizeof(LongRun), hipMemcpyDeviceToHost));
+					HIP_TRY(ctx, hipMemcpy(h.data(), d_runs, nlr * sizeof(LongRun), hipMemcpyDeviceToHost));
 					std::sort(h.begin(), h.end(), [](const LongRun& a, const LongRun& b) { return a.s < b.s; });
 					uint64_t steps = 0, groups = 0, eps = 0;
 					for (auto& r : h)
 					{
 						const uint64_t L = r.e - r.s, ns = (L + 63) / 64, ngp = (ns + 63) / 64;
 						const uint64_t half = f.max_total[r.fam] / 2 / f.adder[r.fam];
-						r.step0 = steps; r.group0 = groups; r.epoch0 = eps; r.epoch_cap = (uint32_t)(L / (half > 16 ? half - 8 : 1) + 8);
+						r.step0 = steps; r.group0 = groups; r.epoch0 = eps; r.epoch_cap = (uint32_t)(L / (half > 80 ? half - 40 : 1) + 8);
 						steps += ns; groups += ngp; eps += r.epoch_cap;
 					}
-					HIP_TRY(ctx, hipMemcpyAsync(runs.p, h.data(), nlr * sizeof(LongRun), hipMemcpyHostToDevice, ctx->stream));
-					DevBuf<uint32_t> step_pfx, group_pfx, d_ne, group_epoch; DevBuf<EpochRec> epochs;
-					DEV_ALLOC(ctx, step_pfx, steps * 8 + 8); DEV_ALLOC(ctx, group_pfx, groups * 8 + 8); DEV_ALLOC(ctx, d_ne, nlr); DEV_ALLOC(ctx, group_epoch, groups + 1); DEV_ALLOC(ctx, epochs, eps + 1);
-					LAUNCHB(ctx, steps * 64 * 8.0, k_long_hist, grid_for(groups * 64, 256), 256, (const LongRun*)runs.p, nlr, groups, (const uint64_t*)key.p, step_pfx.p, group_pfx.p);
-					LAUNCH(ctx, k_long_groups, nlr, 64, (const LongRun*)runs.p, nlr, group_pfx.p);
-					LAUNCH(ctx, k_long_epochs, nlr, 64, (const FamTab*)D->d_ft.p, (const LongRun*)runs.p, nlr, (const uint64_t*)key.p, (const uint32_t*)step_pfx.p, (const uint32_t*)group_pfx.p,
-						D->state.p, epochs.p, d_ne.p, group_epoch.p, err.p);
-					LAUNCHB(ctx, steps * 64 * 28.0, k_long_apply, grid_for(steps * 64, 256), 256, (const LongRun*)runs.p, nlr, steps, (const uint64_t*)key.p, (const uint32_t*)sidx.p,
-						(const uint32_t*)step_pfx.p, (const uint32_t*)group_pfx.p, (const EpochRec*)epochs.p, (const uint32_t*)d_ne.p, (const uint32_t*)group_epoch.p, (const FamTab*)D->d_ft.p, trip.p);
+					HIP_TRY(ctx, hipMemcpyAsync(d_runs, h.data(), nlr * sizeof(LongRun), hipMemcpyHostToDevice, ctx->stream));
+					DevBuf<uint32_t> step_pfx, group_pfx, d_ne, group_epoch; DevBuf<uint32_t> epochs;
+					DEV_ALLOC(ctx, step_pfx, (steps + 1) * NS); DEV_ALLOC(ctx, group_pfx, (groups + 1) * NS); DEV_ALLOC(ctx, d_ne, nlr); DEV_ALLOC(ctx, group_epoch, groups + 1);
+					DEV_ALLOC(ctx, epochs, (eps + 1) * (2 + 2 * NS));
+					const LongRun* cr = d_runs;
+					if (which == 0)
+					{
+						LAUNCHB(ctx, steps * 64 * 8.0, (k_long_hist<8>), grid_for(groups * 64, 256), 256, cr, nlr, groups, (const uint64_t*)key.p, step_pfx.p, group_pfx.p);
+						LAUNCH(ctx, (k_long_groups<8>), nlr, 64, cr, nlr, group_pfx.p);
+						LAUNCH(ctx, (k_long_epochs<8>), nlr, 64, (const FamTab*)D->d_ft.p, cr, nlr, (const uint64_t*)key.p, (const uint32_t*)step_pfx.p, (const uint32_t*)group_pfx.p,
+							D->state.p, (EpochRec<8>*)epochs.p, d_ne.p, group_epoch.p, err.p);
+						LAUNCHB(ctx, steps * 64 * 28.0, (k_long_apply<8>), grid_for(steps * 64, 256), 256, cr, nlr, steps, (const uint64_t*)key.p, (const uint32_t*)sidx.p,
+							(const uint32_t*)step_pfx.p, (const uint32_t*)group_pfx.p, (const EpochRec<8>*)epochs.p, (const uint32_t*)d_ne.p, (const uint32_t*)group_epoch.p, (const FamTab*)D->d_ft.p, trip.p);
+					}
+					else
+					{
+						LAUNCHB(ctx, steps * 64 * 8.0, (k_long_hist<32>), grid_for(groups * 64, 256), 256, cr, nlr, groups, (const uint64_t*)key.p, step_pfx.p, group_pfx.p);
+						LAUNCH(ctx, (k_long_groups<32>), nlr, 64, cr, nlr, group_pfx.p);
+						LAUNCH(ctx, (k_long_epochs<32>), nlr, 64, (const FamTab*)D->d_ft.p, cr, nlr, (const uint64_t*)key.p, (const uint32_t*)step_pfx.p, (const uint32_t*)group_pfx.p,
+							D->state.p, (EpochRec<32>*)epochs.p, d_ne.p, group_epoch.p, err.p);
+						LAUNCHB(ctx, steps * 64 * 28.0, (k_long_apply<32>), grid_for(steps * 64, 256), 256, cr, nlr, steps, (const uint64_t*)key.p, (const uint32_t*)sidx.p,
+							(const uint32_t*)step_pfx.p, (const uint32_t*)group_pfx.p, (const EpochRec<32>*)epochs.p, (const uint32_t*)d_ne.p, (const uint32_t*)group_epoch.p, (const FamTab*)D->d_ft.p, trip.p);
+					}
 					HIP_TRY(ctx, hipGetLastError());
 					HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 				}
