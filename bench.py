@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
-"""bench.py — throughput of the MI355X-native CoLoRd hot path on synthetic ONT reads.
+"""bench.py — throughput of the MI355X-native CoLoRd compress data path on synthetic ONT reads.
 
-One "step" = one pass of every hot-path stage built so far over one per-GPU shard of synthetic ONT reads
-that is already resident in HBM as a packed read arena (+ raw quality bytes):
-    a1 canonical k-mer scan + murmur-modulo filter  ->  a2 exact count/threshold (radix sort + RLE)
-    -> a3 membership table  ->  a4 accepted k-mers per read  ->  a6 acceptor  ->  a5 index + candidates
-Stages not yet on the GPU (a8-a15: anchors, edit scripts, DNA/quality range coders) are NOT in the timed
-region and the JSON line says so in config.stages; `value` is therefore a hot-path-prefix rate, not yet a
-whole-compressor rate.
+One "step" = one pass of the whole hot path over one per-GPU shard of synthetic ONT reads that is already
+resident in HBM as a packed read arena (+ raw quality bytes):
+    a1 canonical k-mer scan + murmur-modulo filter -> a2 exact count/threshold -> a3 membership table
+    -> a4 accepted k-mers per read -> a6 acceptor -> a5 index + candidates -> a7 reference-read arena
+    -> a8 m-mer anchors -> a10/a11 gap alignment, cost decisions, recursion -> a12 tuple streams
+    -> a14/a16 DNA stream range coder;   a13/a15 quality stream range coder (4-avg, level 1)
+Not in the step (rows "f / next" of DESIGN.md): FASTQ parsing, the header (ID) stream, the archive container.
 
 Contract: python bench.py --gpus N --steps K --warmup W   (N>1 via torch.distributed.run, one rank/GPU).
 Rank 0 prints ONE JSON line.
@@ -254,7 +254,7 @@ def main():
                                         if times.bytes.get(n, 0) > 0 and times.ms[n] > 0}
         cb = None if args.no_cpu_baseline else cpu_baseline(args.cpu_sample_bases, args.k)
         line = {
-            "metric": "input Gbases/s, synthetic ONT (hot-path stages built so far)", "value": total_bases * args.steps / dt / 1e9,
+            "metric": "input Gbases/s, synthetic ONT (compress data path a1-a16)", "value": total_bases * args.steps / dt / 1e9,
             "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"synthetic ONT, {local_bases} bases/GPU ({n_reads_local} reads, N50~20kb), genome {genome_len} bp, "

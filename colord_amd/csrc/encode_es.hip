@@ -90,6 +90,18 @@ __global__ void k_class_bounds(const uint32_t* __restrict__ keys, uint32_t n, ui
 	for (uint32_t c = a; c < b && c <= N_CLASSES; ++c) bounds[c] = i;
 }
 
+// algorithmic bytes of each size class: 2-bit symbols in, one script byte per symbol out (for the roofline report)
+__global__ void k_class_bytes(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ ids, const uint32_t* __restrict__ cap, uint32_t n, unsigned long long* __restrict__ bytes /* N_CLASSES */)
+{
+	__shared__ unsigned long long s_b[N_CLASSES];
+	if (threadIdx.x < N_CLASSES) s_b[threadIdx.x] = 0;
+	__syncthreads();
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) atomicAdd(&s_b[keys[i] >> 17], (unsigned long long)cap[ids[i]]);
+	__syncthreads();
+	if (threadIdx.x < N_CLASSES && s_b[threadIdx.x]) atomicAdd(&bytes[threadIdx.x], s_b[threadIdx.x]);
+}
+
 // lane-private staging memory in LDS (word w of a lane at lds[w * 64 + lane]) + column history in HBM (lane-interleaved)
 template<int NB>
 struct LdsMem {
@@ -592,7 +604,15 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 		DevBuf<uint32_t> bounds; DEV_ALLOC(ctx, bounds, N_CLASSES + 1);
 		LAUNCH(ctx, k_class_bounds, grid_for(ng + 1, 256), 256, (const uint32_t*)keys.p, L.n_gaps, bounds.p);
 		uint32_t hb[N_CLASSES + 1];
+		unsigned long long h_cb[N_CLASSES] = { 0 };
 		HIP_TRY(ctx, hipMemcpyAsync(hb, bounds.p, 4 * (N_CLASSES + 1), hipMemcpyDeviceToHost, st));
+		if (ctx->timing)
+		{
+			DevBuf<unsigned long long> cb; DEV_ALLOC(ctx, cb, N_CLASSES);
+			HIP_TRY(ctx, hipMemsetAsync(cb.p, 0, 8 * N_CLASSES, st));
+			LAUNCH(ctx, k_class_bytes, grid_for(ng, 256), 256, (const uint32_t*)keys.p, (const uint32_t*)ids.p, (const uint32_t*)capw.p, L.n_gaps, cb.p);
+			HIP_TRY(ctx, hipMemcpyAsync(h_cb, cb.p, 8 * N_CLASSES, hipMemcpyDeviceToHost, st));
+		}
 		HIP_TRY(ctx, hipStreamSynchronize(st));
 		// small gaps
 		{
@@ -605,7 +625,7 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 				if (!n_list) continue;
 				const uint32_t blocks = std::min<uint32_t>(grid_for(n_list, 64), n_cu * 4);
 				const uint32_t lds = (16 * nb + 64 + 16 * nb + 64) * 64 * 4;
-				const double bytes = (double)n_list * 64;
+				const double bytes = 1.25 * (double)h_cb[nb];
 				const uint32_t* list = ids.p + hb[nb];
 				switch (nb)
 				{
@@ -624,7 +644,7 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 			const uint32_t n_list = hb[6] - hb[5];
 			const uint32_t blocks = std::min<uint32_t>(grid_for(n_list, 64), n_cu * 2);
 			DevBuf<uint64_t> scratch; DEV_ALLOC(ctx, scratch, (uint64_t)blocks * HbmMem::WORDS * 64);
-			LAUNCHB(ctx, (double)n_list * 64, k_align_mid, blocks, 64, (const uint32_t*)ids.p + hb[5], n_list, L.gaps.p, L.es.p, A, R, scratch.p);
+			LAUNCHB(ctx, 1.25 * (double)h_cb[5], k_align_mid, blocks, 64, (const uint32_t*)ids.p + hb[5], n_list, L.gaps.p, L.es.p, A, R, scratch.p);
 			HIP_TRY(ctx, hipGetLastError());
 			HIP_TRY(ctx, hipStreamSynchronize(st));
 		}
@@ -651,7 +671,7 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 				const uint32_t lanes = use_wave ? std::min<uint32_t>(n_list, max_lanes) : (uint32_t)std::min<uint64_t>(((uint64_t)n_list + 63) / 64 * 64, max_lanes);
 				DevBuf<uint8_t> scratch; DEV_ALLOC(ctx, scratch, per_lane * lanes);
 				HIP_TRY(ctx, hipMemsetAsync(cnt.p, 0, 8, st));
-				if (use_wave) LAUNCH(ctx, k_align_wave, lanes, 64, list, n_list, L.gaps.p, L.es.p, A, R, scratch.p, per_lane, cnt.p, redo.p, cnt.p + 1,
+				if (use_wave) LAUNCHB(ctx, round == 0 ? 1.25 * (double)h_cb[6] : 0.0, k_align_wave, lanes, 64, list, n_list, L.gaps.p, L.es.p, A, R, scratch.p, per_lane, cnt.p, redo.p, cnt.p + 1,
 					(uint32_t)(getenv("COLORD_HIP_WAVE_DEBUG_STAGE") ? atoi(getenv("COLORD_HIP_WAVE_DEBUG_STAGE")) : 0), hbt_dev);
 				else LAUNCH(ctx, k_align_large, lanes / 64, 64, list, n_list, L.gaps.p, L.es.p, A, R, scratch.p, per_lane, cnt.p, redo.p, cnt.p + 1);
 				HIP_TRY(ctx, hipGetLastError());
