@@ -40,6 +40,26 @@ __device__ inline uint32_t ref_at(const RefStore& R, uint32_t id, bool rev, int6
 	const uint32_t b = (uint32_t)(R.packed[R.word_off[id] + (p >> 5)] >> (62 - 2 * (p & 31))) & 3u;
 	return rev ? 3u - b : b;
 }
+// the same through a per-lane cursor: length / word offset of the current reference and the last packed word stay in
+// registers, so a run of match tuples costs one load per 32 bases instead of three dependent loads per base
+struct RefCur {
+	uint32_t id = 0xffffffffu, len = 0, widx = 0xffffffffu; bool rev = false, ok = false; uint64_t wo = 0, word = 0;
+	__device__ inline void set(const RefStore& R, uint32_t nid, bool nrev)
+	{
+		rev = nrev;
+		if (nid == id) return;
+		id = nid; widx = 0xffffffffu; ok = nid < R.n;
+		if (ok) { len = R.lens[nid]; wo = R.word_off[nid]; }
+	}
+	__device__ inline uint32_t at(const RefStore& R, int64_t pos)
+	{
+		if (!ok || pos < 0 || pos >= (int64_t)len) return 255;
+		const uint32_t p = rev ? (len - 1 - (uint32_t)pos) : (uint32_t)pos;
+		if ((p >> 5) != widx) { widx = p >> 5; word = R.packed[wo + widx]; }
+		const uint32_t b = (uint32_t)(word >> (62 - 2 * (p & 31))) & 3u;
+		return rev ? 3u - b : b;
+	}
+};
 __device__ inline uint32_t ilog2_(uint64_t x) { return x ? 64u - (uint32_t)__clzll((long long)x) : 0u; }     // bit length (basic_coder.h:39-47)
 __device__ inline uint32_t no_bytes_(uint64_t x) { uint32_t r = 1; x >>= 8; for (; x; ++r) x >>= 8; return r; }
 
@@ -179,9 +199,11 @@ __global__ __launch_bounds__(64) void k_dna_walk(const FamTab* __restrict__ ftp,
 	emit_read_id(em, ref_id, cur_read_id);
 	rev_comp_flag(ref_id, ref_rev);
 	const uint32_t s3 = 3 * ft.T;
+	RefCur mainc, altc;
+	mainc.set(R, ref_id, ref_rev);
 	while (rd.next(type, v1, v2))
 	{
-		const uint32_t ref_symbol = is_main ? ref_at(R, ref_id, ref_rev, ref_pos) : ref_at(R, alt_id, alt_rev, alt_pos);
+		const uint32_t ref_symbol = is_main ? mainc.at(R, ref_pos) : altc.at(R, alt_pos);
 		{	// encode_tuple_type (:651-710) with the guard case moved to its own dense region
 			uint32_t cls = delta < -10 ? 1u : delta < -1 ? 2u : delta > 10 ? 3u : delta > 1 ? 4u : 0u;
 			uint32_t c = (uint32_t)ctx_tuple | ((uint32_t)(ctx_symbol & 0xf) << s3);
@@ -226,6 +248,7 @@ __global__ __launch_bounds__(64) void k_dna_walk(const FamTab* __restrict__ ftp,
 			if (is_new) alt_rev_of[slot] = (uint8_t)v2;
 			rev_comp_flag(v1, v2 != 0);
 			alt_id = v1; alt_slot = slot; alt_rev = alt_rev_of[slot] != 0;
+			altc.set(R, alt_id, alt_rev);
 			alt_pos = 0; is_main = false; delta = 0;
 			break;
 		}
@@ -233,7 +256,7 @@ __global__ __launch_bounds__(64) void k_dna_walk(const FamTab* __restrict__ ftp,
 			emit_anchor_len(em, v2);
 			if (is_main) ref_pos += v2; else alt_pos += v2;
 			for (int i = ft.S; i > 0; --i)
-				ctx_symbol = (ctx_symbol << 2) + (is_main ? ref_at(R, ref_id, ref_rev, ref_pos - i) : ref_at(R, alt_id, alt_rev, alt_pos - i));
+				ctx_symbol = (ctx_symbol << 2) + (is_main ? mainc.at(R, ref_pos - i) : altc.at(R, alt_pos - i));
 			ctx_symbol &= mask_symbol;
 			delta = 0;
 			break;

@@ -596,7 +596,15 @@ CL_DEV inline uint32_t pend_walk(const TreeV& T, uint32_t frame0, uint32_t* out)
 // ---- tuple emission (encoder.cpp:1348-1443) -------------------------------------------------------------------------
 struct TupleOut {
 	uint8_t* p; uint64_t n; uint32_t n_tuples; bool write;
-	CL_DEV inline void byte(uint8_t v) { if (write) p[n] = v; ++n; }
+	uint64_t acc = 0; uint32_t have = 0; bool aligned = false;               // bytes are gathered into aligned 8-byte stores
+	CL_DEV inline void byte(uint8_t v)
+	{
+		if (!write) { ++n; return; }
+		if (!aligned) { p[n] = v; ++n; aligned = (((uint64_t)(size_t)p + n) & 7) == 0; return; }
+		acc |= (uint64_t)v << (8 * have); ++have; ++n;
+		if (have == 8) { *(uint64_t*)(p + n - 8) = acc; acc = 0; have = 0; }
+	}
+	CL_DEV inline void finish() { if (write) for (uint32_t i = 0; i < have; ++i) p[n - have + i] = (uint8_t)(acc >> (8 * i)); have = 0; }
 	CL_DEV inline void t1(uint32_t type, uint32_t val) { byte((uint8_t)((type << 4) + val)); ++n_tuples; }
 	CL_DEV inline void t28(uint32_t type, uint32_t v) { byte((uint8_t)((type << 4) + (v >> 24))); byte((v >> 16) & 0xff); byte((v >> 8) & 0xff); byte(v & 0xff); ++n_tuples; }
 	CL_DEV inline void tid(uint32_t type, uint32_t id, uint32_t rev) { byte((uint8_t)((type << 4) + rev)); byte(id >> 24); byte((id >> 16) & 0xff); byte((id >> 8) & 0xff); byte(id & 0xff); ++n_tuples; }
@@ -637,6 +645,7 @@ CL_DEV inline void emit_read(const ArenaV& A, const uint32_t* inv, const uint8_t
 {
 	const uint32_t len = A.lens[r]; const uint64_t wb = A.word_off[r];
 	TupleOut o{ WRITE ? out + es_off[r] : nullptr, 0, 0, WRITE };
+	if (WRITE) o.aligned = (((uint64_t)(size_t)o.p) & 7) == 0;
 	const uint32_t f0 = T.frame_of_read[r];
 	if (f0 == 0xffffffffu)
 	{	// AddPlainRead / AddPlainReadWithN (encoder.cpp:663-681)
@@ -646,6 +655,7 @@ CL_DEV inline void emit_read(const ArenaV& A, const uint32_t* inv, const uint8_t
 			const bool isn = (inv[wb + (i >> 5)] >> (31 - (i & 31))) & 1u;
 			o.t1(8, isn ? 4u : arena_base_at(A, wb, i));
 		}
+		o.finish();
 		if (!WRITE) { sizes[r] = (uint32_t)o.n; ntuples[r] = o.n_tuples; }
 		return;
 	}
@@ -692,8 +702,12 @@ CL_DEV inline void emit_read(const ArenaV& A, const uint32_t* inv, const uint8_t
 		if (as_es)
 		{
 			w.add('D', g.d_before);
-			const char* es = L.es + g.es_off;
-			for (uint32_t q = 0; q < g.es_len; ++q) w.add(es[q], 1);
+			const uint32_t* es4 = (const uint32_t*)(L.es + g.es_off);               // script slots are dword-aligned
+			for (uint32_t q = 0; q < g.es_len; q += 4)
+			{
+				const uint32_t word = es4[q >> 2]; const uint32_t nb = g.es_len - q < 4 ? g.es_len - q : 4;
+				for (uint32_t b = 0; b < nb; ++b) w.add((char)((word >> (8 * b)) & 0xff), 1);
+			}
 		}
 		else if (g.state == GS_CHILD)
 		{	// StoreFrag of what the parent has so far, then the child frame (encoder.cpp:1483-1488)
@@ -707,6 +721,7 @@ CL_DEV inline void emit_read(const ArenaV& A, const uint32_t* inv, const uint8_t
 			w.add('D', g.d_after);
 		}
 	}
+	o.finish();
 	if (!WRITE) { sizes[r] = (uint32_t)o.n; ntuples[r] = o.n_tuples; }
 }
 
