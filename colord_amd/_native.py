@@ -79,6 +79,7 @@ _SIG = {
     "cl_qual_coder_free": (None, [_P]),
     "cl_qual_encode": (C.c_int32, [_P, _P, _P, _P, _P, _P, _P, C.c_uint32, _P, C.c_uint64, _P, C.POINTER(C.c_uint64)]),
     "cl_anchor_candidates": (C.c_int32, [_P, _P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_double, C.c_double, C.c_double, C.c_uint32, C.POINTER(_P)]),
+    "cl_anchor_candidates_hifi": (C.c_int32, [_P, _P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, C.POINTER(_P)]),
     "cl_anchors_free": (None, [_P]),
     "cl_anchors_total": (C.c_uint64, [_P]),
     "cl_anchors_n_cands": (_P, [_P]),

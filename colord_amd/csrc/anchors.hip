@@ -250,32 +250,183 @@ __global__ __launch_bounds__(64) void k_lis_anchors(Arena A, Arena R, TaskCfg cf
 	t_nanch[t] = n_anch; t_tot[t] = tot;
 }
 
+// ---- A5': HiFi k-mer anchors (a9): AnalyseRefReadWithKmers / KmerBasedAnchors (encoder.cpp:870-1013,1113-1147) ------
+// One lane per (read, candidate).  The shared k-mers of the pair (canonical, from the similarity graph) seed anchors of
+// length k where the k-mer is unique in both reads on the same strand pairing; they must be colinear, overlapping ones
+// are dropped, then every anchor is extended base by base and touching anchors merge.  Both orientations of the
+// reference are analysed; a candidate with an accepted orientation keeps these anchors instead of the m-mer ones.
+struct KmerArgs {
+	const uint64_t* common; const uint64_t* common_off;      // per (read, slot): shared k-mers in read order (cl_candidates_common)
+	uint64_t* sorted; uint32_t* tab;                          // scratch: per shared k-mer 1 u64 + 8 u32 (count / position per read and strand)
+	uint32_t* kanch;                                          // per shared k-mer 2 x 3 u32: anchors of the rc / forward analysis
+	uint32_t* k_n; uint32_t* k_tot; uint8_t* k_use;           // per task (2 per slot): anchors, total length; per slot: 0 rc, 1 fwd, 2 none
+	uint64_t base;                                            // common_off value of the chunk's first slot
+	uint32_t k; ModTest mt;
+};
+__device__ inline uint32_t oriented_sym(const Arena& R, uint64_t wb, uint32_t len, bool rev, uint32_t pos)
+{
+	const uint32_t p = rev ? len - 1 - pos : pos;
+	const uint32_t b = (uint32_t)(R.packed[wb + (p >> 5)] >> (62 - 2 * (p & 31))) & 3u;
+	return rev ? 3u - b : b;
+}
+// occurrences of the shared k-mers in one read: per k-mer and strand a count and the (last) start position
+__device__ inline void kmer_occurrences(const Arena& A, uint64_t wb, uint32_t len, uint32_t k, const ModTest& mt, const uint64_t* sorted, uint32_t n, uint32_t* cntF, uint32_t* posF, uint32_t* cntR, uint32_t* posR)
+{
+	for (uint32_t i = 0; i < n; ++i) { cntF[i] = cntR[i] = 0; posF[i] = posR[i] = 0; }
+	if (len < k) return;
+	const uint64_t mask = (1ULL << (2 * k)) - 1; uint64_t f = 0, r = 0;
+	for (uint32_t p = 0; p < len; ++p)
+	{
+		const uint64_t b = (A.packed[wb + (p >> 5)] >> (62 - 2 * (p & 31))) & 3u;
+		f = ((f << 2) + b) & mask; r = (r >> 2) + ((3 - b) << (2 * (k - 1)));
+		if (p + 1 < k) continue;
+		const uint64_t can = f < r ? f : r;
+		if (!mod_is_zero(hash_mm(can), mt)) continue;
+		uint32_t lo = 0, hi = n;
+		while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sorted[mid] < can) lo = mid + 1; else hi = mid; }
+		if (lo >= n || sorted[lo] != can) continue;
+		if (f == can) { ++cntF[lo]; posF[lo] = p + 1 - k; } else { ++cntR[lo]; posR[lo] = p + 1 - k; }
+	}
+}
+// returns 0 no anchors, 1 incompatible, 2 accepted; anchors (len, pos_enc, pos_ref) x n_out
+__device__ inline uint32_t kmer_anchor_chain(const Arena& A, uint64_t ewb, uint32_t elen, const Arena& R, uint64_t rwb, uint32_t rlen, bool rev, uint32_t k,
+                                             uint32_t* a, uint32_t n, uint32_t* n_out, uint32_t* tot_out)
+{
+	*n_out = 0; *tot_out = 0;
+	if (n == 0) return 0;
+	auto L = [&](uint32_t i) -> uint32_t& { return a[3 * i]; }; auto E = [&](uint32_t i) -> uint32_t& { return a[3 * i + 1]; }; auto Q = [&](uint32_t i) -> uint32_t& { return a[3 * i + 2]; };
+	auto erase = [&](uint32_t i) { for (uint32_t j = i; j + 1 < n; ++j) { a[3 * j] = a[3 * j + 3]; a[3 * j + 1] = a[3 * j + 4]; a[3 * j + 2] = a[3 * j + 5]; } --n; };
+	auto enc = [&](uint32_t p) -> uint32_t { return (uint32_t)(A.packed[ewb + (p >> 5)] >> (62 - 2 * (p & 31))) & 3u; };
+	auto ref = [&](uint32_t p) -> uint32_t { return oriented_sym(R, rwb, rlen, rev, p); };
+	for (uint32_t i = 1; i < n; ++i)                                             // by position in the read (positions are distinct)
+	{
+		const uint32_t x0 = a[3 * i], x1 = a[3 * i + 1], x2 = a[3 * i + 2]; uint32_t j = i;
+		while (j > 0 && a[3 * (j - 1) + 1] > x1) { a[3 * j] = a[3 * j - 3]; a[3 * j + 1] = a[3 * j - 2]; a[3 * j + 2] = a[3 * j - 1]; --j; }
+		a[3 * j] = x0; a[3 * j + 1] = x1; a[3 * j + 2] = x2;
+	}
+	for (uint32_t i = 1; i < n; ++i) if (Q(i) < Q(i - 1)) return 1;
+	for (uint64_t i = 0; i + 1 < n; ++i)                                         // drop overlapping k-mers (:912-920)
+		if (E((uint32_t)i) + L((uint32_t)i) > E((uint32_t)i + 1) || Q((uint32_t)i) + L((uint32_t)i) > Q((uint32_t)i + 1)) { erase((uint32_t)i + 1); --i; }
+	while (E(0) > 0 && Q(0) > 0 && enc(E(0) - 1) == ref(Q(0) - 1)) { --E(0); --Q(0); ++L(0); }
+	for (uint64_t ii = 0; ii < n; ++ii)
+	{
+		uint32_t i = (uint32_t)ii;
+		if (i > 0)
+		{
+			const uint32_t pe = E(i - 1) + L(i - 1), pr = Q(i - 1) + L(i - 1);
+			for (;;)
+			{
+				const bool re = E(i) == pe, rr = Q(i) == pr;
+				if (re && rr) { L(i) += L(i - 1); erase(i - 1); break; }               // as the reference: the merged anchor keeps its own positions (:944-948)
+				if (re || rr) break;
+				if (enc(E(i) - 1) != ref(Q(i) - 1)) break;
+				++L(i); --E(i); --Q(i);
+			}
+		}
+		if (i != n - 1)
+		{
+			const uint32_t ne_ = E(i + 1), nr_ = Q(i + 1);
+			uint32_t pe = E(i) + L(i), pr = Q(i) + L(i);
+			for (;;)
+			{
+				const bool re = pe == ne_, rr = pr == nr_;
+				if (re && rr) { L(i) += L(i + 1); erase(i + 1); --ii; break; }
+				else if (re || rr) break;
+				if (enc(pe) != ref(pr)) break;
+				++pe; ++pr; ++L(i);
+			}
+		}
+	}
+	{
+		const uint32_t l = n - 1; uint32_t pe = E(l) + L(l), pr = Q(l) + L(l);
+		while (pe < elen && pr < rlen && enc(pe) == ref(pr)) { ++pe; ++pr; ++L(l); }
+	}
+	uint32_t tot = 0; for (uint32_t i = 0; i < n; ++i) tot += L(i);
+	*n_out = n; *tot_out = tot;
+	return 2;
+}
+__global__ void k_kmer_anchors(Arena A, Arena R, TaskCfg cfg, const uint32_t* __restrict__ cand_refs, const uint32_t* __restrict__ cand_n, const uint8_t* __restrict__ has_n,
+                               const uint32_t* __restrict__ n_distinct, KmerArgs ka)
+{
+	const uint64_t sl = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;              // slot inside the chunk
+	const uint32_t c = cfg.c, rl = (uint32_t)(sl / c), j = (uint32_t)(sl % c);
+	const uint32_t r = cfg.r0 + rl;
+	if (r >= cfg.r1) return;
+	ka.k_use[sl] = 2; ka.k_n[2 * sl] = ka.k_n[2 * sl + 1] = 0; ka.k_tot[2 * sl] = ka.k_tot[2 * sl + 1] = 0;
+	if (has_n[r] || j >= cand_n[r]) return;
+	{	// read-level decision (encoder.cpp:1069-1078), as in k_match
+		const double el = (double)A.lens[r], nd = (double)n_distinct[rl];
+		if (nd < cfg.frac_min * el && !(nd > cfg.frac_always * el)) return;
+	}
+	const uint64_t gs = (uint64_t)r * c + j;
+	const uint64_t o = ka.common_off[gs] - ka.base; const uint32_t n = (uint32_t)(ka.common_off[gs + 1] - ka.common_off[gs]);
+	if (n == 0) return;
+	uint64_t* sorted = ka.sorted + o;
+	for (uint32_t i = 0; i < n; ++i)                                              // ascending (the reference sorts the list, :1117)
+	{
+		const uint64_t x = ka.common[ka.common_off[gs] + i]; uint32_t q = i;
+		while (q > 0 && sorted[q - 1] > x) { sorted[q] = sorted[q - 1]; --q; }
+		sorted[q] = x;
+	}
+	uint32_t* tab = ka.tab + 8 * o;
+	uint32_t* eF = tab, * ePF = tab + n, * eR = tab + 2 * n, * ePR = tab + 3 * n, * rF = tab + 4 * n, * rPF = tab + 5 * n, * rR = tab + 6 * n, * rPR = tab + 7 * n;
+	const uint32_t id = cand_refs[gs];
+	const uint64_t ewb = A.word_off[r], rwb = R.word_off[id]; const uint32_t elen = A.lens[r], rlen = R.lens[id], k = ka.k;
+	kmer_occurrences(A, ewb, elen, k, ka.mt, sorted, n, eF, ePF, eR, ePR);
+	kmer_occurrences(R, rwb, rlen, k, ka.mt, sorted, n, rF, rPF, rR, rPR);
+	uint32_t st[2], na[2], tt[2];
+	for (uint32_t orient = 0; orient < 2; ++orient)                                  // 0: reverse complement of the reference, 1: as stored
+	{
+		const bool rev = orient == 0;
+		uint32_t* a = ka.kanch + 6 * o + (uint64_t)orient * 3 * n; uint32_t m = 0;
+		for (uint32_t i = 0; i < n; ++i)
+		{
+			// forward text of the k-mer in the read and in the oriented reference, else its reverse complement in both
+			// (in the reverse-complemented reference a forward occurrence is a reverse-strand occurrence of the stored read)
+			const uint32_t cF = rev ? rR[i] : rF[i], cR = rev ? rF[i] : rR[i];
+			const uint32_t pF = rev ? rlen - k - rPR[i] : rPF[i], pR = rev ? rlen - k - rPF[i] : rPR[i];
+			if (eF[i] == 1 && cF == 1) { a[3 * m] = k; a[3 * m + 1] = ePF[i]; a[3 * m + 2] = pF; ++m; }
+			else if (eR[i] == 1 && cR == 1) { a[3 * m] = k; a[3 * m + 1] = ePR[i]; a[3 * m + 2] = pR; ++m; }
+		}
+		st[orient] = kmer_anchor_chain(A, ewb, elen, R, rwb, rlen, rev, k, a, m, &na[orient], &tt[orient]);
+		ka.k_n[2 * sl + orient] = st[orient] == 2 ? na[orient] : 0; ka.k_tot[2 * sl + orient] = st[orient] == 2 ? tt[orient] : 0;
+	}
+	uint8_t use = 2;
+	if (st[0] == 2 && st[1] == 2) use = tt[1] > tt[0] ? 1 : 0;                       // reverse complement wins ties (:1127-1139)
+	else if (st[0] == 2) use = 0;
+	else if (st[1] == 2) use = 1;
+	ka.k_use[sl] = use;
+}
+
 // ---- A6: per read: orientation choice, stable sort by total anchor length (encoder.cpp:1106-1108,1157-1191) --------
 __global__ void k_select(TaskCfg cfg, const uint32_t* __restrict__ cand_refs, const uint32_t* __restrict__ cand_n, uint32_t min_anchors,
                          const uint32_t* __restrict__ t_nanch, const uint32_t* __restrict__ t_tot,
+                         const uint8_t* __restrict__ k_use, const uint32_t* __restrict__ k_n, const uint32_t* __restrict__ k_tot,
                          uint32_t* __restrict__ o_ncand, uint32_t* __restrict__ o_cand, uint32_t* __restrict__ o_task, uint32_t* __restrict__ o_count)
 {
 	const uint32_t r = cfg.r0 + blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= cfg.r1) return;
 	const uint32_t rl = r - cfg.r0, c = cfg.c;
 	uint32_t n = 0;
-	uint32_t sel_task[16], sel_tot[16];
+	uint32_t sel_task[16], sel_tot[16], sel_n[16];                          // task | 0x80000000: the anchors are the k-mer ones
 	const uint32_t nc = cand_n[r] < c ? cand_n[r] : c;
 	for (uint32_t j = 0; j < nc && j < 16; ++j)
 	{
 		const uint32_t trc = (rl * c + j) * 2, tfw = trc + 1;
 		const bool arc = t_nanch[trc] >= min_anchors && t_nanch[trc] > 0, afw = t_nanch[tfw] >= min_anchors && t_nanch[tfw] > 0;
+		const uint32_t ku = k_use ? k_use[(uint64_t)rl * c + j] : 2u;
+		if (ku != 2) { sel_task[n] = (trc + ku) | 0x80000000u; sel_tot[n] = k_tot[trc + ku]; sel_n[n] = k_n[trc + ku]; ++n; continue; }   // HiFi k-mer anchors (:1235-1239)
 		int pick = -1;
 		if (arc && afw) pick = t_tot[tfw] > t_tot[trc] ? 1 : 0;       // reverse complement wins ties
 		else if (arc) pick = 0;
 		else if (afw) pick = 1;
-		if (pick >= 0) { sel_task[n] = trc + (uint32_t)pick; sel_tot[n] = t_tot[trc + pick]; ++n; }
+		if (pick >= 0) { sel_task[n] = trc + (uint32_t)pick; sel_tot[n] = t_tot[trc + pick]; sel_n[n] = t_nanch[trc + pick]; ++n; }
 	}
 	for (uint32_t i = 1; i < n; ++i)                                 // insertion sort = libstdc++ std::sort on <= 16 elements, stable
 	{
-		uint32_t xt = sel_task[i], xv = sel_tot[i]; uint32_t j = i;
-		while (j > 0 && xv > sel_tot[j - 1]) { sel_task[j] = sel_task[j - 1]; sel_tot[j] = sel_tot[j - 1]; --j; }
-		sel_task[j] = xt; sel_tot[j] = xv;
+		uint32_t xt = sel_task[i], xv = sel_tot[i], xn = sel_n[i]; uint32_t j = i;
+		while (j > 0 && xv > sel_tot[j - 1]) { sel_task[j] = sel_task[j - 1]; sel_tot[j] = sel_tot[j - 1]; sel_n[j] = sel_n[j - 1]; --j; }
+		sel_task[j] = xt; sel_tot[j] = xv; sel_n[j] = xn;
 	}
 	o_ncand[r] = n;
 	for (uint32_t i = 0; i < c; ++i)
@@ -283,24 +434,32 @@ __global__ void k_select(TaskCfg cfg, const uint32_t* __restrict__ cand_refs, co
 		const uint64_t s = (uint64_t)r * c + i;
 		if (i < n)
 		{
-			const uint32_t t = sel_task[i], slot = (t / 2) % c;
+			const uint32_t t = sel_task[i] & 0x7fffffffu, slot = (t / 2) % c;
 			o_cand[4 * s] = cand_refs[(uint64_t)r * c + slot]; o_cand[4 * s + 1] = (t & 1) == 0 ? 1u : 0u;
-			o_cand[4 * s + 2] = sel_tot[i]; o_cand[4 * s + 3] = t_nanch[t];
-			o_task[(uint64_t)rl * c + i] = t; o_count[(uint64_t)rl * c + i] = t_nanch[t];
+			o_cand[4 * s + 2] = sel_tot[i]; o_cand[4 * s + 3] = sel_n[i];
+			o_task[(uint64_t)rl * c + i] = sel_task[i]; o_count[(uint64_t)rl * c + i] = sel_n[i];
 		}
 		else { o_cand[4 * s] = ~0u; o_cand[4 * s + 1] = 0; o_cand[4 * s + 2] = 0; o_cand[4 * s + 3] = 0; o_task[(uint64_t)rl * c + i] = ~0u; o_count[(uint64_t)rl * c + i] = 0; }
 	}
 }
 // ---- A7: copy the chosen anchors, trimming overlaps in reference then read coordinates (encoder.cpp:1577-1622) ------
 __global__ void k_copy_fix(const uint32_t* __restrict__ o_task, const uint64_t* __restrict__ slot_off, uint64_t n_slots,
-                           const uint64_t* __restrict__ pair_off, const uint32_t* __restrict__ anch, uint64_t dst_base, uint32_t* __restrict__ out)
+                           const uint64_t* __restrict__ pair_off, const uint32_t* __restrict__ anch, uint64_t dst_base, uint32_t* __restrict__ out,
+                           TaskCfg cfg, const uint32_t* __restrict__ kanch, const uint64_t* __restrict__ common_off, uint64_t common_base)
 {
 	const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (s >= n_slots) return;
-	const uint32_t t = o_task[s];
-	if (t == ~0u) return;
+	const uint32_t tm = o_task[s];
+	if (tm == ~0u) return;
+	const uint32_t t = tm & 0x7fffffffu;
 	const uint32_t n = (uint32_t)(slot_off[s + 1] - slot_off[s]);
 	const uint32_t* src = anch + 3 * pair_off[t];
+	if (tm & 0x80000000u)
+	{	// k-mer anchors of candidate slot t/2 of the chunk, orientation t&1
+		const uint64_t gs = (uint64_t)cfg.r0 * cfg.c + t / 2;
+		const uint64_t o = common_off[gs] - common_base; const uint32_t nk = (uint32_t)(common_off[gs + 1] - common_off[gs]);
+		src = kanch + 6 * o + (uint64_t)(t & 1) * 3 * nk;
+	}
 	uint32_t* dst = out + 3 * (dst_base + slot_off[s]);
 	for (uint32_t i = 0; i < 3 * n; ++i) dst[i] = src[i];
 	for (uint32_t i = 0; i + 1 < n; ++i)
@@ -317,11 +476,22 @@ __global__ void k_copy_fix(const uint32_t* __restrict__ o_task, const uint64_t* 
 __global__ void k_add_u64(uint64_t* v, uint64_t n, uint64_t c) { uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) v[i] += c; }
 } // namespace
 
+extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* reads, const cl_reads* refs, const uint32_t* d_cand_refs, const uint32_t* d_cand_n,
+                                               uint32_t c, uint32_t anchor_len, double frac_always, double frac_min, double max_matches_mult,
+                                               uint32_t min_anchors, uint32_t kmer_len, uint32_t modulo, const uint64_t* d_common_off, const uint64_t* d_common, cl_anchors** out);
 extern "C" cl_status cl_anchor_candidates(cl_ctx* ctx, const cl_reads* reads, const cl_reads* refs, const uint32_t* d_cand_refs, const uint32_t* d_cand_n,
                                           uint32_t c, uint32_t anchor_len, double frac_always, double frac_min, double max_matches_mult,
                                           uint32_t min_anchors, cl_anchors** out)
 {
+	return cl_anchor_candidates_hifi(ctx, reads, refs, d_cand_refs, d_cand_n, c, anchor_len, frac_always, frac_min, max_matches_mult, min_anchors, 0, 0, nullptr, nullptr, out);
+}
+extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* reads, const cl_reads* refs, const uint32_t* d_cand_refs, const uint32_t* d_cand_n,
+                                               uint32_t c, uint32_t anchor_len, double frac_always, double frac_min, double max_matches_mult,
+                                               uint32_t min_anchors, uint32_t kmer_len, uint32_t modulo, const uint64_t* d_common_off, const uint64_t* d_common, cl_anchors** out)
+{
 	if (!ctx || !reads || !refs || !d_cand_refs || !d_cand_n || !out) return cl_fail(ctx, CL_E_INVALID, "cl_anchor_candidates: null argument");
+	const bool hifi = d_common_off != nullptr;
+	if (hifi && (kmer_len < 2 || kmer_len > 28 || modulo == 0)) return cl_fail(ctx, CL_E_INVALID, "cl_anchor_candidates_hifi: 2 <= kmer_len <= 28, modulo >= 1");
 	if (c == 0 || c > 16 || anchor_len < 2 || anchor_len > 28) return cl_fail(ctx, CL_E_INVALID, "cl_anchor_candidates: 1 <= c <= 16, 2 <= anchor_len <= 28");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	const uint32_t nr = reads->n_reads, m = anchor_len;
@@ -379,15 +549,32 @@ extern "C" cl_status cl_anchor_candidates(cl_ctx* ctx, const cl_reads* reads, co
 			tf.p, ts.p, pred.p, anch.p, t_nanch.p, t_tot.p);
 		HIP_TRY(ctx, hipGetLastError());
 		const uint64_t n_slots = (uint64_t)nb * c;
+		// HiFi: k-mer anchors from the shared k-mers of every (read, candidate)
+		DevBuf<uint64_t> k_sorted; DevBuf<uint32_t> k_tab, kanch, k_n, k_tot; DevBuf<uint8_t> k_use;
+		uint64_t common_base = 0;
+		if (hifi)
+		{
+			uint64_t hb[2] = { 0, 0 };
+			HIP_TRY(ctx, hipMemcpy(&hb[0], d_common_off + (uint64_t)r0 * c, 8, hipMemcpyDeviceToHost));
+			HIP_TRY(ctx, hipMemcpy(&hb[1], d_common_off + (uint64_t)r1 * c, 8, hipMemcpyDeviceToHost));
+			common_base = hb[0];
+			const uint64_t nk = hb[1] - hb[0];
+			DEV_ALLOC(ctx, k_sorted, nk + 1); DEV_ALLOC(ctx, k_tab, 8 * nk + 8); DEV_ALLOC(ctx, kanch, 6 * nk + 6);
+			DEV_ALLOC(ctx, k_n, 2 * n_slots); DEV_ALLOC(ctx, k_tot, 2 * n_slots); DEV_ALLOC(ctx, k_use, n_slots);
+			KmerArgs ka{ d_common, d_common_off, k_sorted.p, k_tab.p, kanch.p, k_n.p, k_tot.p, k_use.p, common_base, kmer_len, make_modtest(modulo) };
+			LAUNCH(ctx, k_kmer_anchors, grid_for(n_slots, 64), 64, A, R, cfg, d_cand_refs, d_cand_n, (const uint8_t*)reads->has_n.p, (const uint32_t*)n_distinct.p, ka);
+			HIP_TRY(ctx, hipGetLastError());
+		}
 		DevBuf<uint32_t> o_task, o_count; DEV_ALLOC(ctx, o_task, n_slots); DEV_ALLOC(ctx, o_count, n_slots);
 		LAUNCH(ctx, k_select, grid_for(nb, 128), 128, cfg, d_cand_refs, d_cand_n, min_anchors, (const uint32_t*)t_nanch.p, (const uint32_t*)t_tot.p,
+			(const uint8_t*)(hifi ? k_use.p : nullptr), (const uint32_t*)k_n.p, (const uint32_t*)k_tot.p,
 			X->n_cands.p, X->cand.p, o_task.p, o_count.p);
 		DevBuf<uint64_t> slot_off; DEV_ALLOC(ctx, slot_off, n_slots + 1);
 		uint64_t n_here = 0;
 		CL_TRY(dev_exclusive_scan_u64(ctx, o_count.p, slot_off.p, n_slots, &n_here));
 		DevBuf<uint32_t> chunk; DEV_ALLOC(ctx, chunk, 3 * n_here);
 		LAUNCH(ctx, k_copy_fix, grid_for(n_slots, 128), 128, (const uint32_t*)o_task.p, (const uint64_t*)slot_off.p, n_slots, (const uint64_t*)pair_off.p,
-			(const uint32_t*)anch.p, (uint64_t)0, chunk.p);
+			(const uint32_t*)anch.p, (uint64_t)0, chunk.p, cfg, (const uint32_t*)kanch.p, d_common_off, common_base);
 		// global candidate offsets of this batch
 		HIP_TRY(ctx, hipMemcpyAsync(X->cand_off.p + (uint64_t)r0 * c, slot_off.p, n_slots * 8, hipMemcpyDeviceToDevice, ctx->stream));
 		if (total_anchors) LAUNCH(ctx, k_add_u64, grid_for(n_slots, 256), 256, X->cand_off.p + (uint64_t)r0 * c, n_slots, total_anchors);

@@ -214,9 +214,16 @@ class Context:
 
     # ---- a8 ----
     def anchor_candidates(self, reads: "Reads", refs: "Reads", cand_refs: torch.Tensor, cand_n: torch.Tensor, anchor_len: int,
-                          frac_always=0.9, frac_min=0.5, max_matches_mult=10.0, min_anchors=1) -> "Anchors":
+                          frac_always=0.9, frac_min=0.5, max_matches_mult=10.0, min_anchors=1, hifi=None) -> "Anchors":
+        """hifi = (kmer_len, modulo, common_off, common) from candidates_common: HiFi k-mer anchors first (a9)."""
         c = cand_refs.shape[1]
         h = N._P()
+        if hifi is not None:
+            k, f, coff, common = hifi
+            _check(self, self.lib.cl_anchor_candidates_hifi(self.h, reads.h, refs.h, cand_refs.contiguous().data_ptr(), cand_n.contiguous().data_ptr(), c, anchor_len,
+                                                            frac_always, frac_min, max_matches_mult, min_anchors, k, f, coff.contiguous().data_ptr(),
+                                                            common.contiguous().data_ptr() if common.numel() else None, C.byref(h)))
+            return Anchors(self, h, reads.n_reads, c)
         _check(self, self.lib.cl_anchor_candidates(self.h, reads.h, refs.h, cand_refs.contiguous().data_ptr(), cand_n.contiguous().data_ptr(), c, anchor_len,
                                                    frac_always, frac_min, max_matches_mult, min_anchors, C.byref(h)))
         return Anchors(self, h, reads.n_reads, c)

@@ -191,6 +191,15 @@ typedef struct cl_anchors cl_anchors;
 cl_status cl_anchor_candidates(cl_ctx* ctx, const cl_reads* reads, const cl_reads* refs, const uint32_t* d_cand_refs, const uint32_t* d_cand_n,
                                uint32_t c, uint32_t anchor_len, double frac_always, double frac_min, double max_matches_mult,
                                uint32_t min_anchors, cl_anchors** out);
+/* a9, DataSource::PBHiFi (prepareEncodeCandidatesHiFi, KmerBasedAnchors, AnalyseRefReadWithKmers; encoder.cpp:870-1013,
+ * 1113-1147,1194-1253): as above, but a candidate is first anchored on the k-mers it shares with the read
+ * (d_common_off / d_common from cl_candidates_common; kmer_len, modulo = the graph's k and f): k-mers unique in both
+ * reads seed anchors of length k, which must be colinear, are extended base by base and merged; the m-mer analysis
+ * decides only the candidates without accepted k-mer anchors. */
+cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* reads, const cl_reads* refs, const uint32_t* d_cand_refs, const uint32_t* d_cand_n,
+                                    uint32_t c, uint32_t anchor_len, double frac_always, double frac_min, double max_matches_mult,
+                                    uint32_t min_anchors, uint32_t kmer_len, uint32_t modulo, const uint64_t* d_common_off, const uint64_t* d_common,
+                                    cl_anchors** out);
 void cl_anchors_free(cl_anchors* a);
 uint64_t cl_anchors_total(const cl_anchors* a);
 const uint32_t* cl_anchors_n_cands(const cl_anchors* a);        /* device, n_reads */

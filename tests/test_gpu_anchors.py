@@ -10,7 +10,22 @@ from test_gpu_dna import ref_subset
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("cfg", ["c3_clr_ratio", "s6m_ont", "s3m_ont_n_ratio"])
+def hifi_args(ctx, g, c):
+    """(kmer_len, modulo, common_off, common) in the layout of cl_candidates_common, from the reference's own lists."""
+    n = g.reads.n_reads
+    off = np.zeros(n * c + 1, np.int64)
+    vals = []
+    for i, e in enumerate(g.cands):
+        for j in range(c):
+            if j < len(e["refs"]):
+                vals.append(np.asarray(e["common"][j], np.uint64))
+                off[i * c + j + 1] = len(vals[-1])
+    off = np.cumsum(off)
+    common = np.concatenate(vals) if vals else np.zeros(0, np.uint64)
+    return (g.p("k"), g.p("f"), torch.from_numpy(off).to(ctx.device), torch.from_numpy(common.view(np.int64).copy()).to(ctx.device))
+
+
+@pytest.mark.parametrize("cfg", ["c3_clr_ratio", "s6m_ont", "s3m_ont_n_ratio", "s5m_hifi", "c7_hifi_balanced", "c2_hifi_org"])
 def test_anchor_candidates_equal_oracle(ctx, cfg):
     g = golden(cfg)
     rs = g.reads
@@ -24,7 +39,9 @@ def test_anchor_candidates_equal_oracle(ctx, cfg):
     for i, e in enumerate(g.cands):
         cn[i] = len(e["refs"])
         cand[i, :cn[i]] = e["refs"]
-    anc = ctx.anchor_candidates(reads, refs, torch.from_numpy(cand.view(np.int32)).to(ctx.device), torch.from_numpy(cn.view(np.int32)).to(ctx.device), g.p("a"))
+    hifi = g.p("source") == 2
+    anc = ctx.anchor_candidates(reads, refs, torch.from_numpy(cand.view(np.int32)).to(ctx.device), torch.from_numpy(cn.view(np.int32)).to(ctx.device), g.p("a"),
+                                hifi=hifi_args(ctx, g, c) if hifi else None)
     n_c = anc.n_cands().cpu().numpy()
     tab = anc.cands().cpu().numpy().view(np.uint32)
     off = anc.cand_offsets().cpu().numpy()
@@ -35,7 +52,7 @@ def test_anchor_candidates_equal_oracle(ctx, cfg):
             enc.add_ref(rs.read(i))
     n_with = 0
     for i in range(rs.n_reads):
-        exp = [] if has_n[i] else enc.candidates(rs.read(i), g.cands[i]["refs"])
+        exp = [] if has_n[i] else enc.candidates(rs.read(i), g.cands[i]["refs"], g.cands[i]["common"] if hifi else None)
         assert n_c[i] == len(exp), f"read {i}"
         for j, (rid, rev, tot, anchors) in enumerate(exp):
             assert tuple(tab[i, j]) == (rid, rev, tot, len(anchors)), f"read {i} cand {j}"

@@ -26,7 +26,9 @@ def gpu_streams(ctx, g, pack_bounds=None):
     for i, e in enumerate(g.cands):
         cn[i] = len(e["refs"])
         cand[i, :cn[i]] = e["refs"]
-    anc = ctx.anchor_candidates(reads, refs, torch.from_numpy(cand.view(np.int32)).to(ctx.device), torch.from_numpy(cn.view(np.int32)).to(ctx.device), g.p("a"))
+    from test_gpu_anchors import hifi_args
+    anc = ctx.anchor_candidates(reads, refs, torch.from_numpy(cand.view(np.int32)).to(ctx.device), torch.from_numpy(cn.view(np.int32)).to(ctx.device), g.p("a"),
+                                hifi=hifi_args(ctx, g, c) if g.p("source") == 2 else None)
     min_alt, max_rec = PRESET_BY_LEVEL[g.p("level")]
     es, off, nt = ctx.encode_reads(reads, refs, anc, g.p("a"), min_alt, max_rec, 1.0, rs.pack_bounds() if pack_bounds is None else pack_bounds)
     es, off, nt = es.cpu().numpy(), off.cpu().numpy(), nt.cpu().numpy()
@@ -34,7 +36,7 @@ def gpu_streams(ctx, g, pack_bounds=None):
     return es, off, nt
 
 
-@pytest.mark.parametrize("cfg", ["c3_clr_ratio", "s6m_ont", "s3m_ont_n_ratio", "c1_ont_default", "c6_ont_org"])
+@pytest.mark.parametrize("cfg", ["c3_clr_ratio", "s6m_ont", "s3m_ont_n_ratio", "c1_ont_default", "c6_ont_org", "s5m_hifi", "c7_hifi_balanced", "c2_hifi_org"])
 def test_tuple_streams_equal_reference(ctx, cfg):
     g = golden(cfg)
     es, off, nt = gpu_streams(ctx, g)
@@ -46,11 +48,11 @@ def test_tuple_streams_equal_reference(ctx, cfg):
             bad.append(i)
         n_es += len(got) > 0 and got[0] >> 4 == 10
     assert not bad, f"{len(bad)} of {g.reads.n_reads} reads differ, first {bad[:10]}"
-    if cfg in ("c3_clr_ratio", "s6m_ont", "s3m_ont_n_ratio"):
+    if cfg in ("c3_clr_ratio", "s6m_ont", "s3m_ont_n_ratio", "s5m_hifi", "c7_hifi_balanced"):
         assert n_es > 10                                    # the edit-script path is really exercised
 
 
-@pytest.mark.parametrize("cfg", ["c3_clr_ratio", "s6m_ont", "s3m_ont_n_ratio", "c1_ont_default"])
+@pytest.mark.parametrize("cfg", ["c3_clr_ratio", "s6m_ont", "s3m_ont_n_ratio", "c1_ont_default", "s5m_hifi", "c7_hifi_balanced", "c2_hifi_org"])
 def test_whole_dna_path_byte_identical_to_reference(ctx, cfg):
     """Read bases in, `dna` stream parts out, every stage on the GPU (a1-a8, a10-a12, a14, a16): the parts must have the
     sizes and SHA-256 of the parts the unmodified reference wrote for the same file."""
@@ -67,7 +69,11 @@ def test_whole_dna_path_byte_identical_to_reference(ctx, cfg):
     crefs, votes, cnt = ctx.candidates(index, lists, c)
     refs = ctx.select_reads(reads, accept)
     assert refs.n_reads == int(accept.sum().item())
-    anc = ctx.anchor_candidates(reads, refs, crefs, cnt, g.p("a"))
+    hifi = None
+    if g.p("source") == 2:                                  # HiFi: the graph also delivers the shared k-mers of every candidate
+        coff, common = ctx.candidates_common(index, lists, c, crefs, cnt)
+        hifi = (k, f, coff, common)
+    anc = ctx.anchor_candidates(reads, refs, crefs, cnt, g.p("a"), hifi=hifi)
     min_alt, max_rec = PRESET_BY_LEVEL[g.p("level")]
     bounds = rs.pack_bounds()
     es, off, nt = ctx.encode_reads(reads, refs, anc, g.p("a"), min_alt, max_rec, 1.0, bounds)
