@@ -59,5 +59,5 @@ def test_anchor_candidates_equal_oracle(ctx, cfg):
             a = off[i * c + j]
             assert [tuple(x) for x in data[a:a + len(anchors)]] == anchors, f"read {i} cand {j}"
         n_with += len(exp) > 0
-    assert n_with > 10
+    assert n_with > (10 if cfg != "c2_hifi_org" else 2)      # the D.melanogaster fixture has 3 coded reads
     anc.free(); refs.free(); reads.free()
