@@ -185,7 +185,8 @@ __global__ __launch_bounds__(64) void k_align_mid(const uint32_t* __restrict__ l
 	}
 }
 
-// large gaps: one WAVE per gap (align_wave.hpp); waves pull gaps from a queue, largest first
+// large gaps: one WAVE per gap (align_wave.hpp), largest first
+constexpr uint32_t WAVE_LDS_BYTES = 32768;
 __device__ inline bool align_wave_gap(wv::WavePool& pool, GapRec& g, const ArenaV& A, const ArenaV& R, char* dst, uint32_t dbg_stage)
 {
 	g.es_len = 0; g.d_before = 0;
@@ -261,8 +262,35 @@ __device__ inline bool align_wave_gap(wv::WavePool& pool, GapRec& g, const Arena
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 	pool.beat(7);
 	if (dbg_stage == 4) return true;
-	// canonical indel placement (sequential; every lane runs the same walk and issues the same stores)
+	// canonical indel placement (sequential; every lane runs the same walk and issues the same stores).  When the script
+	// and both sequences fit the wave's LDS they are staged there: the walk is a chain of dependent byte accesses.
 	uint32_t d_before = 0;
+	if (2ull * ((uint64_t)g.use + g.ne) + 64 <= WAVE_LDS_BYTES)
+	{
+		extern __shared__ uint8_t wave_lds[];
+		uint8_t* l_es = wave_lds; uint8_t* l_ref = wave_lds + ((k + 15) & ~15u); uint8_t* l_enc = l_ref + ((g.use + 15) & ~15u);
+		for (uint32_t i = lane; i < k; i += 64) l_es[i] = (uint8_t)dst[i];
+		for (uint32_t i = lane; i < g.use; i += 64) l_ref[i] = rbuf[i];
+		for (uint32_t i = lane; i < g.ne; i += 64) l_enc[i] = ebuf[i];
+		__builtin_amdgcn_s_waitcnt(0);
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		struct LES { uint8_t* p; __device__ char get(uint32_t i) const { return (char)p[i]; } __device__ void set(uint32_t i, char c) { p[i] = (uint8_t)c; } } les{ l_es };
+		if (left && g.kind != GK_INNER)
+		{
+			const uint32_t ref_offset = (g.nr - 1) - ref_end;
+			const uint8_t* rf = l_ref + (ref_offset - (g.nr - g.use));
+			refactor_es(les, k, [&](uint32_t i) -> uint32_t { return rf[i]; }, [&](uint32_t i) -> uint32_t { return l_enc[i]; });
+			d_before = ref_offset;
+		}
+		else refactor_es(les, k, [&](uint32_t i) -> uint32_t { return l_ref[i]; }, [&](uint32_t i) -> uint32_t { return l_enc[i]; });
+		__builtin_amdgcn_s_waitcnt(0);
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		for (uint32_t i = lane; i < k; i += 64) dst[i] = (char)l_es[i];
+		__builtin_amdgcn_s_waitcnt(0);
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		g.es_len = k; g.d_before = d_before;
+		return true;
+	}
 	struct WES { char* p; uint32_t lane; __device__ char get(uint32_t i) const { return p[i]; } __device__ void set(uint32_t i, char c) { p[i] = c; } } es{ dst, lane };   // every lane stores the same byte: each thread then reads back its own store
 	if (left && g.kind != GK_INNER)
 	{
@@ -642,7 +670,7 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 		if (hb[6] > hb[5])
 		{
 			const uint32_t n_list = hb[6] - hb[5];
-			const uint32_t blocks = std::min<uint32_t>(grid_for(n_list, 64), n_cu * 2);
+			const uint32_t blocks = std::min<uint32_t>(grid_for(n_list, 64), n_cu * 8);
 			DevBuf<uint64_t> scratch; DEV_ALLOC(ctx, scratch, (uint64_t)blocks * HbmMem::WORDS * 64);
 			LAUNCHB(ctx, 1.25 * (double)h_cb[5], k_align_mid, blocks, 64, (const uint32_t*)ids.p + hb[5], n_list, L.gaps.p, L.es.p, A, R, scratch.p);
 			HIP_TRY(ctx, hipGetLastError());
@@ -654,7 +682,7 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 			DevBuf<uint32_t> todo, redo; DEV_ALLOC(ctx, todo, (uint64_t)n_list + 1); DEV_ALLOC(ctx, redo, (uint64_t)n_list + 1);
 			DevBuf<unsigned int> cnt; DEV_ALLOC(ctx, cnt, 2);
 			const uint32_t* list = ids.p + hb[6];
-			uint64_t per_lane = 6ull << 20; uint32_t max_lanes = 2048;           // waves (k_align_wave) / lanes (k_align_large)
+			uint64_t per_lane = 6ull << 20; uint32_t max_lanes = 5120;           // waves (k_align_wave) / lanes (k_align_large)
 			const bool use_wave = getenv("COLORD_HIP_NO_WAVE_ALIGN") == nullptr;
 			uint32_t* hbt_host = nullptr; uint32_t* hbt_dev = nullptr;
 			if (use_wave && n_list && getenv("COLORD_HIP_WAVE_HEARTBEAT"))
@@ -671,7 +699,7 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 				const uint32_t lanes = use_wave ? std::min<uint32_t>(n_list, max_lanes) : (uint32_t)std::min<uint64_t>(((uint64_t)n_list + 63) / 64 * 64, max_lanes);
 				DevBuf<uint8_t> scratch; DEV_ALLOC(ctx, scratch, per_lane * lanes);
 				HIP_TRY(ctx, hipMemsetAsync(cnt.p, 0, 8, st));
-				if (use_wave) LAUNCHB(ctx, round == 0 ? 1.25 * (double)h_cb[6] : 0.0, k_align_wave, lanes, 64, list, n_list, L.gaps.p, L.es.p, A, R, scratch.p, per_lane, cnt.p, redo.p, cnt.p + 1,
+				if (use_wave) LAUNCHB_SHM(ctx, round == 0 ? 1.25 * (double)h_cb[6] : 0.0, k_align_wave, lanes, 64, WAVE_LDS_BYTES, list, n_list, L.gaps.p, L.es.p, A, R, scratch.p, per_lane, cnt.p, redo.p, cnt.p + 1,
 					(uint32_t)(getenv("COLORD_HIP_WAVE_DEBUG_STAGE") ? atoi(getenv("COLORD_HIP_WAVE_DEBUG_STAGE")) : 0), hbt_dev);
 				else LAUNCH(ctx, k_align_large, lanes / 64, 64, list, n_list, L.gaps.p, L.es.p, A, R, scratch.p, per_lane, cnt.p, redo.p, cnt.p + 1);
 				HIP_TRY(ctx, hipGetLastError());
