@@ -16,6 +16,8 @@ namespace wv {
 
 struct WavePool {
 	uint8_t* base; uint64_t cap, top; bool overflow; volatile uint32_t* hb;       // hb: optional host-visible progress word (debugging)
+	unsigned long long* prof = nullptr; uint64_t t_last = 0;                      // optional per-phase clock accumulation (debugging)
+	__device__ inline void lap(uint32_t phase) { if (prof) { const uint64_t now = wall_clock64(); if ((threadIdx.x & 63) == 0) atomicAdd(prof + phase, (unsigned long long)(now - t_last)); t_last = now; } }
 	__device__ inline void beat(uint32_t code) { if (hb && (threadIdx.x & 63) == 0) *hb = code; }
 	__device__ inline void* alloc(uint64_t bytes)
 	{
@@ -253,6 +255,79 @@ __device__ inline void wave_path(WavePool& pool, const uint8_t* q, uint32_t n, c
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 	}
 	pool.release(mk0);
+}
+
+// refactor_edit_script (edit_script.h:416-446,591-671) by the whole wave.  Each of its two passes rewrites every maximal
+// REGION — consecutive script symbols that are neither a break (pass 1: insertion / substitution, pass 2: deletion /
+// substitution) nor step onto a different sequence symbol than their predecessor — as its matches first, then its
+// other symbols (pass 1: 'D'; pass 2: the inserted letter, the same throughout a region).  A forward sweep gives every
+// symbol its rank in the region and the matches up to it, a backward sweep the matches after it; 64 symbols per step,
+// regions may span steps (carries).
+__device__ inline bool wave_refactor_pass(WavePool& pool, char* es, uint32_t k, const uint8_t* seq, int pass)
+{
+	const uint32_t lane = lane_id();
+	const uint64_t mk = pool.mark();
+	const uint32_t n_chunks = (k + 63) / 64;
+	uint32_t* rank = (uint32_t*)pool.alloc((uint64_t)n_chunks * 64 * 4); uint32_t* mi = (uint32_t*)pool.alloc((uint64_t)n_chunks * 64 * 4);
+	uint8_t* oth = (uint8_t*)pool.alloc((uint64_t)n_chunks * 64);
+	uint64_t* bits = (uint64_t*)pool.alloc((uint64_t)n_chunks * 16);              // per chunk: boundary mask, match mask
+	if (pool.overflow) { pool.release(mk); return false; }
+	const uint64_t le = lane == 63 ? ~0ull : ((2ull << lane) - 1);                  // lanes <= me
+	uint32_t pos_base = 0; bool c_reg = false; uint32_t c_sym = 0xff, c_start = 0, c_m = 0;
+	for (uint32_t ch = 0; ch < n_chunks; ++ch)
+	{
+		const uint32_t x = ch * 64 + lane; const bool valid = x < k;
+		const char c = valid ? es[x] : ' ';
+		const bool ins = c == 'A' || c == 'C' || c == 'G' || c == 'T', mis = c == 'X' || c == 'Y' || c == 'Z', del = c == 'D';
+		const bool cons = valid && (pass == 1 ? !ins : !del), reg = valid && (pass == 1 ? !(ins || mis) : !(del || mis));
+		const uint64_t cmask = __ballot(cons);
+		const uint32_t pos = pos_base + (uint32_t)__popcll(cmask & (le >> 1));
+		const uint32_t sym = reg ? seq[pos] : 0xffu;
+		uint32_t p_sym = __shfl_up(sym, 1); bool p_reg = __shfl_up((int)reg, 1) != 0;
+		if (lane == 0) { p_sym = c_sym; p_reg = c_reg; }
+		const bool head = reg && (!p_reg || p_sym != sym);
+		const uint64_t H = __ballot(head), R = __ballot(reg), Mm = __ballot(reg && c == 'M');
+		uint32_t start = 0, m_incl = 0;
+		if (reg)
+		{
+			const uint64_t below = H & le;
+			if (below) { const uint32_t h = 63 - (uint32_t)__builtin_clzll(below); start = ch * 64 + h; m_incl = (uint32_t)__popcll(Mm & le & ~((1ull << h) - 1)); }
+			else { start = c_start; m_incl = c_m + (uint32_t)__popcll(Mm & le); }
+			rank[x] = x - start; mi[x] = m_incl; oth[x] = pass == 1 ? (uint8_t)'D' : (uint8_t)(sym == 0 ? 'A' : sym == 1 ? 'C' : sym == 2 ? 'G' : 'T');
+		}
+		if (lane == 0) { bits[2 * ch] = H | ~R; bits[2 * ch + 1] = Mm; }
+		c_reg = bcast((int)reg, 63) != 0; c_sym = bcast(sym, 63); c_start = bcast(start, 63); c_m = bcast(m_incl, 63);
+		pos_base += (uint32_t)__popcll(cmask);
+	}
+	__builtin_amdgcn_s_waitcnt(0);
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	uint32_t c_ma = 0;                                                               // matches from the start of the later chunks up to their first boundary
+	for (uint32_t ch = n_chunks; ch-- > 0;)
+	{
+		const uint32_t x = ch * 64 + lane;
+		const uint64_t Bd = bits[2 * ch], Mm = bits[2 * ch + 1];                      // boundary = region head or not a region symbol
+		const uint64_t above = Bd & ~le;
+		uint32_t ma;
+		if (above) { const uint32_t e = (uint32_t)__builtin_ctzll(above); ma = (uint32_t)__popcll(Mm & ~le & ((1ull << e) - 1)); }
+		else ma = (uint32_t)__popcll(Mm & ~le) + c_ma;
+		if (x < k)
+		{
+			const char c = es[x];
+			const bool ins = c == 'A' || c == 'C' || c == 'G' || c == 'T', mis = c == 'X' || c == 'Y' || c == 'Z', del = c == 'D';
+			const bool rg = pass == 1 ? !(ins || mis) : !(del || mis);
+			if (rg) es[x] = rank[x] < mi[x] + ma ? 'M' : (char)oth[x];
+		}
+		if (Bd) { const uint32_t e0 = (uint32_t)__builtin_ctzll(Bd); c_ma = (uint32_t)__popcll(Mm & ((1ull << e0) - 1)); }
+		else c_ma += (uint32_t)__popcll(Mm);
+	}
+	__builtin_amdgcn_s_waitcnt(0);
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	pool.release(mk);
+	return true;
+}
+__device__ inline bool wave_refactor(WavePool& pool, char* es, uint32_t k, const uint8_t* ref, const uint8_t* enc)
+{
+	return wave_refactor_pass(pool, es, k, ref, 1) && wave_refactor_pass(pool, es, k, enc, 2);
 }
 
 } // namespace wv

@@ -186,7 +186,6 @@ __global__ __launch_bounds__(64) void k_align_mid(const uint32_t* __restrict__ l
 }
 
 // large gaps: one WAVE per gap (align_wave.hpp), largest first
-constexpr uint32_t WAVE_LDS_BYTES = 32768;
 __device__ inline bool align_wave_gap(wv::WavePool& pool, GapRec& g, const ArenaV& A, const ArenaV& R, char* dst, uint32_t dbg_stage)
 {
 	g.es_len = 0; g.d_before = 0;
@@ -199,12 +198,14 @@ __device__ inline bool align_wave_gap(wv::WavePool& pool, GapRec& g, const Arena
 	uint8_t* opsbuf = (uint8_t*)pool.alloc((uint64_t)g.use + g.ne + 64);
 	if (pool.overflow) return false;
 	pool.beat(4);
+	pool.lap(0);
 	const uint32_t lo = left ? g.nr - g.use : 0;
 	for (uint32_t i = lane; i < g.use; i += 64) { const uint8_t v = (uint8_t)ref_sym(R, rwb, rlen, rev, g.cur_ref + lo + i); rbuf[i] = v; r2[left ? g.use - 1 - i : i] = v; }
 	for (uint32_t i = lane; i < g.ne; i += 64) { const uint8_t v = (uint8_t)arena_base_at(A, ewb, g.enc_start + i); ebuf[i] = v; e2[left ? g.ne - 1 - i : i] = v; }
 	__builtin_amdgcn_s_waitcnt(0);
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 	pool.beat(5);
+	pool.lap(1);
 	if (dbg_stage == 1) return true;
 	wv::Ops ops{ opsbuf, 0 };
 	const uint8_t* Q; const uint8_t* T; uint32_t n, m; bool rows_ref; uint32_t ref_end = 0;
@@ -213,6 +214,7 @@ __device__ inline bool align_wave_gap(wv::WavePool& pool, GapRec& g, const Arena
 		Q = rbuf; n = g.nr; T = ebuf; m = g.ne; rows_ref = true;
 		const wv::Sweep sw = wv::wave_sweep(pool, Q, 1, n, T, 1, m, false, nullptr, nullptr);
 		if (pool.overflow) return false;
+		pool.lap(2);
 		if (dbg_stage == 2) return true;
 		wv::wave_path(pool, Q, n, T, m, sw.score, ops);
 	}
@@ -221,6 +223,7 @@ __device__ inline bool align_wave_gap(wv::WavePool& pool, GapRec& g, const Arena
 		Q = r2; n = g.use; T = e2; m = g.ne; rows_ref = true; ref_end = g.use - 1;
 		const wv::Sweep sw = wv::wave_sweep(pool, Q, 1, n, T, 1, m, false, nullptr, nullptr);
 		if (pool.overflow) return false;
+		pool.lap(2);
 		wv::wave_path(pool, Q, n, T, m, sw.score, ops);
 	}
 	else
@@ -229,6 +232,7 @@ __device__ inline bool align_wave_gap(wv::WavePool& pool, GapRec& g, const Arena
 		const wv::Sweep sw = wv::wave_sweep(pool, Q, 1, n, T, 1, g.use, true, nullptr, nullptr);
 		if (pool.overflow) return false;
 		ref_end = (uint32_t)sw.end; m = (uint32_t)(sw.end + 1);
+		pool.lap(2);
 		if (dbg_stage == 2) return true;
 		wv::wave_path(pool, Q, n, T, m, sw.best, ops);
 	}
@@ -236,6 +240,7 @@ __device__ inline bool align_wave_gap(wv::WavePool& pool, GapRec& g, const Arena
 	__builtin_amdgcn_s_waitcnt(0);
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 	pool.beat(6);
+	pool.lap(3);
 	if (dbg_stage == 3) return true;
 	// operations -> script symbols, 64 at a time; for the left flank the script of the reversed sequences is written reversed
 	const uint32_t k = (uint32_t)ops.n;
@@ -261,54 +266,52 @@ __device__ inline bool align_wave_gap(wv::WavePool& pool, GapRec& g, const Arena
 	__builtin_amdgcn_s_waitcnt(0);
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 	pool.beat(7);
+	pool.lap(4);
 	if (dbg_stage == 4) return true;
-	// canonical indel placement (sequential; every lane runs the same walk and issues the same stores).  When the script
-	// and both sequences fit the wave's LDS they are staged there: the walk is a chain of dependent byte accesses.
+	// canonical indel placement (wave-parallel segmented form of refactor_edit_script, align_wave.hpp)
 	uint32_t d_before = 0;
-	if (2ull * ((uint64_t)g.use + g.ne) + 64 <= WAVE_LDS_BYTES)
-	{
-		extern __shared__ uint8_t wave_lds[];
-		uint8_t* l_es = wave_lds; uint8_t* l_ref = wave_lds + ((k + 15) & ~15u); uint8_t* l_enc = l_ref + ((g.use + 15) & ~15u);
-		for (uint32_t i = lane; i < k; i += 64) l_es[i] = (uint8_t)dst[i];
-		for (uint32_t i = lane; i < g.use; i += 64) l_ref[i] = rbuf[i];
-		for (uint32_t i = lane; i < g.ne; i += 64) l_enc[i] = ebuf[i];
-		__builtin_amdgcn_s_waitcnt(0);
-		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-		struct LES { uint8_t* p; __device__ char get(uint32_t i) const { return (char)p[i]; } __device__ void set(uint32_t i, char c) { p[i] = (uint8_t)c; } } les{ l_es };
-		if (left && g.kind != GK_INNER)
-		{
-			const uint32_t ref_offset = (g.nr - 1) - ref_end;
-			const uint8_t* rf = l_ref + (ref_offset - (g.nr - g.use));
-			refactor_es(les, k, [&](uint32_t i) -> uint32_t { return rf[i]; }, [&](uint32_t i) -> uint32_t { return l_enc[i]; });
-			d_before = ref_offset;
-		}
-		else refactor_es(les, k, [&](uint32_t i) -> uint32_t { return l_ref[i]; }, [&](uint32_t i) -> uint32_t { return l_enc[i]; });
-		__builtin_amdgcn_s_waitcnt(0);
-		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-		for (uint32_t i = lane; i < k; i += 64) dst[i] = (char)l_es[i];
-		__builtin_amdgcn_s_waitcnt(0);
-		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-		g.es_len = k; g.d_before = d_before;
-		return true;
-	}
-	struct WES { char* p; uint32_t lane; __device__ char get(uint32_t i) const { return p[i]; } __device__ void set(uint32_t i, char c) { p[i] = c; } } es{ dst, lane };   // every lane stores the same byte: each thread then reads back its own store
+	const uint8_t* rf = rbuf;
 	if (left && g.kind != GK_INNER)
 	{
 		const uint32_t ref_offset = (g.nr - 1) - ref_end;                      // uint32 wrap for end = -1, as in the reference
-		const uint8_t* rf = rbuf + (ref_offset - (g.nr - g.use));
-		refactor_es(es, k, [&](uint32_t i) -> uint32_t { return rf[i]; }, [&](uint32_t i) -> uint32_t { return ebuf[i]; });
+		rf = rbuf + (ref_offset - (g.nr - g.use));
 		d_before = ref_offset;
 	}
-	else refactor_es(es, k, [&](uint32_t i) -> uint32_t { return rbuf[i]; }, [&](uint32_t i) -> uint32_t { return ebuf[i]; });
+#ifdef CL_DEBUG_REFACTOR
+	char* t0 = (char*)pool.alloc(k + 64ull); char* t1 = (char*)pool.alloc(k + 64ull);
+	if (pool.overflow) return false;
+	for (uint32_t i = lane; i < k; i += 64) { t0[i] = dst[i]; t1[i] = dst[i]; }
 	__builtin_amdgcn_s_waitcnt(0);
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	{
+		struct WES { char* p; __device__ char get(uint32_t i) const { return p[i]; } __device__ void set(uint32_t i, char c) { p[i] = c; } } es{ t1 };
+		refactor_es(es, k, [&](uint32_t i) -> uint32_t { return rf[i]; }, [&](uint32_t i) -> uint32_t { return ebuf[i]; });
+	}
+	__builtin_amdgcn_s_waitcnt(0);
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#endif
+	if (!wv::wave_refactor(pool, dst, k, rf, ebuf)) return false;
+#ifdef CL_DEBUG_REFACTOR
+	if (lane == 0)
+	{
+		uint32_t bad = k;
+		for (uint32_t i = 0; i < k; ++i) if (dst[i] != t1[i]) { bad = i; break; }
+		if (bad < k)
+		{
+			const uint32_t lo = bad > 70 ? bad - 70 : 0;
+			printf("refactor mismatch k=%u at %u (lo %u)\n in : %.100s\n exp: %.100s\n got: %.100s\n", k, bad, lo, t0 + lo, t1 + lo, dst + lo);
+		}
+	}
+#endif
 	g.es_len = k; g.d_before = d_before;
+	pool.lap(5);
 	return true;
 }
 __global__ __launch_bounds__(64) void k_align_wave(const uint32_t* __restrict__ list, uint32_t n_list, GapRec* __restrict__ gaps, char* __restrict__ es_pool, ArenaV A, ArenaV R,
-                                                  uint8_t* __restrict__ scratch, uint64_t per_wave, unsigned int* __restrict__ next, uint32_t* __restrict__ redo, unsigned int* __restrict__ n_redo, uint32_t dbg_stage, uint32_t* hbt)
+                                                  uint8_t* __restrict__ scratch, uint64_t per_wave, unsigned int* __restrict__ next, uint32_t* __restrict__ redo, unsigned int* __restrict__ n_redo, uint32_t dbg_stage, uint32_t* hbt, unsigned long long* prof)
 {
 	wv::WavePool pool{ scratch + (uint64_t)blockIdx.x * per_wave, per_wave, 0, false, hbt ? hbt + blockIdx.x : nullptr };
+	pool.prof = prof; if (prof) pool.t_last = wall_clock64();
 	pool.beat(1);
 	const uint32_t lane = threadIdx.x;
 	for (uint32_t slot = blockIdx.x; slot < n_list; slot += gridDim.x)
@@ -318,6 +321,7 @@ __global__ __launch_bounds__(64) void k_align_wave(const uint32_t* __restrict__ 
 		pool.top = 0; pool.overflow = false;
 		GapRec g = gaps[gi];
 		pool.beat(3);
+		pool.lap(7);
 		if (!align_wave_gap(pool, g, A, R, es_pool + g.es_off, dbg_stage))
 		{
 			if (lane == 0) redo[atomicAdd(n_redo, 1u)] = gi;
@@ -684,6 +688,8 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 			const uint32_t* list = ids.p + hb[6];
 			uint64_t per_lane = 6ull << 20; uint32_t max_lanes = 5120;           // waves (k_align_wave) / lanes (k_align_large)
 			const bool use_wave = getenv("COLORD_HIP_NO_WAVE_ALIGN") == nullptr;
+			DevBuf<unsigned long long> prof;
+			if (getenv("COLORD_HIP_WAVE_PROFILE")) { DEV_ALLOC(ctx, prof, 8); HIP_TRY(ctx, hipMemsetAsync(prof.p, 0, 64, st)); }
 			uint32_t* hbt_host = nullptr; uint32_t* hbt_dev = nullptr;
 			if (use_wave && n_list && getenv("COLORD_HIP_WAVE_HEARTBEAT"))
 			{	// debugging: host-visible progress words, dumped by a watchdog thread if the kernel is still running after a while
@@ -699,8 +705,19 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 				const uint32_t lanes = use_wave ? std::min<uint32_t>(n_list, max_lanes) : (uint32_t)std::min<uint64_t>(((uint64_t)n_list + 63) / 64 * 64, max_lanes);
 				DevBuf<uint8_t> scratch; DEV_ALLOC(ctx, scratch, per_lane * lanes);
 				HIP_TRY(ctx, hipMemsetAsync(cnt.p, 0, 8, st));
-				if (use_wave) LAUNCHB_SHM(ctx, round == 0 ? 1.25 * (double)h_cb[6] : 0.0, k_align_wave, lanes, 64, WAVE_LDS_BYTES, list, n_list, L.gaps.p, L.es.p, A, R, scratch.p, per_lane, cnt.p, redo.p, cnt.p + 1,
-					(uint32_t)(getenv("COLORD_HIP_WAVE_DEBUG_STAGE") ? atoi(getenv("COLORD_HIP_WAVE_DEBUG_STAGE")) : 0), hbt_dev);
+				if (use_wave)
+				{
+				LAUNCHB(ctx, round == 0 ? 1.25 * (double)h_cb[6] : 0.0, k_align_wave, lanes, 64, list, n_list, L.gaps.p, L.es.p, A, R, scratch.p, per_lane, cnt.p, redo.p, cnt.p + 1,
+					(uint32_t)(getenv("COLORD_HIP_WAVE_DEBUG_STAGE") ? atoi(getenv("COLORD_HIP_WAVE_DEBUG_STAGE")) : 0), hbt_dev, prof.p);
+				if (prof.p)
+				{
+					unsigned long long hp[8];
+					HIP_TRY(ctx, hipStreamSynchronize(st));
+					HIP_TRY(ctx, hipMemcpy(hp, prof.p, 64, hipMemcpyDeviceToHost));
+					fprintf(stderr, "[wave phases, level %u, %u gaps, Mcycles of 100 MHz] alloc %llu stage %llu sweep %llu path %llu convert %llu refactor %llu fetch %llu\n", lv, n_list,
+						hp[0] / 1000000, hp[1] / 1000000, hp[2] / 1000000, hp[3] / 1000000, hp[4] / 1000000, hp[5] / 1000000, hp[7] / 1000000);
+				}
+				}
 				else LAUNCH(ctx, k_align_large, lanes / 64, 64, list, n_list, L.gaps.p, L.es.p, A, R, scratch.p, per_lane, cnt.p, redo.p, cnt.p + 1);
 				HIP_TRY(ctx, hipGetLastError());
 				unsigned int hc[2];
