@@ -65,12 +65,13 @@ __device__ inline uint32_t no_bytes_(uint64_t x) { uint32_t r = 1; x >>= 8; for 
 
 struct Emitter {
 	bool write; uint64_t* key; uint32_t* sidx; uint64_t off; uint32_t count; const FamTab* ft; TripLayoutDev lay; uint32_t part;
+	uint64_t tbase = 0;
 	__device__ inline void operator()(int fam, uint32_t ctx, uint32_t sym, int e1 = 15, int e2 = 15)
 	{
 		if (write)
 		{
 			key[off + count] = ((uint64_t)(ft->ctx_base[fam] + ctx) << 16) | ((uint64_t)(e1 & 15) << 12) | ((uint64_t)(e2 & 15) << 8) | sym;
-			sidx[off + count] = trip_index(lay, part, off + count);
+			sidx[off + count] = (uint32_t)(tbase + (off + count) * 64);          // = trip_index(lay, part, off + count), part constants hoisted
 		}
 		++count;
 	}
@@ -78,16 +79,29 @@ struct Emitter {
 
 struct EsReader {
 	const uint8_t* p; const uint8_t* e;
+	uint64_t w0 = 0, w1 = 0; uint32_t have = 0;                  // up to 16 prefetched stream bytes (the walk is latency-bound on them)
+	__device__ inline void refill()
+	{	// 8-byte aligned loads of the words that hold stream bytes (never a word entirely past the end)
+		const uint64_t a = (uint64_t)(size_t)p; const uint32_t sh = (uint32_t)(a & 7);
+		const uint64_t* q = (const uint64_t*)(a & ~7ull);
+		const uint64_t* lim = (const uint64_t*)(((uint64_t)(size_t)e + 7) & ~7ull);   // words holding at least one stream byte
+		const uint64_t x0 = q[0], x1 = q + 1 < lim ? q[1] : 0ull, x2 = q + 2 < lim ? q[2] : 0ull;
+		w0 = sh ? (x0 >> (8 * sh)) | (x1 << (64 - 8 * sh)) : x0;
+		w1 = sh ? (x1 >> (8 * sh)) | (x2 << (64 - 8 * sh)) : x1;
+		have = 16;
+	}
+	__device__ inline void drop(uint32_t n) { p += n; have -= n; w0 = (w0 >> (8 * n)) | (w1 << (64 - 8 * n)); w1 >>= 8 * n; }
 	__device__ inline bool next(uint32_t& type, uint32_t& v1, uint32_t& v2)
 	{
 		if (p >= e) return false;
-		const uint32_t t = p[0] >> 4; type = t;
+		if (have < 5) refill();
+		const uint32_t b0 = (uint32_t)(w0 & 0xff), t = b0 >> 4; type = t;
 		switch (t)
 		{
-		case T_INS: case T_SUBST: case T_PLAIN: v1 = p[0] & 0xf; p += 1; break;
-		case T_ANCHOR: case T_SKIP: v2 = ((uint32_t)(p[0] & 0xf) << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; p += 4; break;
-		case T_ALT_ID: case T_START_ES: v2 = p[0] & 0xf; v1 = ((uint32_t)p[1] << 24) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 8) | p[4]; p += 5; break;
-		default: p += 1;
+		case T_INS: case T_SUBST: case T_PLAIN: v1 = b0 & 0xf; drop(1); break;
+		case T_ANCHOR: case T_SKIP: v2 = ((b0 & 0xf) << 24) | ((uint32_t)((w0 >> 8) & 0xff) << 16) | ((uint32_t)((w0 >> 16) & 0xff) << 8) | (uint32_t)((w0 >> 24) & 0xff); drop(4); break;
+		case T_ALT_ID: case T_START_ES: v2 = b0 & 0xf; v1 = ((uint32_t)((w0 >> 8) & 0xff) << 24) | ((uint32_t)((w0 >> 16) & 0xff) << 16) | ((uint32_t)((w0 >> 24) & 0xff) << 8) | (uint32_t)((w0 >> 32) & 0xff); drop(5); break;
+		default: drop(1);
 		}
 		return true;
 	}
@@ -148,6 +162,7 @@ __device__ inline void emit_skip_len(Emitter& em, uint32_t len, bool local)     
 }
 
 // ---- D1: one lane per read walks the tuple stream (CDNACoder::Encode, dna_coder.cpp:26-231) ----------
+constexpr uint32_t WALK_LPW = 64;
 // WRITE = false: only counts the symbols of each read.  Bases of plain reads are left to k_dna_plain.
 template<bool WRITE>
 __global__ __launch_bounds__(64) void k_dna_walk(const FamTab* __restrict__ ftp, RefStore R, const uint8_t* __restrict__ es, const uint64_t* __restrict__ es_off,
@@ -159,9 +174,12 @@ __global__ __launch_bounds__(64) void k_dna_walk(const FamTab* __restrict__ ftp,
 	__shared__ FamTab ft;
 	for (uint32_t i = threadIdx.x; i < sizeof(FamTab) / 4; i += blockDim.x) ((uint32_t*)&ft)[i] = ((const uint32_t*)ftp)[i];
 	__syncthreads();
-	const uint32_t r = r0 + blockIdx.x * blockDim.x + threadIdx.x;
+	// WALK_LPW reads per wave (divergent walk, plenty of idle wave slots)
+	if (threadIdx.x >= WALK_LPW) return;
+	const uint32_t r = r0 + blockIdx.x * WALK_LPW + threadIdx.x;
 	if (r >= r1) return;
 	Emitter em{ WRITE, key, sidx, WRITE ? sym_off[r - r0] : 0, 0, &ft, lay, WRITE ? part_of_read(lay, r) : 0 };
+	if (WRITE) em.tbase = lay.group_base[em.part >> 6] - lay.part_sym_start[em.part] * 64 + (em.part & 63);
 	EsReader rd{ es + es_off[r], es + es_off[r + 1] };
 	uint32_t type = T_NONE, v1 = 0, v2 = 0;
 	rd.next(type, v1, v2);
@@ -843,7 +861,7 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 			if (nr)
 			{
 				LAUNCH(ctx, k_read_flags, grid_for(nr, 256), 256, d_es, d_es_off, r0, r1, rflag.p);
-				LAUNCH(ctx, (k_dna_walk<false>), grid_for(nr, 64), 64, (const FamTab*)D->d_ft.p, R, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, r0, r1,
+				LAUNCH(ctx, (k_dna_walk<false>), grid_for(nr, WALK_LPW), 64, (const FamTab*)D->d_ft.p, R, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, r0, r1,
 					D->prev_types, D->cur_read_id, nolay, counts.p, hdr.p, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, err.p);
 				HIP_TRY(ctx, hipGetLastError());
 			}
@@ -879,7 +897,7 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 		if (n_syms)
 		{
 			DevBuf<uint64_t> key; DevBuf<uint32_t> sidx; DEV_ALLOC(ctx, key, n_syms); DEV_ALLOC(ctx, sidx, n_syms);
-			LAUNCH(ctx, (k_dna_walk<true>), grid_for(nr, 64), 64, (const FamTab*)D->d_ft.p, R, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, r0, r1,
+			LAUNCH(ctx, (k_dna_walk<true>), grid_for(nr, WALK_LPW), 64, (const FamTab*)D->d_ft.p, R, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, r0, r1,
 				D->prev_types, D->cur_read_id, lay, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint64_t*)sym_off.p, key.p, sidx.p, err.p);
 			LAUNCH(ctx, k_dna_plain, grid_for(nr, 4), 256, (const FamTab*)D->d_ft.p, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, (const uint32_t*)hdr.p,
 				(const uint64_t*)sym_off.p, r0, r1, lay, key.p, sidx.p);

@@ -650,10 +650,15 @@ CL_DEV inline void emit_read(const ArenaV& A, const uint32_t* inv, const uint8_t
 	if (f0 == 0xffffffffu)
 	{	// AddPlainRead / AddPlainReadWithN (encoder.cpp:663-681)
 		o.t1(has_n[r] ? 11 : 9, 0);
-		for (uint32_t i = 0; i < len; ++i)
-		{
-			const bool isn = (inv[wb + (i >> 5)] >> (31 - (i & 31))) & 1u;
-			o.t1(8, isn ? 4u : arena_base_at(A, wb, i));
+		for (uint32_t i0 = 0; i0 < len; i0 += 32)
+		{	// one word of bases and one of N flags per 32 tuples
+			const uint64_t pw = A.packed[wb + (i0 >> 5)]; const uint32_t iw = inv[wb + (i0 >> 5)];
+			const uint32_t nb = len - i0 < 32 ? len - i0 : 32;
+			for (uint32_t j = 0; j < nb; ++j)
+			{
+				const bool isn = (iw >> (31 - j)) & 1u;
+				o.t1(8, isn ? 4u : (uint32_t)(pw >> (62 - 2 * j)) & 3u);
+			}
 		}
 		o.finish();
 		if (!WRITE) { sizes[r] = (uint32_t)o.n; ntuples[r] = o.n_tuples; }
@@ -703,10 +708,15 @@ CL_DEV inline void emit_read(const ArenaV& A, const uint32_t* inv, const uint8_t
 		{
 			w.add('D', g.d_before);
 			const uint32_t* es4 = (const uint32_t*)(L.es + g.es_off);               // script slots are dword-aligned
-			for (uint32_t q = 0; q < g.es_len; q += 4)
-			{
-				const uint32_t word = es4[q >> 2]; const uint32_t nb = g.es_len - q < 4 ? g.es_len - q : 4;
-				for (uint32_t b = 0; b < nb; ++b) w.add((char)((word >> (8 * b)) & 0xff), 1);
+			for (uint32_t q = 0; q < g.es_len; q += 32)
+			{	// eight independent loads in flight, then 32 symbols from registers (the walk is latency-bound otherwise)
+				uint32_t wd[8];
+#pragma unroll
+				for (uint32_t t = 0; t < 8; ++t) wd[t] = q + 4 * t < g.es_len ? es4[(q >> 2) + t] : 0u;
+				const uint32_t nb = g.es_len - q < 32 ? g.es_len - q : 32;
+#pragma unroll
+				for (uint32_t t = 0; t < 8; ++t)
+					for (uint32_t b2 = 0; b2 < 4; ++b2) if (4 * t + b2 < nb) w.add((char)((wd[t] >> (8 * b2)) & 0xff), 1);
 			}
 		}
 		else if (g.state == GS_CHILD)

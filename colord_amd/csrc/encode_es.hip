@@ -554,11 +554,14 @@ __global__ __launch_bounds__(64) void k_estimator(TreeV T, const uint32_t* __res
 		}
 	}
 }
+constexpr uint32_t EMIT_LPW = 16;
 template<bool WRITE>
 __global__ __launch_bounds__(64) void k_emit_tuples(ArenaV A, const uint32_t* __restrict__ inv, const uint8_t* __restrict__ has_n, TreeV T, uint32_t n_reads, const uint32_t* __restrict__ data,
                                                    uint32_t* __restrict__ sizes, uint32_t* __restrict__ ntuples, const uint64_t* __restrict__ es_off, uint8_t* __restrict__ out)
-{
-	const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+{	// EMIT_LPW reads per wave: the walk is divergent (every lane is somewhere else in its frame tree), and the machine has
+	// far more wave slots than a 64-reads-per-wave launch would use
+	if (threadIdx.x >= EMIT_LPW) return;
+	const uint32_t r = blockIdx.x * EMIT_LPW + threadIdx.x;
 	if (r < n_reads) emit_read<WRITE>(A, inv, has_n, T, r, data, sizes, ntuples, es_off, out);
 }
 
@@ -777,13 +780,13 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 	LAUNCH(ctx, k_pend_list, grid_for(nr, 64), 64, T, nr, (const uint64_t*)ev_off.p, events.p);
 	if (n_packs) LAUNCH(ctx, k_estimator, n_packs, 64, T, (const uint32_t*)d_pb.p, n_packs, (const uint32_t*)reads->lens.p, has_n, (const uint32_t*)base_counts.p, (const uint64_t*)ev_off.p, (const uint32_t*)events.p);
 	DevBuf<uint32_t> sizes; DEV_ALLOC(ctx, sizes, nr);
-	LAUNCH(ctx, (k_emit_tuples<false>), grid_for(nr, 64), 64, A, (const uint32_t*)reads->inv.p, has_n, T, nr, AV.data, sizes.p, d_es_ntuples, (const uint64_t*)nullptr, (uint8_t*)nullptr);
+	LAUNCH(ctx, (k_emit_tuples<false>), grid_for(nr, EMIT_LPW), 64, A, (const uint32_t*)reads->inv.p, has_n, T, nr, AV.data, sizes.p, d_es_ntuples, (const uint64_t*)nullptr, (uint8_t*)nullptr);
 	HIP_TRY(ctx, hipGetLastError());
 	uint64_t total = 0;
 	CL_TRY(dev_exclusive_scan_u64(ctx, sizes.p, d_es_off, nr, &total));
 	*n_out = total;
 	if (total > cap || (total && !d_es)) return cl_fail(ctx, CL_E_CAPACITY, "cl_encode_reads: need " + std::to_string(total) + " bytes");
-	LAUNCH(ctx, (k_emit_tuples<true>), grid_for(nr, 64), 64, A, (const uint32_t*)reads->inv.p, has_n, T, nr, AV.data, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint64_t*)d_es_off, d_es);
+	LAUNCH(ctx, (k_emit_tuples<true>), grid_for(nr, EMIT_LPW), 64, A, (const uint32_t*)reads->inv.p, has_n, T, nr, AV.data, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint64_t*)d_es_off, d_es);
 	HIP_TRY(ctx, hipGetLastError());
 	HIP_TRY(ctx, hipStreamSynchronize(st));
 	cl_timing_collect(ctx);
