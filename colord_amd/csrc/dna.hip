@@ -897,7 +897,7 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 		if (n_syms)
 		{
 			DevBuf<uint64_t> key; DevBuf<uint32_t> sidx; DEV_ALLOC(ctx, key, n_syms); DEV_ALLOC(ctx, sidx, n_syms);
-			LAUNCHB(ctx, n_syms * 13.0, (k_dna_walk<true>), grid_for(nr, WALK_LPW), 64,       // tuple bytes in (<= 1 per symbol), 8 + 4 bytes per symbol out (const FamTab*)D->d_ft.p, R, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, r0, r1,
+			LAUNCHB(ctx, n_syms * 13.0, (k_dna_walk<true>), grid_for(nr, WALK_LPW), 64, /* tuple bytes in (<= 1 per symbol), 8 + 4 bytes per symbol out */ (const FamTab*)D->d_ft.p, R, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, r0, r1,
 				D->prev_types, D->cur_read_id, lay, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint64_t*)sym_off.p, key.p, sidx.p, err.p);
 			LAUNCH(ctx, k_dna_plain, grid_for(nr, 4), 256, (const FamTab*)D->d_ft.p, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, (const uint32_t*)hdr.p,
 				(const uint64_t*)sym_off.p, r0, r1, lay, key.p, sidx.p);
