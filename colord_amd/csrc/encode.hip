@@ -1,7 +1,7 @@
-// encode.hip — tuple-stream emission (a12).  This round: the plain forms CEncoder::AddPlainRead /
-// AddPlainReadWithN (src/colord/encoder.cpp:663-681) — a read stored verbatim is `start_plain` (or
-// `start_plain_with_Ns`) followed by one `plain` tuple per base (utils.h:56-273, one byte each).
-// The anchor / edit-script forms (a8-a11) are not on the GPU yet.
+// encode.hip — small tuple-stream helpers (a12 / a15).  The plain forms CEncoder::AddPlainRead / AddPlainReadWithN
+// (src/colord/encoder.cpp:663-681): a read stored verbatim is `start_plain` (or `start_plain_with_Ns`) followed by one
+// `plain` tuple per base (utils.h:56-273, one byte each); the edit-script forms are in encode_es.hip.  And the per-base
+// classes the quality coder derives from a read's own tuple stream at levels 2 and 3 (quality_coder_impl.cpp:25-75).
 #include "common.hpp"
 #include "objects.hpp"
 
@@ -31,7 +31,48 @@ __global__ __launch_bounds__(256) void k_plain_es(const uint64_t* __restrict__ p
 		o[1 + i] = (uint8_t)((8u << 4) | (isn ? 4u : b));                  // plain = 8, low nibble = base 0..4
 	}
 }
+// analyze_es of the quality coder (quality_coder_impl.cpp:25-75): 'P' plain read, 'A' inside an anchor tuple, 'M' unit
+// match, ' ' inserted / substituted base.  One lane per read, 16 reads per wave (divergent walk).
+__global__ __launch_bounds__(64) void k_es_flags(const uint8_t* __restrict__ es, const uint64_t* __restrict__ es_off, const uint32_t* __restrict__ lens, uint32_t n,
+                                                const uint64_t* __restrict__ base_off, uint8_t* __restrict__ flags)
+{
+	if (threadIdx.x >= 16) return;
+	const uint32_t r = blockIdx.x * 16 + threadIdx.x;
+	if (r >= n) return;
+	const uint8_t* p = es + es_off[r]; const uint8_t* e = es + es_off[r + 1];
+	uint8_t* f = flags + base_off[r]; const uint32_t len = lens[r];
+	if (p >= e) return;
+	const uint32_t t0 = p[0] >> 4;
+	if (t0 == 9 || t0 == 11) { for (uint32_t i = 0; i < len; ++i) f[i] = 'P'; return; }
+	p += t0 == 10 ? 5 : 1;                                                  // start_es carries a 32-bit id
+	uint32_t o = 0;
+	while (p < e && o <= len)
+	{
+		const uint32_t t = p[0] >> 4;
+		switch (t)
+		{
+		case 4: { const uint32_t v = ((uint32_t)(p[0] & 0xf) << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+		          for (uint32_t i = 0; i < v && o + i < len; ++i) f[o + i] = 'A'; o += v; p += 4; break; }
+		case 5: p += 4; break;
+		case 2: if (o < len) f[o] = 'M'; ++o; p += 1; break;
+		case 0: case 3: if (o < len) f[o] = ' '; ++o; p += 1; break;
+		case 6: p += 5; break;
+		default: p += 1;
+		}
+	}
+}
 } // namespace
+
+extern "C" cl_status cl_es_flags(cl_ctx* ctx, const cl_reads* R, const uint8_t* d_es, const uint64_t* d_es_off, const uint64_t* d_base_off, uint8_t* d_flags)
+{
+	if (!ctx || !R || !d_es_off || !d_base_off || (R->total_bases && !d_flags)) return cl_fail(ctx, CL_E_INVALID, "cl_es_flags: null argument");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	if (R->n_reads) LAUNCHB(ctx, R->total_bases * 1.3, k_es_flags, grid_for(R->n_reads, 16), 64, d_es, d_es_off, (const uint32_t*)R->lens.p, R->n_reads, d_base_off, d_flags);
+	HIP_TRY(ctx, hipGetLastError());
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	cl_timing_collect(ctx);
+	return CL_OK;
+}
 
 extern "C" cl_status cl_encode_plain(cl_ctx* ctx, const cl_reads* R, uint8_t* d_es, uint64_t cap, uint64_t* d_es_off, uint32_t* d_es_ntuples, uint64_t* n_out)
 {

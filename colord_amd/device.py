@@ -261,6 +261,13 @@ class Context:
             break
         return es[:need.value], off, nt[:n]
 
+    def es_flags(self, reads: "Reads", es: torch.Tensor, es_off: torch.Tensor, base_off: torch.Tensor) -> torch.Tensor:
+        """Per-base classes for the quality coder at levels 2-3 (quality_coder_impl.cpp:25-75) from the tuple streams."""
+        flags = torch.empty(max(int(reads.total_bases), 1), dtype=torch.uint8, device=self.device)
+        _check(self, self.lib.cl_es_flags(self.h, reads.h, es.contiguous().data_ptr() if es.numel() else None, es_off.contiguous().data_ptr(),
+                                          base_off.contiguous().data_ptr(), flags.data_ptr()))
+        return flags[:int(reads.total_bases)]
+
     # ---- a14 ----
     def dna_coder(self, max_alt_refs: int, level: int, start_read_id: int = 0) -> "DnaCoder":
         h = N._P()

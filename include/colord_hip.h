@@ -227,6 +227,11 @@ cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const cl_reads* re
                           uint32_t min_part_alt, uint32_t max_rec, double cost_mult, const uint32_t* h_pack_bounds, uint32_t n_packs,
                           uint8_t* d_es, uint64_t cap, uint64_t* d_es_off, uint32_t* d_es_ntuples, uint64_t* n_out);
 
+/* The per-base classes the quality coder uses at levels 2 and 3 (analyze_es, quality_coder_impl.cpp:25-75), from the
+ * reads' own tuple streams: 'P' plain read, 'A' base inside an anchor tuple, 'M' unit match, ' ' inserted or substituted.
+ * d_base_off: n_reads+1 offsets of the reads' bases (the d_qual_off of cl_qual_encode); d_flags: total_bases bytes. */
+cl_status cl_es_flags(cl_ctx* ctx, const cl_reads* reads, const uint8_t* d_es, const uint64_t* d_es_off, const uint64_t* d_base_off, uint8_t* d_flags);
+
 /* ---- a14 + a16: CDNACoder / CEntrComprReads (dna_coder.{h,cpp}, entr_read.h:56-80) --------------------- */
 typedef struct cl_dna_coder cl_dna_coder;
 /* CDNACoder::Init(true, maxCandidates, level, ., n_ref_genome_pseudo_reads): one adaptive model set that

@@ -5,6 +5,7 @@ pack) cost decisions, recursion into alternative references, tuple run-length ru
 import numpy as np
 import pytest
 import torch
+from oracle import pyoracle as O
 from util import golden
 from test_gpu_dna import ref_subset
 
@@ -54,8 +55,8 @@ def test_tuple_streams_equal_reference(ctx, cfg):
 
 @pytest.mark.parametrize("cfg", ["c3_clr_ratio", "s6m_ont", "s3m_ont_n_ratio", "c1_ont_default", "s5m_hifi", "c7_hifi_balanced", "c2_hifi_org"])
 def test_whole_dna_path_byte_identical_to_reference(ctx, cfg):
-    """Read bases in, `dna` stream parts out, every stage on the GPU (a1-a8, a10-a12, a14, a16): the parts must have the
-    sizes and SHA-256 of the parts the unmodified reference wrote for the same file."""
+    """Read bases (and qualities) in, `dna` and `qual` stream parts out, every stage on the GPU (a1-a16): the parts must
+    have the sizes and SHA-256 of the parts the unmodified reference wrote for the same file."""
     import hashlib
     g = golden(cfg)
     rs = g.reads
@@ -85,6 +86,24 @@ def test_whole_dna_path_byte_identical_to_reference(ctx, cfg):
         got.append([int(bounds[i + 1] - bounds[i]), int(s), hashlib.sha256(raw[o:o + s]).hexdigest()])
         o += s
     assert got == g.spec["streams"]["dna"]["parts"]
+    # the quality stream from the same tuple streams: at levels 2 and 3 its contexts use the per-base classes of the script
+    if rs.quals is not None and len(rs.quals) and g.p("qual_mode") != O.QM.get("none", 8):
+        from oracle import pyoracle as O2
+        qoff = torch.from_numpy(rs.offsets).to(ctx.device)
+        flags = ctx.es_flags(reads, es, off, qoff) if g.p("level") > 1 else None
+        if flags is not None:
+            exp_fl = np.concatenate([O2.es_flags(g.es[i][2], len(rs.read(i))) for i in range(rs.n_reads)])
+            assert np.array_equal(flags.cpu().numpy(), exp_fl)
+        d = O2.QUAL_DEFAULTS[g.p("qual_mode")]
+        qc = ctx.qual_coder(g.p("qual_mode"), g.p("source"), g.p("level"), d[0], d[1])
+        qout, qsizes = qc.encode(reads, torch.from_numpy(rs.quals).to(ctx.device), qoff, np.asarray(bounds), flags)
+        qraw = qout.cpu().numpy().tobytes()
+        qgot, o = [], 0
+        for s_ in qsizes:
+            qgot.append([0, int(s_), hashlib.sha256(qraw[o:o + s_]).hexdigest()])
+            o += s_
+        assert qgot == g.spec["streams"]["qual"]["parts"]
+        qc.free()
     dc.free(); anc.free(); refs.free(); index.free(); lists.free(); kset.free(); reads.free()
 
 
