@@ -189,10 +189,16 @@ def main():
         if world == 1 and args.gpus > 1:
             print("bench.py: launch with torch.distributed.run for --gpus > 1", file=sys.stderr)
             sys.exit(2)
+    backend = os.environ.get("BENCH_BACKEND", "nccl")      # "gloo": functional check of the multi-rank path with ranks sharing GPUs
+    if backend != "nccl":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     from colord_amd.device import Context
     from colord_amd.synth_device import make_reads_device
 
@@ -227,8 +233,9 @@ def main():
         info = hot_path_step(ctx, reads, args.k, **qargs)
     sync()
     dt = time.perf_counter() - t0
-    tdev = torch.tensor([dt], dtype=torch.float64, device=ctx.device)
-    tb = torch.tensor([local_bases], dtype=torch.int64, device=ctx.device)
+    red_dev = ctx.device if backend == "nccl" else torch.device("cpu")
+    tdev = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+    tb = torch.tensor([local_bases], dtype=torch.int64, device=red_dev)
     if world > 1:
         dist.all_reduce(tdev, op=dist.ReduceOp.MAX)
         dist.all_reduce(tb)

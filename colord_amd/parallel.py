@@ -21,6 +21,12 @@ def rank():
     return dist.get_rank() if dist.is_initialized() else 0
 
 
+def _host_staged() -> bool:
+    """gloo moves tensors through host memory: device tensors are staged explicitly (functional tests of the multi-rank
+    path on fewer GPUs than ranks use gloo; production is nccl = RCCL, device to device)."""
+    return dist.is_initialized() and dist.get_backend() == "gloo"
+
+
 def owner_of(kmers: torch.Tensor, w: int) -> torch.Tensor:
     """Key partition (any fixed function of the key works): k-mer mod a prime, mod world."""
     return kmers.remainder(1000003).remainder(w)
@@ -31,6 +37,9 @@ def exchange_kmers(kmers: torch.Tensor) -> torch.Tensor:
     w = world()
     if w == 1:
         return kmers
+    dev = kmers.device
+    if _host_staged():
+        kmers = kmers.cpu()
     dest = owner_of(kmers, w)
     order = torch.argsort(dest, stable=True)
     send = kmers[order].contiguous()
@@ -39,7 +48,7 @@ def exchange_kmers(kmers: torch.Tensor) -> torch.Tensor:
     dist.all_to_all_single(rcnt, scnt)
     recv = torch.empty(int(rcnt.sum().item()), dtype=kmers.dtype, device=kmers.device)
     dist.all_to_all_single(recv, send, rcnt.tolist(), scnt.tolist())
-    return recv
+    return recv.to(dev)
 
 
 def all_gather_v(t: torch.Tensor) -> list:
@@ -47,6 +56,9 @@ def all_gather_v(t: torch.Tensor) -> list:
     w = world()
     if w == 1:
         return [t]
+    dev = t.device
+    if _host_staged():
+        t = t.cpu()
     n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
     sizes = [torch.zeros_like(n) for _ in range(w)]
     dist.all_gather(sizes, n)
@@ -56,7 +68,7 @@ def all_gather_v(t: torch.Tensor) -> list:
     pad[:t.numel()] = t
     bufs = [torch.empty_like(pad) for _ in range(w)]
     dist.all_gather(bufs, pad)
-    return [b[:s] for b, s in zip(bufs, sizes)]
+    return [b[:s].to(dev) for b, s in zip(bufs, sizes)]
 
 
 def all_reduce_sum_ints(*vals):
