@@ -83,6 +83,16 @@ def hot_path_step(ctx, reads, k, quals=None, qual_off=None, part_bounds=None, es
     from colord_amd import parallel as par
     p = PRESET
     w, rank = par.world(), par.rank()
+    if w == 1 and quals is not None and not os.environ.get("BENCH_STAGE_TIMES"):
+        # single GPU: the whole path is one native call (cl_compress_shard, the C++ wiring of the stages)
+        prm = dict(k=k, f=p["f"], ci=p["ci"], cs=p["cs"], c=p["c"], anchor_len=p["a"], min_part_alt=p["min_part_alt"], max_rec=p["max_rec"], min_anchors=1,
+                   level=1, source=0, sparse=1, sparse_g=p["g"], sparse_exponent=p["exponent"], cost_mult=1.0, frac_always=0.9, frac_min=0.5, max_matches_mult=10.0)
+        qc = ctx.qual_coder(2, 0, 1, (7, 14, 26), ())
+        dc = ctx.dna_coder(p["c"], 1, 0)
+        dna, dsz, qual, qsz, inf = ctx.compress_shard(reads, prm, part_bounds, est_bounds, dc, qc, quals, qual_off)
+        qc.free(); dc.free()
+        return dict(tot_kmers=inf["tot_kmers"], kept=inf["n_kept_kmers"], refs=inf["n_refs"], anchors=inf["n_anchors"], tuple_bytes=inf["tuple_bytes"],
+                    dna_bytes=inf["dna_bytes"], qual_bytes=inf["qual_bytes"], qual_parts=len(qsz), sparse_range=inf["sparse_range"])
     stage_t = {} if os.environ.get("BENCH_STAGE_TIMES") else None
     t_last = [time.perf_counter()]
 

@@ -30,6 +30,19 @@ class KmerStats(C.Structure):
 
 
 _P = C.c_void_p
+class CompressParams(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("f", C.c_uint32), ("ci", C.c_uint32), ("cs", C.c_uint32), ("c", C.c_uint32),
+                ("anchor_len", C.c_uint32), ("min_part_alt", C.c_uint32), ("max_rec", C.c_uint32), ("min_anchors", C.c_uint32),
+                ("level", C.c_int32), ("source", C.c_int32), ("sparse", C.c_int32),
+                ("sparse_g", C.c_double), ("sparse_exponent", C.c_double),
+                ("cost_mult", C.c_double), ("frac_always", C.c_double), ("frac_min", C.c_double), ("max_matches_mult", C.c_double)]
+
+
+class CompressInfo(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n_reads", "n_bases", "tot_kmers", "n_kept_kmers", "n_refs", "n_anchors", "tuple_bytes", "dna_bytes", "qual_bytes")] + \
+               [("sparse_range", C.c_uint32), ("pad", C.c_uint32)]
+
+
 _SIG = {
     "cl_ctx_create": (C.c_int32, [C.c_int, C.POINTER(_P)]),
     "cl_ctx_destroy": (None, [_P]),
@@ -90,6 +103,8 @@ _SIG = {
     "cl_reads_select": (C.c_int32, [_P, _P, _P, C.POINTER(_P)]),
     "cl_reads_from_arena": (C.c_int32, [_P, _P, _P, _P, C.c_uint32, C.POINTER(_P)]),
     "cl_es_flags": (C.c_int32, [_P, _P, _P, _P, _P, _P]),
+    "cl_compress_shard": (C.c_int32, [_P, C.POINTER(CompressParams), _P, _P, _P, _P, C.c_uint32, _P, C.c_uint32, _P, _P, _P, C.c_uint64, _P, _P, C.c_uint64, _P,
+                                      C.POINTER(CompressInfo)]),
     "cl_encode_reads": (C.c_int32, [_P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, _P, C.c_uint32, _P, C.c_uint64, _P, _P, C.POINTER(C.c_uint64)]),
     "cl_dna_coder_create": (C.c_int32, [_P, C.c_uint32, C.c_int32, C.c_uint32, C.POINTER(_P)]),
     "cl_dna_coder_free": (None, [_P]),

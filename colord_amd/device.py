@@ -268,6 +268,31 @@ class Context:
                                           base_off.contiguous().data_ptr(), flags.data_ptr()))
         return flags[:int(reads.total_bases)]
 
+    # ---- the whole data path of one shard in one native call ----
+    def compress_shard(self, reads: "Reads", params: dict, part_bounds, pack_bounds, dna: "DnaCoder", qual: "QualCoder | None" = None,
+                       quals: torch.Tensor | None = None, base_off: torch.Tensor | None = None):
+        """cl_compress_shard: returns (dna payload, dna part sizes, qual payload or None, qual part sizes, info dict)."""
+        import numpy as np
+        P = N.CompressParams()
+        for k_, v in params.items():
+            setattr(P, k_, v)
+        pb = np.ascontiguousarray(np.asarray(part_bounds, dtype=np.uint32)); kb = np.ascontiguousarray(np.asarray(pack_bounds, dtype=np.uint32))
+        npart = len(pb) - 1
+        dcap = int(reads.total_bases) + 64 * npart + 4096
+        dout = torch.empty(dcap, dtype=torch.uint8, device=self.device)
+        dsz = np.zeros(max(npart, 1), np.uint64)
+        qout, qsz, qcap = None, np.zeros(max(npart, 1), np.uint64), 0
+        if qual is not None:
+            qcap = int(int(reads.total_bases) * 1.35) + 64 * npart + 4096
+            qout = torch.empty(qcap, dtype=torch.uint8, device=self.device)
+        info = N.CompressInfo()
+        _check(self, self.lib.cl_compress_shard(self.h, C.byref(P), reads.h, quals.data_ptr() if qual is not None else None,
+                                                base_off.contiguous().data_ptr() if qual is not None else None,
+                                                pb.ctypes.data, npart, kb.ctypes.data, len(kb) - 1, dna.h, qual.h if qual is not None else None,
+                                                dout.data_ptr(), dcap, dsz.ctypes.data, qout.data_ptr() if qout is not None else None, qcap, qsz.ctypes.data, C.byref(info)))
+        inf = {n_: getattr(info, n_) for n_, _ in N.CompressInfo._fields_ if n_ != "pad"}
+        return dout[:inf["dna_bytes"]], dsz[:npart], (qout[:inf["qual_bytes"]] if qout is not None else None), qsz[:npart], inf
+
     # ---- a14 ----
     def dna_coder(self, max_alt_refs: int, level: int, start_read_id: int = 0) -> "DnaCoder":
         h = N._P()

@@ -255,6 +255,30 @@ cl_status cl_reads_select(cl_ctx* ctx, const cl_reads* src, const uint8_t* d_kee
  * CReferenceReads is one process-wide store; with reads sharded over GPUs each rank replicates it). */
 cl_status cl_reads_from_arena(cl_ctx* ctx, const uint64_t* d_packed, const uint32_t* d_inv, const uint32_t* d_lens, uint32_t n_reads, cl_reads** out);
 
+/* ---- the whole compress data path of one shard: runCompression's stage wiring (compression.cpp:432-689) ---------- */
+typedef struct {
+	uint32_t k, f, ci, cs, c;                 /* kmerLen, filterHashModulo, minKmerCount, maxKmerCount, maxCandidates */
+	uint32_t anchor_len, min_part_alt, max_rec, min_anchors;   /* anchorLen, minPartLenToConsiderAltRead, maxRecurence, minAnchors */
+	int32_t level, source;                    /* compression level 1..3, DataSource (0 ONT, 1 PBRaw, 2 PBHiFi) */
+	int32_t sparse;                           /* referenceReadsMode == Sparse (else every N-free read is a reference read) */
+	double sparse_g, sparse_exponent;         /* sparseMode_range_symbols (in genome lengths), sparseMode_exponent */
+	double cost_mult, frac_always, frac_min, max_matches_mult;   /* editScriptCostMultiplier, minFractionOfMmersInEncode*, maxMatchesMultiplier */
+} cl_compress_params;
+typedef struct {
+	uint64_t n_reads, n_bases, tot_kmers, n_kept_kmers, n_refs, n_anchors, tuple_bytes, dna_bytes, qual_bytes;
+	uint32_t sparse_range, pad;
+} cl_compress_info;
+/* reads (+ ASCII qualities d_quals with per-read offsets d_base_off, or NULLs with qual == NULL) -> `dna` and `qual` stream
+ * parts.  h_part_bounds: the parts of both streams (read indices); h_pack_bounds: the reader packs (estimator reset).
+ * dna / qual: the long-lived coders (model state persists across calls, as one CEntrCompr* thread).  Outputs as for
+ * cl_dna_encode / cl_qual_encode.  Single GPU; with reads sharded over GPUs the caller runs the stages itself around the
+ * two exchanges (bench.py). */
+cl_status cl_compress_shard(cl_ctx* ctx, const cl_compress_params* params, const cl_reads* reads, const uint8_t* d_quals, const uint64_t* d_base_off,
+                            const uint32_t* h_part_bounds, uint32_t n_parts, const uint32_t* h_pack_bounds, uint32_t n_packs,
+                            cl_dna_coder* dna, cl_qual_coder* qual,
+                            uint8_t* d_dna_out, uint64_t dna_cap, uint64_t* h_dna_part_sizes,
+                            uint8_t* d_qual_out, uint64_t qual_cap, uint64_t* h_qual_part_sizes, cl_compress_info* info);
+
 /* ---- a7: CReferenceReads (reference_reads.h:27-259) ---------------------------------------------- */
 /* Byte image of one stored reference read (4 bases/byte MSB first + trailing count byte) produced from
  * the arena; h_out needs (len+3)/4+1 bytes.  Used by the parity tests and by the host archive code. */

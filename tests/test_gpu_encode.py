@@ -126,3 +126,50 @@ def test_select_reads_and_arena_concat(ctx):
     assert torch.equal(both.has_n(), torch.cat([sub.has_n(), reads.has_n()]))
     assert torch.equal(both.word_offsets()[sub.n_reads:], reads.word_offsets() + sub.total_words)
     both.free(); exp.free(); sub.free(); reads.free()
+
+
+def sparse_g(g):
+    """The preset's sparse range in genome lengths (-g; arg_parse.cpp presets use 1, 2, 4, ...): the value that yields the
+    range the reference stored (compression.cpp:501-503)."""
+    for v in (1.0, 2.0, 3.0, 4.0, 0.5, 1.5, 6.0, 8.0):
+        if max(1, int(v * g.p("n_unique") * g.p("f") / g.p("mean_read_len"))) == g.p("sparse_range"):
+            return v
+    return 1.0
+
+
+@pytest.mark.parametrize("cfg", ["c1_ont_default", "c2_hifi_org", "c3_clr_ratio", "s6m_ont", "s3m_ont_n_ratio", "s5m_hifi", "c7_hifi_balanced"])
+def test_compress_shard_one_call_equals_reference(ctx, cfg):
+    """cl_compress_shard — the C++ wiring of all stages (runCompression's data path) — from read bases and qualities to
+    the parts of both streams in one native call: sizes and SHA-256 of the unmodified reference's parts."""
+    import hashlib
+    g = golden(cfg)
+    rs = g.reads
+    min_alt, max_rec = PRESET_BY_LEVEL[g.p("level")]
+    prm = dict(k=g.p("k"), f=g.p("f"), ci=g.p("ci"), cs=g.p("cs"), c=g.p("c"), anchor_len=g.p("a"), min_part_alt=min_alt, max_rec=max_rec, min_anchors=1,
+               level=g.p("level"), source=g.p("source"), sparse=g.p("sparse"), sparse_g=sparse_g(g),
+               sparse_exponent=float(g.p("sparse_exp")), cost_mult=1.0, frac_always=0.9, frac_min=0.5, max_matches_mult=10.0)
+    reads = ctx.pack_readset(rs)
+    bounds = rs.pack_bounds()
+    dc = ctx.dna_coder(g.p("c"), g.p("level"), 0)
+    with_q = rs.quals is not None and len(rs.quals) > 0 and g.p("qual_mode") != 8
+    qc = None
+    if with_q:
+        d = O.QUAL_DEFAULTS[g.p("qual_mode")]
+        qc = ctx.qual_coder(g.p("qual_mode"), g.p("source"), g.p("level"), d[0], d[1])
+    dna, dsz, qual, qsz, info = ctx.compress_shard(reads, prm, bounds, bounds, dc, qc, torch.from_numpy(rs.quals).to(ctx.device) if with_q else None,
+                                                   torch.from_numpy(rs.offsets).to(ctx.device) if with_q else None)
+    if g.p("sparse"):
+        assert info["sparse_range"] == g.p("sparse_range")
+    assert info["n_refs"] == int((g.accept.astype(bool) & ~rs.has_n()).sum())
+
+    def parts(raw, sizes, meta):
+        raw, o, out = raw.cpu().numpy().tobytes(), 0, []
+        for i, s in enumerate(sizes):
+            out.append([meta(i), int(s), hashlib.sha256(raw[o:o + int(s)]).hexdigest()])
+            o += int(s)
+        return out
+    assert parts(dna, dsz, lambda i: int(bounds[i + 1] - bounds[i])) == g.spec["streams"]["dna"]["parts"]
+    if with_q:
+        assert parts(qual, qsz, lambda i: 0) == g.spec["streams"]["qual"]["parts"]
+        qc.free()
+    dc.free(); reads.free()
