@@ -177,6 +177,39 @@ CL_DEV inline void refactor_es(ES& es, uint32_t n, const RefAt& ref, const EncAt
 	fix_in_range(es, es_start, n);
 }
 
+// The same transformation in one forward stream per pass: a pass rewrites every maximal REGION — consecutive symbols that
+// are not a break (pass 1: insertion / substitution; pass 2: deletion / substitution) and step onto the same sequence
+// symbol as their predecessor — as its matches first, then its other symbols (pass 1: 'D'; pass 2: the inserted letter,
+// one and the same throughout a region).  One read per symbol, one write per region symbol, no swaps.  Equivalent to
+// refactor_es above (which the generic path keeps): tests/tools/encode_host_check.py runs both against the reference.
+template<class ES, class SeqAt>
+CL_DEV inline void refactor_stream_pass(ES& es, uint32_t n, const SeqAt& seq, bool pass1)
+{
+	uint32_t pos = 0, start = 0, a = 0, len = 0, prev = 0xffffffffu; bool in_region = false; char other = 'D';
+	for (uint32_t p = 0; p <= n; ++p)
+	{
+		const char c = p < n ? es.get(p) : 'X';                                     // a final break closes the last region
+		const bool mis = is_mismatch(c), ins = c == 'A' || c == 'C' || c == 'G' || c == 'T', del = c == 'D';
+		const bool brk = pass1 ? (ins || mis) : (del || mis);
+		uint32_t sym = 0xffffffffu;
+		if (!brk) sym = seq(pos);
+		if (in_region && (brk || sym != prev))
+		{
+			if (len > 1) for (uint32_t q = 0; q < len; ++q) es.set(start + q, q < a ? 'M' : other);
+			in_region = false;
+		}
+		if (brk) { if (pass1 ? !ins : !del) ++pos; continue; }
+		if (!in_region) { in_region = true; start = p; a = 0; len = 0; prev = sym; other = pass1 ? 'D' : base_letter(sym); }
+		a += c == 'M'; ++len; ++pos;
+	}
+}
+template<class ES, class RefAt, class EncAt>
+CL_DEV inline void refactor_stream(ES& es, uint32_t n, const RefAt& ref, const EncAt& enc)
+{
+	refactor_stream_pass(es, n, ref, true);
+	refactor_stream_pass(es, n, enc, false);
+}
+
 // ---- small gaps: rows <= 64*NB, columns <= 256; Myers' bit-vector recurrence held in registers ------------------
 // MEM provides the lane's staging memory: q(i)/t(j) sequence bytes in ALIGNMENT orientation, es get/set, and the
 // per-column history hist_put(j, b, P, Ph) / hist_get(j, b, P&, Ph&).  Traceback (edlib.cpp:1021-1147) prefers up
@@ -263,14 +296,14 @@ CL_DEV inline uint32_t align_small(MEM& mem, uint32_t n, uint32_t m, uint32_t ki
 		const uint32_t r_used = shw ? t_used : n, e_len = shw ? n : m;
 		auto ref = [&](uint32_t x) -> uint32_t { const uint32_t idx = r_used - 1 - x; return rows_ref ? mem.q(idx) : mem.t(idx); };
 		auto encf = [&](uint32_t x) -> uint32_t { const uint32_t idx = e_len - 1 - x; return rows_ref ? mem.t(idx) : mem.q(idx); };
-		refactor_es(es, k, ref, encf);
+		refactor_stream(es, k, ref, encf);
 		*d_before = ref_offset;
 	}
 	else
 	{
 		auto ref = [&](uint32_t x) -> uint32_t { return rows_ref ? mem.q(x) : mem.t(x); };
 		auto encf = [&](uint32_t x) -> uint32_t { return rows_ref ? mem.t(x) : mem.q(x); };
-		refactor_es(es, k, ref, encf);
+		refactor_stream(es, k, ref, encf);
 	}
 	return k;
 }
@@ -279,10 +312,12 @@ CL_DEV inline uint32_t align_small(MEM& mem, uint32_t n, uint32_t m, uint32_t ki
 // MEM additionally provides peq / peq_set (symbol, block), pv / mv get + set (block).  Same observable behaviour as
 // align_small (and as edlib below its 1 MiB traceback budget: 20 bytes * blocks * columns stays under it).
 constexpr uint32_t MID_CELLS = 16384, MID_ROWS = 16384, MID_COLS = 4096;
-template<class MEM>
+// NBR > 0: the vertical deltas of up to NBR blocks stay in registers (only the match masks and the history are memory).
+template<int NBR, class MEM>
 CL_DEV inline uint32_t align_mid(MEM& mem, uint32_t n, uint32_t m, uint32_t kind, bool left, uint32_t nr, uint32_t use, uint32_t* d_before)
 {
 	const uint32_t nb = (n + 63) / 64;
+	uint64_t rPv[NBR > 0 ? NBR : 1], rMv[NBR > 0 ? NBR : 1];
 	for (uint32_t b = 0; b < nb; ++b)
 	{
 		uint64_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
@@ -293,8 +328,14 @@ CL_DEV inline uint32_t align_mid(MEM& mem, uint32_t n, uint32_t m, uint32_t kind
 			e0 |= s == 0 ? bit : 0; e1 |= s == 1 ? bit : 0; e2 |= s == 2 ? bit : 0; e3 |= s == 3 ? bit : 0;
 		}
 		mem.peq_set(0, b, e0); mem.peq_set(1, b, e1); mem.peq_set(2, b, e2); mem.peq_set(3, b, e3);
-		mem.pv_set(b, ~0ull); mem.mv_set(b, 0);
+		if (NBR == 0) { mem.pv_set(b, ~0ull); mem.mv_set(b, 0); }
 	}
+	if (NBR > 0)
+	{
+#pragma unroll
+		for (int b = 0; b < (NBR > 0 ? NBR : 1); ++b) { rPv[b] = ~0ull; rMv[b] = 0; }
+	}
+	mem.lap(0);
 	const bool shw = kind == GK_FLANK;
 	const uint32_t lastbit = (n - 1) & 63;
 	uint32_t score = n, best = 0xffffffffu; int32_t end = (int32_t)m - 1;
@@ -303,6 +344,31 @@ CL_DEV inline uint32_t align_mid(MEM& mem, uint32_t n, uint32_t m, uint32_t kind
 	{
 		const uint32_t c = mem.t(j);
 		int hin = 1;
+		if (NBR > 0)
+		{
+#pragma unroll
+			for (int b = 0; b < (NBR > 0 ? NBR : 1); ++b)
+			{
+				if ((uint32_t)b >= nb) continue;
+				uint64_t Eq = mem.peq(c, b); const uint64_t Pv = rPv[b], Mv = rMv[b];
+				const uint64_t hneg = hin < 0 ? 1ull : 0ull;
+				const uint64_t Xv = Eq | Mv;
+				Eq |= hneg;
+				const uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+				uint64_t Ph = Mv | ~(Xh | Pv);
+				uint64_t Mh = Pv & Xh;
+				if ((uint32_t)b == nb - 1) score += (uint32_t)((Ph >> lastbit) & 1) - (uint32_t)((Mh >> lastbit) & 1);
+				const uint64_t ph_rows = Ph;
+				const int hout = (int)(Ph >> 63) - (int)(Mh >> 63);
+				Ph <<= 1; Mh <<= 1;
+				Mh |= hneg; Ph |= hin > 0 ? 1ull : 0ull;
+				const uint64_t Pn = Mh | ~(Xv | Ph);
+				rPv[b] = Pn; rMv[b] = Ph & Xv;
+				mem.hist_put(j, b, Pn, ph_rows);
+				hin = hout;
+			}
+		}
+		else
 		for (uint32_t b = 0; b < nb; ++b)
 		{
 			uint64_t Eq = mem.peq(c, b); const uint64_t Pv = mem.pv(b), Mv = mem.mv(b);
@@ -324,6 +390,7 @@ CL_DEV inline uint32_t align_mid(MEM& mem, uint32_t n, uint32_t m, uint32_t kind
 		}
 		if (shw && score < best) { best = score; end = (int32_t)j; }
 	}
+	mem.lap(1);
 	uint32_t i = n, j = shw ? (uint32_t)(end + 1) : m, k = 0;
 	const uint32_t t_used = j;
 	uint64_t P = 0, Ph = 0; uint32_t cj = 0xffffffffu, cb = 0xffffffffu;
@@ -342,6 +409,7 @@ CL_DEV inline uint32_t align_mid(MEM& mem, uint32_t n, uint32_t m, uint32_t kind
 	while (i > 0) { --i; mem.es_set(k++, shw ? base_letter(mem.q(i)) : 'D'); }
 	while (j > 0) { --j; mem.es_set(k++, shw ? 'D' : base_letter(mem.t(j))); }
 	if (!left) for (uint32_t a = 0, z = k; a + 1 < z; ++a) { --z; const char t = mem.es_get(a); mem.es_set(a, mem.es_get(z)); mem.es_set(z, t); }
+	mem.lap(2);
 	*d_before = 0;
 	struct ES { MEM& m; CL_DEV char get(uint32_t p) const { return m.es_get(p); } CL_DEV void set(uint32_t p, char c) { m.es_set(p, c); } } es{ mem };
 	const bool rows_ref = !shw;
@@ -352,15 +420,16 @@ CL_DEV inline uint32_t align_mid(MEM& mem, uint32_t n, uint32_t m, uint32_t kind
 		const uint32_t r_used = shw ? t_used : n, e_len = shw ? n : m;
 		auto ref = [&](uint32_t x) -> uint32_t { const uint32_t idx = r_used - 1 - x; return rows_ref ? mem.q(idx) : mem.t(idx); };
 		auto encf = [&](uint32_t x) -> uint32_t { const uint32_t idx = e_len - 1 - x; return rows_ref ? mem.t(idx) : mem.q(idx); };
-		refactor_es(es, k, ref, encf);
+		refactor_stream(es, k, ref, encf);
 		*d_before = ref_offset;
 	}
 	else
 	{
 		auto ref = [&](uint32_t x) -> uint32_t { return rows_ref ? mem.q(x) : mem.t(x); };
 		auto encf = [&](uint32_t x) -> uint32_t { return rows_ref ? mem.t(x) : mem.q(x); };
-		refactor_es(es, k, ref, encf);
+		refactor_stream(es, k, ref, encf);
 	}
+	mem.lap(3);
 	return k;
 }
 

@@ -115,6 +115,7 @@ struct LdsMem {
 	__device__ inline char es_get(uint32_t k) const { return (char)base[addr(QW + TW, k)]; }
 	__device__ inline void es_set(uint32_t k, char c) { base[addr(QW + TW, k)] = (uint8_t)c; }
 	__device__ inline uint32_t es_word(uint32_t w) const { return ((const uint32_t*)base)[(QW + TW + w) * 64 + lane]; }
+	__device__ inline void lap(uint32_t) {}
 	__device__ inline void hist_put(uint32_t j, uint32_t b, uint64_t P, uint64_t Ph) { uint64_t* h = hist + ((uint64_t)(j * NB + b) * 2) * 64 + lane; h[0] = P; h[64] = Ph; }
 	__device__ inline void hist_get(uint32_t j, uint32_t b, uint64_t& P, uint64_t& Ph) const { const uint64_t* h = hist + ((uint64_t)(j * NB + b) * 2) * 64 + lane; P = h[0]; Ph = h[64]; }
 };
@@ -147,6 +148,8 @@ struct HbmMem {
 	static constexpr uint64_t HIST_W = 2ull * MID_CELLS, PEQ_W = 4ull * 256, ST_W = 256, Q_W = MID_ROWS / 8, T_W = MID_COLS / 8, ES_W = (MID_ROWS + MID_COLS) / 8;   // 64-bit words per lane
 	static constexpr uint64_t WORDS = HIST_W + PEQ_W + 2 * ST_W + Q_W + T_W + ES_W;
 	uint64_t* base; uint32_t lane, nb;
+	unsigned long long* prof = nullptr; uint64_t t_last = 0;                 // optional phase clocks (debugging)
+	__device__ inline void lap(uint32_t ph) { if (prof) { const uint64_t now = wall_clock64(); if (lane == 0) atomicAdd(prof + ph, (unsigned long long)(now - t_last)); t_last = now; } }
 	__device__ inline uint64_t* w(uint64_t region, uint64_t e) const { return base + (region + e) * 64 + lane; }
 	__device__ inline uint8_t* byte(uint64_t region, uint32_t b) const { return (uint8_t*)(base + (region + (b >> 3)) * 64 + lane) + (b & 7); }
 	__device__ inline void hist_put(uint32_t j, uint32_t b, uint64_t P, uint64_t Ph) { const uint64_t e = ((uint64_t)j * nb + b) * 2; *w(0, e) = P; *w(0, e + 1) = Ph; }
@@ -165,9 +168,10 @@ struct HbmMem {
 	__device__ inline void es_set(uint32_t k, char c) { *byte(HIST_W + PEQ_W + 2 * ST_W + Q_W + T_W, k) = (uint8_t)c; }
 	__device__ inline uint32_t es_word(uint32_t wi) const { return ((const uint32_t*)w(HIST_W + PEQ_W + 2 * ST_W + Q_W + T_W, wi >> 1))[wi & 1]; }
 };
-__global__ __launch_bounds__(64) void k_align_mid(const uint32_t* __restrict__ list, uint32_t n_list, GapRec* __restrict__ gaps, char* __restrict__ es_pool, ArenaV A, ArenaV R, uint64_t* __restrict__ scratch)
+__global__ __launch_bounds__(64) void k_align_mid(const uint32_t* __restrict__ list, uint32_t n_list, GapRec* __restrict__ gaps, char* __restrict__ es_pool, ArenaV A, ArenaV R, uint64_t* __restrict__ scratch, unsigned long long* prof)
 {
 	HbmMem mem{ scratch + (uint64_t)blockIdx.x * HbmMem::WORDS * 64, threadIdx.x, 0 };
+	mem.prof = prof; if (prof) mem.t_last = wall_clock64();
 	for (uint32_t chunk = blockIdx.x; (uint64_t)chunk * 64 < n_list; chunk += gridDim.x)
 	{
 		const uint32_t idx = chunk * 64 + threadIdx.x;
@@ -175,10 +179,14 @@ __global__ __launch_bounds__(64) void k_align_mid(const uint32_t* __restrict__ l
 		const uint32_t gi = list[idx];
 		const GapRec g = gaps[gi];
 		uint32_t n, m;
+		mem.lap(5);
 		stage_small(mem, g, A, R, n, m);
+		mem.lap(4);
 		mem.nb = (n + 63) / 64;
 		uint32_t d_before;
-		const uint32_t k = align_mid(mem, n, m, g.kind, g.left != 0, g.nr, g.use, &d_before);
+		const uint32_t k = mem.nb <= 8 ? align_mid<8>(mem, n, m, g.kind, g.left != 0, g.nr, g.use, &d_before)
+		                 : mem.nb <= 16 ? align_mid<16>(mem, n, m, g.kind, g.left != 0, g.nr, g.use, &d_before)
+		                 : align_mid<0>(mem, n, m, g.kind, g.left != 0, g.nr, g.use, &d_before);
 		uint32_t* dst = (uint32_t*)(es_pool + g.es_off);
 		for (uint32_t wi = 0; wi * 4 < k; ++wi) dst[wi] = mem.es_word(wi);
 		gaps[gi].es_len = k; gaps[gi].d_before = d_before;
@@ -679,7 +687,17 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 			const uint32_t n_list = hb[6] - hb[5];
 			const uint32_t blocks = std::min<uint32_t>(grid_for(n_list, 64), n_cu * 8);
 			DevBuf<uint64_t> scratch; DEV_ALLOC(ctx, scratch, (uint64_t)blocks * HbmMem::WORDS * 64);
-			LAUNCHB(ctx, 1.25 * (double)h_cb[5], k_align_mid, blocks, 64, (const uint32_t*)ids.p + hb[5], n_list, L.gaps.p, L.es.p, A, R, scratch.p);
+			DevBuf<unsigned long long> mprof;
+			if (getenv("COLORD_HIP_WAVE_PROFILE")) { DEV_ALLOC(ctx, mprof, 8); HIP_TRY(ctx, hipMemsetAsync(mprof.p, 0, 64, st)); }
+			LAUNCHB(ctx, 1.25 * (double)h_cb[5], k_align_mid, blocks, 64, (const uint32_t*)ids.p + hb[5], n_list, L.gaps.p, L.es.p, A, R, scratch.p, mprof.p);
+			if (mprof.p)
+			{
+				unsigned long long hp[8];
+				HIP_TRY(ctx, hipStreamSynchronize(st));
+				HIP_TRY(ctx, hipMemcpy(hp, mprof.p, 64, hipMemcpyDeviceToHost));
+				fprintf(stderr, "[mid phases, level %u, %u gaps, M ticks of 100 MHz] stage %llu peq %llu forward %llu traceback %llu refactor %llu tail %llu\n", lv, n_list,
+					hp[4] / 1000000, hp[0] / 1000000, hp[1] / 1000000, hp[2] / 1000000, hp[3] / 1000000, hp[5] / 1000000);
+			}
 			HIP_TRY(ctx, hipGetLastError());
 			HIP_TRY(ctx, hipStreamSynchronize(st));
 		}

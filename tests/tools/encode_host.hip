@@ -15,6 +15,7 @@ using namespace enc;
 struct HostMem {
 	uint8_t qb[MID_ROWS], tb[MID_COLS]; char esb[MID_ROWS + MID_COLS]; std::vector<uint64_t> hist; uint32_t nb;
 	uint64_t peq_[4][256], pv_[256], mv_[256];
+	void lap(uint32_t) {}
 	uint64_t peq(uint32_t s, uint32_t b) const { return peq_[s][b]; } void peq_set(uint32_t s, uint32_t b, uint64_t v) { peq_[s][b] = v; }
 	uint64_t pv(uint32_t b) const { return pv_[b]; } uint64_t mv(uint32_t b) const { return mv_[b]; } void pv_set(uint32_t b, uint64_t v) { pv_[b] = v; } void mv_set(uint32_t b, uint64_t v) { mv_[b] = v; }
 	uint32_t q(uint32_t i) const { return qb[i]; } uint32_t t(uint32_t j) const { return tb[j]; }
@@ -82,7 +83,9 @@ extern "C" int dbg_encode(const uint64_t* r_packed, const uint64_t* r_woff, cons
 				uint32_t n, mm, d_before;
 				stage_small(hm, g, A, R, n, mm);
 				hm.nb = (n + 63) / 64; hm.hist.assign(2ull * hm.nb * mm + 2, 0);
-				const uint32_t k = align_mid(hm, n, mm, g.kind, g.left != 0, g.nr, g.use, &d_before);
+				const uint32_t k = hm.nb <= 8 ? align_mid<8>(hm, n, mm, g.kind, g.left != 0, g.nr, g.use, &d_before)
+				                 : hm.nb <= 16 ? align_mid<16>(hm, n, mm, g.kind, g.left != 0, g.nr, g.use, &d_before)
+				                 : align_mid<0>(hm, n, mm, g.kind, g.left != 0, g.nr, g.use, &d_before);
 				memcpy(L.es.data() + g.es_off, hm.esb, k);
 				g.es_len = k; g.d_before = d_before;
 			}
