@@ -160,20 +160,30 @@ struct HbmMem {
 	__device__ inline uint64_t mv(uint32_t b) const { return *w(HIST_W + PEQ_W + ST_W, b); }
 	__device__ inline void pv_set(uint32_t b, uint64_t v) { *w(HIST_W + PEQ_W, b) = v; }
 	__device__ inline void mv_set(uint32_t b, uint64_t v) { *w(HIST_W + PEQ_W + ST_W, b) = v; }
-	__device__ inline uint32_t q(uint32_t i) const { return *byte(HIST_W + PEQ_W + 2 * ST_W, i); }
-	__device__ inline uint32_t t(uint32_t j) const { return *byte(HIST_W + PEQ_W + 2 * ST_W + Q_W, j); }
-	__device__ inline void q_set(uint32_t i, uint32_t v) { *byte(HIST_W + PEQ_W + 2 * ST_W, i) = (uint8_t)v; }
-	__device__ inline void t_set(uint32_t j, uint32_t v) { *byte(HIST_W + PEQ_W + 2 * ST_W + Q_W, j) = (uint8_t)v; }
-	__device__ inline char es_get(uint32_t k) const { return (char)*byte(HIST_W + PEQ_W + 2 * ST_W + Q_W + T_W, k); }
-	__device__ inline void es_set(uint32_t k, char c) { *byte(HIST_W + PEQ_W + 2 * ST_W + Q_W + T_W, k) = (uint8_t)c; }
+	// byte arrays are read through one cached 8-byte word each: the walks over them are sequential, and a byte load per
+	// symbol is a full memory round trip
+	static constexpr uint64_t QR = HIST_W + PEQ_W + 2 * ST_W, TR = QR + Q_W, ER = TR + T_W;
+	uint64_t cq = 0, ct = 0, ce = 0; uint32_t iq = 0xffffffffu, it = 0xffffffffu, ie = 0xffffffffu;
+	__device__ inline uint32_t q(uint32_t i) { if ((i >> 3) != iq) { iq = i >> 3; cq = *w(QR, iq); } return (uint32_t)(cq >> (8 * (i & 7))) & 0xffu; }
+	__device__ inline uint32_t t(uint32_t j) { if ((j >> 3) != it) { it = j >> 3; ct = *w(TR, it); } return (uint32_t)(ct >> (8 * (j & 7))) & 0xffu; }
+	__device__ inline void q_set(uint32_t i, uint32_t v) { *byte(QR, i) = (uint8_t)v; iq = 0xffffffffu; }
+	__device__ inline void t_set(uint32_t j, uint32_t v) { *byte(TR, j) = (uint8_t)v; it = 0xffffffffu; }
+	__device__ inline char es_get(uint32_t k) { if ((k >> 3) != ie) { ie = k >> 3; ce = *w(ER, ie); } return (char)((ce >> (8 * (k & 7))) & 0xff); }
+	__device__ inline void es_set(uint32_t k, char c)
+	{
+		*byte(ER, k) = (uint8_t)c;
+		if ((k >> 3) == ie) ce = (ce & ~(0xffull << (8 * (k & 7)))) | ((uint64_t)(uint8_t)c << (8 * (k & 7)));
+	}
 	__device__ inline uint32_t es_word(uint32_t wi) const { return ((const uint32_t*)w(HIST_W + PEQ_W + 2 * ST_W + Q_W + T_W, wi >> 1))[wi & 1]; }
 };
 __global__ __launch_bounds__(64) void k_align_mid(const uint32_t* __restrict__ list, uint32_t n_list, GapRec* __restrict__ gaps, char* __restrict__ es_pool, ArenaV A, ArenaV R, uint64_t* __restrict__ scratch, unsigned long long* prof)
 {
 	HbmMem mem{ scratch + (uint64_t)blockIdx.x * HbmMem::WORDS * 64, threadIdx.x, 0 };
 	mem.prof = prof; if (prof) mem.t_last = wall_clock64();
-	for (uint32_t chunk = blockIdx.x; (uint64_t)chunk * 64 < n_list; chunk += gridDim.x)
-	{
+	const uint32_t n_chunks = (n_list + 63) / 64;
+	for (uint32_t ci = blockIdx.x; ci < n_chunks; ci += gridDim.x)
+	{	// the list is ascending in size: largest chunks first, so that the small ones fill the tail
+		const uint32_t chunk = n_chunks - 1 - ci;
 		const uint32_t idx = chunk * 64 + threadIdx.x;
 		if (idx >= n_list) continue;
 		const uint32_t gi = list[idx];
