@@ -89,6 +89,7 @@ _SIG = {
     "cl_candidates": (C.c_int32, [_P, _P, _P, C.c_uint32, _P, _P, _P]),
     "cl_candidates_common": (C.c_int32, [_P, _P, _P, C.c_uint32, _P, _P, _P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "cl_qual_coder_create": (C.c_int32, [_P, C.POINTER(QualParams), C.POINTER(_P)]),
+    "cl_qual_coder_ctx": (_P, [_P]),
     "cl_qual_coder_free": (None, [_P]),
     "cl_qual_encode": (C.c_int32, [_P, _P, _P, _P, _P, _P, _P, C.c_uint32, _P, C.c_uint64, _P, C.POINTER(C.c_uint64)]),
     "cl_anchor_candidates": (C.c_int32, [_P, _P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_double, C.c_double, C.c_double, C.c_uint32, C.POINTER(_P)]),

@@ -6,6 +6,7 @@
 #include "objects.hpp"
 #include <vector>
 #include <memory>
+#include <thread>
 
 namespace {
 __global__ void k_accept_flags(const uint8_t* __restrict__ acc, const uint8_t* __restrict__ has_n, uint32_t n, uint8_t* __restrict__ out)
@@ -32,6 +33,15 @@ extern "C" cl_status cl_compress_shard(cl_ctx* ctx, const cl_compress_params* P,
 	info->n_reads = n; info->n_bases = reads->total_bases;
 	if (!n) return CL_OK;
 	hipStream_t st = ctx->stream;
+	// The quality stream of level 1 does not depend on the edit scripts: when its coder lives on a second context of the
+	// same GPU (own stream, own pool) it is coded concurrently with the whole DNA path — both are latency-bound chains
+	// that leave most of the machine idle on their own.
+	struct Joiner { std::thread t; ~Joiner() { if (t.joinable()) t.join(); } } qjob;
+	cl_status qstatus = CL_OK;
+	cl_ctx* qctx = qual ? cl_qual_coder_ctx(qual) : nullptr;
+	const bool overlap = qual && P->level <= 1 && qctx && qctx != ctx;
+	if (overlap)
+		qjob.t = std::thread([&]() { qstatus = cl_qual_encode(qctx, qual, reads, d_quals, d_base_off, nullptr, h_part_bounds, n_parts, d_qual_out, qual_cap, h_qual_part_sizes, &info->qual_bytes); });
 	// a1 + a2 + a3: k-mer scan, exact count / threshold, membership set (compression.cpp:432-464)
 	Handle<cl_kmer_set, cl_kmer_set_free> kset; cl_kmer_stats ks{};
 	{
@@ -101,7 +111,12 @@ extern "C" cl_status cl_compress_shard(cl_ctx* ctx, const cl_compress_params* P,
 	info->tuple_bytes = es_bytes;
 	// a14 + a16: DNA stream; a13 + a15: quality stream (levels 2 and 3 take the per-base classes of the scripts)
 	CL_TRY(cl_dna_encode(ctx, dna, refs, es.p, es_off.p, es_nt.p, n, h_part_bounds, n_parts, d_dna_out, dna_cap, h_dna_part_sizes, &info->dna_bytes));
-	if (qual)
+	if (overlap)
+	{
+		qjob.t.join();
+		if (qstatus != CL_OK) return cl_fail(ctx, qstatus, std::string("quality stream: ") + cl_last_error(qctx));
+	}
+	else if (qual)
 	{
 		DevBuf<uint8_t> flags;
 		if (P->level > 1)

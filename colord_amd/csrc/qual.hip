@@ -386,6 +386,7 @@ extern "C" cl_status cl_qual_coder_create(cl_ctx* ctx, const cl_qual_params* prm
 	*out = guard.release();
 	return CL_OK;
 }
+extern "C" cl_ctx* cl_qual_coder_ctx(const cl_qual_coder* q) { return q ? q->ctx : nullptr; }
 extern "C" void cl_qual_coder_free(cl_qual_coder* q) { delete q; }
 
 // CEntrComprQuals::Compress for a batch of whole parts (entr_qual.h:100-135).  Models persist across calls.

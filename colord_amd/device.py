@@ -290,6 +290,8 @@ class Context:
                                                 base_off.contiguous().data_ptr() if qual is not None else None,
                                                 pb.ctypes.data, npart, kb.ctypes.data, len(kb) - 1, dna.h, qual.h if qual is not None else None,
                                                 dout.data_ptr(), dcap, dsz.ctypes.data, qout.data_ptr() if qout is not None else None, qcap, qsz.ctypes.data, C.byref(info)))
+        if qual is not None and qual.ctx is not self:
+            _check(qual.ctx, N.CL_OK)                       # collect the kernel times of the concurrent quality stream
         inf = {n_: getattr(info, n_) for n_, _ in N.CompressInfo._fields_ if n_ != "pad"}
         return dout[:inf["dna_bytes"]], dsz[:npart], (qout[:inf["qual_bytes"]] if qout is not None else None), qsz[:npart], inf
 

@@ -170,6 +170,7 @@ typedef struct {
 /* CQualityCoder::Init(true, ...): one adaptive model set that persists across cl_qual_encode calls. */
 cl_status cl_qual_coder_create(cl_ctx* ctx, const cl_qual_params* params, cl_qual_coder** out);
 void cl_qual_coder_free(cl_qual_coder* q);
+cl_ctx* cl_qual_coder_ctx(const cl_qual_coder* q);          /* the context the coder was created on */
 /* CEntrComprQuals::Compress for a batch of whole parts.  Reads [h_part_bounds[p], h_part_bounds[p+1]) of the
  * arena form part p (the reference cuts parts where sum(len+1) >= 4 Mi, in_reads.cpp:62-77; any cut at read
  * boundaries yields a valid archive).  d_quals: ASCII quality bytes, d_qual_off: n_reads+1 offsets into it
@@ -271,7 +272,8 @@ typedef struct {
 /* reads (+ ASCII qualities d_quals with per-read offsets d_base_off, or NULLs with qual == NULL) -> `dna` and `qual` stream
  * parts.  h_part_bounds: the parts of both streams (read indices); h_pack_bounds: the reader packs (estimator reset).
  * dna / qual: the long-lived coders (model state persists across calls, as one CEntrCompr* thread).  Outputs as for
- * cl_dna_encode / cl_qual_encode.  Single GPU; with reads sharded over GPUs the caller runs the stages itself around the
+ * cl_dna_encode / cl_qual_encode.  If `qual` was created on a second context of the same GPU and level == 1 (no
+ * dependence on the edit scripts) the quality stream is coded concurrently with the DNA path.  Single GPU; with reads sharded over GPUs the caller runs the stages itself around the
  * two exchanges (bench.py). */
 cl_status cl_compress_shard(cl_ctx* ctx, const cl_compress_params* params, const cl_reads* reads, const uint8_t* d_quals, const uint64_t* d_base_off,
                             const uint32_t* h_part_bounds, uint32_t n_parts, const uint32_t* h_pack_bounds, uint32_t n_packs,

@@ -153,9 +153,13 @@ def test_compress_shard_one_call_equals_reference(ctx, cfg):
     dc = ctx.dna_coder(g.p("c"), g.p("level"), 0)
     with_q = rs.quals is not None and len(rs.quals) > 0 and g.p("qual_mode") != 8
     qc = None
+    ctx2 = None
     if with_q:
         d = O.QUAL_DEFAULTS[g.p("qual_mode")]
-        qc = ctx.qual_coder(g.p("qual_mode"), g.p("source"), g.p("level"), d[0], d[1])
+        if g.p("level") == 1:                              # a coder on a second context: the quality stream runs concurrently
+            from colord_amd.device import Context
+            ctx2 = Context(0)
+        qc = (ctx2 or ctx).qual_coder(g.p("qual_mode"), g.p("source"), g.p("level"), d[0], d[1])
     dna, dsz, qual, qsz, info = ctx.compress_shard(reads, prm, bounds, bounds, dc, qc, torch.from_numpy(rs.quals).to(ctx.device) if with_q else None,
                                                    torch.from_numpy(rs.offsets).to(ctx.device) if with_q else None)
     if g.p("sparse"):
@@ -172,4 +176,6 @@ def test_compress_shard_one_call_equals_reference(ctx, cfg):
     if with_q:
         assert parts(qual, qsz, lambda i: 0) == g.spec["streams"]["qual"]["parts"]
         qc.free()
+    if ctx2 is not None:
+        ctx2.close()
     dc.free(); reads.free()
