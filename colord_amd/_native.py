@@ -104,6 +104,10 @@ _SIG = {
     "cl_reads_select": (C.c_int32, [_P, _P, _P, C.POINTER(_P)]),
     "cl_reads_from_arena": (C.c_int32, [_P, _P, _P, _P, C.c_uint32, C.POINTER(_P)]),
     "cl_es_flags": (C.c_int32, [_P, _P, _P, _P, _P, _P]),
+    "cl_id_coder_create": (C.c_int32, [C.c_int32, C.POINTER(_P)]),
+    "cl_id_coder_free": (None, [_P]),
+    "cl_id_coder_error": (C.c_char_p, [_P]),
+    "cl_id_encode_part": (C.c_int32, [_P, _P, _P, _P, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "cl_compress_shard": (C.c_int32, [_P, C.POINTER(CompressParams), _P, _P, _P, _P, C.c_uint32, _P, C.c_uint32, _P, _P, _P, C.c_uint64, _P, _P, C.c_uint64, _P,
                                       C.POINTER(CompressInfo)]),
     "cl_encode_reads": (C.c_int32, [_P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, _P, C.c_uint32, _P, C.c_uint64, _P, _P, C.POINTER(C.c_uint64)]),

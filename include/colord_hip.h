@@ -256,6 +256,19 @@ cl_status cl_reads_select(cl_ctx* ctx, const cl_reads* src, const uint8_t* d_kee
  * CReferenceReads is one process-wide store; with reads sharded over GPUs each rank replicates it). */
 cl_status cl_reads_from_arena(cl_ctx* ctx, const uint64_t* d_packed, const uint32_t* d_inv, const uint32_t* d_lens, uint32_t n_reads, cl_reads** out);
 
+/* ---- the `header` stream: CIDCoder + CEntrComprHeaders (id_coder.{h,cpp}, entr_header.cpp:23-45) — HOST functions --- */
+typedef struct cl_id_coder cl_id_coder;
+/* header_mode = HeaderComprMode (params.h:44): 0 Original (lossless), 1 Main, 2 None (the latter two code no id bytes,
+ * as in the reference).  One coder per archive: models and the previous id persist from part to part. */
+cl_status cl_id_coder_create(int32_t header_mode, cl_id_coder** out);
+void cl_id_coder_free(cl_id_coder* c);
+const char* cl_id_coder_error(const cl_id_coder* c);
+/* One pack of headers -> one part (archive metadata = n).  h_ids: the ids back to back without the leading '@' / '>',
+ * h_off: n+1 offsets, h_plus[i] != 0 when the '+' line of record i repeats the id.  The reference closes a pack when the
+ * id bytes reach 4 Mi (in_reads.cpp:50-56,93-101).  cap >= 2 * id bytes + 64. */
+cl_status cl_id_encode_part(cl_id_coder* c, const uint8_t* h_ids, const uint64_t* h_off, const uint8_t* h_plus, uint32_t n,
+                            uint8_t* h_out, uint64_t cap, uint64_t* n_out);
+
 /* ---- the whole compress data path of one shard: runCompression's stage wiring (compression.cpp:432-689) ---------- */
 typedef struct {
 	uint32_t k, f, ci, cs, c;                 /* kmerLen, filterHashModulo, minKmerCount, maxKmerCount, maxCandidates */
