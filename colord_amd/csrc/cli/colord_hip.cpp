@@ -254,7 +254,7 @@ int main(int argc, char** argv)
 	fprintf(stderr, "colord_hip: %u reads, %llu bases, k=%u a=%u; dna %llu B, qual %llu B, header %zu parts; %llu reference reads; %.2f s\n", n, (unsigned long long)total, k, a,
 		(unsigned long long)info.dna_bytes, (unsigned long long)info.qual_bytes, hdr_parts.size(), (unsigned long long)info.n_refs, sec);
 	cl_qual_coder_free(qual); cl_dna_coder_free(dna); cl_reads_free(reads);
-	hipFree(d_off); hipFree(d_quals); hipFree(d_dna); hipFree(d_qual);
+	(void)hipFree(d_off); (void)hipFree(d_quals); (void)hipFree(d_dna); (void)hipFree(d_qual);
 	cl_ctx_destroy(qctx); cl_ctx_destroy(ctx);
 	return 0;
 }

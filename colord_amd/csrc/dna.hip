@@ -71,7 +71,8 @@ struct Emitter {
 		if (write)
 		{
 			key[off + count] = ((uint64_t)(ft->ctx_base[fam] + ctx) << 16) | ((uint64_t)(e1 & 15) << 12) | ((uint64_t)(e2 & 15) << 8) | sym;
-			sidx[off + count] = (uint32_t)(tbase + (off + count) * 64);          // = trip_index(lay, part, off + count), part constants hoisted
+			// the triple index of symbol i, trip_index(lay, part, i), is a function of i alone within a read: k_fill_sidx writes
+			// them coalesced instead of one scattered 4-byte store per symbol here
 		}
 		++count;
 	}
@@ -351,6 +352,18 @@ __global__ void k_read_flags(const uint8_t* __restrict__ es, const uint64_t* __r
 	flag[r - r0] = t == T_START_PLAIN ? 0 : t == T_START_PLAIN_N ? 1 : 2;
 }
 
+// triple slot of every symbol: one wave per read (all symbols of a read are in one part)
+__global__ __launch_bounds__(256) void k_fill_sidx(const uint64_t* __restrict__ sym_off, uint32_t r0, uint32_t r1, TripLayoutDev lay, uint32_t* __restrict__ sidx)
+{
+	const uint32_t r = r0 + blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (r >= r1) return;
+	const uint32_t lane = threadIdx.x & 63;
+	const uint64_t a = sym_off[r - r0], b = sym_off[r - r0 + 1];
+	if (a == b) return;
+	const uint32_t part = part_of_read(lay, r);
+	const uint64_t tbase = lay.group_base[part >> 6] - lay.part_sym_start[part] * 64 + (part & 63);
+	for (uint64_t i = a + lane; i < b; i += 64) sidx[i] = (uint32_t)(tbase + i * 64);
+}
 // ---- D1b: bases of plain reads, one wave per read, one lane per base (dna_coder.cpp:1178-1227) ----------
 __global__ __launch_bounds__(256) void k_dna_plain(const FamTab* __restrict__ ftp, const uint8_t* __restrict__ es, const uint64_t* __restrict__ es_off,
                                                   const uint32_t* __restrict__ es_ntup, const uint8_t* __restrict__ read_flag, const uint32_t* __restrict__ hdr_counts,
@@ -366,7 +379,6 @@ __global__ __launch_bounds__(256) void k_dna_plain(const FamTab* __restrict__ ft
 	const uint8_t* b = es + es_off[r] + 1;                    // one byte per base after the start tuple (low nibble = base)
 	const uint32_t len = es_ntup[r] - 1;
 	const uint64_t off = sym_off[r - r0] + hdr_counts[r - r0];
-	const uint32_t part = part_of_read(lay, r);
 	const uint32_t S2 = 2 * ft.S; const uint32_t mask = (1u << S2) - 1;
 	const uint32_t fam = fl == 0 ? F_SYMBOLS : F_SYMBOLS_N;
 	const uint32_t cbase = ft.ctx_base[fam];
@@ -385,7 +397,6 @@ __global__ __launch_bounds__(256) void k_dna_plain(const FamTab* __restrict__ ft
 			for (uint32_t t = n; t >= 1; --t) ctx = ((ctx << 4) + (b[i - t] & 0xfu)) & mask;
 		}
 		key[off + i] = ((uint64_t)(cbase + ctx) << 16) | (15u << 12) | (15u << 8) | (b[i] & 0xfu);
-		sidx[off + i] = trip_index(lay, part, off + i);
 	}
 }
 
@@ -899,6 +910,7 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 			DevBuf<uint64_t> key; DevBuf<uint32_t> sidx; DEV_ALLOC(ctx, key, n_syms); DEV_ALLOC(ctx, sidx, n_syms);
 			LAUNCHB(ctx, n_syms * 13.0, (k_dna_walk<true>), grid_for(nr, WALK_LPW), 64, /* tuple bytes in (<= 1 per symbol), 8 + 4 bytes per symbol out */ (const FamTab*)D->d_ft.p, R, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, r0, r1,
 				D->prev_types, D->cur_read_id, lay, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint64_t*)sym_off.p, key.p, sidx.p, err.p);
+			LAUNCHB(ctx, n_syms * 4.0, k_fill_sidx, grid_for(nr, 4), 256, (const uint64_t*)sym_off.p, r0, r1, lay, sidx.p);
 			LAUNCH(ctx, k_dna_plain, grid_for(nr, 4), 256, (const FamTab*)D->d_ft.p, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, (const uint32_t*)hdr.p,
 				(const uint64_t*)sym_off.p, r0, r1, lay, key.p, sidx.p);
 			HIP_TRY(ctx, hipGetLastError());
