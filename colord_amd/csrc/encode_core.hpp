@@ -311,7 +311,11 @@ CL_DEV inline uint32_t align_small(MEM& mem, uint32_t n, uint32_t m, uint32_t ki
 // ---- mid-size gaps: the same recurrence with the state in the lane's memory (rows * columns / 64 <= MID_CELLS) --------
 // MEM additionally provides peq / peq_set (symbol, block), pv / mv get + set (block).  Same observable behaviour as
 // align_small (and as edlib below its 1 MiB traceback budget: 20 bytes * blocks * columns stays under it).
-constexpr uint32_t MID_CELLS = 16384, MID_ROWS = 16384, MID_COLS = 4096;
+// MID_CELLS = 0 switches the class off: measured on the bench set (1.27 M gaps of ~350 x 350), the wave-per-gap kernel
+// (align_wave.hpp) does them in 155 ms against 250 ms here — its sweep, symbol conversion and indel canonicalisation are
+// wave-parallel, only the traceback is serial; one lane per gap keeps 64 serial tracebacks in lock step but pays a memory
+// round trip per block step.  The class stays as the reference point (16384 turns it back on).
+constexpr uint32_t MID_CELLS = 0, MID_ROWS = 16384, MID_COLS = 4096;
 // NBR > 0: the vertical deltas of up to NBR blocks stay in registers (only the match masks and the history are memory).
 template<int NBR, class MEM>
 CL_DEV inline uint32_t align_mid(MEM& mem, uint32_t n, uint32_t m, uint32_t kind, bool left, uint32_t nr, uint32_t use, uint32_t* d_before)
