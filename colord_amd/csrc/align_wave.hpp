@@ -30,7 +30,14 @@ struct WavePool {
 };
 
 __device__ inline uint32_t lane_id() { return threadIdx.x & 63; }
-template<class T> __device__ inline T bcast(T v, uint32_t src) { return __shfl(v, (int)src); }
+// broadcast from a lane whose index is the same in every lane: v_readlane (a few cycles) instead of a permute through LDS
+__device__ inline uint32_t bcast(uint32_t v, uint32_t src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane(src)); }
+__device__ inline int bcast(int v, uint32_t src) { return __builtin_amdgcn_readlane(v, (int)__builtin_amdgcn_readfirstlane(src)); }
+__device__ inline uint64_t bcast(uint64_t v, uint32_t src)
+{
+	const int s = (int)__builtin_amdgcn_readfirstlane(src);
+	return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), s) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, s);
+}
 __device__ inline uint32_t bcast_first(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
 struct Hist { uint64_t* P; uint64_t* H; uint32_t W, m; };       // cell (tile, s, lane) at ((tile * (m + 64)) + s) * W + lane
