@@ -171,20 +171,43 @@ __device__ inline void wave_traceback(WavePool& pool, const uint8_t* q, uint32_t
 				wP = h.P[idx]; wH = h.H[idx]; wt = t[jj - 1];
 			}
 		}
-		const uint32_t src = wj0 - j;
-		const uint64_t P = bcast(wP, src), H = bcast(wH, src);
-		const uint32_t ts = bcast(wt, src);
-		const uint64_t bit = 1ull << (r & 63);
-		uint8_t op;
-		if (P & bit) { op = 1; --i; }
-		else if (H & bit) { op = 2; --j; }
-		else
-		{
-			if (i > wi0 || wi0 - i >= 64) { wi0 = i; wq = i > lane ? q[i - 1 - lane] : 0u; }
-			op = bcast(wq, wi0 - i) == ts ? 0 : 3; --i; --j;
+		// The walk takes the same decisions as edlib's cell by cell (up if the vertical delta is +1, else left if the
+		// horizontal delta is +1, else diagonal), but a whole RUN per iteration: the lanes look at the cells the run
+		// would visit (same column going up, same row going left, the diagonal) and a ballot finds where it stops.
+		const uint32_t src = wj0 - j, rb = r & 63;
+		const int d = (int)lane - (int)src;                                  // this lane's column is j - d
+		const bool col_ok = d >= 0 && lane < wj0;
+		const uint32_t pr = (uint32_t)(wP >> rb) & 1, hr = (uint32_t)(wH >> rb) & 1;
+		const uint32_t p0 = bcast(pr, src), h0 = bcast(hr, src);
+		const uint64_t from_src = ~0ull << src;
+		if (p0)
+		{	// up while the vertical +1 bits of column j continue (inside this block)
+			const uint64_t x = ~bcast(wP, src) << (63 - rb);
+			uint32_t run = x ? (uint32_t)__builtin_clzll(x) : 64u;
+			if (run > rb + 1) run = rb + 1;
+			if (lane < run) rev[k + lane] = 1;
+			i -= run; k += run;
 		}
-		if (lane == 0) rev[k] = op;
-		++k;
+		else if (h0)
+		{	// left while row r has no vertical +1 and a horizontal +1
+			const uint64_t stop = ~__ballot(col_ok && !pr && hr) & from_src;
+			const uint32_t run = (stop ? (uint32_t)__builtin_ctzll(stop) : 64u) - src;
+			if (d >= 0 && (uint32_t)d < run) rev[k + (uint32_t)d] = 2;
+			j -= run; k += run;
+		}
+		else
+		{	// diagonal while neither bit is set at (r - d, j - d); the symbols decide match / mismatch
+			const uint32_t bp = (rb - (uint32_t)d) & 63;
+			const bool ok = col_ok && (uint32_t)d <= rb && !((wP >> bp) & 1) && !((wH >> bp) & 1);
+			const uint64_t stop = ~__ballot(ok) & from_src;
+			uint32_t run = (stop ? (uint32_t)__builtin_ctzll(stop) : 64u) - src;
+			if (i > wi0 || wi0 - i >= 64) { wi0 = i; wq = i > lane ? q[i - 1 - lane] : 0u; }
+			const uint32_t qoff = wi0 - i;
+			if (run > 64 - qoff) run = 64 - qoff;
+			const uint32_t qs = (uint32_t)__shfl((int)wq, (int)((qoff + (uint32_t)d) & 63));
+			if (d >= 0 && (uint32_t)d < run) rev[k + (uint32_t)d] = qs == wt ? 0 : 3;
+			i -= run; j -= run; k += run;
+		}
 	}
 	__builtin_amdgcn_s_waitcnt(0);
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");

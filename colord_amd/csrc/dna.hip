@@ -866,13 +866,16 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 		DevBuf<uint32_t> err; DEV_ALLOC(ctx, err, 1);
 		HIP_TRY(ctx, hipMemsetAsync(err.p, 0, 4, ctx->stream));
 		TripLayoutDev nolay{ nullptr, nullptr, nullptr, 0 };
-		uint64_t n_syms = 0;
+		uint64_t n_syms = 0, h_eb[2] = { 0, 0 };
 		for (;;)
 		{	// a tuple can take several symbols: shrink the group until its symbols fit 31-bit indices
 			if (nr)
 			{
+				HIP_TRY(ctx, hipMemcpyAsync(&h_eb[0], d_es_off + r0, 8, hipMemcpyDeviceToHost, ctx->stream));
+				HIP_TRY(ctx, hipMemcpyAsync(&h_eb[1], d_es_off + r1, 8, hipMemcpyDeviceToHost, ctx->stream));
+				HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 				LAUNCH(ctx, k_read_flags, grid_for(nr, 256), 256, d_es, d_es_off, r0, r1, rflag.p);
-				LAUNCH(ctx, (k_dna_walk<false>), grid_for(nr, WALK_LPW), 64, (const FamTab*)D->d_ft.p, R, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, r0, r1,
+				LAUNCHB(ctx, (double)(h_eb[1] - h_eb[0]) + 8.0 * nr, (k_dna_walk<false>), grid_for(nr, WALK_LPW), 64, /* tuple bytes in, one count out */ (const FamTab*)D->d_ft.p, R, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, r0, r1,
 					D->prev_types, D->cur_read_id, nolay, counts.p, hdr.p, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, err.p);
 				HIP_TRY(ctx, hipGetLastError());
 			}

@@ -808,13 +808,13 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 	LAUNCH(ctx, k_pend_list, grid_for(nr, 64), 64, T, nr, (const uint64_t*)ev_off.p, events.p);
 	if (n_packs) LAUNCH(ctx, k_estimator, n_packs, 64, T, (const uint32_t*)d_pb.p, n_packs, (const uint32_t*)reads->lens.p, has_n, (const uint32_t*)base_counts.p, (const uint64_t*)ev_off.p, (const uint32_t*)events.p);
 	DevBuf<uint32_t> sizes; DEV_ALLOC(ctx, sizes, nr);
-	LAUNCH(ctx, (k_emit_tuples<false>), grid_for(nr, EMIT_LPW), 64, A, (const uint32_t*)reads->inv.p, has_n, T, nr, AV.data, sizes.p, d_es_ntuples, (const uint64_t*)nullptr, (uint8_t*)nullptr);
+	LAUNCHB(ctx, reads->total_bases * 1.25, (k_emit_tuples<false>), grid_for(nr, EMIT_LPW), 64, /* 2 bits per base + at most one script byte per base in */ A, (const uint32_t*)reads->inv.p, has_n, T, nr, AV.data, sizes.p, d_es_ntuples, (const uint64_t*)nullptr, (uint8_t*)nullptr);
 	HIP_TRY(ctx, hipGetLastError());
 	uint64_t total = 0;
 	CL_TRY(dev_exclusive_scan_u64(ctx, sizes.p, d_es_off, nr, &total));
 	*n_out = total;
 	if (total > cap || (total && !d_es)) return cl_fail(ctx, CL_E_CAPACITY, "cl_encode_reads: need " + std::to_string(total) + " bytes");
-	LAUNCH(ctx, (k_emit_tuples<true>), grid_for(nr, EMIT_LPW), 64, A, (const uint32_t*)reads->inv.p, has_n, T, nr, AV.data, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint64_t*)d_es_off, d_es);
+	LAUNCHB(ctx, reads->total_bases * 1.25 + (double)total, (k_emit_tuples<true>), grid_for(nr, EMIT_LPW), 64, /* the same in + the tuple bytes out */ A, (const uint32_t*)reads->inv.p, has_n, T, nr, AV.data, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint64_t*)d_es_off, d_es);
 	HIP_TRY(ctx, hipGetLastError());
 	HIP_TRY(ctx, hipStreamSynchronize(st));
 	cl_timing_collect(ctx);
