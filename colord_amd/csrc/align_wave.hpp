@@ -139,21 +139,12 @@ __device__ inline Sweep wave_sweep(WavePool& pool, const uint8_t* q, int qstep, 
 
 struct Ops { uint8_t* p; uint64_t n; };                   // 0 match, 1 consume query, 2 consume target, 3 mismatch (forward order)
 
-// traceback of q[0..n) x t[0..m) (forward byte sequences) on a fresh history; appends n..n+m ops
-__device__ inline void wave_traceback(WavePool& pool, const uint8_t* q, uint32_t n, const uint8_t* t, uint32_t m, Ops& out)
+// walks the history of a sweep over q[0..n) x t[0..h.m) back from cell (n, j_start), j_start <= h.m; appends the ops
+__device__ inline void wave_walk(WavePool& pool, const Hist& h, const uint8_t* q, uint32_t n, const uint8_t* t, uint32_t j_start, uint8_t* rev, Ops& out)
 {
 	const uint32_t lane = lane_id();
-	const uint64_t mk = pool.mark();
-	const uint32_t nb = (n + 63) / 64;
-	const uint64_t hw = hist_words(nb, m);
-	Hist h{ (uint64_t*)pool.alloc(hw * 8), (uint64_t*)pool.alloc(hw * 8), nb < 64 ? nb : 64, m };
-	uint8_t* rev = (uint8_t*)pool.alloc((uint64_t)n + m + 64);
-	if (pool.overflow) { pool.release(mk); return; }
-	wave_sweep(pool, q, 1, n, t, 1, m, false, &h, nullptr);
-	if (pool.overflow) { pool.release(mk); return; }
-	__builtin_amdgcn_s_waitcnt(0);
-	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-	uint32_t i = n, j = m; uint64_t k = 0;
+	const uint32_t m = h.m;
+	uint32_t i = n, j = j_start; uint64_t k = 0;
 	// window: lanes hold (P, H) of block wb for columns wj0 - lane (1-based column wj0 at lane 0, descending)
 	uint32_t wb = 0xffffffffu, wj0 = 0; uint64_t wP = 0, wH = 0; uint32_t wt = 0;
 	uint32_t wi0 = 0, wq = 0;                                                // lanes hold q[wi0 - 1 - lane]
@@ -220,8 +211,35 @@ __device__ inline void wave_traceback(WavePool& pool, const uint8_t* q, uint32_t
 	out.n += pre + k;
 	__builtin_amdgcn_s_waitcnt(0);
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-	pool.release(mk);
 }
+// edlib keeps the whole history when it fits 1 MiB (edlib.cpp:1176-1183), else it divides (Hirschberg)
+__device__ inline bool wave_direct_fits(uint32_t n, uint32_t m)
+{
+	const long long blocks = (n + 63) / 64;
+	return (2ll * 8 + 4) * blocks * m + 2ll * 4 * m < 1024 * 1024;
+}
+// ONE sweep that keeps the history, then the walk from (n, m) — or, shw, from (n, end + 1): the columns up to the end
+// position are the same whether or not the sweep went on beyond it, so the reference's second pass over the truncated
+// target (edlib.cpp:196-236) is not needed.  Appends the ops, returns the sweep's result.
+__device__ inline Sweep wave_align_direct(WavePool& pool, const uint8_t* q, uint32_t n, const uint8_t* t, uint32_t m, bool shw, Ops& out)
+{
+	const uint64_t mk = pool.mark();
+	const uint32_t nb = (n + 63) / 64;
+	const uint64_t hw = hist_words(nb, m);
+	Hist h{ (uint64_t*)pool.alloc(hw * 8), (uint64_t*)pool.alloc(hw * 8), nb < 64 ? nb : 64, m };
+	uint8_t* rev = (uint8_t*)pool.alloc((uint64_t)n + m + 64);
+	Sweep sw{ n, 0xffffffffu, (int32_t)m - 1 };
+	if (pool.overflow) { pool.release(mk); return sw; }
+	sw = wave_sweep(pool, q, 1, n, t, 1, m, shw, &h, nullptr);
+	if (pool.overflow) { pool.release(mk); return sw; }
+	__builtin_amdgcn_s_waitcnt(0);
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	wave_walk(pool, h, q, n, t, shw ? (uint32_t)(sw.end + 1) : m, rev, out);
+	pool.release(mk);
+	return sw;
+}
+// traceback of q[0..n) x t[0..m) (forward byte sequences) on a fresh history; appends n..n+m ops
+__device__ inline void wave_traceback(WavePool& pool, const uint8_t* q, uint32_t n, const uint8_t* t, uint32_t m, Ops& out) { wave_align_direct(pool, q, n, t, m, false, out); }
 
 // obtainAlignment (edlib.cpp:1164-1215): optimal path of q (rows) against t (columns) given the optimal score
 __device__ inline void wave_path(WavePool& pool, const uint8_t* q, uint32_t n, const uint8_t* t, uint32_t m, uint32_t best, Ops& out)
@@ -248,9 +266,7 @@ __device__ inline void wave_path(WavePool& pool, const uint8_t* q, uint32_t n, c
 			out.n += (uint64_t)jb.n + jb.m;
 			continue;
 		}
-		const long long blocks = (jb.n + 63) / 64;
-		const long long sz = (2ll * 8 + 4) * blocks * jb.m + 2ll * 4 * jb.m;
-		if (sz < 1024 * 1024) { wave_traceback(pool, q + jb.qo, jb.n, t + jb.to, jb.m, out); continue; }
+		if (wave_direct_fits(jb.n, jb.m)) { wave_traceback(pool, q + jb.qo, jb.n, t + jb.to, jb.m, out); continue; }
 		const uint32_t L = jb.m / 2, R = jb.m - L;
 		const uint64_t mk = pool.mark();
 		int32_t* left = (int32_t*)pool.alloc(((uint64_t)jb.n + 1) * 4);

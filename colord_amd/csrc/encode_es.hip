@@ -227,32 +227,45 @@ __device__ inline bool align_wave_gap(wv::WavePool& pool, GapRec& g, const Arena
 	if (dbg_stage == 1) return true;
 	wv::Ops ops{ opsbuf, 0 };
 	const uint8_t* Q; const uint8_t* T; uint32_t n, m; bool rows_ref; uint32_t ref_end = 0;
-	if (g.kind == GK_INNER)
+	// when edlib would keep the whole history anyway (it decides on the truncated target, which is never longer), one
+	// sweep delivers both the score / end position and the history; else score sweep first, then divide and conquer
+	if (g.kind == GK_INNER || g.kind == GK_FLANK_TINY)
 	{
-		Q = rbuf; n = g.nr; T = ebuf; m = g.ne; rows_ref = true;
-		const wv::Sweep sw = wv::wave_sweep(pool, Q, 1, n, T, 1, m, false, nullptr, nullptr);
-		if (pool.overflow) return false;
-		pool.lap(2);
-		if (dbg_stage == 2) return true;
-		wv::wave_path(pool, Q, n, T, m, sw.score, ops);
-	}
-	else if (g.kind == GK_FLANK_TINY)
-	{
-		Q = r2; n = g.use; T = e2; m = g.ne; rows_ref = true; ref_end = g.use - 1;
-		const wv::Sweep sw = wv::wave_sweep(pool, Q, 1, n, T, 1, m, false, nullptr, nullptr);
-		if (pool.overflow) return false;
-		pool.lap(2);
-		wv::wave_path(pool, Q, n, T, m, sw.score, ops);
+		if (g.kind == GK_INNER) { Q = rbuf; n = g.nr; T = ebuf; m = g.ne; }
+		else { Q = r2; n = g.use; T = e2; m = g.ne; ref_end = g.use - 1; }
+		rows_ref = true;
+		if (n && m && wv::wave_direct_fits(n, m))
+		{
+			wv::wave_align_direct(pool, Q, n, T, m, false, ops);
+			pool.lap(2);
+		}
+		else
+		{
+			const wv::Sweep sw = wv::wave_sweep(pool, Q, 1, n, T, 1, m, false, nullptr, nullptr);
+			if (pool.overflow) return false;
+			pool.lap(2);
+			if (dbg_stage == 2) return true;
+			wv::wave_path(pool, Q, n, T, m, sw.score, ops);
+		}
 	}
 	else
 	{
 		Q = e2; n = g.ne; T = r2; rows_ref = false;
-		const wv::Sweep sw = wv::wave_sweep(pool, Q, 1, n, T, 1, g.use, true, nullptr, nullptr);
-		if (pool.overflow) return false;
-		ref_end = (uint32_t)sw.end; m = (uint32_t)(sw.end + 1);
-		pool.lap(2);
-		if (dbg_stage == 2) return true;
-		wv::wave_path(pool, Q, n, T, m, sw.best, ops);
+		if (n && g.use && wv::wave_direct_fits(n, g.use))
+		{
+			const wv::Sweep sw = wv::wave_align_direct(pool, Q, n, T, g.use, true, ops);
+			ref_end = (uint32_t)sw.end; m = (uint32_t)(sw.end + 1);
+			pool.lap(2);
+		}
+		else
+		{
+			const wv::Sweep sw = wv::wave_sweep(pool, Q, 1, n, T, 1, g.use, true, nullptr, nullptr);
+			if (pool.overflow) return false;
+			ref_end = (uint32_t)sw.end; m = (uint32_t)(sw.end + 1);
+			pool.lap(2);
+			if (dbg_stage == 2) return true;
+			wv::wave_path(pool, Q, n, T, m, sw.best, ops);
+		}
 	}
 	if (pool.overflow) return false;
 	__builtin_amdgcn_s_waitcnt(0);
