@@ -40,6 +40,8 @@ struct DevPool {
 		if (it != free_blocks.end() && it->first <= r + r / 2 + (64ull << 20))
 		{ *out = it->second; *got = it->first; cached_bytes -= it->first; free_blocks.erase(it); return hipSuccess; }
 		hipError_t e = hipMalloc(out, r);
+		static const bool dbg = getenv("COLORD_HIP_POOL_DEBUG") != nullptr;
+		if (dbg) fprintf(stderr, "[pool] hipMalloc %.3f GB (%s), cached %.3f GB in %zu blocks\n", r / 1e9, e == hipSuccess ? "ok" : "failed", cached_bytes / 1e9, free_blocks.size());
 		while (e != hipSuccess && !free_blocks.empty())
 		{	// out of memory: give back cached blocks, largest first, until the request fits
 			(void)hipGetLastError();

@@ -64,8 +64,7 @@ __device__ inline uint32_t ilog2_(uint64_t x) { return x ? 64u - (uint32_t)__clz
 __device__ inline uint32_t no_bytes_(uint64_t x) { uint32_t r = 1; x >>= 8; for (; x; ++r) x >>= 8; return r; }
 
 struct Emitter {
-	bool write; uint64_t* key; uint32_t* sidx; uint64_t off; uint32_t count; const FamTab* ft; TripLayoutDev lay; uint32_t part;
-	uint64_t tbase = 0;
+	bool write; uint64_t* key; uint64_t off; uint32_t count; const FamTab* ft;
 	__device__ inline void operator()(int fam, uint32_t ctx, uint32_t sym, int e1 = 15, int e2 = 15)
 	{
 		if (write)
@@ -179,8 +178,7 @@ __global__ __launch_bounds__(64) void k_dna_walk(const FamTab* __restrict__ ftp,
 	if (threadIdx.x >= WALK_LPW) return;
 	const uint32_t r = r0 + blockIdx.x * WALK_LPW + threadIdx.x;
 	if (r >= r1) return;
-	Emitter em{ WRITE, key, sidx, WRITE ? sym_off[r - r0] : 0, 0, &ft, lay, WRITE ? part_of_read(lay, r) : 0 };
-	if (WRITE) em.tbase = lay.group_base[em.part >> 6] - lay.part_sym_start[em.part] * 64 + (em.part & 63);
+	Emitter em{ WRITE, key, WRITE ? sym_off[r - r0] : 0, 0, &ft };
 	EsReader rd{ es + es_off[r], es + es_off[r + 1] };
 	uint32_t type = T_NONE, v1 = 0, v2 = 0;
 	rd.next(type, v1, v2);
@@ -353,12 +351,13 @@ __global__ void k_read_flags(const uint8_t* __restrict__ es, const uint64_t* __r
 }
 
 // triple slot of every symbol: one wave per read (all symbols of a read are in one part)
-__global__ __launch_bounds__(256) void k_fill_sidx(const uint64_t* __restrict__ sym_off, uint32_t r0, uint32_t r1, TripLayoutDev lay, uint32_t* __restrict__ sidx)
+// (sym_off: symbol offsets of ALL reads; s0 = that of read r0, the first of the group the layout describes)
+__global__ __launch_bounds__(256) void k_fill_sidx(const uint64_t* __restrict__ sym_off, uint64_t s0, uint32_t r0, uint32_t r1, TripLayoutDev lay, uint32_t* __restrict__ sidx)
 {
 	const uint32_t r = r0 + blockIdx.x * 4 + (threadIdx.x >> 6);
 	if (r >= r1) return;
 	const uint32_t lane = threadIdx.x & 63;
-	const uint64_t a = sym_off[r - r0], b = sym_off[r - r0 + 1];
+	const uint64_t a = sym_off[r] - s0, b = sym_off[r + 1] - s0;
 	if (a == b) return;
 	const uint32_t part = part_of_read(lay, r);
 	const uint64_t tbase = lay.group_base[part >> 6] - lay.part_sym_start[part] * 64 + (part & 63);
@@ -367,8 +366,7 @@ __global__ __launch_bounds__(256) void k_fill_sidx(const uint64_t* __restrict__ 
 // ---- D1b: bases of plain reads, one wave per read, one lane per base (dna_coder.cpp:1178-1227) ----------
 __global__ __launch_bounds__(256) void k_dna_plain(const FamTab* __restrict__ ftp, const uint8_t* __restrict__ es, const uint64_t* __restrict__ es_off,
                                                   const uint32_t* __restrict__ es_ntup, const uint8_t* __restrict__ read_flag, const uint32_t* __restrict__ hdr_counts,
-                                                  const uint64_t* __restrict__ sym_off, uint32_t r0, uint32_t r1, TripLayoutDev lay,
-                                                  uint64_t* __restrict__ key, uint32_t* __restrict__ sidx)
+                                                  const uint64_t* __restrict__ sym_off, uint32_t r0, uint32_t r1, uint64_t* __restrict__ key)
 {
 	const uint32_t r = r0 + blockIdx.x * 4 + (threadIdx.x >> 6);
 	if (r >= r1) return;
@@ -848,51 +846,67 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 	const FamTab& f = D->ft;
 	RefStore R{ refs->packed.p, refs->word_off.p, refs->lens.p, refs->n_reads };
 	uint64_t written = 0;
-	// tuple counts bound the number of symbols: group parts so that a group stays below ~2^28 tuples
-	std::vector<uint32_t> h_ntup(n_reads);
-	HIP_TRY(ctx, hipMemcpy(h_ntup.data(), d_es_ntuples, (uint64_t)n_reads * 4, hipMemcpyDeviceToHost));
-	std::vector<uint64_t> tup_prefix(n_reads + 1, 0);
-	for (uint32_t i = 0; i < n_reads; ++i) tup_prefix[i + 1] = tup_prefix[i] + h_ntup[i];
-	const uint64_t GROUP_TUPLES = 3ull << 29;       // as few launches as 32-bit symbol indices allow (see qual.hip)
+	// D1 for ALL reads at once: the walks are one lane per read and as long as the longest read's chain of tuples takes,
+	// whatever the number of reads — so one count pass and one write pass per call, not per group.  Only what follows
+	// (sort, models, interval arithmetic) is grouped, by the 32-bit symbol / triple indices.
+	DevBuf<uint8_t> rflag; DEV_ALLOC(ctx, rflag, (uint64_t)n_reads + 1);
+	DevBuf<uint32_t> hdr; DEV_ALLOC(ctx, hdr, (uint64_t)n_reads + 1);
+	DevBuf<uint64_t> sym_off; DEV_ALLOC(ctx, sym_off, (uint64_t)n_reads + 1);
+	DevBuf<uint32_t> err; DEV_ALLOC(ctx, err, 1);
+	HIP_TRY(ctx, hipMemsetAsync(err.p, 0, 4, ctx->stream));
+	DevBuf<uint64_t> key;
+	std::vector<uint64_t> h_sym_off((size_t)n_reads + 1, 0);
+	TripLayoutDev nolay{ nullptr, nullptr, nullptr, 0 };
+	if (n_reads)
+	{
+		uint64_t total_syms = 0, h_eb[2] = { 0, 0 };
+		HIP_TRY(ctx, hipMemcpyAsync(&h_eb[0], d_es_off, 8, hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(ctx, hipMemcpyAsync(&h_eb[1], d_es_off + n_reads, 8, hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		{
+			DevBuf<uint32_t> counts; DEV_ALLOC(ctx, counts, n_reads);
+			LAUNCH(ctx, k_read_flags, grid_for(n_reads, 256), 256, d_es, d_es_off, 0u, n_reads, rflag.p);
+			LAUNCHB(ctx, (double)(h_eb[1] - h_eb[0]) + 8.0 * n_reads, (k_dna_walk<false>), grid_for(n_reads, WALK_LPW), 64, /* tuple bytes in, one count out */ (const FamTab*)D->d_ft.p, R, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, 0u, n_reads,
+				D->prev_types, D->cur_read_id, nolay, counts.p, hdr.p, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, err.p);
+			HIP_TRY(ctx, hipGetLastError());
+			CL_TRY(dev_exclusive_scan_u64(ctx, counts.p, sym_off.p, n_reads, &total_syms));
+		}
+		HIP_TRY(ctx, hipMemcpy(h_sym_off.data(), sym_off.p, ((uint64_t)n_reads + 1) * 8, hipMemcpyDeviceToHost));
+		DEV_ALLOC(ctx, key, total_syms);
+		LAUNCHB(ctx, total_syms * 9.0, (k_dna_walk<true>), grid_for(n_reads, WALK_LPW), 64, /* tuple bytes in (<= 1 per symbol), 8 bytes per symbol out */ (const FamTab*)D->d_ft.p, R, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, 0u, n_reads,
+			D->prev_types, D->cur_read_id, nolay, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint64_t*)sym_off.p, key.p, (uint32_t*)nullptr, err.p);
+		LAUNCH(ctx, k_dna_plain, grid_for(n_reads, 4), 256, (const FamTab*)D->d_ft.p, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, (const uint32_t*)hdr.p,
+			(const uint64_t*)sym_off.p, 0u, n_reads, key.p);
+		HIP_TRY(ctx, hipGetLastError());
+	}
 	uint32_t p0 = 0;
 	while (p0 < n_parts)
 	{
-		uint32_t p1 = p0 + 1;
-		while (p1 < n_parts && tup_prefix[h_part_bounds[p1 + 1]] - tup_prefix[h_part_bounds[p0]] <= GROUP_TUPLES) ++p1;
-		uint32_t r0 = h_part_bounds[p0], r1 = h_part_bounds[p1], nr = r1 - r0, np = p1 - p0, ng = (np + 63) / 64;
-		DevBuf<uint8_t> rflag; DEV_ALLOC(ctx, rflag, nr);
-		DevBuf<uint32_t> counts, hdr; DEV_ALLOC(ctx, counts, nr); DEV_ALLOC(ctx, hdr, nr);
-		DevBuf<uint64_t> sym_off; DEV_ALLOC(ctx, sym_off, (uint64_t)nr + 1);
-		DevBuf<uint32_t> err; DEV_ALLOC(ctx, err, 1);
-		HIP_TRY(ctx, hipMemsetAsync(err.p, 0, 4, ctx->stream));
-		TripLayoutDev nolay{ nullptr, nullptr, nullptr, 0 };
-		uint64_t n_syms = 0, h_eb[2] = { 0, 0 };
-		for (;;)
-		{	// a tuple can take several symbols: shrink the group until its symbols fit 31-bit indices
-			if (nr)
+		// the group: as many parts as 31-bit symbol indices and the triple slots allow (16 bytes each; parts of unequal
+		// length leave slots unused)
+		const uint64_t GROUP_SLOTS = 9ull << 28;
+		uint32_t p1 = p0; const uint32_t r0 = h_part_bounds[p0];
+		std::vector<uint64_t> gbase(1, 0);
+		{
+			uint64_t slots_done = 0; uint32_t lm = 0;                                 // finished 64-part groups; longest part of the open one
+			while (p1 < n_parts)
 			{
-				HIP_TRY(ctx, hipMemcpyAsync(&h_eb[0], d_es_off + r0, 8, hipMemcpyDeviceToHost, ctx->stream));
-				HIP_TRY(ctx, hipMemcpyAsync(&h_eb[1], d_es_off + r1, 8, hipMemcpyDeviceToHost, ctx->stream));
-				HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-				LAUNCH(ctx, k_read_flags, grid_for(nr, 256), 256, d_es, d_es_off, r0, r1, rflag.p);
-				LAUNCHB(ctx, (double)(h_eb[1] - h_eb[0]) + 8.0 * nr, (k_dna_walk<false>), grid_for(nr, WALK_LPW), 64, /* tuple bytes in, one count out */ (const FamTab*)D->d_ft.p, R, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, r0, r1,
-					D->prev_types, D->cur_read_id, nolay, counts.p, hdr.p, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, err.p);
-				HIP_TRY(ctx, hipGetLastError());
+				const uint64_t pl = h_sym_off[h_part_bounds[p1 + 1]] - h_sym_off[h_part_bounds[p1]];
+				if (pl >= (1ull << 31) - 64) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_dna_encode: one part has >= 2^31 symbols");
+				const uint32_t nlm = std::max(lm, (uint32_t)pl);
+				if (p1 > p0 && (h_sym_off[h_part_bounds[p1 + 1]] - h_sym_off[r0] >= (1ull << 31) || slots_done + (uint64_t)nlm * 64 >= GROUP_SLOTS)) break;
+				lm = nlm; ++p1;
+				if (((p1 - p0) & 63) == 0) { slots_done += (uint64_t)lm * 64; lm = 0; }
 			}
-			CL_TRY(dev_exclusive_scan_u64(ctx, counts.p, sym_off.p, nr, &n_syms));
-			if (n_syms < (1ull << 31)) break;
-			if (np == 1) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_dna_encode: one part has >= 2^31 symbols");
-			p1 = p0 + np / 2;
-			r1 = h_part_bounds[p1]; nr = r1 - r0; np = p1 - p0; ng = (np + 63) / 64;
 		}
+		const uint32_t r1 = h_part_bounds[p1], nr = r1 - r0, np = p1 - p0, ng = (np + 63) / 64;
+		const uint64_t s0 = h_sym_off[r0], n_syms = h_sym_off[r1] - s0;
 		// part geometry
-		std::vector<uint64_t> h_sym_off((size_t)nr + 1);
-		HIP_TRY(ctx, hipMemcpy(h_sym_off.data(), sym_off.p, ((uint64_t)nr + 1) * 8, hipMemcpyDeviceToHost));
-		std::vector<uint64_t> sym_start(np + 1), gbase(ng + 1);
+		std::vector<uint64_t> sym_start(np + 1);
 		std::vector<uint32_t> plen(np), pfirst(np + 1);
-		for (uint32_t p = 0; p <= np; ++p) { pfirst[p] = h_part_bounds[p0 + p]; sym_start[p] = h_sym_off[pfirst[p] - r0]; }
+		for (uint32_t p = 0; p <= np; ++p) { pfirst[p] = h_part_bounds[p0 + p]; sym_start[p] = h_sym_off[pfirst[p]] - s0; }
 		for (uint32_t p = 0; p < np; ++p) plen[p] = (uint32_t)(sym_start[p + 1] - sym_start[p]);
-		gbase[0] = 0;
+		gbase.assign(ng + 1, 0);
 		for (uint32_t g = 0; g < ng; ++g)
 		{
 			uint32_t lm = 0;
@@ -910,22 +924,19 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 		DevBuf<triple_t> trip; DEV_ALLOC(ctx, trip, gbase[ng]);
 		if (n_syms)
 		{
-			DevBuf<uint64_t> key; DevBuf<uint32_t> sidx; DEV_ALLOC(ctx, key, n_syms); DEV_ALLOC(ctx, sidx, n_syms);
-			LAUNCHB(ctx, n_syms * 13.0, (k_dna_walk<true>), grid_for(nr, WALK_LPW), 64, /* tuple bytes in (<= 1 per symbol), 8 + 4 bytes per symbol out */ (const FamTab*)D->d_ft.p, R, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, r0, r1,
-				D->prev_types, D->cur_read_id, lay, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint64_t*)sym_off.p, key.p, sidx.p, err.p);
-			LAUNCHB(ctx, n_syms * 4.0, k_fill_sidx, grid_for(nr, 4), 256, (const uint64_t*)sym_off.p, r0, r1, lay, sidx.p);
-			LAUNCH(ctx, k_dna_plain, grid_for(nr, 4), 256, (const FamTab*)D->d_ft.p, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, (const uint32_t*)hdr.p,
-				(const uint64_t*)sym_off.p, r0, r1, lay, key.p, sidx.p);
+			uint64_t* const gkey = key.p + s0;                                       // this group's keys (written by the walk above)
+			DevBuf<uint32_t> sidx; DEV_ALLOC(ctx, sidx, n_syms);
+			LAUNCHB(ctx, n_syms * 4.0, k_fill_sidx, grid_for(nr, 4), 256, (const uint64_t*)sym_off.p, s0, r0, r1, lay, sidx.p);
 			HIP_TRY(ctx, hipGetLastError());
 			uint32_t cbits = 1; while ((1ull << cbits) < f.ctx_base[N_FAM]) ++cbits;
-			CL_TRY(dev_sort_pairs(ctx, key.p, sidx.p, n_syms, 16, 16 + cbits));
+			CL_TRY(dev_sort_pairs(ctx, gkey, sidx.p, n_syms, 16, 16 + cbits));
 			DevBuf<uint32_t> hf; DEV_ALLOC(ctx, hf, n_syms);
-			LAUNCH(ctx, k_ctx_heads, grid_for(n_syms, 256), 256, (const uint64_t*)key.p, n_syms, hf.p);
+			LAUNCH(ctx, k_ctx_heads, grid_for(n_syms, 256), 256, (const uint64_t*)gkey, n_syms, hf.p);
 			uint64_t n_seg = 0;
 			CL_TRY(dev_exclusive_scan_u32(ctx, hf.p, n_syms, &n_seg));
 			DevBuf<uint32_t> seg; DEV_ALLOC(ctx, seg, n_seg + 1);
 			LAUNCH(ctx, k_seg_starts, grid_for(n_syms, 256), 256, (const uint32_t*)hf.p, n_syms, n_seg, seg.p);
-			LAUNCHB(ctx, n_syms * 28.0, k_dna_evolve, grid_for(n_seg, 4), 256, (const FamTab*)D->d_ft.p, (const uint64_t*)key.p, (const uint32_t*)sidx.p, (const uint32_t*)seg.p,
+			LAUNCHB(ctx, n_syms * 28.0, k_dna_evolve, grid_for(n_seg, 4), 256, (const FamTab*)D->d_ft.p, (const uint64_t*)gkey, (const uint32_t*)sidx.p, (const uint32_t*)seg.p,
 				(uint32_t)n_seg, D->state.p, trip.p);
 			HIP_TRY(ctx, hipGetLastError());
 			{	// long runs of the models with up to 32 symbols (k_dna_evolve skipped them)
@@ -933,7 +944,7 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 				DevBuf<LongRun> runs; DEV_ALLOC(ctx, runs, 2 * RUN_CAP);
 				DevBuf<uint32_t> n_runs; DEV_ALLOC(ctx, n_runs, 2);
 				HIP_TRY(ctx, hipMemsetAsync(n_runs.p, 0, 8, ctx->stream));
-				LAUNCH(ctx, k_long_find, grid_for(n_seg, 256), 256, (const uint32_t*)seg.p, (uint32_t)n_seg, (const uint64_t*)key.p, (const FamTab*)D->d_ft.p, runs.p, RUN_CAP, n_runs.p);
+				LAUNCH(ctx, k_long_find, grid_for(n_seg, 256), 256, (const uint32_t*)seg.p, (uint32_t)n_seg, (const uint64_t*)gkey, (const FamTab*)D->d_ft.p, runs.p, RUN_CAP, n_runs.p);
 				uint32_t nlr2[2] = { 0, 0 };
 				HIP_TRY(ctx, hipMemcpyAsync(nlr2, n_runs.p, 8, hipMemcpyDeviceToHost, ctx->stream));
 				HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -961,20 +972,20 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 					const LongRun* cr = d_runs;
 					if (which == 0)
 					{
-						LAUNCHB(ctx, steps * 64 * 8.0, (k_long_hist<8>), grid_for(groups * 64, 256), 256, cr, nlr, groups, (const uint64_t*)key.p, step_pfx.p, group_pfx.p);
+						LAUNCHB(ctx, steps * 64 * 8.0, (k_long_hist<8>), grid_for(groups * 64, 256), 256, cr, nlr, groups, (const uint64_t*)gkey, step_pfx.p, group_pfx.p);
 						LAUNCH(ctx, (k_long_groups<8>), nlr, 64, cr, nlr, group_pfx.p);
-						LAUNCH(ctx, (k_long_epochs<8>), nlr, 64, (const FamTab*)D->d_ft.p, cr, nlr, (const uint64_t*)key.p, (const uint32_t*)step_pfx.p, (const uint32_t*)group_pfx.p,
+						LAUNCH(ctx, (k_long_epochs<8>), nlr, 64, (const FamTab*)D->d_ft.p, cr, nlr, (const uint64_t*)gkey, (const uint32_t*)step_pfx.p, (const uint32_t*)group_pfx.p,
 							D->state.p, (EpochRec<8>*)epochs.p, d_ne.p, group_epoch.p, err.p);
-						LAUNCHB(ctx, steps * 64 * 28.0, (k_long_apply<8>), grid_for(steps * 64, 256), 256, cr, nlr, steps, (const uint64_t*)key.p, (const uint32_t*)sidx.p,
+						LAUNCHB(ctx, steps * 64 * 28.0, (k_long_apply<8>), grid_for(steps * 64, 256), 256, cr, nlr, steps, (const uint64_t*)gkey, (const uint32_t*)sidx.p,
 							(const uint32_t*)step_pfx.p, (const uint32_t*)group_pfx.p, (const EpochRec<8>*)epochs.p, (const uint32_t*)d_ne.p, (const uint32_t*)group_epoch.p, (const FamTab*)D->d_ft.p, trip.p);
 					}
 					else
 					{
-						LAUNCHB(ctx, steps * 64 * 8.0, (k_long_hist<32>), grid_for(groups * 64, 256), 256, cr, nlr, groups, (const uint64_t*)key.p, step_pfx.p, group_pfx.p);
+						LAUNCHB(ctx, steps * 64 * 8.0, (k_long_hist<32>), grid_for(groups * 64, 256), 256, cr, nlr, groups, (const uint64_t*)gkey, step_pfx.p, group_pfx.p);
 						LAUNCH(ctx, (k_long_groups<32>), nlr, 64, cr, nlr, group_pfx.p);
-						LAUNCH(ctx, (k_long_epochs<32>), nlr, 64, (const FamTab*)D->d_ft.p, cr, nlr, (const uint64_t*)key.p, (const uint32_t*)step_pfx.p, (const uint32_t*)group_pfx.p,
+						LAUNCH(ctx, (k_long_epochs<32>), nlr, 64, (const FamTab*)D->d_ft.p, cr, nlr, (const uint64_t*)gkey, (const uint32_t*)step_pfx.p, (const uint32_t*)group_pfx.p,
 							D->state.p, (EpochRec<32>*)epochs.p, d_ne.p, group_epoch.p, err.p);
-						LAUNCHB(ctx, steps * 64 * 28.0, (k_long_apply<32>), grid_for(steps * 64, 256), 256, cr, nlr, steps, (const uint64_t*)key.p, (const uint32_t*)sidx.p,
+						LAUNCHB(ctx, steps * 64 * 28.0, (k_long_apply<32>), grid_for(steps * 64, 256), 256, cr, nlr, steps, (const uint64_t*)gkey, (const uint32_t*)sidx.p,
 							(const uint32_t*)step_pfx.p, (const uint32_t*)group_pfx.p, (const EpochRec<32>*)epochs.p, (const uint32_t*)d_ne.p, (const uint32_t*)group_epoch.p, (const FamTab*)D->d_ft.p, trip.p);
 					}
 					HIP_TRY(ctx, hipGetLastError());
@@ -1006,15 +1017,16 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 		if (w > cap) { *n_out = w; return cl_fail(ctx, CL_E_CAPACITY, "cl_dna_encode: output capacity " + std::to_string(cap) + " too small"); }
 		HIP_TRY(ctx, hipMemcpyAsync(d_dst_off.p, dst_off.data(), np * 8, hipMemcpyHostToDevice, ctx->stream));
 		LAUNCH(ctx, k_gather_bytes2, np, 256, (const uint8_t*)tmp.p, (const uint64_t*)d_out_off.p, (const uint64_t*)d_dst_off.p, (const uint64_t*)d_size.p, d_out);
-		// carry the coder state to the next group / call
+		written = w;
+		p0 = p1;
+	}
+	{	// carry the coder state to the next call
 		DevBuf<uint32_t> lt; DEV_ALLOC(ctx, lt, 1);
-		LAUNCH(ctx, k_last_types, 1, 1, (const uint8_t*)rflag.p, nr, D->prev_types, lt.p);
+		LAUNCH(ctx, k_last_types, 1, 1, (const uint8_t*)rflag.p, n_reads, D->prev_types, lt.p);
 		HIP_TRY(ctx, hipGetLastError());
 		HIP_TRY(ctx, hipMemcpyAsync(&D->prev_types, lt.p, 4, hipMemcpyDeviceToHost, ctx->stream));
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-		D->cur_read_id += nr;
-		written = w;
-		p0 = p1;
+		D->cur_read_id += n_reads;
 	}
 	cl_timing_collect(ctx);
 	*n_out = written;
