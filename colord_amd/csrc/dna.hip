@@ -161,44 +161,57 @@ __device__ inline void emit_skip_len(Emitter& em, uint32_t len, bool local)     
 	}
 }
 
-// ---- D1: one lane per read walks the tuple stream (CDNACoder::Encode, dna_coder.cpp:26-231) ----------
-constexpr uint32_t WALK_LPW = 64;
-// WRITE = false: only counts the symbols of each read.  Bases of plain reads are left to k_dna_plain.
+// ---- D1: the walk over the tuple streams (CDNACoder::Encode, dna_coder.cpp:26-231) ----------
+// A read's tuples are a chain (contexts, reference cursors, the tables of alternative references), and one lane walking
+// a 170 k-tuple read takes ~0.1 s however idle the machine is.  So the walk is done twice, differently:
+//   count pass  one lane per READ: counts the symbols and, every WALK_CHUNK tuples, saves the state of the walk;
+//   write pass  one lane per CHUNK: resumes from the saved state and writes the keys of its WALK_CHUNK tuples.
+// The count pass is the shorter chain (no reference symbols, no stores); the write pass is bounded by a chunk, not a read.
+constexpr uint32_t WALK_LPW = 64, WALK_CHUNK = 4096;
+struct WalkCk {
+	uint64_t byte_off, ctx_tuple, ctx_symbol; int64_t ref_pos, alt_pos;
+	uint32_t read, sym, ctx_rev, n_rc, n_alt, alt_id; int32_t alt_slot, delta; uint32_t last_type, last_flag, flags, pad;   // flags: is_main | first << 1 | alt_rev << 2
+	int32_t rc_ids[MAX_ALT + 1], alt_ids[MAX_ALT], alt_pos_of[MAX_ALT]; uint8_t alt_rev_of[MAX_ALT];
+};
+// chunks of every read: plain reads (their bases are left to k_dna_plain) and empty scripts have one, for the header symbols
+__global__ void k_walk_chunks(const uint32_t* __restrict__ es_ntup, const uint8_t* __restrict__ read_flag, uint32_t n, uint32_t* __restrict__ out)
+{
+	const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n) return;
+	const uint32_t t = es_ntup[r] ? es_ntup[r] - 1 : 0;
+	out[r] = read_flag[r] != 2 || t == 0 ? 1u : (t + WALK_CHUNK - 1) / WALK_CHUNK;
+}
 template<bool WRITE>
 __global__ __launch_bounds__(64) void k_dna_walk(const FamTab* __restrict__ ftp, RefStore R, const uint8_t* __restrict__ es, const uint64_t* __restrict__ es_off,
                                                 const uint32_t* __restrict__ es_ntup, const uint8_t* __restrict__ read_flag,
-                                                uint32_t r0, uint32_t r1, uint32_t prev_types, uint32_t cur_read_id0, TripLayoutDev lay,
+                                                uint32_t n_reads, uint32_t prev_types, uint32_t cur_read_id0, const uint64_t* __restrict__ chunk_off, WalkCk* __restrict__ cks, uint32_t n_chunks,
                                                 uint32_t* __restrict__ counts, uint32_t* __restrict__ hdr_counts, const uint64_t* __restrict__ sym_off,
-                                                uint64_t* __restrict__ key, uint32_t* __restrict__ sidx, uint32_t* __restrict__ err)
+                                                uint64_t* __restrict__ key, uint32_t* __restrict__ err)
 {
 	__shared__ FamTab ft;
 	for (uint32_t i = threadIdx.x; i < sizeof(FamTab) / 4; i += blockDim.x) ((uint32_t*)&ft)[i] = ((const uint32_t*)ftp)[i];
 	__syncthreads();
-	// WALK_LPW reads per wave (divergent walk, plenty of idle wave slots)
-	if (threadIdx.x >= WALK_LPW) return;
-	const uint32_t r = r0 + blockIdx.x * WALK_LPW + threadIdx.x;
-	if (r >= r1) return;
-	Emitter em{ WRITE, key, WRITE ? sym_off[r - r0] : 0, 0, &ft };
+	uint32_t r, c, j = 0;                                                        // read, chunk, chunk index within the read
+	if (WRITE)
+	{
+		c = blockIdx.x * WALK_LPW + threadIdx.x;
+		if (c >= n_chunks) return;
+		r = cks[c].read; j = c - (uint32_t)chunk_off[r];
+	}
+	else
+	{
+		r = blockIdx.x * WALK_LPW + threadIdx.x;
+		if (r >= n_reads) return;
+		c = (uint32_t)chunk_off[r];
+	}
+	const uint32_t n_ch = (uint32_t)(chunk_off[r + 1] - chunk_off[r]);
+	if (!WRITE) for (uint32_t x = 0; x < n_ch; ++x) cks[c + x].read = r;
+	Emitter em{ WRITE, key, WRITE ? sym_off[r] : 0, 0, &ft };
 	EsReader rd{ es + es_off[r], es + es_off[r + 1] };
 	uint32_t type = T_NONE, v1 = 0, v2 = 0;
 	rd.next(type, v1, v2);
-	// read-type history: types of the four previous reads, also across calls (dna_coder.cpp:440-463)
-	uint32_t ctx_rt = 0;
-	for (uint32_t t = 1; t <= 4; ++t)
-	{
-		uint32_t f = (r >= r0 + t) ? read_flag[r - t - r0] : ((prev_types >> (2 * (t - 1 - (r - r0)))) & 3u);
-		ctx_rt |= f << (2 * (t - 1));
-	}
-	const uint32_t flag = type == T_START_PLAIN ? 0u : type == T_START_PLAIN_N ? 1u : 2u;
-	em(F_READ_TYPE, ctx_rt, flag);
 	const uint32_t ntup = es_ntup[r];
-	emit_read_len(em, ntup - 1);
-	const uint32_t cur_read_id = cur_read_id0 + (r - r0);
-	if (type == T_START_PLAIN || type == T_START_PLAIN_N)
-	{
-		if (!WRITE) { hdr_counts[r - r0] = em.count; counts[r - r0] = em.count + (ntup - 1); }
-		return;
-	}
+	const uint32_t cur_read_id = cur_read_id0 + r;
 	const uint64_t mask_tuple = (1ULL << (3 * ft.T)) - 1, mask_symbol = (1ULL << (2 * ft.S)) - 1;
 	uint64_t ctx_tuple = mask_tuple, ctx_symbol = mask_symbol; uint32_t ctx_rev = 0xf;
 	int32_t rc_ids[MAX_ALT + 1]; uint32_t n_rc = 0;                               // uo_rev_comp keys (values are not needed to encode)
@@ -213,13 +226,58 @@ __global__ __launch_bounds__(64) void k_dna_walk(const FamTab* __restrict__ ftp,
 		if (n_rc < MAX_ALT + 1) rc_ids[n_rc++] = (int32_t)id;
 		ctx_rev = ((ctx_rev << 2) + (rc ? 1u : 0u)) & 0xf;
 	};
-	emit_read_id(em, ref_id, cur_read_id);
-	rev_comp_flag(ref_id, ref_rev);
-	const uint32_t s3 = 3 * ft.T;
 	RefCur mainc, altc;
-	mainc.set(R, ref_id, ref_rev);
-	while (rd.next(type, v1, v2))
+	uint32_t t_idx = 0;                                                          // tuples of the script done
+	if (j == 0)
 	{
+		// read-type history: types of the four previous reads, also across calls (dna_coder.cpp:440-463)
+		uint32_t ctx_rt = 0;
+		for (uint32_t t = 1; t <= 4; ++t)
+		{
+			uint32_t f = (r >= t) ? read_flag[r - t] : ((prev_types >> (2 * (t - 1 - r))) & 3u);
+			ctx_rt |= f << (2 * (t - 1));
+		}
+		const uint32_t flag = type == T_START_PLAIN ? 0u : type == T_START_PLAIN_N ? 1u : 2u;
+		em(F_READ_TYPE, ctx_rt, flag);
+		emit_read_len(em, ntup - 1);
+		if (type == T_START_PLAIN || type == T_START_PLAIN_N)
+		{
+			if (!WRITE) { hdr_counts[r] = em.count; counts[r] = em.count + (ntup - 1); }
+			return;
+		}
+		emit_read_id(em, ref_id, cur_read_id);
+		rev_comp_flag(ref_id, ref_rev);
+	}
+	else
+	{	// resume where the count pass was after j * WALK_CHUNK tuples
+		const WalkCk& k = cks[c];
+		rd = EsReader{ es + es_off[r] + k.byte_off, es + es_off[r + 1] };
+		em.count = k.sym;
+		ctx_tuple = k.ctx_tuple; ctx_symbol = k.ctx_symbol; ref_pos = k.ref_pos; alt_pos = k.alt_pos;
+		ctx_rev = k.ctx_rev; n_rc = k.n_rc; n_alt = k.n_alt; alt_id = k.alt_id; alt_slot = k.alt_slot; delta = k.delta; last_type = k.last_type; last_flag = k.last_flag;
+		is_main = k.flags & 1; first = (k.flags >> 1) & 1; alt_rev = (k.flags >> 2) & 1;
+		for (uint32_t i = 0; i < n_rc; ++i) rc_ids[i] = k.rc_ids[i];
+		for (uint32_t i = 0; i < n_alt; ++i) { alt_ids[i] = k.alt_ids[i]; alt_pos_of[i] = k.alt_pos_of[i]; alt_rev_of[i] = k.alt_rev_of[i]; }
+		if (alt_slot >= 0) altc.set(R, alt_id, alt_rev);
+		t_idx = j * WALK_CHUNK;
+	}
+	const uint32_t stop = WRITE && j + 1 < n_ch ? (j + 1) * WALK_CHUNK : 0xffffffffu;
+	const uint32_t s3 = 3 * ft.T;
+	mainc.set(R, ref_id, ref_rev);
+	for (;;)
+	{
+		if (!WRITE && t_idx && t_idx % WALK_CHUNK == 0 && t_idx / WALK_CHUNK < n_ch && rd.p < rd.e)
+		{
+			WalkCk& k = cks[c + t_idx / WALK_CHUNK];
+			k.byte_off = (uint64_t)(rd.p - (es + es_off[r])); k.sym = em.count;
+			k.ctx_tuple = ctx_tuple; k.ctx_symbol = ctx_symbol; k.ref_pos = ref_pos; k.alt_pos = alt_pos;
+			k.ctx_rev = ctx_rev; k.n_rc = n_rc; k.n_alt = n_alt; k.alt_id = alt_id; k.alt_slot = alt_slot; k.delta = delta; k.last_type = last_type; k.last_flag = last_flag;
+			k.flags = (is_main ? 1u : 0u) | (first ? 2u : 0u) | (alt_rev ? 4u : 0u);
+			for (uint32_t i = 0; i < n_rc; ++i) k.rc_ids[i] = rc_ids[i];
+			for (uint32_t i = 0; i < n_alt; ++i) { k.alt_ids[i] = alt_ids[i]; k.alt_pos_of[i] = alt_pos_of[i]; k.alt_rev_of[i] = alt_rev_of[i]; }
+		}
+		if (t_idx == stop || !rd.next(type, v1, v2)) break;
+		++t_idx;
 		const uint32_t ref_symbol = is_main ? mainc.at(R, ref_pos) : altc.at(R, alt_pos);
 		{	// encode_tuple_type (:651-710) with the guard case moved to its own dense region
 			uint32_t cls = delta < -10 ? 1u : delta < -1 ? 2u : delta > 10 ? 3u : delta > 1 ? 4u : 0u;
@@ -338,7 +396,11 @@ __global__ __launch_bounds__(64) void k_dna_walk(const FamTab* __restrict__ ftp,
 		}
 		last_type = type;
 	}
-	if (!WRITE) { hdr_counts[r - r0] = em.count; counts[r - r0] = em.count; }
+	if (!WRITE)
+	{
+		hdr_counts[r] = em.count; counts[r] = em.count;
+		if (t_idx != ntup - 1 && err) atomicOr(err, 2u);                            // the chunks rely on the tuple counts
+	}
 }
 
 // first tuple of every read -> read-type flag (0 plain, 1 plain with N, 2 edit script)
@@ -863,18 +925,30 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 		HIP_TRY(ctx, hipMemcpyAsync(&h_eb[0], d_es_off, 8, hipMemcpyDeviceToHost, ctx->stream));
 		HIP_TRY(ctx, hipMemcpyAsync(&h_eb[1], d_es_off + n_reads, 8, hipMemcpyDeviceToHost, ctx->stream));
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		DevBuf<uint64_t> chunk_off; DEV_ALLOC(ctx, chunk_off, (uint64_t)n_reads + 1);
+		DevBuf<WalkCk> cks; uint64_t n_chunks = 0;
 		{
 			DevBuf<uint32_t> counts; DEV_ALLOC(ctx, counts, n_reads);
 			LAUNCH(ctx, k_read_flags, grid_for(n_reads, 256), 256, d_es, d_es_off, 0u, n_reads, rflag.p);
-			LAUNCHB(ctx, (double)(h_eb[1] - h_eb[0]) + 8.0 * n_reads, (k_dna_walk<false>), grid_for(n_reads, WALK_LPW), 64, /* tuple bytes in, one count out */ (const FamTab*)D->d_ft.p, R, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, 0u, n_reads,
-				D->prev_types, D->cur_read_id, nolay, counts.p, hdr.p, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, err.p);
+			LAUNCH(ctx, k_walk_chunks, grid_for(n_reads, 256), 256, d_es_ntuples, (const uint8_t*)rflag.p, n_reads, counts.p);
+			CL_TRY(dev_exclusive_scan_u64(ctx, counts.p, chunk_off.p, n_reads, &n_chunks));
+			if (n_chunks >= (1ull << 32)) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_dna_encode: too many tuples in one call");
+			DEV_ALLOC(ctx, cks, n_chunks);
+			LAUNCHB(ctx, (double)(h_eb[1] - h_eb[0]) + 8.0 * n_reads + (double)n_chunks * sizeof(WalkCk), (k_dna_walk<false>), grid_for(n_reads, WALK_LPW), 64, /* tuple bytes in, one count and the chunk states out */
+				(const FamTab*)D->d_ft.p, R, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, n_reads,
+				D->prev_types, D->cur_read_id, (const uint64_t*)chunk_off.p, cks.p, (uint32_t)n_chunks, counts.p, hdr.p, (const uint64_t*)nullptr, (uint64_t*)nullptr, err.p);
 			HIP_TRY(ctx, hipGetLastError());
 			CL_TRY(dev_exclusive_scan_u64(ctx, counts.p, sym_off.p, n_reads, &total_syms));
 		}
 		HIP_TRY(ctx, hipMemcpy(h_sym_off.data(), sym_off.p, ((uint64_t)n_reads + 1) * 8, hipMemcpyDeviceToHost));
+		uint32_t herr0 = 0;
+		HIP_TRY(ctx, hipMemcpy(&herr0, err.p, 4, hipMemcpyDeviceToHost));
+		if (herr0 & 2) return cl_fail(ctx, CL_E_INVALID, "cl_dna_encode: the tuple count of a read does not match its stream");
+		if (herr0) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_dna_encode: a read uses more than 64 alternative references");
 		DEV_ALLOC(ctx, key, total_syms);
-		LAUNCHB(ctx, total_syms * 9.0, (k_dna_walk<true>), grid_for(n_reads, WALK_LPW), 64, /* tuple bytes in (<= 1 per symbol), 8 bytes per symbol out */ (const FamTab*)D->d_ft.p, R, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, 0u, n_reads,
-			D->prev_types, D->cur_read_id, nolay, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint64_t*)sym_off.p, key.p, (uint32_t*)nullptr, err.p);
+		LAUNCHB(ctx, total_syms * 9.0, (k_dna_walk<true>), grid_for(n_chunks, WALK_LPW), 64, /* tuple bytes in (<= 1 per symbol), 8 bytes per symbol out */
+			(const FamTab*)D->d_ft.p, R, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, n_reads,
+			D->prev_types, D->cur_read_id, (const uint64_t*)chunk_off.p, cks.p, (uint32_t)n_chunks, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint64_t*)sym_off.p, key.p, err.p);
 		LAUNCH(ctx, k_dna_plain, grid_for(n_reads, 4), 256, (const FamTab*)D->d_ft.p, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, (const uint32_t*)hdr.p,
 			(const uint64_t*)sym_off.p, 0u, n_reads, key.p);
 		HIP_TRY(ctx, hipGetLastError());
