@@ -166,8 +166,11 @@ __device__ inline void emit_skip_len(Emitter& em, uint32_t len, bool local)     
 // a 170 k-tuple read takes ~0.1 s however idle the machine is.  So the walk is done twice, differently:
 //   count pass  one lane per READ: counts the symbols and, every WALK_CHUNK tuples, saves the state of the walk;
 //   write pass  one lane per CHUNK: resumes from the saved state and writes the keys of its WALK_CHUNK tuples.
-// The count pass is the shorter chain (no reference symbols, no stores); the write pass is bounded by a chunk, not a read.
-constexpr uint32_t WALK_LPW = 64, WALK_CHUNK = 4096;
+// The count pass is the shorter chain: no stores, one-byte tuples eight at a time, and the symbol history (the only state
+// that needs reference symbols) only over the WALK_WARM tuples before a saved state — enough unless fewer than S of
+// them add a symbol, in which case the read is walked again keeping the history throughout.  The write pass is bounded
+// by a chunk, not a read.
+constexpr uint32_t WALK_LPW = 64, WALK_CHUNK = 4096, WALK_WARM = 128;
 struct WalkCk {
 	uint64_t byte_off, ctx_tuple, ctx_symbol; int64_t ref_pos, alt_pos;
 	uint32_t read, sym, ctx_rev, n_rc, n_alt, alt_id; int32_t alt_slot, delta; uint32_t last_type, last_flag, flags, pad;   // flags: is_main | first << 1 | alt_rev << 2
@@ -206,6 +209,8 @@ __global__ __launch_bounds__(64) void k_dna_walk(const FamTab* __restrict__ ftp,
 	}
 	const uint32_t n_ch = (uint32_t)(chunk_off[r + 1] - chunk_off[r]);
 	if (!WRITE) for (uint32_t x = 0; x < n_ch; ++x) cks[c + x].read = r;
+	bool track_all = WRITE;                                                      // symbol history kept throughout
+restart:
 	Emitter em{ WRITE, key, WRITE ? sym_off[r] : 0, 0, &ft };
 	EsReader rd{ es + es_off[r], es + es_off[r + 1] };
 	uint32_t type = T_NONE, v1 = 0, v2 = 0;
@@ -264,10 +269,13 @@ __global__ __launch_bounds__(64) void k_dna_walk(const FamTab* __restrict__ ftp,
 	const uint32_t stop = WRITE && j + 1 < n_ch ? (j + 1) * WALK_CHUNK : 0xffffffffu;
 	const uint32_t s3 = 3 * ft.T;
 	mainc.set(R, ref_id, ref_rev);
+	uint32_t known = 0;                                                          // symbols in ctx_symbol since the history is kept
 	for (;;)
 	{
 		if (!WRITE && t_idx && t_idx % WALK_CHUNK == 0 && t_idx / WALK_CHUNK < n_ch && rd.p < rd.e)
 		{
+			if (!track_all && known < (uint32_t)ft.S) { track_all = true; goto restart; }
+			known = 0;
 			WalkCk& k = cks[c + t_idx / WALK_CHUNK];
 			k.byte_off = (uint64_t)(rd.p - (es + es_off[r])); k.sym = em.count;
 			k.ctx_tuple = ctx_tuple; k.ctx_symbol = ctx_symbol; k.ref_pos = ref_pos; k.alt_pos = alt_pos;
@@ -276,9 +284,37 @@ __global__ __launch_bounds__(64) void k_dna_walk(const FamTab* __restrict__ ftp,
 			for (uint32_t i = 0; i < n_rc; ++i) k.rc_ids[i] = rc_ids[i];
 			for (uint32_t i = 0; i < n_alt; ++i) { k.alt_ids[i] = alt_ids[i]; k.alt_pos_of[i] = alt_pos_of[i]; k.alt_rev_of[i] = alt_rev_of[i]; }
 		}
-		if (t_idx == stop || !rd.next(type, v1, v2)) break;
+		if (t_idx == stop) break;
+		bool track = true;
+		if (!WRITE)
+		{
+			const uint32_t q = t_idx % WALK_CHUNK;
+			const bool ck_ahead = t_idx / WALK_CHUNK + 1 < n_ch;
+			track = track_all || (ck_ahead && q >= WALK_CHUNK - WALK_WARM);
+			if (!track) known = 0;
+			if (!track && (!ck_ahead || q + 8 <= WALK_CHUNK - WALK_WARM) && rd.e - rd.p >= 8)
+			{	// eight one-byte tuples (insertion, deletion, match, substitution: types 0..3 in the high nibble) at once
+				if (rd.have < 8) rd.refill();
+				const uint64_t w = rd.w0;
+				if (!(w & 0xC0C0C0C0C0C0C0C0ull))
+				{
+					const uint64_t b4 = (w >> 4) & 0x0101010101010101ull, b5 = (w >> 5) & 0x0101010101010101ull;
+					const uint32_t n_sub = (uint32_t)__popcll(b4 & b5), n_del = (uint32_t)__popcll(b4 & ~b5), n_mat = (uint32_t)__popcll(b5 & ~b4), n_ins = 8 - n_sub - n_del - n_mat;
+					em.count += 8 + n_ins + n_sub;                                      // a tuple-type symbol each, a base for insertions and substitutions
+					delta += (int32_t)n_ins - (int32_t)n_del;
+					if (is_main) ref_pos += n_del + n_mat + n_sub; else alt_pos += n_del + n_mat + n_sub;
+#pragma unroll
+					for (int x = 0; x < 8; ++x) ctx_tuple = ((ctx_tuple << 3) + ((w >> (8 * x + 4)) & 3)) & mask_tuple;
+					first = false; last_flag = last_type = (uint32_t)(w >> 60) & 3;
+					rd.p += 8; rd.have -= 8; rd.w0 = rd.w1; rd.w1 = 0;
+					t_idx += 8;
+					continue;
+				}
+			}
+		}
+		if (!rd.next(type, v1, v2)) break;
 		++t_idx;
-		const uint32_t ref_symbol = is_main ? mainc.at(R, ref_pos) : altc.at(R, alt_pos);
+		const uint32_t ref_symbol = !track ? 0u : is_main ? mainc.at(R, ref_pos) : altc.at(R, alt_pos);
 		{	// encode_tuple_type (:651-710) with the guard case moved to its own dense region
 			uint32_t cls = delta < -10 ? 1u : delta < -1 ? 2u : delta > 10 ? 3u : delta > 1 ? 4u : 0u;
 			uint32_t c = (uint32_t)ctx_tuple | ((uint32_t)(ctx_symbol & 0xf) << s3);
@@ -330,13 +366,17 @@ __global__ __launch_bounds__(64) void k_dna_walk(const FamTab* __restrict__ ftp,
 		case T_ANCHOR:
 			emit_anchor_len(em, v2);
 			if (is_main) ref_pos += v2; else alt_pos += v2;
-			for (int i = ft.S; i > 0; --i)
-				ctx_symbol = (ctx_symbol << 2) + (is_main ? mainc.at(R, ref_pos - i) : altc.at(R, alt_pos - i));
-			ctx_symbol &= mask_symbol;
+			if (track)
+			{
+				for (int i = ft.S; i > 0; --i)
+					ctx_symbol = (ctx_symbol << 2) + (is_main ? mainc.at(R, ref_pos - i) : altc.at(R, alt_pos - i));
+				ctx_symbol &= mask_symbol;
+				known = (uint32_t)ft.S;
+			}
 			delta = 0;
 			break;
 		case T_MATCH:
-			ctx_symbol = ((ctx_symbol << 2) + ref_symbol) & mask_symbol;
+			ctx_symbol = ((ctx_symbol << 2) + ref_symbol) & mask_symbol; ++known;
 			if (is_main) ++ref_pos; else ++alt_pos;
 			break;
 		case T_INS:
@@ -350,7 +390,7 @@ __global__ __launch_bounds__(64) void k_dna_walk(const FamTab* __restrict__ ftp,
 			c += (uint32_t)(ctx_tuple & 0777) << shift;
 			if (guard) c += 1u << ft.sym_B;
 			em(F_SYMBOLS, c, v1);
-			ctx_symbol = ((ctx_symbol << 2) + v1) & mask_symbol;
+			ctx_symbol = ((ctx_symbol << 2) + v1) & mask_symbol; ++known;
 			++delta;
 			break;
 		}
@@ -369,7 +409,7 @@ __global__ __launch_bounds__(64) void k_dna_walk(const FamTab* __restrict__ ftp,
 			c += rs << shift; shift += 2;
 			c += (uint32_t)(ctx_tuple & 07777) << shift;
 			em(F_SYMBOLS, c, sym, (int)rs);
-			ctx_symbol = ((ctx_symbol << 2) + sym) & mask_symbol;
+			ctx_symbol = ((ctx_symbol << 2) + sym) & mask_symbol; ++known;
 			if (is_main) ++ref_pos; else ++alt_pos;
 			break;
 		}
