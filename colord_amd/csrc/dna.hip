@@ -27,6 +27,7 @@ struct FamTab {
 	uint32_t sym_B;                     // bit width of the regular symbols-family contexts
 	uint32_t max_alt;
 	uint32_t long_run;                  // runs of a small-alphabet model at least this long take the k_long_* path
+	uint32_t walk_chunk, walk_warm;     // tuples per chunk of the write pass; tuples before a saved state with the symbol history kept
 };
 
 struct RefStore { const uint64_t* packed; const uint64_t* word_off; const uint32_t* lens; uint32_t n; };
@@ -170,19 +171,19 @@ __device__ inline void emit_skip_len(Emitter& em, uint32_t len, bool local)     
 // that needs reference symbols) only over the WALK_WARM tuples before a saved state — enough unless fewer than S of
 // them add a symbol, in which case the read is walked again keeping the history throughout.  The write pass is bounded
 // by a chunk, not a read.
-constexpr uint32_t WALK_LPW = 64, WALK_CHUNK = 4096, WALK_WARM = 128;
+constexpr uint32_t WALK_LPW = 64, WALK_CHUNK = 4096, WALK_WARM = 128;   // defaults of FamTab::walk_chunk / walk_warm (COLORD_HIP_WALK_CHUNK / _WARM override them, for tests)
 struct WalkCk {
 	uint64_t byte_off, ctx_tuple, ctx_symbol; int64_t ref_pos, alt_pos;
 	uint32_t read, sym, ctx_rev, n_rc, n_alt, alt_id; int32_t alt_slot, delta; uint32_t last_type, last_flag, flags, pad;   // flags: is_main | first << 1 | alt_rev << 2
 	int32_t rc_ids[MAX_ALT + 1], alt_ids[MAX_ALT], alt_pos_of[MAX_ALT]; uint8_t alt_rev_of[MAX_ALT];
 };
 // chunks of every read: plain reads (their bases are left to k_dna_plain) and empty scripts have one, for the header symbols
-__global__ void k_walk_chunks(const uint32_t* __restrict__ es_ntup, const uint8_t* __restrict__ read_flag, uint32_t n, uint32_t* __restrict__ out)
+__global__ void k_walk_chunks(const uint32_t* __restrict__ es_ntup, const uint8_t* __restrict__ read_flag, uint32_t n, uint32_t chunk, uint32_t* __restrict__ out)
 {
 	const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= n) return;
 	const uint32_t t = es_ntup[r] ? es_ntup[r] - 1 : 0;
-	out[r] = read_flag[r] != 2 || t == 0 ? 1u : (t + WALK_CHUNK - 1) / WALK_CHUNK;
+	out[r] = read_flag[r] != 2 || t == 0 ? 1u : (t + chunk - 1) / chunk;
 }
 template<bool WRITE>
 __global__ __launch_bounds__(64) void k_dna_walk(const FamTab* __restrict__ ftp, RefStore R, const uint8_t* __restrict__ es, const uint64_t* __restrict__ es_off,
@@ -194,6 +195,7 @@ __global__ __launch_bounds__(64) void k_dna_walk(const FamTab* __restrict__ ftp,
 	__shared__ FamTab ft;
 	for (uint32_t i = threadIdx.x; i < sizeof(FamTab) / 4; i += blockDim.x) ((uint32_t*)&ft)[i] = ((const uint32_t*)ftp)[i];
 	__syncthreads();
+	const uint32_t CH = ft.walk_chunk, WARM = ft.walk_warm;
 	uint32_t r, c, j = 0;                                                        // read, chunk, chunk index within the read
 	if (WRITE)
 	{
@@ -254,7 +256,7 @@ restart:
 		rev_comp_flag(ref_id, ref_rev);
 	}
 	else
-	{	// resume where the count pass was after j * WALK_CHUNK tuples
+	{	// resume where the count pass was after j * CH tuples
 		const WalkCk& k = cks[c];
 		rd = EsReader{ es + es_off[r] + k.byte_off, es + es_off[r + 1] };
 		em.count = k.sym;
@@ -264,19 +266,19 @@ restart:
 		for (uint32_t i = 0; i < n_rc; ++i) rc_ids[i] = k.rc_ids[i];
 		for (uint32_t i = 0; i < n_alt; ++i) { alt_ids[i] = k.alt_ids[i]; alt_pos_of[i] = k.alt_pos_of[i]; alt_rev_of[i] = k.alt_rev_of[i]; }
 		if (alt_slot >= 0) altc.set(R, alt_id, alt_rev);
-		t_idx = j * WALK_CHUNK;
+		t_idx = j * CH;
 	}
-	const uint32_t stop = WRITE && j + 1 < n_ch ? (j + 1) * WALK_CHUNK : 0xffffffffu;
+	const uint32_t stop = WRITE && j + 1 < n_ch ? (j + 1) * CH : 0xffffffffu;
 	const uint32_t s3 = 3 * ft.T;
 	mainc.set(R, ref_id, ref_rev);
 	uint32_t known = 0;                                                          // symbols in ctx_symbol since the history is kept
 	for (;;)
 	{
-		if (!WRITE && t_idx && t_idx % WALK_CHUNK == 0 && t_idx / WALK_CHUNK < n_ch && rd.p < rd.e)
+		if (!WRITE && t_idx && t_idx % CH == 0 && t_idx / CH < n_ch && rd.p < rd.e)
 		{
 			if (!track_all && known < (uint32_t)ft.S) { track_all = true; goto restart; }
 			known = 0;
-			WalkCk& k = cks[c + t_idx / WALK_CHUNK];
+			WalkCk& k = cks[c + t_idx / CH];
 			k.byte_off = (uint64_t)(rd.p - (es + es_off[r])); k.sym = em.count;
 			k.ctx_tuple = ctx_tuple; k.ctx_symbol = ctx_symbol; k.ref_pos = ref_pos; k.alt_pos = alt_pos;
 			k.ctx_rev = ctx_rev; k.n_rc = n_rc; k.n_alt = n_alt; k.alt_id = alt_id; k.alt_slot = alt_slot; k.delta = delta; k.last_type = last_type; k.last_flag = last_flag;
@@ -288,11 +290,11 @@ restart:
 		bool track = true;
 		if (!WRITE)
 		{
-			const uint32_t q = t_idx % WALK_CHUNK;
-			const bool ck_ahead = t_idx / WALK_CHUNK + 1 < n_ch;
-			track = track_all || (ck_ahead && q >= WALK_CHUNK - WALK_WARM);
+			const uint32_t q = t_idx % CH;
+			const bool ck_ahead = t_idx / CH + 1 < n_ch;
+			track = track_all || (ck_ahead && q >= CH - WARM);
 			if (!track) known = 0;
-			if (!track && (!ck_ahead || q + 8 <= WALK_CHUNK - WALK_WARM) && rd.e - rd.p >= 8)
+			if (!track && (!ck_ahead || q + 8 <= CH - WARM) && rd.e - rd.p >= 8)
 			{	// eight one-byte tuples (insertion, deletion, match, substitution: types 0..3 in the high nibble) at once
 				if (rd.have < 8) rd.refill();
 				const uint64_t w = rd.w0;
@@ -905,6 +907,10 @@ extern "C" cl_status cl_dna_coder_create(cl_ctx* ctx, uint32_t max_alt_refs, int
 	f.sym_B = level == 3 ? 24 : level == 2 ? 23 : 22;
 	f.long_run = LONG_RUN;
 	if (const char* lr = getenv("COLORD_HIP_LONG_RUN")) f.long_run = (uint32_t)std::max(64, atoi(lr));
+	f.walk_chunk = WALK_CHUNK; f.walk_warm = WALK_WARM;
+	if (const char* v = getenv("COLORD_HIP_WALK_CHUNK")) f.walk_chunk = (uint32_t)std::min(1 << 20, std::max(32, atoi(v)));
+	if (const char* v = getenv("COLORD_HIP_WALK_WARM")) f.walk_warm = (uint32_t)std::max(0, atoi(v));
+	f.walk_warm = std::min(f.walk_warm, f.walk_chunk / 2);
 	auto set = [&](int i, uint32_t ns, uint32_t mt, uint32_t ad, uint32_t nc) { f.n_sym[i] = ns; f.max_total[i] = mt; f.adder[i] = ad; f.n_ctx[i] = nc; };
 	set(F_READ_TYPE, 3, 1u << 15, 1, 256);                  // dna_coder.h:48-60
 	set(F_REV_COMP, 2, 1u << 15, 1, 16);
@@ -970,7 +976,7 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 		{
 			DevBuf<uint32_t> counts; DEV_ALLOC(ctx, counts, n_reads);
 			LAUNCH(ctx, k_read_flags, grid_for(n_reads, 256), 256, d_es, d_es_off, 0u, n_reads, rflag.p);
-			LAUNCH(ctx, k_walk_chunks, grid_for(n_reads, 256), 256, d_es_ntuples, (const uint8_t*)rflag.p, n_reads, counts.p);
+			LAUNCH(ctx, k_walk_chunks, grid_for(n_reads, 256), 256, d_es_ntuples, (const uint8_t*)rflag.p, n_reads, f.walk_chunk, counts.p);
 			CL_TRY(dev_exclusive_scan_u64(ctx, counts.p, chunk_off.p, n_reads, &n_chunks));
 			if (n_chunks >= (1ull << 32)) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_dna_encode: too many tuples in one call");
 			DEV_ALLOC(ctx, cks, n_chunks);

@@ -106,3 +106,19 @@ def test_long_context_runs_take_the_parallel_path(ctx, cfg, long_run, monkeypatc
     parts = gpu_dna(ctx, g, bounds)
     got = [[int(bounds[i + 1] - bounds[i]), len(p), hashlib.sha256(p).hexdigest()] for i, p in enumerate(parts)]
     assert got == g.spec["streams"]["dna"]["parts"]
+
+
+@pytest.mark.parametrize("cfg", ["s6m_ont", "c3_clr_ratio", "s5m_hifi"])
+@pytest.mark.parametrize("chunk,warm", [("32", "16"), ("64", "0"), ("256", "4"), ("1000", "128")])
+def test_walk_chunks_resume_the_same_walk(ctx, cfg, chunk, warm, monkeypatch):
+    """The write pass of the tuple walk resumes from states the count pass saved every `chunk` tuples, and the count pass
+    keeps the symbol history only over the `warm` tuples before a saved state (a read is walked again with the history
+    throughout when that was not enough: always with warm = 0).  Small chunks put many resumes into the golden streams,
+    which must still be byte-identical to the reference."""
+    monkeypatch.setenv("COLORD_HIP_WALK_CHUNK", chunk)
+    monkeypatch.setenv("COLORD_HIP_WALK_WARM", warm)
+    g = golden(cfg)
+    bounds = g.reads.pack_bounds()
+    parts = gpu_dna(ctx, g, bounds)
+    got = [[int(bounds[i + 1] - bounds[i]), len(p), hashlib.sha256(p).hexdigest()] for i, p in enumerate(parts)]
+    assert got == g.spec["streams"]["dna"]["parts"]
