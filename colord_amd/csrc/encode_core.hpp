@@ -688,12 +688,14 @@ struct SegWriter {
 	TupleOut* o; char sym; uint32_t rep; bool open, first; uint32_t main_id;
 	uint32_t level, ref_id, rev, last_pos;
 	CL_DEV inline void flush_run()
-	{
+	{	// (one t28 and one t1 call site: their inlined bodies are large)
 		if (!rep) return;
-		if (sym == 'M') { if (rep >= 15) o->t28(4, rep); else for (uint32_t i = 0; i < rep; ++i) o->t1(2, 0); }
-		else if (sym == 'D') { if (rep > 16) o->t28(5, rep); else for (uint32_t i = 0; i < rep; ++i) o->t1(1, 0); }
-		else if (sym == 'X' || sym == 'Y' || sym == 'Z') { for (uint32_t i = 0; i < rep; ++i) o->t1(3, (uint32_t)(sym - 'X')); }
-		else { const uint32_t code = sym == 'A' ? 0 : sym == 'C' ? 1 : sym == 'G' ? 2 : 3; for (uint32_t i = 0; i < rep; ++i) o->t1(0, code); }
+		uint32_t type, val = 0;
+		if (sym == 'M') type = 2; else if (sym == 'D') type = 1;
+		else if (sym == 'X' || sym == 'Y' || sym == 'Z') { type = 3; val = (uint32_t)(sym - 'X'); }
+		else { type = 0; val = sym == 'A' ? 0 : sym == 'C' ? 1 : sym == 'G' ? 2 : 3; }
+		if ((type == 2 && rep >= 15) || (type == 1 && rep > 16)) o->t28(type == 2 ? 4 : 5, rep);
+		else for (uint32_t i = 0; i < rep; ++i) o->t1(type, val);
 		rep = 0;
 	}
 	CL_DEV inline void run(char s, uint32_t n) { if (rep && s == sym) { rep += n; return; } flush_run(); sym = s; rep = n; }
@@ -712,9 +714,21 @@ struct SegWriter {
 	CL_DEV inline bool store() { const bool had = open; if (open) { flush_run(); first = false; } open = false; return had; }
 };
 
+// A saved state of the walk below at the top of its loop (`it` fragments done, `n` bytes / `n_tuples` tuples out, the
+// open run in (sym, rep)).  The count pass of the kernels saves one every few KB of output, so that the write pass can
+// run one lane per CHUNK, not per read: the chunk that starts at the state ends at (stop_it, stop_q).  States are saved
+// between fragments and, every 32 symbols, inside the scripts of gaps (a gap can be most of a read).
+struct EmitCk {
+	uint32_t read, used; uint64_t start_it, stop_it, n; uint32_t mid_q, stop_q;     // mid_q / stop_q != 0: inside the script of fragment start_it / stop_it, at that symbol
+	uint32_t sf[10], si[10], s_last[10], s_cur[10]; int32_t sp; uint32_t enter, n_tuples;
+	uint32_t sym, rep, open, first, main_id, level, ref_id, rev, last_pos, pad;
+};
+// WRITE = false: sizes / tuple counts of read r; with cks != nullptr also the saved states, one per `chunk` output bytes, in
+// its n_slots slots (slot 0 = the start of the read).  WRITE = true: the whole read (ck == nullptr) or the chunk of *ck.
 template<bool WRITE>
 CL_DEV inline void emit_read(const ArenaV& A, const uint32_t* inv, const uint8_t* has_n, const TreeV& T, uint32_t r, const uint32_t* anchors_data,
-                             uint32_t* sizes, uint32_t* ntuples, const uint64_t* es_off, uint8_t* out)
+                             uint32_t* sizes, uint32_t* ntuples, const uint64_t* es_off, uint8_t* out,
+                             EmitCk* cks = nullptr, uint32_t n_slots = 0, uint32_t chunk = 1, const EmitCk* ck = nullptr)
 {
 	const uint32_t len = A.lens[r]; const uint64_t wb = A.word_off[r];
 	TupleOut o{ WRITE ? out + es_off[r] : nullptr, 0, 0, WRITE };
@@ -744,17 +758,45 @@ CL_DEV inline void emit_read(const ArenaV& A, const uint32_t* inv, const uint8_t
 		const FrameRec& F = T.lv[0].frames[f0];
 		const CandEnt& M = T.lv[0].cands[F.cand_base];
 		w.main_id = M.ref_id;
-		o.tid(10, M.ref_id, M.rev);                                   // start_es (encoder.cpp:1523-1527)
+		if (!(WRITE && ck && ck->start_it)) o.tid(10, M.ref_id, M.rev);  // start_es (encoder.cpp:1523-1527)
 	}
 	bool enter = true;
-	while (sp >= 0)
+	uint64_t it = 0, stop = ~0ull; uint32_t last_k = 0, prev_slot = 0, stop_q = 0, mid_q = 0;
+	if (WRITE && ck)
 	{
+		stop = ck->stop_it; stop_q = ck->stop_q;
+		if (ck->start_it)
+		{	// resume at the saved state
+			for (int i = 0; i < 10; ++i) { sf[i] = ck->sf[i]; si[i] = ck->si[i]; s_last[i] = ck->s_last[i]; s_cur[i] = ck->s_cur[i]; }
+			sp = ck->sp; enter = ck->enter != 0; it = ck->start_it; mid_q = ck->mid_q;
+			o.n = ck->n; o.n_tuples = ck->n_tuples; o.aligned = (((uint64_t)(size_t)o.p + o.n) & 7) == 0;
+			w.sym = (char)ck->sym; w.rep = ck->rep; w.open = ck->open != 0; w.first = ck->first != 0; w.main_id = ck->main_id;
+			w.level = ck->level; w.ref_id = ck->ref_id; w.rev = ck->rev; w.last_pos = ck->last_pos;
+		}
+	}
+	if (!WRITE && cks) { cks[0].read = r; cks[0].used = 1; cks[0].start_it = 0; cks[0].stop_it = ~0ull; cks[0].mid_q = 0; cks[0].stop_q = 0; }
+	auto save_state = [&](uint32_t q) {          // count pass: a state per `chunk` output bytes
+		const uint32_t k = (uint32_t)(o.n / chunk);
+		if (k <= last_k || k >= n_slots) return;
+		EmitCk& c = cks[k];
+		for (int i = 0; i < 10; ++i) { c.sf[i] = sf[i]; c.si[i] = si[i]; c.s_last[i] = s_last[i]; c.s_cur[i] = s_cur[i]; }
+		c.sp = sp; c.enter = enter ? 1 : 0; c.n = o.n; c.n_tuples = o.n_tuples;
+		c.sym = (uint32_t)(uint8_t)w.sym; c.rep = w.rep; c.open = w.open ? 1 : 0; c.first = w.first ? 1 : 0; c.main_id = w.main_id;
+		c.level = w.level; c.ref_id = w.ref_id; c.rev = w.rev; c.last_pos = w.last_pos;
+		c.read = r; c.used = 1; c.start_it = it; c.mid_q = q; c.stop_it = ~0ull; c.stop_q = 0;
+		cks[prev_slot].stop_it = it; cks[prev_slot].stop_q = q; prev_slot = k; last_k = k;
+	};
+	for (;; ++it)
+	{
+		if (sp < 0 || (it == stop && stop_q == 0)) break;
+		const bool mid = mid_q != 0;                                   // resuming inside the script of this fragment
+		if (!WRITE && cks) save_state(0);
 		const LevelV& L = T.lv[sp];
 		const FrameRec& F = L.frames[sf[sp]];
 		const CandEnt& M = L.cands[F.cand_base + F.level];
 		if (enter) { w.level = F.level; w.ref_id = M.ref_id; w.rev = M.rev; w.last_pos = s_last[sp]; enter = false; }
 		const uint32_t n_frag = 2 * M.n + 1;
-		if (si[sp] == n_frag)
+		if (!mid && si[sp] == n_frag)
 		{	// final StoreFrag of the frame (encoder.cpp:1574)
 			if (w.store()) s_last[sp] = s_cur[sp];
 			--sp;
@@ -767,7 +809,7 @@ CL_DEV inline void emit_read(const ArenaV& A, const uint32_t* inv, const uint8_t
 			}
 			continue;
 		}
-		const uint32_t i = si[sp]++;
+		const uint32_t i = mid ? si[sp] - 1 : si[sp]++;
 		if (i & 1)
 		{
 			uint32_t al, ape, apr; cand_anchor(M, anchors_data, i >> 1, al, ape, apr);
@@ -779,18 +821,39 @@ CL_DEV inline void emit_read(const ArenaV& A, const uint32_t* inv, const uint8_t
 		const bool as_es = g.state == GS_ES || (g.state == GS_PENDING && L.dec[g.aux] != 0);
 		if (as_es)
 		{
-			w.add('D', g.d_before);
+			if (!mid) w.add('D', g.d_before);
 			const uint32_t* es4 = (const uint32_t*)(L.es + g.es_off);               // script slots are dword-aligned
-			for (uint32_t q = 0; q < g.es_len; q += 32)
+			bool stopped = false;
+			for (uint32_t q = mid_q; q < g.es_len; q += 32)
 			{	// eight independent loads in flight, then 32 symbols from registers (the walk is latency-bound otherwise)
+				if (q && q != mid_q)
+				{
+					if (!WRITE && cks) save_state(q);
+					if (WRITE && it == stop && q == stop_q) { stopped = true; break; }
+				}
 				uint32_t wd[8];
 #pragma unroll
 				for (uint32_t t = 0; t < 8; ++t) wd[t] = q + 4 * t < g.es_len ? es4[(q >> 2) + t] : 0u;
 				const uint32_t nb = g.es_len - q < 32 ? g.es_len - q : 32;
-#pragma unroll
-				for (uint32_t t = 0; t < 8; ++t)
-					for (uint32_t b2 = 0; b2 < 4; ++b2) if (4 * t + b2 < nb) w.add((char)((wd[t] >> (8 * b2)) & 0xff), 1);
+				// ONE call site of add() (its inlined body is large; 32 copies would not fit the instruction cache): the 32
+				// bytes go through a 256-bit shift register
+				uint64_t x0 = wd[0] | ((uint64_t)wd[1] << 32), x1 = wd[2] | ((uint64_t)wd[3] << 32), x2 = wd[4] | ((uint64_t)wd[5] << 32), x3 = wd[6] | ((uint64_t)wd[7] << 32);
+#pragma nounroll
+				for (uint32_t t = 0; t < nb;)
+				{	// a run of matches (up to 8) at once, else one symbol
+					const uint64_t nm = x0 ^ 0x4d4d4d4d4d4d4d4dull;
+					uint32_t cnt = nm ? (uint32_t)__builtin_ctzll(nm) >> 3 : 8u;
+					if (cnt > nb - t) cnt = nb - t;
+					if (cnt == 0) cnt = 1;
+					const char c = (char)(x0 & 0xff);
+					if (cnt == 8) { x0 = x1; x1 = x2; x2 = x3; x3 = 0; }
+					else { const uint32_t sh = 8 * cnt; x0 = (x0 >> sh) | (x1 << (64 - sh)); x1 = (x1 >> sh) | (x2 << (64 - sh)); x2 = (x2 >> sh) | (x3 << (64 - sh)); x3 >>= sh; }
+					w.add(c, cnt);
+					t += cnt;
+				}
 			}
+			mid_q = 0;
+			if (stopped) break;
 		}
 		else if (g.state == GS_CHILD)
 		{	// StoreFrag of what the parent has so far, then the child frame (encoder.cpp:1483-1488)

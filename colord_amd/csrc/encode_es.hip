@@ -585,15 +585,52 @@ __global__ __launch_bounds__(64) void k_estimator(TreeV T, const uint32_t* __res
 		}
 	}
 }
-constexpr uint32_t EMIT_LPW = 16;
-template<bool WRITE>
-__global__ __launch_bounds__(64) void k_emit_tuples(ArenaV A, const uint32_t* __restrict__ inv, const uint8_t* __restrict__ has_n, TreeV T, uint32_t n_reads, const uint32_t* __restrict__ data,
-                                                   uint32_t* __restrict__ sizes, uint32_t* __restrict__ ntuples, const uint64_t* __restrict__ es_off, uint8_t* __restrict__ out)
+// Tuple emission.  A read's tuples come out of one sequential walk over its frame tree (runs of equal symbols merge
+// across anchors and gaps), and one lane takes ~0.2 s for a 170 k-tuple read however idle the machine is.  So:
+//   k_emit_count  one lane per READ: sizes and tuple counts, and every EMIT_CHUNK output bytes the state of the walk;
+//   k_emit_write  one lane per saved STATE: resumes there and writes the bytes up to the next saved state;
+//   k_emit_plain  reads stored plain: one wave per read, one lane per base.
+constexpr uint32_t EMIT_LPW = 16, EMIT_WPW = 32, EMIT_CHUNK = 2048;
+__global__ void k_emit_slots(const uint32_t* __restrict__ lens, const uint32_t* __restrict__ frame_of_read, uint32_t n, uint32_t* __restrict__ out)
+{	// slots for saved states: a guess of the output size; a read with more output just gets longer last chunks
+	const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r < n) out[r] = frame_of_read[r] == 0xffffffffu ? 0u : lens[r] / EMIT_CHUNK + 2;
+}
+__global__ __launch_bounds__(64) void k_emit_count(ArenaV A, const uint32_t* __restrict__ inv, const uint8_t* __restrict__ has_n, TreeV T, uint32_t n_reads, const uint32_t* __restrict__ data,
+                                                  const uint64_t* __restrict__ slot_off, EmitCk* __restrict__ cks, uint32_t* __restrict__ sizes, uint32_t* __restrict__ ntuples)
 {	// EMIT_LPW reads per wave: the walk is divergent (every lane is somewhere else in its frame tree), and the machine has
 	// far more wave slots than a 64-reads-per-wave launch would use
 	if (threadIdx.x >= EMIT_LPW) return;
 	const uint32_t r = blockIdx.x * EMIT_LPW + threadIdx.x;
-	if (r < n_reads) emit_read<WRITE>(A, inv, has_n, T, r, data, sizes, ntuples, es_off, out);
+	if (r >= n_reads) return;
+	if (T.frame_of_read[r] == 0xffffffffu) { sizes[r] = A.lens[r] + 1; ntuples[r] = A.lens[r] + 1; return; }   // a start tuple and one tuple per base
+	const uint64_t base = slot_off[r];
+	emit_read<false>(A, inv, has_n, T, r, data, sizes, ntuples, nullptr, nullptr, cks + base, (uint32_t)(slot_off[r + 1] - base), EMIT_CHUNK, nullptr);
+}
+__global__ __launch_bounds__(64) void k_emit_write(ArenaV A, const uint32_t* __restrict__ inv, const uint8_t* __restrict__ has_n, TreeV T, const uint32_t* __restrict__ data,
+                                                  const EmitCk* __restrict__ cks, uint64_t n_slots, const uint64_t* __restrict__ es_off, uint8_t* __restrict__ out)
+{
+	if (threadIdx.x >= EMIT_WPW) return;
+	const uint64_t s = (uint64_t)blockIdx.x * EMIT_WPW + threadIdx.x;
+	if (s >= n_slots) return;
+	const EmitCk* k = cks + s;
+	if (!k->used) return;
+	emit_read<true>(A, inv, has_n, T, k->read, data, nullptr, nullptr, es_off, out, nullptr, 0, EMIT_CHUNK, k);
+}
+__global__ __launch_bounds__(256) void k_emit_plain(ArenaV A, const uint32_t* __restrict__ inv, const uint8_t* __restrict__ has_n, const uint32_t* __restrict__ frame_of_read, uint32_t n_reads,
+                                                   const uint64_t* __restrict__ es_off, uint8_t* __restrict__ out)
+{	// AddPlainRead / AddPlainReadWithN (encoder.cpp:663-681): a start tuple, then one tuple per base
+	const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+	if (r >= n_reads || frame_of_read[r] != 0xffffffffu) return;
+	const uint32_t len = A.lens[r]; const uint64_t wb = A.word_off[r];
+	uint8_t* o = out + es_off[r];
+	if (lane == 0) o[0] = (uint8_t)((has_n[r] ? 11 : 9) << 4);
+	for (uint32_t i = lane; i < len; i += 64)
+	{
+		const uint64_t pw = A.packed[wb + (i >> 5)]; const uint32_t iw = inv[wb + (i >> 5)];
+		const bool isn = (iw >> (31 - (i & 31))) & 1u;
+		o[1 + i] = (uint8_t)((8u << 4) + (isn ? 4u : (uint32_t)(pw >> (62 - 2 * (i & 31))) & 3u));
+	}
 }
 
 struct LevelBufs {
@@ -821,13 +858,20 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 	LAUNCH(ctx, k_pend_list, grid_for(nr, 64), 64, T, nr, (const uint64_t*)ev_off.p, events.p);
 	if (n_packs) LAUNCH(ctx, k_estimator, n_packs, 64, T, (const uint32_t*)d_pb.p, n_packs, (const uint32_t*)reads->lens.p, has_n, (const uint32_t*)base_counts.p, (const uint64_t*)ev_off.p, (const uint32_t*)events.p);
 	DevBuf<uint32_t> sizes; DEV_ALLOC(ctx, sizes, nr);
-	LAUNCHB(ctx, reads->total_bases * 1.25, (k_emit_tuples<false>), grid_for(nr, EMIT_LPW), 64, /* 2 bits per base + at most one script byte per base in */ A, (const uint32_t*)reads->inv.p, has_n, T, nr, AV.data, sizes.p, d_es_ntuples, (const uint64_t*)nullptr, (uint8_t*)nullptr);
+	DevBuf<uint64_t> slot_off; DEV_ALLOC(ctx, slot_off, (uint64_t)nr + 1);
+	uint64_t n_slots = 0;
+	LAUNCH(ctx, k_emit_slots, grid_for(nr, 256), 256, (const uint32_t*)reads->lens.p, (const uint32_t*)frame_of_read.p, nr, sizes.p);
+	CL_TRY(dev_exclusive_scan_u64(ctx, sizes.p, slot_off.p, nr, &n_slots));
+	DevBuf<EmitCk> cks; DEV_ALLOC(ctx, cks, n_slots + 1);
+	HIP_TRY(ctx, hipMemsetAsync(cks.p, 0, (n_slots + 1) * sizeof(EmitCk), st));
+	LAUNCHB(ctx, reads->total_bases * 1.25, k_emit_count, grid_for(nr, EMIT_LPW), 64, /* 2 bits per base + at most one script byte per base in */ A, (const uint32_t*)reads->inv.p, has_n, T, nr, AV.data, (const uint64_t*)slot_off.p, cks.p, sizes.p, d_es_ntuples);
 	HIP_TRY(ctx, hipGetLastError());
 	uint64_t total = 0;
 	CL_TRY(dev_exclusive_scan_u64(ctx, sizes.p, d_es_off, nr, &total));
 	*n_out = total;
 	if (total > cap || (total && !d_es)) return cl_fail(ctx, CL_E_CAPACITY, "cl_encode_reads: need " + std::to_string(total) + " bytes");
-	LAUNCHB(ctx, reads->total_bases * 1.25 + (double)total, (k_emit_tuples<true>), grid_for(nr, EMIT_LPW), 64, /* the same in + the tuple bytes out */ A, (const uint32_t*)reads->inv.p, has_n, T, nr, AV.data, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint64_t*)d_es_off, d_es);
+	if (n_slots) LAUNCHB(ctx, reads->total_bases * 1.25 + (double)total, k_emit_write, grid_for(n_slots, EMIT_WPW), 64, /* the same in + the tuple bytes out */ A, (const uint32_t*)reads->inv.p, has_n, T, AV.data, (const EmitCk*)cks.p, n_slots, (const uint64_t*)d_es_off, d_es);
+	LAUNCH(ctx, k_emit_plain, grid_for(nr, 4), 256, A, (const uint32_t*)reads->inv.p, has_n, (const uint32_t*)frame_of_read.p, nr, (const uint64_t*)d_es_off, d_es);
 	HIP_TRY(ctx, hipGetLastError());
 	HIP_TRY(ctx, hipStreamSynchronize(st));
 	cl_timing_collect(ctx);
