@@ -59,6 +59,11 @@ __device__ inline uint64_t ref_mmer(const Arena& R, uint32_t id, bool rev, uint3
 	return rev ? revcomp_m(mmer_at(R, wb, len - m - q, m), m) : mmer_at(R, wb, q, m);
 }
 
+// Per read: open-addressing table of its m-mers under their CANONICAL form (the smaller of the m-mer and its reverse
+// complement) with two position chains per key: heads[2 * slot] the positions where the read has the canonical form
+// itself, heads[2 * slot + 1] those where it has the other one.  One probe with a reference m-mer then serves both
+// orientations of the reference (the reference's two anchor analyses, encoder.cpp:1046-1066, probe the same hash of the
+// read with the m-mers of the reference and of its reverse complement).
 struct EncTable { uint64_t* keys; uint32_t* heads; const uint64_t* toff; uint32_t* next; const uint64_t* noff; };
 constexpr uint64_t KEY_EMPTY = ~0ULL;
 constexpr uint32_t NIL = 0xffffffffu;
@@ -89,88 +94,106 @@ __global__ __launch_bounds__(256) void k_table_insert(Arena A, uint32_t r0, uint
 	uint32_t fresh = 0;
 	for (uint32_t p = lane; p < n; p += 64)
 	{
-		const uint64_t x = mmer_at(A, wb, p, m);
+		const uint64_t xf = mmer_at(A, wb, p, m), xr = revcomp_m(xf, m), x = xf < xr ? xf : xr;
 		uint32_t h = (uint32_t)(hash_mm(x) >> 17) & (tsz - 1);
 		for (;;)
 		{
 			unsigned long long old = atomicCAS((unsigned long long*)&T.keys[t0 + h], (unsigned long long)KEY_EMPTY, (unsigned long long)x);
-			if (old == KEY_EMPTY) { ++fresh; break; }
-			if (old == x) break;
+			if (old == KEY_EMPTY || old == x) break;
 			h = (h + 1) & (tsz - 1);
 		}
-		T.next[n0 + p] = atomicExch(&T.heads[t0 + h], p);
+		const uint32_t prev = atomicExch(&T.heads[2 * (t0 + h) + (xf != x ? 1 : 0)], p);
+		T.next[n0 + p] = prev;
+		if (prev == NIL) ++fresh;                                       // first position with this m-mer: distinct m-mers of the read
 	}
 	fresh = wave_sum(fresh);
 	if (lane == 0) n_distinct[r - r0] = fresh;
 }
-__device__ inline uint32_t table_head(const EncTable& T, uint64_t t0, uint32_t tsz, uint64_t x)
+// both chain heads of canonical m-mer x (NIL, NIL when absent)
+__device__ inline uint2 table_heads(const EncTable& T, uint64_t t0, uint32_t tsz, uint64_t x)
 {
 	uint32_t h = (uint32_t)(hash_mm(x) >> 17) & (tsz - 1);
 	for (;;)
 	{
 		const uint64_t k = T.keys[t0 + h];
-		if (k == x) return T.heads[t0 + h];
-		if (k == KEY_EMPTY) return NIL;
+		if (k == x) return *(const uint2*)(T.heads + 2 * (t0 + h));
+		if (k == KEY_EMPTY) return make_uint2(NIL, NIL);
 		h = (h + 1) & (tsz - 1);
 	}
 }
 
-// ---- A2 / A3: one wave per task (read, candidate slot, orientation): count, then emit the match pairs ----------
-// task id t -> read r0 + t / (2c), slot (t / 2) % c, orientation t & 1 (0 = reverse complement, analysed first)
+// ---- A2 / A3: one wave per (read, candidate slot): the match pairs of BOTH orientations in one pass over the reference ----
+// task id t -> read r0 + t / (2c), slot (t / 2) % c, orientation t & 1 (0 = reverse complement, analysed first).
+// Pairs go to one array in any order (they are sorted by (task, read position, ~reference position) next): a wave
+// reserves room for the hits of its 64 probes with one atomic add.  The total is counted past the capacity too, so the
+// caller can repeat the pass with enough room.
 struct TaskCfg { uint32_t r0, r1, c, m; float pad; double frac_always, frac_min, max_mult; };
 
-template<bool EMIT>
 __global__ __launch_bounds__(256) void k_match(Arena A, Arena R, EncTable T, TaskCfg cfg, const uint32_t* __restrict__ cand_refs, const uint32_t* __restrict__ cand_n,
-                                              const uint32_t* __restrict__ n_distinct, uint32_t n_tasks,
-                                              uint32_t* __restrict__ counts, const uint64_t* __restrict__ pair_off, uint64_t* __restrict__ pairs)
+                                              const uint32_t* __restrict__ n_distinct, uint32_t n_slots,
+                                              unsigned long long* __restrict__ n_pairs, uint64_t cap, uint64_t* __restrict__ pairs)
 {
-	const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
-	if (t >= n_tasks) return;
+	const uint32_t sl = blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (sl >= n_slots) return;
 	const uint32_t lane = threadIdx.x & 63;
-	const uint32_t rl = t / (2 * cfg.c), slot = (t / 2) % cfg.c; const bool rev = (t & 1) == 0;
+	const uint32_t rl = sl / cfg.c, slot = sl % cfg.c;
 	const uint32_t r = cfg.r0 + rl;
 	const uint64_t t0 = T.toff[rl]; const uint32_t tsz = (uint32_t)(T.toff[rl + 1] - t0);
-	uint32_t total = 0;
-	bool active = tsz != 0 && slot < cand_n[r];
-	uint32_t elen = 0;
-	if (active)
+	if (tsz == 0 || slot >= cand_n[r]) return;
 	{	// read-level decision (encoder.cpp:1069-1078): refuse when too few distinct m-mers
-		elen = A.lens[r];
-		if ((double)n_distinct[rl] < cfg.frac_min * (double)elen && !((double)n_distinct[rl] > cfg.frac_always * (double)elen)) active = false;
+		const uint32_t elen = A.lens[r];
+		if ((double)n_distinct[rl] < cfg.frac_min * (double)elen && !((double)n_distinct[rl] > cfg.frac_always * (double)elen)) return;
 	}
-	uint32_t id = 0, rlen = 0;
-	if (active) { id = cand_refs[(uint64_t)r * cfg.c + slot]; rlen = R.lens[id]; if (rlen < cfg.m) active = false; }
-	if (!active) { if (!EMIT && lane == 0) counts[t] = 0; return; }
-	if (EMIT && pair_off[t + 1] == pair_off[t]) return;
-	const uint64_t n0 = T.noff[rl];
+	const uint32_t id = cand_refs[(uint64_t)r * cfg.c + slot], rlen = R.lens[id];
+	if (rlen < cfg.m) return;
+	const uint64_t n0 = T.noff[rl], rwb = R.word_off[id];
 	const uint32_t nq = rlen - cfg.m + 1;
-	uint64_t base = EMIT ? pair_off[t] : 0;
+	const uint64_t key_rev = (uint64_t)(2 * sl) << (2 * POS_BITS), key_fwd = (uint64_t)(2 * sl + 1) << (2 * POS_BITS);
 	for (uint32_t q0 = 0; q0 < nq; q0 += 64)
 	{
 		const uint32_t q = q0 + lane;
-		uint32_t head = NIL, cnt = 0;
+		uint32_t hf = NIL, hr = NIL, cnt = 0;
 		if (q < nq)
-		{
-			head = table_head(T, t0, tsz, ref_mmer(R, id, rev, q, cfg.m));
-			for (uint32_t p = head; p != NIL; p = T.next[n0 + p]) ++cnt;
+		{	// y: the m-mer at q of the reference as stored; z: the one at nq - 1 - q of its reverse complement
+			const uint64_t y = mmer_at(R, rwb, q, cfg.m), z = revcomp_m(y, cfg.m), x = y < z ? y : z;
+			const uint2 hd = table_heads(T, t0, tsz, x);
+			hf = y != x ? hd.y : hd.x; hr = z != x ? hd.y : hd.x;
+			for (uint32_t p = hf; p != NIL; p = T.next[n0 + p]) ++cnt;
+			for (uint32_t p = hr; p != NIL; p = T.next[n0 + p]) ++cnt;
 		}
-		if (!EMIT) { total += cnt; continue; }
-		const uint32_t incl = wave_incl_scan(cnt);
+		const uint32_t incl = wave_incl_scan(cnt), tot = __shfl(incl, 63, 64);
+		if (tot == 0) continue;
+		unsigned long long base = 0;
+		if (lane == 0) base = atomicAdd(n_pairs, (unsigned long long)tot);
+		base = ((unsigned long long)__shfl((int)(base >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)base, 0, 64);
+		if (base + tot > cap) continue;
 		uint64_t o = base + incl - cnt;
-		for (uint32_t p = head; p != NIL; p = T.next[n0 + p])
-			pairs[o++] = ((uint64_t)t << (2 * POS_BITS)) | ((uint64_t)p << POS_BITS) | (uint64_t)(~q & (uint32_t)POS_MASK);
-		base += __shfl(incl, 63, 64);
+		for (uint32_t p = hf; p != NIL; p = T.next[n0 + p]) pairs[o++] = key_fwd | ((uint64_t)p << POS_BITS) | (uint64_t)(~q & (uint32_t)POS_MASK);
+		const uint32_t qr = nq - 1 - q;
+		for (uint32_t p = hr; p != NIL; p = T.next[n0 + p]) pairs[o++] = key_rev | ((uint64_t)p << POS_BITS) | (uint64_t)(~qr & (uint32_t)POS_MASK);
 	}
-	if (!EMIT)
-	{
-		total = wave_sum(total);
-		if (lane == 0)
-		{	// "too many matches" veto unless the read is always encoded (encoder.cpp:1034-1042; enc_read.size() counts the guard)
-			bool always = (double)n_distinct[rl] > cfg.frac_always * (double)elen;
-			if (!always && (double)total > cfg.max_mult * (double)(elen + 1)) total = 0;
-			counts[t] = total;
-		}
-	}
+}
+// the pairs of every task in the sorted array; a task with "too many matches" keeps none unless its read is always
+// encoded (encoder.cpp:1034-1042; enc_read.size() counts the guard)
+__global__ void k_task_pairs(const uint64_t* __restrict__ pairs, uint64_t n_pairs, Arena A, TaskCfg cfg, const uint32_t* __restrict__ n_distinct, uint32_t n_tasks,
+                             uint64_t* __restrict__ pair_off, uint32_t* __restrict__ pair_cnt)
+{
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t > n_tasks) return;
+	auto lower = [&](uint64_t task) -> uint64_t {
+		const uint64_t key = task << (2 * POS_BITS);
+		uint64_t lo = 0, hi = n_pairs;
+		while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (pairs[mid] < key) lo = mid + 1; else hi = mid; }
+		return lo;
+	};
+	const uint64_t a = lower(t);
+	pair_off[t] = a;
+	if (t == n_tasks) return;
+	uint32_t total = (uint32_t)(lower((uint64_t)t + 1) - a);
+	const uint32_t rl = t / (2 * cfg.c); const uint32_t elen = A.lens[cfg.r0 + rl];
+	const bool always = (double)n_distinct[rl] > cfg.frac_always * (double)elen;
+	if (!always && (double)total > cfg.max_mult * (double)(elen + 1)) total = 0;
+	pair_cnt[t] = total;
 }
 
 // ---- A5: one lane per task: LIS (utils.cpp:157-209), map-back (encoder.cpp:644-658), MergeAnchors (:731-776) ----
@@ -187,13 +210,13 @@ __device__ inline int lis_search(const int* __restrict__ tf, int size, int value
 	return low;
 }
 __global__ __launch_bounds__(64) void k_lis_anchors(Arena A, Arena R, TaskCfg cfg, const uint32_t* __restrict__ cand_refs, uint32_t n_tasks,
-                                                   const uint64_t* __restrict__ pair_off, const uint64_t* __restrict__ pairs,
+                                                   const uint64_t* __restrict__ pair_off, const uint32_t* __restrict__ pair_cnt, const uint64_t* __restrict__ pairs,
                                                    int* __restrict__ tf, int* __restrict__ ts, int* __restrict__ pred,
                                                    uint32_t* __restrict__ anch, uint32_t* __restrict__ t_nanch, uint32_t* __restrict__ t_tot)
 {
 	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= n_tasks) return;
-	const uint64_t a = pair_off[t], b = pair_off[t + 1];
+	const uint64_t a = pair_off[t], b = a + pair_cnt[t];
 	uint32_t n_anch = 0, tot = 0;
 	if (b > a)
 	{
@@ -505,6 +528,7 @@ extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* read
 	const uint64_t BATCH_BASES = 1ull << 28;
 	std::vector<DevBuf<uint32_t>> chunks; std::vector<uint64_t> chunk_n;
 	uint64_t total_anchors = 0;
+	double pairs_per_base = 0.5;                                     // match pairs per read base seen so far (room for the next batch)
 	uint32_t r0 = 0;
 	while (r0 < nr)
 	{
@@ -522,30 +546,42 @@ extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* read
 		CL_TRY(dev_exclusive_scan_u64(ctx, nsize.p, noff.p, nb, &nsum));
 		uint32_t herr = 0; HIP_TRY(ctx, hipMemcpy(&herr, err.p, 4, hipMemcpyDeviceToHost));
 		if (herr) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_anchor_candidates: reads of 2^20 bases or more are not supported yet");
-		DevBuf<uint64_t> keys; DevBuf<uint32_t> heads, next; DEV_ALLOC(ctx, keys, tsum); DEV_ALLOC(ctx, heads, tsum); DEV_ALLOC(ctx, next, nsum);
+		DevBuf<uint64_t> keys; DevBuf<uint32_t> heads, next; DEV_ALLOC(ctx, keys, tsum); DEV_ALLOC(ctx, heads, 2 * tsum); DEV_ALLOC(ctx, next, nsum);
 		HIP_TRY(ctx, hipMemsetAsync(keys.p, 0xff, tsum * 8, ctx->stream));
-		HIP_TRY(ctx, hipMemsetAsync(heads.p, 0xff, tsum * 4, ctx->stream));
+		HIP_TRY(ctx, hipMemsetAsync(heads.p, 0xff, tsum * 8, ctx->stream));
 		EncTable T{ keys.p, heads.p, toff.p, next.p, noff.p };
 		LAUNCHB(ctx, nsum * (0.25 + 16.0), k_table_insert, grid_for(nb, 4), 256, A, r0, r1, m, T, n_distinct.p);
-		DevBuf<uint32_t> counts; DEV_ALLOC(ctx, counts, n_tasks);
+		DevBuf<uint32_t> pair_cnt; DEV_ALLOC(ctx, pair_cnt, (uint64_t)n_tasks + 1);
 		DevBuf<uint64_t> pair_off; DEV_ALLOC(ctx, pair_off, (uint64_t)n_tasks + 1);
-		LAUNCH(ctx, (k_match<false>), grid_for(n_tasks, 4), 256, A, R, T, cfg, d_cand_refs, d_cand_n, (const uint32_t*)n_distinct.p, n_tasks, counts.p, (const uint64_t*)nullptr, (uint64_t*)nullptr);
-		HIP_TRY(ctx, hipGetLastError());
+		DevBuf<unsigned long long> d_np; DEV_ALLOC(ctx, d_np, 1);
+		DevBuf<uint64_t> pairs;
 		uint64_t n_pairs = 0;
-		CL_TRY(dev_exclusive_scan_u64(ctx, counts.p, pair_off.p, n_tasks, &n_pairs));
-		if (n_pairs >= (1ull << 32)) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_anchor_candidates: batch produces >= 2^32 match pairs");
-		DevBuf<uint64_t> pairs; DEV_ALLOC(ctx, pairs, n_pairs);
+		for (uint64_t cap = (uint64_t)(pairs_per_base * 1.25 * (double)acc) + (1u << 20);;)
+		{	// one pass when the room guessed from the batches before suffices, else a second with the counted size
+			DEV_ALLOC(ctx, pairs, cap);
+			HIP_TRY(ctx, hipMemsetAsync(d_np.p, 0, 8, ctx->stream));
+			LAUNCHB(ctx, (double)std::min(cap, n_pairs ? n_pairs : cap) * 8.0, k_match, grid_for(nb * c, 4), 256, A, R, T, cfg, d_cand_refs, d_cand_n, (const uint32_t*)n_distinct.p, nb * c, d_np.p, cap, pairs.p);
+			HIP_TRY(ctx, hipGetLastError());
+			unsigned long long h_np = 0;
+			HIP_TRY(ctx, hipMemcpyAsync(&h_np, d_np.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+			HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+			n_pairs = h_np;
+			if (getenv("COLORD_HIP_ANCHOR_DEBUG")) fprintf(stderr, "[anchors] batch reads %u..%u bases %llu: pairs %llu cap %llu\n", r0, r1, (unsigned long long)acc, h_np, (unsigned long long)cap);
+			if (n_pairs >= (1ull << 32)) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_anchor_candidates: batch produces >= 2^32 match pairs");
+			if (n_pairs <= cap) break;
+			cap = n_pairs;
+		}
+		if (acc) pairs_per_base = std::max(pairs_per_base, (double)n_pairs / (double)acc);
 		DevBuf<int> tf, ts, pred; DEV_ALLOC(ctx, tf, n_pairs); DEV_ALLOC(ctx, ts, n_pairs); DEV_ALLOC(ctx, pred, n_pairs);
 		DevBuf<uint32_t> anch; DEV_ALLOC(ctx, anch, 3 * n_pairs);
 		DevBuf<uint32_t> t_nanch, t_tot; DEV_ALLOC(ctx, t_nanch, n_tasks); DEV_ALLOC(ctx, t_tot, n_tasks);
 		if (n_pairs)
 		{
-			LAUNCHB(ctx, n_pairs * 8.0, (k_match<true>), grid_for(n_tasks, 4), 256, A, R, T, cfg, d_cand_refs, d_cand_n, (const uint32_t*)n_distinct.p, n_tasks, (uint32_t*)nullptr, (const uint64_t*)pair_off.p, pairs.p);
-			HIP_TRY(ctx, hipGetLastError());
 			uint32_t tb = 1; while ((1ull << tb) < n_tasks) ++tb;
 			CL_TRY(dev_sort_pairs(ctx, pairs.p, nullptr, n_pairs, 0, 2 * POS_BITS + tb));
 		}
-		LAUNCHB(ctx, n_pairs * 32.0, k_lis_anchors, grid_for(n_tasks, 64), 64, A, R, cfg, d_cand_refs, n_tasks, (const uint64_t*)pair_off.p, (const uint64_t*)pairs.p,
+		LAUNCH(ctx, k_task_pairs, grid_for((uint64_t)n_tasks + 1, 256), 256, (const uint64_t*)pairs.p, n_pairs, A, cfg, (const uint32_t*)n_distinct.p, n_tasks, pair_off.p, pair_cnt.p);
+		LAUNCHB(ctx, n_pairs * 32.0, k_lis_anchors, grid_for(n_tasks, 64), 64, A, R, cfg, d_cand_refs, n_tasks, (const uint64_t*)pair_off.p, (const uint32_t*)pair_cnt.p, (const uint64_t*)pairs.p,
 			tf.p, ts.p, pred.p, anch.p, t_nanch.p, t_tot.p);
 		HIP_TRY(ctx, hipGetLastError());
 		const uint64_t n_slots = (uint64_t)nb * c;
