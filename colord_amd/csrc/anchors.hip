@@ -149,6 +149,7 @@ __global__ __launch_bounds__(256) void k_match(Arena A, Arena R, EncTable T, Tas
 	const uint64_t n0 = T.noff[rl], rwb = R.word_off[id];
 	const uint32_t nq = rlen - cfg.m + 1;
 	const uint64_t key_rev = (uint64_t)(2 * sl) << (2 * POS_BITS), key_fwd = (uint64_t)(2 * sl + 1) << (2 * POS_BITS);
+	if (lane == 0) atomicAdd(n_pairs + 1, (unsigned long long)nq);          // probes, for the achieved-bandwidth report
 	for (uint32_t q0 = 0; q0 < nq; q0 += 64)
 	{
 		const uint32_t q = q0 + lane;
@@ -553,19 +554,22 @@ extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* read
 		LAUNCHB(ctx, nsum * (0.25 + 16.0), k_table_insert, grid_for(nb, 4), 256, A, r0, r1, m, T, n_distinct.p);
 		DevBuf<uint32_t> pair_cnt; DEV_ALLOC(ctx, pair_cnt, (uint64_t)n_tasks + 1);
 		DevBuf<uint64_t> pair_off; DEV_ALLOC(ctx, pair_off, (uint64_t)n_tasks + 1);
-		DevBuf<unsigned long long> d_np; DEV_ALLOC(ctx, d_np, 1);
+		DevBuf<unsigned long long> d_np; DEV_ALLOC(ctx, d_np, 2);           // match pairs, probes
 		DevBuf<uint64_t> pairs;
 		uint64_t n_pairs = 0;
 		for (uint64_t cap = (uint64_t)(pairs_per_base * 1.25 * (double)acc) + (1u << 20);;)
 		{	// one pass when the room guessed from the batches before suffices, else a second with the counted size
 			DEV_ALLOC(ctx, pairs, cap);
-			HIP_TRY(ctx, hipMemsetAsync(d_np.p, 0, 8, ctx->stream));
-			LAUNCHB(ctx, (double)std::min(cap, n_pairs ? n_pairs : cap) * 8.0, k_match, grid_for(nb * c, 4), 256, A, R, T, cfg, d_cand_refs, d_cand_n, (const uint32_t*)n_distinct.p, nb * c, d_np.p, cap, pairs.p);
+			HIP_TRY(ctx, hipMemsetAsync(d_np.p, 0, 16, ctx->stream));
+			LAUNCHB(ctx, 0.0, k_match, grid_for(nb * c, 4), 256, A, R, T, cfg, d_cand_refs, d_cand_n, (const uint32_t*)n_distinct.p, nb * c, d_np.p, cap, pairs.p);
 			HIP_TRY(ctx, hipGetLastError());
-			unsigned long long h_np = 0;
-			HIP_TRY(ctx, hipMemcpyAsync(&h_np, d_np.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+			unsigned long long h_np2[2] = { 0, 0 };
+			HIP_TRY(ctx, hipMemcpyAsync(h_np2, d_np.p, 16, hipMemcpyDeviceToHost, ctx->stream));
 			HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+			const unsigned long long h_np = h_np2[0];
 			n_pairs = h_np;
+			// algorithmic bytes of the pass: 2 bits of reference and one 8-byte key slot per probe, 8 bytes per pair out
+			if (ctx->timing && !ctx->pending_bytes.empty()) ctx->pending_bytes.back() = (double)h_np2[1] * 8.25 + (double)std::min<uint64_t>(h_np, cap) * 8.0;
 			if (getenv("COLORD_HIP_ANCHOR_DEBUG")) fprintf(stderr, "[anchors] batch reads %u..%u bases %llu: pairs %llu cap %llu\n", r0, r1, (unsigned long long)acc, h_np, (unsigned long long)cap);
 			if (n_pairs >= (1ull << 32)) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_anchor_candidates: batch produces >= 2^32 match pairs");
 			if (n_pairs <= cap) break;
