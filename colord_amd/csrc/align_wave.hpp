@@ -39,6 +39,10 @@ __device__ inline uint64_t bcast(uint64_t v, uint32_t src)
 	return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), s) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, s);
 }
 __device__ inline uint32_t bcast_first(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+// lane l receives the value of lane l - 1 (lane 0: 0): one DPP move (wave_shr:1) instead of a permute through LDS — the
+// sweep is a dependent chain of such shifts
+__device__ inline int shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
+__device__ inline uint32_t shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }
 
 struct Hist { uint64_t* P; uint64_t* H; uint32_t W, m; };       // cell (tile, s, lane) at ((tile * (m + 64)) + s) * W + lane
 __device__ inline uint64_t hist_words(uint32_t nb, uint32_t m) { const uint32_t tiles = (nb + 63) / 64, W = nb < 64 ? nb : 64; return (uint64_t)tiles * (m + 64) * W; }
@@ -87,7 +91,7 @@ __device__ inline Sweep wave_sweep(WavePool& pool, const uint8_t* q, int qstep, 
 				hchunk = hin_arr ? (j0 < m ? (int)hin_arr[j0] : 0) : 1;
 			}
 			const uint32_t c_new = bcast(tchunk, s & 63); const int h_new = bcast(hchunk, s & 63);
-			uint32_t c_up = __shfl_up(c, 1); int h_up = __shfl_up(hout, 1);
+			const uint32_t c_up = shr1(c); const int h_up = shr1(hout);
 			c = lane == 0 ? c_new : c_up;
 			const int hin = lane == 0 ? h_new : h_up;
 			const bool valid = act && s >= lane && s - lane < m;
@@ -329,7 +333,7 @@ __device__ inline bool wave_refactor_pass(WavePool& pool, char* es, uint32_t k, 
 		const uint64_t cmask = __ballot(cons);
 		const uint32_t pos = pos_base + (uint32_t)__popcll(cmask & (le >> 1));
 		const uint32_t sym = reg ? seq[pos] : 0xffu;
-		uint32_t p_sym = __shfl_up(sym, 1); bool p_reg = __shfl_up((int)reg, 1) != 0;
+		uint32_t p_sym = shr1(sym); bool p_reg = shr1((int)reg) != 0;
 		if (lane == 0) { p_sym = c_sym; p_reg = c_reg; }
 		const bool head = reg && (!p_reg || p_sym != sym);
 		const uint64_t H = __ballot(head), R = __ballot(reg), Mm = __ballot(reg && c == 'M');

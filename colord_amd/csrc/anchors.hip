@@ -60,11 +60,13 @@ __device__ inline uint64_t ref_mmer(const Arena& R, uint32_t id, bool rev, uint3
 }
 
 // Per read: open-addressing table of its m-mers under their CANONICAL form (the smaller of the m-mer and its reverse
-// complement) with two position chains per key: heads[2 * slot] the positions where the read has the canonical form
-// itself, heads[2 * slot + 1] those where it has the other one.  One probe with a reference m-mer then serves both
+// complement) with two position chains per key: head[0] the positions where the read has the canonical form
+// itself, head[1] those where it has the other one.  One probe with a reference m-mer then serves both
 // orientations of the reference (the reference's two anchor analyses, encoder.cpp:1046-1066, probe the same hash of the
 // read with the m-mers of the reference and of its reverse complement).
-struct EncTable { uint64_t* keys; uint32_t* heads; const uint64_t* toff; uint32_t* next; const uint64_t* noff; };
+// A slot is 16 bytes — key and both chain heads in one sector, so an insertion touches two sectors (slot, next), not three.
+struct EncSlot { uint64_t key; uint32_t head[2]; };
+struct EncTable { EncSlot* slots; const uint64_t* toff; uint32_t* next; const uint64_t* noff; };
 constexpr uint64_t KEY_EMPTY = ~0ULL;
 constexpr uint32_t NIL = 0xffffffffu;
 
@@ -98,11 +100,11 @@ __global__ __launch_bounds__(256) void k_table_insert(Arena A, uint32_t r0, uint
 		uint32_t h = (uint32_t)(hash_mm(x) >> 17) & (tsz - 1);
 		for (;;)
 		{
-			unsigned long long old = atomicCAS((unsigned long long*)&T.keys[t0 + h], (unsigned long long)KEY_EMPTY, (unsigned long long)x);
+			unsigned long long old = atomicCAS((unsigned long long*)&T.slots[t0 + h].key, (unsigned long long)KEY_EMPTY, (unsigned long long)x);
 			if (old == KEY_EMPTY || old == x) break;
 			h = (h + 1) & (tsz - 1);
 		}
-		const uint32_t prev = atomicExch(&T.heads[2 * (t0 + h) + (xf != x ? 1 : 0)], p);
+		const uint32_t prev = atomicExch(&T.slots[t0 + h].head[xf != x ? 1 : 0], p);
 		T.next[n0 + p] = prev;
 		if (prev == NIL) ++fresh;                                       // first position with this m-mer: distinct m-mers of the read
 	}
@@ -115,8 +117,8 @@ __device__ inline uint2 table_heads(const EncTable& T, uint64_t t0, uint32_t tsz
 	uint32_t h = (uint32_t)(hash_mm(x) >> 17) & (tsz - 1);
 	for (;;)
 	{
-		const uint64_t k = T.keys[t0 + h];
-		if (k == x) return *(const uint2*)(T.heads + 2 * (t0 + h));
+		const uint64_t k = T.slots[t0 + h].key;
+		if (k == x) return *(const uint2*)T.slots[t0 + h].head;
 		if (k == KEY_EMPTY) return make_uint2(NIL, NIL);
 		h = (h + 1) & (tsz - 1);
 	}
@@ -547,10 +549,9 @@ extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* read
 		CL_TRY(dev_exclusive_scan_u64(ctx, nsize.p, noff.p, nb, &nsum));
 		uint32_t herr = 0; HIP_TRY(ctx, hipMemcpy(&herr, err.p, 4, hipMemcpyDeviceToHost));
 		if (herr) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_anchor_candidates: reads of 2^20 bases or more are not supported yet");
-		DevBuf<uint64_t> keys; DevBuf<uint32_t> heads, next; DEV_ALLOC(ctx, keys, tsum); DEV_ALLOC(ctx, heads, 2 * tsum); DEV_ALLOC(ctx, next, nsum);
-		HIP_TRY(ctx, hipMemsetAsync(keys.p, 0xff, tsum * 8, ctx->stream));
-		HIP_TRY(ctx, hipMemsetAsync(heads.p, 0xff, tsum * 8, ctx->stream));
-		EncTable T{ keys.p, heads.p, toff.p, next.p, noff.p };
+		DevBuf<EncSlot> slots; DevBuf<uint32_t> next; DEV_ALLOC(ctx, slots, tsum); DEV_ALLOC(ctx, next, nsum);
+		HIP_TRY(ctx, hipMemsetAsync(slots.p, 0xff, tsum * sizeof(EncSlot), ctx->stream));
+		EncTable T{ slots.p, toff.p, next.p, noff.p };
 		LAUNCHB(ctx, nsum * (0.25 + 16.0), k_table_insert, grid_for(nb, 4), 256, A, r0, r1, m, T, n_distinct.p);
 		DevBuf<uint32_t> pair_cnt; DEV_ALLOC(ctx, pair_cnt, (uint64_t)n_tasks + 1);
 		DevBuf<uint64_t> pair_off; DEV_ALLOC(ctx, pair_off, (uint64_t)n_tasks + 1);
