@@ -45,6 +45,13 @@ __device__ inline uint64_t mmer_at(const Arena& A, uint64_t wb, uint32_t p, uint
 	const uint64_t v = (s >= 64) ? (hi >> (s - 64)) : ((hi << (64 - s)) | (lo >> s));
 	return v & ((1ULL << (2 * m)) - 1);
 }
+// the same from the two words that hold it (loaded ahead of their use)
+__device__ inline uint64_t mmer_of(uint64_t hi, uint64_t lo, uint32_t p, uint32_t m)
+{
+	const uint32_t s = 128 - 2 * ((p & 31) + m);
+	const uint64_t v = (s >= 64) ? (hi >> (s - 64)) : ((hi << (64 - s)) | (lo >> s));
+	return v & ((1ULL << (2 * m)) - 1);
+}
 __device__ inline uint64_t revcomp_m(uint64_t x, uint32_t m)
 {
 	x = ~x; x = __brevll(x);
@@ -112,9 +119,9 @@ __global__ __launch_bounds__(256) void k_table_insert(Arena A, uint32_t r0, uint
 	if (lane == 0) n_distinct[r - r0] = fresh;
 }
 // both chain heads of canonical m-mer x (NIL, NIL when absent)
-__device__ inline uint2 table_heads(const EncTable& T, uint64_t t0, uint32_t tsz, uint64_t x)
+__device__ inline uint2 table_heads(const EncTable& T, uint64_t t0, uint32_t tsz, uint64_t x, uint64_t hash)
 {
-	uint32_t h = (uint32_t)(hash_mm(x) >> 17) & (tsz - 1);
+	uint32_t h = (uint32_t)(hash >> 17) & (tsz - 1);
 	for (;;)
 	{
 		const uint64_t k = T.slots[t0 + h].key;
@@ -124,57 +131,123 @@ __device__ inline uint2 table_heads(const EncTable& T, uint64_t t0, uint32_t tsz
 	}
 }
 
-// ---- A2 / A3: one wave per (read, candidate slot): the match pairs of BOTH orientations in one pass over the reference ----
+// ---- A2 / A3: the match pairs of BOTH orientations of every candidate in one pass over the reference ----
 // task id t -> read r0 + t / (2c), slot (t / 2) % c, orientation t & 1 (0 = reverse complement, analysed first).
 // Pairs go to one array in any order (they are sorted by (task, read position, ~reference position) next): a wave
 // reserves room for the hits of its 64 probes with one atomic add.  The total is counted past the capacity too, so the
 // caller can repeat the pass with enough room.
 struct TaskCfg { uint32_t r0, r1, c, m; float pad; double frac_always, frac_min, max_mult; };
 
+// One BLOCK per read.  Nearly all probes miss (a candidate shares a stretch with the read, not its whole length), and a
+// miss in the read's table in HBM costs a random 64-byte line and, worse, its latency: the 64 probes of a wave step wait
+// for the slowest.  So the block first builds a Bloom filter of the read's m-mers in LDS — 32 KB (five blocks per CU),
+// blocked: one 64-bit word per m-mer, three bits in it, all from the m-mer's one hash — and only probes that pass it
+// go to the table: for a read of 15 k bases ~0.6 % of the misses, i.e. two of three wave steps touch no table at all.
+constexpr uint32_t FILT_WORDS = 4096, STAGE = 512;
+__device__ inline uint32_t filt_word(uint64_t hash) { return (uint32_t)(hash >> 46) & (FILT_WORDS - 1); }
+__device__ inline uint64_t filt_mask(uint64_t hash) { return (1ull << ((hash >> 40) & 63)) | (1ull << ((hash >> 34) & 63)) | (1ull << ((hash >> 28) & 63)); }
 __global__ __launch_bounds__(256) void k_match(Arena A, Arena R, EncTable T, TaskCfg cfg, const uint32_t* __restrict__ cand_refs, const uint32_t* __restrict__ cand_n,
-                                              const uint32_t* __restrict__ n_distinct, uint32_t n_slots,
+                                              const uint32_t* __restrict__ n_distinct, uint32_t n_reads,
                                               unsigned long long* __restrict__ n_pairs, uint64_t cap, uint64_t* __restrict__ pairs)
 {
-	const uint32_t sl = blockIdx.x * 4 + (threadIdx.x >> 6);
-	if (sl >= n_slots) return;
-	const uint32_t lane = threadIdx.x & 63;
-	const uint32_t rl = sl / cfg.c, slot = sl % cfg.c;
+	__shared__ unsigned long long filt[FILT_WORDS];
+	__shared__ uint64_t stage_all[4][STAGE];                          // per wave: pairs on their way out
+	const uint32_t rl = blockIdx.x;
+	if (rl >= n_reads) return;
+	const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	const uint32_t r = cfg.r0 + rl;
 	const uint64_t t0 = T.toff[rl]; const uint32_t tsz = (uint32_t)(T.toff[rl + 1] - t0);
-	if (tsz == 0 || slot >= cand_n[r]) return;
-	{	// read-level decision (encoder.cpp:1069-1078): refuse when too few distinct m-mers
-		const uint32_t elen = A.lens[r];
-		if ((double)n_distinct[rl] < cfg.frac_min * (double)elen && !((double)n_distinct[rl] > cfg.frac_always * (double)elen)) return;
-	}
-	const uint32_t id = cand_refs[(uint64_t)r * cfg.c + slot], rlen = R.lens[id];
-	if (rlen < cfg.m) return;
-	const uint64_t n0 = T.noff[rl], rwb = R.word_off[id];
-	const uint32_t nq = rlen - cfg.m + 1;
-	const uint64_t key_rev = (uint64_t)(2 * sl) << (2 * POS_BITS), key_fwd = (uint64_t)(2 * sl + 1) << (2 * POS_BITS);
-	if (lane == 0) atomicAdd(n_pairs + 1, (unsigned long long)nq);          // probes, for the achieved-bandwidth report
-	for (uint32_t q0 = 0; q0 < nq; q0 += 64)
+	const uint32_t n_slots = cand_n[r] < cfg.c ? cand_n[r] : cfg.c;
+	if (tsz == 0 || n_slots == 0) return;
+	const uint32_t elen = A.lens[r];
+	// read-level decision (encoder.cpp:1069-1078): refuse when too few distinct m-mers
+	if ((double)n_distinct[rl] < cfg.frac_min * (double)elen && !((double)n_distinct[rl] > cfg.frac_always * (double)elen)) return;
+	for (uint32_t i = threadIdx.x; i < FILT_WORDS; i += 256) filt[i] = 0;
+	__syncthreads();
 	{
-		const uint32_t q = q0 + lane;
-		uint32_t hf = NIL, hr = NIL, cnt = 0;
-		if (q < nq)
-		{	// y: the m-mer at q of the reference as stored; z: the one at nq - 1 - q of its reverse complement
-			const uint64_t y = mmer_at(R, rwb, q, cfg.m), z = revcomp_m(y, cfg.m), x = y < z ? y : z;
-			const uint2 hd = table_heads(T, t0, tsz, x);
-			hf = y != x ? hd.y : hd.x; hr = z != x ? hd.y : hd.x;
-			for (uint32_t p = hf; p != NIL; p = T.next[n0 + p]) ++cnt;
-			for (uint32_t p = hr; p != NIL; p = T.next[n0 + p]) ++cnt;
+		const uint64_t ewb = A.word_off[r]; const uint32_t n = elen - cfg.m + 1;       // tsz != 0: elen >= m
+		for (uint32_t p = threadIdx.x; p < n; p += 256)
+		{
+			const uint64_t xf = mmer_at(A, ewb, p, cfg.m), xr = revcomp_m(xf, cfg.m);
+			const uint64_t hash = hash_mm(xf < xr ? xf : xr);
+			atomicOr(&filt[filt_word(hash)], (unsigned long long)filt_mask(hash));
 		}
-		const uint32_t incl = wave_incl_scan(cnt), tot = __shfl(incl, 63, 64);
-		if (tot == 0) continue;
-		unsigned long long base = 0;
-		if (lane == 0) base = atomicAdd(n_pairs, (unsigned long long)tot);
-		base = ((unsigned long long)__shfl((int)(base >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)base, 0, 64);
-		if (base + tot > cap) continue;
-		uint64_t o = base + incl - cnt;
-		for (uint32_t p = hf; p != NIL; p = T.next[n0 + p]) pairs[o++] = key_fwd | ((uint64_t)p << POS_BITS) | (uint64_t)(~q & (uint32_t)POS_MASK);
-		const uint32_t qr = nq - 1 - q;
-		for (uint32_t p = hr; p != NIL; p = T.next[n0 + p]) pairs[o++] = key_rev | ((uint64_t)p << POS_BITS) | (uint64_t)(~qr & (uint32_t)POS_MASK);
 	}
+	__syncthreads();
+	const uint64_t n0 = T.noff[rl];
+	// Pairs are staged per wave in LDS and leave in runs of up to STAGE with ONE atomic add on the global counter (an add
+	// per wave step — ~15 M a pass, all on one address — serialises the whole grid in the L2).
+	uint64_t* stage = stage_all[wv]; uint32_t fill = 0;
+	auto flush = [&]() {
+		if (!fill) return;
+		unsigned long long base = 0;
+		if (lane == 0) base = atomicAdd(n_pairs, (unsigned long long)fill);
+		base = ((unsigned long long)__shfl((int)(base >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)base, 0, 64);
+		if (base + fill <= cap) for (uint32_t i = lane; i < fill; i += 64) pairs[base + i] = stage[i];
+		fill = 0;
+	};
+	for (uint32_t slot = 0; slot < n_slots; ++slot)
+	{
+		const uint32_t id = cand_refs[(uint64_t)r * cfg.c + slot], rlen = R.lens[id];
+		if (rlen < cfg.m) continue;
+		const uint64_t rwb = R.word_off[id];
+		const uint32_t nq = rlen - cfg.m + 1, sl = rl * cfg.c + slot;
+		const uint64_t key_rev = (uint64_t)(2 * sl) << (2 * POS_BITS), key_fwd = (uint64_t)(2 * sl + 1) << (2 * POS_BITS);
+		if (threadIdx.x == 0) atomicAdd(n_pairs + 1, (unsigned long long)nq);      // probes, for the achieved-bandwidth report
+		// the words of the next step are loaded while this one is worked on (the block streams through the candidate:
+		// every step is a new line)
+		const uint64_t* rw = R.packed + rwb;
+		uint64_t hi = 0, lo = 0;
+		{ const uint32_t q = wv * 64 + lane; if (q < nq) { hi = rw[q >> 5]; lo = rw[(q >> 5) + 1]; } }
+		for (uint32_t q0 = wv * 64; q0 < nq; q0 += 256)
+		{
+			const uint32_t q = q0 + lane;
+			uint64_t hi2 = 0, lo2 = 0;
+			if (q + 256 < nq) { hi2 = rw[(q + 256) >> 5]; lo2 = rw[((q + 256) >> 5) + 1]; }
+			uint32_t hf = NIL, hr = NIL, nf = NIL, nr = NIL, cnt = 0;      // chain heads and their successors (most chains have one element)
+			if (q < nq)
+			{	// y: the m-mer at q of the reference as stored; z: the one at nq - 1 - q of its reverse complement
+				const uint64_t y = mmer_of(hi, lo, q, cfg.m), z = revcomp_m(y, cfg.m), x = y < z ? y : z;
+				const uint64_t hash = hash_mm(x);
+				const uint64_t fm = filt_mask(hash);
+				if ((filt[filt_word(hash)] & fm) == fm)
+				{
+					const uint2 hd = table_heads(T, t0, tsz, x, hash);
+					hf = y != x ? hd.y : hd.x; hr = z != x ? hd.y : hd.x;
+					if (hf != NIL) { nf = T.next[n0 + hf]; ++cnt; }           // (two independent loads)
+					if (hr != NIL) { nr = T.next[n0 + hr]; ++cnt; }
+					for (uint32_t p = nf; p != NIL; p = T.next[n0 + p]) ++cnt;
+					for (uint32_t p = nr; p != NIL; p = T.next[n0 + p]) ++cnt;
+				}
+			}
+			hi = hi2; lo = lo2;
+			if (!__any(cnt != 0)) continue;
+			const uint32_t incl = wave_incl_scan(cnt), tot = __shfl(incl, 63, 64);
+			const uint64_t kf = key_fwd | (uint64_t)(~q & (uint32_t)POS_MASK), kr = key_rev | (uint64_t)(~(nq - 1 - q) & (uint32_t)POS_MASK);
+			if (fill + tot > STAGE) flush();
+			if (tot <= STAGE)
+			{
+				uint32_t o = fill + incl - cnt;
+				if (hf != NIL) stage[o++] = kf | ((uint64_t)hf << POS_BITS);
+				for (uint32_t p = nf; p != NIL; p = T.next[n0 + p]) stage[o++] = kf | ((uint64_t)p << POS_BITS);
+				if (hr != NIL) stage[o++] = kr | ((uint64_t)hr << POS_BITS);
+				for (uint32_t p = nr; p != NIL; p = T.next[n0 + p]) stage[o++] = kr | ((uint64_t)p << POS_BITS);
+				fill += tot;
+				continue;
+			}
+			// more hits in one step than the stage holds (long chains of a repeated m-mer): straight to the array
+			unsigned long long base = 0;
+			if (lane == 0) base = atomicAdd(n_pairs, (unsigned long long)tot);
+			base = ((unsigned long long)__shfl((int)(base >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)base, 0, 64);
+			if (base + tot > cap) continue;
+			uint64_t o = base + incl - cnt;
+			if (hf != NIL) pairs[o++] = kf | ((uint64_t)hf << POS_BITS);
+			for (uint32_t p = nf; p != NIL; p = T.next[n0 + p]) pairs[o++] = kf | ((uint64_t)p << POS_BITS);
+			if (hr != NIL) pairs[o++] = kr | ((uint64_t)hr << POS_BITS);
+			for (uint32_t p = nr; p != NIL; p = T.next[n0 + p]) pairs[o++] = kr | ((uint64_t)p << POS_BITS);
+		}
+	}
+	flush();
 }
 // the pairs of every task in the sorted array; a task with "too many matches" keeps none unless its read is always
 // encoded (encoder.cpp:1034-1042; enc_read.size() counts the guard)
@@ -562,7 +635,7 @@ extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* read
 		{	// one pass when the room guessed from the batches before suffices, else a second with the counted size
 			DEV_ALLOC(ctx, pairs, cap);
 			HIP_TRY(ctx, hipMemsetAsync(d_np.p, 0, 16, ctx->stream));
-			LAUNCHB(ctx, 0.0, k_match, grid_for(nb * c, 4), 256, A, R, T, cfg, d_cand_refs, d_cand_n, (const uint32_t*)n_distinct.p, nb * c, d_np.p, cap, pairs.p);
+			LAUNCHB(ctx, 0.0, k_match, nb, 256, A, R, T, cfg, d_cand_refs, d_cand_n, (const uint32_t*)n_distinct.p, nb, d_np.p, cap, pairs.p);
 			HIP_TRY(ctx, hipGetLastError());
 			unsigned long long h_np2[2] = { 0, 0 };
 			HIP_TRY(ctx, hipMemcpyAsync(h_np2, d_np.p, 16, hipMemcpyDeviceToHost, ctx->stream));
