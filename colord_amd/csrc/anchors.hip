@@ -143,7 +143,7 @@ struct TaskCfg { uint32_t r0, r1, c, m; float pad; double frac_always, frac_min,
 // for the slowest.  So the block first builds a Bloom filter of the read's m-mers in LDS — 32 KB (five blocks per CU),
 // blocked: one 64-bit word per m-mer, three bits in it, all from the m-mer's one hash — and only probes that pass it
 // go to the table: for a read of 15 k bases ~0.6 % of the misses, i.e. two of three wave steps touch no table at all.
-constexpr uint32_t FILT_WORDS = 4096, STAGE = 512;
+constexpr uint32_t FILT_WORDS = 2048, STAGE = 128;
 __device__ inline uint32_t filt_word(uint64_t hash) { return (uint32_t)(hash >> 46) & (FILT_WORDS - 1); }
 __device__ inline uint64_t filt_mask(uint64_t hash) { return (1ull << ((hash >> 40) & 63)) | (1ull << ((hash >> 34) & 63)) | (1ull << ((hash >> 28) & 63)); }
 __global__ __launch_bounds__(256) void k_match(Arena A, Arena R, EncTable T, TaskCfg cfg, const uint32_t* __restrict__ cand_refs, const uint32_t* __restrict__ cand_n,
