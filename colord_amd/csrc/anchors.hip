@@ -91,9 +91,9 @@ __global__ void k_table_sizes(const uint32_t* __restrict__ lens, const uint8_t* 
 	if (n) { t = 16; while (t < 2 * n + n / 2) t <<= 1; }
 	tsize[r - r0] = t; nsize[r - r0] = n;
 }
-__global__ __launch_bounds__(256) void k_table_insert(Arena A, uint32_t r0, uint32_t r1, uint32_t m, EncTable T, uint32_t* __restrict__ n_distinct)
-{
-	const uint32_t r = r0 + blockIdx.x * 4 + (threadIdx.x >> 6);
+__global__ __launch_bounds__(1024) void k_table_insert(Arena A, uint32_t r0, uint32_t r1, uint32_t m, EncTable T, uint32_t* __restrict__ n_distinct)
+{	// one block of 16 waves per read (measured: 212 -> 162 ms against one wave per read)
+	const uint32_t r = r0 + blockIdx.x;
 	if (r >= r1) return;
 	const uint64_t t0 = T.toff[r - r0]; const uint32_t tsz = (uint32_t)(T.toff[r - r0 + 1] - t0);
 	if (!tsz) return;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void k_table_insert(Arena A, uint32_t r0, uint
 	const uint64_t wb = A.word_off[r];
 	const uint32_t lane = threadIdx.x & 63;
 	uint32_t fresh = 0;
-	for (uint32_t p = lane; p < n; p += 64)
+	for (uint32_t p = threadIdx.x; p < n; p += 1024)
 	{
 		const uint64_t xf = mmer_at(A, wb, p, m), xr = revcomp_m(xf, m), x = xf < xr ? xf : xr;
 		uint32_t h = (uint32_t)(hash_mm(x) >> 17) & (tsz - 1);
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void k_table_insert(Arena A, uint32_t r0, uint
 		if (prev == NIL) ++fresh;                                       // first position with this m-mer: distinct m-mers of the read
 	}
 	fresh = wave_sum(fresh);
-	if (lane == 0) n_distinct[r - r0] = fresh;
+	if (lane == 0 && fresh) atomicAdd(&n_distinct[r - r0], fresh);       // (zeroed by the caller)
 }
 // both chain heads of canonical m-mer x (NIL, NIL when absent)
 __device__ inline uint2 table_heads(const EncTable& T, uint64_t t0, uint32_t tsz, uint64_t x, uint64_t hash)
@@ -625,7 +625,7 @@ extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* read
 		DevBuf<EncSlot> slots; DevBuf<uint32_t> next; DEV_ALLOC(ctx, slots, tsum); DEV_ALLOC(ctx, next, nsum);
 		HIP_TRY(ctx, hipMemsetAsync(slots.p, 0xff, tsum * sizeof(EncSlot), ctx->stream));
 		EncTable T{ slots.p, toff.p, next.p, noff.p };
-		LAUNCHB(ctx, nsum * (0.25 + 16.0), k_table_insert, grid_for(nb, 4), 256, A, r0, r1, m, T, n_distinct.p);
+		LAUNCHB(ctx, nsum * (0.25 + 16.0), k_table_insert, nb, 1024, A, r0, r1, m, T, n_distinct.p);
 		DevBuf<uint32_t> pair_cnt; DEV_ALLOC(ctx, pair_cnt, (uint64_t)n_tasks + 1);
 		DevBuf<uint64_t> pair_off; DEV_ALLOC(ctx, pair_off, (uint64_t)n_tasks + 1);
 		DevBuf<unsigned long long> d_np; DEV_ALLOC(ctx, d_np, 2);           // match pairs, probes
