@@ -677,6 +677,21 @@ struct TupleOut {
 		acc |= (uint64_t)v << (8 * have); ++have; ++n;
 		if (have == 8) { *(uint64_t*)(p + n - 8) = acc; acc = 0; have = 0; }
 	}
+	// `rep` one-byte tuples of the same value (runs of matches shorter than an anchor, of deletions, ...)
+	CL_DEV inline void fill(uint8_t v, uint32_t rep)
+	{
+		n_tuples += rep;
+		if (!write) { n += rep; return; }
+		while (rep && !aligned) { p[n] = v; ++n; --rep; aligned = (((uint64_t)(size_t)p + n) & 7) == 0; }
+		const uint64_t pat = 0x0101010101010101ull * v;
+		while (rep)
+		{
+			const uint32_t k = rep < 8 - have ? rep : 8 - have;
+			const uint64_t m = k == 8 ? ~0ull : ((1ull << (8 * k)) - 1);
+			acc |= (pat & m) << (8 * have); have += k; n += k; rep -= k;
+			if (have == 8) { *(uint64_t*)(p + n - 8) = acc; acc = 0; have = 0; }
+		}
+	}
 	CL_DEV inline void finish() { if (write) for (uint32_t i = 0; i < have; ++i) p[n - have + i] = (uint8_t)(acc >> (8 * i)); have = 0; }
 	CL_DEV inline void t1(uint32_t type, uint32_t val) { byte((uint8_t)((type << 4) + val)); ++n_tuples; }
 	CL_DEV inline void t28(uint32_t type, uint32_t v) { byte((uint8_t)((type << 4) + (v >> 24))); byte((v >> 16) & 0xff); byte((v >> 8) & 0xff); byte(v & 0xff); ++n_tuples; }
@@ -695,7 +710,7 @@ struct SegWriter {
 		else if (sym == 'X' || sym == 'Y' || sym == 'Z') { type = 3; val = (uint32_t)(sym - 'X'); }
 		else { type = 0; val = sym == 'A' ? 0 : sym == 'C' ? 1 : sym == 'G' ? 2 : 3; }
 		if ((type == 2 && rep >= 15) || (type == 1 && rep > 16)) o->t28(type == 2 ? 4 : 5, rep);
-		else for (uint32_t i = 0; i < rep; ++i) o->t1(type, val);
+		else o->fill((uint8_t)((type << 4) + val), rep);
 		rep = 0;
 	}
 	CL_DEV inline void run(char s, uint32_t n) { if (rep && s == sym) { rep += n; return; } flush_run(); sym = s; rep = n; }

@@ -91,12 +91,22 @@ cl_status sort_impl(cl_ctx* ctx, K* d_keys, uint32_t* d_vals, uint64_t n, uint32
 	if (n <= 1 || end_bit <= begin_bit) return CL_OK;
 	if (n >= (1ULL << 32)) return cl_fail(ctx, CL_E_UNSUPPORTED, "radix sort: n must be < 2^32 per call");
 	const uint32_t nb = grid_for(n, STILE);
-	DevBuf<K> ktmp; DEV_ALLOC(ctx, ktmp, n);
-	DevBuf<uint32_t> vtmp; if (d_vals) DEV_ALLOC(ctx, vtmp, n);
+	// ping-pong between the caller's arrays and a temporary; with an ODD number of passes a second temporary takes the
+	// first pass, so that the last one lands in the caller's arrays without a copy back
+	const uint32_t n_pass = (end_bit - begin_bit + 7) / 8;
+	DevBuf<K> ktmp, ktmp2; DEV_ALLOC(ctx, ktmp, n);
+	DevBuf<uint32_t> vtmp, vtmp2; if (d_vals) DEV_ALLOC(ctx, vtmp, n);
+	if (n_pass & 1) { DEV_ALLOC(ctx, ktmp2, n); if (d_vals) DEV_ALLOC(ctx, vtmp2, n); }
 	DevBuf<uint32_t> hist; DEV_ALLOC(ctx, hist, (uint64_t)256 * nb);
-	K* kin = d_keys; K* kout = ktmp.p; uint32_t* vin = d_vals; uint32_t* vout = vtmp.p;
-	for (uint32_t shift = begin_bit; shift < end_bit; shift += 8)
+	K* kin = d_keys; uint32_t* vin = d_vals;
+	uint32_t pass = 0;
+	for (uint32_t shift = begin_bit; shift < end_bit; shift += 8, ++pass)
 	{
+		// destinations: even count: tmp, keys, tmp, keys ...; odd count: tmp2, tmp, keys, tmp, keys ...
+		K* kout; uint32_t* vout;
+		if (n_pass & 1) { kout = pass == 0 ? ktmp2.p : (pass & 1) ? ktmp.p : d_keys; vout = pass == 0 ? vtmp2.p : (pass & 1) ? vtmp.p : d_vals; }
+		else { kout = (pass & 1) ? d_keys : ktmp.p; vout = (pass & 1) ? d_vals : vtmp.p; }
+		if (n_pass == 1) { kout = ktmp.p; vout = vtmp.p; }
 		{
 			LAUNCHB(ctx, n * sizeof(K), (k_sort_hist<K>), nb, ST, (const K*)kin, n, shift, hist.p, nb);
 		}
@@ -109,7 +119,7 @@ cl_status sort_impl(cl_ctx* ctx, K* d_keys, uint32_t* d_vals, uint64_t n, uint32
 				LAUNCHB(ctx, n * 2 * sizeof(K), (k_sort_scatter<K, false>), nb, ST, (const K*)kin, (const uint32_t*)nullptr, kout, (uint32_t*)nullptr, n, shift, (const uint32_t*)hist.p, nb);
 		}
 		HIP_TRY(ctx, hipGetLastError());
-		std::swap(kin, kout); std::swap(vin, vout);
+		kin = kout; vin = vout;
 	}
 	if (kin != d_keys)
 	{
