@@ -27,6 +27,7 @@ extern "C" void cl_ctx_destroy(cl_ctx* c)
 	for (auto& p : c->pending) { (void)hipEventDestroy(p.second.first); (void)hipEventDestroy(p.second.second); }
 	for (auto e : c->ev_pool) (void)hipEventDestroy(e);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
+	if (c->side) (void)hipStreamDestroy(c->side);
 	c->pool.trim();
 	delete c;
 }

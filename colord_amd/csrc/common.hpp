@@ -60,6 +60,7 @@ struct cl_ctx {
 	DevPool pool;
 	int device = 0;
 	hipStream_t stream = nullptr;
+	hipStream_t side = nullptr;                  // second stream for chains that would leave the machine idle (created on first use)
 	std::string err;
 	bool timing = false;
 	std::map<std::string, KernelTime> times;     // per-kernel accumulated HIP-event time of the last API call

@@ -940,6 +940,17 @@ extern "C" cl_status cl_dna_coder_create(cl_ctx* ctx, uint32_t max_alt_refs, int
 }
 extern "C" void cl_dna_coder_free(cl_dna_coder* d) { delete d; }
 
+// The interval coding of a group is a set of dependent chains (one lane per part, rc_dev.hpp) that leaves the machine
+// idle: it runs on the context's side stream while the main stream sorts and evolves the models of the NEXT group.
+namespace {
+struct SideSync { hipStream_t s = nullptr; ~SideSync() { if (s) (void)hipStreamSynchronize(s); } };
+struct PendingGroup {
+	DevBuf<triple_t> trip; DevBuf<uint64_t> d_gbase, d_out_off, d_size, d_dst_off; DevBuf<uint32_t> d_plen; DevBuf<uint8_t> tmp;
+	std::vector<uint64_t> out_off; uint32_t p0 = 0, np = 0;
+	SideSync sync;                                  // destroyed first: nothing above is released while the side stream runs
+};
+} // namespace
+
 // CEntrComprReads::Compress for a batch of whole parts (entr_read.h:56-80)
 extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads* refs, const uint8_t* d_es, const uint64_t* d_es_off,
                                    const uint32_t* d_es_ntuples, uint32_t n_reads, const uint32_t* h_part_bounds, uint32_t n_parts,
@@ -999,6 +1010,23 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 			(const uint64_t*)sym_off.p, 0u, n_reads, key.p);
 		HIP_TRY(ctx, hipGetLastError());
 	}
+	std::unique_ptr<PendingGroup> pending;
+	auto finish_group = [&](PendingGroup& g) -> cl_status {
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->side));
+		g.sync.s = nullptr;
+		HIP_TRY(ctx, hipMemcpy(h_part_sizes + g.p0, g.d_size.p, g.np * 8, hipMemcpyDeviceToHost));   // (a copy to pageable memory queued behind the kernel would block the host there)
+		for (uint32_t p = 0; p < g.np; ++p) if (h_part_sizes[g.p0 + p] == ~0ULL) return cl_fail(ctx, CL_E_CAPACITY, "cl_dna_encode: internal part buffer overflow");
+		std::vector<uint64_t> dst_off(g.np);
+		uint64_t w = written;
+		for (uint32_t p = 0; p < g.np; ++p) { dst_off[p] = w; w += h_part_sizes[g.p0 + p]; }
+		if (w > cap) { *n_out = w; return cl_fail(ctx, CL_E_CAPACITY, "cl_dna_encode: output capacity " + std::to_string(cap) + " too small"); }
+		HIP_TRY(ctx, hipMemcpyAsync(g.d_dst_off.p, dst_off.data(), g.np * 8, hipMemcpyHostToDevice, ctx->stream));
+		LAUNCH(ctx, k_gather_bytes2, g.np, 256, (const uint8_t*)g.tmp.p, (const uint64_t*)g.d_out_off.p, (const uint64_t*)g.d_dst_off.p, (const uint64_t*)g.d_size.p, d_out);
+		HIP_TRY(ctx, hipGetLastError());
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                         // (dst_off is read by the copy above)
+		written = w;
+		return CL_OK;
+	};
 	uint32_t p0 = 0;
 	while (p0 < n_parts)
 	{
@@ -1034,14 +1062,16 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 			gbase[g + 1] = gbase[g] + (uint64_t)lm * 64;
 		}
 		if (gbase[ng] >= (1ull << 32)) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_dna_encode: group too large for 32-bit triple indices");
-		DevBuf<uint64_t> d_sym_start, d_gbase; DevBuf<uint32_t> d_plen, d_pfirst;
+		auto G = std::make_unique<PendingGroup>(); G->p0 = p0; G->np = np;
+		DevBuf<uint64_t>& d_gbase = G->d_gbase; DevBuf<uint32_t>& d_plen = G->d_plen; DevBuf<triple_t>& trip = G->trip;
+		DevBuf<uint64_t> d_sym_start; DevBuf<uint32_t> d_pfirst;
 		DEV_ALLOC(ctx, d_sym_start, np + 1); DEV_ALLOC(ctx, d_gbase, ng + 1); DEV_ALLOC(ctx, d_plen, np); DEV_ALLOC(ctx, d_pfirst, np + 1);
 		HIP_TRY(ctx, hipMemcpyAsync(d_sym_start.p, sym_start.data(), (np + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
 		HIP_TRY(ctx, hipMemcpyAsync(d_gbase.p, gbase.data(), (ng + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
 		HIP_TRY(ctx, hipMemcpyAsync(d_plen.p, plen.data(), np * 4, hipMemcpyHostToDevice, ctx->stream));
 		HIP_TRY(ctx, hipMemcpyAsync(d_pfirst.p, pfirst.data(), (np + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
 		TripLayoutDev lay{ d_pfirst.p, d_sym_start.p, d_gbase.p, np };
-		DevBuf<triple_t> trip; DEV_ALLOC(ctx, trip, gbase[ng]);
+		DEV_ALLOC(ctx, trip, gbase[ng]);
 		if (n_syms)
 		{
 			uint64_t* const gkey = key.p + s0;                                       // this group's keys (written by the walk above)
@@ -1118,28 +1148,29 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 		HIP_TRY(ctx, hipMemcpy(&herr, err.p, 4, hipMemcpyDeviceToHost));
 		if (herr & 8) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_dna_encode: epoch table of a long context run too small");
 		if (herr) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_dna_encode: a read uses more than 64 alternative references");
-		// interval arithmetic per part
-		std::vector<uint64_t> out_off(np + 1);
-		out_off[0] = 0;
-		for (uint32_t p = 0; p < np; ++p) { uint64_t s = plen[p]; out_off[p + 1] = out_off[p] + ((s * 18 + 7) / 8 + s / 16 + 64 + 7) / 8 * 8; }
-		DevBuf<uint8_t> tmp; DEV_ALLOC(ctx, tmp, out_off[np]);
-		DevBuf<uint64_t> d_out_off, d_size, d_dst_off;
-		DEV_ALLOC(ctx, d_out_off, np + 1); DEV_ALLOC(ctx, d_size, np); DEV_ALLOC(ctx, d_dst_off, np);
-		HIP_TRY(ctx, hipMemcpyAsync(d_out_off.p, out_off.data(), (np + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-		LAUNCHB(ctx, n_syms * 16.0, k_range_code, ng, 64, (const triple_t*)trip.p, (const uint64_t*)d_gbase.p, (const uint32_t*)d_plen.p, np, tmp.p, (const uint64_t*)d_out_off.p, d_size.p);
-		HIP_TRY(ctx, hipGetLastError());
-		HIP_TRY(ctx, hipMemcpyAsync(h_part_sizes + p0, d_size.p, np * 8, hipMemcpyDeviceToHost, ctx->stream));
-		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-		for (uint32_t p = 0; p < np; ++p) if (h_part_sizes[p0 + p] == ~0ULL) return cl_fail(ctx, CL_E_CAPACITY, "cl_dna_encode: internal part buffer overflow");
-		std::vector<uint64_t> dst_off(np);
-		uint64_t w = written;
-		for (uint32_t p = 0; p < np; ++p) { dst_off[p] = w; w += h_part_sizes[p0 + p]; }
-		if (w > cap) { *n_out = w; return cl_fail(ctx, CL_E_CAPACITY, "cl_dna_encode: output capacity " + std::to_string(cap) + " too small"); }
-		HIP_TRY(ctx, hipMemcpyAsync(d_dst_off.p, dst_off.data(), np * 8, hipMemcpyHostToDevice, ctx->stream));
-		LAUNCH(ctx, k_gather_bytes2, np, 256, (const uint8_t*)tmp.p, (const uint64_t*)d_out_off.p, (const uint64_t*)d_dst_off.p, (const uint64_t*)d_size.p, d_out);
-		written = w;
+		// interval arithmetic per part: on the side stream; the previous group's result is collected first
+		if (pending) { CL_TRY(finish_group(*pending)); pending.reset(); }
+		if (!ctx->side) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+		G->out_off.resize(np + 1);
+		G->out_off[0] = 0;
+		for (uint32_t p = 0; p < np; ++p) { uint64_t sy = plen[p]; G->out_off[p + 1] = G->out_off[p] + ((sy * 18 + 7) / 8 + sy / 16 + 64 + 7) / 8 * 8; }
+		DEV_ALLOC(ctx, G->tmp, G->out_off[np]);
+		DEV_ALLOC(ctx, G->d_out_off, np + 1); DEV_ALLOC(ctx, G->d_size, np); DEV_ALLOC(ctx, G->d_dst_off, np);
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                         // the triples are complete
+		{
+			hipStream_t main_stream = ctx->stream;
+			ctx->stream = ctx->side;                                              // (launch + timing events on the side stream)
+			G->sync.s = ctx->side;
+			hipError_t e1 = hipMemcpyAsync(G->d_out_off.p, G->out_off.data(), (np + 1) * 8, hipMemcpyHostToDevice, ctx->side);
+			LAUNCHB(ctx, n_syms * 16.0, k_range_code, ng, 64, (const triple_t*)trip.p, (const uint64_t*)d_gbase.p, (const uint32_t*)d_plen.p, np, G->tmp.p, (const uint64_t*)G->d_out_off.p, G->d_size.p);
+			hipError_t e2 = hipGetLastError();
+			ctx->stream = main_stream;
+			HIP_TRY(ctx, e1); HIP_TRY(ctx, e2);
+		}
+		pending = std::move(G);
 		p0 = p1;
 	}
+	if (pending) { CL_TRY(finish_group(*pending)); pending.reset(); }
 	{	// carry the coder state to the next call
 		DevBuf<uint32_t> lt; DEV_ALLOC(ctx, lt, 1);
 		LAUNCH(ctx, k_last_types, 1, 1, (const uint8_t*)rflag.p, n_reads, D->prev_types, lt.p);

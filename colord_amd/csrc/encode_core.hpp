@@ -733,6 +733,9 @@ struct SegWriter {
 // open run in (sym, rep)).  The count pass of the kernels saves one every few KB of output, so that the write pass can
 // run one lane per CHUNK, not per read: the chunk that starts at the state ends at (stop_it, stop_q).  States are saved
 // between fragments and, every 32 symbols, inside the scripts of gaps (a gap can be most of a read).
+#ifdef CL_EMIT_DEBUG
+__device__ unsigned long long g_emit_dbg[2];
+#endif
 struct EmitCk {
 	uint32_t read, used; uint64_t start_it, stop_it, n; uint32_t mid_q, stop_q;     // mid_q / stop_q != 0: inside the script of fragment start_it / stop_it, at that symbol
 	uint32_t sf[10], si[10], s_last[10], s_cur[10]; int32_t sp; uint32_t enter, n_tuples;
@@ -883,6 +886,9 @@ CL_DEV inline void emit_read(const ArenaV& A, const uint32_t* inv, const uint8_t
 		}
 	}
 	o.finish();
+#ifdef CL_EMIT_DEBUG
+	if (WRITE && ck) atomicAdd(&g_emit_dbg[0], (unsigned long long)(o.n - (ck->start_it ? ck->n : 0))), atomicAdd(&g_emit_dbg[1], 1ull);
+#endif
 	if (!WRITE) { sizes[r] = (uint32_t)o.n; ntuples[r] = o.n_tuples; }
 }
 

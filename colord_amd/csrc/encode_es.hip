@@ -590,7 +590,7 @@ __global__ __launch_bounds__(64) void k_estimator(TreeV T, const uint32_t* __res
 //   k_emit_count  one lane per READ: sizes and tuple counts, and every EMIT_CHUNK output bytes the state of the walk;
 //   k_emit_write  one lane per saved STATE: resumes there and writes the bytes up to the next saved state;
 //   k_emit_plain  reads stored plain: one wave per read, one lane per base.
-constexpr uint32_t EMIT_LPW = 16, EMIT_WPW = 32, EMIT_CHUNK = 2048;
+constexpr uint32_t EMIT_LPW = 16, EMIT_WPW = 64, EMIT_CHUNK = 2048;
 __global__ void k_emit_slots(const uint32_t* __restrict__ lens, const uint32_t* __restrict__ frame_of_read, uint32_t n, uint32_t* __restrict__ out)
 {	// slots for saved states: a guess of the output size; a read with more output just gets longer last chunks
 	const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -871,6 +871,9 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 	*n_out = total;
 	if (total > cap || (total && !d_es)) return cl_fail(ctx, CL_E_CAPACITY, "cl_encode_reads: need " + std::to_string(total) + " bytes");
 	if (n_slots) LAUNCHB(ctx, reads->total_bases * 1.25 + (double)total, k_emit_write, grid_for(n_slots, EMIT_WPW), 64, /* the same in + the tuple bytes out */ A, (const uint32_t*)reads->inv.p, has_n, T, AV.data, (const EmitCk*)cks.p, n_slots, (const uint64_t*)d_es_off, d_es);
+#ifdef CL_EMIT_DEBUG
+	{ (void)hipDeviceSynchronize(); unsigned long long h[2]; (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(enc::g_emit_dbg), 16); fprintf(stderr, "[emit dbg] bytes written by chunk lanes %llu in %llu chunks; total output %llu\n", h[0], h[1], (unsigned long long)total); }
+#endif
 	LAUNCH(ctx, k_emit_plain, grid_for(nr, 4), 256, A, (const uint32_t*)reads->inv.p, has_n, (const uint32_t*)frame_of_read.p, nr, (const uint64_t*)d_es_off, d_es);
 	HIP_TRY(ctx, hipGetLastError());
 	HIP_TRY(ctx, hipStreamSynchronize(st));
