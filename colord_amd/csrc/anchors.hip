@@ -605,27 +605,56 @@ extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* read
 	std::vector<DevBuf<uint32_t>> chunks; std::vector<uint64_t> chunk_n;
 	uint64_t total_anchors = 0;
 	double pairs_per_base = 0.5;                                     // match pairs per read base seen so far (room for the next batch)
-	uint32_t r0 = 0;
-	while (r0 < nr)
-	{
+	// The table build of a batch (random atomics, bound by the memory system) runs on the context's side stream while the
+	// main stream matches, sorts and chains the batch before it (ALU / latency bound): batches are independent.
+	struct TableBatch {
+		uint32_t r0 = 0, r1 = 0; uint64_t acc = 0, nsum = 0;
+		DevBuf<uint32_t> n_distinct, next; DevBuf<uint64_t> toff, noff; DevBuf<EncSlot> slots;
+		struct SideSync { hipStream_t s = nullptr; ~SideSync() { if (s) (void)hipStreamSynchronize(s); } } sync;   // destroyed first
+	};
+	if (!ctx->side) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+	auto prepare = [&](uint32_t r0, std::unique_ptr<TableBatch>& out) -> cl_status {
+		out = std::make_unique<TableBatch>();
+		TableBatch& B = *out;
 		uint32_t r1 = r0; uint64_t acc = 0;
 		while (r1 < nr && (r1 == r0 || acc + h_len[r1] <= BATCH_BASES) && (uint64_t)(r1 - r0 + 1) * 2 * c < (1ull << 24)) { acc += h_len[r1]; ++r1; }
-		const uint32_t nb = r1 - r0, n_tasks = nb * 2 * c;
-		TaskCfg cfg{ r0, r1, c, m, 0.f, frac_always, frac_min, max_matches_mult };
-		DevBuf<uint32_t> tsize, nsize, err, n_distinct; DEV_ALLOC(ctx, tsize, nb); DEV_ALLOC(ctx, nsize, nb); DEV_ALLOC(ctx, err, 1); DEV_ALLOC(ctx, n_distinct, nb);
+		B.r0 = r0; B.r1 = r1; B.acc = acc;
+		const uint32_t nb = r1 - r0;
+		DevBuf<uint32_t> tsize, nsize, err; DEV_ALLOC(ctx, tsize, nb); DEV_ALLOC(ctx, nsize, nb); DEV_ALLOC(ctx, err, 1); DEV_ALLOC(ctx, B.n_distinct, nb);
 		HIP_TRY(ctx, hipMemsetAsync(err.p, 0, 4, ctx->stream));
-		HIP_TRY(ctx, hipMemsetAsync(n_distinct.p, 0, (uint64_t)nb * 4, ctx->stream));
 		LAUNCH(ctx, k_table_sizes, grid_for(nb, 256), 256, (const uint32_t*)reads->lens.p, (const uint8_t*)reads->has_n.p, d_cand_n, r0, r1, m, tsize.p, nsize.p, err.p);
-		DevBuf<uint64_t> toff, noff; DEV_ALLOC(ctx, toff, (uint64_t)nb + 1); DEV_ALLOC(ctx, noff, (uint64_t)nb + 1);
-		uint64_t tsum = 0, nsum = 0;
-		CL_TRY(dev_exclusive_scan_u64(ctx, tsize.p, toff.p, nb, &tsum));
-		CL_TRY(dev_exclusive_scan_u64(ctx, nsize.p, noff.p, nb, &nsum));
+		DEV_ALLOC(ctx, B.toff, (uint64_t)nb + 1); DEV_ALLOC(ctx, B.noff, (uint64_t)nb + 1);
+		uint64_t tsum = 0;
+		CL_TRY(dev_exclusive_scan_u64(ctx, tsize.p, B.toff.p, nb, &tsum));
+		CL_TRY(dev_exclusive_scan_u64(ctx, nsize.p, B.noff.p, nb, &B.nsum));
 		uint32_t herr = 0; HIP_TRY(ctx, hipMemcpy(&herr, err.p, 4, hipMemcpyDeviceToHost));
 		if (herr) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_anchor_candidates: reads of 2^20 bases or more are not supported yet");
-		DevBuf<EncSlot> slots; DevBuf<uint32_t> next; DEV_ALLOC(ctx, slots, tsum); DEV_ALLOC(ctx, next, nsum);
-		HIP_TRY(ctx, hipMemsetAsync(slots.p, 0xff, tsum * sizeof(EncSlot), ctx->stream));
-		EncTable T{ slots.p, toff.p, next.p, noff.p };
-		LAUNCHB(ctx, nsum * (0.25 + 16.0), k_table_insert, nb, 1024, A, r0, r1, m, T, n_distinct.p);
+		DEV_ALLOC(ctx, B.slots, tsum); DEV_ALLOC(ctx, B.next, B.nsum);
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                         // offsets complete before the side stream reads them
+		B.sync.s = ctx->side;
+		HIP_TRY(ctx, hipMemsetAsync(B.n_distinct.p, 0, (uint64_t)nb * 4, ctx->side));
+		HIP_TRY(ctx, hipMemsetAsync(B.slots.p, 0xff, tsum * sizeof(EncSlot), ctx->side));
+		EncTable T{ B.slots.p, B.toff.p, B.next.p, B.noff.p };
+		hipStream_t main_stream = ctx->stream;
+		ctx->stream = ctx->side;                                                  // (launch + timing events on the side stream)
+		LAUNCHB(ctx, B.nsum * (0.25 + 16.0), k_table_insert, nb, 1024, A, r0, r1, m, T, B.n_distinct.p);
+		ctx->stream = main_stream;
+		HIP_TRY(ctx, hipGetLastError());
+		return CL_OK;
+	};
+	std::unique_ptr<TableBatch> cur, nxt;
+	if (nr) CL_TRY(prepare(0, cur));
+	while (cur)
+	{
+		const uint32_t r0 = cur->r0, r1 = cur->r1; const uint64_t acc = cur->acc;
+		const uint32_t nb = r1 - r0, n_tasks = nb * 2 * c;
+		TaskCfg cfg{ r0, r1, c, m, 0.f, frac_always, frac_min, max_matches_mult };
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                         // the batch before is through (its buffers may be handed to the side stream)
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->side));                           // this batch's tables are built
+		cur->sync.s = nullptr;
+		if (r1 < nr) CL_TRY(prepare(r1, nxt));
+		DevBuf<uint32_t>& n_distinct = cur->n_distinct;
+		EncTable T{ cur->slots.p, cur->toff.p, cur->next.p, cur->noff.p };
 		DevBuf<uint32_t> pair_cnt; DEV_ALLOC(ctx, pair_cnt, (uint64_t)n_tasks + 1);
 		DevBuf<uint64_t> pair_off; DEV_ALLOC(ctx, pair_off, (uint64_t)n_tasks + 1);
 		DevBuf<unsigned long long> d_np; DEV_ALLOC(ctx, d_np, 2);           // match pairs, probes
@@ -696,7 +725,7 @@ extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* read
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 		chunks.push_back(std::move(chunk)); chunk_n.push_back(n_here);
 		total_anchors += n_here;
-		r0 = r1;
+		cur = std::move(nxt);
 	}
 	X->n_anchors = total_anchors;
 	DEV_ALLOC(ctx, X->anchors, 3 * total_anchors);

@@ -39,6 +39,10 @@ struct DevPool {
 		auto it = free_blocks.lower_bound(r);
 		if (it != free_blocks.end() && it->first <= r + r / 2 + (64ull << 20))
 		{ *out = it->second; *got = it->first; cached_bytes -= it->first; free_blocks.erase(it); return hipSuccess; }
+		// a large request rather borrows a larger cached block than grows the footprint (the stages of a pass run one after
+		// the other; their big buffers are not needed at the same time)
+		if (it != free_blocks.end() && r >= (1ull << 30))
+		{ *out = it->second; *got = it->first; cached_bytes -= it->first; free_blocks.erase(it); return hipSuccess; }
 		hipError_t e = hipMalloc(out, r);
 		static const bool dbg = getenv("COLORD_HIP_POOL_DEBUG") != nullptr;
 		if (dbg) fprintf(stderr, "[pool] hipMalloc %.3f GB (%s), cached %.3f GB in %zu blocks\n", r / 1e9, e == hipSuccess ? "ok" : "failed", cached_bytes / 1e9, free_blocks.size());
