@@ -110,6 +110,22 @@ def hot_path_step(ctx, reads, k, quals=None, qual_off=None, part_bounds=None, es
             now = time.perf_counter()
             stage_t[name] = stage_t.get(name, 0.0) + (now - t_last[0]) * 1e3
             t_last[0] = now
+    qjob = None
+    if quals is not None and QUAL_CTX is not None and stage_t is None:
+        # the quality stream of level 1 needs nothing of the DNA path: a second context of the same GPU codes it on a
+        # host thread meanwhile (the native call releases the GIL), as cl_compress_shard does on one GPU
+        import threading
+        qres = {}
+
+        def qrun():
+            try:
+                qc_ = QUAL_CTX.qual_coder(2, 0, 1, (7, 14, 26), ())
+                qres["out"] = qc_.encode(reads, quals, qual_off, part_bounds)
+                qc_.free()
+            except Exception as e:          # surfaced after the join
+                qres["err"] = e
+        qjob = threading.Thread(target=qrun)
+        qjob.start()
     km = ctx.kmer_scan(reads, k, p["f"])
     n_surv = km.numel()
     km = par.exchange_kmers(km)                            # exchange 1a: k-mers to the owner of their key
@@ -141,11 +157,12 @@ def hot_path_step(ctx, reads, k, quals=None, qual_off=None, part_bounds=None, es
     if quals is not None:
         # a13+a15: quality stream, ONT default 4-avg at level 1 (contexts do not need the edit script at level 1).
         # One model domain per GPU (the adaptive models live for the whole shard), parts cut like the reference's packs.
-        qc = ctx.qual_coder(2, 0, 1, (7, 14, 26), ())
-        payload, sizes = qc.encode(reads, quals, qual_off, part_bounds)
-        qc.free()
-        lap("a13+a15 quality stream")
-        out.update(qual_bytes=int(payload.numel()), qual_parts=len(sizes))
+        if qjob is None:
+            qc = ctx.qual_coder(2, 0, 1, (7, 14, 26), ())
+            payload, sizes = qc.encode(reads, quals, qual_off, part_bounds)
+            qc.free()
+            lap("a13+a15 quality stream")
+            out.update(qual_bytes=int(payload.numel()), qual_parts=len(sizes))
         # a8 + a10-a12 + a14: DNA stream.  Reference reads = the accepted reads of all ranks (CReferenceReads is one
         # process-wide store in the reference; each rank replicates it), anchors against the candidates, edit scripts,
         # tuple streams, DNA coder at level 1.  The estimator packs are the reference's reader packs (4 Mi symbols,
@@ -169,6 +186,12 @@ def hot_path_step(ctx, reads, k, quals=None, qual_off=None, part_bounds=None, es
         lap("a14 DNA stream")
         out.update(dna_bytes=int(dpayload.numel()), tuple_bytes=int(es.numel()), reads_stored_plain=n_plain, anchors=int(anc.total))
         anc.free(); my_refs.free()
+        if qjob is not None:
+            qjob.join()
+            if "err" in qres:
+                raise qres["err"]
+            payload, sizes = qres["out"]
+            out.update(qual_bytes=int(payload.numel()), qual_parts=len(sizes))
     index.free(); lists.free(); kset.free()
     if stage_t is not None:
         print("stage wall ms:", {k_: round(v, 1) for k_, v in stage_t.items()}, file=sys.stderr)
@@ -222,7 +245,7 @@ def main():
 
     ctx = Context(local, timing=True)
     global QUAL_CTX
-    QUAL_CTX = Context(local, timing=True) if world == 1 and not os.environ.get("BENCH_NO_OVERLAP") else None
+    QUAL_CTX = Context(local, timing=True) if not os.environ.get("BENCH_NO_OVERLAP") else None
     bases = int(args.bases)
     genome_len = max(1_000_000, int(bases * world / args.coverage))
     # same genome on every rank (seed), different reads per rank
