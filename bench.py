@@ -322,6 +322,8 @@ def main():
         print(json.dumps(line))
     reads.free()
     ctx.close()
+    if QUAL_CTX is not None:
+        QUAL_CTX.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -24,7 +24,8 @@ struct KernelTime { double ms = 0; uint32_t launches = 0; double bytes = 0; };  
 // which dominated short calls.  Blocks are binned by rounded size and reused across calls.
 struct DevPool {
 	std::multimap<uint64_t, void*> free_blocks;
-	uint64_t cached_bytes = 0;
+	uint64_t cached_bytes = 0, live_bytes = 0, peak_live = 0, peak_total = 0;   // (statistics for COLORD_HIP_POOL_DEBUG)
+	void account(uint64_t got) { live_bytes += got; if (live_bytes > peak_live) peak_live = live_bytes; if (live_bytes + cached_bytes > peak_total) peak_total = live_bytes + cached_bytes; }
 	static uint64_t round_size(uint64_t bytes)
 	{
 		if (bytes < 256) return 256;
@@ -38,11 +39,11 @@ struct DevPool {
 		// costs around a second, and a cache of exact sizes only would outgrow HBM over one pass of the pipeline)
 		auto it = free_blocks.lower_bound(r);
 		if (it != free_blocks.end() && it->first <= r + r / 2 + (64ull << 20))
-		{ *out = it->second; *got = it->first; cached_bytes -= it->first; free_blocks.erase(it); return hipSuccess; }
+		{ *out = it->second; *got = it->first; cached_bytes -= it->first; free_blocks.erase(it); account(*got); return hipSuccess; }
 		// a large request rather borrows a larger cached block than grows the footprint (the stages of a pass run one after
 		// the other; their big buffers are not needed at the same time)
 		if (it != free_blocks.end() && r >= (1ull << 30))
-		{ *out = it->second; *got = it->first; cached_bytes -= it->first; free_blocks.erase(it); return hipSuccess; }
+		{ *out = it->second; *got = it->first; cached_bytes -= it->first; free_blocks.erase(it); account(*got); return hipSuccess; }
 		hipError_t e = hipMalloc(out, r);
 		static const bool dbg = getenv("COLORD_HIP_POOL_DEBUG") != nullptr;
 		if (dbg) fprintf(stderr, "[pool] hipMalloc %.3f GB (%s), cached %.3f GB in %zu blocks\n", r / 1e9, e == hipSuccess ? "ok" : "failed", cached_bytes / 1e9, free_blocks.size());
@@ -54,10 +55,12 @@ struct DevPool {
 			e = hipMalloc(out, r);
 		}
 		*got = r;
+		if (e == hipSuccess) account(r);
 		return e;
 	}
-	void put(void* p, uint64_t r) { free_blocks.emplace(r, p); cached_bytes += r; }
-	void trim() { for (auto& b : free_blocks) (void)hipFree(b.second); free_blocks.clear(); cached_bytes = 0; }
+	void put(void* p, uint64_t r) { free_blocks.emplace(r, p); cached_bytes += r; live_bytes -= r; }
+	void trim() { if (getenv("COLORD_HIP_POOL_DEBUG")) fprintf(stderr, "[pool] at trim: peak live %.1f GB, peak live + cached %.1f GB, cached %.1f GB\n", peak_live / 1e9, peak_total / 1e9, cached_bytes / 1e9);
+		for (auto& b : free_blocks) (void)hipFree(b.second); free_blocks.clear(); cached_bytes = 0; }
 };
 
 struct cl_ctx {

@@ -463,8 +463,8 @@ __global__ __launch_bounds__(256) void k_fill_sidx(const uint64_t* __restrict__ 
 	const uint32_t lane = threadIdx.x & 63;
 	const uint64_t a = sym_off[r] - s0, b = sym_off[r + 1] - s0;
 	if (a == b) return;
-	const uint32_t part = part_of_read(lay, r);
-	const uint64_t tbase = lay.group_base[part >> 6] - lay.part_sym_start[part] * 64 + (part & 63);
+	const uint32_t part = part_of_read(lay, r), pl = lay.rank ? lay.rank[part] : part;
+	const uint64_t tbase = lay.group_base[pl >> 6] - lay.part_sym_start[part] * 64 + (pl & 63);
 	for (uint64_t i = a + lane; i < b; i += 64) sidx[i] = (uint32_t)(tbase + i * 64);
 }
 // ---- D1b: bases of plain reads, one wave per read, one lane per base (dna_coder.cpp:1178-1227) ----------
@@ -946,7 +946,7 @@ namespace {
 struct SideSync { hipStream_t s = nullptr; ~SideSync() { if (s) (void)hipStreamSynchronize(s); } };
 struct PendingGroup {
 	DevBuf<triple_t> trip; DevBuf<uint64_t> d_gbase, d_out_off, d_size, d_dst_off; DevBuf<uint32_t> d_plen; DevBuf<uint8_t> tmp;
-	std::vector<uint64_t> out_off; uint32_t p0 = 0, np = 0;
+	std::vector<uint64_t> out_off; std::vector<uint32_t> rank; uint32_t p0 = 0, np = 0;   // rank: part -> place (descending length)
 	SideSync sync;                                  // destroyed first: nothing above is released while the side stream runs
 };
 } // namespace
@@ -1014,11 +1014,12 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 	auto finish_group = [&](PendingGroup& g) -> cl_status {
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->side));
 		g.sync.s = nullptr;
-		HIP_TRY(ctx, hipMemcpy(h_part_sizes + g.p0, g.d_size.p, g.np * 8, hipMemcpyDeviceToHost));   // (a copy to pageable memory queued behind the kernel would block the host there)
-		for (uint32_t p = 0; p < g.np; ++p) if (h_part_sizes[g.p0 + p] == ~0ULL) return cl_fail(ctx, CL_E_CAPACITY, "cl_dna_encode: internal part buffer overflow");
-		std::vector<uint64_t> dst_off(g.np);
+		std::vector<uint64_t> size_r(g.np);                                      // by place
+		HIP_TRY(ctx, hipMemcpy(size_r.data(), g.d_size.p, g.np * 8, hipMemcpyDeviceToHost));   // (a copy to pageable memory queued behind the kernel would block the host there)
+		for (uint32_t p = 0; p < g.np; ++p) { h_part_sizes[g.p0 + p] = size_r[g.rank[p]]; if (h_part_sizes[g.p0 + p] == ~0ULL) return cl_fail(ctx, CL_E_CAPACITY, "cl_dna_encode: internal part buffer overflow"); }
+		std::vector<uint64_t> dst_off(g.np);                                     // by place, the bytes in part order
 		uint64_t w = written;
-		for (uint32_t p = 0; p < g.np; ++p) { dst_off[p] = w; w += h_part_sizes[g.p0 + p]; }
+		for (uint32_t p = 0; p < g.np; ++p) { dst_off[g.rank[p]] = w; w += h_part_sizes[g.p0 + p]; }
 		if (w > cap) { *n_out = w; return cl_fail(ctx, CL_E_CAPACITY, "cl_dna_encode: output capacity " + std::to_string(cap) + " too small"); }
 		HIP_TRY(ctx, hipMemcpyAsync(g.d_dst_off.p, dst_off.data(), g.np * 8, hipMemcpyHostToDevice, ctx->stream));
 		LAUNCH(ctx, k_gather_bytes2, g.np, 256, (const uint8_t*)g.tmp.p, (const uint64_t*)g.d_out_off.p, (const uint64_t*)g.d_dst_off.p, (const uint64_t*)g.d_size.p, d_out);
@@ -1030,22 +1031,16 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 	uint32_t p0 = 0;
 	while (p0 < n_parts)
 	{
-		// the group: as many parts as 31-bit symbol indices and the triple slots allow (16 bytes each; parts of unequal
-		// length leave slots unused)
-		const uint64_t GROUP_SLOTS = 9ull << 28;
+		// the group: as many parts as the symbol indices (31 bits) and the memory for the triples (16 bytes a symbol) allow
+		const uint64_t GROUP_SYMS = 5ull << 28;
 		uint32_t p1 = p0; const uint32_t r0 = h_part_bounds[p0];
 		std::vector<uint64_t> gbase(1, 0);
+		while (p1 < n_parts)
 		{
-			uint64_t slots_done = 0; uint32_t lm = 0;                                 // finished 64-part groups; longest part of the open one
-			while (p1 < n_parts)
-			{
-				const uint64_t pl = h_sym_off[h_part_bounds[p1 + 1]] - h_sym_off[h_part_bounds[p1]];
-				if (pl >= (1ull << 31) - 64) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_dna_encode: one part has >= 2^31 symbols");
-				const uint32_t nlm = std::max(lm, (uint32_t)pl);
-				if (p1 > p0 && (h_sym_off[h_part_bounds[p1 + 1]] - h_sym_off[r0] >= (1ull << 31) || slots_done + (uint64_t)nlm * 64 >= GROUP_SLOTS)) break;
-				lm = nlm; ++p1;
-				if (((p1 - p0) & 63) == 0) { slots_done += (uint64_t)lm * 64; lm = 0; }
-			}
+			const uint64_t pl = h_sym_off[h_part_bounds[p1 + 1]] - h_sym_off[h_part_bounds[p1]];
+			if (pl >= (1ull << 31) - 64) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_dna_encode: one part has >= 2^31 symbols");
+			if (p1 > p0 && h_sym_off[h_part_bounds[p1 + 1]] - h_sym_off[r0] >= GROUP_SYMS) break;
+			++p1;
 		}
 		const uint32_t r1 = h_part_bounds[p1], nr = r1 - r0, np = p1 - p0, ng = (np + 63) / 64;
 		const uint64_t s0 = h_sym_off[r0], n_syms = h_sym_off[r1] - s0;
@@ -1054,23 +1049,26 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 		std::vector<uint32_t> plen(np), pfirst(np + 1);
 		for (uint32_t p = 0; p <= np; ++p) { pfirst[p] = h_part_bounds[p0 + p]; sym_start[p] = h_sym_off[pfirst[p]] - s0; }
 		for (uint32_t p = 0; p < np; ++p) plen[p] = (uint32_t)(sym_start[p + 1] - sym_start[p]);
+		// places in the interleaved layout by descending length: the 64 parts of a wave of the interval coder are alike, and no
+		// slots are wasted on the longest part of a group (parts hold whole reads: 65 k to 265 k symbols in one group otherwise)
+		std::vector<uint32_t> order(np), rank(np), plen_r(np);
+		for (uint32_t p = 0; p < np; ++p) order[p] = p;
+		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return plen[a] > plen[b]; });
+		for (uint32_t i = 0; i < np; ++i) { rank[order[i]] = i; plen_r[i] = plen[order[i]]; }
 		gbase.assign(ng + 1, 0);
-		for (uint32_t g = 0; g < ng; ++g)
-		{
-			uint32_t lm = 0;
-			for (uint32_t p = g * 64; p < std::min(np, g * 64 + 64); ++p) lm = std::max(lm, plen[p]);
-			gbase[g + 1] = gbase[g] + (uint64_t)lm * 64;
-		}
+		for (uint32_t g = 0; g < ng; ++g) gbase[g + 1] = gbase[g] + (uint64_t)plen_r[g * 64] * 64;
 		if (gbase[ng] >= (1ull << 32)) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_dna_encode: group too large for 32-bit triple indices");
-		auto G = std::make_unique<PendingGroup>(); G->p0 = p0; G->np = np;
+		auto G = std::make_unique<PendingGroup>(); G->p0 = p0; G->np = np; G->rank = rank;
 		DevBuf<uint64_t>& d_gbase = G->d_gbase; DevBuf<uint32_t>& d_plen = G->d_plen; DevBuf<triple_t>& trip = G->trip;
-		DevBuf<uint64_t> d_sym_start; DevBuf<uint32_t> d_pfirst;
+		DevBuf<uint64_t> d_sym_start; DevBuf<uint32_t> d_pfirst, d_rank;
+		DEV_ALLOC(ctx, d_rank, np);
+		HIP_TRY(ctx, hipMemcpyAsync(d_rank.p, rank.data(), np * 4, hipMemcpyHostToDevice, ctx->stream));
 		DEV_ALLOC(ctx, d_sym_start, np + 1); DEV_ALLOC(ctx, d_gbase, ng + 1); DEV_ALLOC(ctx, d_plen, np); DEV_ALLOC(ctx, d_pfirst, np + 1);
 		HIP_TRY(ctx, hipMemcpyAsync(d_sym_start.p, sym_start.data(), (np + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
 		HIP_TRY(ctx, hipMemcpyAsync(d_gbase.p, gbase.data(), (ng + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-		HIP_TRY(ctx, hipMemcpyAsync(d_plen.p, plen.data(), np * 4, hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(ctx, hipMemcpyAsync(d_plen.p, plen_r.data(), np * 4, hipMemcpyHostToDevice, ctx->stream));
 		HIP_TRY(ctx, hipMemcpyAsync(d_pfirst.p, pfirst.data(), (np + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-		TripLayoutDev lay{ d_pfirst.p, d_sym_start.p, d_gbase.p, np };
+		TripLayoutDev lay{ d_pfirst.p, d_sym_start.p, d_gbase.p, np, d_rank.p };
 		DEV_ALLOC(ctx, trip, gbase[ng]);
 		if (n_syms)
 		{
@@ -1153,7 +1151,7 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 		if (!ctx->side) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
 		G->out_off.resize(np + 1);
 		G->out_off[0] = 0;
-		for (uint32_t p = 0; p < np; ++p) { uint64_t sy = plen[p]; G->out_off[p + 1] = G->out_off[p] + ((sy * 18 + 7) / 8 + sy / 16 + 64 + 7) / 8 * 8; }
+		for (uint32_t p = 0; p < np; ++p) { uint64_t sy = plen_r[p]; G->out_off[p + 1] = G->out_off[p] + ((sy * 18 + 7) / 8 + sy / 16 + 64 + 7) / 8 * 8; }
 		DEV_ALLOC(ctx, G->tmp, G->out_off[np]);
 		DEV_ALLOC(ctx, G->d_out_off, np + 1); DEV_ALLOC(ctx, G->d_size, np); DEV_ALLOC(ctx, G->d_dst_off, np);
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                         // the triples are complete

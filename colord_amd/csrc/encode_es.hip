@@ -717,11 +717,19 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 			HIP_TRY(ctx, hipMemcpyAsync(h_cb, cb.p, 8 * N_CLASSES, hipMemcpyDeviceToHost, st));
 		}
 		HIP_TRY(ctx, hipStreamSynchronize(st));
-		// small gaps
+		// small gaps: on the side stream, next to the large ones on the main stream (one wave per SIMD with its state in
+		// LDS here, five waves per SIMD on a bump pool in HBM there: they share the machine well)
+		if (!ctx->side) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+		struct SideJoin { hipStream_t s; ~SideJoin() { (void)hipStreamSynchronize(s); } };
+		DevBuf<uint64_t> hist;
+		SideJoin side_join{ ctx->side };                                         // (after hist in destruction order: joins first)
 		{
 			uint32_t max_blocks = 1;
 			for (int nb = 1; nb <= 4; ++nb) max_blocks = std::max(max_blocks, std::min<uint32_t>(grid_for(hb[nb + 1] - hb[nb], 64), n_cu * 4));
-			DevBuf<uint64_t> hist; DEV_ALLOC(ctx, hist, (uint64_t)max_blocks * 256 * 4 * 2 * 64);
+			DEV_ALLOC(ctx, hist, (uint64_t)max_blocks * 256 * 4 * 2 * 64);
+			hipStream_t main_stream = ctx->stream;
+			ctx->stream = ctx->side;                                              // (launches + timing events on the side stream)
+			hipError_t le = hipSuccess;
 			for (int nb = 1; nb <= 4; ++nb)
 			{
 				const uint32_t n_list = hb[nb + 1] - hb[nb];
@@ -737,9 +745,10 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 				case 3: LAUNCHB_SHM(ctx, bytes, (k_align_small<3>), blocks, 64, lds, list, n_list, L.gaps.p, L.es.p, A, R, hist.p); break;
 				default: LAUNCHB_SHM(ctx, bytes, (k_align_small<4>), blocks, 64, lds, list, n_list, L.gaps.p, L.es.p, A, R, hist.p); break;
 				}
-				HIP_TRY(ctx, hipGetLastError());
+				if (le == hipSuccess) le = hipGetLastError();
 			}
-			HIP_TRY(ctx, hipStreamSynchronize(st));
+			ctx->stream = main_stream;
+			HIP_TRY(ctx, le);
 		}
 		// mid-size gaps
 		if (hb[6] > hb[5])
@@ -814,6 +823,7 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 				per_lane *= 8; max_lanes = std::max<uint32_t>(max_lanes / 8, 64);
 			}
 		}
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->side));                           // the small gaps are through
 		// statistics / decisions, children
 		DevBuf<uint32_t> sflag, sncand; DEV_ALLOC(ctx, sflag, ng + 1); DEV_ALLOC(ctx, sncand, ng + 1);
 		const uint32_t n_long = (uint32_t)(ng - n_pend);

@@ -23,6 +23,8 @@ struct TripLayoutDev {
 	const uint64_t* part_sym_start;    // np + 1 stream positions (relative to the call's first symbol)
 	const uint64_t* group_base;        // ceil(np / 64)
 	uint32_t np;
+	const uint32_t* rank = nullptr;    // optional: part -> place in the interleaved layout (places 64 g .. 64 g + 63 form group g);
+	                                   // parts placed by descending length waste no slots on the longest part of their group
 };
 // part containing read r (binary search over the part bounds)
 __device__ inline uint32_t part_of_read(const TripLayoutDev& L, uint32_t r)
@@ -33,7 +35,8 @@ __device__ inline uint32_t part_of_read(const TripLayoutDev& L, uint32_t r)
 }
 __device__ inline uint32_t trip_index(const TripLayoutDev& L, uint32_t part, uint64_t stream_pos)
 {
-	return (uint32_t)(L.group_base[part >> 6] + (stream_pos - L.part_sym_start[part]) * 64 + (part & 63));
+	const uint32_t pl = L.rank ? L.rank[part] : part;
+	return (uint32_t)(L.group_base[pl >> 6] + (stream_pos - L.part_sym_start[part]) * 64 + (pl & 63));
 }
 
 // floor(x / d) given inv = floor((2^64-1) / d): the high product is at most 2 below the quotient.

@@ -93,7 +93,10 @@ cl_status sort_impl(cl_ctx* ctx, K* d_keys, uint32_t* d_vals, uint64_t n, uint32
 	const uint32_t nb = grid_for(n, STILE);
 	// ping-pong between the caller's arrays and a temporary; with an ODD number of passes a second temporary takes the
 	// first pass, so that the last one lands in the caller's arrays without a copy back
-	const uint32_t n_pass = (end_bit - begin_bit + 7) / 8;
+	const uint32_t n_pass_real = (end_bit - begin_bit + 7) / 8;
+	// (the second temporary only while it is small: on the largest sorts its footprint costs more than the copy)
+	const bool third = (n_pass_real & 1) && n_pass_real > 1 && n * (sizeof(K) + (d_vals ? 4 : 0)) <= (16ull << 30);
+	const uint32_t n_pass = third ? n_pass_real : (n_pass_real + 1) & ~1u;          // even: plain ping-pong (+ copy back if the real count is odd)
 	DevBuf<K> ktmp, ktmp2; DEV_ALLOC(ctx, ktmp, n);
 	DevBuf<uint32_t> vtmp, vtmp2; if (d_vals) DEV_ALLOC(ctx, vtmp, n);
 	if (n_pass & 1) { DEV_ALLOC(ctx, ktmp2, n); if (d_vals) DEV_ALLOC(ctx, vtmp2, n); }
@@ -106,7 +109,6 @@ cl_status sort_impl(cl_ctx* ctx, K* d_keys, uint32_t* d_vals, uint64_t n, uint32
 		K* kout; uint32_t* vout;
 		if (n_pass & 1) { kout = pass == 0 ? ktmp2.p : (pass & 1) ? ktmp.p : d_keys; vout = pass == 0 ? vtmp2.p : (pass & 1) ? vtmp.p : d_vals; }
 		else { kout = (pass & 1) ? d_keys : ktmp.p; vout = (pass & 1) ? d_vals : vtmp.p; }
-		if (n_pass == 1) { kout = ktmp.p; vout = vtmp.p; }
 		{
 			LAUNCHB(ctx, n * sizeof(K), (k_sort_hist<K>), nb, ST, (const K*)kin, n, shift, hist.p, nb);
 		}
