@@ -669,33 +669,44 @@ CL_DEV inline uint32_t pend_walk(const TreeV& T, uint32_t frame0, uint32_t* out)
 // ---- tuple emission (encoder.cpp:1348-1443) -------------------------------------------------------------------------
 struct TupleOut {
 	uint8_t* p; uint64_t n; uint32_t n_tuples; bool write;
-	uint64_t acc = 0; uint32_t have = 0; bool aligned = false;               // bytes are gathered into aligned 8-byte stores
-	CL_DEV inline void byte(uint8_t v)
+	// Bytes are assembled in the aligned 8-byte word that holds position n and leave with one store per word; `have` bytes
+	// of that word are taken, the first `skip` of them by whoever wrote before this stream / chunk (first word only).
+	uint64_t acc = 0; uint32_t have = 0, skip = 0;
+	CL_DEV inline void start() { have = skip = (uint32_t)(((uint64_t)(size_t)p + n) & 7); acc = 0; }   // write mode: after p and n are set
+	// nb <= 8 bytes, the first in the low byte of v
+	CL_DEV inline void put(uint64_t v, uint32_t nb)
 	{
-		if (!write) { ++n; return; }
-		if (!aligned) { p[n] = v; ++n; aligned = (((uint64_t)(size_t)p + n) & 7) == 0; return; }
-		acc |= (uint64_t)v << (8 * have); ++have; ++n;
-		if (have == 8) { *(uint64_t*)(p + n - 8) = acc; acc = 0; have = 0; }
+		n += nb;
+		if (!write) return;
+		acc |= v << (8 * have);
+		const uint32_t tot = have + nb;
+		if (tot >= 8)
+		{
+			uint8_t* w = p + (n - tot);                                // the word's address
+			if (skip) { for (uint32_t i = skip; i < 8; ++i) w[i] = (uint8_t)(acc >> (8 * i)); skip = 0; }
+			else *(uint64_t*)w = acc;
+			acc = have ? v >> (8 * (8 - have)) : 0;
+			have = tot - 8;
+		}
+		else have = tot;
 	}
 	// `rep` one-byte tuples of the same value (runs of matches shorter than an anchor, of deletions, ...)
 	CL_DEV inline void fill(uint8_t v, uint32_t rep)
 	{
 		n_tuples += rep;
 		if (!write) { n += rep; return; }
-		while (rep && !aligned) { p[n] = v; ++n; --rep; aligned = (((uint64_t)(size_t)p + n) & 7) == 0; }
 		const uint64_t pat = 0x0101010101010101ull * v;
 		while (rep)
 		{
-			const uint32_t k = rep < 8 - have ? rep : 8 - have;
-			const uint64_t m = k == 8 ? ~0ull : ((1ull << (8 * k)) - 1);
-			acc |= (pat & m) << (8 * have); have += k; n += k; rep -= k;
-			if (have == 8) { *(uint64_t*)(p + n - 8) = acc; acc = 0; have = 0; }
+			const uint32_t k = rep < 8 ? rep : 8;
+			put(k == 8 ? pat : pat & ((1ull << (8 * k)) - 1), k);
+			rep -= k;
 		}
 	}
-	CL_DEV inline void finish() { if (write) for (uint32_t i = 0; i < have; ++i) p[n - have + i] = (uint8_t)(acc >> (8 * i)); have = 0; }
-	CL_DEV inline void t1(uint32_t type, uint32_t val) { byte((uint8_t)((type << 4) + val)); ++n_tuples; }
-	CL_DEV inline void t28(uint32_t type, uint32_t v) { byte((uint8_t)((type << 4) + (v >> 24))); byte((v >> 16) & 0xff); byte((v >> 8) & 0xff); byte(v & 0xff); ++n_tuples; }
-	CL_DEV inline void tid(uint32_t type, uint32_t id, uint32_t rev) { byte((uint8_t)((type << 4) + rev)); byte(id >> 24); byte((id >> 16) & 0xff); byte((id >> 8) & 0xff); byte(id & 0xff); ++n_tuples; }
+	CL_DEV inline void finish() { if (write) { uint8_t* w = p + (n - have); for (uint32_t i = skip; i < have; ++i) w[i] = (uint8_t)(acc >> (8 * i)); } have = skip = 0; acc = 0; }
+	CL_DEV inline void t1(uint32_t type, uint32_t val) { put((type << 4) + val, 1); ++n_tuples; }
+	CL_DEV inline void t28(uint32_t type, uint32_t v) { put(__builtin_bswap32((type << 28) + v), 4); ++n_tuples; }           // type nibble + 28 bits, big-endian
+	CL_DEV inline void tid(uint32_t type, uint32_t id, uint32_t rev) { put(((type << 4) + rev) | ((uint64_t)__builtin_bswap32(id) << 8), 5); ++n_tuples; }
 };
 // One StoreFrag segment at a time (encoder.cpp:1414-1443): the header (alt_id / main_ref, and for level > 0 the
 // last_pos_in_ref deletions) is emitted when the first symbol of the segment arrives, so empty segments leave no trace.
@@ -750,7 +761,7 @@ CL_DEV inline void emit_read(const ArenaV& A, const uint32_t* inv, const uint8_t
 {
 	const uint32_t len = A.lens[r]; const uint64_t wb = A.word_off[r];
 	TupleOut o{ WRITE ? out + es_off[r] : nullptr, 0, 0, WRITE };
-	if (WRITE) o.aligned = (((uint64_t)(size_t)o.p) & 7) == 0;
+	if (WRITE) o.start();
 	const uint32_t f0 = T.frame_of_read[r];
 	if (f0 == 0xffffffffu)
 	{	// AddPlainRead / AddPlainReadWithN (encoder.cpp:663-681)
@@ -787,7 +798,7 @@ CL_DEV inline void emit_read(const ArenaV& A, const uint32_t* inv, const uint8_t
 		{	// resume at the saved state
 			for (int i = 0; i < 10; ++i) { sf[i] = ck->sf[i]; si[i] = ck->si[i]; s_last[i] = ck->s_last[i]; s_cur[i] = ck->s_cur[i]; }
 			sp = ck->sp; enter = ck->enter != 0; it = ck->start_it; mid_q = ck->mid_q;
-			o.n = ck->n; o.n_tuples = ck->n_tuples; o.aligned = (((uint64_t)(size_t)o.p + o.n) & 7) == 0;
+			o.n = ck->n; o.n_tuples = ck->n_tuples; o.start();
 			w.sym = (char)ck->sym; w.rep = ck->rep; w.open = ck->open != 0; w.first = ck->first != 0; w.main_id = ck->main_id;
 			w.level = ck->level; w.ref_id = ck->ref_id; w.rev = ck->rev; w.last_pos = ck->last_pos;
 		}
