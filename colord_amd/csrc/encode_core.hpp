@@ -110,7 +110,12 @@ CL_DEV inline double lens_add(double cost, uint64_t lens)
 	for (uint32_t i = 0; i < cnt; ++i) cost += (double)((uint32_t)(lens >> (6 * i)) & 63u);
 	return cost;
 }
-struct LevelV { FrameRec* frames; CandEnt* cands; GapRec* gaps; char* es; PendRec* pend; uint8_t* dec; uint32_t n_frames, n_gaps; };
+// What the tuple emission needs of a gap's script when it only COUNTS (sizes, saved states): the first and the last run,
+// which may merge with their neighbours, and the output of the runs in between, which is fixed.
+struct GapSum { uint32_t first_len, last_len, mid_bytes, mid_tuples, syms; };     // syms: first | last << 8 | (one run only) << 16
+constexpr uint32_t SUM_LIMIT = 1024;          // scripts up to this length are counted from their summary (longer ones symbol by
+                                              // symbol, so that states can be saved inside them)
+struct LevelV { FrameRec* frames; CandEnt* cands; GapRec* gaps; char* es; PendRec* pend; uint8_t* dec; uint32_t n_frames, n_gaps; const GapSum* sums = nullptr; };
 struct TreeV { LevelV lv[10]; const uint32_t* frame_of_read; };     // frame_of_read: level-0 frame of a read or ~0
 
 // geometry of gap g of frame F coded against candidate M (EncodePart, encoder.cpp:1445-1470)
@@ -740,6 +745,29 @@ struct SegWriter {
 	CL_DEV inline bool store() { const bool had = open; if (open) { flush_run(); first = false; } open = false; return had; }
 };
 
+// bytes / tuples a finished run of `len` symbols `sym` puts out (singleEditScriptSymbolStore, as SegWriter::flush_run)
+CL_DEV inline uint32_t run_bytes(char sym, uint32_t len) { return (sym == 'M' && len >= 15) || (sym == 'D' && len > 16) ? 4u : len; }
+CL_DEV inline uint32_t run_tuples(char sym, uint32_t len) { return (sym == 'M' && len >= 15) || (sym == 'D' && len > 16) ? 1u : len; }
+CL_DEV inline GapSum gap_summary(const char* es, uint32_t k)
+{
+	GapSum s{ 0, 0, 0, 0, 0 };
+	if (!k) return s;
+	const char f = es[0];
+	uint32_t i = 1;
+	while (i < k && es[i] == f) ++i;
+	s.first_len = i;
+	if (i == k) { s.last_len = i; s.syms = (uint32_t)(uint8_t)f | ((uint32_t)(uint8_t)f << 8) | (1u << 16); return s; }
+	char c = es[i]; uint32_t len = 0;
+	for (; i < k; ++i)
+	{
+		if (es[i] == c) { ++len; continue; }
+		s.mid_bytes += run_bytes(c, len); s.mid_tuples += run_tuples(c, len);
+		c = es[i]; len = 1;
+	}
+	s.last_len = len;
+	s.syms = (uint32_t)(uint8_t)f | ((uint32_t)(uint8_t)c << 8);
+	return s;
+}
 // A saved state of the walk below at the top of its loop (`it` fragments done, `n` bytes / `n_tuples` tuples out, the
 // open run in (sym, rep)).  The count pass of the kernels saves one every few KB of output, so that the write pass can
 // run one lane per CHUNK, not per read: the chunk that starts at the state ends at (stop_it, stop_q).  States are saved
@@ -851,6 +879,13 @@ CL_DEV inline void emit_read(const ArenaV& A, const uint32_t* inv, const uint8_t
 		if (as_es)
 		{
 			if (!mid) w.add('D', g.d_before);
+			if (!WRITE && L.sums && g.es_len && g.es_len <= SUM_LIMIT)
+			{	// count pass: the script from its summary
+				const GapSum sm = L.sums[F.first_gap + (i >> 1)];
+				w.add((char)(sm.syms & 0xff), sm.first_len);
+				if (!(sm.syms >> 16)) { w.flush_run(); o.n += sm.mid_bytes; o.n_tuples += sm.mid_tuples; w.sym = (char)((sm.syms >> 8) & 0xff); w.rep = sm.last_len; }
+				continue;
+			}
 			const uint32_t* es4 = (const uint32_t*)(L.es + g.es_off);               // script slots are dword-aligned
 			bool stopped = false;
 			for (uint32_t q = mid_q; q < g.es_len; q += 32)

@@ -389,6 +389,14 @@ __global__ void k_gap_stats(LevelV L, ArenaV A, EncCfg cfg, const uint32_t* __re
 	if (L.gaps[gi].ne >= cfg.min_part_alt) { long_list[gi - pend_idx[gi]] = gi; return; }      // pend_idx = number of short gaps before gi
 	spawn_flag[gi] = gap_finish(L, gi, A, cfg, pend_idx[gi]) ? 1u : 0u;
 }
+// run summaries of the scripts for the count pass of the tuple emission: one lane per gap
+__global__ void k_gap_sums(LevelV L, GapSum* __restrict__ sums)
+{
+	const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
+	if (gi >= L.n_gaps) return;
+	const uint32_t k = L.gaps[gi].es_len;
+	if (k && k <= SUM_LIMIT) sums[gi] = gap_summary(L.es + L.gaps[gi].es_off, k);
+}
 // long gaps: the static entropy test (EncodeWithEditScript, encoder.cpp:1315-1327; CEntropy, utils.h:706-752) by one wave
 __global__ __launch_bounds__(256) void k_gap_stats_long(LevelV L, ArenaV A, EncCfg cfg, const uint32_t* __restrict__ long_list, uint32_t n_long, uint32_t* __restrict__ spawn_flag)
 {
@@ -634,9 +642,9 @@ __global__ __launch_bounds__(256) void k_emit_plain(ArenaV A, const uint32_t* __
 }
 
 struct LevelBufs {
-	DevBuf<FrameRec> frames; DevBuf<CandEnt> cands; DevBuf<GapRec> gaps; DevBuf<char> es; DevBuf<PendRec> pend; DevBuf<uint8_t> dec;
+	DevBuf<FrameRec> frames; DevBuf<CandEnt> cands; DevBuf<GapRec> gaps; DevBuf<char> es; DevBuf<PendRec> pend; DevBuf<uint8_t> dec; DevBuf<GapSum> sums;
 	uint32_t n_frames = 0, n_gaps = 0; uint64_t n_cands = 0;
-	LevelV view() { return LevelV{ frames.p, cands.p, gaps.p, es.p, pend.p, dec.p, n_frames, n_gaps }; }
+	LevelV view() { return LevelV{ frames.p, cands.p, gaps.p, es.p, pend.p, dec.p, n_frames, n_gaps, sums.p }; }
 };
 } // namespace
 
@@ -830,6 +838,8 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 		DevBuf<uint32_t> long_list; DEV_ALLOC(ctx, long_list, (uint64_t)n_long + 1);
 		LAUNCH(ctx, k_gap_stats, grid_for(ng, 64), 64, V, A, cfg, (const uint32_t*)pflag.p, sflag.p, long_list.p);
 		if (n_long) LAUNCH(ctx, k_gap_stats_long, grid_for((uint64_t)n_long * 64, 256), 256, V, A, cfg, (const uint32_t*)long_list.p, n_long, sflag.p);
+		DEV_ALLOC(ctx, L.sums, ng + 1);
+		LAUNCH(ctx, k_gap_sums, grid_for(ng, 64), 64, V, L.sums.p);
 		LAUNCH(ctx, k_spawn_mark, grid_for(ng, 64), 64, V, AV.data, cfg, sflag.p, sncand.p);      // refuses beyond max_rec: those gaps become literals
 		HIP_TRY(ctx, hipGetLastError());
 		if (lv >= max_rec || lv + 1 >= 10) { HIP_TRY(ctx, hipStreamSynchronize(st)); break; }
