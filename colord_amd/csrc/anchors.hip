@@ -91,8 +91,17 @@ __global__ void k_table_sizes(const uint32_t* __restrict__ lens, const uint8_t* 
 	if (n) { t = 16; while (t < 2 * n + n / 2) t <<= 1; }
 	tsize[r - r0] = t; nsize[r - r0] = n;
 }
-__global__ __launch_bounds__(1024) void k_table_insert(Arena A, uint32_t r0, uint32_t r1, uint32_t m, EncTable T, uint32_t* __restrict__ n_distinct)
-{	// one block of 16 waves per read (measured: 212 -> 162 ms against one wave per read)
+// Table build, one block of 16 waves per read.  Inserting straight into the table in HBM costs a random 128-byte line
+// read and written per m-mer (measured 100 bytes written per insertion).  Instead the table is built REGION by region
+// (REGION slots = 32 KB) in LDS and written out once, coalesced: the read's positions are first binned by the region of
+// their slot (counting sort through a scratch list), then every region is filled with LDS atomics.  Probing wraps
+// inside the region, here and in table_heads.
+constexpr uint32_t REGION = 2048;
+__global__ __launch_bounds__(1024) void k_table_insert(Arena A, uint32_t r0, uint32_t r1, uint32_t m, EncTable T, uint32_t* __restrict__ n_distinct,
+                                                       uint2* __restrict__ bins /* per position: (position, slot), grouped by region */, uint32_t* __restrict__ err)
+{
+	__shared__ EncSlot reg[REGION];
+	__shared__ uint32_t cnt[512], start[513];                             // positions per region (a read of 2^20 bases has 2^21 * 2 / 2048 = ... see below)
 	const uint32_t r = r0 + blockIdx.x;
 	if (r >= r1) return;
 	const uint64_t t0 = T.toff[r - r0]; const uint32_t tsz = (uint32_t)(T.toff[r - r0 + 1] - t0);
@@ -100,20 +109,58 @@ __global__ __launch_bounds__(1024) void k_table_insert(Arena A, uint32_t r0, uin
 	const uint64_t n0 = T.noff[r - r0]; const uint32_t n = (uint32_t)(T.noff[r - r0 + 1] - n0);
 	const uint64_t wb = A.word_off[r];
 	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t rs = tsz < REGION ? tsz : REGION, n_reg = tsz / rs, rshift = 31 - (uint32_t)__clz((int)rs);
+	uint2* bin = bins + n0;
 	uint32_t fresh = 0;
-	for (uint32_t p = threadIdx.x; p < n; p += 1024)
-	{
-		const uint64_t xf = mmer_at(A, wb, p, m), xr = revcomp_m(xf, m), x = xf < xr ? xf : xr;
-		uint32_t h = (uint32_t)(hash_mm(x) >> 17) & (tsz - 1);
-		for (;;)
+	for (uint32_t rg0 = 0; rg0 < n_reg; rg0 += 512)
+	{	// (512 regions = 2^20 slots per round: one round for reads up to ~400 k bases)
+		const uint32_t nr = n_reg - rg0 < 512 ? n_reg - rg0 : 512;
+		for (uint32_t i = threadIdx.x; i < 512; i += 1024) cnt[i] = 0;
+		__syncthreads();
+		for (uint32_t p = threadIdx.x; p < n; p += 1024)
 		{
-			unsigned long long old = atomicCAS((unsigned long long*)&T.slots[t0 + h].key, (unsigned long long)KEY_EMPTY, (unsigned long long)x);
-			if (old == KEY_EMPTY || old == x) break;
-			h = (h + 1) & (tsz - 1);
+			const uint64_t xf = mmer_at(A, wb, p, m), xr = revcomp_m(xf, m), x = xf < xr ? xf : xr;
+			const uint32_t h = (uint32_t)(hash_mm(x) >> 17) & (tsz - 1), rg = (h >> rshift) - rg0;
+			if (rg < nr) atomicAdd(&cnt[rg], 1u);
 		}
-		const uint32_t prev = atomicExch(&T.slots[t0 + h].head[xf != x ? 1 : 0], p);
-		T.next[n0 + p] = prev;
-		if (prev == NIL) ++fresh;                                       // first position with this m-mer: distinct m-mers of the read
+		__syncthreads();
+		if (threadIdx.x == 0) { uint32_t a = 0; for (uint32_t i = 0; i < nr; ++i) { start[i] = a; a += cnt[i]; cnt[i] = 0; } start[nr] = a; }
+		__syncthreads();
+		for (uint32_t p = threadIdx.x; p < n; p += 1024)
+		{
+			const uint64_t xf = mmer_at(A, wb, p, m), xr = revcomp_m(xf, m), x = xf < xr ? xf : xr;
+			const uint32_t h = (uint32_t)(hash_mm(x) >> 17) & (tsz - 1), rg = (h >> rshift) - rg0;
+			if (rg < nr) bin[start[rg] + atomicAdd(&cnt[rg], 1u)] = make_uint2(p, h);
+		}
+		__syncthreads();
+		__threadfence_block();
+		for (uint32_t rg = 0; rg < nr; ++rg)
+		{
+			for (uint32_t i = threadIdx.x; i < rs; i += 1024) { reg[i].key = KEY_EMPTY; reg[i].head[0] = NIL; reg[i].head[1] = NIL; }
+			__syncthreads();
+			const uint32_t b = start[rg], e = start[rg + 1];
+			for (uint32_t i = b + threadIdx.x; i < e; i += 1024)
+			{
+				const uint2 ph = bin[i];
+				const uint32_t pp = ph.x;
+				const uint64_t xf = mmer_at(A, wb, pp, m), xr = revcomp_m(xf, m), x = xf < xr ? xf : xr;
+				uint32_t off = ph.y & (rs - 1), tries = 0;
+				for (;;)
+				{
+					unsigned long long old = atomicCAS((unsigned long long*)&reg[off].key, (unsigned long long)KEY_EMPTY, (unsigned long long)x);
+					if (old == KEY_EMPTY || old == x) break;
+					off = (off + 1) & (rs - 1);
+					if (++tries > rs) { atomicOr(err, 2u); break; }                // a full region: cannot happen below load 1
+				}
+				const uint32_t prev = atomicExch(&reg[off].head[xf != x ? 1 : 0], pp);
+				T.next[n0 + pp] = prev;
+				if (prev == NIL) ++fresh;                                   // first position with this m-mer: distinct m-mers of the read
+			}
+			__syncthreads();
+			EncSlot* dst = T.slots + t0 + (uint64_t)(rg0 + rg) * rs;
+			for (uint32_t i = threadIdx.x; i < rs; i += 1024) dst[i] = reg[i];
+			__syncthreads();
+		}
 	}
 	fresh = wave_sum(fresh);
 	if (lane == 0 && fresh) atomicAdd(&n_distinct[r - r0], fresh);       // (zeroed by the caller)
@@ -122,12 +169,13 @@ __global__ __launch_bounds__(1024) void k_table_insert(Arena A, uint32_t r0, uin
 __device__ inline uint2 table_heads(const EncTable& T, uint64_t t0, uint32_t tsz, uint64_t x, uint64_t hash)
 {
 	uint32_t h = (uint32_t)(hash >> 17) & (tsz - 1);
+	const uint32_t rmask = (tsz < REGION ? tsz : REGION) - 1;           // probing wraps inside the region the table was built by
 	for (;;)
 	{
 		const uint64_t k = T.slots[t0 + h].key;
 		if (k == x) return *(const uint2*)T.slots[t0 + h].head;
 		if (k == KEY_EMPTY) return make_uint2(NIL, NIL);
-		h = (h + 1) & (tsz - 1);
+		h = (h & ~rmask) | ((h + 1) & rmask);
 	}
 }
 
@@ -609,7 +657,7 @@ extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* read
 	// main stream matches, sorts and chains the batch before it (ALU / latency bound): batches are independent.
 	struct TableBatch {
 		uint32_t r0 = 0, r1 = 0; uint64_t acc = 0, nsum = 0;
-		DevBuf<uint32_t> n_distinct, next; DevBuf<uint64_t> toff, noff; DevBuf<EncSlot> slots;
+		DevBuf<uint32_t> n_distinct, next, err; DevBuf<uint64_t> toff, noff; DevBuf<EncSlot> slots; DevBuf<uint2> bins;
 		struct SideSync { hipStream_t s = nullptr; ~SideSync() { if (s) (void)hipStreamSynchronize(s); } } sync;   // destroyed first
 	};
 	if (!ctx->side) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
@@ -629,15 +677,15 @@ extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* read
 		CL_TRY(dev_exclusive_scan_u64(ctx, nsize.p, B.noff.p, nb, &B.nsum));
 		uint32_t herr = 0; HIP_TRY(ctx, hipMemcpy(&herr, err.p, 4, hipMemcpyDeviceToHost));
 		if (herr) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_anchor_candidates: reads of 2^20 bases or more are not supported yet");
-		DEV_ALLOC(ctx, B.slots, tsum); DEV_ALLOC(ctx, B.next, B.nsum);
+		DEV_ALLOC(ctx, B.slots, tsum); DEV_ALLOC(ctx, B.next, B.nsum); DEV_ALLOC(ctx, B.bins, B.nsum); DEV_ALLOC(ctx, B.err, 1);
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                         // offsets complete before the side stream reads them
 		B.sync.s = ctx->side;
 		HIP_TRY(ctx, hipMemsetAsync(B.n_distinct.p, 0, (uint64_t)nb * 4, ctx->side));
-		HIP_TRY(ctx, hipMemsetAsync(B.slots.p, 0xff, tsum * sizeof(EncSlot), ctx->side));
+		HIP_TRY(ctx, hipMemsetAsync(B.err.p, 0, 4, ctx->side));                  // (the slots are written region by region, all of them)
 		EncTable T{ B.slots.p, B.toff.p, B.next.p, B.noff.p };
 		hipStream_t main_stream = ctx->stream;
 		ctx->stream = ctx->side;                                                  // (launch + timing events on the side stream)
-		LAUNCHB(ctx, B.nsum * (0.25 + 16.0), k_table_insert, nb, 1024, A, r0, r1, m, T, B.n_distinct.p);
+		LAUNCHB(ctx, B.nsum * (0.25 + 16.0), k_table_insert, nb, 1024, A, r0, r1, m, T, B.n_distinct.p, B.bins.p, B.err.p);
 		ctx->stream = main_stream;
 		HIP_TRY(ctx, hipGetLastError());
 		return CL_OK;
@@ -652,6 +700,7 @@ extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* read
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                         // the batch before is through (its buffers may be handed to the side stream)
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->side));                           // this batch's tables are built
 		cur->sync.s = nullptr;
+		{ uint32_t herr = 0; HIP_TRY(ctx, hipMemcpy(&herr, cur->err.p, 4, hipMemcpyDeviceToHost)); if (herr) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_anchor_candidates: a region of an m-mer table overflowed"); }
 		if (r1 < nr) CL_TRY(prepare(r1, nxt));
 		DevBuf<uint32_t>& n_distinct = cur->n_distinct;
 		EncTable T{ cur->slots.p, cur->toff.p, cur->next.p, cur->noff.p };
