@@ -96,8 +96,8 @@ __global__ void k_table_sizes(const uint32_t* __restrict__ lens, const uint8_t* 
 // (REGION slots = 32 KB) in LDS and written out once, coalesced: the read's positions are first binned by the region of
 // their slot (counting sort through a scratch list), then every region is filled with LDS atomics.  Probing wraps
 // inside the region, here and in table_heads.
-constexpr uint32_t REGION = 2048;
-__global__ __launch_bounds__(1024) void k_table_insert(Arena A, uint32_t r0, uint32_t r1, uint32_t m, EncTable T, uint32_t* __restrict__ n_distinct,
+constexpr uint32_t REGION = 2048, INS_T = 256;
+__global__ __launch_bounds__(INS_T) void k_table_insert(Arena A, uint32_t r0, uint32_t r1, uint32_t m, EncTable T, uint32_t* __restrict__ n_distinct,
                                                        uint2* __restrict__ bins /* per position: (position, slot), grouped by region */, uint32_t* __restrict__ err)
 {
 	__shared__ EncSlot reg[REGION];
@@ -115,9 +115,9 @@ __global__ __launch_bounds__(1024) void k_table_insert(Arena A, uint32_t r0, uin
 	for (uint32_t rg0 = 0; rg0 < n_reg; rg0 += 512)
 	{	// (512 regions = 2^20 slots per round: one round for reads up to ~400 k bases)
 		const uint32_t nr = n_reg - rg0 < 512 ? n_reg - rg0 : 512;
-		for (uint32_t i = threadIdx.x; i < 512; i += 1024) cnt[i] = 0;
+		for (uint32_t i = threadIdx.x; i < 512; i += INS_T) cnt[i] = 0;
 		__syncthreads();
-		for (uint32_t p = threadIdx.x; p < n; p += 1024)
+		for (uint32_t p = threadIdx.x; p < n; p += INS_T)
 		{
 			const uint64_t xf = mmer_at(A, wb, p, m), xr = revcomp_m(xf, m), x = xf < xr ? xf : xr;
 			const uint32_t h = (uint32_t)(hash_mm(x) >> 17) & (tsz - 1), rg = (h >> rshift) - rg0;
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(1024) void k_table_insert(Arena A, uint32_t r0, uin
 		__syncthreads();
 		if (threadIdx.x == 0) { uint32_t a = 0; for (uint32_t i = 0; i < nr; ++i) { start[i] = a; a += cnt[i]; cnt[i] = 0; } start[nr] = a; }
 		__syncthreads();
-		for (uint32_t p = threadIdx.x; p < n; p += 1024)
+		for (uint32_t p = threadIdx.x; p < n; p += INS_T)
 		{
 			const uint64_t xf = mmer_at(A, wb, p, m), xr = revcomp_m(xf, m), x = xf < xr ? xf : xr;
 			const uint32_t h = (uint32_t)(hash_mm(x) >> 17) & (tsz - 1), rg = (h >> rshift) - rg0;
@@ -136,10 +136,10 @@ __global__ __launch_bounds__(1024) void k_table_insert(Arena A, uint32_t r0, uin
 		__threadfence_block();
 		for (uint32_t rg = 0; rg < nr; ++rg)
 		{
-			for (uint32_t i = threadIdx.x; i < rs; i += 1024) { reg[i].key = KEY_EMPTY; reg[i].head[0] = NIL; reg[i].head[1] = NIL; }
+			for (uint32_t i = threadIdx.x; i < rs; i += INS_T) { reg[i].key = KEY_EMPTY; reg[i].head[0] = NIL; reg[i].head[1] = NIL; }
 			__syncthreads();
 			const uint32_t b = start[rg], e = start[rg + 1];
-			for (uint32_t i = b + threadIdx.x; i < e; i += 1024)
+			for (uint32_t i = b + threadIdx.x; i < e; i += INS_T)
 			{
 				const uint2 ph = bin[i];
 				const uint32_t pp = ph.x;
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(1024) void k_table_insert(Arena A, uint32_t r0, uin
 			}
 			__syncthreads();
 			EncSlot* dst = T.slots + t0 + (uint64_t)(rg0 + rg) * rs;
-			for (uint32_t i = threadIdx.x; i < rs; i += 1024) dst[i] = reg[i];
+			for (uint32_t i = threadIdx.x; i < rs; i += INS_T) dst[i] = reg[i];
 			__syncthreads();
 		}
 	}
@@ -685,7 +685,7 @@ extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* read
 		EncTable T{ B.slots.p, B.toff.p, B.next.p, B.noff.p };
 		hipStream_t main_stream = ctx->stream;
 		ctx->stream = ctx->side;                                                  // (launch + timing events on the side stream)
-		LAUNCHB(ctx, B.nsum * (0.25 + 16.0), k_table_insert, nb, 1024, A, r0, r1, m, T, B.n_distinct.p, B.bins.p, B.err.p);
+		LAUNCHB(ctx, B.nsum * (0.25 + 16.0), k_table_insert, nb, INS_T, A, r0, r1, m, T, B.n_distinct.p, B.bins.p, B.err.p);
 		ctx->stream = main_stream;
 		HIP_TRY(ctx, hipGetLastError());
 		return CL_OK;
