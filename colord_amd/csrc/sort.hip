@@ -34,12 +34,20 @@ __global__ __launch_bounds__(ST) void k_sort_scatter(const K* __restrict__ kin, 
                                                      K* __restrict__ kout, uint32_t* __restrict__ vout,
                                                      uint64_t n, uint32_t shift, const uint32_t* __restrict__ offs, uint32_t nb)
 {
-	__shared__ uint32_t wh[4][256];
+	// The tile is first ordered by digit in LDS (stable: wave by wave, ballot ranks inside a wave), then written out
+	// linearly: consecutive threads write consecutive elements of a bucket, so a bucket's share of the tile (16 keys on
+	// average) leaves as whole lines instead of one 4/8-byte store per lane and bucket.
+	__shared__ uint32_t wh[4][256];          // per wave and digit: count, then the wave's first place in the ordered tile
+	__shared__ uint32_t lstart[257];         // first place of a digit in the ordered tile
+	__shared__ uint32_t gdelta[256];         // global position of a digit's first tile element minus lstart
+	__shared__ uint32_t wtot[4];
+	__shared__ K skey[STILE];
+	__shared__ uint32_t sval[HAS_V ? STILE : 1];
 	const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	for (uint32_t i = threadIdx.x; i < 4 * 256; i += ST) (&wh[0][0])[i] = 0;
 	__syncthreads();
 
-	const uint64_t wbase = (uint64_t)blockIdx.x * STILE + (uint64_t)w * (64 * SI);
+	const uint64_t tbase = (uint64_t)blockIdx.x * STILE, wbase = tbase + (uint64_t)w * (64 * SI);
 	K key[SI]; uint32_t rank[SI];
 	const uint64_t lt = (1ULL << lane) - 1;
 #pragma unroll
@@ -64,11 +72,21 @@ __global__ __launch_bounds__(ST) void k_sort_scatter(const K* __restrict__ kin, 
 		__builtin_amdgcn_wave_barrier();
 	}
 	__syncthreads();
-	{	// thread d: turn per-wave counts of digit d into global start offsets
-		uint32_t d = threadIdx.x;
-		uint32_t g = offs[(uint64_t)d * nb + blockIdx.x];
+	{	// thread d: digit totals -> exclusive scan over the digits -> places of the waves' shares
+		const uint32_t d = threadIdx.x;
+		const uint32_t c0 = wh[0][d], c1 = wh[1][d], c2 = wh[2][d], c3 = wh[3][d], tot = c0 + c1 + c2 + c3;
+		uint32_t incl = tot;
 #pragma unroll
-		for (uint32_t i = 0; i < 4; ++i) { uint32_t t = wh[i][d]; wh[i][d] = g; g += t; }
+		for (uint32_t o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+		if (lane == 63) wtot[w] = incl;
+		__syncthreads();
+		uint32_t before = 0;
+		for (uint32_t i = 0; i < w; ++i) before += wtot[i];
+		const uint32_t ls = before + incl - tot;
+		lstart[d] = ls;
+		if (d == 255) lstart[256] = ls + tot;
+		gdelta[d] = offs[(uint64_t)d * nb + blockIdx.x] - ls;
+		wh[0][d] = ls; wh[1][d] = ls + c0; wh[2][d] = ls + c0 + c1; wh[3][d] = ls + c0 + c1 + c2;
 	}
 	__syncthreads();
 #pragma unroll
@@ -78,10 +96,19 @@ __global__ __launch_bounds__(ST) void k_sort_scatter(const K* __restrict__ kin, 
 		if (idx < n)
 		{
 			uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
-			uint32_t pos = wh[w][d] + rank[r];
-			kout[pos] = key[r];
-			if (HAS_V) vout[pos] = vin[idx];
+			uint32_t lp = wh[w][d] + rank[r];
+			skey[lp] = key[r];
+			if (HAS_V) sval[lp] = vin[idx];
 		}
+	}
+	__syncthreads();
+	const uint32_t tile_n = lstart[256];
+	for (uint32_t j = threadIdx.x; j < tile_n; j += ST)
+	{
+		const K k = skey[j];
+		const uint32_t pos = gdelta[(uint32_t)(k >> shift) & 255u] + j;
+		kout[pos] = k;
+		if (HAS_V) vout[pos] = sval[j];
 	}
 }
 
