@@ -351,14 +351,20 @@ __global__ __launch_bounds__(64) void k_lis_anchors(Arena A, Arena R, TaskCfg cf
 		auto enc_pos = [&](uint32_t i) -> uint32_t { return (uint32_t)(P[i] >> POS_BITS) & (uint32_t)POS_MASK; };
 		F[0] = ref_pos(0); S[0] = 0; PR[0] = -1;
 		int out_len = 1;
-		for (int i = 1; i < (int)n; ++i)
+		int last_f = F[0], last_s = 0;                                  // F / S at out_len - 1: the common step (the next match extends
+		for (int i = 1; i < (int)n; ++i)                                // the chain) then needs no load but its own pair
 		{
 			const int x = ref_pos((uint32_t)i);
-			int pos;
-			if (F[out_len - 1] < x) pos = out_len; else pos = lis_search(F, out_len, x);
-			if (pos == out_len) ++out_len;
+			if (last_f < x)
+			{
+				F[out_len] = x; S[out_len] = i; PR[i] = last_s;
+				++out_len; last_f = x; last_s = i;
+				continue;
+			}
+			const int pos = lis_search(F, out_len, x);
 			F[pos] = x; S[pos] = i;
 			PR[i] = pos > 0 ? S[pos - 1] : -1;
+			if (pos == out_len - 1) { last_f = x; last_s = i; }
 		}
 		// chain in increasing order: walk the predecessor links backwards, storing the pair indices in S (reused)
 		int cur = S[out_len - 1];
@@ -369,13 +375,14 @@ __global__ __launch_bounds__(64) void k_lis_anchors(Arena A, Arena R, TaskCfg cf
 		const uint32_t r = cfg.r0 + rl;
 		const uint32_t id = cand_refs[(uint64_t)r * cfg.c + slot];
 		const uint64_t ewb = A.word_off[r];
+		const uint32_t rlen = R.lens[id]; const uint64_t rwb = R.word_off[id];
 		uint32_t* out = anch + 3 * a;
 		uint32_t ep = 0;                                   // index into the pairs, positioned on the first pair of a distinct enc position
 		uint32_t run = 0, start_e = 0, start_r = 0, prev_e = 0, prev_r = 0;
 		for (int i = 0; i < out_len; ++i)
 		{
 			const uint32_t pr = (uint32_t)ref_pos((uint32_t)F[i]);
-			const uint64_t mm = ref_mmer(R, id, rev, pr, cfg.m);
+			const uint64_t mm = rev ? revcomp_m(mmer_at(R, rwb, rlen - cfg.m - pr, cfg.m), cfg.m) : mmer_at(R, rwb, pr, cfg.m);
 			uint32_t pe;
 			for (;;)
 			{
