@@ -450,21 +450,23 @@ extern "C" cl_status cl_qual_encode(cl_ctx* ctx, cl_qual_coder* Q, const cl_read
 			plen[p] = (uint32_t)sl; sym_start[p + 1] = sym_start[p] + sl; pfirst[p] = h_part_bounds[p0 + p];
 		}
 		pfirst[np] = h_part_bounds[p1];
+		// places in the interleaved layout by descending length (as in cl_dna_encode): the 64 parts of a wave of the interval
+		// coder are alike and no slots are wasted on the longest part of a group
+		std::vector<uint32_t> order(np), rank(np), plen_r(np);
+		for (uint32_t p = 0; p < np; ++p) order[p] = p;
+		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return plen[a] > plen[b]; });
+		for (uint32_t i = 0; i < np; ++i) { rank[order[i]] = i; plen_r[i] = plen[order[i]]; }
 		gbase[0] = 0;
-		for (uint32_t g = 0; g < ng; ++g)
-		{
-			uint32_t lm = 0;
-			for (uint32_t p = g * 64; p < std::min(np, g * 64 + 64); ++p) lm = std::max(lm, plen[p]);
-			gbase[g + 1] = gbase[g] + (uint64_t)lm * 64;
-		}
+		for (uint32_t g = 0; g < ng; ++g) gbase[g + 1] = gbase[g] + (uint64_t)plen_r[g * 64] * 64;
 		if (gbase[ng] >= (1ull << 32)) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_qual_encode: group too large for 32-bit triple indices");
-		DevBuf<uint64_t> d_sym_start, d_gbase; DevBuf<uint32_t> d_plen, d_pfirst;
-		DEV_ALLOC(ctx, d_sym_start, np + 1); DEV_ALLOC(ctx, d_gbase, ng + 1); DEV_ALLOC(ctx, d_plen, np); DEV_ALLOC(ctx, d_pfirst, np + 1);
+		DevBuf<uint64_t> d_sym_start, d_gbase; DevBuf<uint32_t> d_plen, d_pfirst, d_rank;
+		DEV_ALLOC(ctx, d_sym_start, np + 1); DEV_ALLOC(ctx, d_gbase, ng + 1); DEV_ALLOC(ctx, d_plen, np); DEV_ALLOC(ctx, d_pfirst, np + 1); DEV_ALLOC(ctx, d_rank, np);
+		HIP_TRY(ctx, hipMemcpyAsync(d_rank.p, rank.data(), np * 4, hipMemcpyHostToDevice, ctx->stream));
 		HIP_TRY(ctx, hipMemcpyAsync(d_sym_start.p, sym_start.data(), (np + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
 		HIP_TRY(ctx, hipMemcpyAsync(d_gbase.p, gbase.data(), (ng + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-		HIP_TRY(ctx, hipMemcpyAsync(d_plen.p, plen.data(), np * 4, hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(ctx, hipMemcpyAsync(d_plen.p, plen_r.data(), np * 4, hipMemcpyHostToDevice, ctx->stream));
 		HIP_TRY(ctx, hipMemcpyAsync(d_pfirst.p, pfirst.data(), (np + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-		TripLayoutDev lay{ d_pfirst.p, d_sym_start.p, d_gbase.p, np };
+		TripLayoutDev lay{ d_pfirst.p, d_sym_start.p, d_gbase.p, np, d_rank.p };
 		DevBuf<triple_t> trip; DEV_ALLOC(ctx, trip, gbase[ng]);
 		{
 			DevBuf<uint32_t> key, sidx, bkey, bsidx;
@@ -511,7 +513,7 @@ extern "C" cl_status cl_qual_encode(cl_ctx* ctx, cl_qual_coder* Q, const cl_read
 		out_off[0] = 0;
 		for (uint32_t p = 0; p < np; ++p)
 		{
-			uint64_t s = plen[p];
+			uint64_t s = plen_r[p];                                             // (by place)
 			out_off[p + 1] = out_off[p] + ((s * bits_max + 7) / 8 + s / 16 + 64 + 7) / 8 * 8;
 		}
 		DevBuf<uint8_t> tmp; DEV_ALLOC(ctx, tmp, out_off[np]);
@@ -520,13 +522,17 @@ extern "C" cl_status cl_qual_encode(cl_ctx* ctx, cl_qual_coder* Q, const cl_read
 		HIP_TRY(ctx, hipMemcpyAsync(d_out_off.p, out_off.data(), (np + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
 		LAUNCHB(ctx, n_syms * 16.0, k_range_code, ng, 64, (const triple_t*)trip.p, (const uint64_t*)d_gbase.p, (const uint32_t*)d_plen.p, np, tmp.p, (const uint64_t*)d_out_off.p, d_size.p);
 		HIP_TRY(ctx, hipGetLastError());
-		HIP_TRY(ctx, hipMemcpyAsync(h_part_sizes + p0, d_size.p, np * 8, hipMemcpyDeviceToHost, ctx->stream));
+		std::vector<uint64_t> size_r(np);                                       // by place
+		HIP_TRY(ctx, hipMemcpyAsync(size_r.data(), d_size.p, np * 8, hipMemcpyDeviceToHost, ctx->stream));
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-		for (uint32_t p = 0; p < np; ++p) if (h_part_sizes[p0 + p] == ~0ULL)
-			return cl_fail(ctx, CL_E_CAPACITY, "cl_qual_encode: internal part buffer overflow (pathological interval clamping)");
-		std::vector<uint64_t> dst_off(np);
+		for (uint32_t p = 0; p < np; ++p)
+		{
+			h_part_sizes[p0 + p] = size_r[rank[p]];
+			if (h_part_sizes[p0 + p] == ~0ULL) return cl_fail(ctx, CL_E_CAPACITY, "cl_qual_encode: internal part buffer overflow (pathological interval clamping)");
+		}
+		std::vector<uint64_t> dst_off(np);                                      // by place, the bytes in part order
 		uint64_t w = written;
-		for (uint32_t p = 0; p < np; ++p) { dst_off[p] = w; w += h_part_sizes[p0 + p]; }
+		for (uint32_t p = 0; p < np; ++p) { dst_off[rank[p]] = w; w += h_part_sizes[p0 + p]; }
 		if (w > cap) { *n_out = w; return cl_fail(ctx, CL_E_CAPACITY, "cl_qual_encode: output capacity " + std::to_string(cap) + " too small"); }
 		HIP_TRY(ctx, hipMemcpyAsync(d_dst_off.p, dst_off.data(), np * 8, hipMemcpyHostToDevice, ctx->stream));
 		LAUNCH(ctx, k_gather_bytes, np, 256, (const uint8_t*)tmp.p, (const uint64_t*)d_out_off.p, (const uint64_t*)d_dst_off.p, (const uint64_t*)d_size.p, d_out);
