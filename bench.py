@@ -91,7 +91,7 @@ def hot_path_step(ctx, reads, k, quals=None, qual_off=None, part_bounds=None, es
     from colord_amd import parallel as par
     p = PRESET
     w, rank = par.world(), par.rank()
-    if w == 1 and quals is not None and not os.environ.get("BENCH_STAGE_TIMES"):
+    if w == 1 and quals is not None and not os.environ.get("BENCH_STAGE_TIMES") and not os.environ.get("BENCH_PY_STAGES"):   # BENCH_PY_STAGES: the stage-by-stage path of the multi-GPU runs, on one GPU
         # single GPU: the whole path is one native call (cl_compress_shard, the C++ wiring of the stages)
         prm = dict(k=k, f=p["f"], ci=p["ci"], cs=p["cs"], c=p["c"], anchor_len=p["a"], min_part_alt=p["min_part_alt"], max_rec=p["max_rec"], min_anchors=1,
                    level=1, source=0, sparse=1, sparse_g=p["g"], sparse_exponent=p["exponent"], cost_mult=1.0, frac_always=0.9, frac_min=0.5, max_matches_mult=10.0)
