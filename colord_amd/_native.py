@@ -43,6 +43,17 @@ class CompressInfo(C.Structure):
                [("sparse_range", C.c_uint32), ("pad", C.c_uint32)]
 
 
+_EXCH_GATHER_HOST = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_uint64))
+_EXCH_A2AV = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64))
+_EXCH_GATHERV = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64))
+
+
+class Exchange(C.Structure):
+    """cl_exchange: the collectives a multi-GPU cl_compressor calls back into (colord_amd/parallel.py fills it)."""
+    _fields_ = [("user", C.c_void_p), ("rank", C.c_uint32), ("world", C.c_uint32),
+                ("all_gather_host", _EXCH_GATHER_HOST), ("all_to_all_v", _EXCH_A2AV), ("all_gather_v", _EXCH_GATHERV)]
+
+
 _SIG = {
     "cl_ctx_create": (C.c_int32, [C.c_int, C.POINTER(_P)]),
     "cl_ctx_destroy": (None, [_P]),
@@ -110,6 +121,15 @@ _SIG = {
     "cl_id_encode_part": (C.c_int32, [_P, _P, _P, _P, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "cl_compress_shard": (C.c_int32, [_P, C.POINTER(CompressParams), _P, _P, _P, _P, C.c_uint32, _P, C.c_uint32, _P, _P, _P, C.c_uint64, _P, _P, C.c_uint64, _P,
                                       C.POINTER(CompressInfo)]),
+    "cl_candidates_at": (C.c_int32, [_P, _P, _P, _P, C.c_uint32, _P, _P, _P]),
+    "cl_compressor_create": (C.c_int32, [_P, _P, C.POINTER(CompressParams), C.POINTER(QualParams), C.POINTER(Exchange), C.c_uint64, C.POINTER(_P)]),
+    "cl_compressor_free": (None, [_P]),
+    "cl_compressor_count_add": (C.c_int32, [_P, _P]),
+    "cl_compressor_count_finish": (C.c_int32, [_P, C.POINTER(KmerStats)]),
+    "cl_compressor_refs_add": (C.c_int32, [_P, _P]),
+    "cl_compressor_refs_finish": (C.c_int32, [_P]),
+    "cl_compressor_encode": (C.c_int32, [_P, _P, _P, _P, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint64, _P, _P, C.c_uint64, _P, C.POINTER(CompressInfo)]),
+    "cl_compressor_info": (C.c_int32, [_P, C.POINTER(KmerStats), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "cl_encode_reads": (C.c_int32, [_P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, _P, C.c_uint32, _P, C.c_uint64, _P, _P, C.POINTER(C.c_uint64)]),
     "cl_dna_coder_create": (C.c_int32, [_P, C.c_uint32, C.c_int32, C.c_uint32, C.POINTER(_P)]),
     "cl_dna_coder_free": (None, [_P]),

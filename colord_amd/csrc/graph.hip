@@ -201,13 +201,14 @@ extern "C" cl_status cl_index_build_pairs(cl_ctx* ctx, const cl_kmer_set* S, uin
                                           const uint32_t* d_bounds, uint32_t n_reads, uint32_t n_refs_total,
                                           uint32_t n_pseudo, uint32_t max_kmer_count, cl_index** out)
 {
-	if (!ctx || !S || !d_bounds || !out) return cl_fail(ctx, CL_E_INVALID, "cl_index_build_pairs: null argument");
+	if (!ctx || !S || (!d_bounds && n_reads) || !out) return cl_fail(ctx, CL_E_INVALID, "cl_index_build_pairs: null argument");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	cl_timing_begin(ctx);
 	cl_index* X = new cl_index(); X->ctx = ctx; X->n_reads = n_reads; X->n_pseudo = n_pseudo; X->n_keys = S->n; X->n_refs = n_refs_total;
 	std::unique_ptr<cl_index> guard(X);
 	DEV_ALLOC(ctx, X->ref_rank, (uint64_t)n_reads + 1);
-	HIP_TRY(ctx, hipMemcpyAsync(X->ref_rank.p, d_bounds, ((uint64_t)n_reads + 1) * 4, hipMemcpyDeviceToDevice, ctx->stream));
+	if (d_bounds) HIP_TRY(ctx, hipMemcpyAsync(X->ref_rank.p, d_bounds, ((uint64_t)n_reads + 1) * 4, hipMemcpyDeviceToDevice, ctx->stream));
+	else HIP_TRY(ctx, hipMemsetAsync(X->ref_rank.p, 0, 4, ctx->stream));
 	uint64_t n_keep = 0;
 	DevBuf<uint32_t> id_counts; DEV_ALLOC(ctx, id_counts, S->n + 1);
 	HIP_TRY(ctx, hipMemsetAsync(id_counts.p, 0, (S->n + 1) * 4, ctx->stream));
@@ -262,8 +263,17 @@ extern "C" const uint32_t* cl_index_ref_rank(const cl_index* ix) { return ix->re
 extern "C" cl_status cl_candidates(cl_ctx* ctx, const cl_index* X, const cl_kmer_lists* L, uint32_t c,
                                    uint32_t* d_refs, uint32_t* d_votes, uint32_t* d_n)
 {
-	if (!ctx || !X || !L || !d_refs || !d_votes || !d_n) return cl_fail(ctx, CL_E_INVALID, "cl_candidates: null argument");
-	if (X->n_reads != L->n_reads || c == 0) return cl_fail(ctx, CL_E_INVALID, "cl_candidates: index/lists mismatch or max_candidates == 0");
+	if (!ctx || !X || !L) return cl_fail(ctx, CL_E_INVALID, "cl_candidates: null argument");
+	if (X->n_reads != L->n_reads) return cl_fail(ctx, CL_E_INVALID, "cl_candidates: index/lists mismatch");
+	return cl_candidates_at(ctx, X, L, X->ref_rank.p, c, d_refs, d_votes, d_n);
+}
+// The query of one CHUNK of reads against an index that covers the reference reads of the whole input: d_bounds[i] =
+// number of reference reads that precede read i of `lists` in file order (read i sees exactly those, App. F1 of SURVEY.md).
+extern "C" cl_status cl_candidates_at(cl_ctx* ctx, const cl_index* X, const cl_kmer_lists* L, const uint32_t* d_bounds, uint32_t c,
+                                      uint32_t* d_refs, uint32_t* d_votes, uint32_t* d_n)
+{
+	if (!ctx || !X || !L || !d_bounds || !d_refs || !d_votes || !d_n) return cl_fail(ctx, CL_E_INVALID, "cl_candidates: null argument");
+	if (c == 0) return cl_fail(ctx, CL_E_INVALID, "cl_candidates: max_candidates == 0");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	cl_timing_begin(ctx);
 	const uint32_t nr = L->n_reads; const uint64_t ne = L->total;
@@ -275,7 +285,7 @@ extern "C" cl_status cl_candidates(cl_ctx* ctx, const cl_index* X, const cl_kmer
 	if (ne)
 	{
 		LAUNCH(ctx, k_pair_counts, grid_for(ne, 256), 256, (const uint32_t*)L->ids.p, (const uint32_t*)L->read.p, ne,
-			(const uint32_t*)X->ref_rank.p, (const uint64_t*)X->off.p, (const uint32_t*)X->refs.p, cnt.p);
+			d_bounds, (const uint64_t*)X->off.p, (const uint32_t*)X->refs.p, cnt.p);
 	}
 	HIP_TRY(ctx, hipGetLastError());
 	CL_TRY(dev_exclusive_scan_u64(ctx, cnt.p, poff.p, ne, &n_pairs));

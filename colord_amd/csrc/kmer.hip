@@ -483,16 +483,69 @@ __global__ void k_table_check(const void* slots, uint64_t bmask, const uint64_t*
 
 static cl_status build_table(cl_ctx* ctx, cl_kmer_set* S);
 
-extern "C" cl_status cl_kmer_count_filter(cl_ctx* ctx, uint64_t* d_kmers, uint64_t n, uint32_t k, uint32_t ci, uint32_t cs,
-                                          cl_kmer_set** out, cl_kmer_stats* stats)
+namespace {
+// ---- key-range partitioning: inputs of 2^32 and more k-mers (C5: 4.2 G) are counted range by range, and the ranks of a
+// multi-GPU run own one range each.  Ranges are unions of the 4096 bins of the keys' top 12 bits, so the kept keys of
+// consecutive ranges are ascending as a whole (the rank of a key in that order is its id everywhere downstream).
+constexpr uint32_t PART_BITS = 12, PART_BINS = 1u << PART_BITS;
+__global__ __launch_bounds__(256) void k_key_hist(const uint64_t* __restrict__ keys, uint64_t n, uint32_t shift, unsigned long long* __restrict__ bins)
 {
-	if (!ctx || !out) return cl_fail(ctx, CL_E_INVALID, "cl_kmer_count_filter: null argument");
-	if (k < 1 || k > 28) return cl_fail(ctx, CL_E_INVALID, "cl_kmer_count_filter: need 1 <= k <= 28");
-	if (n >= (1ULL << 32)) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_kmer_count_filter: n must be < 2^32 per call");
-	HIP_TRY(ctx, hipSetDevice(ctx->device));
-	cl_timing_begin(ctx);
-	cl_kmer_set* S = new cl_kmer_set(); S->ctx = ctx; S->k = k;
-	std::unique_ptr<cl_kmer_set> guard(S);
+	__shared__ uint32_t sh[PART_BINS];
+	for (uint32_t i = threadIdx.x; i < PART_BINS; i += 256) sh[i] = 0;
+	__syncthreads();
+	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+		atomicAdd(&sh[(uint32_t)(keys[i] >> shift) & (PART_BINS - 1)], 1u);
+	__syncthreads();
+	for (uint32_t i = threadIdx.x; i < PART_BINS; i += 256) if (sh[i]) atomicAdd(&bins[i], (unsigned long long)sh[i]);
+}
+// keys whose bin lies in [b0, b1) are appended to out (any order: they are sorted next)
+__global__ __launch_bounds__(256) void k_key_gather(const uint64_t* __restrict__ keys, uint64_t n, uint32_t shift, uint32_t b0, uint32_t b1,
+                                                    uint64_t* __restrict__ out, unsigned long long* __restrict__ counter)
+{
+	__shared__ uint32_t sh[4];
+	__shared__ unsigned long long sbase;
+	const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	uint64_t key = 0; uint32_t take = 0;
+	if (i < n) { key = keys[i]; const uint32_t b = (uint32_t)(key >> shift) & (PART_BINS - 1); take = b >= b0 && b < b1; }
+	uint32_t total;
+	const uint32_t ex = block_excl_scan_256(take, sh, &total);
+	if (threadIdx.x == 0) sbase = total ? atomicAdd(counter, (unsigned long long)total) : 0ULL;
+	__syncthreads();
+	if (take) out[sbase + ex] = key;
+}
+struct CountPiece { DevBuf<uint64_t> keys; DevBuf<uint32_t> counts; uint64_t n = 0; };
+} // namespace
+
+uint32_t cl_part_shift(uint32_t k) { return 2 * k > PART_BITS ? 2 * k - PART_BITS : 0; }
+// histogram of the keys over the 4096 top-bit bins (host copy)
+cl_status cl_key_histogram(cl_ctx* ctx, const uint64_t* d_kmers, uint64_t n, uint32_t k, std::vector<uint64_t>& h_bins)
+{
+	DevBuf<unsigned long long> bins; DEV_ALLOC(ctx, bins, PART_BINS);
+	HIP_TRY(ctx, hipMemsetAsync(bins.p, 0, PART_BINS * 8, ctx->stream));
+	if (n) LAUNCHB(ctx, n * 8.0, k_key_hist, (uint32_t)std::min<uint64_t>(4096, grid_for(n, 256)), 256, d_kmers, n, cl_part_shift(k), bins.p);
+	HIP_TRY(ctx, hipGetLastError());
+	h_bins.resize(PART_BINS);
+	HIP_TRY(ctx, hipMemcpyAsync(h_bins.data(), bins.p, PART_BINS * 8, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return CL_OK;
+}
+// the keys of bins [b0, b1) copied to d_out (which holds the `expect` keys the histogram counted for them)
+cl_status cl_key_gather(cl_ctx* ctx, const uint64_t* d_kmers, uint64_t n, uint32_t k, uint32_t b0, uint32_t b1, uint64_t* d_out, uint64_t expect)
+{
+	DevBuf<unsigned long long> counter; DEV_ALLOC(ctx, counter, 1);
+	HIP_TRY(ctx, hipMemsetAsync(counter.p, 0, 8, ctx->stream));
+	if (n) LAUNCHB(ctx, n * 8.0 + expect * 8.0, k_key_gather, grid_for(n, 256), 256, d_kmers, n, cl_part_shift(k), b0, b1, d_out, counter.p);
+	HIP_TRY(ctx, hipGetLastError());
+	unsigned long long got = 0;
+	HIP_TRY(ctx, hipMemcpyAsync(&got, counter.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	if (got != expect) return cl_fail(ctx, CL_E_INVALID, "cl_key_gather: histogram and gather disagree");
+	return CL_OK;
+}
+
+// exact counts of one key range that fits a single sort: d_kmers (n < 2^32) is sorted in place
+static cl_status count_range(cl_ctx* ctx, uint64_t* d_kmers, uint64_t n, uint32_t k, uint32_t ci, uint32_t cs, CountPiece& out, uint64_t* n_unique, uint64_t* filt_out)
+{
 	uint64_t n_heads = 0, n_kept = 0; unsigned long long filt = 0;
 	if (n)
 	{
@@ -504,26 +557,84 @@ extern "C" cl_status cl_kmer_count_filter(cl_ctx* ctx, uint64_t* d_kmers, uint64
 		DevBuf<uint32_t> head_pos; DEV_ALLOC(ctx, head_pos, n_heads);
 		{ LAUNCH(ctx, k_scatter_heads, grid_for(n, 256), 256, (const uint64_t*)d_kmers, (const uint32_t*)flags.p, n, n_heads, head_pos.p); }
 		HIP_TRY(ctx, hipGetLastError());
+		flags.release();
 		DevBuf<uint32_t> kflags; DEV_ALLOC(ctx, kflags, n_heads);
 		LAUNCH(ctx, k_count_flags, grid_for(n_heads, 256), 256, (const uint32_t*)head_pos.p, n_heads, n, ci, kflags.p);
 		HIP_TRY(ctx, hipGetLastError());
 		CL_TRY(dev_exclusive_scan_u32(ctx, kflags.p, n_heads, &n_kept));
-		DEV_ALLOC(ctx, S->keys, n_kept); DEV_ALLOC(ctx, S->counts, n_kept);
+		DEV_ALLOC(ctx, out.keys, n_kept); DEV_ALLOC(ctx, out.counts, n_kept);
 		DevBuf<unsigned long long> sum; DEV_ALLOC(ctx, sum, 1);
 		HIP_TRY(ctx, hipMemsetAsync(sum.p, 0, 8, ctx->stream));
 		LAUNCH(ctx, k_scatter_kept, grid_for(n_heads, 256), 256, (const uint64_t*)d_kmers, (const uint32_t*)head_pos.p,
-			(const uint32_t*)kflags.p, n_heads, n_kept, n, cs, S->keys.p, S->counts.p);
+			(const uint32_t*)kflags.p, n_heads, n_kept, n, cs, out.keys.p, out.counts.p);
 		HIP_TRY(ctx, hipGetLastError());
-		if (n_kept) LAUNCH(ctx, k_sum_u32, (uint32_t)std::min<uint64_t>(1024, grid_for(n_kept, 256)), 256, (const uint32_t*)S->counts.p, n_kept, sum.p);
+		if (n_kept) LAUNCH(ctx, k_sum_u32, (uint32_t)std::min<uint64_t>(1024, grid_for(n_kept, 256)), 256, (const uint32_t*)out.counts.p, n_kept, sum.p);
 		HIP_TRY(ctx, hipGetLastError());
 		HIP_TRY(ctx, hipMemcpyAsync(&filt, sum.p, 8, hipMemcpyDeviceToHost, ctx->stream));
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	}
-	else { DEV_ALLOC(ctx, S->keys, 0); DEV_ALLOC(ctx, S->counts, 0); }
-	S->n = n_kept;
+	out.n = n_kept; *n_unique += n_heads; *filt_out += filt;
+	return CL_OK;
+}
+
+extern "C" cl_status cl_kmer_count_filter(cl_ctx* ctx, uint64_t* d_kmers, uint64_t n, uint32_t k, uint32_t ci, uint32_t cs,
+                                          cl_kmer_set** out, cl_kmer_stats* stats)
+{
+	if (!ctx || !out) return cl_fail(ctx, CL_E_INVALID, "cl_kmer_count_filter: null argument");
+	if (k < 1 || k > 28) return cl_fail(ctx, CL_E_INVALID, "cl_kmer_count_filter: need 1 <= k <= 28");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	cl_timing_begin(ctx);
+	cl_kmer_set* S = new cl_kmer_set(); S->ctx = ctx; S->k = k;
+	std::unique_ptr<cl_kmer_set> guard(S);
+	uint64_t n_unique = 0, filt = 0;
+	// one sort handles < 2^32 keys and needs a second buffer of the same size: above the limit the input is counted
+	// one key range after the other (COLORD_HIP_COUNT_LIMIT lowers it so that small test inputs take this path)
+	uint64_t limit = 1ull << 30;
+	if (const char* e = getenv("COLORD_HIP_COUNT_LIMIT")) { const uint64_t v = strtoull(e, nullptr, 10); if (v) limit = v; }
+	if (n <= limit)
+	{
+		CountPiece pc;
+		CL_TRY(count_range(ctx, d_kmers, n, k, ci, cs, pc, &n_unique, &filt));
+		S->keys = std::move(pc.keys); S->counts = std::move(pc.counts); S->n = pc.n;
+		if (!n) { DEV_ALLOC(ctx, S->keys, 0); DEV_ALLOC(ctx, S->counts, 0); }
+	}
+	else
+	{
+		std::vector<uint64_t> bins;
+		CL_TRY(cl_key_histogram(ctx, d_kmers, n, k, bins));
+		std::vector<CountPiece> pieces;
+		uint64_t total_kept = 0;
+		for (uint32_t b0 = 0; b0 < PART_BINS; )
+		{
+			uint32_t b1 = b0; uint64_t cnt = 0;
+			while (b1 < PART_BINS && (b1 == b0 || cnt + bins[b1] <= limit)) cnt += bins[b1++];
+			if (cnt >= (1ull << 32)) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_kmer_count_filter: one of the 4096 key ranges holds >= 2^32 k-mers");
+			if (cnt)
+			{
+				DevBuf<uint64_t> work; DEV_ALLOC(ctx, work, cnt);
+				CL_TRY(cl_key_gather(ctx, d_kmers, n, k, b0, b1, work.p, cnt));
+				pieces.emplace_back();
+				CL_TRY(count_range(ctx, work.p, cnt, k, ci, cs, pieces.back(), &n_unique, &filt));
+				total_kept += pieces.back().n;
+			}
+			b0 = b1;
+		}
+		if (total_kept >= (1ull << 32)) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_kmer_count_filter: >= 2^32 kept k-mers (ids are 32-bit)");
+		DEV_ALLOC(ctx, S->keys, total_kept); DEV_ALLOC(ctx, S->counts, total_kept);
+		uint64_t o = 0;
+		for (auto& pc : pieces)
+		{
+			if (!pc.n) continue;
+			HIP_TRY(ctx, hipMemcpyAsync(S->keys.p + o, pc.keys.p, pc.n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+			HIP_TRY(ctx, hipMemcpyAsync(S->counts.p + o, pc.counts.p, pc.n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+			o += pc.n;
+		}
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		S->n = total_kept;
+	}
 	CL_TRY(build_table(ctx, S));          // a3: table with >= 2 slots per key
 	cl_timing_collect(ctx);
-	if (stats) { stats->tot_kmers = n; stats->n_unique = n_heads; stats->n_unique_counted = n_kept; stats->total_count_filtered = filt; }
+	if (stats) { stats->tot_kmers = n; stats->n_unique = n_unique; stats->n_unique_counted = S->n; stats->total_count_filtered = filt; }
 	*out = guard.release();
 	return CL_OK;
 }

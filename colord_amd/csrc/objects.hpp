@@ -43,3 +43,8 @@ struct cl_index {
 	DevBuf<uint64_t> off;         // n_keys + 1 (CSR over set ranks)
 	DevBuf<uint32_t> refs;        // reference ids, ascending inside a list
 };
+
+// key-range partitioning of k-mers (kmer.hip): histogram over the 4096 bins of the top 12 key bits, gather of a bin range
+uint32_t cl_part_shift(uint32_t k);
+cl_status cl_key_histogram(cl_ctx* ctx, const uint64_t* d_kmers, uint64_t n, uint32_t k, std::vector<uint64_t>& h_bins);
+cl_status cl_key_gather(cl_ctx* ctx, const uint64_t* d_kmers, uint64_t n, uint32_t k, uint32_t b0, uint32_t b1, uint64_t* d_out, uint64_t expect);

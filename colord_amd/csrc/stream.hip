@@ -1,0 +1,441 @@
+// stream.hip — runCompression for inputs that do not fit one call, and for reads sharded over GPUs.
+//
+// The reference streams a file of any size through its two passes: pass 1 counts the k-mers of the WHOLE input
+// (compression.cpp:432, CKmerCounter), pass 2 pushes reader packs of 4 Mi symbols through graph -> encoder -> coders
+// (compression.cpp:547-561, in_reads.cpp:62-77), the similarity graph growing as reference reads pass by
+// (reads_sim_graph.cpp:324-427).  cl_compressor is that state between calls; the caller hands it the input CHUNK by
+// chunk (a chunk = whole reader packs, e.g. 1 Gbase), three times:
+//   count_add*  -> count_finish      pass 1: surviving k-mers accumulate, then exact counts / the filtered set
+//   refs_add*   -> refs_finish       which reads become reference reads (acceptor), their store (a7) and the k-mer ->
+//                                    reference-reads index over the whole input; a read of any chunk sees exactly the
+//                                    index entries of EARLIER reference reads (lists are prefixes in id order, SURVEY
+//                                    App. F1), so the chunked result is byte-identical to one call over everything
+//   encode*                          pass 2: candidates, anchors, edit scripts, `dna` / `qual` parts of a chunk; the
+//                                    coders' adaptive models persist from chunk to chunk as in one CEntrCompr* thread
+// With a cl_exchange (one process per GPU, reads sharded in file order) the two finish steps run the exchanges of SURVEY
+// §8e: k-mers to the owner of their key range, kept keys all-gathered (replicated set); reference reads and index
+// entries all-gathered (replicated store + index).  The collectives themselves are the caller's (torch.distributed over
+// RCCL in colord_amd/parallel.py); this file only says what is exchanged.  Host code; all data work is in the stages.
+#include "common.hpp"
+#include "objects.hpp"
+#include <algorithm>
+#include <memory>
+#include <thread>
+
+namespace {
+__global__ void k_accept_flags2(const uint8_t* __restrict__ acc, const uint8_t* __restrict__ has_n, uint32_t n, uint8_t* __restrict__ out)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) out[i] = acc[i] && !has_n[i] ? 1 : 0;
+}
+__global__ void k_add_u32(uint32_t* v, uint64_t n, uint32_t c) { const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) v[i] += c; }
+// k-mers grouped by destination rank (the owner of the 4096-bin range a key falls into); cursor[r] = start of r's group
+__global__ __launch_bounds__(256) void k_owner_scatter(const uint64_t* __restrict__ keys, uint64_t n, uint32_t shift, const uint32_t* __restrict__ owner_of_bin,
+                                                       uint32_t world, unsigned long long* __restrict__ cursor, uint64_t* __restrict__ out)
+{
+	__shared__ uint32_t cnt[64];
+	__shared__ unsigned long long base[64];
+	if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
+	__syncthreads();
+	const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	uint64_t key = 0; uint32_t o = 0, my = 0;
+	if (i < n) { key = keys[i]; o = owner_of_bin[(uint32_t)(key >> shift) & 4095u]; my = atomicAdd(&cnt[o], 1u); }
+	__syncthreads();
+	if (threadIdx.x < world && cnt[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], (unsigned long long)cnt[threadIdx.x]);
+	__syncthreads();
+	if (i < n) out[base[o] + my] = key;
+}
+template<class T> struct Grow {            // device array that grows geometrically (k-mers of pass 1, index entries of pass 2a)
+	DevBuf<T> buf; uint64_t n = 0;
+	cl_status reserve(cl_ctx* ctx, uint64_t need)
+	{
+		if (need <= buf.n) return CL_OK;
+		uint64_t cap = std::max<uint64_t>(need, buf.n + buf.n / 2 + 1024);
+		DevBuf<T> nb; DEV_ALLOC(ctx, nb, cap);
+		if (n) { HIP_TRY(ctx, hipMemcpyAsync(nb.p, buf.p, n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream)); HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); }
+		buf = std::move(nb);
+		return CL_OK;
+	}
+};
+} // namespace
+
+struct cl_compressor {
+	cl_ctx* ctx = nullptr; cl_ctx* qctx = nullptr;
+	cl_compress_params P{}; bool has_qual = false; cl_qual_params Q{};
+	cl_exchange X{}; uint32_t rank = 0, world = 1;
+	int phase = 0;                                  // 0 counting, 1 counted, 2 references listed, 3 encoding
+	// pass 1
+	Grow<uint64_t> kmers; uint64_t expected_bases = 0;
+	std::vector<uint32_t> chunk_reads; uint64_t n_reads_local = 0, n_bases_local = 0;
+	cl_kmer_set* kset = nullptr; cl_kmer_stats gstats{};
+	uint64_t n_reads_total = 0, first_read = 0, mean_read_len = 0; uint32_t sparse_range = 0;
+	std::vector<uint8_t> h_accept;                  // acceptor decisions of this rank's reads
+	// pass 2a
+	size_t refs_chunk = 0; uint64_t refs_reads_seen = 0; uint32_t n_refs_local = 0;
+	std::vector<cl_reads*> ref_pieces;
+	Grow<uint32_t> pair_ids, pair_refs;
+	std::vector<DevBuf<uint32_t>> bounds;           // per chunk: n_reads + 1, reference reads before each read
+	cl_reads* refs = nullptr; cl_index* index = nullptr; uint32_t ref_base = 0, n_refs_total = 0;
+	cl_dna_coder* dna = nullptr; cl_qual_coder* qual = nullptr;
+	// pass 2b
+	size_t enc_chunk = 0;
+	~cl_compressor()
+	{
+		for (auto* r : ref_pieces) cl_reads_free(r);
+		if (refs) cl_reads_free(refs);
+		if (index) cl_index_free(index);
+		if (kset) cl_kmer_set_free(kset);
+		if (dna) cl_dna_coder_free(dna);
+		if (qual) cl_qual_coder_free(qual);
+	}
+};
+
+extern "C" cl_status cl_compressor_create(cl_ctx* ctx, cl_ctx* qual_ctx, const cl_compress_params* params, const cl_qual_params* qparams,
+                                          const cl_exchange* exchange, uint64_t expected_bases, cl_compressor** out)
+{
+	if (!ctx || !params || !out) return cl_fail(ctx, CL_E_INVALID, "cl_compressor_create: null argument");
+	if (exchange && (exchange->world < 1 || exchange->world > 64 || exchange->rank >= exchange->world ||
+	                 (exchange->world > 1 && (!exchange->all_gather_host || !exchange->all_to_all_v || !exchange->all_gather_v))))
+		return cl_fail(ctx, CL_E_INVALID, "cl_compressor_create: exchange needs 1 <= world <= 64, rank < world and its three collectives");
+	cl_compressor* c = new cl_compressor();
+	c->ctx = ctx; c->qctx = qual_ctx ? qual_ctx : ctx; c->P = *params; c->expected_bases = expected_bases;
+	if (qparams) { c->has_qual = true; c->Q = *qparams; }
+	if (exchange && exchange->world > 1) { c->X = *exchange; c->rank = exchange->rank; c->world = exchange->world; }
+	*out = c;
+	return CL_OK;
+}
+extern "C" void cl_compressor_free(cl_compressor* c) { delete c; }
+
+// ---- pass 1 ---------------------------------------------------------------------------------------------------------
+extern "C" cl_status cl_compressor_count_add(cl_compressor* c, const cl_reads* chunk)
+{
+	if (!c || !chunk) return CL_E_INVALID;
+	cl_ctx* ctx = c->ctx;
+	if (c->phase != 0) return cl_fail(ctx, CL_E_INVALID, "cl_compressor_count_add: pass 1 is already finished");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	const uint32_t f = c->P.f;
+	uint64_t want = f > 1 ? (uint64_t)(chunk->total_bases / f * 1.15) + 4096 : chunk->total_bases + 64;
+	if (!c->kmers.buf.n && c->expected_bases > chunk->total_bases)          // one allocation for the whole input when its size is known
+		CL_TRY(c->kmers.reserve(ctx, f > 1 ? (uint64_t)(c->expected_bases / f * 1.03) + 4096 : c->expected_bases + 64));
+	if (c->kmers.buf.n - c->kmers.n >= chunk->total_bases / f) want = c->kmers.buf.n - c->kmers.n;     // what is left probably holds the chunk: no regrowth
+	for (;;)
+	{
+		CL_TRY(c->kmers.reserve(ctx, c->kmers.n + want));
+		uint64_t got = 0;
+		const cl_status s = cl_kmer_scan(ctx, chunk, c->P.k, f, c->kmers.buf.p + c->kmers.n, c->kmers.buf.n - c->kmers.n, &got);
+		if (s == CL_E_CAPACITY) { want = got + got / 64; continue; }
+		CL_TRY(s);
+		c->kmers.n += got;
+		break;
+	}
+	c->chunk_reads.push_back(chunk->n_reads);
+	c->n_reads_local += chunk->n_reads; c->n_bases_local += chunk->total_bases;
+	return CL_OK;
+}
+
+// k-mers to the rank that owns their key range; returns the received k-mers in c->kmers
+static cl_status exchange_kmers(cl_compressor* c)
+{
+	cl_ctx* ctx = c->ctx; const uint32_t W = c->world, k = c->P.k;
+	std::vector<uint64_t> bins;
+	CL_TRY(cl_key_histogram(ctx, c->kmers.buf.p, c->kmers.n, k, bins));
+	// global histogram -> W contiguous bin ranges of about equal weight (the same cut on every rank)
+	std::vector<uint64_t> all((size_t)W * 4096);
+	CL_TRY(c->X.all_gather_host(c->X.user, bins.data(), 4096, all.data()));
+	std::vector<uint64_t> g(4096, 0); uint64_t total = 0;
+	for (uint32_t r = 0; r < W; ++r) for (uint32_t b = 0; b < 4096; ++b) g[b] += all[(size_t)r * 4096 + b];
+	for (uint64_t v : g) total += v;
+	std::vector<uint32_t> owner(4096); uint64_t acc = 0; uint32_t r = 0;
+	for (uint32_t b = 0; b < 4096; ++b)
+	{
+		while (r + 1 < W && acc >= (total * (r + 1) + W - 1) / W) ++r;
+		owner[b] = r; acc += g[b];
+	}
+	DevBuf<uint32_t> d_owner; DEV_ALLOC(ctx, d_owner, 4096);
+	HIP_TRY(ctx, hipMemcpyAsync(d_owner.p, owner.data(), 4096 * 4, hipMemcpyHostToDevice, ctx->stream));
+	std::vector<uint64_t> send(W, 0);
+	for (uint32_t b = 0; b < 4096; ++b) send[owner[b]] += bins[b];
+	std::vector<unsigned long long> cur(W, 0);
+	for (uint32_t i = 1; i < W; ++i) cur[i] = cur[i - 1] + send[i - 1];
+	DevBuf<unsigned long long> d_cur; DEV_ALLOC(ctx, d_cur, 64);
+	HIP_TRY(ctx, hipMemcpyAsync(d_cur.p, cur.data(), W * 8, hipMemcpyHostToDevice, ctx->stream));
+	DevBuf<uint64_t> sorted; DEV_ALLOC(ctx, sorted, c->kmers.n);
+	if (c->kmers.n)
+		LAUNCHB(ctx, c->kmers.n * 16.0, k_owner_scatter, grid_for(c->kmers.n, 256), 256, (const uint64_t*)c->kmers.buf.p, c->kmers.n, cl_part_shift(k), (const uint32_t*)d_owner.p, W, d_cur.p, sorted.p);
+	HIP_TRY(ctx, hipGetLastError());
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	// counts each rank sends to me
+	std::vector<uint64_t> mat((size_t)W * W);
+	CL_TRY(c->X.all_gather_host(c->X.user, send.data(), W, mat.data()));
+	std::vector<uint64_t> sb(W), rb(W); uint64_t n_recv = 0;
+	for (uint32_t i = 0; i < W; ++i) { sb[i] = send[i] * 8; rb[i] = mat[(size_t)i * W + c->rank] * 8; n_recv += mat[(size_t)i * W + c->rank]; }
+	c->kmers.buf.release(); c->kmers.n = 0;
+	DevBuf<uint64_t> recv; DEV_ALLOC(ctx, recv, n_recv);
+	CL_TRY(c->X.all_to_all_v(c->X.user, sorted.p, sb.data(), recv.p, rb.data()));
+	c->kmers.buf = std::move(recv); c->kmers.n = n_recv;
+	return CL_OK;
+}
+
+extern "C" cl_status cl_compressor_count_finish(cl_compressor* c, cl_kmer_stats* stats)
+{
+	if (!c) return CL_E_INVALID;
+	cl_ctx* ctx = c->ctx;
+	if (c->phase != 0) return cl_fail(ctx, CL_E_INVALID, "cl_compressor_count_finish: called twice");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	const uint32_t W = c->world;
+	cl_kmer_stats st{};
+	if (W > 1) CL_TRY(exchange_kmers(c));
+	CL_TRY(cl_kmer_count_filter(ctx, c->kmers.buf.p, c->kmers.n, c->P.k, c->P.ci, c->P.cs, &c->kset, &st));
+	c->kmers.buf.release(); c->kmers.n = 0;
+	c->first_read = 0; c->n_reads_total = c->n_reads_local;
+	if (W > 1)
+	{
+		// replicate the filtered set: partitions are key ranges in rank order, so the concatenation is ascending
+		uint64_t mine[6] = { st.tot_kmers, st.n_unique, st.n_unique_counted, st.total_count_filtered, c->n_reads_local, 0 };
+		std::vector<uint64_t> all((size_t)W * 6);
+		CL_TRY(c->X.all_gather_host(c->X.user, mine, 6, all.data()));
+		std::vector<uint64_t> kb(W), cb(W); uint64_t n_all = 0;
+		st = cl_kmer_stats{}; c->n_reads_total = 0;
+		for (uint32_t r = 0; r < W; ++r)
+		{
+			const uint64_t* a = &all[(size_t)r * 6];
+			st.tot_kmers += a[0]; st.n_unique += a[1]; st.n_unique_counted += a[2]; st.total_count_filtered += a[3];
+			if (r < c->rank) c->first_read += a[4];
+			c->n_reads_total += a[4];
+			kb[r] = a[2] * 8; cb[r] = a[2] * 4; n_all += a[2];
+		}
+		if (n_all >= (1ull << 32)) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_compressor_count_finish: >= 2^32 kept k-mers");
+		DevBuf<uint64_t> keys; DevBuf<uint32_t> counts; DEV_ALLOC(ctx, keys, n_all); DEV_ALLOC(ctx, counts, n_all);
+		CL_TRY(c->X.all_gather_v(c->X.user, cl_kmer_set_keys(c->kset), kb[c->rank], keys.p, kb.data()));
+		CL_TRY(c->X.all_gather_v(c->X.user, cl_kmer_set_counts(c->kset), cb[c->rank], counts.p, cb.data()));
+		cl_kmer_set_free(c->kset); c->kset = nullptr;
+		CL_TRY(cl_kmer_set_create(ctx, keys.p, counts.p, n_all, c->P.k, &c->kset));
+	}
+	if (c->n_reads_total >= (1ull << 30)) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_compressor: >= 2^30 reads (reference ids are 30-bit, hm_compact.h:545-552)");
+	st.n_reads = c->n_reads_total;
+	c->gstats = st;
+	// host scalars of compression.cpp:443,501-503 and the acceptor's decisions (one stream over the whole input, a6)
+	const uint64_t n = c->n_reads_total;
+	c->mean_read_len = n ? (uint64_t)((double)(st.tot_kmers * c->P.f) / n + c->P.k - 1) : 0;
+	c->h_accept.assign(c->n_reads_local, 1);
+	if (c->P.sparse && n)
+	{
+		uint32_t range = (uint32_t)((c->P.sparse_g * (double)st.n_unique_counted * c->P.f) / (double)(c->mean_read_len ? c->mean_read_len : 1));
+		if (range < 1) range = 1;
+		c->sparse_range = range;
+		std::vector<uint8_t> all(n);
+		CL_TRY(cl_ref_accept((uint32_t)n, 0, range, c->P.sparse_exponent, all.data()));
+		std::copy(all.begin() + c->first_read, all.begin() + c->first_read + c->n_reads_local, c->h_accept.begin());
+	}
+	c->phase = 1;
+	if (stats) *stats = st;
+	return CL_OK;
+}
+
+// ---- pass 2a --------------------------------------------------------------------------------------------------------
+extern "C" cl_status cl_compressor_refs_add(cl_compressor* c, const cl_reads* chunk)
+{
+	if (!c || !chunk) return CL_E_INVALID;
+	cl_ctx* ctx = c->ctx;
+	if (c->phase != 1) return cl_fail(ctx, CL_E_INVALID, "cl_compressor_refs_add: call after count_finish and before refs_finish");
+	if (c->refs_chunk >= c->chunk_reads.size() || c->chunk_reads[c->refs_chunk] != chunk->n_reads)
+		return cl_fail(ctx, CL_E_INVALID, "cl_compressor_refs_add: chunks must come in the order and sizes of pass 1");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	const uint32_t n = chunk->n_reads;
+	DevBuf<uint8_t> accept; DEV_ALLOC(ctx, accept, n);
+	{
+		DevBuf<uint8_t> d_acc; DEV_ALLOC(ctx, d_acc, n);
+		if (n) HIP_TRY(ctx, hipMemcpyAsync(d_acc.p, c->h_accept.data() + c->refs_reads_seen, n, hipMemcpyHostToDevice, ctx->stream));
+		if (n) LAUNCH(ctx, k_accept_flags2, grid_for(n, 256), 256, (const uint8_t*)d_acc.p, (const uint8_t*)chunk->has_n.p, n, accept.p);
+		HIP_TRY(ctx, hipGetLastError());
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	}
+	cl_kmer_lists* lists = nullptr;
+	CL_TRY(cl_accepted_kmers(ctx, c->kset, chunk, c->P.k, c->P.f, &lists));
+	std::unique_ptr<cl_kmer_lists, void (*)(cl_kmer_lists*)> lg(lists, cl_kmer_lists_free);
+	c->bounds.emplace_back();
+	DEV_ALLOC(ctx, c->bounds.back(), (uint64_t)n + 1);
+	uint64_t n_sel = 0; uint32_t n_acc = 0;
+	cl_status s = cl_index_entries_of(ctx, lists, accept.p, c->n_refs_local, nullptr, nullptr, 0, &n_sel, c->bounds.back().p, &n_acc);
+	if (s != CL_OK && s != CL_E_CAPACITY) return s;
+	if (n_sel)
+	{
+		CL_TRY(c->pair_ids.reserve(ctx, c->pair_ids.n + n_sel)); CL_TRY(c->pair_refs.reserve(ctx, c->pair_refs.n + n_sel));
+		CL_TRY(cl_index_entries_of(ctx, lists, accept.p, c->n_refs_local, c->pair_ids.buf.p + c->pair_ids.n, c->pair_refs.buf.p + c->pair_refs.n, n_sel, &n_sel, nullptr, nullptr));
+		c->pair_ids.n += n_sel; c->pair_refs.n += n_sel;
+	}
+	cl_reads* piece = nullptr;
+	CL_TRY(cl_reads_select(ctx, chunk, accept.p, &piece));
+	c->ref_pieces.push_back(piece);
+	c->n_refs_local += n_acc;
+	c->refs_reads_seen += n; ++c->refs_chunk;
+	return CL_OK;
+}
+
+extern "C" cl_status cl_compressor_refs_finish(cl_compressor* c)
+{
+	if (!c) return CL_E_INVALID;
+	cl_ctx* ctx = c->ctx;
+	if (c->phase != 1 || c->refs_chunk != c->chunk_reads.size()) return cl_fail(ctx, CL_E_INVALID, "cl_compressor_refs_finish: every chunk of pass 1 must have been listed");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	const uint32_t W = c->world;
+	// this rank's reference reads as one arena
+	uint64_t words = 0; uint32_t nr = 0;
+	for (auto* p : c->ref_pieces) { words += p->total_words; nr += p->n_reads; }
+	DevBuf<uint64_t> pk; DevBuf<uint32_t> iv, ln; DEV_ALLOC(ctx, pk, words + 1); DEV_ALLOC(ctx, iv, words + 1); DEV_ALLOC(ctx, ln, (uint64_t)nr + 1);
+	{
+		uint64_t wo = 0; uint32_t ro = 0;
+		for (auto* p : c->ref_pieces)
+		{
+			if (p->total_words) { HIP_TRY(ctx, hipMemcpyAsync(pk.p + wo, p->packed.p, p->total_words * 8, hipMemcpyDeviceToDevice, ctx->stream)); HIP_TRY(ctx, hipMemcpyAsync(iv.p + wo, p->inv.p, p->total_words * 4, hipMemcpyDeviceToDevice, ctx->stream)); }
+			if (p->n_reads) HIP_TRY(ctx, hipMemcpyAsync(ln.p + ro, p->lens.p, (uint64_t)p->n_reads * 4, hipMemcpyDeviceToDevice, ctx->stream));
+			wo += p->total_words; ro += p->n_reads;
+		}
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		for (auto* p : c->ref_pieces) cl_reads_free(p);
+		c->ref_pieces.clear();
+	}
+	c->ref_base = 0; c->n_refs_total = nr;
+	uint64_t n_pairs = c->pair_ids.n;
+	if (W > 1)
+	{
+		uint64_t mine[4] = { nr, words, c->pair_ids.n, 0 };
+		std::vector<uint64_t> all((size_t)W * 4);
+		CL_TRY(c->X.all_gather_host(c->X.user, mine, 4, all.data()));
+		std::vector<uint64_t> b_pk(W), b_iv(W), b_ln(W), b_pr(W); uint64_t t_words = 0, t_reads = 0, t_pairs = 0;
+		for (uint32_t r = 0; r < W; ++r)
+		{
+			const uint64_t* a = &all[(size_t)r * 4];
+			if (r < c->rank) c->ref_base += (uint32_t)a[0];
+			t_reads += a[0]; t_words += a[1]; t_pairs += a[2];
+			b_ln[r] = a[0] * 4; b_pk[r] = a[1] * 8; b_iv[r] = a[1] * 4; b_pr[r] = a[2] * 4;
+		}
+		if (t_reads >= (1ull << 30)) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_compressor: >= 2^30 reference reads");
+		c->n_refs_total = (uint32_t)t_reads;
+		// global reference ids: this rank's references follow those of the lower ranks (file order)
+		if (c->ref_base)
+		{
+			if (c->pair_refs.n) LAUNCH(ctx, k_add_u32, grid_for(c->pair_refs.n, 256), 256, c->pair_refs.buf.p, c->pair_refs.n, c->ref_base);
+			for (size_t i = 0; i < c->bounds.size(); ++i) { const uint64_t m = (uint64_t)c->chunk_reads[i] + 1; LAUNCH(ctx, k_add_u32, grid_for(m, 256), 256, c->bounds[i].p, m, c->ref_base); }
+			HIP_TRY(ctx, hipGetLastError());
+			HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		}
+		DevBuf<uint64_t> g_pk; DevBuf<uint32_t> g_iv, g_ln, g_id, g_rf;
+		DEV_ALLOC(ctx, g_pk, t_words + 1); DEV_ALLOC(ctx, g_iv, t_words + 1); DEV_ALLOC(ctx, g_ln, t_reads + 1); DEV_ALLOC(ctx, g_id, t_pairs + 1); DEV_ALLOC(ctx, g_rf, t_pairs + 1);
+		CL_TRY(c->X.all_gather_v(c->X.user, pk.p, b_pk[c->rank], g_pk.p, b_pk.data()));
+		CL_TRY(c->X.all_gather_v(c->X.user, iv.p, b_iv[c->rank], g_iv.p, b_iv.data()));
+		CL_TRY(c->X.all_gather_v(c->X.user, ln.p, b_ln[c->rank], g_ln.p, b_ln.data()));
+		CL_TRY(c->X.all_gather_v(c->X.user, c->pair_ids.buf.p, b_pr[c->rank], g_id.p, b_pr.data()));
+		CL_TRY(c->X.all_gather_v(c->X.user, c->pair_refs.buf.p, b_pr[c->rank], g_rf.p, b_pr.data()));
+		pk = std::move(g_pk); iv = std::move(g_iv); ln = std::move(g_ln);
+		c->pair_ids.buf = std::move(g_id); c->pair_refs.buf = std::move(g_rf); n_pairs = t_pairs;
+		nr = (uint32_t)t_reads;
+	}
+	CL_TRY(cl_reads_from_arena(ctx, pk.p, iv.p, ln.p, nr, &c->refs));
+	pk.release(); iv.release(); ln.release();
+	CL_TRY(cl_index_build_pairs(ctx, c->kset, c->pair_ids.buf.p, c->pair_refs.buf.p, n_pairs, nullptr, 0, c->n_refs_total, 0, c->P.cs, &c->index));
+	c->pair_ids.buf.release(); c->pair_refs.buf.release(); c->pair_ids.n = c->pair_refs.n = 0;
+	// the coders of this rank's model domain; cur_read_id starts at the global index of the first read, so that the ids of
+	// references from lower ranks fit the byte count the coder derives from it (dna_coder.cpp:26-63)
+	CL_TRY(cl_dna_coder_create(ctx, c->P.c, c->P.level, (uint32_t)c->first_read, &c->dna));
+	if (c->has_qual)
+	{
+		cl_ctx* qc = (c->P.level <= 1) ? c->qctx : ctx;        // levels 2 and 3 need the edit scripts: same stream as the DNA path
+		const cl_status s = cl_qual_coder_create(qc, &c->Q, &c->qual);
+		if (s != CL_OK) return cl_fail(ctx, s, std::string("quality coder: ") + cl_last_error(qc));
+	}
+	c->phase = 2;
+	return CL_OK;
+}
+
+// ---- pass 2b --------------------------------------------------------------------------------------------------------
+extern "C" cl_status cl_compressor_encode(cl_compressor* c, const cl_reads* reads, const uint8_t* d_quals, const uint64_t* d_base_off,
+                                          const uint32_t* h_part_bounds, uint32_t n_parts, const uint32_t* h_pack_bounds, uint32_t n_packs,
+                                          uint8_t* d_dna_out, uint64_t dna_cap, uint64_t* h_dna_part_sizes,
+                                          uint8_t* d_qual_out, uint64_t qual_cap, uint64_t* h_qual_part_sizes, cl_compress_info* info)
+{
+	if (!c || !reads || !h_part_bounds || !h_pack_bounds || !info) return CL_E_INVALID;
+	cl_ctx* ctx = c->ctx;
+	if (c->phase != 2) return cl_fail(ctx, CL_E_INVALID, "cl_compressor_encode: call after refs_finish");
+	if (c->enc_chunk >= c->chunk_reads.size() || c->chunk_reads[c->enc_chunk] != reads->n_reads)
+		return cl_fail(ctx, CL_E_INVALID, "cl_compressor_encode: chunks must come in the order and sizes of pass 1");
+	if (c->has_qual && (!d_quals || !d_base_off || !h_qual_part_sizes || !d_qual_out)) return cl_fail(ctx, CL_E_INVALID, "cl_compressor_encode: quality stream without qualities");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	const cl_compress_params* P = &c->P;
+	memset(info, 0, sizeof(*info));
+	const uint32_t n = reads->n_reads;
+	info->n_reads = n; info->n_bases = reads->total_bases; info->tot_kmers = c->gstats.tot_kmers; info->n_kept_kmers = c->gstats.n_unique_counted;
+	info->n_refs = c->n_refs_total; info->sparse_range = c->sparse_range;
+	const uint32_t* d_bounds = c->bounds[c->enc_chunk].p;
+	if (!n) { c->bounds[c->enc_chunk].release(); ++c->enc_chunk; return CL_OK; }
+	struct Joiner { std::thread t; ~Joiner() { if (t.joinable()) t.join(); } } qjob;
+	cl_status qstatus = CL_OK;
+	cl_ctx* qctx = c->qual ? cl_qual_coder_ctx(c->qual) : nullptr;
+	const bool overlap = c->qual && P->level <= 1 && qctx && qctx != ctx;
+	if (overlap)
+		qjob.t = std::thread([&]() { qstatus = cl_qual_encode(qctx, c->qual, reads, d_quals, d_base_off, nullptr, h_part_bounds, n_parts, d_qual_out, qual_cap, h_qual_part_sizes, &info->qual_bytes); });
+	cl_kmer_lists* lists = nullptr;
+	CL_TRY(cl_accepted_kmers(ctx, c->kset, reads, P->k, P->f, &lists));
+	std::unique_ptr<cl_kmer_lists, void (*)(cl_kmer_lists*)> lg(lists, cl_kmer_lists_free);
+	const uint32_t cc = P->c;
+	DevBuf<uint32_t> crefs, votes, cnt; DEV_ALLOC(ctx, crefs, (uint64_t)n * cc); DEV_ALLOC(ctx, votes, (uint64_t)n * cc); DEV_ALLOC(ctx, cnt, n);
+	CL_TRY(cl_candidates_at(ctx, c->index, lists, d_bounds, cc, crefs.p, votes.p, cnt.p));
+	votes.release();
+	DevBuf<uint64_t> common_off, common;
+	const bool hifi = P->source == 2;
+	if (hifi)
+	{
+		DEV_ALLOC(ctx, common_off, (uint64_t)n * cc + 1);
+		uint64_t need = 0;
+		cl_status s = cl_candidates_common(ctx, c->index, lists, cc, crefs.p, cnt.p, common_off.p, nullptr, 0, &need);
+		if (s != CL_OK && s != CL_E_CAPACITY) return s;
+		DEV_ALLOC(ctx, common, need + 1);
+		CL_TRY(cl_candidates_common(ctx, c->index, lists, cc, crefs.p, cnt.p, common_off.p, common.p, need, &need));
+	}
+	lg.reset();
+	cl_anchors* anc = nullptr;
+	CL_TRY(cl_anchor_candidates_hifi(ctx, reads, c->refs, crefs.p, cnt.p, cc, P->anchor_len, P->frac_always, P->frac_min, P->max_matches_mult, P->min_anchors,
+		P->k, P->f, hifi ? common_off.p : nullptr, hifi ? common.p : nullptr, &anc));
+	std::unique_ptr<cl_anchors, void (*)(cl_anchors*)> ag(anc, cl_anchors_free);
+	info->n_anchors = cl_anchors_total(anc);
+	crefs.release(); cnt.release(); common_off.release(); common.release();
+	DevBuf<uint8_t> es; DevBuf<uint64_t> es_off; DevBuf<uint32_t> es_nt;
+	const uint64_t es_cap = reads->total_bases + 16ull * n + 4096;
+	DEV_ALLOC(ctx, es, es_cap); DEV_ALLOC(ctx, es_off, (uint64_t)n + 1); DEV_ALLOC(ctx, es_nt, n);
+	uint64_t es_bytes = 0;
+	CL_TRY(cl_encode_reads(ctx, reads, c->refs, anc, cc, P->anchor_len, P->min_part_alt, P->max_rec, P->cost_mult, h_pack_bounds, n_packs, es.p, es_cap, es_off.p, es_nt.p, &es_bytes));
+	ag.reset();
+	info->tuple_bytes = es_bytes;
+	CL_TRY(cl_dna_encode(ctx, c->dna, c->refs, es.p, es_off.p, es_nt.p, n, h_part_bounds, n_parts, d_dna_out, dna_cap, h_dna_part_sizes, &info->dna_bytes));
+	if (overlap)
+	{
+		qjob.t.join();
+		if (qstatus != CL_OK) return cl_fail(ctx, qstatus, std::string("quality stream: ") + cl_last_error(qctx));
+	}
+	else if (c->qual)
+	{
+		DevBuf<uint8_t> flags;
+		if (P->level > 1)
+		{
+			DEV_ALLOC(ctx, flags, reads->total_bases + 1);
+			CL_TRY(cl_es_flags(ctx, reads, es.p, es_off.p, d_base_off, flags.p));
+		}
+		CL_TRY(cl_qual_encode(ctx, c->qual, reads, d_quals, d_base_off, P->level > 1 ? flags.p : nullptr, h_part_bounds, n_parts, d_qual_out, qual_cap, h_qual_part_sizes, &info->qual_bytes));
+	}
+	c->bounds[c->enc_chunk].release();
+	++c->enc_chunk;
+	return CL_OK;
+}
+
+extern "C" cl_status cl_compressor_info(const cl_compressor* c, cl_kmer_stats* stats, uint64_t* first_read, uint64_t* n_reads_total, uint64_t* mean_read_len,
+                                        uint32_t* sparse_range, uint32_t* n_refs_total)
+{
+	if (!c || c->phase < 1) return CL_E_INVALID;
+	if (stats) *stats = c->gstats;
+	if (first_read) *first_read = c->first_read;
+	if (n_reads_total) *n_reads_total = c->n_reads_total;
+	if (mean_read_len) *mean_read_len = c->mean_read_len;
+	if (sparse_range) *sparse_range = c->sparse_range;
+	if (n_refs_total) *n_refs_total = c->n_refs_total;
+	return CL_OK;
+}

@@ -295,6 +295,25 @@ class Context:
         inf = {n_: getattr(info, n_) for n_, _ in N.CompressInfo._fields_ if n_ != "pad"}
         return dout[:inf["dna_bytes"]], dsz[:npart], (qout[:inf["qual_bytes"]] if qout is not None else None), qsz[:npart], inf
 
+    # ---- the same path chunk by chunk (any input size; one rank of a multi-GPU run when `exchange` is given) ----
+    def compressor(self, params: dict, qual_params=None, qual_ctx: "Context | None" = None, exchange=None, expected_bases: int = 0) -> "Compressor":
+        """cl_compressor_create.  qual_params: (mode, source, level, fwd, rev) or None."""
+        P = N.CompressParams()
+        for k_, v in params.items():
+            setattr(P, k_, v)
+        Q = None
+        if qual_params is not None:
+            mode, source, level, fwd, rev = qual_params
+            Q = N.QualParams(mode=mode, source=source, level=level, n_fwd=len(fwd), n_rev=len(rev))
+            for i, v in enumerate(fwd):
+                Q.fwd[i] = v
+            for i, v in enumerate(rev):
+                Q.rev[i] = v
+        h = N._P()
+        _check(self, self.lib.cl_compressor_create(self.h, qual_ctx.h if qual_ctx is not None else None, C.byref(P), C.byref(Q) if Q is not None else None,
+                                                   C.byref(exchange.c_struct) if exchange is not None else None, int(expected_bases), C.byref(h)))
+        return Compressor(self, h, qual_ctx, Q is not None, exchange)
+
     # ---- a14 ----
     def dna_coder(self, max_alt_refs: int, level: int, start_read_id: int = 0) -> "DnaCoder":
         h = N._P()
@@ -406,6 +425,56 @@ class QualCoder(_Obj):
                 raise N.ColordHipError(st, "qual output capacity exceeded after models advanced; retry with a larger cap")
             _check(ctx, st)
             return out[:n.value], [int(x) for x in sizes[:n_parts]]
+
+
+class Compressor(_Obj):
+    """cl_compressor: pass 1 / reference listing / pass 2 over the chunks of an input (csrc/stream.hip)."""
+    _free = "cl_compressor_free"
+
+    def __init__(self, ctx, h, qual_ctx, has_qual, exchange):
+        super().__init__(ctx, h)
+        self.qual_ctx, self.has_qual, self.exchange = qual_ctx, has_qual, exchange       # (the exchange's callbacks must outlive the handle)
+
+    def count_add(self, reads: "Reads"):
+        _check(self.ctx, self.ctx.lib.cl_compressor_count_add(self.h, reads.h))
+
+    def count_finish(self):
+        st = N.KmerStats()
+        _check(self.ctx, self.ctx.lib.cl_compressor_count_finish(self.h, C.byref(st)))
+        return st
+
+    def refs_add(self, reads: "Reads"):
+        _check(self.ctx, self.ctx.lib.cl_compressor_refs_add(self.h, reads.h))
+
+    def refs_finish(self):
+        _check(self.ctx, self.ctx.lib.cl_compressor_refs_finish(self.h))
+
+    def info(self) -> dict:
+        st = N.KmerStats(); a, b, m = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0); r, nr = C.c_uint32(0), C.c_uint32(0)
+        _check(self.ctx, self.ctx.lib.cl_compressor_info(self.h, C.byref(st), C.byref(a), C.byref(b), C.byref(m), C.byref(r), C.byref(nr)))
+        return dict(tot_kmers=st.tot_kmers, n_unique_counted=st.n_unique_counted, first_read=a.value, n_reads_total=b.value, mean_read_len=m.value,
+                    sparse_range=r.value, n_refs_total=nr.value)
+
+    def encode(self, reads: "Reads", part_bounds, pack_bounds, quals: torch.Tensor | None = None, base_off: torch.Tensor | None = None,
+               dna_out: torch.Tensor | None = None, qual_out: torch.Tensor | None = None):
+        """One chunk of pass 2.  Returns (dna payload, dna part sizes, qual payload or None, qual part sizes, info dict); with
+        dna_out / qual_out the payloads are written to the START of those caller tensors (views are returned)."""
+        ctx = self.ctx
+        pb = np.ascontiguousarray(np.asarray(part_bounds, dtype=np.uint32)); kb = np.ascontiguousarray(np.asarray(pack_bounds, dtype=np.uint32))
+        npart = len(pb) - 1
+        if dna_out is None:
+            dna_out = torch.empty(int(reads.total_bases) + 64 * npart + 4096, dtype=torch.uint8, device=ctx.device)
+        dsz, qsz = np.zeros(max(npart, 1), np.uint64), np.zeros(max(npart, 1), np.uint64)
+        if self.has_qual and qual_out is None:
+            qual_out = torch.empty(int(int(reads.total_bases) * 1.35) + 64 * npart + 4096, dtype=torch.uint8, device=ctx.device)
+        info = N.CompressInfo()
+        _check(ctx, ctx.lib.cl_compressor_encode(self.h, reads.h, quals.data_ptr() if self.has_qual else None, base_off.contiguous().data_ptr() if self.has_qual else None,
+                                                 pb.ctypes.data, npart, kb.ctypes.data, len(kb) - 1, dna_out.data_ptr(), dna_out.numel(), dsz.ctypes.data,
+                                                 qual_out.data_ptr() if self.has_qual else None, qual_out.numel() if self.has_qual else 0, qsz.ctypes.data, C.byref(info)))
+        if self.qual_ctx is not None and self.qual_ctx is not ctx:
+            _check(self.qual_ctx, N.CL_OK)                  # collect the kernel times of the concurrent quality stream
+        inf = {n_: getattr(info, n_) for n_, _ in N.CompressInfo._fields_ if n_ != "pad"}
+        return dna_out[:inf["dna_bytes"]], dsz[:npart], (qual_out[:inf["qual_bytes"]] if self.has_qual else None), qsz[:npart], inf
 
 
 class DnaCoder(_Obj):

@@ -89,3 +89,136 @@ def exclusive_prefix(val: int, device) -> tuple:
     parts = all_gather_v(torch.tensor([val], dtype=torch.int64, device=device))
     vals = [int(p.item()) for p in parts]
     return sum(vals[:rank()]), sum(vals)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# cl_exchange: the collectives a multi-GPU cl_compressor (csrc/stream.hip) calls back into.  The library says WHAT is
+# exchanged (k-mers by key-range owner, kept keys, reference reads, index entries); this class moves the bytes with
+# torch.distributed — backend "nccl" is RCCL over xGMI, device to device; "gloo" stages through host memory and exists for
+# functional tests with fewer GPUs than ranks (and for the CPU suite, where the "device" pointers are host pointers).
+# ---------------------------------------------------------------------------------------------------------------------
+import ctypes as _C
+import numpy as _np
+from . import _native as _N
+
+
+class _DevPtr:
+    """A raw device pointer as a __cuda_array_interface__ object (zero-copy view for torch.as_tensor)."""
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+class TorchExchange:
+    def __init__(self, device=None):
+        self.rank, self.world = rank(), world()
+        self.device = device
+        self.host_mem = device is None or torch.device(device).type == "cpu"     # CPU suite: pointers are host pointers
+        self.err = None
+        self.bytes_moved = 0                                                       # payload bytes this rank received (diagnostic)
+        self._cbs = (_N._EXCH_GATHER_HOST(self._gather_host), _N._EXCH_A2AV(self._all_to_all_v), _N._EXCH_GATHERV(self._all_gather_v))
+        self.c_struct = _N.Exchange(None, self.rank, self.world, *self._cbs)
+
+    # -- pointer -> tensor views --------------------------------------------------------------------------------------
+    def _view(self, ptr, nbytes):
+        if not nbytes:
+            return torch.empty(0, dtype=torch.uint8, device="cpu" if self.host_mem else self.device)
+        if self.host_mem:
+            return torch.from_numpy(_np.ctypeslib.as_array(_C.cast(ptr, _C.POINTER(_C.c_uint8)), (int(nbytes),)))
+        return torch.as_tensor(_DevPtr(int(ptr), int(nbytes)), device=self.device)
+
+    @staticmethod
+    def _widen(t, *counts):
+        """View byte tensors / byte counts in the widest element type that divides them all (fewer, larger elements)."""
+        for dt, w in ((torch.int64, 8), (torch.int32, 4)):
+            if all(c % w == 0 for cs in counts for c in cs) and all(x.numel() % w == 0 and x.data_ptr() % w == 0 for x in t):
+                return [x.view(dt) for x in t], [[c // w for c in cs] for cs in counts]
+        return list(t), [list(cs) for cs in counts]
+
+    def _guard(self, fn):
+        try:
+            fn()
+            return 0
+        except Exception as e:                      # surfaces as CL_E_HIP from the library call; the caller re-raises self.err
+            self.err = e
+            return _N.CL_E_HIP
+
+    # -- callbacks ----------------------------------------------------------------------------------------------------
+    def _gather_host(self, user, vals, n, out):
+        def run():
+            mine = torch.from_numpy(_np.ctypeslib.as_array(vals, (int(n),)).view(_np.int64).copy())
+            dev = "cpu" if (self.host_mem or _host_staged()) else self.device
+            parts = [torch.empty(int(n), dtype=torch.int64, device=dev) for _ in range(self.world)]
+            dist.all_gather(parts, mine.to(dev))
+            res = torch.cat(parts).cpu().numpy().view(_np.uint64)
+            _np.ctypeslib.as_array(out, (int(n) * self.world,))[:] = res
+        return self._guard(run)
+
+    def _all_to_all_v(self, user, d_send, h_send, d_recv, h_recv):
+        def run():
+            sb = [int(h_send[i]) for i in range(self.world)]
+            rb = [int(h_recv[i]) for i in range(self.world)]
+            send, recv = self._view(d_send, sum(sb)), self._view(d_recv, sum(rb))
+            (send, recv), (sc, rc) = self._widen([send, recv], sb, rb)
+            if self.host_mem or not _host_staged():
+                dist.all_to_all_single(recv, send, rc, sc)
+            else:
+                tmp = torch.empty(recv.shape, dtype=recv.dtype)
+                dist.all_to_all_single(tmp, send.cpu(), rc, sc)
+                recv.copy_(tmp)
+            if not self.host_mem:
+                torch.cuda.synchronize()
+            self.bytes_moved += sum(rb) - rb[self.rank]
+        return self._guard(run)
+
+    def _all_gather_v(self, user, d_send, send_bytes, d_recv, h_recv):
+        def run():
+            rb = [int(h_recv[i]) for i in range(self.world)]
+            assert int(send_bytes) == rb[self.rank], "all_gather_v: send size differs from the announced size"
+            recv = self._view(d_recv, sum(rb))
+            off = 0
+            staged = (not self.host_mem) and _host_staged()
+            for r in range(self.world):                          # one broadcast per source rank, straight into its slice
+                sl = recv[off:off + rb[r]]
+                if rb[r]:
+                    if r == self.rank:
+                        sl.copy_(self._view(d_send, rb[r]))
+                    (v,), _ = self._widen([sl])
+                    if staged:
+                        h = v.cpu()
+                        dist.broadcast(h, src=r)
+                        if r != self.rank:
+                            v.copy_(h)
+                    else:
+                        dist.broadcast(v, src=r)
+                off += rb[r]
+            if not self.host_mem:
+                torch.cuda.synchronize()
+            self.bytes_moved += sum(rb) - rb[self.rank]
+        return self._guard(run)
+
+
+def gather_to_root(t: torch.Tensor, root: int = 0):
+    """Variable-length gather of byte tensors to `root` (compressed parts go to the rank that writes the archive).
+    Point-to-point sends (nccl: RCCL send/recv over xGMI); returns the list of per-rank tensors on root, None elsewhere."""
+    w, r = world(), rank()
+    if w == 1:
+        return [t]
+    staged = _host_staged()
+    n = torch.tensor([t.numel()], dtype=torch.int64, device="cpu" if staged else t.device)
+    sizes = [torch.zeros_like(n) for _ in range(w)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    if r == root:
+        out = []
+        for src in range(w):
+            if src == root:
+                out.append(t)
+                continue
+            buf = torch.empty(sizes[src], dtype=t.dtype, device="cpu" if staged else t.device)
+            if sizes[src]:
+                dist.recv(buf, src=src)
+            out.append(buf.to(t.device))
+        return out
+    if t.numel():
+        dist.send(t.cpu() if staged else t, dst=root)
+    return None

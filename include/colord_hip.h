@@ -92,7 +92,8 @@ typedef struct {
 	uint64_t total_count_filtered; /* CKmerFilter::GetTotalKmers() */
 } cl_kmer_stats;
 /* d_kmers (n survivors of cl_kmer_scan, possibly from several arenas) is sorted in place; distinct
- * k-mers with multiplicity >= ci are kept with counter min(count, cs).  Builds the membership table. */
+ * k-mers with multiplicity >= ci are kept with counter min(count, cs).  Builds the membership table.
+ * Any n: above 2^30 k-mers the input is counted key range by key range (d_kmers is then left unsorted). */
 cl_status cl_kmer_count_filter(cl_ctx* ctx, uint64_t* d_kmers, uint64_t n, uint32_t k, uint32_t ci, uint32_t cs,
                                cl_kmer_set** out, cl_kmer_stats* stats);
 /* Set object from keys that are already counted/filtered (ascending, distinct) — used to replicate the
@@ -148,6 +149,10 @@ const uint32_t* cl_index_ref_rank(const cl_index* ix);   /* device, n_reads+1: #
  * d_n: n_reads. */
 cl_status cl_candidates(cl_ctx* ctx, const cl_index* ix, const cl_kmer_lists* lists, uint32_t max_candidates,
                         uint32_t* d_refs, uint32_t* d_votes, uint32_t* d_n);
+/* The same query for one CHUNK of reads against an index built over the reference reads of the WHOLE input
+ * (cl_index_build_pairs with n_reads = 0): d_bounds[i] = number of reference reads that precede read i in file order. */
+cl_status cl_candidates_at(cl_ctx* ctx, const cl_index* ix, const cl_kmer_lists* lists, const uint32_t* d_bounds, uint32_t max_candidates,
+                           uint32_t* d_refs, uint32_t* d_votes, uint32_t* d_n);
 /* HiFi variant (processReadsPackHiFi): additionally, per chosen candidate, the shared k-mers in read
  * order.  d_common_off: n_reads*max_candidates+1 offsets into d_common (capacity cap k-mers);
  * *n_common = needed size. */
@@ -293,6 +298,53 @@ cl_status cl_compress_shard(cl_ctx* ctx, const cl_compress_params* params, const
                             cl_dna_coder* dna, cl_qual_coder* qual,
                             uint8_t* d_dna_out, uint64_t dna_cap, uint64_t* h_dna_part_sizes,
                             uint8_t* d_qual_out, uint64_t qual_cap, uint64_t* h_qual_part_sizes, cl_compress_info* info);
+
+/* ---- runCompression over an input of any size, chunk by chunk, on one GPU or on one GPU per rank --------------------
+ * The reference streams the file twice: pass 1 counts the k-mers of the whole input (compression.cpp:432), pass 2 pushes
+ * reader packs through graph -> encoder -> coders (compression.cpp:547-561, in_reads.cpp:62-77) while the similarity
+ * graph grows (reads_sim_graph.cpp:324-427).  cl_compressor holds that state between calls.  A chunk is an arena of whole
+ * reader packs (any size the GPU holds, e.g. 1 Gbase); the caller presents the same chunks, in file order, three times:
+ *     cl_compressor_count_add (each chunk) -> cl_compressor_count_finish
+ *     cl_compressor_refs_add  (each chunk) -> cl_compressor_refs_finish
+ *     cl_compressor_encode    (each chunk)
+ * The `dna` / `qual` parts are byte-identical to one cl_compress_shard call over the whole input.
+ *
+ * cl_exchange: with reads sharded over GPUs (one process per GPU, rank r holds the r-th contiguous range of the file)
+ * the two *_finish steps exchange what SURVEY.md section 8e lists: k-mers go to the rank owning their key range and the
+ * kept keys are all-gathered (replicated set); reference reads and index entries are all-gathered (replicated store and
+ * index).  The caller supplies the collectives (colord_amd/parallel.py: torch.distributed, "nccl" = RCCL over xGMI);
+ * every rank must call the compressor functions in the same order.  Each rank is its own model domain of the coders. */
+typedef struct cl_compressor cl_compressor;
+typedef struct {
+	void* user;
+	uint32_t rank, world;
+	/* host: every rank contributes n uint64; h_out[world * n] receives them in rank order */
+	cl_status (*all_gather_host)(void* user, const uint64_t* h_vals, uint32_t n, uint64_t* h_out);
+	/* device: d_send holds the bytes for rank 0, 1, ... back to back (h_send_bytes[world]); d_recv receives the bytes
+	 * from rank 0, 1, ... back to back (h_recv_bytes[world]) */
+	cl_status (*all_to_all_v)(void* user, const void* d_send, const uint64_t* h_send_bytes, void* d_recv, const uint64_t* h_recv_bytes);
+	/* device: d_recv = the send buffers of rank 0, 1, ... back to back; h_recv_bytes[world] (send_bytes == h_recv_bytes[rank]) */
+	cl_status (*all_gather_v)(void* user, const void* d_send, uint64_t send_bytes, void* d_recv, const uint64_t* h_recv_bytes);
+} cl_exchange;
+/* qual_ctx: second context of the same GPU for the quality stream (coded concurrently at level 1), or NULL.  qparams NULL =
+ * no quality stream.  exchange NULL = single GPU.  expected_bases: size hint for the k-mer buffer of pass 1 (0 = unknown). */
+cl_status cl_compressor_create(cl_ctx* ctx, cl_ctx* qual_ctx, const cl_compress_params* params, const cl_qual_params* qparams,
+                               const cl_exchange* exchange, uint64_t expected_bases, cl_compressor** out);
+void cl_compressor_free(cl_compressor* c);
+cl_status cl_compressor_count_add(cl_compressor* c, const cl_reads* chunk);
+/* stats (optional): the statistics over the whole input (all ranks) */
+cl_status cl_compressor_count_finish(cl_compressor* c, cl_kmer_stats* stats);
+cl_status cl_compressor_refs_add(cl_compressor* c, const cl_reads* chunk);
+cl_status cl_compressor_refs_finish(cl_compressor* c);
+/* arguments as for cl_compress_shard, bounds relative to the chunk */
+cl_status cl_compressor_encode(cl_compressor* c, const cl_reads* chunk, const uint8_t* d_quals, const uint64_t* d_base_off,
+                               const uint32_t* h_part_bounds, uint32_t n_parts, const uint32_t* h_pack_bounds, uint32_t n_packs,
+                               uint8_t* d_dna_out, uint64_t dna_cap, uint64_t* h_dna_part_sizes,
+                               uint8_t* d_qual_out, uint64_t qual_cap, uint64_t* h_qual_part_sizes, cl_compress_info* info);
+/* what the archive's `meta` stream needs (compression.cpp:704-779), valid after count_finish (n_refs_total after refs_finish):
+ * first_read = global index of this rank's first read (start of its model domain) */
+cl_status cl_compressor_info(const cl_compressor* c, cl_kmer_stats* stats, uint64_t* first_read, uint64_t* n_reads_total, uint64_t* mean_read_len,
+                             uint32_t* sparse_range, uint32_t* n_refs_total);
 
 /* ---- a7: CReferenceReads (reference_reads.h:27-259) ---------------------------------------------- */
 /* Byte image of one stored reference read (4 bases/byte MSB first + trailing count byte) produced from
