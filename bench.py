@@ -1,13 +1,20 @@
 #!/usr/bin/env python3
-"""bench.py — throughput of the MI355X-native CoLoRd compress data path on synthetic ONT reads.
+"""bench.py — throughput of the MI355X-native CoLoRd compress data path on the configuration BASELINE.json's metric is
+quoted on: a synthetic ONT set of 50 Gbases (N50 ~ 20 kb, 4-avg qualities, 3 Gb genome), on 1, 2, 4 or 8 MI355X.
 
-One "step" = one pass of the whole hot path over one per-GPU shard of synthetic ONT reads that is already
-resident in HBM as a packed read arena (+ raw quality bytes):
-    a1 canonical k-mer scan + murmur-modulo filter -> a2 exact count/threshold -> a3 membership table
-    -> a4 accepted k-mers per read -> a6 acceptor -> a5 index + candidates -> a7 reference-read arena
-    -> a8 m-mer anchors -> a10/a11 gap alignment, cost decisions, recursion -> a12 tuple streams
-    -> a14/a16 DNA stream range coder;   a13/a15 quality stream range coder (4-avg, level 1)
-Not in the step (rows "f / next" of DESIGN.md): FASTQ parsing, the header (ID) stream, the archive container.
+One "step" = one pass of the WHOLE hot path over the whole input, which is already resident in HBM as 2-bit read arenas
+plus raw quality bytes (cut in chunks of ~1 Gbase, the unit the streaming compressor works on, csrc/stream.hip):
+    pass 1   a1 canonical k-mer scan + murmur-modulo filter of every chunk -> a2 exact counts by key range -> a3 set
+    pass 2a  a4 accepted k-mers, a6 acceptor, a7 reference-read store, a5 k-mer -> reference-reads index over the whole input
+    pass 2b  per chunk: a5 candidates, a8 m-mer anchors, a10/a11 gap alignment + cost decisions + recursion, a12 tuples,
+             a14/a16 `dna` stream parts, a13/a15 `qual` stream parts (4-avg, level 1) with coders that persist across chunks
+With N > 1 the reads are sharded in file order (total work fixed: "scaling": "strong"), the k-mer set, the reference reads and
+the index are replicated through the two exchanges of SURVEY.md §8e (RCCL via torch.distributed), and the compressed parts
+are gathered to rank 0 inside the step.  Not in the step: FASTQ parsing, the header (ID) stream, the archive container.
+
+Also in the JSON line: `archive_vs_ref` — on a bounded sample of the same recipe, written as FASTQ by the host form of the
+generator (bit-identical to the device form), the archive of `colord_amd/colord_hip` (same library, reference part cut)
+divided by the archive of the unmodified reference (`oracle/_ref/colord`), which is also the timed `cpu_baseline`.
 
 Contract: python bench.py --gpus N --steps K --warmup W   (N>1 via torch.distributed.run, one rank/GPU).
 Rank 0 prints ONE JSON line.
@@ -30,31 +37,41 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
+README_DERIVED_GBASES_S = 0.030   # the only published figure (README time/size of the `memory` preset, hardware not stated)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--bases", type=float, default=2.0e9, help="synthetic bases per GPU (weak scaling)")
-    ap.add_argument("--coverage", type=float, default=16.7, help="genome = total bases / coverage (50 Gbases over 3 Gb)")
-    ap.add_argument("--k", type=int, default=25)           # compression.cpp:84-88 for a 50 Gbase input
-    ap.add_argument("--cpu-sample-bases", type=float, default=1.5e8)
+    ap.add_argument("--bases", type=float, default=5.0e10, help="synthetic bases of the WHOLE input (all GPUs together; BASELINE.json: 50 Gbases)")
+    ap.add_argument("--coverage", type=float, default=16.7, help="genome = bases / coverage (50 Gbases over 3 Gb)")
+    ap.add_argument("--chunk-bases", type=float, default=1.0e9, help="bases per chunk of the streaming compressor")
+    ap.add_argument("--k", type=int, default=0, help="k-mer length; 0 = the reference's choice for this input size (compression.cpp:62-93)")
+    ap.add_argument("--a", type=int, default=0, help="anchor length; 0 = the reference's choice")
+    ap.add_argument("--cpu-sample-bases", type=float, default=3.0e8)
     ap.add_argument("--pack-symbols", type=int, default=1 << 16,
                     help="part (= range-coder restart) size in symbols.  4194304 reproduces the reference's packs (defs.h:45) and its exact "
                          "bytes; smaller parts are equally valid archives (the reference decoder follows the part table), cost 8 flush "
                          "bytes each (+0.04 %% at 64 Ki) and expose the parallelism the per-part dependent chain needs")
+    ap.add_argument("--budget-s", type=float, default=1800.0,
+                    help="if (steps + warmup) passes over --bases would exceed this at ~1 Gbases/s/GPU, the input is reduced to fit (and named so)")
     ap.add_argument("--no-qual", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
 
 # ONT default ("memory") preset: arg_parse.cpp:89-408 / SURVEY App. B
-PRESET = dict(f=12, ci=4, cs=80, c=5, g=1.0, exponent=1.0, a=22, min_part_alt=64, max_rec=3)   # a: compression.cpp:84-88 with k=25
+PRESET = dict(f=12, ci=4, cs=80, c=5, g=1.0, exponent=1.0, min_part_alt=64, max_rec=3)
 
 
-QUAL_CTX = None       # second context of the same GPU for the quality stream (single-GPU runs)
+def kmer_anchor_len(bases: float):
+    """adjustKmerAndAnchorLen (compression.cpp:62-93) on the number of bases."""
+    for lim, k, a in ((1e9, 20, 16), (4e9, 21, 18), (16e9, 23, 21), (48e9, 24, 22), (128e9, 25, 22)):
+        if bases < lim:
+            return k, a
+    return 26, 23
 
 
 class StepTimes:
@@ -86,139 +103,168 @@ def reference_part_bounds(lengths: np.ndarray, pack_symbols: int) -> np.ndarray:
     return np.asarray(bounds, dtype=np.uint32)
 
 
-def hot_path_step(ctx, reads, k, quals=None, qual_off=None, part_bounds=None, est_bounds=None):
-    """One pass of the stages built so far (single- or multi-GPU).  Returns sizes for reporting."""
-    from colord_amd import parallel as par
+def params_for(k: int, a: int) -> dict:
     p = PRESET
-    w, rank = par.world(), par.rank()
-    if w == 1 and quals is not None and not os.environ.get("BENCH_STAGE_TIMES") and not os.environ.get("BENCH_PY_STAGES"):   # BENCH_PY_STAGES: the stage-by-stage path of the multi-GPU runs, on one GPU
-        # single GPU: the whole path is one native call (cl_compress_shard, the C++ wiring of the stages)
-        prm = dict(k=k, f=p["f"], ci=p["ci"], cs=p["cs"], c=p["c"], anchor_len=p["a"], min_part_alt=p["min_part_alt"], max_rec=p["max_rec"], min_anchors=1,
-                   level=1, source=0, sparse=1, sparse_g=p["g"], sparse_exponent=p["exponent"], cost_mult=1.0, frac_always=0.9, frac_min=0.5, max_matches_mult=10.0)
-        qc = (QUAL_CTX or ctx).qual_coder(2, 0, 1, (7, 14, 26), ())   # on a second context: coded concurrently with the DNA path
-        dc = ctx.dna_coder(p["c"], 1, 0)
-        dna, dsz, qual, qsz, inf = ctx.compress_shard(reads, prm, part_bounds, est_bounds, dc, qc, quals, qual_off)
-        qc.free(); dc.free()
-        return dict(tot_kmers=inf["tot_kmers"], kept=inf["n_kept_kmers"], refs=inf["n_refs"], anchors=inf["n_anchors"], tuple_bytes=inf["tuple_bytes"],
-                    dna_bytes=inf["dna_bytes"], qual_bytes=inf["qual_bytes"], qual_parts=len(qsz), sparse_range=inf["sparse_range"])
-    stage_t = {} if os.environ.get("BENCH_STAGE_TIMES") else None
-    t_last = [time.perf_counter()]
+    return dict(k=k, f=p["f"], ci=p["ci"], cs=p["cs"], c=p["c"], anchor_len=a, min_part_alt=p["min_part_alt"], max_rec=p["max_rec"], min_anchors=1,
+                level=1, source=0, sparse=1, sparse_g=p["g"], sparse_exponent=p["exponent"], cost_mult=1.0, frac_always=0.9, frac_min=0.5, max_matches_mult=10.0)
 
-    def lap(name):                                         # wall time per stage (diagnostic; adds syncs)
-        if stage_t is not None:
-            torch.cuda.synchronize()
-            now = time.perf_counter()
-            stage_t[name] = stage_t.get(name, 0.0) + (now - t_last[0]) * 1e3
-            t_last[0] = now
-    qjob = None
-    if quals is not None and QUAL_CTX is not None and stage_t is None:
-        # the quality stream of level 1 needs nothing of the DNA path: a second context of the same GPU codes it on a
-        # host thread meanwhile (the native call releases the GIL), as cl_compress_shard does on one GPU
-        import threading
-        qres = {}
 
-        def qrun():
-            try:
-                qc_ = QUAL_CTX.qual_coder(2, 0, 1, (7, 14, 26), ())
-                qres["out"] = qc_.encode(reads, quals, qual_off, part_bounds)
-                qc_.free()
-            except Exception as e:          # surfaced after the join
-                qres["err"] = e
-        qjob = threading.Thread(target=qrun)
-        qjob.start()
-    km = ctx.kmer_scan(reads, k, p["f"])
-    n_surv = km.numel()
-    km = par.exchange_kmers(km)                            # exchange 1a: k-mers to the owner of their key
-    kset, st = ctx.count_filter(km, k, p["ci"], p["cs"])
-    tot_kmers, n_unique, n_reads_total = par.all_reduce_sum_ints(st.tot_kmers, st.n_unique_counted, reads.n_reads)
-    if w > 1:                                              # exchange 1b: replicate the filtered set
-        allk = torch.cat(par.all_gather_v(kset.keys()))
-        allc = torch.cat(par.all_gather_v(kset.counts()))
-        kset.free()
-        kset = ctx.kmer_set_from_keys(allk, allc, k)
-    lists = ctx.accepted_kmers(kset, reads, k, p["f"])
-    # host scalars exactly as compression.cpp:443,501 derives them
-    mean_read_len = int(float(tot_kmers * p["f"]) / n_reads_total + k - 1)
-    sparse_range = max(1, int((p["g"] * n_unique * p["f"]) / mean_read_len))
-    first_read, _ = par.exclusive_prefix(reads.n_reads, ctx.device)
-    acc_all = ctx.ref_accept(n_reads_total, 0, sparse_range, p["exponent"])    # same stream on every rank
-    acc = acc_all[first_read:first_read + reads.n_reads]
-    accept = torch.from_numpy(acc.copy()).to(ctx.device) & (reads.has_n() == 0).to(torch.uint8)
-    ref_base, n_refs_total = par.exclusive_prefix(int(accept.sum().item()), ctx.device)
-    ids, refs, bounds, _ = ctx.index_entries(lists, accept, ref_base)
-    if w > 1:                                              # exchange 2: replicate the k-mer -> reference reads index
-        ids = torch.cat(par.all_gather_v(ids))
-        refs = torch.cat(par.all_gather_v(refs))
-    index = ctx.index_build_pairs(kset, ids, refs, bounds, n_refs_total, 0, p["cs"])
-    crefs, votes, cnt = ctx.candidates(index, lists, p["c"])
-    lap("a1-a7 k-mers, index, candidates")
-    out = dict(survivors=n_surv, tot_kmers=tot_kmers, kept=kset.size, accepted=lists.total, refs=n_refs_total,
-               index_entries=index.entries, with_candidates=int((cnt > 0).sum().item()))
-    if quals is not None:
-        # a13+a15: quality stream, ONT default 4-avg at level 1 (contexts do not need the edit script at level 1).
-        # One model domain per GPU (the adaptive models live for the whole shard), parts cut like the reference's packs.
-        if qjob is None:
-            qc = ctx.qual_coder(2, 0, 1, (7, 14, 26), ())
-            payload, sizes = qc.encode(reads, quals, qual_off, part_bounds)
-            qc.free()
-            lap("a13+a15 quality stream")
-            out.update(qual_bytes=int(payload.numel()), qual_parts=len(sizes))
-        # a8 + a10-a12 + a14: DNA stream.  Reference reads = the accepted reads of all ranks (CReferenceReads is one
-        # process-wide store in the reference; each rank replicates it), anchors against the candidates, edit scripts,
-        # tuple streams, DNA coder at level 1.  The estimator packs are the reference's reader packs (4 Mi symbols,
-        # defs.h:45); the coder parts are the same as the quality stream's (the decoder requires that, entr_qual.h:150-170).
-        my_refs = ctx.select_reads(reads, accept)
-        if w > 1:                                          # exchange 3: replicate the reference reads
-            pk = torch.cat(par.all_gather_v(my_refs.packed()[:my_refs.total_words]))
-            iv = torch.cat(par.all_gather_v(my_refs.invalid()[:my_refs.total_words]))
-            ln = torch.cat(par.all_gather_v(my_refs.lengths()))
-            my_refs.free()
-            my_refs = ctx.reads_from_arena(pk, iv, ln)
-        lap("reference reads")
-        anc = ctx.anchor_candidates(reads, my_refs, crefs, cnt, p["a"])
-        lap("a8 anchors")
-        es, es_off, es_nt = ctx.encode_reads(reads, my_refs, anc, p["a"], p["min_part_alt"], p["max_rec"], 1.0, est_bounds)
-        lap("a10-a12 encoder")
-        n_plain = int((es[es_off[:-1]] >> 4 != 10).sum().item())
-        dc = ctx.dna_coder(p["c"], 1, 0)
-        dpayload, dsizes = dc.encode(my_refs, es, es_off, es_nt, part_bounds)
-        dc.free()
-        lap("a14 DNA stream")
-        out.update(dna_bytes=int(dpayload.numel()), tuple_bytes=int(es.numel()), reads_stored_plain=n_plain, anchors=int(anc.total))
-        anc.free(); my_refs.free()
-        if qjob is not None:
-            qjob.join()
-            if "err" in qres:
-                raise qres["err"]
-            payload, sizes = qres["out"]
-            out.update(qual_bytes=int(payload.numel()), qual_parts=len(sizes))
-    index.free(); lists.free(); kset.free()
-    if stage_t is not None:
-        print("stage wall ms:", {k_: round(v, 1) for k_, v in stage_t.items()}, file=sys.stderr)
+class Shard:
+    """This rank's reads, resident in HBM as chunks of whole reader packs: (arena, part bounds, pack bounds, quals, base offsets)."""
+
+    def __init__(self, ctx, table, r0: int, r1: int, chunk_bases: float, pack_symbols: int, with_quals: bool):
+        from colord_amd import ontsim
+        self.chunks, self.n_reads, self.n_bases = [], r1 - r0, 0
+        # lengths of all reads first (cheap): the reader packs are cut over the rank's whole read sequence (in_reads.cpp:62-77)
+        lens = []
+        sub = [r0 + x for x in _sub_cuts(table, r0, r1, 4e9)]
+        for a, b in zip(sub[:-1], sub[1:]):
+            lens.append(_device_lengths(table, ctx.device, a, b))
+        lens = np.concatenate(lens) if lens else np.zeros(0, np.uint32)
+        packs = reference_part_bounds(lens, 1 << 22)
+        acc = np.concatenate([[0], np.cumsum(lens.astype(np.int64))])
+        cuts, target = [0], chunk_bases
+        for p in range(1, len(packs)):
+            if acc[packs[p]] >= target or p == len(packs) - 1:
+                cuts.append(p)
+                target = acc[packs[p]] + chunk_bases
+        for ca, cb in zip(cuts[:-1], cuts[1:]):
+            a, b = int(packs[ca]), int(packs[cb])
+            codes, off, quals = ontsim.device_reads(table, ctx.device, r0 + a, r0 + b, with_quals=with_quals)
+            assert np.array_equal((off[1:] - off[:-1]).cpu().numpy().astype(np.uint32), lens[a:b])
+            arena = ctx.pack_reads(codes, off)
+            del codes
+            est = (packs[ca:cb + 1] - packs[ca]).astype(np.uint32)
+            parts = est if pack_symbols == (1 << 22) else reference_part_bounds(lens[a:b], pack_symbols)
+            self.chunks.append((arena, parts, est, quals, off))
+            self.n_bases += int(arena.total_bases)
+        self.n_parts = sum(len(c[1]) - 1 for c in self.chunks)
+
+    def free(self):
+        for c in self.chunks:
+            c[0].free()
+
+
+def _sub_cuts(table, r0, r1, bases):
+    acc = np.cumsum(table.len_src[r0:r1].astype(np.int64))
+    out, base = [0], 0
+    while out[-1] < r1 - r0:
+        i = min(max(int(np.searchsorted(acc, base + bases, side="left")) + 1, out[-1] + 1), r1 - r0)
+        out.append(i)
+        base = int(acc[i - 1])
     return out
 
 
-def cpu_baseline(sample_bases: float, k_hint: int):
-    """The UNMODIFIED reference binary (oracle/_ref/colord, built by oracle/Makefile.ref) timed on this
-    host's cores on a bounded sample of the same synthetic recipe.  It runs the WHOLE compressor."""
-    from colord_amd.synth import make_reads
-    from colord_amd.fastq import write_fastq
+def _device_lengths(table, device, r0, r1):
+    from colord_amd import ontsim
+    L = ontsim._lib()
+    n = r1 - r0
+    d_start = torch.from_numpy(table.start[r0:r1].view(np.int64)).to(device)
+    d_len = torch.from_numpy(table.len_src[r0:r1].view(np.int32)).to(device)
+    d_strand = torch.from_numpy(table.strand[r0:r1]).to(device)
+    out = torch.empty(n, dtype=torch.int32, device=device)
+    if L.os_dev_lengths(table.seed, table.gseed, d_start.data_ptr(), d_len.data_ptr(), d_strand.data_ptr(), r0, n, out.data_ptr(), torch.cuda.current_stream(device).cuda_stream):
+        raise RuntimeError("os_dev_lengths failed")
+    return out.cpu().numpy().view(np.uint32)
+
+
+def hot_path_step(ctx, qctx, shard: Shard, prm: dict, with_qual: bool, exchange, dna_out, qual_out, expected_bases: int):
+    """One pass of the whole compress data path over the shard (all chunks).  Returns sizes for reporting."""
+    from colord_amd import parallel as par
+    qa = (2, 0, 1, (7, 14, 26), ()) if with_qual else None       # ONT default: 4-avg at level 1 (arg_parse.cpp:410-450)
+    cmp_ = ctx.compressor(prm, qa, qctx, exchange, expected_bases=expected_bases)
+    try:
+        for ch in shard.chunks:
+            cmp_.count_add(ch[0])
+        st = cmp_.count_finish()
+        for ch in shard.chunks:
+            cmp_.refs_add(ch[0])
+        cmp_.refs_finish()
+        do, qo = 0, 0
+        tot = dict(n_anchors=0, tuple_bytes=0, dna_bytes=0, qual_bytes=0)
+        for arena, parts, est, quals, off in shard.chunks:
+            _, _, _, _, inf = cmp_.encode(arena, parts, est, quals, off, dna_out[do:], qual_out[qo:] if with_qual else None)
+            do += inf["dna_bytes"]; qo += inf["qual_bytes"]
+            for k_ in tot:
+                tot[k_] += inf[k_]
+        info = cmp_.info()
+    except Exception:
+        if exchange is not None and exchange.err is not None:
+            raise exchange.err
+        raise
+    finally:
+        cmp_.free()
+    if par.world() > 1:
+        # SURVEY §8e "collective for results": the parts of every rank go to the rank that writes the archive
+        par.gather_to_root(dna_out[:do])
+        if with_qual:
+            par.gather_to_root(qual_out[:qo])
+    return dict(tot_kmers=int(st.tot_kmers), kept=int(st.n_unique_counted), refs=info["n_refs_total"], sparse_range=info["sparse_range"],
+                anchors=tot["n_anchors"], tuple_bytes=tot["tuple_bytes"], dna_bytes=tot["dna_bytes"], qual_bytes=tot["qual_bytes"], parts=shard.n_parts, chunks=len(shard.chunks))
+
+
+def cpu_baseline_and_size_check(ctx, qctx, sample_bases: float, coverage: float, pack_symbols: int):
+    """The UNMODIFIED reference binary (oracle/_ref/colord, built by oracle/Makefile.ref) timed on this host's cores on a
+    bounded sample of the same synthetic recipe, and — on the very same FASTQ — the archive of colord_hip (this library)
+    against the reference's archive: the second half of the metric."""
+    from colord_amd import ontsim, archive as AR
     ref = os.path.join(ROOT, "oracle", "_ref", "colord")
+    ours = os.path.join(ROOT, "colord_amd", "colord_hip")
     if not os.path.exists(ref):
-        return None
+        return None, None
     cores = os.cpu_count() or 1
-    rs = make_reads(seed=101, genome_len=int(sample_bases / 16.7), target_bases=int(sample_bases))
+    table = ontsim.ReadTable(seed=101, genome_len=max(1_000_000, int(sample_bases / coverage)), target_bases=int(sample_bases))
     with tempfile.TemporaryDirectory() as tmp:
         fq = os.path.join(tmp, "sample.fastq")
-        write_fastq(fq, rs)
+        n_bases = ontsim.write_fastq(table, fq)
         t0 = time.time()
-        subprocess.check_call([ref, "compress-ont", "-t", str(cores), fq, os.path.join(tmp, "o.colord")],
-                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        subprocess.check_call([ref, "compress-ont", "-t", str(cores), fq, os.path.join(tmp, "ref.colord")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         dt = time.time() - t0
-        size = os.path.getsize(os.path.join(tmp, "o.colord"))
-    return {"value": len(rs.bases) / dt / 1e9, "unit": "Gbases/s", "cores": cores, "kind": "reference",
-            "sample": f"oracle/_ref/colord compress-ont -t {cores} on {len(rs.bases)} synthetic ONT bases ({rs.n_reads} reads), "
-                      f"whole compressor (parsing, header stream and archive included); {dt:.2f} s wall, archive {size} B = {size / len(rs.bases):.4f} B/base"}
+        ref_size = os.path.getsize(os.path.join(tmp, "ref.colord"))
+        ref_arc = AR.read_archive(os.path.join(tmp, "ref.colord"))
+        ref_streams = {n: sum(len(p) for _, p in s.parts) for n, s in ref_arc.items()}
+        cb = {"value": n_bases / dt / 1e9, "unit": "Gbases/s", "cores": cores, "kind": "reference",
+              "sample": f"oracle/_ref/colord compress-ont -t {cores} on {n_bases} synthetic ONT bases ({table.n_reads} reads, same recipe, genome {table.genome_len} bp), "
+                        f"whole compressor (parsing, header stream and archive included); {dt:.2f} s wall, archive {ref_size} B = {ref_size / n_bases:.4f} B/base"}
+        size = {"sample_bases": n_bases, "ref_archive_bytes": ref_size, "ref_dna_bytes": ref_streams.get("dna"), "ref_qual_bytes": ref_streams.get("qual")}
+        # (1) the command-line compressor of this build on the same file: whole archive, reference part cut
+        if os.path.exists(ours):
+            t0 = time.time()
+            r = subprocess.run([ours, "compress-ont", fq, os.path.join(tmp, "hip.colord")], capture_output=True, text=True)
+            if r.returncode == 0:
+                hs = os.path.getsize(os.path.join(tmp, "hip.colord"))
+                arc = AR.read_archive(os.path.join(tmp, "hip.colord"))
+                same = all([p for _, p in arc[n].parts] == [p for _, p in ref_arc[n].parts] for n in ("dna", "qual", "header", "meta"))
+                size.update({"hip_archive_bytes": hs, "archive_vs_ref": hs / ref_size, "cli_wall_s": round(time.time() - t0, 2),
+                             "streams_byte_identical_to_ref": bool(same)})
+            else:
+                size["cli_error"] = (r.stderr or r.stdout)[-300:]
+        # (2) the bench path itself (device generator, chunked compressor) on the same reads, with the bench's part cut and with the reference's
+        k, a = kmer_anchor_len(0.49 * os.path.getsize(fq))
+        for cut, name in ((1 << 22, "ref_cut"), (pack_symbols, f"cut_{pack_symbols}")):
+            shard = Shard(ctx, table, 0, table.n_reads, 1e9, cut, True)
+            dna_out = torch.empty(int(shard.n_bases * 0.5) + (1 << 20), dtype=torch.uint8, device=ctx.device)
+            qual_out = torch.empty(int(shard.n_bases * 0.6) + (1 << 20), dtype=torch.uint8, device=ctx.device)
+            inf = hot_path_step(ctx, qctx, shard, params_for(k, a), True, None, dna_out, qual_out, shard.n_bases)
+            size[f"streams_vs_ref_{name}"] = (inf["dna_bytes"] + inf["qual_bytes"]) / (ref_streams["dna"] + ref_streams["qual"])
+            size[f"dna_qual_bytes_{name}"] = [inf["dna_bytes"], inf["qual_bytes"]]
+            shard.free()
+            del dna_out, qual_out
+            if cut == pack_symbols:
+                break
+    return cb, size
+
+
+def load_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (tools/pmc_traffic.py -> profiles/r02_traffic.json)."""
+    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    if not os.path.exists(path):
+        return None, None
+    t = json.load(open(path))
+    e = t.get("kernels", {}).get(kernel)
+    if not e:
+        return None, t.get("source")
+    return e["hbm_bytes_per_launch"], t.get("source")
 
 
 def main():
@@ -241,24 +287,32 @@ def main():
         else:
             dist.init_process_group(backend)
     from colord_amd.device import Context
-    from colord_amd.synth_device import make_reads_device
+    from colord_amd import ontsim, parallel as par
 
     ctx = Context(local, timing=True)
-    global QUAL_CTX
-    QUAL_CTX = Context(local, timing=True) if not os.environ.get("BENCH_NO_OVERLAP") else None
-    bases = int(args.bases)
-    genome_len = max(1_000_000, int(bases * world / args.coverage))
-    # same genome on every rank (seed), different reads per rank
-    codes, offsets, quals = make_reads_device(ctx.device, seed=1234, genome_len=genome_len, target_bases=bases,
-                                              with_quals=True, read_seed=1000 + rank)
-    n_reads_local = offsets.numel() - 1
-    reads = ctx.pack_reads(codes, offsets)
-    local_bases = reads.total_bases
-    del codes
-    qual_off = offsets.contiguous()
-    part_bounds = reference_part_bounds(reads.lengths().cpu().numpy().view(np.uint32), args.pack_symbols)
-    est_bounds = reference_part_bounds(reads.lengths().cpu().numpy().view(np.uint32), 1 << 22)      # reader packs (defs.h:45)
-    qargs = {} if args.no_qual else dict(quals=quals, qual_off=qual_off, part_bounds=part_bounds, est_bounds=est_bounds)
+    qctx = Context(local, timing=True) if not os.environ.get("BENCH_NO_OVERLAP") else None
+    bases = float(args.bases)
+    est_s = (args.steps + args.warmup) * bases / (1.0e9 * world)
+    reduced = False
+    if est_s > args.budget_s:
+        bases = max(1e8, args.budget_s * 1.0e9 * world / (args.steps + args.warmup))
+        reduced = True
+    genome_len = max(1_000_000, int(bases / args.coverage))
+    table = ontsim.ReadTable(seed=1, genome_len=genome_len, target_bases=int(bases))        # the same table on every rank
+    k, a = kmer_anchor_len(bases)
+    k, a = (args.k or k), (args.a or a)
+    # this rank's contiguous range of the file: equal shares of the source bases
+    acc = np.cumsum(table.len_src.astype(np.int64))
+    r0 = int(np.searchsorted(acc, acc[-1] * rank / world, side="left")) if rank else 0
+    r1 = int(np.searchsorted(acc, acc[-1] * (rank + 1) / world, side="left")) if rank + 1 < world else table.n_reads
+    t_gen = time.perf_counter()
+    shard = Shard(ctx, table, r0, r1, args.chunk_bases, args.pack_symbols, not args.no_qual)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t_gen
+    dna_out = torch.empty(int(shard.n_bases * 0.30) + (1 << 20), dtype=torch.uint8, device=ctx.device)
+    qual_out = None if args.no_qual else torch.empty(int(shard.n_bases * 0.36) + (1 << 20), dtype=torch.uint8, device=ctx.device)
+    exchange = par.TorchExchange(ctx.device) if world > 1 else None
+    prm = params_for(k, a)
 
     def sync():
         torch.cuda.synchronize()
@@ -266,64 +320,88 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def step():
+        return hot_path_step(ctx, qctx, shard, prm, not args.no_qual, exchange, dna_out, qual_out, shard.n_bases)
+
     for _ in range(args.warmup):
-        hot_path_step(ctx, reads, args.k, **qargs)
+        step()
     ctx.acc.clear()
-    if QUAL_CTX is not None:
-        QUAL_CTX.acc.clear()
+    if qctx is not None:
+        qctx.acc.clear()
     sync()
     t0 = time.perf_counter()
     info = None
     for _ in range(args.steps):
-        info = hot_path_step(ctx, reads, args.k, **qargs)
+        info = step()
     sync()
     dt = time.perf_counter() - t0
     red_dev = ctx.device if backend == "nccl" else torch.device("cpu")
     tdev = torch.tensor([dt], dtype=torch.float64, device=red_dev)
-    tb = torch.tensor([local_bases], dtype=torch.int64, device=red_dev)
+    tb = torch.tensor([shard.n_bases, info["dna_bytes"], info["qual_bytes"]], dtype=torch.int64, device=red_dev)
     if world > 1:
         dist.all_reduce(tdev, op=dist.ReduceOp.MAX)
         dist.all_reduce(tb)
     dt = float(tdev.item())
-    total_bases = int(tb.item())
+    total_bases, total_dna, total_qual = (int(x) for x in tb.tolist())
 
-    times = StepTimes(ctx, QUAL_CTX)
+    times = StepTimes(ctx, qctx)
     if rank == 0:
-        # dominant kernel by measured HIP-event time on the context stream; `achieved` = the library's algorithmic HBM
+        # dominant kernel by measured HIP-event time on the context streams; `achieved` = the library's algorithmic HBM
         # byte count of those launches (per-kernel formulas in DESIGN.md) / their measured duration
         dom = max(times.ms, key=times.ms.get)
         launches = times.launches[dom]
         avg_ms = times.ms[dom] / launches
+        traffic, traffic_src = load_traffic(dom)
         roof = {"bound": "hbm", "kernel": dom, "avg_ms": avg_ms, "launches_per_step": launches / args.steps,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": traffic, "traffic_source": traffic_src}
         if times.bytes.get(dom, 0) > 0:
             ach = times.bytes[dom] / (times.ms[dom] * 1e-3) / 1e9
             roof.update({"achieved": ach, "frac": ach / HBM_PEAK_GBS, "alg_bytes_per_launch": times.bytes[dom] / launches})
         else:
             roof.update({"achieved": None, "frac": None})
-        roof["kernel_ms_per_step"] = {n: times.ms[n] / args.steps for n in sorted(times.ms, key=times.ms.get, reverse=True)}
-        roof["kernel_achieved_GBps"] = {n: times.bytes[n] / (times.ms[n] * 1e-3) / 1e9 for n in sorted(times.ms, key=times.ms.get, reverse=True)
-                                        if times.bytes.get(n, 0) > 0 and times.ms[n] > 0}
-        cb = None if args.no_cpu_baseline else cpu_baseline(args.cpu_sample_bases, args.k)
+        order = sorted(times.ms, key=times.ms.get, reverse=True)
+        roof["kernel_ms_per_step"] = {n: round(times.ms[n] / args.steps, 3) for n in order[:40]}
+        roof["kernel_achieved_GBps"] = {n: round(times.bytes[n] / (times.ms[n] * 1e-3) / 1e9, 1) for n in order if times.bytes.get(n, 0) > 0 and times.ms[n] > 0}
+        # compulsory floor of the whole path (3.2 B/base) against the step time
+        roof["whole_path_floor_frac"] = 3.2 * total_bases * args.steps / dt / 1e9 / (HBM_PEAK_GBS * world)
+        cb, size = (None, None)
+        if not args.no_cpu_baseline and world == 1:
+            shard.free()                                    # the sample runs (and the command-line compressor) need the memory:
+            del dna_out, qual_out                           # give everything back, pools included, and start from fresh contexts
+            ctx.close()
+            if qctx is not None:
+                qctx.close()
+            torch.cuda.empty_cache()
+            ctx = Context(local)
+            qctx = Context(local) if qctx is not None else None
+            cb, size = cpu_baseline_and_size_check(ctx, qctx, args.cpu_sample_bases, args.coverage, args.pack_symbols)
+        value = total_bases * args.steps / dt / 1e9
         line = {
-            "metric": "input Gbases/s + archive size vs ref, ONT 50 Gb at 1/2/4/8 MI355X", "value": total_bases * args.steps / dt / 1e9,
+            "metric": "input Gbases/s + archive size vs ref, ONT 50 Gb at 1/2/4/8 MI355X", "value": value,
             "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"synthetic ONT, {local_bases} bases/GPU ({n_reads_local} reads, N50~20kb), genome {genome_len} bp, "
-                                   f"k={args.k} f={PRESET['f']} ci={PRESET['ci']} cs={PRESET['cs']} c={PRESET['c']} (ONT default preset)",
-                       "stages": "a1 k-mer scan, a2 count/filter, a3 set build, a4 accepted k-mers, a6 acceptor, a5 index+candidates"
-                                 + ("" if args.no_qual else f", a13+a15 quality stream (4-avg, level 1, parts of {args.pack_symbols} symbols)")
-                                 + ("" if args.no_qual else ", a8 m-mer anchors, a10-a12 gap alignment + cost decisions + tuple streams, a14+a16 DNA stream coder"),
-                       "stream_bytes_per_base": (None if args.no_qual or not info else round((info.get("dna_bytes", 0) + info.get("qual_bytes", 0)) / max(local_bases, 1), 4)),
-                       "parallelism": f"reads sharded x{world}, k-mer set replicated" if world > 1 else "single GPU",
-                       "sizes": info},
-            "roofline": roof, "cpu_baseline": cb,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": value / README_DERIVED_GBASES_S,
+            "vs_baseline_note": "BASELINE.md §1: 0.030 Gbases/s derived from the reference README's time and size for its `memory` preset (human ONT, "
+                                "whole program, hardware not stated) — the only published figure; the measured reference on this host is `cpu_baseline`",
+            "archive_vs_ref": (size or {}).get("archive_vs_ref"),
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"synthetic ONT {total_bases / 1e9:.2f} Gbases ({table.n_reads} reads, N50~20kb, 4-avg quals), genome {genome_len} bp, "
+                                   f"k={k} a={a} f={PRESET['f']} ci={PRESET['ci']} cs={PRESET['cs']} c={PRESET['c']} (compress-ont default preset)"
+                                   + (f"; REDUCED from {args.bases / 1e9:.1f} Gbases to fit --budget-s {args.budget_s:.0f}" if reduced else ""),
+                       "chunks_per_gpu": info["chunks"], "chunk_bases": args.chunk_bases, "part_symbols": args.pack_symbols,
+                       "stages": "pass 1: a1 a2 a3; pass 2a: a4 a6 a7 a5 (index); pass 2b per chunk: a5 (candidates) a8 a10 a11 a12 a14 a16"
+                                 + ("" if args.no_qual else " + a13 a15 (4-avg, level 1)") + ("; parts gathered to rank 0" if world > 1 else ""),
+                       "stream_bytes_per_base": round((total_dna + total_qual) / max(total_bases, 1), 4),
+                       "dna_bytes": total_dna, "qual_bytes": total_qual,
+                       "parallelism": f"reads sharded x{world} in file order, k-mer set + reference reads + index replicated (RCCL), one model domain per GPU" if world > 1 else "single GPU",
+                       "input_generation_s": round(t_gen, 1), "rank0_sizes": info},
+            "roofline": roof, "cpu_baseline": cb, "size_check": size,
         }
         print(json.dumps(line))
-    reads.free()
+    else:
+        shard.free()
     ctx.close()
-    if QUAL_CTX is not None:
-        QUAL_CTX.close()
+    if qctx is not None:
+        qctx.close()
     if world > 1:
         dist.destroy_process_group()
 
