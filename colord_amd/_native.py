@@ -130,6 +130,19 @@ _SIG = {
     "cl_compressor_refs_finish": (C.c_int32, [_P]),
     "cl_compressor_encode": (C.c_int32, [_P, _P, _P, _P, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint64, _P, _P, C.c_uint64, _P, C.POINTER(CompressInfo)]),
     "cl_compressor_info": (C.c_int32, [_P, C.POINTER(KmerStats), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "cl_dna_decoder_create": (C.c_int32, [C.c_uint32, C.c_int32, C.c_uint32, C.c_uint32, C.c_int32, C.c_uint32, C.c_double, C.POINTER(_P)]),
+    "cl_dna_decoder_free": (None, [_P]),
+    "cl_dna_decoder_error": (C.c_char_p, [_P]),
+    "cl_dna_decoder_add_ref": (C.c_int32, [_P, _P, C.c_uint32]),
+    "cl_dna_decoder_new_domain": (C.c_int32, [_P]),
+    "cl_dna_decode_part": (C.c_int32, [_P, _P, C.c_uint64, C.c_uint32, _P, C.c_uint64, _P, C.POINTER(C.c_uint64)]),
+    "cl_qual_decoder_create": (C.c_int32, [C.POINTER(QualParams), C.POINTER(_P)]),
+    "cl_qual_decoder_free": (None, [_P]),
+    "cl_qual_decoder_new_domain": (C.c_int32, [_P]),
+    "cl_qual_decode_part": (C.c_int32, [_P, _P, C.c_uint64, _P, _P, C.c_uint32, _P]),
+    "cl_id_decoder_create": (C.c_int32, [C.c_int32, C.POINTER(_P)]),
+    "cl_id_decoder_free": (None, [_P]),
+    "cl_id_decode_part": (C.c_int32, [_P, _P, C.c_uint64, C.c_uint32, _P, C.c_uint64, _P, _P, C.POINTER(C.c_uint64)]),
     "cl_encode_reads": (C.c_int32, [_P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, _P, C.c_uint32, _P, C.c_uint64, _P, _P, C.POINTER(C.c_uint64)]),
     "cl_dna_coder_create": (C.c_int32, [_P, C.c_uint32, C.c_int32, C.c_uint32, C.POINTER(_P)]),
     "cl_dna_coder_free": (None, [_P]),

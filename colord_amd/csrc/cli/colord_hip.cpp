@@ -8,6 +8,7 @@
 // Limits of this first version: FASTQ with 4-line records (plain or gzip), one GPU, the whole file resident (288 GB of HBM
 // hold ~100 Gbases), no reference genome (-G), quality / header modes = the preset's.
 #include "colord_hip.h"
+#include "archive.hpp"
 #include <hip/hip_runtime_api.h>
 #include <zlib.h>
 #include <algorithm>
@@ -43,42 +44,11 @@ QDef qual_defaults(int mode)
 	default: return { {}, {} };
 	}
 }
-[[noreturn]] void die(const std::string& m) { fprintf(stderr, "colord_hip: %s\n", m.c_str()); exit(1); }
 void hipck(hipError_t e, const char* what) { if (e != hipSuccess) die(std::string(what) + ": " + hipGetErrorString(e)); }
 void ck(cl_ctx* ctx, cl_status s, const char* what) { if (s != CL_OK) die(std::string(what) + ": " + (ctx ? cl_last_error(ctx) : "error")); }
 
 template<class T> void le(std::vector<uint8_t>& v, T x) { for (size_t i = 0; i < sizeof(T); ++i) v.push_back((uint8_t)((uint64_t)x >> (8 * i))); }
 void le_double(std::vector<uint8_t>& v, double d) { uint64_t u; memcpy(&u, &d, 8); le(v, u); }
-
-// archive container (archive.cpp:92-114,170-236,268-283): part = varint(metadata) + payload; footer lists the streams
-struct Archive {
-	struct Part { uint64_t off, size; };
-	struct Stream { std::string name; std::vector<Part> parts; };
-	FILE* f = nullptr; uint64_t off = 0; std::vector<Stream> streams;
-	static void varint(std::vector<uint8_t>& v, uint64_t x) { int n = 0; for (uint64_t t = x; t; t >>= 8) ++n; v.push_back((uint8_t)n); for (int i = n - 1; i >= 0; --i) v.push_back((uint8_t)(x >> (8 * i))); }
-	int reg(const std::string& n) { streams.push_back(Stream{ n, {} }); return (int)streams.size() - 1; }
-	void add(int s, const uint8_t* p, uint64_t n, uint64_t meta)
-	{
-		std::vector<uint8_t> h; varint(h, meta);
-		streams[s].parts.push_back(Part{ off, n });
-		if (fwrite(h.data(), 1, h.size(), f) != h.size() || (n && fwrite(p, 1, n, f) != n)) die("cannot write the archive");
-		off += h.size() + n;
-	}
-	void close()
-	{
-		std::vector<uint8_t> ft; varint(ft, streams.size());
-		for (auto& s : streams)
-		{
-			ft.insert(ft.end(), s.name.begin(), s.name.end()); ft.push_back(0);
-			varint(ft, s.parts.size()); varint(ft, 0);                       // raw size: unused by these streams
-			for (auto& p : s.parts) { varint(ft, p.off); varint(ft, p.size); }
-		}
-		const uint64_t n = ft.size();
-		fwrite(ft.data(), 1, n, f);
-		for (int i = 0; i < 8; ++i) fputc((int)((n >> (8 * i)) & 0xff), f);
-		fclose(f);
-	}
-};
 
 struct Input {
 	std::vector<uint8_t> bases, quals, ids, plus; std::vector<uint64_t> off, id_off;      // off: per-read base offsets
@@ -134,9 +104,19 @@ template<class T> T* to_device(const std::vector<T>& v, size_t extra = 0)
 }
 } // namespace
 
+int run_decompress(int argc, char** argv);      // decompress.cpp
+int run_info(int argc, char** argv);
+
 int main(int argc, char** argv)
 {
-	if (argc < 4) { fprintf(stderr, "usage: colord_hip compress-ont|compress-pbhifi|compress-pbraw [-p ratio|balanced|memory] [--gpu N] input.fastq[.gz] output.colord\n"); return 1; }
+	if (argc >= 2 && std::string(argv[1]) == "decompress") return run_decompress(argc, argv);
+	if (argc >= 2 && std::string(argv[1]) == "info") return run_info(argc, argv);
+	if (argc < 4)
+	{
+		fprintf(stderr, "usage: colord_hip compress-ont|compress-pbhifi|compress-pbraw [-p ratio|balanced|memory] [--gpu N] input.fastq[.gz] output.colord\n"
+		                "       colord_hip decompress archive.colord output.fastq\n       colord_hip info archive.colord\n");
+		return 1;
+	}
 	const std::string mode = argv[1];
 	const int source = mode == "compress-ont" ? 0 : mode == "compress-pbraw" ? 1 : mode == "compress-pbhifi" ? 2 : -1;
 	if (source < 0) die("unknown mode " + mode);
@@ -223,8 +203,7 @@ int main(int argc, char** argv)
 	if (!hdr_err.empty()) die("header stream: " + hdr_err);
 
 	// archive: meta (compression.cpp:704-779), info (utils.cpp:326-342), then the stream parts
-	Archive ar; ar.f = fopen(pos[1].c_str(), "wb");
-	if (!ar.f) die("cannot open file: " + pos[1]);
+	ArchiveWriter ar; ar.open(pos[1]);
 	const int s_meta = ar.reg("meta"), s_header = ar.reg("header"), s_dna = ar.reg("dna"), s_qual = ar.reg("qual");
 	uint64_t o = 0; for (uint32_t p = 0; p < n_parts; ++p) { ar.add(s_dna, h_dna.data() + o, dna_sz[p], packs[p + 1] - packs[p]); o += dna_sz[p]; }
 	o = 0; for (uint32_t p = 0; p < n_parts; ++p) { ar.add(s_qual, h_qual.data() + o, qual_sz[p], 0); o += qual_sz[p]; }

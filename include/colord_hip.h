@@ -346,6 +346,44 @@ cl_status cl_compressor_encode(cl_compressor* c, const cl_reads* chunk, const ui
 cl_status cl_compressor_info(const cl_compressor* c, cl_kmer_stats* stats, uint64_t* first_read, uint64_t* n_reads_total, uint64_t* mean_read_len,
                              uint32_t* sparse_range, uint32_t* n_refs_total);
 
+/* ---- a17, the inverse path: CRangeDecoder (sub_rc.h:216-392), CDNACoder::Decode (dna_coder.cpp:234-437), CQualityCoder::Decode
+ *      (quality_coder.cpp:605-657, quality_coder_impl.cpp:506-559,800-849), CIDCoder::Decode (id_coder.cpp:396-600); drivers
+ *      CEntropyDecomprReads / CEntrDecomprQuals / CEntrDecomprHeaders (entr_read.h:146-191, entr_qual.h:136-260, entr_header.cpp:46-80).
+ *      HOST functions (h_* pointers): a model domain decodes as one dependent chain; streams and domains are the parallelism. ---- */
+typedef struct cl_dna_decoder cl_dna_decoder;
+typedef struct cl_qual_decoder cl_qual_decoder;
+typedef struct cl_id_decoder cl_id_decoder;
+/* CDNACoder::Init(false, ...) + CReferenceReads + CRefReadsAccepter: max_alt_refs / level / sparse range + exponent come from the
+ * archive's `meta` stream; accept_all = ReferenceReadsMode::All; start_read_id = n_pseudo for single-domain archives. */
+cl_status cl_dna_decoder_create(uint32_t max_alt_refs, int32_t level, uint32_t start_read_id, uint32_t n_pseudo,
+                                int32_t accept_all, uint32_t sparse_range, double sparse_exponent, cl_dna_decoder** out);
+void cl_dna_decoder_free(cl_dna_decoder* d);
+const char* cl_dna_decoder_error(const cl_dna_decoder* d);
+/* a reference-genome pseudo read (codes 0..3), in order, before the first part (decompression_common.cpp:300-305) */
+cl_status cl_dna_decoder_add_ref(cl_dna_decoder* d, const uint8_t* h_codes, uint32_t len);
+/* Archives written by several GPUs hold one model domain per rank: fresh adaptive models from here on; the reference reads, the
+ * read counter and the acceptor's random stream continue. */
+cl_status cl_dna_decoder_new_domain(cl_dna_decoder* d);
+/* One `dna` part of n_reads reads (the part's archive metadata) -> bases back to back: codes 0..3, 4 = N, at levels 2 and 3 with
+ * the class flags 0x80 (anchor) / 0x40 (match) the quality decoder reads (basic_coder.h:34-35); h_off[n_reads+1].  If cap is too
+ * small: CL_E_CAPACITY with *n_out = bytes needed; the decoded part stays inside the decoder and the same call with a buffer of
+ * that size fetches it (nothing is decoded twice).  cl_id_decode_part behaves the same way. */
+cl_status cl_dna_decode_part(cl_dna_decoder* d, const uint8_t* h_in, uint64_t n_in, uint32_t n_reads,
+                             uint8_t* h_bases, uint64_t cap, uint64_t* h_off, uint64_t* n_out);
+/* CQualityCoder::Init(false, ...): params as for the encoder; rev[] = the representatives stored in `meta` (-D). */
+cl_status cl_qual_decoder_create(const cl_qual_params* params, cl_qual_decoder** out);
+void cl_qual_decoder_free(cl_qual_decoder* q);
+cl_status cl_qual_decoder_new_domain(cl_qual_decoder* q);
+/* One `qual` part: h_bases / h_off are the output of cl_dna_decode_part for the same part; h_quals receives ASCII qualities at
+ * the same offsets. */
+cl_status cl_qual_decode_part(cl_qual_decoder* q, const uint8_t* h_in, uint64_t n_in, const uint8_t* h_bases, const uint64_t* h_off,
+                              uint32_t n_reads, uint8_t* h_quals);
+cl_status cl_id_decoder_create(int32_t header_mode, cl_id_decoder** out);
+void cl_id_decoder_free(cl_id_decoder* c);
+/* One `header` part of n ids -> the ids back to back (without '@' / '>'), h_off[n+1], h_plus[n] (1 = the '+' line repeats the id). */
+cl_status cl_id_decode_part(cl_id_decoder* c, const uint8_t* h_in, uint64_t n_in, uint32_t n, uint8_t* h_ids, uint64_t cap,
+                            uint64_t* h_off, uint8_t* h_plus, uint64_t* n_out);
+
 /* ---- a7: CReferenceReads (reference_reads.h:27-259) ---------------------------------------------- */
 /* Byte image of one stored reference read (4 bases/byte MSB first + trailing count byte) produced from
  * the arena; h_out needs (len+3)/4+1 bytes.  Used by the parity tests and by the host archive code. */

@@ -1,0 +1,67 @@
+"""CPU suite for the inverse path (host functions of the C ABI, no GPU needed): `colord_hip decompress` — the
+library's DNA / quality / id decoders behind the reference's decompression driver — must return, for archives written by the
+UNMODIFIED reference, exactly what the reference's own `decompress` returns (tests/golden/archives, made by make_archives.py).
+Covers the three sequencing modes, levels 1-3, sparse / all-reads reference sets, every quality mode incl. the *-avg error
+diffusion in IEEE double, the class flags of levels 2-3 and the three header modes."""
+import ctypes as C
+import hashlib
+import json
+import os
+import subprocess
+import numpy as np
+import pytest
+from colord_amd import _native as N, archive as AR
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ARC = os.path.join(ROOT, "tests", "golden", "archives")
+CLI = os.path.join(ROOT, "colord_amd", "colord_hip")
+EXP = json.load(open(os.path.join(ARC, "expected.json")))
+
+
+@pytest.mark.parametrize("name", sorted(EXP))
+def test_decompress_reference_archive(name, tmp_path):
+    out = str(tmp_path / "out.fastq")
+    r = subprocess.run([CLI, "decompress", os.path.join(ARC, name + ".colord"), out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert hashlib.sha256(open(out, "rb").read()).hexdigest() == EXP[name]["decompressed_sha256"]
+
+
+def test_info_prints_the_reference_fields():
+    r = subprocess.run([CLI, "info", os.path.join(ARC, "c1_ont_default.colord")], capture_output=True, text=True)
+    assert r.returncode == 0
+    for key in ("version major: 1", "version minor: 2", "total bases: 449286", "total reads: 100", "command: "):
+        assert key in r.stderr
+
+
+def test_dna_decode_capacity_retry_keeps_the_part():
+    """cl_dna_decode_part with a buffer that is too small returns the size and keeps the decoded part for the next call."""
+    lib = N.load()
+    arc = AR.read_archive(os.path.join(ARC, "c1_ont_default.colord"))
+    meta = arc["meta"].parts[0][1]
+    max_c, level = int.from_bytes(meta[4:8], "little"), int.from_bytes(meta[8:12], "little")
+    n_reads, payload = arc["dna"].parts[0]
+    d = N._P()
+    # c1: sparse reference set, range and exponent sit after quality mode (1 B), header mode (1 B), reference mode (1 B)
+    assert meta[21] == 2 and meta[23] == 1
+    rng = int.from_bytes(meta[24:28], "little"); exp = np.frombuffer(meta[28:36], np.float64)[0]
+    assert lib.cl_dna_decoder_create(max_c, level, 0, 0, 0, rng, float(exp), C.byref(d)) == 0
+    buf = np.frombuffer(payload, np.uint8)
+    off = np.zeros(n_reads + 1, np.uint64); got = C.c_uint64(0)
+    small = np.zeros(16, np.uint8)
+    assert lib.cl_dna_decode_part(d, buf.ctypes.data, len(buf), n_reads, small.ctypes.data, 16, off.ctypes.data, C.byref(got)) == N.CL_E_CAPACITY
+    assert got.value == 449286
+    bases = np.zeros(got.value, np.uint8)
+    assert lib.cl_dna_decode_part(d, buf.ctypes.data, len(buf), n_reads, bases.ctypes.data, got.value, off.ctypes.data, C.byref(got)) == 0
+    assert off[-1] == 449286 and bases.max() <= 4
+    lib.cl_dna_decoder_free(d)
+
+
+def test_corrupt_part_is_an_error_not_a_crash(tmp_path):
+    arc = AR.read_archive(os.path.join(ARC, "bovis24_q_4-avg_balanced.colord"))
+    st = arc["dna"]
+    meta, payload = st.parts[0]
+    st.parts[0] = (meta, payload[:len(payload) // 2] + bytes(len(payload) - len(payload) // 2))
+    bad = str(tmp_path / "bad.colord")
+    AR.write_archive(bad, list(arc.values()))
+    r = subprocess.run([CLI, "decompress", bad, str(tmp_path / "o.fastq")], capture_output=True, text=True, timeout=120)
+    assert r.returncode in (0, 1)                            # garbage in: either a reported stream error or garbage bases, never a hang / signal
