@@ -1,0 +1,402 @@
+// compress.cpp — `colord_hip compress-ont | compress-pbhifi | compress-pbraw [options] input output`: the compress side of the
+// reference CLI (src/colord/arg_parse.cpp:455-640 options and their checks, :89-408 presets) and the host side of runCompression
+// (compression.cpp:344-785): input parsing with the reader's semantics (in_reads.cpp:62-226: FASTQ / FASTA / multi-line FASTA,
+// plain or gzip, CR LF tolerated, blank lines skipped, '+' line empty or equal to the id), k / anchor length from the file size,
+// reader packs, the `header`, `meta` and `info` streams and the archive container.  Everything between read bases / qualities
+// and the `dna` / `qual` parts is the chunked compressor of the library (cl_compressor_*, csrc/stream.hip): the input is cut in
+// chunks of whole reader packs (--chunk-bases, default 1 Gbase) that stay resident in HBM as 2-bit arenas + quality bytes for the
+// three passes, so the file is parsed once and any size the GPU holds (~150 Gbases of FASTQ on 288 GB) is one run.
+#include "colord_hip.h"
+#include "archive.hpp"
+#include <hip/hip_runtime_api.h>
+#include <zlib.h>
+#include <algorithm>
+#include <chrono>
+#include <ctime>
+#include <thread>
+
+namespace {
+struct Preset { int level; uint32_t ci, cs, f, c, max_rec, min_part_alt; int qual_mode; int sparse; double g; };
+// arg_parse.cpp:89-408 — [source][priority]: ratio, balanced, memory (memory is the default priority)
+const Preset PRESETS[3][3] = {
+	{ { 3, 2, 120, 8, 10, 6, 48, 2, 0, 1 }, { 2, 3, 100, 9, 8, 5, 48, 2, 1, 2 }, { 1, 4, 80, 12, 5, 3, 64, 2, 1, 1 } },          // ONT, 4-avg qualities
+	{ { 3, 2, 120, 8, 10, 6, 48, 8, 0, 1 }, { 2, 3, 100, 9, 8, 5, 48, 8, 1, 2 }, { 1, 4, 80, 12, 5, 3, 64, 8, 1, 1 } },          // PBRaw, qualities dropped
+	{ { 3, 2, 150, 20, 12, 6, 48, 1, 0, 1 }, { 2, 3, 120, 30, 10, 5, 48, 1, 1, 6 }, { 2, 3, 100, 40, 8, 5, 48, 1, 1, 3 } },       // PBHiFi, 5-avg qualities
+};
+// default -T / -D values of the quality modes (arg_parse.cpp:32-84,410-450): mode -> forward thresholds, decoder representatives
+struct QDef { std::vector<uint32_t> fwd, rev; };
+QDef qual_defaults(int mode)
+{
+	switch (mode)
+	{
+	case 1: return { { 7, 14, 26, 93 }, {} };
+	case 2: return { { 7, 14, 26 }, {} };
+	case 3: return { { 7 }, {} };
+	case 4: return { { 7, 14, 26, 93 }, { 3, 10, 18, 35, 93 } };
+	case 5: return { { 7, 14, 26 }, { 3, 10, 18, 35 } };
+	case 6: return { { 7 }, { 1, 13 } };
+	case 8: return { {}, { 0 } };
+	default: return { {}, {} };
+	}
+}
+int qual_mode_of(const std::string& s)      // QualityComprMode (params.h:33-43)
+{
+	static const char* names[] = { "org", "5-avg", "4-avg", "2-avg", "5-fix", "4-fix", "2-fix", "avg", "none" };
+	for (int i = 0; i < 9; ++i) if (s == names[i]) return i;
+	return -1;
+}
+void hipck(hipError_t e, const char* what) { if (e != hipSuccess) die(std::string(what) + ": " + hipGetErrorString(e)); }
+void ck(cl_ctx* ctx, cl_status s, const char* what) { if (s != CL_OK) die(std::string(what) + ": " + (ctx ? cl_last_error(ctx) : "error")); }
+template<class T> void le(std::vector<uint8_t>& v, T x) { for (size_t i = 0; i < sizeof(T); ++i) v.push_back((uint8_t)((uint64_t)x >> (8 * i))); }
+void le_double(std::vector<uint8_t>& v, double d) { uint64_t u; memcpy(&u, &d, 8); le(v, u); }
+std::vector<uint32_t> list_u32(const std::string& s) { std::vector<uint32_t> v; size_t p = 0; while (p < s.size()) { size_t e = s.find_first_of(", ", p); if (e == std::string::npos) e = s.size(); if (e > p) v.push_back((uint32_t)strtoul(s.substr(p, e - p).c_str(), nullptr, 10)); p = e + 1; } return v; }
+
+struct Options {
+	int source = 0, prio = 2, gpu = 0; bool verbose = false;
+	uint32_t k = 0, a = 0; std::string in, out, genome; bool store_genome = false;
+	long ci = -1, cs = -1, f = -1, c = -1, max_rec = -1, min_to_alt = -1, min_anchors = 1;
+	double cost_mult = 1.0, frac_min = 0.5, frac_always = 0.9, max_matches_mult = 10.0, g = -1, exponent = 1.0;
+	int qual_mode = -1, header_mode = 0, ref_mode = -1;
+	std::vector<uint32_t> T, D; bool has_T = false, has_D = false;
+	double chunk_bases = 1.0e9;
+};
+
+// ---- input: one sequential pass that finds lines (memchr) and assigns them their role; bases / qualities / ids are appended to the
+// ---- chunk under construction.  A chunk closes at the first reader-pack boundary at or after chunk_bases.
+struct Chunk {
+	uint8_t* bases = nullptr; uint8_t* quals = nullptr; uint64_t cap = 0, n = 0;       // pinned staging (ASCII)
+	std::vector<uint64_t> off{ 0 }; std::vector<uint32_t> packs{ 0 }; uint64_t pack_acc = 0;
+	void reserve(uint64_t need, bool with_quals)
+	{
+		if (need <= cap) return;
+		uint64_t nc = std::max<uint64_t>(need, cap + cap / 2 + (1ull << 24));
+		uint8_t* nb = nullptr; uint8_t* nq = nullptr;
+		hipck(hipHostMalloc((void**)&nb, nc, hipHostMallocDefault), "hipHostMalloc");
+		if (n) memcpy(nb, bases, n);
+		if (bases) (void)hipHostFree(bases);
+		bases = nb;
+		if (with_quals) { hipck(hipHostMalloc((void**)&nq, nc, hipHostMallocDefault), "hipHostMalloc"); if (n) memcpy(nq, quals, n); if (quals) (void)hipHostFree(quals); quals = nq; }
+		cap = nc;
+	}
+	void clear() { n = 0; off.assign(1, 0); packs.assign(1, 0); pack_acc = 0; }
+	void release() { if (bases) (void)hipHostFree(bases); if (quals) (void)hipHostFree(quals); bases = quals = nullptr; cap = 0; }
+};
+struct Reader {
+	gzFile g = nullptr; bool gz = false, fastq = true; uint64_t file_bytes = 0, total_bytes = 0, header_symbols = 0;
+	std::vector<uint8_t> buf; size_t pos = 0, len = 0; bool eof = false;
+	std::string line[4]; int which = 0;                          // FASTQ record under construction
+	std::string fa_header, fa_seq; int fa_state = 0;            // FASTA: 0 header, 1 EOLs after header, 2 read, 3 EOLs after / inside read
+	std::vector<uint8_t> ids, plus; std::vector<uint64_t> id_off{ 0 };
+	uint64_t n_reads = 0, n_bases = 0;
+	void open(const std::string& path)
+	{
+		FILE* probe = fopen(path.c_str(), "rb");
+		if (!probe) die("cannot open file: " + path);
+		unsigned char mg[2] = { 0, 0 }; const size_t got = fread(mg, 1, 2, probe);
+		fseeko(probe, 0, SEEK_END); file_bytes = (uint64_t)ftello(probe); fclose(probe);
+		gz = got == 2 && mg[0] == 0x1f && mg[1] == 0x8b;
+		g = gzopen(path.c_str(), "rb");
+		if (!g) die("cannot open file: " + path);
+		gzbuffer(g, 1 << 22);
+		buf.resize(1 << 25);
+		fill();
+		if (!len) die("file " + path + " is empty");
+		if (buf[0] != '@' && buf[0] != '>') die("unknown file format (the first character must be '@' or '>')");      // in_reads.cpp:256-262
+		fastq = buf[0] == '@';
+	}
+	void fill() { const int n = gzread(g, buf.data(), (unsigned)buf.size()); if (n < 0) die("read error (zlib)"); len = (size_t)n; pos = 0; total_bytes += len; if (!n) eof = true; }
+	void add_record(Chunk& ch, const char* id, size_t id_len, const char* seq, size_t seq_len, const char* qual, bool plus_eq)
+	{
+		ids.insert(ids.end(), id, id + id_len); id_off.push_back(ids.size()); plus.push_back(plus_eq ? 1 : 0);
+		ch.reserve(ch.n + seq_len + 1, fastq);
+		memcpy(ch.bases + ch.n, seq, seq_len);
+		if (fastq) memcpy(ch.quals + ch.n, qual, seq_len);
+		ch.n += seq_len; ch.off.push_back(ch.n);
+		++n_reads; n_bases += seq_len;
+		ch.pack_acc += seq_len + 1;                               // a pack closes once its reads (with one guard byte each) reach 4 Mi symbols (in_reads.cpp:62-77)
+		if (ch.pack_acc >= (2u << 21)) { ch.packs.push_back((uint32_t)(ch.off.size() - 1)); ch.pack_acc = 0; }
+	}
+	void flush_fastq(Chunk& ch)
+	{
+		if (line[0].empty() || line[0][0] != '@') die("FASTQ record does not start with '@'");
+		if (line[2].empty() || line[2][0] != '+') die("FASTQ record without '+' line");
+		if (line[1].size() != line[3].size()) die("sequence and quality lengths differ");
+		header_symbols += line[0].size() + line[2].size();
+		const bool eq = line[2].size() > 1;
+		if (eq && line[2].compare(1, std::string::npos, line[0], 1, std::string::npos) != 0) die("quality header not empty but different than read header");   // in_reads.cpp:79-92
+		add_record(ch, line[0].data() + 1, line[0].size() - 1, line[1].data(), line[1].size(), line[3].data(), eq);
+	}
+	void flush_fasta(Chunk& ch)
+	{
+		header_symbols += fa_header.size();
+		add_record(ch, fa_header.data() + 1, fa_header.size() - 1, fa_seq.data(), fa_seq.size(), nullptr, false);
+		fa_header.clear(); fa_seq.clear();
+	}
+	// fills `ch` up to the first pack boundary at or after `target` bases; returns false when the input is exhausted and ch is empty
+	bool next_chunk(Chunk& ch, uint64_t target)
+	{
+		ch.clear();
+		auto chunk_full = [&]() { return ch.n >= target && ch.pack_acc == 0 && ch.off.size() > 1; };
+		while (!eof && !chunk_full())
+		{
+			if (pos >= len) { fill(); if (eof) break; }
+			if (fastq)
+			{	// lines end at '\n' or '\r'; empty lines are skipped (in_reads.cpp:188-226)
+				const uint8_t* p = buf.data() + pos; const uint8_t* e = buf.data() + len;
+				const uint8_t* q = (const uint8_t*)memchr(p, '\n', (size_t)(e - p)); const uint8_t* lim = q ? q : e;
+				const uint8_t* r = (const uint8_t*)memchr(p, '\r', (size_t)(lim - p)); const uint8_t* nl = r ? r : lim;
+				line[which].append((const char*)p, (size_t)(nl - p));
+				pos = (size_t)(nl - buf.data());
+				if (nl < e)
+				{
+					++pos;
+					if (!line[which].empty()) { if (++which == 4) { flush_fastq(ch); which = 0; for (auto& l : line) l.clear(); } }
+				}
+			}
+			else
+			{	// porcessFastaOrMultiFasta (in_reads.cpp:114-178)
+				for (; pos < len && !chunk_full(); ++pos)
+				{
+					const uint8_t s = buf[pos]; const bool eol = s == '\n' || s == '\r';
+					switch (fa_state)
+					{
+					case 0: if (eol) fa_state = 1; else fa_header.push_back((char)s); break;
+					case 1: if (!eol) { fa_seq.push_back((char)s); fa_state = 2; } break;
+					case 2: if (eol) fa_state = 3; else fa_seq.push_back((char)s); break;
+					case 3: if (!eol) { if (s == '>') { flush_fasta(ch); fa_state = 0; fa_header.push_back((char)s); } else { fa_state = 2; fa_seq.push_back((char)s); } } break;
+					}
+				}
+			}
+		}
+		if (eof)
+		{
+			if (fastq) { if (!line[which].empty()) { if (++which == 4) { flush_fastq(ch); which = 0; for (auto& l : line) l.clear(); } } if (which != 0) die("truncated FASTQ record at the end of the input"); }
+			else if (!fa_header.empty()) flush_fasta(ch);
+		}
+		if (ch.off.size() > 1 && ch.packs.back() != ch.off.size() - 1) { ch.packs.push_back((uint32_t)(ch.off.size() - 1)); ch.pack_acc = 0; }
+		return ch.off.size() > 1;
+	}
+};
+struct DevChunk { cl_reads* reads = nullptr; uint8_t* d_quals = nullptr; uint64_t* d_off = nullptr; std::vector<uint32_t> packs; uint64_t n_bases = 0; uint32_t n_reads = 0; };
+} // namespace
+
+static void usage()
+{
+	fprintf(stderr,
+		"usage: colord_hip compress-ont|compress-pbhifi|compress-pbraw [options] input.fastq|fasta[.gz] output.colord\n"
+		"       colord_hip decompress archive.colord output.fastq\n       colord_hip info archive.colord\n"
+		"options (as the reference, arg_parse.cpp:455-640):\n"
+		"  -p,--priority ratio|balanced|memory   -k,--kmer-len K with -a,--anchor-len A (both or none)\n"
+		"  -q,--qual org|none|avg|2-fix|4-fix|5-fix|2-avg|4-avg|5-avg   -T,--qual-thresholds a,b,..   -D,--qual-values a,b,..\n"
+		"  -i,--identifier org|main|none   -c,--max-candidates N   -L,--Lowest-count N   -H,--Highest-count N   -f,--filter-modulo N\n"
+		"  -e,--edit-script-mult X   -r,--max-recurence-level N   --min-to-alt N   --min-mmer-frac X   --min-mmer-force-enc X\n"
+		"  --max-matches-mult X   --min-anchors N   -R,--Ref-reads-mode all|sparse   -g,--sparse-range X   -x,--sparse-exponent X\n"
+		"  -t,--threads N (accepted; the data path runs on the GPU)   -v,--verbose   --gpu N   --chunk-bases X\n");
+}
+
+int run_compress(int argc, char** argv)
+{
+	Options O;
+	const std::string mode = argv[1];
+	O.source = mode == "compress-ont" ? 0 : mode == "compress-pbraw" ? 1 : mode == "compress-pbhifi" ? 2 : -1;
+	if (O.source < 0) { usage(); die("unknown mode " + mode); }
+	std::vector<std::string> pos;
+	auto need = [&](int& i) -> std::string { if (i + 1 >= argc) die(std::string("option ") + argv[i] + " needs a value"); return argv[++i]; };
+	for (int i = 2; i < argc; ++i)
+	{
+		const std::string a = argv[i];
+		if (a == "-p" || a == "--priority") { const std::string v = need(i); O.prio = v == "ratio" ? 0 : v == "balanced" ? 1 : v == "memory" ? 2 : -1; if (O.prio < 0) die("unknown priority " + v); }
+		else if (a == "-k" || a == "--kmer-len") { O.k = (uint32_t)atoi(need(i).c_str()); if (O.k < 15 || O.k > 28) die("-k,--kmer-len must be in [15, 28]"); }
+		else if (a == "-a" || a == "--anchor-len") O.a = (uint32_t)atoi(need(i).c_str());
+		else if (a == "-q" || a == "--qual") { const std::string v = need(i); O.qual_mode = qual_mode_of(v); if (O.qual_mode < 0) die("unknown quality mode " + v); }
+		else if (a == "-T" || a == "--qual-thresholds") { O.T = list_u32(need(i)); O.has_T = true; while (i + 1 < argc && isdigit((unsigned char)argv[i + 1][0]) && pos.size() + (size_t)(argc - i - 1) > 2) O.T.push_back((uint32_t)atoi(argv[++i])); }
+		else if (a == "-D" || a == "--qual-values") { O.D = list_u32(need(i)); O.has_D = true; while (i + 1 < argc && isdigit((unsigned char)argv[i + 1][0]) && pos.size() + (size_t)(argc - i - 1) > 2) O.D.push_back((uint32_t)atoi(argv[++i])); }
+		else if (a == "-i" || a == "--identifier") { const std::string v = need(i); O.header_mode = v == "org" ? 0 : v == "main" ? 1 : v == "none" ? 2 : -1; if (O.header_mode < 0) die("unknown header mode " + v); }
+		else if (a == "-c" || a == "--max-candidates") { O.c = atol(need(i).c_str()); if (O.c < 1) die("-c must be positive"); }
+		else if (a == "-L" || a == "--Lowest-count") O.ci = atol(need(i).c_str());
+		else if (a == "-H" || a == "--Highest-count") O.cs = atol(need(i).c_str());
+		else if (a == "-f" || a == "--filter-modulo") { O.f = atol(need(i).c_str()); if (O.f < 1) die("-f must be positive"); }
+		else if (a == "-e" || a == "--edit-script-mult") O.cost_mult = atof(need(i).c_str());
+		else if (a == "-r" || a == "--max-recurence-level") O.max_rec = atol(need(i).c_str());
+		else if (a == "--min-to-alt") O.min_to_alt = atol(need(i).c_str());
+		else if (a == "--min-mmer-frac") O.frac_min = atof(need(i).c_str());
+		else if (a == "--min-mmer-force-enc") O.frac_always = atof(need(i).c_str());
+		else if (a == "--max-matches-mult") O.max_matches_mult = atof(need(i).c_str());
+		else if (a == "--min-anchors") O.min_anchors = atol(need(i).c_str());
+		else if (a == "-R" || a == "--Ref-reads-mode") { const std::string v = need(i); O.ref_mode = v == "all" ? 0 : v == "sparse" ? 1 : -1; if (O.ref_mode < 0) die("unknown reference reads mode " + v); }
+		else if (a == "-g" || a == "--sparse-range") O.g = atof(need(i).c_str());
+		else if (a == "-x" || a == "--sparse-exponent") O.exponent = atof(need(i).c_str());
+		else if (a == "-t" || a == "--threads") (void)need(i);
+		else if (a == "--fill-factor-filtered-kmers" || a == "--fill-factor-kmers-to-reads") (void)need(i);     // host hash-table tuning of the reference: no counterpart here
+		else if (a == "-v" || a == "--verbose") O.verbose = true;
+		else if (a == "-G" || a == "--reference-genome") O.genome = need(i);
+		else if (a == "-s" || a == "--store-reference") O.store_genome = true;
+		else if (a == "--gpu") O.gpu = atoi(need(i).c_str());
+		else if (a == "--chunk-bases") O.chunk_bases = atof(need(i).c_str());
+		else if (a == "-h" || a == "--help") { usage(); return 0; }
+		else if (!a.empty() && a[0] == '-' && a.size() > 1) die("unknown option " + a);
+		else pos.push_back(a);
+	}
+	if (pos.size() != 2) { usage(); die("expected input and output paths"); }
+	O.in = pos[0]; O.out = pos[1];
+	// the checks of arg_parse.cpp:604-625
+	if (O.k && !O.a) die("if -k,--kmer-len is set -a,--anchor-len also must be set");
+	if (!O.k && O.a) die("if -a,--anchor-len is set -k,--kmer-len also must be set");
+	if (O.k && O.a > O.k) die("-a,--anchor-len must be less than or equal to -k,--kmer-len");
+	if (!O.genome.empty()) die("-G,--reference-genome: the reference-genome mode runs at the library level (cl_index_build with pseudo reads, tests/test_gpu_genome.py) but is not wired into this command yet");
+	const Preset P0 = PRESETS[O.source][O.prio];
+	Preset P = P0;
+	if (O.ci >= 0) P.ci = (uint32_t)O.ci;
+	if (O.cs >= 0) P.cs = (uint32_t)O.cs;
+	if (O.f >= 0) P.f = (uint32_t)O.f;
+	if (O.c >= 0) P.c = (uint32_t)O.c;
+	if (O.max_rec >= 0) P.max_rec = (uint32_t)O.max_rec;
+	if (O.min_to_alt >= 0) P.min_part_alt = (uint32_t)O.min_to_alt;
+	if (O.qual_mode >= 0) P.qual_mode = O.qual_mode;
+	if (O.ref_mode >= 0) P.sparse = O.ref_mode;
+	if (O.g >= 0) P.g = O.g;
+	if (P.c > 64) die("-c,--max-candidates above 64 is not supported by the DNA coder of this build");
+	// quality thresholds / representatives (adjust_quality_mode_and_thresholds, arg_parse.cpp:410-450)
+	QDef qd = qual_defaults(P.qual_mode);
+	static const char* qnames[] = { "org", "5-avg", "4-avg", "2-avg", "5-fix", "4-fix", "2-fix", "avg", "none" };
+	if (O.has_T) { if (qd.fwd.empty()) die(std::string("-T,--qual-thresholds is not allowed for '") + qnames[P.qual_mode] + "' quality mode"); if (O.T.size() != qd.fwd.size()) die(std::string("for '") + qnames[P.qual_mode] + "' quality compression mode expected number of quality thresholds is " + std::to_string(qd.fwd.size()) + ", but " + std::to_string(O.T.size()) + " given."); qd.fwd = O.T; }
+	if (O.has_D) { if (qd.rev.empty()) die(std::string("-D,--qual-values is not allowed for '") + qnames[P.qual_mode] + "' quality mode"); if (O.D.size() != qd.rev.size()) die(std::string("for '") + qnames[P.qual_mode] + "' quality compression mode expected number of quality values is " + std::to_string(qd.rev.size()) + ", but " + std::to_string(O.D.size()) + " given."); qd.rev = O.D; }
+	for (size_t i = 0; i < qd.fwd.size(); ++i) if (qd.fwd[i] > 95 || (i && qd.fwd[i] < qd.fwd[i - 1])) die("quality thresholds must be ascending values in [0, 95]");
+
+	const auto t0 = std::chrono::steady_clock::now();
+	hipck(hipSetDevice(O.gpu), "hipSetDevice");
+	Reader R; R.open(O.in);
+	// k-mer / anchor length from the estimated number of bases (adjustKmerAndAnchorLen, compression.cpp:42-95)
+	uint32_t k = O.k, a = O.a;
+	if (!k)
+	{
+		const double fac = R.gz ? (R.fastq ? 2.08 : 3.98) : (R.fastq ? 0.49 : 0.98);
+		const uint64_t est = (uint64_t)(fac * (double)R.file_bytes);
+		if (est < 1000000000ull) { k = 20; a = 16; } else if (est < 4000000000ull) { k = 21; a = 18; } else if (est < 16000000000ull) { k = 23; a = 21; }
+		else if (est < 48000000000ull) { k = 24; a = 22; } else if (est < 128000000000ull) { k = 25; a = 22; } else { k = 26; a = 23; }
+	}
+	cl_ctx* ctx = nullptr; cl_ctx* qctx = nullptr;
+	ck(nullptr, cl_ctx_create(O.gpu, &ctx), "cl_ctx_create");
+	ck(nullptr, cl_ctx_create(O.gpu, &qctx), "cl_ctx_create");
+	cl_compress_params cp{};
+	cp.k = k; cp.f = P.f; cp.ci = P.ci; cp.cs = P.cs; cp.c = P.c; cp.anchor_len = a; cp.min_part_alt = P.min_part_alt; cp.max_rec = P.max_rec; cp.min_anchors = (uint32_t)O.min_anchors;
+	cp.level = P.level; cp.source = O.source; cp.sparse = P.sparse; cp.sparse_g = P.g; cp.sparse_exponent = O.exponent;
+	cp.cost_mult = O.cost_mult; cp.frac_always = O.frac_always; cp.frac_min = O.frac_min; cp.max_matches_mult = O.max_matches_mult;
+	cl_qual_params qp{}; qp.mode = P.qual_mode; qp.source = O.source; qp.level = P.level;
+	qp.n_fwd = (uint32_t)qd.fwd.size(); std::copy(qd.fwd.begin(), qd.fwd.end(), qp.fwd);
+	qp.n_rev = (uint32_t)qd.rev.size(); std::copy(qd.rev.begin(), qd.rev.end(), qp.rev);
+	const bool with_qual = R.fastq;
+	const uint64_t est_bases = (uint64_t)((R.gz ? (R.fastq ? 2.08 : 3.98) : (R.fastq ? 0.49 : 0.98)) * (double)R.file_bytes);
+	cl_compressor* cmp = nullptr;
+	ck(ctx, cl_compressor_create(ctx, qctx, &cp, with_qual ? &qp : nullptr, nullptr, est_bases, &cmp), "cl_compressor_create");
+
+	// pass 1 while parsing: every chunk goes to HBM (2-bit arena + quality bytes) and stays there for the three passes
+	std::vector<DevChunk> chunks; Chunk host;
+	while (R.next_chunk(host, (uint64_t)O.chunk_bases))
+	{
+		DevChunk dc; dc.n_reads = (uint32_t)(host.off.size() - 1); dc.n_bases = host.n; dc.packs = host.packs;
+		if (with_qual)
+		{	// quality bytes outside 33..128 would index past the coder's tables: the input is rejected, not coded (qualities are Phred+33)
+			uint8_t lo = 255, hi = 0; for (uint64_t i = 0; i < host.n; ++i) { lo = std::min(lo, host.quals[i]); hi = std::max(hi, host.quals[i]); }
+			if (host.n && (lo < 33 || hi > 33 + 95)) die("quality values outside '!'..'~'+1 (Phred+33, 0..95) are not supported");
+		}
+		uint8_t* d_bases = nullptr;
+		hipck(hipMalloc((void**)&d_bases, host.n + 1), "hipMalloc"); hipck(hipMalloc((void**)&dc.d_off, host.off.size() * 8), "hipMalloc");
+		hipck(hipMemcpy(d_bases, host.bases, host.n, hipMemcpyHostToDevice), "hipMemcpy");
+		hipck(hipMemcpy(dc.d_off, host.off.data(), host.off.size() * 8, hipMemcpyHostToDevice), "hipMemcpy");
+		if (with_qual) { hipck(hipMalloc((void**)&dc.d_quals, host.n + 1), "hipMalloc (the input does not fit this GPU's memory)"); hipck(hipMemcpy(dc.d_quals, host.quals, host.n, hipMemcpyHostToDevice), "hipMemcpy"); }
+		ck(ctx, cl_reads_pack(ctx, d_bases, dc.d_off, dc.n_reads, 1, &dc.reads), "input");        // "Only ACGTN symbols supported inside a read"
+		hipck(hipFree(d_bases), "hipFree");
+		ck(ctx, cl_compressor_count_add(cmp, dc.reads), "pass 1");
+		chunks.push_back(std::move(dc));
+	}
+	host.release();
+	const uint32_t n = (uint32_t)R.n_reads; const uint64_t total = R.n_bases;
+	if (!n) die("no reads in " + O.in);
+	// the header stream on a host thread, next to the GPU path (CEntrComprHeaders, entr_header.cpp:23-45)
+	std::vector<std::vector<uint8_t>> hdr_parts; std::vector<uint32_t> hdr_counts; std::string hdr_err;
+	std::thread hdr([&]() {
+		cl_id_coder* idc = nullptr;
+		if (cl_id_coder_create(O.header_mode, &idc) != CL_OK) { hdr_err = "cl_id_coder_create"; return; }
+		uint32_t i = 0;
+		while (i < n)
+		{
+			uint32_t j = i; uint64_t acc = 0;
+			while (j < n) { acc += R.id_off[j + 1] - R.id_off[j]; ++j; if (acc >= (2u << 21)) break; }       // in_reads.cpp:50-56,93-101
+			std::vector<uint64_t> off(j - i + 1);
+			for (uint32_t t = i; t <= j; ++t) off[t - i] = R.id_off[t] - R.id_off[i];
+			std::vector<uint8_t> out(2 * (size_t)off.back() + 64); uint64_t got = 0;
+			if (cl_id_encode_part(idc, R.ids.data() + R.id_off[i], off.data(), R.plus.data() + i, j - i, out.data(), out.size(), &got) != CL_OK) { hdr_err = cl_id_coder_error(idc); break; }
+			out.resize(got); hdr_parts.push_back(std::move(out)); hdr_counts.push_back(j - i);
+			i = j;
+		}
+		cl_id_coder_free(idc);
+	});
+	cl_kmer_stats ks{};
+	ck(ctx, cl_compressor_count_finish(cmp, &ks), "k-mer counting");
+	for (auto& dc : chunks) ck(ctx, cl_compressor_refs_add(cmp, dc.reads), "reference reads");
+	ck(ctx, cl_compressor_refs_finish(cmp), "reference index");
+	uint64_t mean_read_len = 0; uint32_t sparse_range = 0, n_refs = 0;
+	ck(ctx, cl_compressor_info(cmp, nullptr, nullptr, nullptr, &mean_read_len, &sparse_range, &n_refs), "cl_compressor_info");
+	if (O.verbose) fprintf(stderr, "k=%u a=%u; %llu k-mers, %llu kept; %u reference reads; sparse range %u\n", k, a, (unsigned long long)ks.tot_kmers, (unsigned long long)ks.n_unique_counted, n_refs, sparse_range);
+
+	ArchiveWriter ar; ar.open(O.out);
+	const int s_meta = ar.reg("meta"), s_header = ar.reg("header"), s_dna = ar.reg("dna"), s_qual = with_qual ? ar.reg("qual") : -1;
+	uint64_t dna_total = 0, qual_total = 0; uint32_t n_parts_total = 0;
+	{	// pass 2: chunk by chunk; the parts of a chunk go to the archive while the next chunk is coded
+		uint64_t max_bases = 0, max_parts = 0; for (auto& dc : chunks) { max_bases = std::max(max_bases, dc.n_bases); max_parts = std::max<uint64_t>(max_parts, dc.packs.size()); }
+		const uint64_t dna_cap = max_bases + 64 * max_parts + 4096, qual_cap = (uint64_t)(max_bases * 1.35) + 64 * max_parts + 4096;
+		uint8_t* d_dna = nullptr; uint8_t* d_qual = nullptr;
+		hipck(hipMalloc((void**)&d_dna, dna_cap), "hipMalloc"); if (with_qual) hipck(hipMalloc((void**)&d_qual, qual_cap), "hipMalloc");
+		std::vector<uint8_t> h_dna, h_qual;
+		for (auto& dc : chunks)
+		{
+			const uint32_t np = (uint32_t)dc.packs.size() - 1;
+			std::vector<uint64_t> dsz(np), qsz(np); cl_compress_info info{};
+			ck(ctx, cl_compressor_encode(cmp, dc.reads, dc.d_quals, dc.d_off, dc.packs.data(), np, dc.packs.data(), np, d_dna, dna_cap, dsz.data(), d_qual, qual_cap, qsz.data(), &info), "pass 2");
+			h_dna.resize(info.dna_bytes); h_qual.resize(info.qual_bytes);
+			if (info.dna_bytes) hipck(hipMemcpy(h_dna.data(), d_dna, info.dna_bytes, hipMemcpyDeviceToHost), "hipMemcpy");
+			if (info.qual_bytes) hipck(hipMemcpy(h_qual.data(), d_qual, info.qual_bytes, hipMemcpyDeviceToHost), "hipMemcpy");
+			uint64_t o = 0; for (uint32_t p = 0; p < np; ++p) { ar.add(s_dna, h_dna.data() + o, dsz[p], dc.packs[p + 1] - dc.packs[p]); o += dsz[p]; }
+			o = 0; if (with_qual) for (uint32_t p = 0; p < np; ++p) { ar.add(s_qual, h_qual.data() + o, qsz[p], 0); o += qsz[p]; }
+			dna_total += info.dna_bytes; qual_total += info.qual_bytes; n_parts_total += np;
+			cl_reads_free(dc.reads); dc.reads = nullptr; if (dc.d_quals) (void)hipFree(dc.d_quals); (void)hipFree(dc.d_off); dc.d_quals = nullptr; dc.d_off = nullptr;
+		}
+		(void)hipFree(d_dna); if (d_qual) (void)hipFree(d_qual);
+	}
+	hdr.join();
+	if (!hdr_err.empty()) die("header stream: " + hdr_err);
+	for (size_t p = 0; p < hdr_parts.size(); ++p) ar.add(s_header, hdr_parts[p].data(), hdr_parts[p].size(), hdr_counts[p]);
+
+	// meta (compression.cpp:704-779), info (utils.cpp:326-342)
+	uint32_t tot_ref = n;
+	if (P.sparse) { std::vector<uint8_t> acc(n); ck(ctx, cl_ref_accept(n, 0, sparse_range, O.exponent, acc.data()), "cl_ref_accept"); tot_ref = 0; for (uint8_t x : acc) tot_ref += x; }
+	std::vector<uint8_t> meta;
+	le<uint32_t>(meta, tot_ref); le<uint32_t>(meta, P.c); le<int32_t>(meta, P.level); meta.push_back((uint8_t)O.source);
+	le<uint64_t>(meta, (uint64_t)n * mean_read_len);
+	if (with_qual)
+	{
+		meta.push_back((uint8_t)P.qual_mode);
+		if (P.qual_mode == 8 || (P.qual_mode >= 4 && P.qual_mode <= 6)) for (uint32_t v : qd.rev) le<uint32_t>(meta, v);
+	}
+	meta.push_back((uint8_t)O.header_mode);
+	meta.push_back(P.sparse ? 1 : 0);                                    // ReferenceReadsMode: All = 0, Sparse = 1
+	if (P.sparse) { le<uint32_t>(meta, sparse_range); le_double(meta, O.exponent); }
+	meta.push_back(0);                                                   // no reference genome
+	ar.add(s_meta, meta.data(), meta.size(), 0);
+	const int s_info = ar.reg("info");
+	std::vector<uint8_t> inf;
+	le<uint32_t>(inf, 1); le<uint32_t>(inf, 2); le<uint32_t>(inf, 1);                        // archive format of CoLoRd 1.2.1 (defs.h:24-26)
+	le<uint64_t>(inf, R.total_bytes); le<uint64_t>(inf, total); le<uint32_t>(inf, n); le<uint64_t>(inf, (uint64_t)time(nullptr));
+	std::string cmd; for (int i = 0; i < argc; ++i) { if (i) cmd += ' '; cmd += argv[i]; }
+	le<uint32_t>(inf, (uint32_t)cmd.size()); inf.insert(inf.end(), cmd.begin(), cmd.end());
+	ar.add(s_info, inf.data(), inf.size(), 0);
+	ar.close();
+	gzclose(R.g);
+	const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	fprintf(stderr, "colord_hip: %u reads, %llu bases, k=%u a=%u, %zu chunk(s); dna %llu B (%u parts), qual %llu B, header %zu parts; %u reference reads; %.2f s\n", n, (unsigned long long)total, k, a,
+		chunks.size(), (unsigned long long)dna_total, n_parts_total, (unsigned long long)qual_total, hdr_parts.size(), n_refs, sec);
+	cl_compressor_free(cmp);
+	cl_ctx_destroy(qctx); cl_ctx_destroy(ctx);
+	return 0;
+}

@@ -26,7 +26,7 @@ __global__ void k_read_geometry(const uint64_t* __restrict__ off, uint32_t n_rea
 __device__ inline uint32_t base_code(uint8_t c, int ascii, uint32_t* bad)
 {
 	if (!ascii) { if (c > 4) *bad = 1; return c; }
-	switch (c | 0x20) { case 'a': return 0; case 'c': return 1; case 'g': return 2; case 't': return 3; case 'n': return 4; }
+	switch (c) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; case 'N': return 4; }   // upper case only: SymbToBinMap (utils.h:466-480) has the lower-case entries commented out
 	*bad = 1; return 4;
 }
 

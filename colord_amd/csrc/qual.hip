@@ -390,6 +390,14 @@ extern "C" cl_ctx* cl_qual_coder_ctx(const cl_qual_coder* q) { return q ? q->ctx
 extern "C" void cl_qual_coder_free(cl_qual_coder* q) { delete q; }
 
 // CEntrComprQuals::Compress for a batch of whole parts (entr_qual.h:100-135).  Models persist across calls.
+namespace {
+__global__ __launch_bounds__(256) void k_qual_check(const uint8_t* __restrict__ q, uint64_t n, uint32_t* __restrict__ bad)
+{
+	bool b = false;
+	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) { const uint32_t v = q[i] - 33u; b |= v > 95u; }
+	if (__ballot(b) && (threadIdx.x & 63) == 0) atomicOr(bad, 1u);
+}
+} // namespace
 extern "C" cl_status cl_qual_encode(cl_ctx* ctx, cl_qual_coder* Q, const cl_reads* R, const uint8_t* d_quals, const uint64_t* d_qual_off,
                                     const uint8_t* d_flags, const uint32_t* h_part_bounds, uint32_t n_parts,
                                     uint8_t* d_out, uint64_t cap, uint64_t* h_part_sizes, uint64_t* n_out)
@@ -419,6 +427,17 @@ extern "C" cl_status cl_qual_encode(cl_ctx* ctx, cl_qual_coder* Q, const cl_read
 		LAUNCH(ctx, k_gather_u64, grid_for((uint64_t)n_parts + 1, 256), 256, d_qual_off, (const uint32_t*)d_pb.p, (uint64_t)n_parts + 1, d_qo.p);
 		HIP_TRY(ctx, hipMemcpyAsync(qo.data(), d_qo.p, ((uint64_t)n_parts + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	}
+	{	// quality bytes index the 96-entry maps: anything outside Phred+33 0..95 is refused, not coded (the reference would read past its tables)
+		DevBuf<uint32_t> bad; DEV_ALLOC(ctx, bad, 1);
+		HIP_TRY(ctx, hipMemsetAsync(bad.p, 0, 4, ctx->stream));
+		const uint64_t nq = qo[n_parts] - qo[0];
+		if (nq) LAUNCHB(ctx, (double)nq, k_qual_check, (uint32_t)std::min<uint64_t>(8192, grid_for(nq, 256 * 16)), 256, d_quals + qo[0], nq, bad.p);
+		HIP_TRY(ctx, hipGetLastError());
+		uint32_t h_bad = 0;
+		HIP_TRY(ctx, hipMemcpyAsync(&h_bad, bad.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		if (h_bad) return cl_fail(ctx, CL_E_INVALID, "cl_qual_encode: quality byte outside '!'..'~'+1 (Phred+33 values 0..95)");
 	}
 	const uint32_t bits_max = c.max_total == (1u << 20) ? 20 : 18;
 	uint64_t written = 0;

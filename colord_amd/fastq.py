@@ -13,8 +13,7 @@ READS_PACK_SIZE = 2 << 21          # defs.h:45
 
 _CODE = np.full(256, 255, dtype=np.uint8)
 for _c, _v in zip(b"ACGTN", range(5)):
-    _CODE[_c] = _v
-    _CODE[ord(chr(_c).lower())] = _v     # SymbToBinMap accepts lower case as well (utils.h)
+    _CODE[_c] = _v                       # upper case only: the lower-case entries of SymbToBinMap are commented out (utils.h:472-475)
 
 
 @dataclass

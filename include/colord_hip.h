@@ -59,8 +59,8 @@ cl_status cl_ctx_kernel_times(cl_ctx* ctx, char* buf, uint64_t cap, uint64_t* ne
 void cl_ctx_set_timing(cl_ctx* ctx, int on);
 
 /* ---- read arena: replaces read_t / read_pack_t (src/colord/utils.h:366-376, in_reads.cpp:24-42) -- */
-/* d_codes: concatenated bases, 1 byte per base; either codes 0..4 (ascii=0) or ASCII ACGTN/acgtn
- * (ascii=1).  d_offsets: n_reads+1 base offsets into d_codes.  Builds the 2-bit arena: every read starts
+/* d_codes: concatenated bases, 1 byte per base; either codes 0..4 (ascii=0) or ASCII ACGTN, upper
+ * case only as the reference (ascii=1; anything else: CL_E_INVALID "Only ACGTN symbols supported inside a read").  d_offsets: n_reads+1 base offsets into d_codes.  Builds the 2-bit arena: every read starts
  * on a 32-base (uint64) word boundary and is followed by at least one pad base; a parallel bit mask
  * marks N and pad bases invalid. */
 cl_status cl_reads_pack(cl_ctx* ctx, const uint8_t* d_codes, const uint64_t* d_offsets, uint32_t n_reads,

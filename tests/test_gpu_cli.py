@@ -32,8 +32,145 @@ def test_cli_archive_decoded_by_reference(tmp_path, mode, prio, seed):
     subprocess.check_call([CLI, mode] + extra + [fq, my_arc])
     subprocess.check_call([REF, "decompress", my_arc, my_out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     assert sha(my_out) == sha(ref_out)
+    # ... and by this build's own decompressor (the inverse path, csrc/decode.hip)
+    own_out = str(tmp_path / "own.fastq")
+    subprocess.check_call([CLI, "decompress", my_arc, own_out])
+    assert sha(own_out) == sha(ref_out)
     a, b = AR.read_archive(ref_arc), AR.read_archive(my_arc)
     assert set(a) == set(b)
     for name in a:
         if name != "info":
             assert [(m, hashlib.sha256(p).hexdigest()) for m, p in a[name].parts] == [(m, hashlib.sha256(p).hexdigest()) for m, p in b[name].parts], name
+
+
+@pytest.mark.skipif(not os.path.exists(CLI), reason="needs colord_amd/colord_hip")
+@pytest.mark.parametrize("cfg", ["c1_ont_default", "c2_hifi_org", "c3_clr_ratio", "c6_ont_org", "c7_hifi_balanced", "s6m_ont", "s3m_ont_n_ratio", "s5m_hifi"])
+def test_cli_round_trip_on_goldens(tmp_path, cfg):
+    """compress on the GPU, decompress with this build's decoders: the output is what the reference returns for the same input
+    (`decompressed_sha256` of the golden vectors: the input itself for -q org, the quantised qualities otherwise)."""
+    import gzip, json
+    spec = json.load(open(os.path.join(ROOT, "tests", "golden", cfg, "streams.json")))
+    fq = str(tmp_path / "in.fastq")
+    if spec.get("synth"):
+        write_fastq(fq, make_reads(**spec["synth"]))
+    else:
+        open(fq, "wb").write(gzip.open(os.path.join(ROOT, "tests", "data", spec["input"] + ".gz"), "rb").read())
+    args = [a if a != "--priority" else "-p" for a in spec["args"]]
+    if "-q" in args:
+        pytest.skip("the command-line compressor has no -q yet") if not _cli_has("-q") else None
+    arc, out = str(tmp_path / "a.colord"), str(tmp_path / "o.fastq")
+    subprocess.check_call([CLI] + args + [fq, arc])
+    subprocess.check_call([CLI, "decompress", arc, out])
+    assert sha(out) == spec["decompressed_sha256"]
+
+
+def _cli_has(flag):
+    r = subprocess.run([CLI], capture_output=True, text=True)
+    return flag in (r.stderr + r.stdout)
+
+
+def _fixture(tmp_path, name="M.bovis.fastq", n_reads=0):
+    import gzip
+    lines = gzip.open(os.path.join(ROOT, "tests", "data", name + ".gz"), "rb").read().split(b"\n")
+    lines = lines[:4 * n_reads] if n_reads else lines[:-1]
+    fq = str(tmp_path / name)
+    open(fq, "wb").write(b"\n".join(lines) + b"\n")
+    return fq, lines
+
+
+def _same_streams(ref_arc, my_arc):
+    a, b = AR.read_archive(ref_arc), AR.read_archive(my_arc)
+    assert set(a) == set(b)
+    for name in a:
+        if name != "info":
+            assert [(m, hashlib.sha256(p).hexdigest()) for m, p in a[name].parts] == [(m, hashlib.sha256(p).hexdigest()) for m, p in b[name].parts], name
+
+
+@pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(CLI)), reason="needs oracle/_ref/colord and colord_amd/colord_hip")
+@pytest.mark.parametrize("extra", [["-q", "org"], ["-q", "5-avg", "-p", "balanced"], ["-q", "2-avg", "-p", "ratio"], ["-q", "5-fix"], ["-q", "4-fix", "-p", "balanced"], ["-q", "2-fix", "-T", "11", "-D", "2", "20"],
+                                   ["-q", "avg"], ["-q", "none", "-D", "5"], ["-q", "4-avg", "-T", "5", "12", "30"], ["-i", "none"], ["-i", "main", "-c", "3"], ["-k", "18", "-a", "15", "-f", "7", "-L", "3", "-H", "60"],
+                                   ["-R", "all", "-r", "2", "--min-to-alt", "40"], ["-g", "2.5", "-x", "1.5", "-e", "1.2"]])
+def test_cli_options_reproduce_the_reference(tmp_path, extra):
+    """Every option of the compress sub-commands that changes the archive: same streams as the reference, and this build's
+    decompressor returns what the reference's returns."""
+    fq, _ = _fixture(tmp_path)
+    ref_arc, ref_out, my_arc, my_out = (str(tmp_path / x) for x in ("ref.colord", "ref.fastq", "gpu.colord", "gpu.fastq"))
+    subprocess.check_call([REF, "compress-ont", "-t", "4"] + extra + [fq, ref_arc], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.check_call([REF, "decompress", ref_arc, ref_out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.check_call([CLI, "compress-ont"] + extra + [fq, my_arc])
+    _same_streams(ref_arc, my_arc)
+    subprocess.check_call([CLI, "decompress", my_arc, my_out])
+    assert sha(my_out) == sha(ref_out)
+
+
+@pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(CLI)), reason="needs oracle/_ref/colord and colord_amd/colord_hip")
+@pytest.mark.parametrize("variant", ["fasta", "fasta_multiline_crlf", "fastq_crlf_blank_lines", "fastq_plus_repeats_id", "fastq_gz"])
+def test_cli_input_formats(tmp_path, variant):
+    """The reader's semantics (in_reads.cpp:62-226): FASTA and multi-line FASTA, CR LF, blank lines, '+' line equal to the id, gzip."""
+    import gzip
+    fq, lines = _fixture(tmp_path, "A.thaliana.fastq")
+    recs = [lines[i:i + 4] for i in range(0, len(lines), 4)]
+    if variant == "fasta":
+        data = b"".join(b">" + r[0][1:] + b"\n" + r[1] + b"\n" for r in recs)
+        src = str(tmp_path / "in.fasta")
+    elif variant == "fasta_multiline_crlf":
+        data = b"".join(b">" + r[0][1:] + b"\r\n" + b"\r\n".join(r[1][i:i + 70] for i in range(0, len(r[1]), 70)) + b"\r\n\r\n" for r in recs)
+        src = str(tmp_path / "in.fasta")
+    elif variant == "fastq_crlf_blank_lines":
+        data = b"".join(b"\r\n".join(r) + b"\r\n" for r in recs) + b"\r\n\r\n"      # (CR LF + a blank line after EVERY record crashes the reference's k-mer counter)
+        src = str(tmp_path / "in.fastq")
+    elif variant == "fastq_plus_repeats_id":
+        data = b"".join(r[0] + b"\n" + r[1] + b"\n+" + r[0][1:] + b"\n" + r[3] + b"\n" for r in recs)
+        src = str(tmp_path / "in.fastq")
+    else:
+        data = b"\n".join(lines) + b"\n"
+        src = str(tmp_path / "in.fastq.gz")
+    if src.endswith(".gz"):
+        gzip.open(src, "wb").write(data)
+    else:
+        open(src, "wb").write(data)
+    ref_arc, ref_out, my_arc, my_out = (str(tmp_path / x) for x in ("ref.colord", "ref.out", "gpu.colord", "gpu.out"))
+    subprocess.check_call([REF, "compress-pbraw", "-t", "4", src, ref_arc], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.check_call([REF, "decompress", ref_arc, ref_out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.check_call([CLI, "compress-pbraw", src, my_arc])
+    _same_streams(ref_arc, my_arc)
+    subprocess.check_call([CLI, "decompress", my_arc, my_out])
+    assert sha(my_out) == sha(ref_out)
+
+
+@pytest.mark.skipif(not os.path.exists(CLI), reason="needs colord_amd/colord_hip")
+def test_cli_rejects_what_the_reference_rejects(tmp_path):
+    fq, lines = _fixture(tmp_path, n_reads=8)
+    low = lines[:]
+    low[1] = low[1][:50] + low[1][50:60].lower() + low[1][60:]                  # lower-case bases: SymbToBinMap has no entry (utils.h:472-475)
+    open(str(tmp_path / "low.fastq"), "wb").write(b"\n".join(low) + b"\n")
+    r = subprocess.run([CLI, "compress-ont", str(tmp_path / "low.fastq"), str(tmp_path / "o.colord")], capture_output=True, text=True)
+    assert r.returncode == 1 and "Only ACGTN symbols supported inside a read" in r.stderr
+    badq = lines[:]
+    badq[3] = badq[3][:10] + b"\x1f" + badq[3][11:]                             # a quality byte below '!'
+    open(str(tmp_path / "badq.fastq"), "wb").write(b"\n".join(badq) + b"\n")
+    r = subprocess.run([CLI, "compress-ont", str(tmp_path / "badq.fastq"), str(tmp_path / "o.colord")], capture_output=True, text=True)
+    assert r.returncode == 1 and "quality" in r.stderr
+    plus = lines[:]
+    plus[2] = b"+something_else"
+    open(str(tmp_path / "plus.fastq"), "wb").write(b"\n".join(plus) + b"\n")
+    r = subprocess.run([CLI, "compress-ont", str(tmp_path / "plus.fastq"), str(tmp_path / "o.colord")], capture_output=True, text=True)
+    assert r.returncode == 1 and "quality header not empty but different than read header" in r.stderr
+    open(str(tmp_path / "trunc.fastq"), "wb").write(b"\n".join(lines[:-2]) + b"\n")
+    r = subprocess.run([CLI, "compress-ont", str(tmp_path / "trunc.fastq"), str(tmp_path / "o.colord")], capture_output=True, text=True)
+    assert r.returncode == 1 and "truncated" in r.stderr
+
+
+@pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(CLI)), reason="needs oracle/_ref/colord and colord_amd/colord_hip")
+def test_cli_several_chunks_equal_one(tmp_path):
+    """--chunk-bases cuts the input into several chunks of the streaming compressor: same archive (and the reference's)."""
+    rs = make_reads(seed=21, genome_len=400_000, target_bases=30_000_000, mean_scale=9000.0)
+    fq = str(tmp_path / "in.fastq")
+    write_fastq(fq, rs)
+    ref_arc, one, many = (str(tmp_path / x) for x in ("ref.colord", "one.colord", "many.colord"))
+    subprocess.check_call([REF, "compress-ont", "-t", "8", fq, ref_arc], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.check_call([CLI, "compress-ont", fq, one])
+    r = subprocess.run([CLI, "compress-ont", "--chunk-bases", "9e6", fq, many], capture_output=True, text=True)
+    assert r.returncode == 0 and "3 chunk(s)" in r.stderr, r.stderr
+    _same_streams(ref_arc, one)
+    _same_streams(ref_arc, many)

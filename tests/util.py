@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
 DATA = os.path.join(ROOT, "tests", "data")
 
-ALL_CONFIGS = sorted(d for d in os.listdir(GOLD) if os.path.isdir(os.path.join(GOLD, d)))
+ALL_CONFIGS = sorted(d for d in os.listdir(GOLD) if os.path.exists(os.path.join(GOLD, d, "streams.json")))
 # configs without a reference genome (pseudo reads need the genome cutter)
 PLAIN_CONFIGS = [c for c in ALL_CONFIGS if "genome" not in c]
 
