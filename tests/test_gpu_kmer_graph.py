@@ -63,15 +63,16 @@ def test_arena_layout(ctx, cfg):
 
 
 def test_arena_ascii_and_errors(ctx):
-    seq = b"ACGTNacgtnAC"
+    seq = b"ACGTNACGTNAC"
     codes = torch.tensor(list(seq), dtype=torch.uint8)
     off = torch.tensor([0, 5, 12], dtype=torch.int64)
     r = ctx.pack_reads(codes, off, ascii=True)
     assert r.has_n().cpu().tolist() == [1, 1]
     r.free()
     from colord_amd._native import ColordHipError
-    with pytest.raises(ColordHipError, match="Only ACGTN"):   # in_reads.cpp:31-35
-        ctx.pack_reads(torch.tensor(list(b"ACGX"), dtype=torch.uint8), torch.tensor([0, 4], dtype=torch.int64), ascii=True)
+    for bad in (b"ACGX", b"ACgT"):                             # in_reads.cpp:31-35; lower case has no entry in SymbToBinMap (utils.h:472-475)
+        with pytest.raises(ColordHipError, match="Only ACGTN"):
+            ctx.pack_reads(torch.tensor(list(bad), dtype=torch.uint8), torch.tensor([0, 4], dtype=torch.int64), ascii=True)
     e = ctx.pack_reads(torch.zeros(0, dtype=torch.uint8), torch.zeros(1, dtype=torch.int64))
     assert e.n_reads == 0 and e.total_words == 0
     assert ctx.kmer_scan(e, 20, 12).numel() == 0
