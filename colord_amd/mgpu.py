@@ -1,0 +1,276 @@
+"""Multi-GPU compress driver: one process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI), reads sharded in file
+order, ONE archive written by rank 0.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 -m colord_amd.mgpu \\
+        compress-ont [-p ratio|balanced|memory] [-q MODE] [--chunk-bases X] input.fastq[.gz] output.colord
+
+What is sharded and what is exchanged (the exchanges themselves are cl_exchange callbacks of the library's
+chunked compressor, csrc/stream.hip, carried out by colord_amd.parallel.TorchExchange):
+  * rank r compresses the r-th contiguous range of the file (equal shares of the bases), chunk by chunk;
+  * k-mers go to the rank owning their key range, kept keys are all-gathered  -> replicated k-mer set;
+  * reference reads and their index entries are all-gathered                   -> replicated reference store + index,
+    so every read sees exactly the candidates the single-process run gives it (tuple streams are identical);
+  * each rank is ONE MODEL DOMAIN of the DNA and quality coders (its adaptive models start fresh at its first read): the only
+    place sharding changes bytes.  The archive records the first `dna` part of every domain in an extra stream `hipdomains`
+    (u32 n, then per domain u64 first read, u64 first part); `colord_hip decompress` restarts its models there.  With one rank the
+    archive is the reference's format byte for byte; with several, the reference's decompressor cannot decode it (it has one
+    model set for the whole stream) — this build's decompressor can;
+  * compressed parts are gathered to rank 0 (point-to-point sends), which adds the `header`, `meta` and `info` streams.
+Host-side plumbing in Python; every byte of `dna` / `qual` comes from the HIP library, `header` from its host id coder.
+"""
+from __future__ import annotations
+import ctypes as C
+import os
+import struct
+import sys
+import time
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _native as N, archive as AR, parallel as par
+from .fastq import ReadSet, read_fastx
+
+# arg_parse.cpp:89-408 — [source][priority]: level, ci, cs, f, c, max_rec, min_part_alt, qual_mode, sparse, g
+PRESETS = {
+    0: {"ratio": (3, 2, 120, 8, 10, 6, 48, 2, 0, 1), "balanced": (2, 3, 100, 9, 8, 5, 48, 2, 1, 2), "memory": (1, 4, 80, 12, 5, 3, 64, 2, 1, 1)},
+    1: {"ratio": (3, 2, 120, 8, 10, 6, 48, 8, 0, 1), "balanced": (2, 3, 100, 9, 8, 5, 48, 8, 1, 2), "memory": (1, 4, 80, 12, 5, 3, 64, 8, 1, 1)},
+    2: {"ratio": (3, 2, 150, 20, 12, 6, 48, 1, 0, 1), "balanced": (2, 3, 120, 30, 10, 5, 48, 1, 1, 6), "memory": (2, 3, 100, 40, 8, 5, 48, 1, 1, 3)},
+}
+QUAL_NAMES = ["org", "5-avg", "4-avg", "2-avg", "5-fix", "4-fix", "2-fix", "avg", "none"]
+QUAL_DEFAULTS = {0: ((), ()), 1: ((7, 14, 26, 93), ()), 2: ((7, 14, 26), ()), 3: ((7,), ()), 4: ((7, 14, 26, 93), (3, 10, 18, 35, 93)),
+                 5: ((7, 14, 26), (3, 10, 18, 35)), 6: ((7,), (1, 13)), 7: ((), ()), 8: ((), (0,))}
+READS_PACK = 2 << 21
+
+
+def kmer_anchor_len(est_bases: float):
+    for lim, k, a in ((1e9, 20, 16), (4e9, 21, 18), (16e9, 23, 21), (48e9, 24, 22), (128e9, 25, 22)):
+        if est_bases < lim:
+            return k, a
+    return 26, 23
+
+
+def _packs(lens: np.ndarray, size: int = READS_PACK) -> np.ndarray:
+    """Reader packs (in_reads.cpp:62-77): a pack closes once sum(len + 1) >= 4 Mi."""
+    acc = np.cumsum(lens.astype(np.int64) + 1)
+    out, base = [0], 0
+    while True:
+        i = int(np.searchsorted(acc, base + size, side="left"))
+        if i >= len(acc):
+            break
+        out.append(i + 1)
+        base = int(acc[i])
+    if out[-1] != len(lens):
+        out.append(len(lens))
+    return np.asarray(out, dtype=np.uint32)
+
+
+def encode_headers(headers, plus_eq, header_mode: int):
+    """The `header` stream (CEntrComprHeaders, entr_header.cpp:23-45): packs of >= 4 Mi id bytes -> [(n ids, payload)]."""
+    lib = N.load()
+    h = N._P()
+    if lib.cl_id_coder_create(header_mode, C.byref(h)) != 0:
+        raise RuntimeError("cl_id_coder_create")
+    parts, i, n = [], 0, len(headers)
+    try:
+        while i < n:
+            j, acc = i, 0
+            while j < n:
+                acc += len(headers[j]); j += 1
+                if acc >= READS_PACK:
+                    break
+            ids = np.frombuffer(b"".join(headers[i:j]), np.uint8)
+            off = np.concatenate([[0], np.cumsum([len(x) for x in headers[i:j]])]).astype(np.uint64)
+            plus = np.asarray(plus_eq[i:j], np.uint8)
+            out = np.empty(2 * len(ids) + 64, np.uint8)
+            got = C.c_uint64(0)
+            if lib.cl_id_encode_part(h, ids.ctypes.data if len(ids) else None, off.ctypes.data, plus.ctypes.data, j - i, out.ctypes.data, len(out), C.byref(got)) != 0:
+                raise RuntimeError("header stream: " + lib.cl_id_coder_error(h).decode())
+            parts.append((j - i, out[:got.value].tobytes()))
+            i = j
+    finally:
+        lib.cl_id_coder_free(h)
+    return parts
+
+
+def compress_readset(rs: ReadSet, out_path: str | None, source: int = 0, priority: str = "memory", qual_mode: int | None = None, header_mode: int = 0,
+                     k: int = 0, a: int = 0, chunk_bases: float = 1.0e9, est_bases: float | None = None, command: str = "", file_bytes: int = 0, device: int | None = None):
+    """Compresses `rs` (every rank holds the same ReadSet; each takes its share).  Rank 0 writes out_path and returns a dict of sizes."""
+    from .device import Context
+    world, rank = par.world(), par.rank()
+    local = int(os.environ.get("LOCAL_RANK", "0")) if device is None else device
+    if dist.is_initialized() and dist.get_backend() != "nccl":
+        local %= torch.cuda.device_count()
+    level, ci, cs, f, c, max_rec, min_alt, qm, sparse, g = PRESETS[source][priority]
+    qm = qm if qual_mode is None else qual_mode
+    lens_all = np.diff(rs.offsets).astype(np.int64)
+    if not k:
+        k, a = kmer_anchor_len(est_bases if est_bases is not None else float(lens_all.sum()))
+    prm = dict(k=k, f=f, ci=ci, cs=cs, c=c, anchor_len=a, min_part_alt=min_alt, max_rec=max_rec, min_anchors=1, level=level, source=source, sparse=sparse,
+               sparse_g=float(g), sparse_exponent=1.0, cost_mult=1.0, frac_always=0.9, frac_min=0.5, max_matches_mult=10.0)
+    with_qual = rs.is_fastq and rs.quals is not None
+    qd = QUAL_DEFAULTS[qm]
+    qargs = (qm, source, level, qd[0], qd[1]) if with_qual else None
+    # this rank's contiguous share of the file
+    acc = np.cumsum(lens_all)
+    r0 = int(np.searchsorted(acc, acc[-1] * rank / world, side="left")) if rank else 0
+    r1 = int(np.searchsorted(acc, acc[-1] * (rank + 1) / world, side="left")) if rank + 1 < world else rs.n_reads
+    lens = lens_all[r0:r1]
+    packs = _packs(lens)
+    cacc = np.concatenate([[0], np.cumsum(lens)])
+    cuts, target = [0], chunk_bases
+    for p in range(1, len(packs)):
+        if cacc[packs[p]] >= target or p == len(packs) - 1:
+            cuts.append(p)
+            target = cacc[packs[p]] + chunk_bases
+    ctx = Context(local)
+    qctx = Context(local) if level == 1 and with_qual else None
+    exchange = par.TorchExchange(ctx.device) if world > 1 else None
+    chunks = []
+    for ca, cb in zip(cuts[:-1], cuts[1:]):
+        a_, b_ = r0 + int(packs[ca]), r0 + int(packs[cb])
+        o0, o1 = int(rs.offsets[a_]), int(rs.offsets[b_])
+        off = torch.from_numpy((rs.offsets[a_:b_ + 1] - o0).astype(np.int64)).to(ctx.device)
+        arena = ctx.pack_reads(torch.from_numpy(rs.bases[o0:o1]), off)
+        q = torch.from_numpy(rs.quals[o0:o1]).to(ctx.device) if with_qual else None
+        chunks.append((arena, (packs[ca:cb + 1] - packs[ca]).astype(np.uint32), q, off))
+    cmp_ = ctx.compressor(prm, qargs, qctx, exchange, expected_bases=int(lens.sum()))
+    try:
+        for ch in chunks:
+            cmp_.count_add(ch[0])
+        cmp_.count_finish()
+        for ch in chunks:
+            cmp_.refs_add(ch[0])
+        cmp_.refs_finish()
+        dna, qual, dsz, qsz, counts = [], [], [], [], []
+        for arena, pb, q, off in chunks:
+            d, ds, qq, qs, _ = cmp_.encode(arena, pb, pb, q, off)
+            dna.append(d.clone()); dsz += [int(x) for x in ds]; counts += [int(x) for x in np.diff(pb)]
+            if with_qual:
+                qual.append(qq.clone()); qsz += [int(x) for x in qs]
+        info = cmp_.info()
+    except Exception:
+        if exchange is not None and exchange.err is not None:
+            raise exchange.err
+        raise
+    finally:
+        cmp_.free()
+        for ch in chunks:
+            ch[0].free()
+    empty = torch.empty(0, dtype=torch.uint8, device=ctx.device)
+    dna = torch.cat(dna) if dna else empty
+    qual = torch.cat(qual) if qual else empty
+    # SURVEY §8e "collective for results": payloads and part tables of every rank to rank 0
+    tab = torch.tensor([len(dsz)] + dsz + counts + (qsz if with_qual else []), dtype=torch.int64, device=ctx.device)
+    g_dna = par.gather_to_root(dna)
+    g_qual = par.gather_to_root(qual) if with_qual else None
+    g_tab = par.gather_to_root(tab.view(torch.uint8))
+    res = None
+    if rank == 0:
+        d_st, q_st = AR.Stream("dna"), AR.Stream("qual")
+        domains, first_read = [], 0
+        reads_per_rank = []
+        for r in range(world):
+            t = g_tab[r].view(torch.int64).cpu().numpy()
+            np_ = int(t[0]); ds = t[1:1 + np_]; cn = t[1 + np_:1 + 2 * np_]; qs = t[1 + 2 * np_:1 + 3 * np_] if with_qual else None
+            domains.append((first_read, len(d_st.parts)))
+            raw = g_dna[r].cpu().numpy().tobytes(); o = 0
+            for s_, n_ in zip(ds, cn):
+                d_st.parts.append((int(n_), raw[o:o + int(s_)])); o += int(s_)
+            if with_qual:
+                raw = g_qual[r].cpu().numpy().tobytes(); o = 0
+                for s_ in qs:
+                    q_st.parts.append((0, raw[o:o + int(s_)])); o += int(s_)
+            first_read += int(cn.sum()); reads_per_rank.append(int(cn.sum()))
+        assert first_read == rs.n_reads
+        h_st = AR.Stream("header"); h_st.parts = encode_headers(rs.headers, rs.plus_eq, header_mode)
+        n = rs.n_reads
+        tot_ref = n
+        if sparse:
+            accd = np.zeros(n, np.uint8)
+            N.load().cl_ref_accept(n, 0, info["sparse_range"], 1.0, accd.ctypes.data)
+            tot_ref = int(accd.sum())
+        meta = struct.pack("<IIiBQ", tot_ref, c, level, source, n * info["mean_read_len"])      # compression.cpp:704-779
+        if with_qual:
+            meta += bytes([qm])
+            if qm in (8, 4, 5, 6):
+                meta += b"".join(struct.pack("<I", v) for v in qd[1])
+        meta += bytes([header_mode, 1 if sparse else 0])
+        if sparse:
+            meta += struct.pack("<Id", info["sparse_range"], 1.0)
+        meta += b"\0"
+        m_st = AR.Stream("meta"); m_st.parts = [(0, meta)]
+        cmd = command.encode()
+        inf = struct.pack("<IIIQQIQI", 1, 2, 1, file_bytes, int(lens_all.sum()), n, int(time.time()), len(cmd)) + cmd      # utils.cpp:326-342
+        i_st = AR.Stream("info"); i_st.parts = [(0, inf)]
+        streams = [m_st, h_st, d_st] + ([q_st] if with_qual else [])
+        if world > 1:
+            dom = AR.Stream("hipdomains")
+            dom.parts = [(0, struct.pack("<I", world) + b"".join(struct.pack("<QQ", fr, fp) for fr, fp in domains))]
+            streams.append(dom)
+        streams.append(i_st)
+        if out_path:
+            AR.write_archive(out_path, streams)
+        res = dict(n_reads=n, n_bases=int(lens_all.sum()), k=k, a=a, dna_bytes=sum(len(p) for _, p in d_st.parts), qual_bytes=sum(len(p) for _, p in q_st.parts),
+                   header_bytes=sum(len(p) for _, p in h_st.parts), dna_parts=len(d_st.parts), refs=info["n_refs_total"], domains=domains, reads_per_rank=reads_per_rank,
+                   exchanged_bytes_rank0=exchange.bytes_moved if exchange else 0)
+    ctx.close()
+    if qctx is not None:
+        qctx.close()
+    return res
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if not argv or argv[0] not in ("compress-ont", "compress-pbraw", "compress-pbhifi"):
+        print(__doc__, file=sys.stderr)
+        return 1
+    source = {"compress-ont": 0, "compress-pbraw": 1, "compress-pbhifi": 2}[argv[0]]
+    prio, qm, hm, chunk, k, a, pos = "memory", None, 0, 1.0e9, 0, 0, []
+    i = 1
+    while i < len(argv):
+        x = argv[i]
+        if x in ("-p", "--priority"):
+            prio = argv[i + 1]; i += 2
+        elif x in ("-q", "--qual"):
+            qm = QUAL_NAMES.index(argv[i + 1]); i += 2
+        elif x in ("-i", "--identifier"):
+            hm = ["org", "main", "none"].index(argv[i + 1]); i += 2
+        elif x in ("-k", "--kmer-len"):
+            k = int(argv[i + 1]); i += 2
+        elif x in ("-a", "--anchor-len"):
+            a = int(argv[i + 1]); i += 2
+        elif x == "--chunk-bases":
+            chunk = float(argv[i + 1]); i += 2
+        else:
+            pos.append(x); i += 1
+    if len(pos) != 2 or bool(k) != bool(a):
+        print("expected input and output paths (and -k together with -a)", file=sys.stderr)
+        return 1
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = os.environ.get("COLORD_BACKEND", "nccl")
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            torch.cuda.set_device(local % torch.cuda.device_count())
+            dist.init_process_group(backend)
+    t0 = time.time()
+    rs = read_fastx(pos[0])
+    size = os.path.getsize(pos[0])
+    gz = open(pos[0], "rb").read(2) == b"\x1f\x8b"
+    est = size * ((2.08 if rs.is_fastq else 3.98) if gz else (0.49 if rs.is_fastq else 0.98))      # compression.cpp:52-61
+    res = compress_readset(rs, pos[1], source, prio, qm, hm, k, a, chunk, est, "colord_amd.mgpu " + " ".join(argv), size)
+    if res is not None:
+        print(f"colord_amd.mgpu: {res['n_reads']} reads, {res['n_bases']} bases on {world} GPU(s), k={res['k']} a={res['a']}; dna {res['dna_bytes']} B ({res['dna_parts']} parts), "
+              f"qual {res['qual_bytes']} B, header {res['header_bytes']} B; {res['refs']} reference reads; {time.time() - t0:.2f} s", file=sys.stderr)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,79 @@
+"""Multi-GPU product path (colord_amd/mgpu.py + cl_exchange callbacks of csrc/stream.hip) on ONE GPU: the ranks share the device
+and the collectives run over gloo (same code path as RCCL: TorchExchange only changes how bytes move).
+  * one rank: the archive is the reference's, stream by stream;
+  * two ranks: the k-mer set, the reference reads and the index are replicated through the exchanges, every rank is one model
+    domain; `colord_hip decompress` returns the input, and the archive stays within 1 % of the one-rank archive."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import numpy as np
+import pytest
+from colord_amd import archive as AR, ontsim
+from colord_amd.fastq import read_fastx, write_fastq
+from colord_amd.synth import make_reads
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "colord_amd", "colord_hip")
+
+
+def sha(path):
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()
+
+
+def run_ranks(n, args, port):
+    env = dict(os.environ, COLORD_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           "-m", "colord_amd.mgpu"] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return r.stderr
+
+
+def test_one_rank_archive_is_the_reference_archive(tmp_path):
+    spec = json.load(open(os.path.join(ROOT, "tests", "golden", "s6m_ont", "streams.json")))
+    fq = str(tmp_path / "in.fastq")
+    write_fastq(fq, make_reads(**spec["synth"]))
+    from colord_amd.mgpu import compress_readset
+    arc = str(tmp_path / "one.colord")
+    res = compress_readset(read_fastx(fq), arc, est_bases=0.49 * os.path.getsize(fq), device=0)
+    assert res["dna_parts"] == len(spec["streams"]["dna"]["parts"])
+    a = AR.read_archive(arc)
+    assert "hipdomains" not in a
+    for name in ("meta", "dna", "qual", "header"):
+        assert [[m, len(p), hashlib.sha256(p).hexdigest()] for m, p in a[name].parts] == spec["streams"][name]["parts"], name
+
+
+@pytest.mark.parametrize("n_ranks", [2, 3])
+def test_ranks_on_golden_decode_to_the_reference_output(tmp_path, n_ranks):
+    """4-avg qualities are quantised per read, so the decoded FASTQ of a multi-domain archive must be exactly what the reference
+    returns for its own archive of the same input."""
+    spec = json.load(open(os.path.join(ROOT, "tests", "golden", "s6m_ont", "streams.json")))
+    fq, arc, out = (str(tmp_path / x) for x in ("in.fastq", "r.colord", "r.fastq"))
+    write_fastq(fq, make_reads(**spec["synth"]))
+    run_ranks(n_ranks, ["compress-ont", "--chunk-bases", "1.5e6", fq, arc], 29610 + n_ranks)
+    a = AR.read_archive(arc)
+    assert "hipdomains" in a and int.from_bytes(a["hipdomains"].parts[0][1][:4], "little") == n_ranks
+    subprocess.check_call([CLI, "decompress", arc, out])
+    assert sha(out) == spec["decompressed_sha256"]
+    # same reads coded against references, same candidates: the tuple streams do not depend on the sharding; only the coders' model domains do
+    ref_total = sum(p[1] for p in spec["streams"]["dna"]["parts"]) + sum(p[1] for p in spec["streams"]["qual"]["parts"])
+    got_total = sum(len(p) for _, p in a["dna"].parts) + sum(len(p) for _, p in a["qual"].parts)
+    assert got_total < ref_total * 1.08                      # 6 Mbases in 2-3 domains: the loss shrinks with the domain size (next test)
+
+
+def test_two_ranks_200_mbases_lossless_and_within_one_percent(tmp_path):
+    t = ontsim.ReadTable(seed=11, genome_len=12_000_000, target_bases=200_000_000)
+    fq, one, two, out = (str(tmp_path / x) for x in ("in.fastq", "one.colord", "two.colord", "two.fastq"))
+    ontsim.write_fastq(t, fq)
+    subprocess.check_call([CLI, "compress-ont", "-q", "org", fq, one])
+    log = run_ranks(2, ["compress-ont", "-q", "org", "--chunk-bases", "4e7", fq, two], 29620)
+    subprocess.check_call([CLI, "decompress", two, out])
+    assert sha(out) == sha(fq)                               # -q org: bit-exact round trip
+    s1, s2 = os.path.getsize(one), os.path.getsize(two)
+    print(f"one rank {s1} B, two ranks {s2} B: {100.0 * (s2 / s1 - 1):+.3f} %; {log.strip().splitlines()[-1]}")
+    assert s2 <= s1 * 1.01
+    a, b = AR.read_archive(one), AR.read_archive(two)
+    assert [m for m, _ in a["dna"].parts] != [] and sum(m for m, _ in a["dna"].parts) == sum(m for m, _ in b["dna"].parts) == t.n_reads
