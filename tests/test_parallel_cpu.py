@@ -83,3 +83,53 @@ def test_two_rank_exchanges_equal_single_process(cfg):
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), cfg, ret), nprocs=world, join=True)
     assert dict(ret) == {0: (True, True), 1: (True, True)}
+
+
+def _exchange_worker(rank, world, port, ret):
+    """The three cl_exchange callbacks (what csrc/stream.hip calls through the C struct) on host pointers, ragged sizes."""
+    import ctypes as C
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from colord_amd import parallel as par
+    ex = par.TorchExchange(None)
+    X = ex.c_struct
+    ok = X.rank == rank and X.world == world
+    U64P = C.POINTER(C.c_uint64)
+    # all_gather_host: 3 values per rank, rank order
+    mine = np.array([rank + 1, 10 * (rank + 1), 2 ** 40 + rank], np.uint64)
+    out = np.zeros(3 * world, np.uint64)
+    ok &= X.all_gather_host(None, mine.ctypes.data_as(U64P), 3, out.ctypes.data_as(U64P)) == 0
+    ok &= np.array_equal(out, np.concatenate([[r + 1, 10 * (r + 1), 2 ** 40 + r] for r in range(world)]).astype(np.uint64))
+    # all_to_all_v: rank r sends (r + 1) * (d + 2) k-mers to rank d (8-byte elements, ragged, one empty pair)
+    cnt = lambda s, d: 0 if (s, d) == (1, 0) else (s + 1) * (d + 2)
+    send = np.concatenate([np.full(cnt(rank, d), 1000 * rank + d, np.uint64) for d in range(world)] + [np.empty(0, np.uint64)])
+    sb = np.array([8 * cnt(rank, d) for d in range(world)], np.uint64)
+    rb = np.array([8 * cnt(s, rank) for s in range(world)], np.uint64)
+    recv = np.zeros(int(rb.sum()) // 8, np.uint64)
+    ok &= X.all_to_all_v(None, send.ctypes.data, sb.ctypes.data_as(U64P), recv.ctypes.data, rb.ctypes.data_as(U64P)) == 0
+    ok &= np.array_equal(recv, np.concatenate([np.full(cnt(s, rank), 1000 * s + rank, np.uint64) for s in range(world)] + [np.empty(0, np.uint64)]))
+    # all_gather_v: odd byte counts (no padding to the largest shard), one rank contributes nothing
+    n_of = lambda r: 0 if r == 1 else 5 + 7 * r
+    mine_b = np.full(n_of(rank), 65 + rank, np.uint8)
+    rbb = np.array([n_of(r) for r in range(world)], np.uint64)
+    got = np.zeros(int(rbb.sum()), np.uint8)
+    ok &= X.all_gather_v(None, mine_b.ctypes.data if len(mine_b) else None, len(mine_b), got.ctypes.data, rbb.ctypes.data_as(U64P)) == 0
+    ok &= np.array_equal(got, np.concatenate([np.full(n_of(r), 65 + r, np.uint8) for r in range(world)]))
+    ok &= ex.err is None and ex.bytes_moved == (int(rb.sum()) - int(rb[rank])) + (int(rbb.sum()) - n_of(rank))
+    # gather_to_root: variable-length payloads to rank 0
+    parts = par.gather_to_root(torch.full((3 + 4 * rank,), rank, dtype=torch.uint8))
+    if rank == 0:
+        ok &= [p.tolist() for p in parts] == [[r] * (3 + 4 * r) for r in range(world)]
+    else:
+        ok &= parts is None
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_exchange_callbacks_over_gloo(world):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_exchange_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {r: True for r in range(world)}
