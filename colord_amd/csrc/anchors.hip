@@ -30,8 +30,9 @@ struct cl_anchors {
 };
 
 namespace {
-constexpr uint32_t POS_BITS = 20;                 // reads < 2^20 bases in this kernel family
-constexpr uint64_t POS_MASK = (1ull << POS_BITS) - 1;
+// Match pairs are 64-bit sort keys  task | position in the read (pe bits) | ~position in the candidate (pr bits).  pe / pr are
+// chosen per call / per batch from the longest candidate / read (TaskCfg), so ultra-long ONT reads only cost sort key bits where
+// they occur, and the usual reads (< 2^18 bases) sort one radix pass less than a fixed 2 x 20 bits would.
 
 struct Arena { const uint64_t* packed; const uint64_t* word_off; const uint32_t* lens; };
 
@@ -85,7 +86,6 @@ __global__ void k_table_sizes(const uint32_t* __restrict__ lens, const uint8_t* 
 	if (r >= r1) return;
 	uint32_t len = lens[r];
 	bool active = ncand[r] > 0 && !has_n[r] && len >= m;
-	if (active && len >= (1u << POS_BITS)) { atomicOr(err, 1u); active = false; }
 	uint32_t n = active ? len - m + 1 : 0;
 	uint32_t t = 0;
 	if (n) { t = 16; while (t < 2 * n + n / 2) t <<= 1; }
@@ -184,7 +184,7 @@ __device__ inline uint2 table_heads(const EncTable& T, uint64_t t0, uint32_t tsz
 // Pairs go to one array in any order (they are sorted by (task, read position, ~reference position) next): a wave
 // reserves room for the hits of its 64 probes with one atomic add.  The total is counted past the capacity too, so the
 // caller can repeat the pass with enough room.
-struct TaskCfg { uint32_t r0, r1, c, m; float pad; double frac_always, frac_min, max_mult; };
+struct TaskCfg { uint32_t r0, r1, c, m; uint32_t pe, pr; double frac_always, frac_min, max_mult; };
 
 // One BLOCK per read.  Nearly all probes miss (a candidate shares a stretch with the read, not its whole length), and a
 // miss in the read's table in HBM costs a random 64-byte line and, worse, its latency: the 64 probes of a wave step wait
@@ -240,7 +240,8 @@ __global__ __launch_bounds__(256) void k_match(Arena A, Arena R, EncTable T, Tas
 		if (rlen < cfg.m) continue;
 		const uint64_t rwb = R.word_off[id];
 		const uint32_t nq = rlen - cfg.m + 1, sl = rl * cfg.c + slot;
-		const uint64_t key_rev = (uint64_t)(2 * sl) << (2 * POS_BITS), key_fwd = (uint64_t)(2 * sl + 1) << (2 * POS_BITS);
+		const uint32_t PR = cfg.pr; const uint32_t pr_mask = (1u << PR) - 1;
+		const uint64_t key_rev = (uint64_t)(2 * sl) << (cfg.pe + PR), key_fwd = (uint64_t)(2 * sl + 1) << (cfg.pe + PR);
 		if (threadIdx.x == 0) atomicAdd(n_pairs + 1, (unsigned long long)nq);      // probes, for the achieved-bandwidth report
 		// the words of the next step are loaded while this one is worked on (the block streams through the candidate:
 		// every step is a new line)
@@ -271,15 +272,15 @@ __global__ __launch_bounds__(256) void k_match(Arena A, Arena R, EncTable T, Tas
 			hi = hi2; lo = lo2;
 			if (!__any(cnt != 0)) continue;
 			const uint32_t incl = wave_incl_scan(cnt), tot = __shfl(incl, 63, 64);
-			const uint64_t kf = key_fwd | (uint64_t)(~q & (uint32_t)POS_MASK), kr = key_rev | (uint64_t)(~(nq - 1 - q) & (uint32_t)POS_MASK);
+			const uint64_t kf = key_fwd | (uint64_t)(~q & pr_mask), kr = key_rev | (uint64_t)(~(nq - 1 - q) & pr_mask);
 			if (fill + tot > STAGE) flush();
 			if (tot <= STAGE)
 			{
 				uint32_t o = fill + incl - cnt;
-				if (hf != NIL) stage[o++] = kf | ((uint64_t)hf << POS_BITS);
-				for (uint32_t p = nf; p != NIL; p = T.next[n0 + p]) stage[o++] = kf | ((uint64_t)p << POS_BITS);
-				if (hr != NIL) stage[o++] = kr | ((uint64_t)hr << POS_BITS);
-				for (uint32_t p = nr; p != NIL; p = T.next[n0 + p]) stage[o++] = kr | ((uint64_t)p << POS_BITS);
+				if (hf != NIL) stage[o++] = kf | ((uint64_t)hf << PR);
+				for (uint32_t p = nf; p != NIL; p = T.next[n0 + p]) stage[o++] = kf | ((uint64_t)p << PR);
+				if (hr != NIL) stage[o++] = kr | ((uint64_t)hr << PR);
+				for (uint32_t p = nr; p != NIL; p = T.next[n0 + p]) stage[o++] = kr | ((uint64_t)p << PR);
 				fill += tot;
 				continue;
 			}
@@ -289,10 +290,10 @@ __global__ __launch_bounds__(256) void k_match(Arena A, Arena R, EncTable T, Tas
 			base = ((unsigned long long)__shfl((int)(base >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)base, 0, 64);
 			if (base + tot > cap) continue;
 			uint64_t o = base + incl - cnt;
-			if (hf != NIL) pairs[o++] = kf | ((uint64_t)hf << POS_BITS);
-			for (uint32_t p = nf; p != NIL; p = T.next[n0 + p]) pairs[o++] = kf | ((uint64_t)p << POS_BITS);
-			if (hr != NIL) pairs[o++] = kr | ((uint64_t)hr << POS_BITS);
-			for (uint32_t p = nr; p != NIL; p = T.next[n0 + p]) pairs[o++] = kr | ((uint64_t)p << POS_BITS);
+			if (hf != NIL) pairs[o++] = kf | ((uint64_t)hf << PR);
+			for (uint32_t p = nf; p != NIL; p = T.next[n0 + p]) pairs[o++] = kf | ((uint64_t)p << PR);
+			if (hr != NIL) pairs[o++] = kr | ((uint64_t)hr << PR);
+			for (uint32_t p = nr; p != NIL; p = T.next[n0 + p]) pairs[o++] = kr | ((uint64_t)p << PR);
 		}
 	}
 	flush();
@@ -305,7 +306,7 @@ __global__ void k_task_pairs(const uint64_t* __restrict__ pairs, uint64_t n_pair
 	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t > n_tasks) return;
 	auto lower = [&](uint64_t task) -> uint64_t {
-		const uint64_t key = task << (2 * POS_BITS);
+		const uint64_t key = task << (cfg.pe + cfg.pr);
 		uint64_t lo = 0, hi = n_pairs;
 		while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (pairs[mid] < key) lo = mid + 1; else hi = mid; }
 		return lo;
@@ -347,8 +348,9 @@ __global__ __launch_bounds__(64) void k_lis_anchors(Arena A, Arena R, TaskCfg cf
 		const uint32_t n = (uint32_t)(b - a);
 		const uint64_t* P = pairs + a;
 		int* F = tf + a; int* S = ts + a; int* PR = pred + a;
-		auto ref_pos = [&](uint32_t i) -> int { return (int)(~(uint32_t)P[i] & (uint32_t)POS_MASK); };
-		auto enc_pos = [&](uint32_t i) -> uint32_t { return (uint32_t)(P[i] >> POS_BITS) & (uint32_t)POS_MASK; };
+		const uint32_t pr_mask = (1u << cfg.pr) - 1, pe_mask = (1u << cfg.pe) - 1;
+		auto ref_pos = [&](uint32_t i) -> int { return (int)(~(uint32_t)P[i] & pr_mask); };
+		auto enc_pos = [&](uint32_t i) -> uint32_t { return (uint32_t)(P[i] >> cfg.pr) & pe_mask; };
 		F[0] = ref_pos(0); S[0] = 0; PR[0] = -1;
 		int out_len = 1;
 		int last_f = F[0], last_s = 0;                                  // F / S at out_len - 1: the common step (the next match extends
@@ -655,6 +657,15 @@ extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* read
 	Arena A{ reads->packed.p, reads->word_off.p, reads->lens.p }, R{ refs->packed.p, refs->word_off.p, refs->lens.p };
 	std::vector<uint32_t> h_len(nr);
 	if (nr) HIP_TRY(ctx, hipMemcpy(h_len.data(), reads->lens.p, (uint64_t)nr * 4, hipMemcpyDeviceToHost));
+	auto bits_for = [](uint64_t v) -> uint32_t { uint32_t b = 1; while ((1ull << b) <= v) ++b; return b; };       // bits that hold 0..v
+	uint32_t max_ref_len = 0;
+	if (refs->n_reads)
+	{
+		std::vector<uint32_t> rl(refs->n_reads);
+		HIP_TRY(ctx, hipMemcpy(rl.data(), refs->lens.p, (uint64_t)refs->n_reads * 4, hipMemcpyDeviceToHost));
+		for (uint32_t l : rl) max_ref_len = std::max(max_ref_len, l);
+	}
+	const uint32_t pr_bits = bits_for(max_ref_len);
 	// batches of reads: bounded by bases (tables) — the pair count is checked per batch
 	const uint64_t BATCH_BASES = 1ull << 28;
 	std::vector<DevBuf<uint32_t>> chunks; std::vector<uint64_t> chunk_n;
@@ -663,7 +674,7 @@ extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* read
 	// The table build of a batch (random atomics, bound by the memory system) runs on the context's side stream while the
 	// main stream matches, sorts and chains the batch before it (ALU / latency bound): batches are independent.
 	struct TableBatch {
-		uint32_t r0 = 0, r1 = 0; uint64_t acc = 0, nsum = 0;
+		uint32_t r0 = 0, r1 = 0, pe = 1; uint64_t acc = 0, nsum = 0;
 		DevBuf<uint32_t> n_distinct, next, err; DevBuf<uint64_t> toff, noff; DevBuf<EncSlot> slots; DevBuf<uint2> bins;
 		struct SideSync { hipStream_t s = nullptr; ~SideSync() { if (s) (void)hipStreamSynchronize(s); } } sync;   // destroyed first
 	};
@@ -672,8 +683,16 @@ extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* read
 		out = std::make_unique<TableBatch>();
 		TableBatch& B = *out;
 		uint32_t r1 = r0; uint64_t acc = 0;
-		while (r1 < nr && (r1 == r0 || acc + h_len[r1] <= BATCH_BASES) && (uint64_t)(r1 - r0 + 1) * 2 * c < (1ull << 24)) { acc += h_len[r1]; ++r1; }
-		B.r0 = r0; B.r1 = r1; B.acc = acc;
+		// the batch also ends where its sort keys would outgrow 64 bits: task bits + position bits of its longest read + those of the longest candidate
+		uint32_t mx = 0;
+		while (r1 < nr && (r1 == r0 || acc + h_len[r1] <= BATCH_BASES))
+		{
+			const uint32_t pe = bits_for(std::max(mx, h_len[r1]));
+			if (r1 > r0 && pe + pr_bits + bits_for((r1 - r0 + 1) * 2 * c) > 64) break;
+			mx = std::max(mx, h_len[r1]); acc += h_len[r1]; ++r1;
+		}
+		B.r0 = r0; B.r1 = r1; B.acc = acc; B.pe = bits_for(mx);
+		if (B.pe + pr_bits + bits_for((r1 - r0) * 2 * c) > 64) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_anchor_candidates: a read and its candidates are too long for 64-bit match keys");
 		const uint32_t nb = r1 - r0;
 		DevBuf<uint32_t> tsize, nsize, err; DEV_ALLOC(ctx, tsize, nb); DEV_ALLOC(ctx, nsize, nb); DEV_ALLOC(ctx, err, 1); DEV_ALLOC(ctx, B.n_distinct, nb);
 		HIP_TRY(ctx, hipMemsetAsync(err.p, 0, 4, ctx->stream));
@@ -683,7 +702,6 @@ extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* read
 		CL_TRY(dev_exclusive_scan_u64(ctx, tsize.p, B.toff.p, nb, &tsum));
 		CL_TRY(dev_exclusive_scan_u64(ctx, nsize.p, B.noff.p, nb, &B.nsum));
 		uint32_t herr = 0; HIP_TRY(ctx, hipMemcpy(&herr, err.p, 4, hipMemcpyDeviceToHost));
-		if (herr) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_anchor_candidates: reads of 2^20 bases or more are not supported yet");
 		DEV_ALLOC(ctx, B.slots, tsum); DEV_ALLOC(ctx, B.next, B.nsum); DEV_ALLOC(ctx, B.bins, B.nsum); DEV_ALLOC(ctx, B.err, 1);
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                         // offsets complete before the side stream reads them
 		B.sync.s = ctx->side;
@@ -703,7 +721,7 @@ extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* read
 	{
 		const uint32_t r0 = cur->r0, r1 = cur->r1; const uint64_t acc = cur->acc;
 		const uint32_t nb = r1 - r0, n_tasks = nb * 2 * c;
-		TaskCfg cfg{ r0, r1, c, m, 0.f, frac_always, frac_min, max_matches_mult };
+		TaskCfg cfg{ r0, r1, c, m, cur->pe, pr_bits, frac_always, frac_min, max_matches_mult };
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                         // the batch before is through (its buffers may be handed to the side stream)
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->side));                           // this batch's tables are built
 		cur->sync.s = nullptr;
@@ -741,7 +759,7 @@ extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* read
 		if (n_pairs)
 		{
 			uint32_t tb = 1; while ((1ull << tb) < n_tasks) ++tb;
-			CL_TRY(dev_sort_pairs(ctx, pairs.p, nullptr, n_pairs, 0, 2 * POS_BITS + tb));
+			CL_TRY(dev_sort_pairs(ctx, pairs.p, nullptr, n_pairs, 0, cfg.pe + cfg.pr + tb));
 		}
 		LAUNCH(ctx, k_task_pairs, grid_for((uint64_t)n_tasks + 1, 256), 256, (const uint64_t*)pairs.p, n_pairs, A, cfg, (const uint32_t*)n_distinct.p, n_tasks, pair_off.p, pair_cnt.p);
 		LAUNCHB(ctx, n_pairs * 32.0, k_lis_anchors, grid_for(n_tasks, 64), 64, A, R, cfg, d_cand_refs, n_tasks, (const uint64_t*)pair_off.p, (const uint32_t*)pair_cnt.p, (const uint64_t*)pairs.p,

@@ -174,3 +174,40 @@ def test_cli_several_chunks_equal_one(tmp_path):
     assert r.returncode == 0 and "3 chunk(s)" in r.stderr, r.stderr
     _same_streams(ref_arc, one)
     _same_streams(ref_arc, many)
+
+
+@pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(CLI)), reason="needs oracle/_ref/colord and colord_amd/colord_hip")
+def test_cli_ultra_long_reads(tmp_path):
+    """Reads of more than 2^20 bases (ONT ultra-long), as reference read and as encoded read: the match keys take their position
+    bits from the longest read / candidate at hand; same archive as the reference."""
+    import numpy as np
+    from colord_amd.fastq import ReadSet
+    rng = np.random.default_rng(5)
+    genome = rng.integers(0, 4, 1_600_000, dtype=np.uint8)
+
+    def noisy(a, b, rev=False):
+        s = genome[a:b].copy()
+        if rev:
+            s = (3 - s)[::-1].copy()
+        r = rng.random(len(s))
+        sub = (r >= 0.02) & (r < 0.05)
+        s[sub] = (s[sub] + rng.integers(1, 4, int(sub.sum()))) % 4
+        return s[r >= 0.02]
+    seqs = [noisy(50_000, 1_250_000), noisy(200_000, 1_350_000, rev=True)]          # 1.18 and 1.13 Mbases: reference read, then encoded against it
+    for _ in range(40):
+        a = int(rng.integers(0, 1_500_000)); ln = int(rng.integers(5_000, 40_000))
+        seqs.append(noisy(a, min(a + ln, len(genome)), rev=bool(rng.integers(0, 2))))
+    lens = np.array([len(s) for s in seqs]); assert lens[0] > (1 << 20) and lens[1] > (1 << 20)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    quals = np.frombuffer(b"%+5C", np.uint8)[rng.choice(4, int(off[-1]))]
+    rs = ReadSet(np.concatenate(seqs), off, quals, [b"r%d" % i for i in range(len(seqs))], [False] * len(seqs), True)
+    fq = str(tmp_path / "ul.fastq")
+    write_fastq(fq, rs)
+    ref_arc, my_arc, my_out = (str(tmp_path / x) for x in ("ref.colord", "gpu.colord", "gpu.fastq"))
+    subprocess.check_call([REF, "compress-ont", "-t", "8", "-q", "org", fq, ref_arc], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.check_call([CLI, "compress-ont", "-q", "org", fq, my_arc])
+    _same_streams(ref_arc, my_arc)
+    dna = sum(len(p) for _, p in AR.read_archive(my_arc)["dna"].parts)
+    assert dna < 0.22 * off[-1]                               # the long reads really are coded against each other (2 bits/base plain = 0.25)
+    subprocess.check_call([CLI, "decompress", my_arc, my_out])
+    assert sha(my_out) == sha(fq)
