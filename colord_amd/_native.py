@@ -114,6 +114,7 @@ _SIG = {
     "cl_encode_plain": (C.c_int32, [_P, _P, _P, C.c_uint64, _P, _P, C.POINTER(C.c_uint64)]),
     "cl_reads_select": (C.c_int32, [_P, _P, _P, C.POINTER(_P)]),
     "cl_reads_from_arena": (C.c_int32, [_P, _P, _P, _P, C.c_uint32, C.POINTER(_P)]),
+    "cl_estimator_logs": (C.c_int32, [_P, _P, _P, C.c_uint64, _P]),
     "cl_es_flags": (C.c_int32, [_P, _P, _P, _P, _P, _P]),
     "cl_id_coder_create": (C.c_int32, [C.c_int32, C.POINTER(_P)]),
     "cl_id_coder_free": (None, [_P]),

@@ -900,3 +900,25 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 	cl_timing_collect(ctx);
 	return CL_OK;
 }
+
+// The decision logarithm on its own (calc_logs, utils.h:800-810), so that tests can pin it against the host's libm over
+// the reachable (count, total) pairs: same translation unit, same flags, same log2 as k_estimator and gap_stats.
+namespace {
+__global__ void k_estimator_logs(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ tot, uint64_t n, double* __restrict__ out)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t x = cnt[i];
+	const double rec = 1.0 / tot[i];
+	out[i] = x ? -log2((double)x * rec) : 0.0;
+}
+} // namespace
+extern "C" cl_status cl_estimator_logs(cl_ctx* ctx, const uint32_t* d_count, const uint32_t* d_total, uint64_t n, double* d_out)
+{
+	if (!ctx || (n && (!d_count || !d_total || !d_out))) return cl_fail(ctx, CL_E_INVALID, "cl_estimator_logs: null argument");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	if (n) LAUNCH(ctx, k_estimator_logs, grid_for(n, 256), 256, d_count, d_total, n, d_out);
+	HIP_TRY(ctx, hipGetLastError());
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return CL_OK;
+}

@@ -268,6 +268,14 @@ class Context:
                                           base_off.contiguous().data_ptr(), flags.data_ptr()))
         return flags[:int(reads.total_bases)]
 
+    def estimator_logs(self, count: torch.Tensor, total: torch.Tensor) -> torch.Tensor:
+        """The decision logarithm -log2(count * (1/total)) as the encoder's kernels evaluate it (calc_logs, utils.h:800-810)."""
+        count, total = count.contiguous(), total.contiguous()
+        assert count.dtype == torch.int32 and total.dtype == torch.int32 and count.numel() == total.numel()
+        out = torch.empty(count.numel(), dtype=torch.float64, device=self.device)
+        _check(self, self.lib.cl_estimator_logs(self.h, count.data_ptr(), total.data_ptr(), count.numel(), out.data_ptr()))
+        return out
+
     # ---- the whole data path of one shard in one native call ----
     def compress_shard(self, reads: "Reads", params: dict, part_bounds, pack_bounds, dna: "DnaCoder", qual: "QualCoder | None" = None,
                        quals: torch.Tensor | None = None, base_off: torch.Tensor | None = None):

@@ -233,6 +233,13 @@ cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const cl_reads* re
                           uint32_t min_part_alt, uint32_t max_rec, double cost_mult, const uint32_t* h_pack_bounds, uint32_t n_packs,
                           uint8_t* d_es, uint64_t cap, uint64_t* d_es_off, uint32_t* d_es_ntuples, uint64_t* n_out);
 
+/* The logarithm every cost decision of the encoder is made of, evaluated ON THE DEVICE exactly as the decision kernels do:
+ * d_out[i] = d_count[i] ? -log2((double)d_count[i] * (1.0 / d_total[i])) : 0.0  (calc_logs, utils.h:800-810; the entropy of
+ * CEntropy, utils.h:706-757, takes log2 of the same products).  The sums built from these values are plain IEEE additions
+ * and multiplications (the library is compiled without FMA contraction), so pinning this function against the host's libm
+ * over the reachable (count, total) pairs pins the decisions (tests/test_gpu_floatpin.py). */
+cl_status cl_estimator_logs(cl_ctx* ctx, const uint32_t* d_count, const uint32_t* d_total, uint64_t n, double* d_out);
+
 /* The per-base classes the quality coder uses at levels 2 and 3 (analyze_es, quality_coder_impl.cpp:25-75), from the
  * reads' own tuple streams: 'P' plain read, 'A' base inside an anchor tuple, 'M' unit match, ' ' inserted or substituted.
  * d_base_off: n_reads+1 offsets of the reads' bases (the d_qual_off of cl_qual_encode); d_flags: total_bases bytes. */

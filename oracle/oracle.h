@@ -105,6 +105,9 @@ uint32_t orc_encoder_candidates(orc_encoder*, const uint8_t* read, uint32_t len,
 size_t orc_encoder_encode(orc_encoder*, const uint8_t* read, uint32_t len, int has_n, const uint32_t* neighbours, uint32_t n_nb,
                           const uint64_t* common, const uint32_t* common_off, uint8_t* out, size_t cap, uint32_t* n_tuples);
 
+/* ---- a11: the decision logarithm (utils.h:800-810), host libm — the pin of the device's log2 ------- */
+void orc_estimator_logs(const uint32_t* count, const uint32_t* total, size_t n, double* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,6 +36,8 @@ def lib():
         L.orc_accepted_kmers.argtypes = [u8p, C.c_size_t, C.c_uint32, C.c_uint32, u64p, C.c_size_t, C.c_void_p, C.c_size_t]
         L.orc_ref_accept.restype = None
         L.orc_ref_accept.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, u8p]
+        L.orc_estimator_logs.restype = None
+        L.orc_estimator_logs.argtypes = [u32p, u32p, C.c_size_t, np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")]
         L.orc_graph_new.restype = C.c_void_p
         L.orc_graph_new.argtypes = [C.c_uint32, C.c_uint32]
         L.orc_graph_free.argtypes = [C.c_void_p]
@@ -106,6 +108,14 @@ def accepted_kmers(bases: np.ndarray, k: int, f: int, kept: np.ndarray) -> np.nd
 def ref_accept(n_reads: int, n_pseudo: int, rng: int, exponent: float) -> np.ndarray:
     out = np.zeros(n_reads + n_pseudo, np.uint8)
     lib().orc_ref_accept(n_reads, n_pseudo, rng, exponent, out)
+    return out
+
+
+def estimator_logs(count: np.ndarray, total: np.ndarray) -> np.ndarray:
+    """-log2(count * (1/total)) by the host's libm (calc_logs, utils.h:800-810)."""
+    c = np.ascontiguousarray(count, dtype=np.uint32); t = np.ascontiguousarray(total, dtype=np.uint32)
+    out = np.empty(len(c), np.float64)
+    lib().orc_estimator_logs(c, t, len(c), out)
     return out
 
 
