@@ -182,6 +182,9 @@ def hot_path_step(ctx, qctx, shard: Shard, prm: dict, with_qual: bool, exchange,
         cmp_.refs_finish()
         do, qo = 0, 0
         tot = dict(n_anchors=0, tuple_bytes=0, dna_bytes=0, qual_bytes=0)
+        if not os.environ.get("BENCH_NO_LOOKAHEAD"):
+            for ch in shard.chunks:                          # every chunk is resident: announce them all, the lanes keep lanes + 1 ahead
+                cmp_.prepare(ch[0], ch[2])
         for arena, parts, est, quals, off in shard.chunks:
             _, _, _, _, inf = cmp_.encode(arena, parts, est, quals, off, dna_out[do:], qual_out[qo:] if with_qual else None)
             do += inf["dna_bytes"]; qo += inf["qual_bytes"]

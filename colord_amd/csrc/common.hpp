@@ -14,6 +14,7 @@
 #include <string>
 #include <vector>
 #include <map>
+#include <mutex>
 #include "../../include/colord_hip.h"
 
 #define CL_WAVE 64
@@ -23,6 +24,7 @@ struct KernelTime { double ms = 0; uint32_t launches = 0; double bytes = 0; };  
 // Grow-only caching device allocator: hipMalloc/hipFree cost ~0.1-1 ms each and synchronise the device,
 // which dominated short calls.  Blocks are binned by rounded size and reused across calls.
 struct DevPool {
+	std::mutex mu;                                // a buffer made on one thread (an encode lane of cl_compressor) may be released on another
 	std::multimap<uint64_t, void*> free_blocks;
 	uint64_t cached_bytes = 0, live_bytes = 0, peak_live = 0, peak_total = 0;   // (statistics for COLORD_HIP_POOL_DEBUG)
 	void account(uint64_t got) { live_bytes += got; if (live_bytes > peak_live) peak_live = live_bytes; if (live_bytes + cached_bytes > peak_total) peak_total = live_bytes + cached_bytes; }
@@ -34,6 +36,7 @@ struct DevPool {
 	}
 	hipError_t get(uint64_t bytes, void** out, uint64_t* got)
 	{
+		std::lock_guard<std::mutex> lock(mu);
 		uint64_t r = round_size(bytes);
 		// best fit: the smallest cached block that holds r without wasting more than half of it (hipMalloc of tens of GB
 		// costs around a second, and a cache of exact sizes only would outgrow HBM over one pass of the pipeline)
@@ -58,10 +61,12 @@ struct DevPool {
 		if (e == hipSuccess) account(r);
 		return e;
 	}
-	void put(void* p, uint64_t r) { free_blocks.emplace(r, p); cached_bytes += r; live_bytes -= r; }
-	void trim() { if (getenv("COLORD_HIP_POOL_DEBUG")) fprintf(stderr, "[pool] at trim: peak live %.1f GB, peak live + cached %.1f GB, cached %.1f GB\n", peak_live / 1e9, peak_total / 1e9, cached_bytes / 1e9);
+	void put(void* p, uint64_t r) { std::lock_guard<std::mutex> lock(mu); free_blocks.emplace(r, p); cached_bytes += r; live_bytes -= r; }
+	void trim() { std::lock_guard<std::mutex> lock(mu); if (getenv("COLORD_HIP_POOL_DEBUG")) fprintf(stderr, "[pool] at trim: peak live %.1f GB, peak live + cached %.1f GB, cached %.1f GB\n", peak_live / 1e9, peak_total / 1e9, cached_bytes / 1e9);
 		for (auto& b : free_blocks) (void)hipFree(b.second); free_blocks.clear(); cached_bytes = 0; }
 };
+
+static inline bool cl_pool_debug() { static const bool dbg = getenv("COLORD_HIP_POOL_DEBUG") != nullptr; return dbg; }
 
 struct cl_ctx {
 	DevPool pool;
@@ -110,7 +115,9 @@ template<typename T> hipError_t DevBuf<T>::alloc(cl_ctx* c, uint64_t count)
 	return e;
 }
 
-#define DEV_ALLOC(ctx, buf, count) do { hipError_t _e = (buf).alloc((ctx), count); if (_e != hipSuccess) \
+#define DEV_ALLOC(ctx, buf, count) do { hipError_t _e = (buf).alloc((ctx), count); \
+	if ((buf).bytes >= (1ull << 30) && cl_pool_debug()) fprintf(stderr, "[pool] %s:%d %s %.2f GB (live %.1f GB)\n", &__FILE__[sizeof(__FILE__) > 24 ? sizeof(__FILE__) - 24 : 0], __LINE__, #buf, (buf).bytes / 1e9, (ctx)->pool.live_bytes / 1e9); \
+	if (_e != hipSuccess) \
 	return cl_fail((ctx), CL_E_NOMEM, std::string("hipMalloc(" #buf ") of ") + std::to_string((uint64_t)(count)) + " elems: " + hipGetErrorString(_e)); } while (0)
 
 // ---- per-kernel timing with HIP events on the context stream -------------------------------------

@@ -781,6 +781,23 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 		// large gaps, in rounds of growing lane pools
 		{
 			uint32_t n_list = hb[7] - hb[6];
+			if (n_list && getenv("COLORD_HIP_GAP_DEBUG"))
+			{	// diagnostic: the largest gaps of the level (the list is ascending in log2 of the work) and the total work
+				HIP_TRY(ctx, hipStreamSynchronize(st));
+				std::vector<uint32_t> h_ids(n_list);
+				HIP_TRY(ctx, hipMemcpy(h_ids.data(), ids.p + hb[6], (uint64_t)n_list * 4, hipMemcpyDeviceToHost));
+				std::vector<GapRec> top(std::min<uint32_t>(n_list, 4096));
+				double work = 0, wmax = 0; std::string txt;
+				for (uint32_t i = 0; i < top.size(); ++i) HIP_TRY(ctx, hipMemcpy(&top[i], L.gaps.p + h_ids[n_list - 1 - i], sizeof(GapRec), hipMemcpyDeviceToHost));
+				for (uint32_t i = 0; i < top.size(); ++i)
+				{
+					const uint32_t rows = top[i].kind == GK_FLANK ? top[i].ne : top[i].use, cols = top[i].kind == GK_FLANK ? top[i].use : top[i].ne;
+					const double w = (double)((rows + 63) / 64) * cols;
+					work += w; wmax = std::max(wmax, w);
+					if (i < 12) txt += " " + std::string(top[i].kind == GK_FLANK ? "F" : "I") + std::to_string(rows) + "x" + std::to_string(cols);
+				}
+				fprintf(stderr, "[gaps] level %u: %u wave-class gaps; top-%zu block-columns %.3g (largest %.3g):%s\n", lv, n_list, top.size(), work, wmax, txt.c_str());
+			}
 			DevBuf<uint32_t> todo, redo; DEV_ALLOC(ctx, todo, (uint64_t)n_list + 1); DEV_ALLOC(ctx, redo, (uint64_t)n_list + 1);
 			DevBuf<unsigned int> cnt; DEV_ALLOC(ctx, cnt, 2);
 			const uint32_t* list = ids.p + hb[6];

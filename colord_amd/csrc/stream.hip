@@ -19,7 +19,10 @@
 #include "common.hpp"
 #include "objects.hpp"
 #include <algorithm>
+#include <condition_variable>
+#include <deque>
 #include <memory>
+#include <mutex>
 #include <thread>
 
 namespace {
@@ -79,8 +82,35 @@ struct cl_compressor {
 	cl_dna_coder* dna = nullptr; cl_qual_coder* qual = nullptr;
 	// pass 2b
 	size_t enc_chunk = 0;
+	// look-ahead (cl_compressor_prepare): stage A of announced chunks — candidates, anchors, alignments, tuple streams, none of
+	// which depends on an earlier chunk's coders — runs on the compressor's own contexts ("encode lanes", one worker thread
+	// each) while the caller's thread codes the chunks before them.
+	struct Prepared {
+		const cl_reads* reads = nullptr; std::vector<uint32_t> packs;
+		DevBuf<uint8_t> es; DevBuf<uint64_t> es_off; DevBuf<uint32_t> es_nt;
+		uint64_t es_bytes = 0, n_anchors = 0;
+		cl_status status = CL_OK; std::string err;
+		std::map<std::string, KernelTime> times;      // kernel times of the lane for this chunk (merged into the caller's context)
+		bool done = false;
+	};
+	std::mutex lane_mu; std::condition_variable lane_cv;
+	std::deque<size_t> lane_queue;                   // announced chunk indices not yet started, ascending
+	std::map<size_t, std::unique_ptr<Prepared>> prepared;
+	std::vector<std::thread> lane_threads; std::vector<cl_ctx*> lane_ctx;
+	size_t n_announced = 0; bool lane_stop = false;
+	void stop_lanes()
+	{
+		{ std::lock_guard<std::mutex> l(lane_mu); lane_stop = true; }
+		lane_cv.notify_all();
+		for (auto& t : lane_threads) if (t.joinable()) t.join();
+		lane_threads.clear();
+		prepared.clear();                                // (buffers go back to the lanes' pools before the lanes go)
+		for (auto* x : lane_ctx) cl_ctx_destroy(x);
+		lane_ctx.clear();
+	}
 	~cl_compressor()
 	{
+		stop_lanes();
 		for (auto* r : ref_pieces) cl_reads_free(r);
 		if (refs) cl_reads_free(refs);
 		if (index) cl_index_free(index);
@@ -349,31 +379,15 @@ extern "C" cl_status cl_compressor_refs_finish(cl_compressor* c)
 }
 
 // ---- pass 2b --------------------------------------------------------------------------------------------------------
-extern "C" cl_status cl_compressor_encode(cl_compressor* c, const cl_reads* reads, const uint8_t* d_quals, const uint64_t* d_base_off,
-                                          const uint32_t* h_part_bounds, uint32_t n_parts, const uint32_t* h_pack_bounds, uint32_t n_packs,
-                                          uint8_t* d_dna_out, uint64_t dna_cap, uint64_t* h_dna_part_sizes,
-                                          uint8_t* d_qual_out, uint64_t qual_cap, uint64_t* h_qual_part_sizes, cl_compress_info* info)
+// Stage A of a chunk on context `ctx` (the caller's, or an encode lane's): a4 accepted k-mers, a5 candidates among the
+// EARLIER reference reads (d_bounds), a8/a9 anchors, a10-a12 edit scripts -> tuple streams.  Reads only state that pass 2a
+// completed (set, index, reference reads), so chunks are independent here.
+static cl_status stage_a(cl_compressor* c, cl_ctx* ctx, size_t chunk_idx, const cl_reads* reads, const uint32_t* h_pack_bounds, uint32_t n_packs, cl_compressor::Prepared& out)
 {
-	if (!c || !reads || !h_part_bounds || !h_pack_bounds || !info) return CL_E_INVALID;
-	cl_ctx* ctx = c->ctx;
-	if (c->phase != 2) return cl_fail(ctx, CL_E_INVALID, "cl_compressor_encode: call after refs_finish");
-	if (c->enc_chunk >= c->chunk_reads.size() || c->chunk_reads[c->enc_chunk] != reads->n_reads)
-		return cl_fail(ctx, CL_E_INVALID, "cl_compressor_encode: chunks must come in the order and sizes of pass 1");
-	if (c->has_qual && (!d_quals || !d_base_off || !h_qual_part_sizes || !d_qual_out)) return cl_fail(ctx, CL_E_INVALID, "cl_compressor_encode: quality stream without qualities");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	const cl_compress_params* P = &c->P;
-	memset(info, 0, sizeof(*info));
 	const uint32_t n = reads->n_reads;
-	info->n_reads = n; info->n_bases = reads->total_bases; info->tot_kmers = c->gstats.tot_kmers; info->n_kept_kmers = c->gstats.n_unique_counted;
-	info->n_refs = c->n_refs_total; info->sparse_range = c->sparse_range;
-	const uint32_t* d_bounds = c->bounds[c->enc_chunk].p;
-	if (!n) { c->bounds[c->enc_chunk].release(); ++c->enc_chunk; return CL_OK; }
-	struct Joiner { std::thread t; ~Joiner() { if (t.joinable()) t.join(); } } qjob;
-	cl_status qstatus = CL_OK;
-	cl_ctx* qctx = c->qual ? cl_qual_coder_ctx(c->qual) : nullptr;
-	const bool overlap = c->qual && P->level <= 1 && qctx && qctx != ctx;
-	if (overlap)
-		qjob.t = std::thread([&]() { qstatus = cl_qual_encode(qctx, c->qual, reads, d_quals, d_base_off, nullptr, h_part_bounds, n_parts, d_qual_out, qual_cap, h_qual_part_sizes, &info->qual_bytes); });
+	const uint32_t* d_bounds = c->bounds[chunk_idx].p;
 	cl_kmer_lists* lists = nullptr;
 	CL_TRY(cl_accepted_kmers(ctx, c->kset, reads, P->k, P->f, &lists));
 	std::unique_ptr<cl_kmer_lists, void (*)(cl_kmer_lists*)> lg(lists, cl_kmer_lists_free);
@@ -397,16 +411,126 @@ extern "C" cl_status cl_compressor_encode(cl_compressor* c, const cl_reads* read
 	CL_TRY(cl_anchor_candidates_hifi(ctx, reads, c->refs, crefs.p, cnt.p, cc, P->anchor_len, P->frac_always, P->frac_min, P->max_matches_mult, P->min_anchors,
 		P->k, P->f, hifi ? common_off.p : nullptr, hifi ? common.p : nullptr, &anc));
 	std::unique_ptr<cl_anchors, void (*)(cl_anchors*)> ag(anc, cl_anchors_free);
-	info->n_anchors = cl_anchors_total(anc);
+	out.n_anchors = cl_anchors_total(anc);
 	crefs.release(); cnt.release(); common_off.release(); common.release();
-	DevBuf<uint8_t> es; DevBuf<uint64_t> es_off; DevBuf<uint32_t> es_nt;
 	const uint64_t es_cap = reads->total_bases + 16ull * n + 4096;
-	DEV_ALLOC(ctx, es, es_cap); DEV_ALLOC(ctx, es_off, (uint64_t)n + 1); DEV_ALLOC(ctx, es_nt, n);
-	uint64_t es_bytes = 0;
-	CL_TRY(cl_encode_reads(ctx, reads, c->refs, anc, cc, P->anchor_len, P->min_part_alt, P->max_rec, P->cost_mult, h_pack_bounds, n_packs, es.p, es_cap, es_off.p, es_nt.p, &es_bytes));
-	ag.reset();
-	info->tuple_bytes = es_bytes;
-	CL_TRY(cl_dna_encode(ctx, c->dna, c->refs, es.p, es_off.p, es_nt.p, n, h_part_bounds, n_parts, d_dna_out, dna_cap, h_dna_part_sizes, &info->dna_bytes));
+	DEV_ALLOC(ctx, out.es, es_cap); DEV_ALLOC(ctx, out.es_off, (uint64_t)n + 1); DEV_ALLOC(ctx, out.es_nt, n);
+	CL_TRY(cl_encode_reads(ctx, reads, c->refs, anc, cc, P->anchor_len, P->min_part_alt, P->max_rec, P->cost_mult, h_pack_bounds, n_packs, out.es.p, es_cap, out.es_off.p, out.es_nt.p, &out.es_bytes));
+	return CL_OK;
+}
+
+static void lane_main(cl_compressor* c, cl_ctx* lane)
+{
+	for (;;)
+	{
+		size_t idx; cl_compressor::Prepared* job;
+		{
+			std::unique_lock<std::mutex> l(c->lane_mu);
+			// a lane runs at most (lanes + 1) chunks ahead of the coders: what it finishes waits in HBM until it is coded
+			c->lane_cv.wait(l, [&]() { return c->lane_stop || (!c->lane_queue.empty() && c->lane_queue.front() <= c->enc_chunk + c->lane_ctx.size()); });
+			if (c->lane_stop) return;
+			idx = c->lane_queue.front(); c->lane_queue.pop_front();
+			job = c->prepared[idx].get();
+		}
+		lane->timing = c->ctx->timing;
+		const cl_status s = stage_a(c, lane, idx, job->reads, job->packs.data(), (uint32_t)job->packs.size() - 1, *job);
+		cl_timing_collect(lane);
+		{
+			std::lock_guard<std::mutex> l(c->lane_mu);
+			job->status = s; if (s != CL_OK) job->err = lane->err;
+			job->times.swap(lane->times); lane->times.clear();
+			job->done = true;
+		}
+		c->lane_cv.notify_all();
+	}
+}
+
+extern "C" cl_status cl_compressor_prepare(cl_compressor* c, const cl_reads* reads, const uint32_t* h_pack_bounds, uint32_t n_packs)
+{
+	if (!c || !reads || !h_pack_bounds) return CL_E_INVALID;
+	cl_ctx* ctx = c->ctx;
+	if (c->phase != 2) return cl_fail(ctx, CL_E_INVALID, "cl_compressor_prepare: call after refs_finish");
+	std::unique_lock<std::mutex> l(c->lane_mu);
+	const size_t idx = std::max(c->n_announced, c->enc_chunk);
+	if (idx < c->enc_chunk || idx >= c->chunk_reads.size() || c->chunk_reads[idx] != reads->n_reads)
+		return cl_fail(ctx, CL_E_INVALID, "cl_compressor_prepare: chunks must be announced in the order and sizes of pass 1, before they are encoded");
+	if (c->lane_ctx.empty())
+	{
+		uint32_t lanes = 1;
+		if (const char* e = getenv("COLORD_HIP_ENCODE_LANES")) lanes = (uint32_t)std::min(4, std::max(1, atoi(e)));
+		for (uint32_t i = 0; i < lanes; ++i)
+		{
+			cl_ctx* x = nullptr;
+			const cl_status s = cl_ctx_create(ctx->device, &x);
+			if (s != CL_OK) return cl_fail(ctx, s, "cl_compressor_prepare: no context for an encode lane");
+			c->lane_ctx.push_back(x);
+		}
+		for (cl_ctx* x : c->lane_ctx) c->lane_threads.emplace_back(lane_main, c, x);
+	}
+	auto job = std::make_unique<cl_compressor::Prepared>();
+	job->reads = reads; job->packs.assign(h_pack_bounds, h_pack_bounds + n_packs + 1);
+	c->prepared[idx] = std::move(job);
+	c->lane_queue.push_back(idx);
+	c->n_announced = idx + 1;
+	l.unlock();
+	c->lane_cv.notify_all();
+	return CL_OK;
+}
+
+extern "C" cl_status cl_compressor_encode(cl_compressor* c, const cl_reads* reads, const uint8_t* d_quals, const uint64_t* d_base_off,
+                                          const uint32_t* h_part_bounds, uint32_t n_parts, const uint32_t* h_pack_bounds, uint32_t n_packs,
+                                          uint8_t* d_dna_out, uint64_t dna_cap, uint64_t* h_dna_part_sizes,
+                                          uint8_t* d_qual_out, uint64_t qual_cap, uint64_t* h_qual_part_sizes, cl_compress_info* info)
+{
+	if (!c || !reads || !h_part_bounds || !h_pack_bounds || !info) return CL_E_INVALID;
+	cl_ctx* ctx = c->ctx;
+	if (c->phase != 2) return cl_fail(ctx, CL_E_INVALID, "cl_compressor_encode: call after refs_finish");
+	if (c->enc_chunk >= c->chunk_reads.size() || c->chunk_reads[c->enc_chunk] != reads->n_reads)
+		return cl_fail(ctx, CL_E_INVALID, "cl_compressor_encode: chunks must come in the order and sizes of pass 1");
+	if (c->has_qual && (!d_quals || !d_base_off || !h_qual_part_sizes || !d_qual_out)) return cl_fail(ctx, CL_E_INVALID, "cl_compressor_encode: quality stream without qualities");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	const cl_compress_params* P = &c->P;
+	memset(info, 0, sizeof(*info));
+	const uint32_t n = reads->n_reads;
+	const size_t idx = c->enc_chunk;
+	info->n_reads = n; info->n_bases = reads->total_bases; info->tot_kmers = c->gstats.tot_kmers; info->n_kept_kmers = c->gstats.n_unique_counted;
+	info->n_refs = c->n_refs_total; info->sparse_range = c->sparse_range;
+	// the chunk leaves the look-ahead window whatever happens below (lanes may go on to the next announced chunk)
+	struct Advance { cl_compressor* c; size_t idx; ~Advance() { { std::lock_guard<std::mutex> l(c->lane_mu); c->prepared.erase(idx); c->bounds[idx].release(); c->enc_chunk = idx + 1; } c->lane_cv.notify_all(); } };
+	std::unique_ptr<cl_compressor::Prepared> own;          // stage A result: announced (taken from the lanes) or made here
+	cl_compressor::Prepared* job = nullptr;
+	{
+		std::unique_lock<std::mutex> l(c->lane_mu);
+		auto it = c->prepared.find(idx);
+		if (it != c->prepared.end())
+		{
+			if (it->second->reads != reads) return cl_fail(ctx, CL_E_INVALID, "cl_compressor_encode: not the chunk that was announced for this position");
+			c->lane_cv.wait(l, [&]() { return it->second->done; });
+			own = std::move(it->second); c->prepared.erase(it);
+			job = own.get();
+		}
+	}
+	Advance adv{ c, idx };
+	if (!n) return CL_OK;
+	struct Joiner { std::thread t; ~Joiner() { if (t.joinable()) t.join(); } } qjob;
+	cl_status qstatus = CL_OK;
+	cl_ctx* qctx = c->qual ? cl_qual_coder_ctx(c->qual) : nullptr;
+	const bool overlap = c->qual && P->level <= 1 && qctx && qctx != ctx;
+	if (overlap)
+		qjob.t = std::thread([&]() { qstatus = cl_qual_encode(qctx, c->qual, reads, d_quals, d_base_off, nullptr, h_part_bounds, n_parts, d_qual_out, qual_cap, h_qual_part_sizes, &info->qual_bytes); });
+	if (job)
+	{
+		if (job->status != CL_OK) return cl_fail(ctx, job->status, "encode lane: " + job->err);
+		for (auto& kv : job->times) { auto& t = ctx->times[kv.first]; t.ms += kv.second.ms; t.launches += kv.second.launches; t.bytes += kv.second.bytes; }
+	}
+	else
+	{
+		own = std::make_unique<cl_compressor::Prepared>();
+		job = own.get();
+		CL_TRY(stage_a(c, ctx, idx, reads, h_pack_bounds, n_packs, *job));
+	}
+	info->n_anchors = job->n_anchors; info->tuple_bytes = job->es_bytes;
+	CL_TRY(cl_dna_encode(ctx, c->dna, c->refs, job->es.p, job->es_off.p, job->es_nt.p, n, h_part_bounds, n_parts, d_dna_out, dna_cap, h_dna_part_sizes, &info->dna_bytes));
 	if (overlap)
 	{
 		qjob.t.join();
@@ -418,12 +542,10 @@ extern "C" cl_status cl_compressor_encode(cl_compressor* c, const cl_reads* read
 		if (P->level > 1)
 		{
 			DEV_ALLOC(ctx, flags, reads->total_bases + 1);
-			CL_TRY(cl_es_flags(ctx, reads, es.p, es_off.p, d_base_off, flags.p));
+			CL_TRY(cl_es_flags(ctx, reads, job->es.p, job->es_off.p, d_base_off, flags.p));
 		}
 		CL_TRY(cl_qual_encode(ctx, c->qual, reads, d_quals, d_base_off, P->level > 1 ? flags.p : nullptr, h_part_bounds, n_parts, d_qual_out, qual_cap, h_qual_part_sizes, &info->qual_bytes));
 	}
-	c->bounds[c->enc_chunk].release();
-	++c->enc_chunk;
 	return CL_OK;
 }
 

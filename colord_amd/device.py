@@ -463,6 +463,12 @@ class Compressor(_Obj):
         return dict(tot_kmers=st.tot_kmers, n_unique_counted=st.n_unique_counted, first_read=a.value, n_reads_total=b.value, mean_read_len=m.value,
                     sparse_range=r.value, n_refs_total=nr.value)
 
+    def prepare(self, reads: "Reads", pack_bounds):
+        """cl_compressor_prepare: announce a chunk of a later encode() call; its candidates / anchors / edit scripts are
+        computed in the background on an encode lane while the chunks before it are coded."""
+        kb = np.ascontiguousarray(np.asarray(pack_bounds, dtype=np.uint32))
+        _check(self.ctx, self.ctx.lib.cl_compressor_prepare(self.h, reads.h, kb.ctypes.data, len(kb) - 1))
+
     def encode(self, reads: "Reads", part_bounds, pack_bounds, quals: torch.Tensor | None = None, base_off: torch.Tensor | None = None,
                dna_out: torch.Tensor | None = None, qual_out: torch.Tensor | None = None):
         """One chunk of pass 2.  Returns (dna payload, dna part sizes, qual payload or None, qual part sizes, info dict); with

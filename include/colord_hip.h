@@ -348,6 +348,15 @@ cl_status cl_compressor_encode(cl_compressor* c, const cl_reads* chunk, const ui
                                const uint32_t* h_part_bounds, uint32_t n_parts, const uint32_t* h_pack_bounds, uint32_t n_packs,
                                uint8_t* d_dna_out, uint64_t dna_cap, uint64_t* h_dna_part_sizes,
                                uint8_t* d_qual_out, uint64_t qual_cap, uint64_t* h_qual_part_sizes, cl_compress_info* info);
+/* Optional look-ahead of pass 2.  Announces a chunk that a LATER cl_compressor_encode call will present (announce in file
+ * order, before the chunk is encoded; the arena and the bounds' meaning stay as they are until that call returns).  What the
+ * chunk needs before the coders — a4 accepted k-mers, a5 candidates, a8/a9 anchors, a10-a12 edit scripts and tuple streams —
+ * depends on no earlier chunk's output (the reference's graph and encoder threads run ahead of its two coder threads in the
+ * same way, compression.cpp:547-661), so it is computed in the background on a context of the compressor's own ("encode
+ * lane", COLORD_HIP_ENCODE_LANES of them, default 1, each with its own HIP streams and memory pool) while the caller's
+ * thread codes the chunks before it; only the adaptive models of the `dna` / `qual` coders chain chunk to chunk.  A lane
+ * runs at most lanes + 1 chunks ahead of the encode calls.  Output bytes are the same with or without announcements. */
+cl_status cl_compressor_prepare(cl_compressor* c, const cl_reads* chunk, const uint32_t* h_pack_bounds, uint32_t n_packs);
 /* what the archive's `meta` stream needs (compression.cpp:704-779), valid after count_finish (n_refs_total after refs_finish):
  * first_read = global index of this rank's first read (start of its model domain) */
 cl_status cl_compressor_info(const cl_compressor* c, cl_kmer_stats* stats, uint64_t* first_read, uint64_t* n_reads_total, uint64_t* mean_read_len,
