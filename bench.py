@@ -312,8 +312,9 @@ def main():
     shard = Shard(ctx, table, r0, r1, args.chunk_bases, args.pack_symbols, not args.no_qual)
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_gen
-    dna_out = torch.empty(int(shard.n_bases * 0.30) + (1 << 20), dtype=torch.uint8, device=ctx.device)
-    qual_out = None if args.no_qual else torch.empty(int(shard.n_bases * 0.36) + (1 << 20), dtype=torch.uint8, device=ctx.device)
+    torch.cuda.empty_cache()                                # the generator's temporaries go back to the device (the library has its own pools)
+    dna_out = torch.empty(int(shard.n_bases * 0.26) + (1 << 24), dtype=torch.uint8, device=ctx.device)
+    qual_out = None if args.no_qual else torch.empty(int(shard.n_bases * 0.28) + (1 << 24), dtype=torch.uint8, device=ctx.device)
     exchange = par.TorchExchange(ctx.device) if world > 1 else None
     prm = params_for(k, a)
 

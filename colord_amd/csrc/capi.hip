@@ -23,6 +23,8 @@ extern "C" cl_status cl_ctx_create(int device, cl_ctx** out)
 extern "C" void cl_ctx_destroy(cl_ctx* c)
 {
 	if (!c) return;
+	for (cl_ctx* l : c->lanes) cl_ctx_destroy(l);
+	c->lanes.clear();
 	(void)hipSetDevice(c->device);
 	for (auto& p : c->pending) { (void)hipEventDestroy(p.second.first); (void)hipEventDestroy(p.second.second); }
 	for (auto e : c->ev_pool) (void)hipEventDestroy(e);

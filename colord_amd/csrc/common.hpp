@@ -13,6 +13,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include "../../include/colord_hip.h"
@@ -21,49 +22,134 @@
 
 struct KernelTime { double ms = 0; uint32_t launches = 0; double bytes = 0; };   // bytes = algorithmic HBM bytes of the timed launches
 
-// Grow-only caching device allocator: hipMalloc/hipFree cost ~0.1-1 ms each and synchronise the device,
-// which dominated short calls.  Blocks are binned by rounded size and reused across calls.
+// Device memory of a context: a sub-allocator over a few large slabs.  hipMalloc / hipFree cost 0.1-1 ms each (a second
+// for tens of GB) and synchronise the device, and a cache of whole hipMalloc blocks keyed by size wastes HBM exactly where
+// this pipeline needs it (stages ask for 34, 19, 16, 15, 10, 9 ... GB one after the other; a block kept for one size serves
+// the next badly).  So: blocks are carved best-fit, at their exact size, out of slabs obtained from the driver; free extents
+// coalesce; a request no extent holds adds a slab (its own size if it is large, else about what the pool holds already, up
+// to 16 GB).  Several contexts work on one GPU at a time (the quality stream's, the encode lanes of cl_compressor), each with
+// its own pool: when the device runs short, slabs that are entirely free are given back — this pool's first, then the others'.
 struct DevPool {
+	struct Slab { char* base = nullptr; uint64_t size = 0, free_bytes = 0; std::map<uint64_t, uint64_t> ext; };   // ext: offset -> length of free extents
 	std::mutex mu;                                // a buffer made on one thread (an encode lane of cl_compressor) may be released on another
-	std::multimap<uint64_t, void*> free_blocks;
-	uint64_t cached_bytes = 0, live_bytes = 0, peak_live = 0, peak_total = 0;   // (statistics for COLORD_HIP_POOL_DEBUG)
-	void account(uint64_t got) { live_bytes += got; if (live_bytes > peak_live) peak_live = live_bytes; if (live_bytes + cached_bytes > peak_total) peak_total = live_bytes + cached_bytes; }
-	static uint64_t round_size(uint64_t bytes)
+	std::vector<Slab> slabs;
+	uint64_t reserved = 0, live_bytes = 0, peak_live = 0, peak_total = 0; uint32_t n_mallocs = 0;   // (statistics for COLORD_HIP_POOL_DEBUG)
+	static constexpr uint64_t ALIGN = 256, PAD = 256, SLAB_MIN = 256ull << 20, SLAB_MAX = 16ull << 30;
+	static std::mutex& reg_mu() { static std::mutex* m = new std::mutex; return *m; }          // (never destroyed: contexts may outlive static destruction)
+	static std::vector<DevPool*>& registry() { static std::vector<DevPool*>* r = new std::vector<DevPool*>; return *r; }
+	DevPool() { std::lock_guard<std::mutex> l(reg_mu()); registry().push_back(this); }
+	~DevPool() { std::lock_guard<std::mutex> l(reg_mu()); auto& r = registry(); for (size_t i = 0; i < r.size(); ++i) if (r[i] == this) { r.erase(r.begin() + i); break; } }
+	// gives entirely free slabs back to the driver, largest first, until `want` bytes are freed; returns the bytes freed
+	uint64_t shed_locked(uint64_t want)
 	{
-		if (bytes < 256) return 256;
-		if (bytes < (1ull << 21)) { uint64_t p = 256; while (p < bytes) p <<= 1; return p; }
-		const uint64_t g = 1ull << 21; return (bytes + g - 1) / g * g;
+		uint64_t freed = 0;
+		while (freed < want)
+		{
+			size_t best = slabs.size();
+			for (size_t i = 0; i < slabs.size(); ++i) if (slabs[i].free_bytes == slabs[i].size && (best == slabs.size() || slabs[i].size > slabs[best].size)) best = i;
+			if (best == slabs.size()) break;
+			(void)hipFree(slabs[best].base); freed += slabs[best].size; reserved -= slabs[best].size;
+			slabs.erase(slabs.begin() + best);
+		}
+		return freed;
+	}
+	// makes room for a new slab of r bytes when the device is short of it: this pool's free slabs first, then the others'
+	void make_room(std::unique_lock<std::mutex>& lock, uint64_t r, bool dbg)
+	{
+		size_t fr = 0, tot = 0;
+		if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return; }
+		const uint64_t need = r + (1ull << 30);
+		if (fr >= need) return;
+		uint64_t freed = shed_locked(need - fr);
+		if (fr + freed < need)
+		{
+			lock.unlock();
+			{
+				std::lock_guard<std::mutex> l(reg_mu());
+				for (DevPool* p : registry()) if (p != this && fr + freed < need) { std::lock_guard<std::mutex> pl(p->mu); freed += p->shed_locked(need - fr - freed); }
+			}
+			lock.lock();
+		}
+		if (dbg) fprintf(stderr, "[pool] device has %.1f GB free, %.3f GB wanted: gave back %.3f GB of free slabs\n", fr / 1e9, r / 1e9, freed / 1e9);
+	}
+	bool carve(uint64_t r, void** out)
+	{
+		size_t bs = slabs.size(); uint64_t boff = 0, blen = ~0ull;
+		for (size_t i = 0; i < slabs.size(); ++i)
+		{
+			if (slabs[i].free_bytes < r) continue;
+			for (auto& e : slabs[i].ext) if (e.second >= r && e.second < blen) { bs = i; boff = e.first; blen = e.second; if (blen == r) break; }
+			if (blen == r) break;
+		}
+		if (bs == slabs.size()) return false;
+		Slab& S = slabs[bs];
+		S.ext.erase(boff);
+		if (blen > r) S.ext.emplace(boff + r, blen - r);
+		S.free_bytes -= r;
+		*out = S.base + boff;
+		return true;
 	}
 	hipError_t get(uint64_t bytes, void** out, uint64_t* got)
 	{
-		std::lock_guard<std::mutex> lock(mu);
-		uint64_t r = round_size(bytes);
-		// best fit: the smallest cached block that holds r without wasting more than half of it (hipMalloc of tens of GB
-		// costs around a second, and a cache of exact sizes only would outgrow HBM over one pass of the pipeline)
-		auto it = free_blocks.lower_bound(r);
-		if (it != free_blocks.end() && it->first <= r + r / 2 + (64ull << 20))
-		{ *out = it->second; *got = it->first; cached_bytes -= it->first; free_blocks.erase(it); account(*got); return hipSuccess; }
-		// a large request rather borrows a larger cached block than grows the footprint (the stages of a pass run one after
-		// the other; their big buffers are not needed at the same time)
-		if (it != free_blocks.end() && r >= (1ull << 30))
-		{ *out = it->second; *got = it->first; cached_bytes -= it->first; free_blocks.erase(it); account(*got); return hipSuccess; }
-		hipError_t e = hipMalloc(out, r);
 		static const bool dbg = getenv("COLORD_HIP_POOL_DEBUG") != nullptr;
-		if (dbg) fprintf(stderr, "[pool] hipMalloc %.3f GB (%s), cached %.3f GB in %zu blocks\n", r / 1e9, e == hipSuccess ? "ok" : "failed", cached_bytes / 1e9, free_blocks.size());
-		while (e != hipSuccess && !free_blocks.empty())
-		{	// out of memory: give back cached blocks, largest first, until the request fits
-			(void)hipGetLastError();
-			auto last = std::prev(free_blocks.end());
-			(void)hipFree(last->second); cached_bytes -= last->first; free_blocks.erase(last);
-			e = hipMalloc(out, r);
-		}
+		std::unique_lock<std::mutex> lock(mu);
+		const uint64_t r = (bytes + ALIGN - 1) / ALIGN * ALIGN + PAD;          // (the pad keeps a kernel's vector load past its last element inside the block)
 		*got = r;
-		if (e == hipSuccess) account(r);
-		return e;
+		if (!carve(r, out))
+		{
+			const uint64_t g = 2ull << 20;
+			uint64_t sz = std::max<uint64_t>(r, std::min<uint64_t>(std::max<uint64_t>(reserved, SLAB_MIN), SLAB_MAX));
+			sz = (sz + g - 1) / g * g;
+			if (sz >= (4ull << 30))
+			{	// a large slab joins: smaller slabs that lie entirely free did not serve this request and rarely serve the next
+				for (size_t i = slabs.size(); i-- > 0;) if (slabs[i].free_bytes == slabs[i].size && slabs[i].size < sz)
+				{ (void)hipFree(slabs[i].base); reserved -= slabs[i].size; slabs.erase(slabs.begin() + i); }
+			}
+			make_room(lock, sz, dbg);
+			if (carve(r, out)) { live_bytes += r; if (live_bytes > peak_live) peak_live = live_bytes; return hipSuccess; }      // (another thread may have released memory meanwhile)
+			void* base = nullptr;
+			hipError_t e = hipMalloc(&base, sz);
+			if (e != hipSuccess && sz > r + g)
+			{	// not even after making room: the request alone
+				(void)hipGetLastError();
+				sz = (r + g - 1) / g * g;
+				make_room(lock, sz, dbg);
+				e = hipMalloc(&base, sz);
+			}
+			++n_mallocs;
+			if (dbg) fprintf(stderr, "[pool] slab of %.3f GB (%s) for a block of %.3f GB; live %.3f GB, reserved %.3f GB in %zu slabs\n", sz / 1e9, e == hipSuccess ? "ok" : "failed", r / 1e9, live_bytes / 1e9, reserved / 1e9, slabs.size());
+			if (e != hipSuccess) { (void)hipGetLastError(); return e; }
+			Slab S; S.base = (char*)base; S.size = sz; S.free_bytes = sz; S.ext.emplace(0, sz);
+			slabs.push_back(std::move(S));
+			reserved += sz; if (reserved > peak_total) peak_total = reserved;
+			if (!carve(r, out)) return hipErrorOutOfMemory;
+		}
+		live_bytes += r; if (live_bytes > peak_live) peak_live = live_bytes;
+		return hipSuccess;
 	}
-	void put(void* p, uint64_t r) { std::lock_guard<std::mutex> lock(mu); free_blocks.emplace(r, p); cached_bytes += r; live_bytes -= r; }
-	void trim() { std::lock_guard<std::mutex> lock(mu); if (getenv("COLORD_HIP_POOL_DEBUG")) fprintf(stderr, "[pool] at trim: peak live %.1f GB, peak live + cached %.1f GB, cached %.1f GB\n", peak_live / 1e9, peak_total / 1e9, cached_bytes / 1e9);
-		for (auto& b : free_blocks) (void)hipFree(b.second); free_blocks.clear(); cached_bytes = 0; }
+	void put(void* p, uint64_t r)
+	{
+		std::lock_guard<std::mutex> lock(mu);
+		for (Slab& S : slabs)
+		{
+			if ((char*)p < S.base || (char*)p >= S.base + S.size) continue;
+			uint64_t off = (uint64_t)((char*)p - S.base), len = r;
+			auto nx = S.ext.lower_bound(off);
+			if (nx != S.ext.begin()) { auto pv = std::prev(nx); if (pv->first + pv->second == off) { off = pv->first; len += pv->second; S.ext.erase(pv); } }
+			if (nx != S.ext.end() && off + len == nx->first) { len += nx->second; S.ext.erase(nx); }
+			S.ext.emplace(off, len);
+			S.free_bytes += r; live_bytes -= r;
+			return;
+		}
+		fprintf(stderr, "colord_hip: pool released a block it does not own\n");
+	}
+	void trim()
+	{
+		std::lock_guard<std::mutex> lock(mu);
+		if (getenv("COLORD_HIP_POOL_DEBUG")) fprintf(stderr, "[pool] at trim: peak live %.1f GB, peak reserved %.1f GB, reserved %.1f GB in %zu slabs, %u hipMalloc calls, still live %.3f GB\n", peak_live / 1e9, peak_total / 1e9, reserved / 1e9, slabs.size(), n_mallocs, live_bytes / 1e9);
+		for (auto& S : slabs) (void)hipFree(S.base);
+		slabs.clear(); reserved = 0;
+	}
 };
 
 static inline bool cl_pool_debug() { static const bool dbg = getenv("COLORD_HIP_POOL_DEBUG") != nullptr; return dbg; }
@@ -81,6 +167,7 @@ struct cl_ctx {
 	double next_bytes = 0;                       // algorithmic bytes of the next LAUNCH (set by LAUNCHB)
 	std::vector<hipEvent_t> ev_pool;
 	int n_cu = 256;
+	std::vector<cl_ctx*> lanes;                  // encode lanes of cl_compressor (contexts of their own; kept for the next compressor, freed with this context)
 };
 
 static inline cl_status cl_fail(cl_ctx* c, cl_status s, const std::string& msg)

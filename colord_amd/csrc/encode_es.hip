@@ -801,7 +801,7 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 			DevBuf<uint32_t> todo, redo; DEV_ALLOC(ctx, todo, (uint64_t)n_list + 1); DEV_ALLOC(ctx, redo, (uint64_t)n_list + 1);
 			DevBuf<unsigned int> cnt; DEV_ALLOC(ctx, cnt, 2);
 			const uint32_t* list = ids.p + hb[6];
-			uint64_t per_lane = 6ull << 20; uint32_t max_lanes = 5120;           // waves (k_align_wave) / lanes (k_align_large)
+			uint64_t per_lane = 3ull << 20; uint32_t max_lanes = 5120;           // waves (k_align_wave) / lanes (k_align_large)
 			const bool use_wave = getenv("COLORD_HIP_NO_WAVE_ALIGN") == nullptr;
 			DevBuf<unsigned long long> prof;
 			if (getenv("COLORD_HIP_WAVE_PROFILE")) { DEV_ALLOC(ctx, prof, 8); HIP_TRY(ctx, hipMemsetAsync(prof.p, 0, 64, st)); }

@@ -122,7 +122,7 @@ cl_status sort_impl(cl_ctx* ctx, K* d_keys, uint32_t* d_vals, uint64_t n, uint32
 	// first pass, so that the last one lands in the caller's arrays without a copy back
 	const uint32_t n_pass_real = (end_bit - begin_bit + 7) / 8;
 	// (the second temporary only while it is small: on the largest sorts its footprint costs more than the copy)
-	const bool third = (n_pass_real & 1) && n_pass_real > 1 && n * (sizeof(K) + (d_vals ? 4 : 0)) <= (16ull << 30);
+	const bool third = (n_pass_real & 1) && n_pass_real > 1 && n * (sizeof(K) + (d_vals ? 4 : 0)) <= (2ull << 30);
 	const uint32_t n_pass = third ? n_pass_real : (n_pass_real + 1) & ~1u;          // even: plain ping-pong (+ copy back if the real count is odd)
 	DevBuf<K> ktmp, ktmp2; DEV_ALLOC(ctx, ktmp, n);
 	DevBuf<uint32_t> vtmp, vtmp2; if (d_vals) DEV_ALLOC(ctx, vtmp, n);

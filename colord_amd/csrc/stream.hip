@@ -104,9 +104,8 @@ struct cl_compressor {
 		lane_cv.notify_all();
 		for (auto& t : lane_threads) if (t.joinable()) t.join();
 		lane_threads.clear();
-		prepared.clear();                                // (buffers go back to the lanes' pools before the lanes go)
-		for (auto* x : lane_ctx) cl_ctx_destroy(x);
-		lane_ctx.clear();
+		prepared.clear();                                // (buffers go back to the lanes' pools)
+		lane_ctx.clear();                                // the contexts stay with ctx for the next compressor (their pools are warm)
 	}
 	~cl_compressor()
 	{
@@ -458,13 +457,14 @@ extern "C" cl_status cl_compressor_prepare(cl_compressor* c, const cl_reads* rea
 	{
 		uint32_t lanes = 1;
 		if (const char* e = getenv("COLORD_HIP_ENCODE_LANES")) lanes = (uint32_t)std::min(4, std::max(1, atoi(e)));
-		for (uint32_t i = 0; i < lanes; ++i)
+		while (ctx->lanes.size() < lanes)
 		{
 			cl_ctx* x = nullptr;
 			const cl_status s = cl_ctx_create(ctx->device, &x);
 			if (s != CL_OK) return cl_fail(ctx, s, "cl_compressor_prepare: no context for an encode lane");
-			c->lane_ctx.push_back(x);
+			ctx->lanes.push_back(x);
 		}
+		c->lane_ctx.assign(ctx->lanes.begin(), ctx->lanes.begin() + lanes);
 		for (cl_ctx* x : c->lane_ctx) c->lane_threads.emplace_back(lane_main, c, x);
 	}
 	auto job = std::make_unique<cl_compressor::Prepared>();

@@ -39,8 +39,10 @@ def one_call(ctx, rs, prm, packs, qual_args):
     return out
 
 
-def chunked(ctx, rs, prm, packs, cuts, qual_args):
-    """cuts: indices into `packs` where chunks start/end (first 0, last len(packs)-1)."""
+def chunked(ctx, rs, prm, packs, cuts, qual_args, announce=None):
+    """cuts: indices into `packs` where chunks start/end (first 0, last len(packs)-1).  announce: None = no look-ahead,
+    "all" = every chunk announced before the first encode, "next" = chunk i+1 announced just before chunk i is encoded,
+    "late" = only the chunks from the second on, announced after the first was encoded without announcement."""
     off = rs.offsets
     chunks = []
     for a, b in zip(cuts[:-1], cuts[1:]):
@@ -58,8 +60,18 @@ def chunked(ctx, rs, prm, packs, cuts, qual_args):
         cmp_.refs_add(arena)
     cmp_.refs_finish()
     dna, dsz, qual, qsz, infos = b"", [], b"", [], []
-    for arena, pb, q, o in chunks:
+    if announce == "all":
+        for arena, pb, q, o in chunks:
+            cmp_.prepare(arena, pb)
+    elif announce == "next":
+        cmp_.prepare(chunks[0][0], chunks[0][1])
+    for i, (arena, pb, q, o) in enumerate(chunks):
+        if announce == "next" and i + 1 < len(chunks):
+            cmp_.prepare(chunks[i + 1][0], chunks[i + 1][1])
         d, ds, qq, qs, info = cmp_.encode(arena, pb, pb, q, o)
+        if announce == "late" and i == 0:
+            for a2, pb2, _, _ in chunks[1:]:
+                cmp_.prepare(a2, pb2)
         dna += d.cpu().numpy().tobytes(); dsz += [int(x) for x in ds]
         if qual_args:
             qual += qq.cpu().numpy().tobytes(); qsz += [int(x) for x in qs]
@@ -99,6 +111,65 @@ def test_chunked_equals_one_call_on_goldens(ctx, cfg, pack_symbols, n_chunks):
     assert sum(i["n_anchors"] for i in got[4]) == ref[4]["n_anchors"]
 
 
+@pytest.mark.parametrize("cfg,pack_symbols,n_chunks,announce,lanes", [("s6m_ont", 1 << 19, 5, "all", 1), ("s6m_ont", 1 << 19, 5, "next", 1), ("s6m_ont", 1 << 19, 5, "late", 2),
+                                                                    ("s5m_hifi", 1 << 20, 3, "all", 2), ("c3_clr_ratio", 1 << 17, 4, "all", 3)])
+def test_lookahead_lanes_change_no_byte(ctx, monkeypatch, cfg, pack_symbols, n_chunks, announce, lanes):
+    """cl_compressor_prepare: chunks whose candidates / anchors / edit scripts are computed ahead on encode lanes (own contexts,
+    own threads) give the bytes of the un-announced run — with every chunk announced up front, one chunk ahead, announcements
+    that start late, and several lanes (level 2 / 3 quality coders read the lane's tuple streams)."""
+    from oracle import pyoracle as O
+    g = golden(cfg)
+    rs = g.reads
+    prm = params_of(g)
+    packs = reference_part_bounds(np.diff(rs.offsets).astype(np.uint32), pack_symbols)
+    assert len(packs) - 1 >= n_chunks
+    qm = g.p("qual_mode")
+    qual_args = None
+    if rs.quals is not None and len(rs.quals) and qm != 8:
+        d = O.QUAL_DEFAULTS[qm]
+        qual_args = (qm, g.p("source"), g.p("level"), tuple(d[0]), tuple(d[1]))
+    cuts = even_cuts(len(packs) - 1, n_chunks)
+    ref = chunked(ctx, rs, prm, packs, cuts, qual_args)
+    monkeypatch.setenv("COLORD_HIP_ENCODE_LANES", str(lanes))
+    got = chunked(ctx, rs, prm, packs, cuts, qual_args, announce=announce)
+    assert got[1] == ref[1] and got[0] == ref[0], "dna parts differ"
+    assert got[3] == ref[3] and got[2] == ref[2], "qual parts differ"
+    assert [i["n_anchors"] for i in got[4]] == [i["n_anchors"] for i in ref[4]] and [i["tuple_bytes"] for i in got[4]] == [i["tuple_bytes"] for i in ref[4]]
+
+
+def test_prepare_rejects_wrong_order(ctx):
+    from colord_amd import _native as N
+    g = golden("s6m_ont")
+    rs = g.reads
+    prm = params_of(g)
+    packs = reference_part_bounds(np.diff(rs.offsets).astype(np.uint32), 1 << 20)
+    off = rs.offsets
+    cuts = even_cuts(len(packs) - 1, 2)
+    chunks = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        r0, r1 = int(packs[a]), int(packs[b])
+        o = torch.from_numpy((off[r0:r1 + 1] - off[r0]).astype(np.int64))
+        chunks.append((ctx.pack_reads(torch.from_numpy(rs.bases[off[r0]:off[r1]]), o), (np.asarray(packs[a:b + 1]) - packs[a]).astype(np.uint32)))
+    cmp_ = ctx.compressor(prm, None, None, None, expected_bases=int(off[-1]))
+    with pytest.raises(N.ColordHipError):
+        cmp_.prepare(chunks[0][0], chunks[0][1])                # before pass 1 / the reference listing
+    for a, _ in chunks:
+        cmp_.count_add(a)
+    cmp_.count_finish()
+    for a, _ in chunks:
+        cmp_.refs_add(a)
+    cmp_.refs_finish()
+    if chunks[0][0].n_reads != chunks[1][0].n_reads:
+        with pytest.raises(N.ColordHipError):
+            cmp_.prepare(chunks[1][0], chunks[1][1])            # the second chunk in the first position
+    cmp_.prepare(chunks[0][0], chunks[0][1])
+    with pytest.raises(N.ColordHipError):
+        cmp_.encode(chunks[1][0], chunks[1][1], chunks[1][1])   # not the announced chunk
+    cmp_.free()
+    for a, _ in chunks:
+        a.free()
+
+
 def test_chunked_equals_one_call_200_mbases(ctx):
     """A synthetic ONT set of 200 Mbases (~13 k reads, 48 reader packs of 4 Mi symbols) in 3 chunks."""
     from colord_amd.synth_device import make_reads_device
@@ -129,6 +200,8 @@ def test_chunked_equals_one_call_200_mbases(ctx):
         cmp_.refs_add(ch[0])
     cmp_.refs_finish()
     got_d, got_ds, got_q, got_qs = b"", [], b"", []
+    for arena, pb, q, o in chunks:                              # (look-ahead on: the product's way of driving pass 2)
+        cmp_.prepare(arena, pb)
     for arena, pb, q, o in chunks:
         d, ds, qq, qs, _ = cmp_.encode(arena, pb, pb, q, o)
         got_d += d.cpu().numpy().tobytes(); got_ds += [int(x) for x in ds]
