@@ -17,6 +17,7 @@
 // the host so that a divergence can be bisected without a GPU.
 #pragma once
 #include "common.hpp"
+#include "log2_glibc.hpp"
 #include "align_dev.hpp"
 
 namespace enc {
@@ -551,7 +552,7 @@ CL_DEV inline double entropy_hist(const uint32_t* h, int k)       // CEntropy (u
 {
 	double sum = 0; for (int i = 0; i < k; ++i) sum += h[i];
 	const double rec = 1.0 / sum; double e = 0;
-	for (int c = 0; c < k; ++c) if (h[c]) { const double p = (double)h[c] * rec; e += log2(p) * p; }
+	for (int c = 0; c < k; ++c) if (h[c]) { const double p = (double)h[c] * rec; e += glibc_log2::log2(p) * p; }
 	return -e;
 }
 CL_DEV inline void gap_stats(GapRec& g, const char* es, const ArenaV& A, uint64_t read_wb, const EncCfg& cfg, PendRec* pend_slot)
@@ -602,7 +603,7 @@ CL_DEV inline void est_rescale(uint32_t* a, int n, uint32_t& sum, uint32_t mx) {
 CL_DEV inline void est_logs(const uint32_t* st, double* lg, int n, uint32_t sum)
 {
 	const double rec = 1.0 / sum;
-	for (int i = 0; i < n; ++i) lg[i] = st[i] ? -log2((double)st[i] * rec) : 0.0;
+	for (int i = 0; i < n; ++i) lg[i] = st[i] ? -glibc_log2::log2((double)st[i] * rec) : 0.0;
 }
 CL_DEV inline void est_reset(Estim& e)
 {

@@ -519,7 +519,7 @@ __global__ __launch_bounds__(64) void k_estimator(TreeV T, const uint32_t* __res
 	uint32_t es_l = lane < 12 ? 1u : 0u, es_sum = 12;
 	uint32_t dna0 = 1, dna1 = 1, dna2 = 1, dna3 = 1, dna_sum = 4, dec0 = 1, dec1 = 1, dec_sum = 2;
 	double dl0, dl1, dl2, dl3, dcl0, dcl1;
-	{ const double r4 = 1.0 / 4, r2 = 1.0 / 2; dl0 = dl1 = dl2 = dl3 = -log2(1.0 * r4); dcl0 = dcl1 = -log2(1.0 * r2); }
+	{ const double r4 = 1.0 / 4, r2 = 1.0 / 2; dl0 = dl1 = dl2 = dl3 = -glibc_log2::log2(1.0 * r4); dcl0 = dcl1 = -glibc_log2::log2(1.0 * r2); }
 	for (uint32_t r = pack_bounds[pk]; r < pack_bounds[pk + 1]; ++r)
 	{
 		if (has_n[r]) continue;                                                  // reads with N never reach the estimator (encoder.cpp:1629-1633)
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(64) void k_estimator(TreeV T, const uint32_t* __res
 			while (dna_sum > MX) { dna0 = (dna0 + 1) / 2; dna1 = (dna1 + 1) / 2; dna2 = (dna2 + 1) / 2; dna3 = (dna3 + 1) / 2; dna_sum = dna0 + dna1 + dna2 + dna3; }
 			const double rec = 1.0 / dna_sum;
 			const uint32_t x = lane == 0 ? dna0 : lane == 1 ? dna1 : lane == 2 ? dna2 : dna3;
-			const double lg = x ? -log2((double)x * rec) : 0.0;
+			const double lg = x ? -glibc_log2::log2((double)x * rec) : 0.0;
 			dl0 = __shfl(lg, 0); dl1 = __shfl(lg, 1); dl2 = __shfl(lg, 2); dl3 = __shfl(lg, 3);
 		}
 		for (uint64_t e0 = ev_off[r]; e0 < ev_off[r + 1]; e0 += 64)
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(64) void k_estimator(TreeV T, const uint32_t* __res
 					x = lane == 12 ? dec0 + 1 : lane == 13 ? dec1 : lane == 14 ? dec0 : dec1 + 1;
 					rec = 1.0 / (dec_sum + 1);
 				}
-				const double lg = x ? -log2((double)x * rec) : 0.0;
+				const double lg = x ? -glibc_log2::log2((double)x * rec) : 0.0;
 				const double term = (double)rd_l * lg;
 				double es_cost = dcl0;
 #pragma unroll
@@ -586,7 +586,7 @@ __global__ __launch_bounds__(64) void k_estimator(TreeV T, const uint32_t* __res
 				{
 					while (dec_sum > MX) { dec0 = (dec0 + 1) / 2; dec1 = (dec1 + 1) / 2; dec_sum = dec0 + dec1; }
 					const double rc = 1.0 / dec_sum;
-					dcl0 = dec0 ? -log2((double)dec0 * rc) : 0.0; dcl1 = dec1 ? -log2((double)dec1 * rc) : 0.0;
+					dcl0 = dec0 ? -glibc_log2::log2((double)dec0 * rc) : 0.0; dcl1 = dec1 ? -glibc_log2::log2((double)dec1 * rc) : 0.0;
 				}
 				if (lane == 0) { const uint32_t ev = ev_id[k]; T.lv[ev >> 28].dec[ev & 0x0fffffffu] = choose_plain ? 0 : 1; }
 			}
@@ -927,7 +927,7 @@ __global__ void k_estimator_logs(const uint32_t* __restrict__ cnt, const uint32_
 	if (i >= n) return;
 	const uint32_t x = cnt[i];
 	const double rec = 1.0 / tot[i];
-	out[i] = x ? -log2((double)x * rec) : 0.0;
+	out[i] = x ? -glibc_log2::log2((double)x * rec) : 0.0;
 }
 } // namespace
 extern "C" cl_status cl_estimator_logs(cl_ctx* ctx, const uint32_t* d_count, const uint32_t* d_total, uint64_t n, double* d_out)
