@@ -216,6 +216,81 @@ __device__ inline void wave_walk(WavePool& pool, const Hist& h, const uint8_t* q
 	__builtin_amdgcn_s_waitcnt(0);
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 }
+// ---- four gaps per wave ---------------------------------------------------------------------------------------------
+// 90 % of the gaps of this class have 4 - 16 row blocks: in wave_sweep they keep 4 - 16 of the 64 lanes busy, and the class
+// is bound by instruction issue.  quad_sweep runs FOUR such gaps at once, one per 16-lane row of the wave: every argument is
+// uniform within a row and may differ between rows (n = 0: the row has no gap).  Same recurrence, same history layout as
+// wave_sweep with one tile (cell of block b, column j at (j + b) * nb + b), so wave_walk reads it unchanged.  The column
+// symbol and the horizontal delta move down a row with DPP row shifts; the symbols of the next 16 columns sit one per lane
+// and rotate towards lane 0 of the row.  n <= 1024 (16 blocks), history always kept (the caller made sure it fits).
+__device__ inline uint32_t row_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); }
+__device__ inline int row_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false); }
+__device__ inline uint32_t row_rol1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x12f, 0xf, 0xf, false); }     // row_ror:15
+__device__ inline Sweep quad_sweep(const uint8_t* q, uint32_t n, const uint8_t* t, uint32_t m, bool shw, uint64_t* histP, uint64_t* histH)
+{
+	const uint32_t lane = lane_id(), bl = lane & 15, row0 = lane & 48;
+	const uint32_t nb = (n + 63) / 64;
+	const bool act = bl < nb;
+	uint64_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+	if (act)
+	{
+		const uint32_t lo = bl * 64, hi = n < lo + 64 ? n : lo + 64;
+		for (uint32_t i = lo; i < hi; ++i)
+		{
+			const uint32_t s = q[i] & 3; const uint64_t bit = 1ull << (i - lo);
+			e0 |= s == 0 ? bit : 0; e1 |= s == 1 ? bit : 0; e2 |= s == 2 ? bit : 0; e3 |= s == 3 ? bit : 0;
+		}
+	}
+	uint64_t Pv = ~0ull, Mv = 0;
+	const bool owner = act && bl == nb - 1;
+	const uint32_t lastbit = (n - 1) & 63;
+	uint32_t sc = n, best = 0xffffffffu; int32_t end = (int32_t)m - 1;
+	if (shw && (n & 63)) { best = n; end = -1; }
+	const uint32_t steps = nb ? m + nb - 1 : 0;
+	uint32_t steps_max = bcast(steps, 0u);
+	{ const uint32_t a = bcast(steps, 16u), b = bcast(steps, 32u), c3 = bcast(steps, 48u); steps_max = steps_max > a ? steps_max : a; steps_max = steps_max > b ? steps_max : b; steps_max = steps_max > c3 ? steps_max : c3; }
+	uint32_t c = 0, tchunk = 0; int hout = 0;
+	for (uint32_t s = 0; s < steps_max; ++s)
+	{
+		if ((s & 15) == 0) { const uint32_t j0 = s + bl; tchunk = (nb && j0 < m) ? (uint32_t)(t[j0] & 3) : 0u; }
+		else tchunk = row_rol1(tchunk);
+		const uint32_t c_up = row_shr1(c); const int h_up = row_shr1(hout);
+		c = bl == 0 ? tchunk : c_up;
+		const int hin = bl == 0 ? 1 : h_up;
+		const bool valid = act && s >= bl && s - bl < m;
+		hout = 0;
+		if (valid)
+		{
+			uint64_t Eq = c == 0 ? e0 : c == 1 ? e1 : c == 2 ? e2 : e3;
+			const uint64_t hneg = hin < 0 ? 1ull : 0ull;
+			const uint64_t Xv = Eq | Mv;
+			Eq |= hneg;
+			const uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+			uint64_t Ph = Mv | ~(Xh | Pv);
+			uint64_t Mh = Pv & Xh;
+			const uint64_t ph_rows = Ph;
+			if (owner)
+			{
+				sc += (uint32_t)((Ph >> lastbit) & 1) - (uint32_t)((Mh >> lastbit) & 1);
+				if (shw && sc < best) { best = sc; end = (int32_t)(s - bl); }
+			}
+			hout = (int)(Ph >> 63) - (int)(Mh >> 63);
+			Ph <<= 1; Mh <<= 1;
+			Mh |= hneg; Ph |= hin > 0 ? 1ull : 0ull;
+			Pv = Mh | ~(Xv | Ph);
+			Mv = Ph & Xv;
+			const uint64_t idx = (uint64_t)s * nb + bl;
+			histP[idx] = Pv; histH[idx] = ph_rows;
+		}
+	}
+	Sweep out;
+	const int own = (int)(row0 + (nb ? nb - 1 : 0));
+	out.score = (uint32_t)__shfl((int)sc, own); out.best = (uint32_t)__shfl((int)best, own); out.end = __shfl(end, own);
+	__builtin_amdgcn_s_waitcnt(0);
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	return out;
+}
+
 // edlib keeps the whole history when it fits 1 MiB (edlib.cpp:1176-1183), else it divides (Hirschberg)
 __device__ inline bool wave_direct_fits(uint32_t n, uint32_t m)
 {

@@ -30,6 +30,7 @@ extern "C" void cl_ctx_destroy(cl_ctx* c)
 	for (auto e : c->ev_pool) (void)hipEventDestroy(e);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	if (c->side) (void)hipStreamDestroy(c->side);
+	if (c->side2) (void)hipStreamDestroy(c->side2);
 	c->pool.trim();
 	delete c;
 }

@@ -159,6 +159,7 @@ struct cl_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
 	hipStream_t side = nullptr;                  // second stream for chains that would leave the machine idle (created on first use)
+	hipStream_t side2 = nullptr;                 // third stream: the four-per-wave aligner next to the tail-bound wave-per-gap one
 	std::string err;
 	bool timing = false;
 	std::map<std::string, KernelTime> times;     // per-kernel accumulated HIP-event time of the last API call

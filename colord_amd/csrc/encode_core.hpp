@@ -317,11 +317,10 @@ CL_DEV inline uint32_t align_small(MEM& mem, uint32_t n, uint32_t m, uint32_t ki
 // ---- mid-size gaps: the same recurrence with the state in the lane's memory (rows * columns / 64 <= MID_CELLS) --------
 // MEM additionally provides peq / peq_set (symbol, block), pv / mv get + set (block).  Same observable behaviour as
 // align_small (and as edlib below its 1 MiB traceback budget: 20 bytes * blocks * columns stays under it).
-// MID_CELLS = 0 switches the class off: measured on the bench set (1.27 M gaps of ~350 x 350), the wave-per-gap kernel
-// (align_wave.hpp) does them in 155 ms against 250 ms here — its sweep, symbol conversion and indel canonicalisation are
-// wave-parallel, only the traceback is serial; one lane per gap keeps 64 serial tracebacks in lock step but pays a memory
-// round trip per block step.  The class stays as the reference point (16384 turns it back on).
-constexpr uint32_t MID_CELLS = 0, MID_ROWS = 16384, MID_COLS = 4096;
+// No kernel of the library uses this form any more (measured on 1.27 M gaps of ~350 x 350: 250 ms against 155 ms for a wave per
+// gap, whose sweep, symbol conversion and indel canonicalisation are wave-parallel); it stays as the plain sequential
+// statement of the recurrence for the debugging host build (tests/tools/encode_host.hip).
+constexpr uint32_t MID_ROWS = 16384, MID_COLS = 4096;
 // NBR > 0: the vertical deltas of up to NBR blocks stay in registers (only the match masks and the history are memory).
 template<int NBR, class MEM>
 CL_DEV inline uint32_t align_mid(MEM& mem, uint32_t n, uint32_t m, uint32_t kind, bool left, uint32_t nr, uint32_t use, uint32_t* d_before)
@@ -956,7 +955,10 @@ CL_DEV inline bool gap_init(const LevelV& L, uint32_t frame, uint32_t g_idx, con
 	return false;
 }
 CL_DEV inline uint32_t gap_es_capacity(const GapRec& g) { return ((g.kind == GK_TRIVIAL ? (g.nr == 0 ? g.ne : 0u) : g.use + g.ne) + 3u) & ~3u; }   // dword-aligned script slots
-// size class of a gap: 0 trivial, 1..4 small with that many 64-row blocks, 5 mid, 6 large
+// size class of a gap: 0 trivial, 1..4 small with that many 64-row blocks, 5 up to 16 row blocks with a history of at most
+// 512 KB (four of them share a wave, k_align_quad; edlib keeps the whole history of such a gap: 20 B * blocks * columns + 8 B *
+// columns stays under its 1 MiB), 6 large (a wave each)
+constexpr uint32_t QUAD_ROWS = 1024, QUAD_CELLS = 32768;
 // sort key = class << 17 | row blocks (9 bits) << 8 | columns / 16 (8 bits): lanes of a wave get gaps of like shape
 constexpr uint32_t N_CLASSES = 7, KEY_BITS = 20;
 CL_DEV inline uint32_t gap_class(const GapRec& g, uint32_t& rows, uint32_t& cols)
@@ -964,7 +966,7 @@ CL_DEV inline uint32_t gap_class(const GapRec& g, uint32_t& rows, uint32_t& cols
 	if (g.kind == GK_TRIVIAL) { rows = cols = 0; return 0; }
 	if (g.kind == GK_FLANK) { rows = g.ne; cols = g.use; } else { rows = g.use; cols = g.ne; }
 	if (rows <= 256 && cols <= 256) return (rows + 63) / 64;
-	if (rows <= MID_ROWS && cols <= MID_COLS && (uint64_t)((rows + 63) / 64) * cols <= MID_CELLS) return 5;
+	if (rows <= QUAD_ROWS && (uint64_t)((rows + 63) / 64) * (cols + 16) <= QUAD_CELLS) return 5;
 	return 6;
 }
 CL_DEV inline uint32_t gap_sort_key(const GapRec& g)

@@ -142,86 +142,43 @@ __global__ __launch_bounds__(64) void k_align_small(const uint32_t* __restrict__
 	}
 }
 
-// mid-size gaps: one lane per gap, all state lane-interleaved in HBM (element e of a lane's array at (e * 64 + lane)):
-// the lanes of a wave walk in lockstep over gaps of like shape, so every access of the wave is one contiguous 512-byte line
-struct HbmMem {
-	static constexpr uint64_t HIST_W = 2ull * MID_CELLS, PEQ_W = 4ull * 256, ST_W = 256, Q_W = MID_ROWS / 8, T_W = MID_COLS / 8, ES_W = (MID_ROWS + MID_COLS) / 8;   // 64-bit words per lane
-	static constexpr uint64_t WORDS = HIST_W + PEQ_W + 2 * ST_W + Q_W + T_W + ES_W;
-	uint64_t* base; uint32_t lane, nb;
-	unsigned long long* prof = nullptr; uint64_t t_last = 0;                 // optional phase clocks (debugging)
-	__device__ inline void lap(uint32_t ph) { if (prof) { const uint64_t now = wall_clock64(); if (lane == 0) atomicAdd(prof + ph, (unsigned long long)(now - t_last)); t_last = now; } }
-	__device__ inline uint64_t* w(uint64_t region, uint64_t e) const { return base + (region + e) * 64 + lane; }
-	__device__ inline uint8_t* byte(uint64_t region, uint32_t b) const { return (uint8_t*)(base + (region + (b >> 3)) * 64 + lane) + (b & 7); }
-	__device__ inline void hist_put(uint32_t j, uint32_t b, uint64_t P, uint64_t Ph) { const uint64_t e = ((uint64_t)j * nb + b) * 2; *w(0, e) = P; *w(0, e + 1) = Ph; }
-	__device__ inline void hist_get(uint32_t j, uint32_t b, uint64_t& P, uint64_t& Ph) const { const uint64_t e = ((uint64_t)j * nb + b) * 2; P = *w(0, e); Ph = *w(0, e + 1); }
-	__device__ inline uint64_t peq(uint32_t s, uint32_t b) const { return *w(HIST_W, s * 256 + b); }
-	__device__ inline void peq_set(uint32_t s, uint32_t b, uint64_t v) { *w(HIST_W, s * 256 + b) = v; }
-	__device__ inline uint64_t pv(uint32_t b) const { return *w(HIST_W + PEQ_W, b); }
-	__device__ inline uint64_t mv(uint32_t b) const { return *w(HIST_W + PEQ_W + ST_W, b); }
-	__device__ inline void pv_set(uint32_t b, uint64_t v) { *w(HIST_W + PEQ_W, b) = v; }
-	__device__ inline void mv_set(uint32_t b, uint64_t v) { *w(HIST_W + PEQ_W + ST_W, b) = v; }
-	// byte arrays are read through one cached 8-byte word each: the walks over them are sequential, and a byte load per
-	// symbol is a full memory round trip
-	static constexpr uint64_t QR = HIST_W + PEQ_W + 2 * ST_W, TR = QR + Q_W, ER = TR + T_W;
-	uint64_t cq = 0, ct = 0, ce = 0; uint32_t iq = 0xffffffffu, it = 0xffffffffu, ie = 0xffffffffu;
-	__device__ inline uint32_t q(uint32_t i) { if ((i >> 3) != iq) { iq = i >> 3; cq = *w(QR, iq); } return (uint32_t)(cq >> (8 * (i & 7))) & 0xffu; }
-	__device__ inline uint32_t t(uint32_t j) { if ((j >> 3) != it) { it = j >> 3; ct = *w(TR, it); } return (uint32_t)(ct >> (8 * (j & 7))) & 0xffu; }
-	__device__ inline void q_set(uint32_t i, uint32_t v) { *byte(QR, i) = (uint8_t)v; iq = 0xffffffffu; }
-	__device__ inline void t_set(uint32_t j, uint32_t v) { *byte(TR, j) = (uint8_t)v; it = 0xffffffffu; }
-	__device__ inline char es_get(uint32_t k) { if ((k >> 3) != ie) { ie = k >> 3; ce = *w(ER, ie); } return (char)((ce >> (8 * (k & 7))) & 0xff); }
-	__device__ inline void es_set(uint32_t k, char c)
-	{
-		*byte(ER, k) = (uint8_t)c;
-		if ((k >> 3) == ie) ce = (ce & ~(0xffull << (8 * (k & 7)))) | ((uint64_t)(uint8_t)c << (8 * (k & 7)));
-	}
-	__device__ inline uint32_t es_word(uint32_t wi) const { return ((const uint32_t*)w(HIST_W + PEQ_W + 2 * ST_W + Q_W + T_W, wi >> 1))[wi & 1]; }
+// large gaps: one WAVE per gap (align_wave.hpp), largest first.  Three steps, so that k_align_quad can run the middle one
+// for four gaps at once: the sequences into byte buffers (stage), sweep + path -> operations, operations -> canonical script.
+struct WaveGap {
+	uint8_t* rbuf; uint8_t* ebuf; uint8_t* r2; uint8_t* e2; uint8_t* opsbuf;
+	const uint8_t* Q; const uint8_t* T; uint32_t n, m; bool rows_ref, shw, left;     // m: columns offered to the sweep (g.use for a flank)
 };
-__global__ __launch_bounds__(64) void k_align_mid(const uint32_t* __restrict__ list, uint32_t n_list, GapRec* __restrict__ gaps, char* __restrict__ es_pool, ArenaV A, ArenaV R, uint64_t* __restrict__ scratch, unsigned long long* prof)
+__device__ inline bool wave_gap_stage(wv::WavePool& pool, const GapRec& g, const ArenaV& A, const ArenaV& R, WaveGap& W)
 {
-	HbmMem mem{ scratch + (uint64_t)blockIdx.x * HbmMem::WORDS * 64, threadIdx.x, 0 };
-	mem.prof = prof; if (prof) mem.t_last = wall_clock64();
-	const uint32_t n_chunks = (n_list + 63) / 64;
-	for (uint32_t ci = blockIdx.x; ci < n_chunks; ci += gridDim.x)
-	{	// the list is ascending in size: largest chunks first, so that the small ones fill the tail
-		const uint32_t chunk = n_chunks - 1 - ci;
-		const uint32_t idx = chunk * 64 + threadIdx.x;
-		if (idx >= n_list) continue;
-		const uint32_t gi = list[idx];
-		const GapRec g = gaps[gi];
-		uint32_t n, m;
-		mem.lap(5);
-		stage_small(mem, g, A, R, n, m);
-		mem.lap(4);
-		mem.nb = (n + 63) / 64;
-		uint32_t d_before;
-		const uint32_t k = mem.nb <= 8 ? align_mid<8>(mem, n, m, g.kind, g.left != 0, g.nr, g.use, &d_before)
-		                 : mem.nb <= 16 ? align_mid<16>(mem, n, m, g.kind, g.left != 0, g.nr, g.use, &d_before)
-		                 : align_mid<0>(mem, n, m, g.kind, g.left != 0, g.nr, g.use, &d_before);
-		uint32_t* dst = (uint32_t*)(es_pool + g.es_off);
-		for (uint32_t wi = 0; wi * 4 < k; ++wi) dst[wi] = mem.es_word(wi);
-		gaps[gi].es_len = k; gaps[gi].d_before = d_before;
-	}
-}
-
-// large gaps: one WAVE per gap (align_wave.hpp), largest first
-__device__ inline bool align_wave_gap(wv::WavePool& pool, GapRec& g, const ArenaV& A, const ArenaV& R, char* dst, uint32_t dbg_stage)
-{
-	g.es_len = 0; g.d_before = 0;
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t ref_id = g.ref_rev & 0x7fffffffu; const bool rev = g.ref_rev >> 31;
 	const uint64_t rwb = R.word_off[ref_id], ewb = A.word_off[g.read]; const uint32_t rlen = R.lens[ref_id];
 	const bool left = g.left != 0;
-	uint8_t* rbuf = (uint8_t*)pool.alloc(g.use + 64ull); uint8_t* ebuf = (uint8_t*)pool.alloc(g.ne + 64ull);
-	uint8_t* r2 = (uint8_t*)pool.alloc(g.use + 64ull); uint8_t* e2 = (uint8_t*)pool.alloc(g.ne + 64ull);
-	uint8_t* opsbuf = (uint8_t*)pool.alloc((uint64_t)g.use + g.ne + 64);
+	W.left = left;
+	W.rbuf = (uint8_t*)pool.alloc(g.use + 64ull); W.ebuf = (uint8_t*)pool.alloc(g.ne + 64ull);
+	W.r2 = (uint8_t*)pool.alloc(g.use + 64ull); W.e2 = (uint8_t*)pool.alloc(g.ne + 64ull);
+	W.opsbuf = (uint8_t*)pool.alloc((uint64_t)g.use + g.ne + 64);
 	if (pool.overflow) return false;
-	pool.beat(4);
-	pool.lap(0);
 	const uint32_t lo = left ? g.nr - g.use : 0;
-	for (uint32_t i = lane; i < g.use; i += 64) { const uint8_t v = (uint8_t)ref_sym(R, rwb, rlen, rev, g.cur_ref + lo + i); rbuf[i] = v; r2[left ? g.use - 1 - i : i] = v; }
-	for (uint32_t i = lane; i < g.ne; i += 64) { const uint8_t v = (uint8_t)arena_base_at(A, ewb, g.enc_start + i); ebuf[i] = v; e2[left ? g.ne - 1 - i : i] = v; }
+	for (uint32_t i = lane; i < g.use; i += 64) { const uint8_t v = (uint8_t)ref_sym(R, rwb, rlen, rev, g.cur_ref + lo + i); W.rbuf[i] = v; W.r2[left ? g.use - 1 - i : i] = v; }
+	for (uint32_t i = lane; i < g.ne; i += 64) { const uint8_t v = (uint8_t)arena_base_at(A, ewb, g.enc_start + i); W.ebuf[i] = v; W.e2[left ? g.ne - 1 - i : i] = v; }
+	if (g.kind == GK_INNER) { W.Q = W.rbuf; W.n = g.nr; W.T = W.ebuf; W.m = g.ne; W.rows_ref = true; W.shw = false; }
+	else if (g.kind == GK_FLANK_TINY) { W.Q = W.r2; W.n = g.use; W.T = W.e2; W.m = g.ne; W.rows_ref = true; W.shw = false; }
+	else { W.Q = W.e2; W.n = g.ne; W.T = W.r2; W.m = g.use; W.rows_ref = false; W.shw = true; }
 	__builtin_amdgcn_s_waitcnt(0);
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	return true;
+}
+__device__ inline bool wave_gap_finish(wv::WavePool& pool, GapRec& g, const WaveGap& W, const wv::Ops& ops, uint32_t ref_end, char* dst, uint32_t dbg_stage);
+__device__ inline bool align_wave_gap(wv::WavePool& pool, GapRec& g, const ArenaV& A, const ArenaV& R, char* dst, uint32_t dbg_stage)
+{
+	g.es_len = 0; g.d_before = 0;
+	WaveGap W;
+	pool.beat(4);
+	pool.lap(0);
+	if (!wave_gap_stage(pool, g, A, R, W)) return false;
+	uint8_t* const opsbuf = W.opsbuf; uint8_t* const rbuf = W.rbuf; uint8_t* const ebuf = W.ebuf; uint8_t* const r2 = W.r2; uint8_t* const e2 = W.e2;
+	(void)rbuf; (void)ebuf; (void)r2; (void)e2;
 	pool.beat(5);
 	pool.lap(1);
 	if (dbg_stage == 1) return true;
@@ -268,6 +225,15 @@ __device__ inline bool align_wave_gap(wv::WavePool& pool, GapRec& g, const Arena
 		}
 	}
 	if (pool.overflow) return false;
+	(void)m;
+	return wave_gap_finish(pool, g, W, ops, ref_end, dst, dbg_stage);
+}
+// operations (0 match, 1 consume query, 2 consume target, 3 mismatch) -> the gap's canonical script
+__device__ inline bool wave_gap_finish(wv::WavePool& pool, GapRec& g, const WaveGap& W, const wv::Ops& ops, uint32_t ref_end, char* dst, uint32_t dbg_stage)
+{
+	const uint32_t lane = threadIdx.x & 63;
+	const uint8_t* const Q = W.Q; const uint8_t* const T = W.T; const bool rows_ref = W.rows_ref, left = W.left;
+	const uint8_t* const rbuf = W.rbuf; const uint8_t* const ebuf = W.ebuf;
 	__builtin_amdgcn_s_waitcnt(0);
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 	pool.beat(6);
@@ -345,15 +311,23 @@ __global__ __launch_bounds__(64) void k_align_wave(const uint32_t* __restrict__ 
 	pool.prof = prof; if (prof) pool.t_last = wall_clock64();
 	pool.beat(1);
 	const uint32_t lane = threadIdx.x;
-	for (uint32_t slot = blockIdx.x; slot < n_list; slot += gridDim.x)
-	{	// static round-robin over the list in descending size (the list is ascending): balanced enough, no queue
+	for (;;)
+	{	// the list is ascending in size: the waves draw from its end, largest first, whenever they are free (a wave that got one
+		// of the few huge gaps takes no further share of the rest)
+		uint32_t slot = 0;
+		if (lane == 0) slot = atomicAdd(next, 1u);
+		slot = wv::bcast_first(slot);
+		if (slot >= n_list) break;
 		pool.beat(2);
 		const uint32_t gi = list[n_list - 1 - slot];
 		pool.top = 0; pool.overflow = false;
 		GapRec g = gaps[gi];
 		pool.beat(3);
 		pool.lap(7);
-		if (!align_wave_gap(pool, g, A, R, es_pool + g.es_off, dbg_stage))
+		const uint64_t t_gap = prof ? wall_clock64() : 0;
+		const bool ok_gap = align_wave_gap(pool, g, A, R, es_pool + g.es_off, dbg_stage);
+		if (prof && lane == 0) atomicMax(prof + 6, ((unsigned long long)(wall_clock64() - t_gap) << 24) | (slot & 0xffffffu));     // (diagnostic: the slowest gap and its rank)
+		if (!ok_gap)
 		{
 			if (lane == 0) redo[atomicAdd(n_redo, 1u)] = gi;
 			continue;
@@ -362,6 +336,68 @@ __global__ __launch_bounds__(64) void k_align_wave(const uint32_t* __restrict__ 
 		if (lane == 0) { gaps[gi].es_len = g.es_len; gaps[gi].d_before = g.d_before; }
 	}
 	pool.beat(9);
+}
+
+// gaps of up to 16 row blocks whose history fits a wave's pool: FOUR per wave (wv::quad_sweep), largest first; what does not
+// fit a wave's pool goes to `redo` (k_align_wave takes it)
+__global__ __launch_bounds__(64) void k_align_quad(const uint32_t* __restrict__ list, uint32_t n_list, GapRec* __restrict__ gaps, char* __restrict__ es_pool, ArenaV A, ArenaV R,
+                                                  uint8_t* __restrict__ scratch, uint64_t per_wave, unsigned int* __restrict__ next, uint32_t* __restrict__ redo, unsigned int* __restrict__ n_redo)
+{
+	wv::WavePool pool{ scratch + (uint64_t)blockIdx.x * per_wave, per_wave, 0, false, nullptr };
+	const uint32_t lane = threadIdx.x, gq = lane >> 4;
+	const uint32_t n_quads = (n_list + 3) / 4;
+	for (;;)
+	{
+		uint32_t slot = 0;
+		if (lane == 0) slot = atomicAdd(next, 1u);
+		slot = wv::bcast_first(slot);
+		if (slot >= n_quads) break;
+		pool.top = 0; pool.overflow = false;
+		const uint32_t hi = n_list - slot * 4, cnt = hi < 4 ? hi : 4;        // gaps list[hi - 1], list[hi - 2], ... (ascending list, taken from its end)
+		GapRec g[4]; WaveGap W[4]; uint64_t* P[4]; uint64_t* H[4]; uint8_t* rev[4]; uint32_t gi[4]; bool ok[4];
+#pragma unroll
+		for (uint32_t j = 0; j < 4; ++j)
+		{
+			ok[j] = false; gi[j] = 0; P[j] = H[j] = nullptr; rev[j] = nullptr;
+			if (j >= cnt) continue;
+			gi[j] = list[hi - 1 - j];
+			g[j] = gaps[gi[j]];
+			g[j].es_len = 0; g[j].d_before = 0;
+			if (pool.overflow) continue;
+			if (!wave_gap_stage(pool, g[j], A, R, W[j])) continue;
+			if (W[j].n == 0 || W[j].m == 0 || W[j].n > 1024) continue;        // (not of this class: the wave kernel handles every shape)
+			const uint64_t words = ((uint64_t)W[j].m + 64) * ((W[j].n + 63) / 64);
+			P[j] = (uint64_t*)pool.alloc(words * 8); H[j] = (uint64_t*)pool.alloc(words * 8); rev[j] = (uint8_t*)pool.alloc((uint64_t)W[j].n + W[j].m + 64);
+			ok[j] = !pool.overflow;
+		}
+		pool.overflow = false;
+		const uint8_t* q = nullptr; const uint8_t* t = nullptr; uint32_t n = 0, m = 0; bool shw = false; uint64_t* hp = nullptr; uint64_t* hh = nullptr;
+#pragma unroll
+		for (uint32_t j = 0; j < 4; ++j) if (gq == j && ok[j]) { q = W[j].Q; n = W[j].n; t = W[j].T; m = W[j].m; shw = W[j].shw; hp = P[j]; hh = H[j]; }
+		const wv::Sweep sw = wv::quad_sweep(q, n, t, m, shw, hp, hh);
+#pragma unroll
+		for (uint32_t j = 0; j < 4; ++j)
+		{
+			if (j >= cnt) continue;
+			bool done = false;
+			if (ok[j])
+			{
+				const int32_t end = wv::bcast(sw.end, 16u * j);
+				wv::Ops ops{ W[j].opsbuf, 0 };
+				const wv::Hist h{ P[j], H[j], (W[j].n + 63) / 64, W[j].m };
+				wv::wave_walk(pool, h, W[j].Q, W[j].n, W[j].T, W[j].shw ? (uint32_t)(end + 1) : W[j].m, rev[j], ops);
+				const uint32_t ref_end = W[j].shw ? (uint32_t)end : g[j].kind == GK_FLANK_TINY ? g[j].use - 1 : 0u;
+				const uint64_t mk = pool.mark();
+				done = wave_gap_finish(pool, g[j], W[j], ops, ref_end, es_pool + g[j].es_off, 0);
+				pool.release(mk); pool.overflow = false;
+			}
+			if (lane == 0)
+			{
+				if (done) { gaps[gi[j]].es_len = g[j].es_len; gaps[gi[j]].d_before = g[j].d_before; }
+				else redo[atomicAdd(n_redo, 1u)] = gi[j];
+			}
+		}
+	}
 }
 
 // the rest: one lane per gap, lane pool in HBM; gaps whose lane ran out of pool are redone with larger pools
@@ -758,50 +794,57 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 			ctx->stream = main_stream;
 			HIP_TRY(ctx, le);
 		}
-		// mid-size gaps
+		// gaps of up to 16 row blocks: four per wave, on a third stream — a throughput kernel next to the wave-per-gap kernel
+		// below, whose launches last as long as their single slowest gap (measured: launch 61.5 ms, slowest gap 61.4 ms) and
+		// leave the machine idle meanwhile.  The few gaps whose buffers do not fit a wave's pool come back in quad_redo.
+		DevBuf<uint32_t> quad_redo; uint32_t n_quad_redo = 0;
+		DevBuf<uint8_t> quad_scratch; DevBuf<unsigned int> qc;
+		struct Side2Join { hipStream_t s = nullptr; ~Side2Join() { if (s) (void)hipStreamSynchronize(s); } } quad_join;   // (after the buffers in destruction order)
 		if (hb[6] > hb[5])
 		{
 			const uint32_t n_list = hb[6] - hb[5];
-			const uint32_t blocks = std::min<uint32_t>(grid_for(n_list, 64), n_cu * 8);
-			DevBuf<uint64_t> scratch; DEV_ALLOC(ctx, scratch, (uint64_t)blocks * HbmMem::WORDS * 64);
-			DevBuf<unsigned long long> mprof;
-			if (getenv("COLORD_HIP_WAVE_PROFILE")) { DEV_ALLOC(ctx, mprof, 8); HIP_TRY(ctx, hipMemsetAsync(mprof.p, 0, 64, st)); }
-			LAUNCHB(ctx, 1.25 * (double)h_cb[5], k_align_mid, blocks, 64, (const uint32_t*)ids.p + hb[5], n_list, L.gaps.p, L.es.p, A, R, scratch.p, mprof.p);
-			if (mprof.p)
-			{
-				unsigned long long hp[8];
-				HIP_TRY(ctx, hipStreamSynchronize(st));
-				HIP_TRY(ctx, hipMemcpy(hp, mprof.p, 64, hipMemcpyDeviceToHost));
-				fprintf(stderr, "[mid phases, level %u, %u gaps, M ticks of 100 MHz] stage %llu peq %llu forward %llu traceback %llu refactor %llu tail %llu\n", lv, n_list,
-					hp[4] / 1000000, hp[0] / 1000000, hp[1] / 1000000, hp[2] / 1000000, hp[3] / 1000000, hp[5] / 1000000);
-			}
+			const uint64_t per_wave = 3ull << 20;
+			const uint32_t waves = std::min<uint32_t>((n_list + 3) / 4, 5120);
+			DEV_ALLOC(ctx, quad_scratch, per_wave * waves);
+			DEV_ALLOC(ctx, qc, 2);
+			DEV_ALLOC(ctx, quad_redo, (uint64_t)n_list + 1);
+			if (!ctx->side2) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side2, hipStreamNonBlocking));
+			quad_join.s = ctx->side2;
+			HIP_TRY(ctx, hipMemsetAsync(qc.p, 0, 8, ctx->side2));
+			hipStream_t main_stream = ctx->stream;
+			ctx->stream = ctx->side2;                                             // (launch + timing events on the third stream)
+			LAUNCHB(ctx, 1.25 * (double)h_cb[5], k_align_quad, waves, 64, (const uint32_t*)ids.p + hb[5], n_list, L.gaps.p, L.es.p, A, R, quad_scratch.p, per_wave, qc.p, quad_redo.p, qc.p + 1);
+			ctx->stream = main_stream;
 			HIP_TRY(ctx, hipGetLastError());
-			HIP_TRY(ctx, hipStreamSynchronize(st));
 		}
 		// large gaps, in rounds of growing lane pools
+		auto run_large = [&](const uint32_t* list, uint32_t n_list, double alg_bytes) -> cl_status
 		{
-			uint32_t n_list = hb[7] - hb[6];
-			if (n_list && getenv("COLORD_HIP_GAP_DEBUG"))
-			{	// diagnostic: the largest gaps of the level (the list is ascending in log2 of the work) and the total work
+			if (n_list && getenv("COLORD_HIP_GAP_DEBUG") && list == ids.p + hb[6])
+			{	// diagnostic: shapes of the wave-class gaps of the level (the list is ascending in log2 of the work)
 				HIP_TRY(ctx, hipStreamSynchronize(st));
 				std::vector<uint32_t> h_ids(n_list);
-				HIP_TRY(ctx, hipMemcpy(h_ids.data(), ids.p + hb[6], (uint64_t)n_list * 4, hipMemcpyDeviceToHost));
-				std::vector<GapRec> top(std::min<uint32_t>(n_list, 4096));
-				double work = 0, wmax = 0; std::string txt;
-				for (uint32_t i = 0; i < top.size(); ++i) HIP_TRY(ctx, hipMemcpy(&top[i], L.gaps.p + h_ids[n_list - 1 - i], sizeof(GapRec), hipMemcpyDeviceToHost));
-				for (uint32_t i = 0; i < top.size(); ++i)
+				HIP_TRY(ctx, hipMemcpy(h_ids.data(), list, (uint64_t)n_list * 4, hipMemcpyDeviceToHost));
+				std::vector<GapRec> all(L.n_gaps);
+				HIP_TRY(ctx, hipMemcpy(all.data(), L.gaps.p, (uint64_t)L.n_gaps * sizeof(GapRec), hipMemcpyDeviceToHost));
+				double work = 0, steps = 0; std::string txt; uint64_t hist[8] = { 0 }; double hwork[8] = { 0 };
+				for (uint32_t i = 0; i < n_list; ++i)
 				{
-					const uint32_t rows = top[i].kind == GK_FLANK ? top[i].ne : top[i].use, cols = top[i].kind == GK_FLANK ? top[i].use : top[i].ne;
-					const double w = (double)((rows + 63) / 64) * cols;
-					work += w; wmax = std::max(wmax, w);
-					if (i < 12) txt += " " + std::string(top[i].kind == GK_FLANK ? "F" : "I") + std::to_string(rows) + "x" + std::to_string(cols);
+					const GapRec& t = all[h_ids[n_list - 1 - i]];
+					const uint32_t rows = t.kind == GK_FLANK ? t.ne : t.use, cols = t.kind == GK_FLANK ? t.use : t.ne;
+					const double w = (double)((rows + 63) / 64) * cols, st_ = (double)((rows + 4095) / 4096) * (cols + 63);
+					work += w; steps += st_;
+					const int b = rows <= 256 ? 0 : rows <= 1024 ? 1 : rows <= 4096 ? 2 : rows <= 16384 ? 3 : 4;
+					hist[b]++; hwork[b] += st_;
+					if (i < 8) txt += " " + std::string(t.kind == GK_FLANK ? "F" : "I") + std::to_string(rows) + "x" + std::to_string(cols);
 				}
-				fprintf(stderr, "[gaps] level %u: %u wave-class gaps; top-%zu block-columns %.3g (largest %.3g):%s\n", lv, n_list, top.size(), work, wmax, txt.c_str());
+				fprintf(stderr, "[gaps] level %u: classes 1-4 %u, quad %u, wave %u; wave class: block-columns %.3g, sweep steps %.3g; by rows <=256 %llu (%.3g steps) <=1024 %llu (%.3g) <=4096 %llu (%.3g) <=16384 %llu (%.3g) more %llu (%.3g); largest:%s\n",
+					lv, hb[5] - hb[1], hb[6] - hb[5], n_list, work, steps, (unsigned long long)hist[0], hwork[0], (unsigned long long)hist[1], hwork[1], (unsigned long long)hist[2], hwork[2],
+					(unsigned long long)hist[3], hwork[3], (unsigned long long)hist[4], hwork[4], txt.c_str());
 			}
 			DevBuf<uint32_t> todo, redo; DEV_ALLOC(ctx, todo, (uint64_t)n_list + 1); DEV_ALLOC(ctx, redo, (uint64_t)n_list + 1);
 			DevBuf<unsigned int> cnt; DEV_ALLOC(ctx, cnt, 2);
-			const uint32_t* list = ids.p + hb[6];
-			uint64_t per_lane = 3ull << 20; uint32_t max_lanes = 5120;           // waves (k_align_wave) / lanes (k_align_large)
+			uint64_t per_lane = 6ull << 20; uint32_t max_lanes = 2560;           // waves (k_align_wave) / lanes (k_align_large): a read of 200 kb fits the first round
 			const bool use_wave = getenv("COLORD_HIP_NO_WAVE_ALIGN") == nullptr;
 			DevBuf<unsigned long long> prof;
 			if (getenv("COLORD_HIP_WAVE_PROFILE")) { DEV_ALLOC(ctx, prof, 8); HIP_TRY(ctx, hipMemsetAsync(prof.p, 0, 64, st)); }
@@ -822,15 +865,16 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 				HIP_TRY(ctx, hipMemsetAsync(cnt.p, 0, 8, st));
 				if (use_wave)
 				{
-				LAUNCHB(ctx, round == 0 ? 1.25 * (double)h_cb[6] : 0.0, k_align_wave, lanes, 64, list, n_list, L.gaps.p, L.es.p, A, R, scratch.p, per_lane, cnt.p, redo.p, cnt.p + 1,
+				const auto t_launch = std::chrono::steady_clock::now();
+				LAUNCHB(ctx, round == 0 ? alg_bytes : 0.0, k_align_wave, lanes, 64, list, n_list, L.gaps.p, L.es.p, A, R, scratch.p, per_lane, cnt.p, redo.p, cnt.p + 1,
 					(uint32_t)(getenv("COLORD_HIP_WAVE_DEBUG_STAGE") ? atoi(getenv("COLORD_HIP_WAVE_DEBUG_STAGE")) : 0), hbt_dev, prof.p);
 				if (prof.p)
 				{
 					unsigned long long hp[8];
 					HIP_TRY(ctx, hipStreamSynchronize(st));
 					HIP_TRY(ctx, hipMemcpy(hp, prof.p, 64, hipMemcpyDeviceToHost));
-					fprintf(stderr, "[wave phases, level %u, %u gaps, Mcycles of 100 MHz] alloc %llu stage %llu sweep %llu path %llu convert %llu refactor %llu fetch %llu\n", lv, n_list,
-						hp[0] / 1000000, hp[1] / 1000000, hp[2] / 1000000, hp[3] / 1000000, hp[4] / 1000000, hp[5] / 1000000, hp[7] / 1000000);
+					fprintf(stderr, "[wave phases, level %u, %u gaps, Mcycles of 100 MHz] alloc %llu stage %llu sweep %llu path %llu convert %llu refactor %llu fetch %llu; slowest gap %.2f ms (rank %llu from the largest); launch of %u waves %.1f ms\n", lv, n_list,
+						hp[0] / 1000000, hp[1] / 1000000, hp[2] / 1000000, hp[3] / 1000000, hp[4] / 1000000, hp[5] / 1000000, hp[7] / 1000000, (double)(hp[6] >> 24) / 1e5, hp[6] & 0xffffffull, lanes, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_launch).count());
 				}
 				}
 				else LAUNCH(ctx, k_align_large, lanes / 64, 64, list, n_list, L.gaps.p, L.es.p, A, R, scratch.p, per_lane, cnt.p, redo.p, cnt.p + 1);
@@ -847,7 +891,18 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 				}
 				per_lane *= 8; max_lanes = std::max<uint32_t>(max_lanes / 8, 64);
 			}
+			return CL_OK;
+		};
+		CL_TRY(run_large(ids.p + hb[6], hb[7] - hb[6], 1.25 * (double)h_cb[6]));
+		if (quad_join.s)
+		{
+			unsigned int hc[2];
+			HIP_TRY(ctx, hipMemcpyAsync(hc, qc.p, 8, hipMemcpyDeviceToHost, ctx->side2));
+			HIP_TRY(ctx, hipStreamSynchronize(ctx->side2));
+			quad_join.s = nullptr;
+			n_quad_redo = hc[1];
 		}
+		if (n_quad_redo) CL_TRY(run_large(quad_redo.p, n_quad_redo, 0.0));
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->side));                           // the small gaps are through
 		// statistics / decisions, children
 		DevBuf<uint32_t> sflag, sncand; DEV_ALLOC(ctx, sflag, ng + 1); DEV_ALLOC(ctx, sncand, ng + 1);

@@ -76,6 +76,7 @@ extern "C" int dbg_encode(const uint64_t* r_packed, const uint64_t* r_woff, cons
 			if (cls == 0) continue;
 			if (force_large == 1) cls = 6;
 			if (force_large == 2 && cls <= 4) cls = 5;                           // everything alignable through the mid path
+			if (cls == 5 && (rows > MID_ROWS || cols > MID_COLS)) cls = 6;
 			stats[cls]++;
 			if (cls == 5)
 			{
