@@ -28,6 +28,7 @@ import sys
 import tempfile
 import time
 
+T_PROCESS_START = time.time()
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -55,8 +56,10 @@ def parse():
                     help="part (= range-coder restart) size in symbols.  4194304 reproduces the reference's packs (defs.h:45) and its exact "
                          "bytes; smaller parts are equally valid archives (the reference decoder follows the part table), cost 8 flush "
                          "bytes each (+0.04 %% at 64 Ki) and expose the parallelism the per-part dependent chain needs")
-    ap.add_argument("--budget-s", type=float, default=1800.0,
-                    help="if (steps + warmup) passes over --bases would exceed this at ~1 Gbases/s/GPU, the input is reduced to fit (and named so)")
+    ap.add_argument("--deadline-s", type=float, default=1500.0,
+                    help="wall-clock budget of the whole process (the driver stops a run after 1800 s).  If (steps + warmup) passes over --bases "
+                         "cannot finish inside it — estimated up front at 1.1 Gbases/s/GPU, then checked against the first warm-up pass — the input "
+                         "is cut to a prefix of the file that can, and `config.workload` says so")
     ap.add_argument("--no-qual", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -143,6 +146,15 @@ class Shard:
     def free(self):
         for c in self.chunks:
             c[0].free()
+
+    def keep_prefix(self, n_chunks: int):
+        """Drops the trailing chunks (the input becomes a prefix of this rank's part of the file)."""
+        for c in self.chunks[n_chunks:]:
+            c[0].free()
+        self.chunks = self.chunks[:n_chunks]
+        self.n_bases = sum(int(c[0].total_bases) for c in self.chunks)
+        self.n_reads = sum(int(c[0].n_reads) for c in self.chunks)
+        self.n_parts = sum(len(c[1]) - 1 for c in self.chunks)
 
 
 def _sub_cuts(table, r0, r1, bases):
@@ -264,7 +276,7 @@ def load_traffic(kernel: str):
     if not os.path.exists(path):
         return None, None
     t = json.load(open(path))
-    e = t.get("kernels", {}).get(kernel)
+    e = t.get("kernels", {}).get(kernel.split("<")[0].strip())
     if not e:
         return None, t.get("source")
     return e["hbm_bytes_per_launch"], t.get("source")
@@ -295,10 +307,13 @@ def main():
     ctx = Context(local, timing=True)
     qctx = Context(local, timing=True) if not os.environ.get("BENCH_NO_OVERLAP") else None
     bases = float(args.bases)
-    est_s = (args.steps + args.warmup) * bases / (1.0e9 * world)
+    # what the passes may take: the deadline minus what is spent already, the CPU-baseline / size-check leg (~2 min) and a margin
+    reserve_s = (150.0 if (world == 1 and not args.no_cpu_baseline) else 30.0) + 30.0
+    pass_budget_s = max(10.0, args.deadline_s - (time.time() - T_PROCESS_START) - reserve_s - bases / 5e9)
+    est_s = (args.steps + args.warmup) * bases / (1.1e9 * world)
     reduced = False
-    if est_s > args.budget_s:
-        bases = max(1e8, args.budget_s * 1.0e9 * world / (args.steps + args.warmup))
+    if est_s > pass_budget_s:
+        bases = max(1e8, pass_budget_s * 1.1e9 * world / (args.steps + args.warmup))
         reduced = True
     genome_len = max(1_000_000, int(bases / args.coverage))
     table = ontsim.ReadTable(seed=1, genome_len=genome_len, target_bases=int(bases))        # the same table on every rank
@@ -327,8 +342,21 @@ def main():
     def step():
         return hot_path_step(ctx, qctx, shard, prm, not args.no_qual, exchange, dna_out, qual_out, shard.n_bases)
 
-    for _ in range(args.warmup):
+    for w in range(args.warmup):
+        t_w = time.perf_counter()
         step()
+        if w == 0 and args.warmup + args.steps > 1:
+            # the first pass is the measurement the estimate above lacked: if the remaining passes cannot finish inside the
+            # deadline at this rate, every rank keeps the same leading fraction of its chunks (a prefix of its part of the file)
+            torch.cuda.synchronize()
+            t_pass = time.perf_counter() - t_w
+            left = args.deadline_s - (time.time() - T_PROCESS_START) - reserve_s
+            frac = torch.tensor([min(1.0, max(0.0, left) / max(1e-9, (args.warmup - 1 + args.steps) * t_pass))], dtype=torch.float64, device=ctx.device if backend == "nccl" else "cpu")
+            if world > 1:
+                dist.all_reduce(frac, op=dist.ReduceOp.MIN)
+            if float(frac.item()) < 1.0:
+                shard.keep_prefix(max(1, int(len(shard.chunks) * float(frac.item()))))
+                reduced = True
     ctx.acc.clear()
     if qctx is not None:
         qctx.acc.clear()
@@ -341,12 +369,12 @@ def main():
     dt = time.perf_counter() - t0
     red_dev = ctx.device if backend == "nccl" else torch.device("cpu")
     tdev = torch.tensor([dt], dtype=torch.float64, device=red_dev)
-    tb = torch.tensor([shard.n_bases, info["dna_bytes"], info["qual_bytes"]], dtype=torch.int64, device=red_dev)
+    tb = torch.tensor([shard.n_bases, info["dna_bytes"], info["qual_bytes"], shard.n_reads], dtype=torch.int64, device=red_dev)
     if world > 1:
         dist.all_reduce(tdev, op=dist.ReduceOp.MAX)
         dist.all_reduce(tb)
     dt = float(tdev.item())
-    total_bases, total_dna, total_qual = (int(x) for x in tb.tolist())
+    total_bases, total_dna, total_qual, total_reads = (int(x) for x in tb.tolist())
 
     times = StepTimes(ctx, qctx)
     if rank == 0:
@@ -388,9 +416,9 @@ def main():
                                 "whole program, hardware not stated) — the only published figure; the measured reference on this host is `cpu_baseline`",
             "archive_vs_ref": (size or {}).get("archive_vs_ref"),
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"synthetic ONT {total_bases / 1e9:.2f} Gbases ({table.n_reads} reads, N50~20kb, 4-avg quals), genome {genome_len} bp, "
+            "config": {"workload": f"synthetic ONT {total_bases / 1e9:.2f} Gbases ({total_reads} reads, N50~20kb, 4-avg quals), genome {genome_len} bp, "
                                    f"k={k} a={a} f={PRESET['f']} ci={PRESET['ci']} cs={PRESET['cs']} c={PRESET['c']} (compress-ont default preset)"
-                                   + (f"; REDUCED from {args.bases / 1e9:.1f} Gbases to fit --budget-s {args.budget_s:.0f}" if reduced else ""),
+                                   + (f"; REDUCED from {args.bases / 1e9:.1f} Gbases (a prefix of the set) so that {args.steps}+{args.warmup} passes fit --deadline-s {args.deadline_s:.0f}" if reduced else ""),
                        "chunks_per_gpu": info["chunks"], "chunk_bases": args.chunk_bases, "part_symbols": args.pack_symbols,
                        "stages": "pass 1: a1 a2 a3; pass 2a: a4 a6 a7 a5 (index); pass 2b per chunk: a5 (candidates) a8 a10 a11 a12 a14 a16"
                                  + ("" if args.no_qual else " + a13 a15 (4-avg, level 1)") + ("; parts gathered to rank 0" if world > 1 else ""),
