@@ -29,6 +29,10 @@ import tempfile
 import time
 
 T_PROCESS_START = time.time()
+# The pipeline keeps up to ten HIP streams busy (three contexts with side streams, the encode lane); with the runtime's default
+# of 4 hardware queues, streams that share a queue serialise (measured at 50 Gbases: 41.4 s/step with 4, 39.6 with 8, 39.3 with
+# 16).  Read by the HIP runtime when it initialises, so it has to be in the environment before the first HIP call.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -328,8 +332,8 @@ def main():
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_gen
     torch.cuda.empty_cache()                                # the generator's temporaries go back to the device (the library has its own pools)
-    dna_out = torch.empty(int(shard.n_bases * 0.26) + (1 << 24), dtype=torch.uint8, device=ctx.device)
-    qual_out = None if args.no_qual else torch.empty(int(shard.n_bases * 0.28) + (1 << 24), dtype=torch.uint8, device=ctx.device)
+    dna_out = torch.empty(int(shard.n_bases * 0.20) + (1 << 26), dtype=torch.uint8, device=ctx.device)
+    qual_out = None if args.no_qual else torch.empty(int(shard.n_bases * 0.26) + (1 << 26), dtype=torch.uint8, device=ctx.device)
     exchange = par.TorchExchange(ctx.device) if world > 1 else None
     prm = params_for(k, a)
 

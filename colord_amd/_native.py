@@ -7,6 +7,9 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# more hardware queues than the HIP runtime's default of 4: the contexts of one compressor keep up to ten streams busy and
+# streams that share a queue serialise (bench.py has the measurement); only effective before the runtime initialises
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcolord_hip.so")
 

@@ -349,6 +349,9 @@ int run_compress(int argc, char** argv)
 		uint8_t* d_dna = nullptr; uint8_t* d_qual = nullptr;
 		hipck(hipMalloc((void**)&d_dna, dna_cap), "hipMalloc"); if (with_qual) hipck(hipMalloc((void**)&d_qual, qual_cap), "hipMalloc");
 		std::vector<uint8_t> h_dna, h_qual;
+		// every chunk is resident: announce them, so that candidates / anchors / edit scripts of the next chunks are computed on the
+		// compressor's encode lanes while this thread codes and writes the parts of the chunks before them
+		for (auto& dc : chunks) ck(ctx, cl_compressor_prepare(cmp, dc.reads, dc.packs.data(), (uint32_t)dc.packs.size() - 1), "look-ahead");
 		for (auto& dc : chunks)
 		{
 			const uint32_t np = (uint32_t)dc.packs.size() - 1;

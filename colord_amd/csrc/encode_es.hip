@@ -803,8 +803,8 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 		if (hb[6] > hb[5])
 		{
 			const uint32_t n_list = hb[6] - hb[5];
-			const uint64_t per_wave = 3ull << 20;
-			const uint32_t waves = std::min<uint32_t>((n_list + 3) / 4, 5120);
+			const uint64_t per_wave = 9ull << 18;                                 // 2.25 MB: four histories of at most 512 KB + the sequences and scripts of four gaps
+			const uint32_t waves = std::min<uint32_t>((n_list + 3) / 4, 4096);
 			DEV_ALLOC(ctx, quad_scratch, per_wave * waves);
 			DEV_ALLOC(ctx, qc, 2);
 			DEV_ALLOC(ctx, quad_redo, (uint64_t)n_list + 1);
@@ -844,7 +844,7 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 			}
 			DevBuf<uint32_t> todo, redo; DEV_ALLOC(ctx, todo, (uint64_t)n_list + 1); DEV_ALLOC(ctx, redo, (uint64_t)n_list + 1);
 			DevBuf<unsigned int> cnt; DEV_ALLOC(ctx, cnt, 2);
-			uint64_t per_lane = 6ull << 20; uint32_t max_lanes = 2560;           // waves (k_align_wave) / lanes (k_align_large): a read of 200 kb fits the first round
+			uint64_t per_lane = 6ull << 20; uint32_t max_lanes = 2048;           // waves (k_align_wave) / lanes (k_align_large): a read of 200 kb fits the first round
 			const bool use_wave = getenv("COLORD_HIP_NO_WAVE_ALIGN") == nullptr;
 			DevBuf<unsigned long long> prof;
 			if (getenv("COLORD_HIP_WAVE_PROFILE")) { DEV_ALLOC(ctx, prof, 8); HIP_TRY(ctx, hipMemsetAsync(prof.p, 0, 64, st)); }

@@ -455,7 +455,7 @@ extern "C" cl_status cl_compressor_prepare(cl_compressor* c, const cl_reads* rea
 		return cl_fail(ctx, CL_E_INVALID, "cl_compressor_prepare: chunks must be announced in the order and sizes of pass 1, before they are encoded");
 	if (c->lane_ctx.empty())
 	{
-		uint32_t lanes = 1;
+		uint32_t lanes = 2;
 		if (const char* e = getenv("COLORD_HIP_ENCODE_LANES")) lanes = (uint32_t)std::min(4, std::max(1, atoi(e)));
 		while (ctx->lanes.size() < lanes)
 		{
