@@ -17,7 +17,8 @@ namespace wv {
 struct WavePool {
 	uint8_t* base; uint64_t cap, top; bool overflow; volatile uint32_t* hb;       // hb: optional host-visible progress word (debugging)
 	unsigned long long* prof = nullptr; uint64_t t_last = 0;                      // optional per-phase clock accumulation (debugging)
-	__device__ inline void lap(uint32_t phase) { if (prof) { const uint64_t now = wall_clock64(); if ((threadIdx.x & 63) == 0) atomicAdd(prof + phase, (unsigned long long)(now - t_last)); t_last = now; } }
+	uint64_t gp[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };                                  // the same per gap (reset by the kernel): phases of the slowest gap
+	__device__ inline void lap(uint32_t phase) { if (prof) { const uint64_t now = wall_clock64(); gp[phase & 7] += now - t_last; if ((threadIdx.x & 63) == 0) atomicAdd(prof + phase, (unsigned long long)(now - t_last)); t_last = now; } }
 	__device__ inline void beat(uint32_t code) { if (hb && (threadIdx.x & 63) == 0) *hb = code; }
 	__device__ inline void* alloc(uint64_t bytes)
 	{
@@ -358,12 +359,17 @@ __device__ inline void wave_path(WavePool& pool, const uint8_t* q, uint32_t n, c
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 		// smallest i in 1..n-1 with left[i] + right[n - i] == best, else the empty prefix, else the whole query
 		int64_t found = -1; uint32_t ls = 0, rs = 0;
-		for (uint32_t base = 1; base + 1 <= jb.n && found < 0; base += 64)
-		{
-			const uint32_t i = base + lane;
-			const bool hit = i + 1 <= jb.n && (uint32_t)(left[i] + right[jb.n - i]) == jb.best;
-			const uint64_t bal = __ballot(hit);
-			if (bal) { const uint32_t f = (uint32_t)__builtin_ctzll(bal); found = base + f; }
+		for (uint32_t base = 1; base + 1 <= jb.n && found < 0; base += 256)
+		{	// four 64-row steps per round trip (the eight loads are independent)
+			bool hit[4];
+#pragma unroll
+			for (uint32_t u = 0; u < 4; ++u) { const uint32_t i = base + u * 64 + lane; hit[u] = i + 1 <= jb.n && (uint32_t)(left[i] + right[jb.n - i]) == jb.best; }
+#pragma unroll
+			for (uint32_t u = 0; u < 4; ++u)
+			{
+				const uint64_t bal = __ballot(hit[u]);
+				if (bal && found < 0) { const uint32_t f = (uint32_t)__builtin_ctzll(bal); found = base + u * 64 + f; }
+			}
 		}
 		if (found >= 0) { ls = bcast_first((uint32_t)left[found]); rs = bcast_first((uint32_t)right[jb.n - (uint32_t)found]); }
 		if (found < 0 && L + (uint32_t)bcast_first((uint32_t)right[jb.n]) == jb.best) { found = 0; ls = L; rs = bcast_first((uint32_t)right[jb.n]); }
@@ -398,16 +404,44 @@ __device__ inline bool wave_refactor_pass(WavePool& pool, char* es, uint32_t k, 
 	uint64_t* bits = (uint64_t*)pool.alloc((uint64_t)n_chunks * 16);              // per chunk: boundary mask, match mask
 	if (pool.overflow) { pool.release(mk); return false; }
 	const uint64_t le = lane == 63 ? ~0ull : ((2ull << lane) - 1);                  // lanes <= me
+	// Both sweeps are chains of memory round trips when written naively (symbols of the step -> their positions -> the
+	// sequence symbols there): on the slowest gaps of a launch — flanks of 10^5 symbols, which bound the launch — that was most
+	// of the time.  So the loads run AHEAD of the carries: script symbols two steps ahead, sequence symbols one step ahead
+	// (their positions need only the consumed-symbol counts of the steps before, not the region carries).
+	auto is_ins = [](char c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; };
+	auto is_mis = [](char c) { return c == 'X' || c == 'Y' || c == 'Z'; };
+	auto load_c = [&](uint32_t ch) -> char { const uint32_t x = ch * 64 + lane; return (ch < n_chunks && x < k) ? es[x] : ' '; };
+	auto classify = [&](uint32_t ch, char c, bool& cons, bool& reg) {
+		const bool valid = ch * 64 + lane < k && ch < n_chunks;
+		const bool ins = is_ins(c), mis = is_mis(c), del = c == 'D';
+		cons = valid && (pass == 1 ? !ins : !del); reg = valid && (pass == 1 ? !(ins || mis) : !(del || mis));
+	};
 	uint32_t pos_base = 0; bool c_reg = false; uint32_t c_sym = 0xff, c_start = 0, c_m = 0;
+	char cA = load_c(0), cB = load_c(1);
+	uint32_t symA; uint32_t pos_next;                                              // sequence symbols of the current step; consumed symbols before the next
+	{
+		bool cons, reg; classify(0, cA, cons, reg);
+		const uint64_t cmask = __ballot(cons);
+		const uint32_t pos = (uint32_t)__popcll(cmask & (le >> 1));
+		symA = reg ? seq[pos] : 0xffu;
+		pos_next = (uint32_t)__popcll(cmask);
+	}
 	for (uint32_t ch = 0; ch < n_chunks; ++ch)
 	{
-		const uint32_t x = ch * 64 + lane; const bool valid = x < k;
-		const char c = valid ? es[x] : ' ';
-		const bool ins = c == 'A' || c == 'C' || c == 'G' || c == 'T', mis = c == 'X' || c == 'Y' || c == 'Z', del = c == 'D';
-		const bool cons = valid && (pass == 1 ? !ins : !del), reg = valid && (pass == 1 ? !(ins || mis) : !(del || mis));
-		const uint64_t cmask = __ballot(cons);
-		const uint32_t pos = pos_base + (uint32_t)__popcll(cmask & (le >> 1));
-		const uint32_t sym = reg ? seq[pos] : 0xffu;
+		const uint32_t x = ch * 64 + lane;
+		const char c = cA;
+		const char cC = load_c(ch + 2);
+		// the next step's sequence symbols
+		uint32_t symB; uint32_t pos_after;
+		{
+			bool consB, regB; classify(ch + 1, cB, consB, regB);
+			const uint64_t cmaskB = __ballot(consB);
+			const uint32_t posB = pos_next + (uint32_t)__popcll(cmaskB & (le >> 1));
+			symB = regB ? seq[posB] : 0xffu;
+			pos_after = pos_next + (uint32_t)__popcll(cmaskB);
+		}
+		bool cons, reg; classify(ch, c, cons, reg);
+		const uint32_t sym = reg ? symA : 0xffu;
 		uint32_t p_sym = shr1(sym); bool p_reg = shr1((int)reg) != 0;
 		if (lane == 0) { p_sym = c_sym; p_reg = c_reg; }
 		const bool head = reg && (!p_reg || p_sym != sym);
@@ -422,28 +456,42 @@ __device__ inline bool wave_refactor_pass(WavePool& pool, char* es, uint32_t k, 
 		}
 		if (lane == 0) { bits[2 * ch] = H | ~R; bits[2 * ch + 1] = Mm; }
 		c_reg = bcast((int)reg, 63) != 0; c_sym = bcast(sym, 63); c_start = bcast(start, 63); c_m = bcast(m_incl, 63);
-		pos_base += (uint32_t)__popcll(cmask);
+		(void)pos_base;
+		cA = cB; cB = cC; symA = symB; pos_next = pos_after;
 	}
 	__builtin_amdgcn_s_waitcnt(0);
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 	uint32_t c_ma = 0;                                                               // matches from the start of the later chunks up to their first boundary
+	// backward: everything a step needs is loaded one step ahead
+	struct Pre { uint64_t Bd, Mm; char c; uint32_t rk, mi_; uint8_t ot; };
+	auto load_back = [&](uint32_t ch) -> Pre {
+		Pre q{ 0, 0, ' ', 0, 0, 0 };
+		if (ch >= n_chunks) return q;
+		const uint32_t x = ch * 64 + lane;
+		q.Bd = bits[2 * ch]; q.Mm = bits[2 * ch + 1];
+		if (x < k) { q.c = es[x]; q.rk = rank[x]; q.mi_ = mi[x]; q.ot = oth[x]; }
+		return q;
+	};
+	Pre cur = load_back(n_chunks - 1);
 	for (uint32_t ch = n_chunks; ch-- > 0;)
 	{
 		const uint32_t x = ch * 64 + lane;
-		const uint64_t Bd = bits[2 * ch], Mm = bits[2 * ch + 1];                      // boundary = region head or not a region symbol
+		const Pre nxt = ch ? load_back(ch - 1) : Pre{ 0, 0, ' ', 0, 0, 0 };
+		const uint64_t Bd = cur.Bd, Mm = cur.Mm;                                      // boundary = region head or not a region symbol
 		const uint64_t above = Bd & ~le;
 		uint32_t ma;
 		if (above) { const uint32_t e = (uint32_t)__builtin_ctzll(above); ma = (uint32_t)__popcll(Mm & ~le & ((1ull << e) - 1)); }
 		else ma = (uint32_t)__popcll(Mm & ~le) + c_ma;
 		if (x < k)
 		{
-			const char c = es[x];
-			const bool ins = c == 'A' || c == 'C' || c == 'G' || c == 'T', mis = c == 'X' || c == 'Y' || c == 'Z', del = c == 'D';
+			const char c = cur.c;
+			const bool ins = is_ins(c), mis = is_mis(c), del = c == 'D';
 			const bool rg = pass == 1 ? !(ins || mis) : !(del || mis);
-			if (rg) es[x] = rank[x] < mi[x] + ma ? 'M' : (char)oth[x];
+			if (rg) es[x] = cur.rk < cur.mi_ + ma ? 'M' : (char)cur.ot;
 		}
 		if (Bd) { const uint32_t e0 = (uint32_t)__builtin_ctzll(Bd); c_ma = (uint32_t)__popcll(Mm & ((1ull << e0) - 1)); }
 		else c_ma += (uint32_t)__popcll(Mm);
+		cur = nxt;
 	}
 	__builtin_amdgcn_s_waitcnt(0);
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");

@@ -186,7 +186,29 @@ __device__ inline bool align_wave_gap(wv::WavePool& pool, GapRec& g, const Arena
 	const uint8_t* Q; const uint8_t* T; uint32_t n, m; bool rows_ref; uint32_t ref_end = 0;
 	// when edlib would keep the whole history anyway (it decides on the truncated target, which is never longer), one
 	// sweep delivers both the score / end position and the history; else score sweep first, then divide and conquer
-	if (g.kind == GK_INNER || g.kind == GK_FLANK_TINY)
+	if (g.kind == GK_FLANK_TINY && g.use == 1 && g.ne >= 1)
+	{	// ONE reference symbol against a flank of the read (seen: 1 x 121 957, 87 ms through the generic sweep + Hirschberg, the
+		// slowest gap of its launch).  find_edit_dist (edit_script.h:156-239) on one row: c[1][j] = j - 1 once the symbol has
+		// occurred among the first j read symbols, else j; its traceback (up, else left, else diagonal) walks left to the FIRST
+		// occurrence and matches there — or, without any occurrence, substitutes the first read symbol.
+		Q = r2; T = e2; n = 1; m = g.ne; rows_ref = true; ref_end = 0;
+		const uint32_t lane = threadIdx.x & 63;
+		const uint32_t qs = Q[0];
+		uint32_t first = m;
+		for (uint32_t base = 0; base < m && first == m; base += 256)
+		{
+			bool hit[4];
+#pragma unroll
+			for (uint32_t u = 0; u < 4; ++u) { const uint32_t j = base + u * 64 + lane; hit[u] = j < m && T[j] == qs; }
+#pragma unroll
+			for (uint32_t u = 0; u < 4; ++u) { const uint64_t bal = __ballot(hit[u]); if (bal && first == m) first = base + u * 64 + (uint32_t)__builtin_ctzll(bal); }
+		}
+		const uint32_t at = first < m ? first : 0; const uint8_t op_at = first < m ? 0 : 3;
+		for (uint32_t j = lane; j < m; j += 64) opsbuf[j] = j == at ? op_at : 2;
+		ops.n = m;
+		pool.lap(2);
+	}
+	else if (g.kind == GK_INNER || g.kind == GK_FLANK_TINY)
 	{
 		if (g.kind == GK_INNER) { Q = rbuf; n = g.nr; T = ebuf; m = g.ne; }
 		else { Q = r2; n = g.use; T = e2; m = g.ne; ref_end = g.use - 1; }
@@ -241,24 +263,43 @@ __device__ inline bool wave_gap_finish(wv::WavePool& pool, GapRec& g, const Wave
 	if (dbg_stage == 3) return true;
 	// operations -> script symbols, 64 at a time; for the left flank the script of the reversed sequences is written reversed
 	const uint32_t k = (uint32_t)ops.n;
-	uint32_t pq = 0, pt = 0;
-	for (uint32_t x0 = 0; x0 < k; x0 += 64)
+	// (loads run ahead of the position carries: operations two steps ahead, the sequence symbols they select one step ahead)
 	{
-		const uint32_t x = x0 + lane; const bool in = x < k;
-		const uint32_t op = in ? ops.p[x] : 4u;
-		const uint64_t cq = __ballot(in && op != 2), ct = __ballot(in && op != 1);
 		const uint64_t lt = lane ? (~0ull >> (64 - lane)) : 0ull;
-		const uint32_t myq = pq + (uint32_t)__popcll(cq & lt), myt = pt + (uint32_t)__popcll(ct & lt);
-		if (in)
+		auto load_op = [&](uint32_t x0) -> uint32_t { const uint32_t x = x0 + lane; return x < k ? (uint32_t)ops.p[x] : 4u; };
+		uint32_t opA = load_op(0), opB = load_op(64);
+		uint32_t pq = 0, pt = 0, qA = 0, tA = 0;
 		{
-			char ch;
-			if (op == 0) ch = 'M';
-			else if (op == 1) ch = rows_ref ? 'D' : base_letter(Q[myq]);
-			else if (op == 2) ch = rows_ref ? base_letter(T[myt]) : 'D';
-			else ch = rows_ref ? mismatch_sym(Q[myq], T[myt]) : mismatch_sym(T[myt], Q[myq]);
-			dst[left ? k - 1 - x : x] = ch;
+			const uint64_t cq = __ballot(opA != 2 && opA != 4), ct = __ballot(opA != 1 && opA != 4);
+			const uint32_t myq = (uint32_t)__popcll(cq & lt), myt = (uint32_t)__popcll(ct & lt);
+			if (opA == 1 || opA == 3) qA = Q[myq];
+			if (opA == 2 || opA == 3) tA = T[myt];
+			pq = (uint32_t)__popcll(cq); pt = (uint32_t)__popcll(ct);
 		}
-		pq += (uint32_t)__popcll(cq); pt += (uint32_t)__popcll(ct);
+		for (uint32_t x0 = 0; x0 < k; x0 += 64)
+		{
+			const uint32_t x = x0 + lane;
+			const uint32_t op = opA, qs = qA, ts = tA;
+			const uint32_t opC = load_op(x0 + 128);
+			uint32_t qB = 0, tB = 0;
+			{	// the next step's symbols
+				const uint64_t cq = __ballot(opB != 2 && opB != 4), ct = __ballot(opB != 1 && opB != 4);
+				const uint32_t myq = pq + (uint32_t)__popcll(cq & lt), myt = pt + (uint32_t)__popcll(ct & lt);
+				if (opB == 1 || opB == 3) qB = Q[myq];
+				if (opB == 2 || opB == 3) tB = T[myt];
+				pq += (uint32_t)__popcll(cq); pt += (uint32_t)__popcll(ct);
+			}
+			if (op != 4)
+			{
+				char ch;
+				if (op == 0) ch = 'M';
+				else if (op == 1) ch = rows_ref ? 'D' : base_letter(qs);
+				else if (op == 2) ch = rows_ref ? base_letter(ts) : 'D';
+				else ch = rows_ref ? mismatch_sym(qs, ts) : mismatch_sym(ts, qs);
+				dst[left ? k - 1 - x : x] = ch;
+			}
+			opA = opB; opB = opC; qA = qB; tA = tB;
+		}
 	}
 	__builtin_amdgcn_s_waitcnt(0);
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -325,8 +366,13 @@ __global__ __launch_bounds__(64) void k_align_wave(const uint32_t* __restrict__ 
 		pool.beat(3);
 		pool.lap(7);
 		const uint64_t t_gap = prof ? wall_clock64() : 0;
+		if (prof) for (int i = 0; i < 8; ++i) pool.gp[i] = 0;
 		const bool ok_gap = align_wave_gap(pool, g, A, R, es_pool + g.es_off, dbg_stage);
-		if (prof && lane == 0) atomicMax(prof + 6, ((unsigned long long)(wall_clock64() - t_gap) << 24) | (slot & 0xffffffu));     // (diagnostic: the slowest gap and its rank)
+		if (prof && lane == 0)
+		{	// (diagnostic: the slowest gap, its rank, shape and phases)
+			const unsigned long long mine = ((unsigned long long)(wall_clock64() - t_gap) << 24) | (slot & 0xffffffu);
+			if (atomicMax(prof + 6, mine) < mine) { for (int i = 0; i < 6; ++i) prof[8 + i] = pool.gp[i]; prof[14] = ((unsigned long long)g.ne << 32) | g.use; prof[15] = g.kind; }
+		}
 		if (!ok_gap)
 		{
 			if (lane == 0) redo[atomicAdd(n_redo, 1u)] = gi;
@@ -847,7 +893,7 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 			uint64_t per_lane = 6ull << 20; uint32_t max_lanes = 2048;           // waves (k_align_wave) / lanes (k_align_large): a read of 200 kb fits the first round
 			const bool use_wave = getenv("COLORD_HIP_NO_WAVE_ALIGN") == nullptr;
 			DevBuf<unsigned long long> prof;
-			if (getenv("COLORD_HIP_WAVE_PROFILE")) { DEV_ALLOC(ctx, prof, 8); HIP_TRY(ctx, hipMemsetAsync(prof.p, 0, 64, st)); }
+			if (getenv("COLORD_HIP_WAVE_PROFILE")) { DEV_ALLOC(ctx, prof, 16); HIP_TRY(ctx, hipMemsetAsync(prof.p, 0, 128, st)); }
 			uint32_t* hbt_host = nullptr; uint32_t* hbt_dev = nullptr;
 			if (use_wave && n_list && getenv("COLORD_HIP_WAVE_HEARTBEAT"))
 			{	// debugging: host-visible progress words, dumped by a watchdog thread if the kernel is still running after a while
@@ -870,9 +916,11 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 					(uint32_t)(getenv("COLORD_HIP_WAVE_DEBUG_STAGE") ? atoi(getenv("COLORD_HIP_WAVE_DEBUG_STAGE")) : 0), hbt_dev, prof.p);
 				if (prof.p)
 				{
-					unsigned long long hp[8];
+					unsigned long long hp[16];
 					HIP_TRY(ctx, hipStreamSynchronize(st));
-					HIP_TRY(ctx, hipMemcpy(hp, prof.p, 64, hipMemcpyDeviceToHost));
+					HIP_TRY(ctx, hipMemcpy(hp, prof.p, 128, hipMemcpyDeviceToHost));
+					fprintf(stderr, "[slowest gap, level %u] kind %llu read symbols %llu reference symbols %llu: stage %.2f sweep %.2f path %.2f convert %.2f refactor %.2f ms\n", lv, hp[15], hp[14] >> 32, hp[14] & 0xffffffffull,
+						hp[9] / 1e5, hp[10] / 1e5, hp[11] / 1e5, hp[12] / 1e5, hp[13] / 1e5);
 					fprintf(stderr, "[wave phases, level %u, %u gaps, Mcycles of 100 MHz] alloc %llu stage %llu sweep %llu path %llu convert %llu refactor %llu fetch %llu; slowest gap %.2f ms (rank %llu from the largest); launch of %u waves %.1f ms\n", lv, n_list,
 						hp[0] / 1000000, hp[1] / 1000000, hp[2] / 1000000, hp[3] / 1000000, hp[4] / 1000000, hp[5] / 1000000, hp[7] / 1000000, (double)(hp[6] >> 24) / 1e5, hp[6] & 0xffffffull, lanes, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_launch).count());
 				}

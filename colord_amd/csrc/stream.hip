@@ -425,8 +425,9 @@ static void lane_main(cl_compressor* c, cl_ctx* lane)
 		size_t idx; cl_compressor::Prepared* job;
 		{
 			std::unique_lock<std::mutex> l(c->lane_mu);
-			// a lane runs at most (lanes + 1) chunks ahead of the coders: what it finishes waits in HBM until it is coded
-			c->lane_cv.wait(l, [&]() { return c->lane_stop || (!c->lane_queue.empty() && c->lane_queue.front() <= c->enc_chunk + c->lane_ctx.size()); });
+			// the lanes run at most (lanes + 2) chunks ahead of the coders: what they finish (tuple streams, ~1.5 GB per Gbase) waits in
+			// HBM until it is coded; the slack evens out chunks whose stage A or coders happen to be slow
+			c->lane_cv.wait(l, [&]() { return c->lane_stop || (!c->lane_queue.empty() && c->lane_queue.front() <= c->enc_chunk + c->lane_ctx.size() + 1); });
 			if (c->lane_stop) return;
 			idx = c->lane_queue.front(); c->lane_queue.pop_front();
 			job = c->prepared[idx].get();

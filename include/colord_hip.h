@@ -354,8 +354,8 @@ cl_status cl_compressor_encode(cl_compressor* c, const cl_reads* chunk, const ui
  * depends on no earlier chunk's output (the reference's graph and encoder threads run ahead of its two coder threads in the
  * same way, compression.cpp:547-661), so it is computed in the background on a context of the compressor's own ("encode
  * lane", COLORD_HIP_ENCODE_LANES of them, default 2, each with its own HIP streams and memory pool, about 30 GB per 1-Gbase chunk) while the caller's
- * thread codes the chunks before it; only the adaptive models of the `dna` / `qual` coders chain chunk to chunk.  A lane
- * runs at most lanes + 1 chunks ahead of the encode calls.  Output bytes are the same with or without announcements. */
+ * thread codes the chunks before it; only the adaptive models of the `dna` / `qual` coders chain chunk to chunk.  The lanes
+ * run at most lanes + 2 chunks ahead of the encode calls.  Output bytes are the same with or without announcements. */
 cl_status cl_compressor_prepare(cl_compressor* c, const cl_reads* chunk, const uint32_t* h_pack_bounds, uint32_t n_packs);
 /* what the archive's `meta` stream needs (compression.cpp:704-779), valid after count_finish (n_refs_total after refs_finish):
  * first_read = global index of this rank's first read (start of its model domain) */

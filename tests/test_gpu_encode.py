@@ -179,3 +179,44 @@ def test_compress_shard_one_call_equals_reference(ctx, cfg):
     if ctx2 is not None:
         ctx2.close()
     dc.free(); reads.free()
+
+
+@pytest.mark.parametrize("side,has_symbol", [("left", True), ("left", False), ("right", True), ("right", False)])
+def test_one_reference_symbol_flank_closed_form(ctx, side, has_symbol):
+    """A flank of the read against ONE reference symbol (GK_FLANK_TINY, use == 1) takes a closed form in the wave aligner instead
+    of a 1 x m sweep + Hirschberg (measured: 1 x 121 957 was the slowest gap of its launch, 87 ms).  The reference runs
+    find_edit_dist there (edit_script.h:156-239, 272-279, 346-354): the oracle's full DP is the judge, for a symbol that occurs in
+    the flank (matched at its first occurrence in alignment order) and for one that does not (substitution), on both flanks."""
+    from colord_amd.fastq import ReadSet
+    rng = np.random.default_rng(11)
+    a, k, f, min_alt, max_rec = 16, 20, 12, 64, 3
+    core = rng.integers(0, 4, 6000, dtype=np.uint8)
+    x = np.uint8(2)
+    flank = rng.integers(0, 4, 40000, dtype=np.uint8)                     # >= 32 752 columns: the wave class, not the four-per-wave one
+    if not has_symbol:
+        flank[flank == x] = (x + 1) % 4
+    if side == "left":
+        ref, enc = np.concatenate([[x], core]), np.concatenate([flank, core])
+    else:
+        ref, enc = np.concatenate([core, [x]]), np.concatenate([core, flank])
+    seqs = [ref.astype(np.uint8), enc.astype(np.uint8)]
+    lens = np.array([len(s) for s in seqs], np.int64)
+    rs = ReadSet(np.concatenate(seqs), np.concatenate([[0], np.cumsum(lens)]).astype(np.int64), None, [], [False, False], False)
+    reads = ctx.pack_readset(rs)
+    accept = torch.tensor([1, 0], dtype=torch.uint8, device=ctx.device)
+    refs = ctx.select_reads(reads, accept)
+    c = 5
+    crefs = torch.zeros((2, c), dtype=torch.int32, device=ctx.device)
+    cnt = torch.tensor([0, 1], dtype=torch.int32, device=ctx.device)
+    anc = ctx.anchor_candidates(reads, refs, crefs, cnt, a)
+    assert int(anc.n_cands().cpu()[1]) == 1
+    es, off, nt = ctx.encode_reads(reads, refs, anc, a, min_alt, max_rec, 1.0, np.array([0, 2], np.uint32))
+    h_es, h_off = es.cpu().numpy(), off.cpu().numpy()
+    orc = O.Encoder(a, k, f, 0, min_part_alt=min_alt, max_rec=max_rec)
+    orc.add_ref(seqs[0])
+    orc.new_pack()
+    for i, cands in ((0, []), (1, [0])):
+        t, n_t = orc.encode(seqs[i], False, cands, None)
+        assert h_es[h_off[i]:h_off[i + 1]].tobytes() == t, f"tuple stream of read {i} differs"
+        assert int(nt.cpu()[i]) == n_t
+    anc.free(); refs.free(); reads.free()
