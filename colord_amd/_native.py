@@ -133,6 +133,11 @@ _SIG = {
     "cl_compressor_refs_add": (C.c_int32, [_P, _P]),
     "cl_compressor_refs_finish": (C.c_int32, [_P]),
     "cl_compressor_encode": (C.c_int32, [_P, _P, _P, _P, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint64, _P, _P, C.c_uint64, _P, C.POINTER(CompressInfo)]),
+    "cl_compressor_genome_add": (C.c_int32, [_P, _P]),
+    "cl_compressor_pseudo_reads": (C.c_int32, [_P, _P]),
+    "cl_genome_encode": (C.c_int32, [_P, _P, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "cl_genome_decode": (C.c_int32, [_P, C.c_uint64, C.c_uint32, _P, C.c_uint64, _P, C.POINTER(C.c_uint64)]),
+    "cl_genome_md5": (C.c_int32, [_P, _P, C.c_uint32, _P]),
     "cl_compressor_prepare": (C.c_int32, [_P, _P, _P, C.c_uint32]),
     "cl_compressor_info": (C.c_int32, [_P, C.POINTER(KmerStats), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "cl_dna_decoder_create": (C.c_int32, [C.c_uint32, C.c_int32, C.c_uint32, C.c_uint32, C.c_int32, C.c_uint32, C.c_double, C.POINTER(_P)]),

@@ -255,11 +255,12 @@ bool cl_dna_decoder::decode_read(std::vector<uint8_t>& out)           // CDNACod
 extern "C" cl_status cl_dna_decoder_create(uint32_t max_alt_refs, int32_t level, uint32_t start_read_id, uint32_t n_pseudo,
                                            int32_t accept_all, uint32_t sparse_range, double sparse_exponent, cl_dna_decoder** out)
 {
-	if (!out || level < 1 || level > 3 || max_alt_refs < 1 || (!accept_all && sparse_range == 0)) return CL_E_INVALID;
+	if (!out || level < 1 || (level > 3 && level != 9) || max_alt_refs < 1 || (!accept_all && sparse_range == 0)) return CL_E_INVALID;
 	cl_dna_decoder* d = new cl_dna_decoder();
 	d->level = level; d->max_alt = max_alt_refs; d->cur_read_id = start_read_id; d->n_pseudo = n_pseudo;
 	d->accept_all = accept_all != 0; d->range = sparse_range ? sparse_range : 1; d->exponent = sparse_exponent;
-	switch (level) { case 3: d->no_tuples_in_mask = 4; d->no_symbols_in_mask = 8; break; case 2: d->no_tuples_in_mask = 3; d->no_symbols_in_mask = 7; break; default: d->no_tuples_in_mask = 2; d->no_symbols_in_mask = 5; }   // dna_coder.cpp:1253-1280
+	switch (level) { case 3: d->no_tuples_in_mask = 4; d->no_symbols_in_mask = 8; break; case 2: d->no_tuples_in_mask = 3; d->no_symbols_in_mask = 7; break; case 1: d->no_tuples_in_mask = 2; d->no_symbols_in_mask = 5; break;
+	default: d->no_tuples_in_mask = 1; d->no_symbols_in_mask = 1; }   // dna_coder.cpp:1253-1280; any other level (9: the stored reference genome, reference_genome.cpp:262,340) takes the last branch
 	d->mask_tuple = (1ULL << (3 * d->no_tuples_in_mask)) - 1; d->mask_symbol = (1ULL << (2 * d->no_symbols_in_mask)) - 1;
 	d->init_models();
 	*out = d;

@@ -72,6 +72,7 @@ struct cl_compressor {
 	std::vector<uint32_t> chunk_reads; uint64_t n_reads_local = 0, n_bases_local = 0;
 	cl_kmer_set* kset = nullptr; cl_kmer_stats gstats{};
 	uint64_t n_reads_total = 0, first_read = 0, mean_read_len = 0; uint32_t sparse_range = 0;
+	uint64_t genome_seqs = 0, genome_len = 0; uint32_t n_pseudo = 0;      // reference-genome mode (compression.cpp:405-447)
 	std::vector<uint8_t> h_accept;                  // acceptor decisions of this rank's reads
 	// pass 2a
 	size_t refs_chunk = 0; uint64_t refs_reads_seen = 0; uint32_t n_refs_local = 0;
@@ -162,6 +163,30 @@ extern "C" cl_status cl_compressor_count_add(cl_compressor* c, const cl_reads* c
 	return CL_OK;
 }
 
+// Reference-genome mode, pass 1 (compression.cpp:405-429): the genome's sequences are a second input of the k-mer counter.
+extern "C" cl_status cl_compressor_genome_add(cl_compressor* c, const cl_reads* seqs)
+{
+	if (!c || !seqs) return CL_E_INVALID;
+	cl_ctx* ctx = c->ctx;
+	if (c->phase != 0) return cl_fail(ctx, CL_E_INVALID, "cl_compressor_genome_add: pass 1 is already finished");
+	if (c->world > 1) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_compressor_genome_add: reference-genome mode with sharded reads is not supported");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	const uint32_t f = c->P.f;
+	uint64_t want = f > 1 ? (uint64_t)(seqs->total_bases / f * 1.15) + 4096 : seqs->total_bases + 64;
+	for (;;)
+	{
+		CL_TRY(c->kmers.reserve(ctx, c->kmers.n + want));
+		uint64_t got = 0;
+		const cl_status s = cl_kmer_scan(ctx, seqs, c->P.k, f, c->kmers.buf.p + c->kmers.n, c->kmers.buf.n - c->kmers.n, &got);
+		if (s == CL_E_CAPACITY) { want = got + got / 64; continue; }
+		CL_TRY(s);
+		c->kmers.n += got;
+		break;
+	}
+	c->genome_seqs += seqs->n_reads; c->genome_len += seqs->total_bases;
+	return CL_OK;
+}
+
 // k-mers to the rank that owns their key range; returns the received k-mers in c->kmers
 static cl_status exchange_kmers(cl_compressor* c)
 {
@@ -246,6 +271,12 @@ extern "C" cl_status cl_compressor_count_finish(cl_compressor* c, cl_kmer_stats*
 	// host scalars of compression.cpp:443,501-503 and the acceptor's decisions (one stream over the whole input, a6)
 	const uint64_t n = c->n_reads_total;
 	c->mean_read_len = n ? (uint64_t)((double)(st.tot_kmers * c->P.f) / n + c->P.k - 1) : 0;
+	if (c->genome_seqs && n)
+	{	// the counter saw the genome's sequences as reads too; the statistics are corrected for them (compression.cpp:443-449)
+		const uint64_t n_all = n + c->genome_seqs;
+		const uint64_t m0 = (uint64_t)((double)(st.tot_kmers * c->P.f) / n_all + c->P.k - 1);
+		c->mean_read_len = (uint64_t)((double)(m0 * n_all - c->genome_len) / (double)(n_all - c->genome_seqs));
+	}
 	c->h_accept.assign(c->n_reads_local, 1);
 	if (c->P.sparse && n)
 	{
@@ -262,6 +293,46 @@ extern "C" cl_status cl_compressor_count_finish(cl_compressor* c, cl_kmer_stats*
 }
 
 // ---- pass 2a --------------------------------------------------------------------------------------------------------
+// Reference-genome mode (reference_genome.cpp:391-419, reads_sim_graph.cpp:295-322): the overlapping pieces of the genome are
+// reference reads 0 .. n_pseudo-1 — always accepted, their k-mer lists not capped — ahead of the first read of the input.
+extern "C" cl_status cl_compressor_pseudo_reads(cl_compressor* c, const cl_reads* pseudo)
+{
+	if (!c || !pseudo) return CL_E_INVALID;
+	cl_ctx* ctx = c->ctx;
+	if (c->phase != 1 || c->refs_chunk != 0 || c->n_pseudo) return cl_fail(ctx, CL_E_INVALID, "cl_compressor_pseudo_reads: once, after count_finish and before the first refs_add");
+	if (c->world > 1) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_compressor_pseudo_reads: reference-genome mode with sharded reads is not supported");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	const uint32_t n = pseudo->n_reads;
+	if (!n) return CL_OK;
+	DevBuf<uint8_t> accept; DEV_ALLOC(ctx, accept, n);
+	HIP_TRY(ctx, hipMemsetAsync(accept.p, 1, n, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	cl_kmer_lists* lists = nullptr;
+	CL_TRY(cl_accepted_kmers(ctx, c->kset, pseudo, c->P.k, c->P.f, &lists));
+	std::unique_ptr<cl_kmer_lists, void (*)(cl_kmer_lists*)> lg(lists, cl_kmer_lists_free);
+	uint64_t n_sel = 0; uint32_t n_acc = 0;
+	cl_status s = cl_index_entries_of(ctx, lists, accept.p, 0, nullptr, nullptr, 0, &n_sel, nullptr, &n_acc);
+	if (s != CL_OK && s != CL_E_CAPACITY) return s;
+	if (n_sel)
+	{
+		CL_TRY(c->pair_ids.reserve(ctx, n_sel)); CL_TRY(c->pair_refs.reserve(ctx, n_sel));
+		CL_TRY(cl_index_entries_of(ctx, lists, accept.p, 0, c->pair_ids.buf.p, c->pair_refs.buf.p, n_sel, &n_sel, nullptr, nullptr));
+		c->pair_ids.n = c->pair_refs.n = n_sel;
+	}
+	cl_reads* piece = nullptr;
+	CL_TRY(cl_reads_select(ctx, pseudo, accept.p, &piece));
+	c->ref_pieces.push_back(piece);
+	c->n_refs_local = n; c->n_pseudo = n;
+	// the acceptor's stream with the pseudo reads in front (ref_reads_accepter.h:41-58): decisions of the real reads follow them
+	if (c->P.sparse && c->n_reads_total)
+	{
+		std::vector<uint8_t> all((size_t)n + c->n_reads_total);
+		CL_TRY(cl_ref_accept((uint32_t)c->n_reads_total, n, c->sparse_range, c->P.sparse_exponent, all.data()));
+		std::copy(all.begin() + n, all.end(), c->h_accept.begin());
+	}
+	return CL_OK;
+}
+
 extern "C" cl_status cl_compressor_refs_add(cl_compressor* c, const cl_reads* chunk)
 {
 	if (!c || !chunk) return CL_E_INVALID;
@@ -362,11 +433,11 @@ extern "C" cl_status cl_compressor_refs_finish(cl_compressor* c)
 	}
 	CL_TRY(cl_reads_from_arena(ctx, pk.p, iv.p, ln.p, nr, &c->refs));
 	pk.release(); iv.release(); ln.release();
-	CL_TRY(cl_index_build_pairs(ctx, c->kset, c->pair_ids.buf.p, c->pair_refs.buf.p, n_pairs, nullptr, 0, c->n_refs_total, 0, c->P.cs, &c->index));
+	CL_TRY(cl_index_build_pairs(ctx, c->kset, c->pair_ids.buf.p, c->pair_refs.buf.p, n_pairs, nullptr, 0, c->n_refs_total, c->n_pseudo, c->P.cs, &c->index));
 	c->pair_ids.buf.release(); c->pair_refs.buf.release(); c->pair_ids.n = c->pair_refs.n = 0;
 	// the coders of this rank's model domain; cur_read_id starts at the global index of the first read, so that the ids of
 	// references from lower ranks fit the byte count the coder derives from it (dna_coder.cpp:26-63)
-	CL_TRY(cl_dna_coder_create(ctx, c->P.c, c->P.level, (uint32_t)c->first_read, &c->dna));
+	CL_TRY(cl_dna_coder_create(ctx, c->P.c, c->P.level, (uint32_t)c->first_read + c->n_pseudo, &c->dna));     // (pseudo reads count as reads 0 .. n_pseudo-1, dna_coder.cpp:1242-1250)
 	if (c->has_qual)
 	{
 		cl_ctx* qc = (c->P.level <= 1) ? c->qctx : ctx;        // levels 2 and 3 need the edit scripts: same stream as the DNA path

@@ -463,6 +463,12 @@ class Compressor(_Obj):
         return dict(tot_kmers=st.tot_kmers, n_unique_counted=st.n_unique_counted, first_read=a.value, n_reads_total=b.value, mean_read_len=m.value,
                     sparse_range=r.value, n_refs_total=nr.value)
 
+    def genome_add(self, sequences: "Reads"):
+        _check(self.ctx, self.ctx.lib.cl_compressor_genome_add(self.h, sequences.h))
+
+    def pseudo_reads(self, pseudo: "Reads"):
+        _check(self.ctx, self.ctx.lib.cl_compressor_pseudo_reads(self.h, pseudo.h))
+
     def prepare(self, reads: "Reads", pack_bounds):
         """cl_compressor_prepare: announce a chunk of a later encode() call; its candidates / anchors / edit scripts are
         computed in the background on an encode lane while the chunks before it are coded."""

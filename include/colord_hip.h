@@ -348,6 +348,14 @@ cl_status cl_compressor_encode(cl_compressor* c, const cl_reads* chunk, const ui
                                const uint32_t* h_part_bounds, uint32_t n_parts, const uint32_t* h_pack_bounds, uint32_t n_packs,
                                uint8_t* d_dna_out, uint64_t dna_cap, uint64_t* h_dna_part_sizes,
                                uint8_t* d_qual_out, uint64_t qual_cap, uint64_t* h_qual_part_sizes, cl_compress_info* info);
+/* Reference-genome mode (`-G`; compression.cpp:405-447, reference_genome.cpp:372-429, reads_sim_graph.cpp:295-322), single GPU:
+ *   cl_compressor_genome_add    before count_finish: the genome's sequences (arenas of ACGT codes, any number of calls) are a second
+ *                               input of the k-mer counter; the statistics of count_finish are corrected for them as in the reference;
+ *   cl_compressor_pseudo_reads  once, after count_finish and before the first refs_add: the overlapping pieces of the sequences
+ *                               (length 20 x mean_read_len of cl_compressor_info, overlap 10 x (k - 1)) become reference reads
+ *                               0 .. n-1 — always accepted, their k-mer lists uncapped; the acceptor and the DNA coder count them. */
+cl_status cl_compressor_genome_add(cl_compressor* c, const cl_reads* sequences);
+cl_status cl_compressor_pseudo_reads(cl_compressor* c, const cl_reads* pseudo_reads);
 /* Optional look-ahead of pass 2.  Announces a chunk that a LATER cl_compressor_encode call will present (announce in file
  * order, before the chunk is encoded; the arena and the bounds' meaning stay as they are until that call returns).  What the
  * chunk needs before the coders — a4 accepted k-mers, a5 candidates, a8/a9 anchors, a10-a12 edit scripts and tuple streams —
@@ -366,10 +374,20 @@ cl_status cl_compressor_info(const cl_compressor* c, cl_kmer_stats* stats, uint6
  *      (quality_coder.cpp:605-657, quality_coder_impl.cpp:506-559,800-849), CIDCoder::Decode (id_coder.cpp:396-600); drivers
  *      CEntropyDecomprReads / CEntrDecomprQuals / CEntrDecomprHeaders (entr_read.h:146-191, entr_qual.h:136-260, entr_header.cpp:46-80).
  *      HOST functions (h_* pointers): a model domain decodes as one dependent chain; streams and domains are the parallelism. ---- */
+/* The `ref-genome` stream of archives written with -G -s (CReferenceGenome::Store / its archive constructor,
+ * reference_genome.cpp:235-279,325-370): every sequence a plain read under the DNA coder's "level 9" models, one part whose
+ * archive metadata is the number of sequences.  h_codes: bases 0..3 back to back, h_off: n_seqs + 1 offsets.  HOST functions.
+ * CL_E_CAPACITY with *n_out = bytes needed when the output does not fit. */
+cl_status cl_genome_encode(const uint8_t* h_codes, const uint64_t* h_off, uint32_t n_seqs, uint8_t* h_out, uint64_t cap, uint64_t* n_out);
+cl_status cl_genome_decode(const uint8_t* h_in, uint64_t n_in, uint32_t n_seqs, uint8_t* h_codes, uint64_t cap, uint64_t* h_off, uint64_t* n_out);
+/* MD5 of the sequences in the reference's packed form — what the `meta` stream carries instead of the genome without -s
+ * (reference_genome.cpp:29-67,205-213; compression.cpp:771-776). */
+cl_status cl_genome_md5(const uint8_t* h_codes, const uint64_t* h_off, uint32_t n_seqs, uint8_t* h_md5_16);
+
 typedef struct cl_dna_decoder cl_dna_decoder;
 typedef struct cl_qual_decoder cl_qual_decoder;
 typedef struct cl_id_decoder cl_id_decoder;
-/* CDNACoder::Init(false, ...) + CReferenceReads + CRefReadsAccepter: max_alt_refs / level / sparse range + exponent come from the
+/* CDNACoder::Init(false, ...) + CReferenceReads + CRefReadsAccepter: max_alt_refs / level (1-3; 9 = the models of the stored reference genome) / sparse range + exponent come from the
  * archive's `meta` stream; accept_all = ReferenceReadsMode::All; start_read_id = n_pseudo for single-domain archives. */
 cl_status cl_dna_decoder_create(uint32_t max_alt_refs, int32_t level, uint32_t start_read_id, uint32_t n_pseudo,
                                 int32_t accept_all, uint32_t sparse_range, double sparse_exponent, cl_dna_decoder** out);

@@ -24,6 +24,12 @@ CASES["bovis24_header_main"] = ("M.bovis.fastq", 24, ["compress-ont", "-i", "mai
 CASES["bovis24_header_none"] = ("M.bovis.fastq", 24, ["compress-ont", "-i", "none"])
 
 
+# reference-genome mode (config 4 of BASELINE.json): the genome stored in the archive (-s) and only its checksum (no -s)
+GENOME = "M.bovis-reference.fna"
+CASES["c4_ont_genome_stored"] = ("M.bovis.fastq", 0, ["compress-ont", "-G", GENOME, "-s"])
+CASES["c4_ont_genome_external"] = ("M.bovis.fastq", 0, ["compress-ont", "-G", GENOME])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     exp = {}
@@ -33,9 +39,13 @@ def main():
             lines = gzip.open(os.path.join(DATA, inp + ".gz"), "rb").read().split(b"\n")
             open(fq, "wb").write(b"\n".join(lines[:4 * n_reads] if n_reads else lines[:-1]) + b"\n")
             arc = os.path.join(OUT, name + ".colord")
-            subprocess.check_call([REF] + args + ["-t", "4", fq, arc], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            genome = os.path.join(tmp, GENOME)
+            if GENOME in args and not os.path.exists(genome):
+                open(genome, "wb").write(gzip.open(os.path.join(DATA, GENOME + ".gz"), "rb").read())
+            run_args = [genome if a == GENOME else a for a in args]
+            subprocess.check_call([REF] + run_args + ["-t", "4", fq, arc], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             out = os.path.join(tmp, name + ".out")
-            subprocess.check_call([REF, "decompress", arc, out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            subprocess.check_call([REF, "decompress"] + (["-G", genome] if name.endswith("_external") else []) + [arc, out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             exp[name] = {"args": args, "input": inp, "first_reads": n_reads, "decompressed_sha256": hashlib.sha256(open(out, "rb").read()).hexdigest(),
                          "archive_bytes": os.path.getsize(arc)}
             print(name, exp[name]["archive_bytes"])
