@@ -38,7 +38,7 @@ namespace colord
 	public:
 		colord_hip_reader::RecordStream rs;
 		Info info;
-		explicit DecompressionStreamImpl(const std::string& path) : rs(path)
+		explicit DecompressionStreamImpl(const std::string& path, const std::string& genome = "") : rs(path, genome)
 		{
 			const auto& I = rs.info(); const auto& M = rs.meta();
 			info.isFastq = rs.is_fastq();
@@ -56,10 +56,7 @@ namespace colord
 	};
 
 	DecompressionStream::DecompressionStream(const std::string& inputFilePath) : pImpl(new DecompressionStreamImpl(inputFilePath)) {}
-	DecompressionStream::DecompressionStream(const std::string& inputFilePath, const std::string& refGenomePath) : pImpl(new DecompressionStreamImpl(inputFilePath))
-	{
-		(void)refGenomePath;          // only archives that carry their reference genome (or have none) are readable; the stream constructor says so otherwise
-	}
+	DecompressionStream::DecompressionStream(const std::string& inputFilePath, const std::string& refGenomePath) : pImpl(new DecompressionStreamImpl(inputFilePath, refGenomePath)) {}
 	DecompressionStream::~DecompressionStream() = default;
 	Info DecompressionStream::GetInfo() const { return pImpl->info; }
 	DecompressionRecord DecompressionStream::NextRecord()

@@ -8,6 +8,7 @@
 // three passes, so the file is parsed once and any size the GPU holds (~150 Gbases of FASTQ on 288 GB) is one run.
 #include "colord_hip.h"
 #include "archive.hpp"
+#include "genome_io.hpp"
 #include <hip/hip_runtime_api.h>
 #include <zlib.h>
 #include <algorithm>
@@ -243,7 +244,6 @@ int run_compress(int argc, char** argv)
 	if (O.k && !O.a) die("if -k,--kmer-len is set -a,--anchor-len also must be set");
 	if (!O.k && O.a) die("if -a,--anchor-len is set -k,--kmer-len also must be set");
 	if (O.k && O.a > O.k) die("-a,--anchor-len must be less than or equal to -k,--kmer-len");
-	if (!O.genome.empty()) die("-G,--reference-genome: the reference-genome mode runs at the library level (cl_index_build with pseudo reads, tests/test_gpu_genome.py) but is not wired into this command yet");
 	const Preset P0 = PRESETS[O.source][O.prio];
 	Preset P = P0;
 	if (O.ci >= 0) P.ci = (uint32_t)O.ci;
@@ -290,6 +290,27 @@ int run_compress(int argc, char** argv)
 	cl_compressor* cmp = nullptr;
 	ck(ctx, cl_compressor_create(ctx, qctx, &cp, with_qual ? &qp : nullptr, nullptr, est_bases, &cmp), "cl_compressor_create");
 
+	// reference-genome mode (compression.cpp:405-429): the genome's sequences are a second input of the k-mer counter
+	genome_io::Sequences G; const bool with_genome = !O.genome.empty();
+	auto upload = [&](const genome_io::Sequences& S) -> cl_reads* {
+		uint8_t* d_codes = nullptr; uint64_t* d_off = nullptr; cl_reads* r = nullptr;
+		hipck(hipMalloc((void**)&d_codes, S.codes.size() + 1), "hipMalloc"); hipck(hipMalloc((void**)&d_off, S.off.size() * 8), "hipMalloc");
+		hipck(hipMemcpy(d_codes, S.codes.data(), S.codes.size(), hipMemcpyHostToDevice), "hipMemcpy");
+		hipck(hipMemcpy(d_off, S.off.data(), S.off.size() * 8, hipMemcpyHostToDevice), "hipMemcpy");
+		ck(ctx, cl_reads_pack(ctx, d_codes, d_off, (uint32_t)(S.off.size() - 1), 0, &r), "reference genome");
+		hipck(hipFree(d_codes), "hipFree"); hipck(hipFree(d_off), "hipFree");
+		return r;
+	};
+	if (with_genome)
+	{
+		try { G = genome_io::read_fasta(O.genome); } catch (const std::exception& e) { die(e.what()); }
+		if (G.off.size() - 1 >= (1ull << 32)) die("reference genome: too many sequences");
+		cl_reads* gr = upload(G);
+		ck(ctx, cl_compressor_genome_add(cmp, gr), "reference genome k-mers");
+		cl_reads_free(gr);
+		if (O.verbose) fprintf(stderr, "total sequences in reference genome file: %zu (%zu bases)\n", G.off.size() - 1, G.codes.size());
+	}
+
 	// pass 1 while parsing: every chunk goes to HBM (2-bit arena + quality bytes) and stays there for the three passes
 	std::vector<DevChunk> chunks; Chunk host;
 	while (R.next_chunk(host, (uint64_t)O.chunk_bases))
@@ -334,6 +355,21 @@ int run_compress(int argc, char** argv)
 	});
 	cl_kmer_stats ks{};
 	ck(ctx, cl_compressor_count_finish(cmp, &ks), "k-mer counting");
+	uint32_t genome_read_len = 0, n_pseudo = 0; const uint32_t genome_overlap = (k - 1) * 10;     // compression.cpp:407,447
+	if (with_genome)
+	{
+		uint64_t mrl = 0;
+		ck(ctx, cl_compressor_info(cmp, nullptr, nullptr, nullptr, &mrl, nullptr, nullptr), "cl_compressor_info");
+		if (20 * mrl >= (1ull << 32)) die("reference genome: pseudo reads too long");
+		genome_read_len = (uint32_t)(20 * mrl);
+		genome_io::Sequences PR;
+		try { PR = genome_io::pseudo_reads(G, genome_read_len, genome_overlap); } catch (const std::exception& e) { die(e.what()); }
+		n_pseudo = (uint32_t)(PR.off.size() - 1);
+		cl_reads* pr = upload(PR);
+		ck(ctx, cl_compressor_pseudo_reads(cmp, pr), "reference genome pseudo reads");
+		cl_reads_free(pr);
+		if (O.verbose) fprintf(stderr, "# ref genome pseudo reads: %u (length %u, overlap %u)\n", n_pseudo, genome_read_len, genome_overlap);
+	}
 	for (auto& dc : chunks) ck(ctx, cl_compressor_refs_add(cmp, dc.reads), "reference reads");
 	ck(ctx, cl_compressor_refs_finish(cmp), "reference index");
 	uint64_t mean_read_len = 0; uint32_t sparse_range = 0, n_refs = 0;
@@ -341,7 +377,15 @@ int run_compress(int argc, char** argv)
 	if (O.verbose) fprintf(stderr, "k=%u a=%u; %llu k-mers, %llu kept; %u reference reads; sparse range %u\n", k, a, (unsigned long long)ks.tot_kmers, (unsigned long long)ks.n_unique_counted, n_refs, sparse_range);
 
 	ArchiveWriter ar; ar.open(O.out);
-	const int s_meta = ar.reg("meta"), s_header = ar.reg("header"), s_dna = ar.reg("dna"), s_qual = with_qual ? ar.reg("qual") : -1;
+	const int s_meta = ar.reg("meta"), s_genome = (with_genome && O.store_genome) ? ar.reg("ref-genome") : -1, s_header = ar.reg("header"), s_dna = ar.reg("dna"), s_qual = with_qual ? ar.reg("qual") : -1;
+	if (s_genome >= 0)
+	{	// CReferenceGenome::Store(archive) (reference_genome.cpp:325-370): one part, metadata = number of sequences
+		std::vector<uint8_t> gs(G.codes.size() / 3 + 4096); uint64_t got = 0;
+		cl_status st = cl_genome_encode(G.codes.data(), G.off.data(), (uint32_t)(G.off.size() - 1), gs.data(), gs.size(), &got);
+		if (st == CL_E_CAPACITY) { gs.resize(got); st = cl_genome_encode(G.codes.data(), G.off.data(), (uint32_t)(G.off.size() - 1), gs.data(), gs.size(), &got); }
+		if (st != CL_OK) die("cannot code the reference genome");
+		ar.add(s_genome, gs.data(), got, G.off.size() - 1);
+	}
 	uint64_t dna_total = 0, qual_total = 0; uint32_t n_parts_total = 0;
 	{	// pass 2: chunk by chunk; the parts of a chunk go to the archive while the next chunk is coded
 		uint64_t max_bases = 0, max_parts = 0; for (auto& dc : chunks) { max_bases = std::max(max_bases, dc.n_bases); max_parts = std::max<uint64_t>(max_parts, dc.packs.size()); }
@@ -372,8 +416,8 @@ int run_compress(int argc, char** argv)
 	for (size_t p = 0; p < hdr_parts.size(); ++p) ar.add(s_header, hdr_parts[p].data(), hdr_parts[p].size(), hdr_counts[p]);
 
 	// meta (compression.cpp:704-779), info (utils.cpp:326-342)
-	uint32_t tot_ref = n;
-	if (P.sparse) { std::vector<uint8_t> acc(n); ck(ctx, cl_ref_accept(n, 0, sparse_range, O.exponent, acc.data()), "cl_ref_accept"); tot_ref = 0; for (uint8_t x : acc) tot_ref += x; }
+	uint32_t tot_ref = n + n_pseudo;
+	if (P.sparse) { std::vector<uint8_t> acc((size_t)n + n_pseudo); ck(ctx, cl_ref_accept(n, n_pseudo, sparse_range, O.exponent, acc.data()), "cl_ref_accept"); tot_ref = 0; for (uint8_t x : acc) tot_ref += x; }
 	std::vector<uint8_t> meta;
 	le<uint32_t>(meta, tot_ref); le<uint32_t>(meta, P.c); le<int32_t>(meta, P.level); meta.push_back((uint8_t)O.source);
 	le<uint64_t>(meta, (uint64_t)n * mean_read_len);
@@ -385,7 +429,18 @@ int run_compress(int argc, char** argv)
 	meta.push_back((uint8_t)O.header_mode);
 	meta.push_back(P.sparse ? 1 : 0);                                    // ReferenceReadsMode: All = 0, Sparse = 1
 	if (P.sparse) { le<uint32_t>(meta, sparse_range); le_double(meta, O.exponent); }
-	meta.push_back(0);                                                   // no reference genome
+	meta.push_back(with_genome ? 1 : 0);                                 // compression.cpp:764-777
+	if (with_genome)
+	{
+		meta.push_back(O.store_genome ? 1 : 0);
+		le<uint32_t>(meta, genome_read_len); le<uint32_t>(meta, genome_overlap); le<uint32_t>(meta, n_pseudo);
+		if (!O.store_genome)
+		{	// the decompressor will ask for the same genome (md5 of its packed sequences)
+			uint8_t md[16];
+			if (cl_genome_md5(G.codes.data(), G.off.data(), (uint32_t)(G.off.size() - 1), md) != CL_OK) die("cannot checksum the reference genome");
+			meta.insert(meta.end(), md, md + 16);
+		}
+	}
 	ar.add(s_meta, meta.data(), meta.size(), 0);
 	const int s_info = ar.reg("info");
 	std::vector<uint8_t> inf;

@@ -23,19 +23,19 @@ int run_info(int argc, char** argv)
 
 int run_decompress(int argc, char** argv)
 {
-	std::vector<std::string> pos;
+	std::vector<std::string> pos; std::string genome;
 	for (int i = 2; i < argc; ++i)
 	{
 		const std::string a = argv[i];
-		if ((a == "-G" || a == "--reference-genome") && i + 1 < argc) die("decompress -G: archives that need an external reference genome are not supported yet (compress with -s)");
+		if ((a == "-G" || a == "--reference-genome") && i + 1 < argc) genome = argv[++i];      // needed when the archive was written with -G but without -s
 		else if (a == "-v" || a == "--verbose") ;
 		else pos.push_back(a);
 	}
-	if (pos.size() != 2) { fprintf(stderr, "usage: colord_hip decompress archive.colord output.fastq\n"); return 1; }
+	if (pos.size() != 2) { fprintf(stderr, "usage: colord_hip decompress [-G reference_genome.fa] archive.colord output.fastq\n"); return 1; }
 	uint64_t n_rec = 0; bool write_ok = true;
 	try
 	{
-		RecordStream rs(pos[0]);
+		RecordStream rs(pos[0], genome);
 		FILE* out = fopen(pos[1].c_str(), "wb");
 		if (!out) die("cannot open file: " + pos[1]);
 		std::vector<char> obuf(1 << 24); setvbuf(out, obuf.data(), _IOFBF, obuf.size());

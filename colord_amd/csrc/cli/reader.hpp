@@ -10,6 +10,7 @@
 #pragma once
 #include "colord_hip.h"
 #include "archive.hpp"
+#include "genome_io.hpp"
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -30,7 +31,7 @@ struct HeaderPart { std::vector<uint8_t> ids; std::vector<uint64_t> off; std::ve
 struct Meta {                                                          // the `meta` stream (compression.cpp:704-779)
 	uint32_t tot_ref_reads = 0, max_candidates = 0; int32_t level = 1; uint8_t source = 0; uint64_t approx_size = 0;
 	uint8_t qual_mode = 8; std::vector<uint32_t> rev; uint8_t header_mode = 0, ref_mode = 0; uint32_t sparse_range = 0; double sparse_exp = 0;
-	bool genome = false;
+	bool genome = false, genome_in_archive = false; uint32_t genome_read_len = 0, genome_overlap = 0, n_pseudo = 0; uint8_t genome_md5[16] = { 0 };
 };
 struct ArchiveInfo {                                                   // the `info` stream (compression.cpp:42-95, info.cpp:24-53)
 	uint32_t version_major = 0, version_minor = 0, version_patch = 0; uint64_t total_bytes = 0, total_bases = 0; uint32_t total_reads = 0; uint64_t time = 0;
@@ -50,6 +51,12 @@ inline Meta parse_meta(const std::vector<uint8_t>& b, bool is_fastq)         // 
 	m.header_mode = rd<uint8_t>(p, e); m.ref_mode = rd<uint8_t>(p, e);
 	if (m.ref_mode == 1) { m.sparse_range = rd<uint32_t>(p, e); m.sparse_exp = rd<double>(p, e); }
 	m.genome = rd<uint8_t>(p, e) != 0;
+	if (m.genome)
+	{	// decompression_common.cpp:231-260
+		m.genome_in_archive = rd<uint8_t>(p, e) != 0;
+		m.genome_read_len = rd<uint32_t>(p, e); m.genome_overlap = rd<uint32_t>(p, e); m.n_pseudo = rd<uint32_t>(p, e);
+		if (!m.genome_in_archive) for (int i = 0; i < 16; ++i) m.genome_md5[i] = rd<uint8_t>(p, e);
+	}
 	return m;
 }
 inline ArchiveInfo parse_info(const std::vector<uint8_t>& b)
@@ -68,6 +75,7 @@ class RecordStream {
 	ArchiveReader ar; Meta M; ArchiveInfo I; bool fastq = false, started = false, finished = false;
 	int s_dna = -1, s_qual = -1, s_hdr = -1;
 	std::vector<uint64_t> domain_first_part;                              // first `dna` part of every model domain after the first
+	genome_io::Sequences pseudo;                                          // reference-genome mode: the pseudo reads that precede the first read
 	Queue<ReadPart> q_bases_for_qual, q_reads, q_quals; Queue<HeaderPart> q_hdr;
 	std::string err_dna, err_qual, err_hdr;
 	std::thread t_dna, t_qual, t_hdr;
@@ -76,7 +84,7 @@ class RecordStream {
 	void start();
 	void join() { if (t_dna.joinable()) t_dna.join(); if (t_qual.joinable()) t_qual.join(); if (t_hdr.joinable()) t_hdr.join(); }
 public:
-	explicit RecordStream(const std::string& path);
+	explicit RecordStream(const std::string& path, const std::string& genome_path = "");
 	~RecordStream() { q_bases_for_qual.abort(); q_reads.abort(); q_quals.abort(); q_hdr.abort(); join(); ar.close(); }
 	RecordStream(const RecordStream&) = delete; RecordStream& operator=(const RecordStream&) = delete;
 	bool is_fastq() const { return fastq; }
@@ -85,7 +93,7 @@ public:
 	bool next(Record& r);                                                 // false at the end; throws on a corrupt archive
 };
 
-inline RecordStream::RecordStream(const std::string& path)
+inline RecordStream::RecordStream(const std::string& path, const std::string& genome_path)
 {
 	if (!ar.open(path)) throw std::runtime_error("cannot open archive: " + path);
 	s_dna = ar.id("dna"); s_qual = ar.id("qual"); s_hdr = ar.id("header");
@@ -96,7 +104,34 @@ inline RecordStream::RecordStream(const std::string& path)
 	if (!ar.part(s_meta, 0, mb, mm)) throw std::runtime_error("cannot read the `meta` stream");
 	M = parse_meta(mb, fastq);
 	if (s_info >= 0 && ar.part(s_info, 0, mb, mm) && mb.size() >= 40) I = parse_info(mb);
-	if (M.genome) throw std::runtime_error("archives compressed against a reference genome (-G) are not supported by this decompressor yet");
+	if (M.genome)
+	{	// the genome from the archive (-s at compression) or from the caller's file, whose checksum must be the one of the
+		// compression (decompression_common.cpp:262-305); its pseudo reads seed the decoder's reference reads
+		genome_io::Sequences G;
+		if (M.genome_in_archive)
+		{
+			const int s_gen = ar.id("ref-genome");
+			std::vector<uint8_t> gb; uint64_t n_seqs = 0;
+			if (s_gen < 0 || !ar.part(s_gen, 0, gb, n_seqs)) throw std::runtime_error("cannot read the `ref-genome` stream");
+			G.off.assign(n_seqs + 1, 0);
+			uint64_t got = 0;
+			G.codes.resize(std::max<size_t>(gb.size() * 5, 1 << 20));
+			cl_status st = cl_genome_decode(gb.data(), gb.size(), (uint32_t)n_seqs, G.codes.data(), G.codes.size(), G.off.data(), &got);
+			if (st == CL_E_CAPACITY) { G.codes.resize(got); st = cl_genome_decode(gb.data(), gb.size(), (uint32_t)n_seqs, G.codes.data(), G.codes.size(), G.off.data(), &got); }
+			if (st != CL_OK) throw std::runtime_error("corrupt `ref-genome` stream");
+			G.codes.resize(got);
+		}
+		else
+		{
+			if (genome_path.empty()) throw std::runtime_error("compressed file was created without -s switch, reference genome is required for decompression");
+			G = genome_io::read_fasta(genome_path);
+			uint8_t md[16];
+			if (cl_genome_md5(G.codes.data(), G.off.data(), (uint32_t)(G.off.size() - 1), md) != CL_OK || memcmp(md, M.genome_md5, 16) != 0)
+				throw std::runtime_error("different reference genome was used during compression. Decompression impossible.");
+		}
+		pseudo = genome_io::pseudo_reads(G, M.genome_read_len, M.genome_overlap);
+		if (pseudo.off.size() - 1 != M.n_pseudo) throw std::runtime_error("reference genome: the number of pseudo reads differs from the archive's");
+	}
 	if (s_dom >= 0)
 	{
 		std::vector<uint8_t> db; uint64_t dm = 0;
@@ -114,7 +149,10 @@ inline void RecordStream::start()
 	const size_t n_parts = ar.n_parts(s_dna);
 	t_dna = std::thread([this, n_parts]() {
 		cl_dna_decoder* d = nullptr;
-		if (cl_dna_decoder_create(M.max_candidates, M.level, 0, 0, M.ref_mode == 0, M.sparse_range, M.sparse_exp, &d) != CL_OK) { err_dna = "cl_dna_decoder_create"; }
+		if (cl_dna_decoder_create(M.max_candidates, M.level, M.n_pseudo, M.n_pseudo, M.ref_mode == 0, M.sparse_range, M.sparse_exp, &d) != CL_OK) { err_dna = "cl_dna_decoder_create"; }
+		for (size_t i = 0; d && i + 1 < pseudo.off.size(); ++i)                    // decompression_common.cpp:287-292
+			if (cl_dna_decoder_add_ref(d, pseudo.codes.data() + pseudo.off[i], (uint32_t)(pseudo.off[i + 1] - pseudo.off[i])) != CL_OK) { err_dna = "cl_dna_decoder_add_ref"; break; }
+		if (!err_dna.empty() && d) { cl_dna_decoder_free(d); d = nullptr; }
 		std::vector<uint8_t> in; uint64_t n_reads = 0;
 		for (size_t p = 0; d && p < n_parts; ++p)
 		{

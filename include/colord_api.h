@@ -2,10 +2,10 @@
  * src/API/colord_api.h:27-103 (namespace colord: DecompressionRecord, Info and its enums, DecompressionStream with GetInfo()
  * and NextRecord()), so that a program written against the reference's libcolord_api.a — e.g. its src/API_example/
  * api_example.cpp — compiles and runs unchanged against this one:
- *     g++ -std=c++17 prog.cpp -I include -L colord_amd -lcolord_hip_api -lcolord_hip -lpthread
+ *     g++ -std=c++17 prog.cpp -I include -L colord_amd -lcolord_hip_api -lcolord_hip -lz -lpthread
  * Archives of the reference and of colord_hip (incl. multi-GPU archives with a `hipdomains` stream) are read alike; the
  * decoders are the host functions of the C ABI (include/colord_hip.h, a17), no GPU is needed.  Errors are std::runtime_error,
- * as in the reference.  Not supported yet: archives that need an external reference genome (-G without -s). */
+ * as in the reference.  Archives written with -G but without -s take the genome's path in the second constructor. */
 #pragma once
 #include <cstdint>
 #include <memory>

@@ -16,12 +16,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ARC = os.path.join(ROOT, "tests", "golden", "archives")
 CLI = os.path.join(ROOT, "colord_amd", "colord_hip")
 EXP = json.load(open(os.path.join(ARC, "expected.json")))
+GENOME = os.path.join(ROOT, "tests", "data", "M.bovis-reference.fna.gz")
 
 
 @pytest.mark.parametrize("name", sorted(EXP))
 def test_decompress_reference_archive(name, tmp_path):
     out = str(tmp_path / "out.fastq")
-    r = subprocess.run([CLI, "decompress", os.path.join(ARC, name + ".colord"), out], capture_output=True, text=True)
+    extra = ["-G", GENOME] if name.endswith("_external") else []          # written with -G but without -s: the genome comes from its file (gz or plain)
+    r = subprocess.run([CLI, "decompress"] + extra + [os.path.join(ARC, name + ".colord"), out], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert hashlib.sha256(open(out, "rb").read()).hexdigest() == EXP[name]["decompressed_sha256"]
 
@@ -65,3 +67,17 @@ def test_corrupt_part_is_an_error_not_a_crash(tmp_path):
     AR.write_archive(bad, list(arc.values()))
     r = subprocess.run([CLI, "decompress", bad, str(tmp_path / "o.fastq")], capture_output=True, text=True, timeout=120)
     assert r.returncode in (0, 1)                            # garbage in: either a reported stream error or garbage bases, never a hang / signal
+
+
+def test_reference_genome_archives_need_the_right_genome(tmp_path):
+    """-G without -s (decompression_common.cpp:262-281): no genome -> refused; another genome -> refused by its checksum."""
+    arc = os.path.join(ARC, "c4_ont_genome_external.colord")
+    r = subprocess.run([CLI, "decompress", arc, str(tmp_path / "o.fastq")], capture_output=True, text=True)
+    assert r.returncode == 1 and "reference genome is required" in r.stderr
+    import gzip
+    other = tmp_path / "other.fna"
+    txt = gzip.open(GENOME, "rb").read()
+    i = txt.index(b"\n", txt.index(b"\n") + 1) + 1000
+    other.write_bytes(txt[:i] + (b"A" if txt[i:i + 1] != b"A" else b"C") + txt[i + 1:])
+    r = subprocess.run([CLI, "decompress", "-G", str(other), arc, str(tmp_path / "o.fastq")], capture_output=True, text=True)
+    assert r.returncode == 1 and "different reference genome" in r.stderr

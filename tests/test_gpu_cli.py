@@ -211,3 +211,31 @@ def test_cli_ultra_long_reads(tmp_path):
     assert dna < 0.22 * off[-1]                               # the long reads really are coded against each other (2 bits/base plain = 0.25)
     subprocess.check_call([CLI, "decompress", my_arc, my_out])
     assert sha(my_out) == sha(fq)
+
+
+@pytest.mark.skipif(not os.path.exists(CLI), reason="needs colord_amd/colord_hip")
+@pytest.mark.parametrize("stored", [True, False])
+def test_cli_reference_genome_mode_equals_the_reference(tmp_path, stored):
+    """Config 4 of BASELINE.json through the command line: `compress-ont -G M.bovis-reference.fna [-s] M.bovis.fastq`.  Against the
+    archive the UNMODIFIED reference wrote for the same command (tests/golden/archives/c4_ont_genome_*, make_archives.py): every
+    stream but `info` byte-identical — `meta` (pseudo-read geometry, checksum), `ref-genome` (-s), `dna`, `qual`, `header` — and this
+    build's decompressor returns the reference's output, from the archive alone (-s) or with the genome file (no -s)."""
+    import gzip, json
+    name = "c4_ont_genome_stored" if stored else "c4_ont_genome_external"
+    exp = json.load(open(os.path.join(ROOT, "tests", "golden", "archives", "expected.json")))[name]
+    fq, gen = str(tmp_path / "M.bovis.fastq"), str(tmp_path / "M.bovis-reference.fna")
+    open(fq, "wb").write(gzip.open(os.path.join(ROOT, "tests", "data", "M.bovis.fastq.gz"), "rb").read())
+    open(gen, "wb").write(gzip.open(os.path.join(ROOT, "tests", "data", "M.bovis-reference.fna.gz"), "rb").read())
+    arc, out = str(tmp_path / "a.colord"), str(tmp_path / "o.fastq")
+    subprocess.check_call([CLI, "compress-ont", "-G", gen] + (["-s"] if stored else []) + [fq, arc])
+    a, b = AR.read_archive(os.path.join(ROOT, "tests", "golden", "archives", name + ".colord")), AR.read_archive(arc)
+    assert set(a) == set(b)
+    for s in a:
+        if s != "info":
+            assert [(m, hashlib.sha256(p).hexdigest()) for m, p in a[s].parts] == [(m, hashlib.sha256(p).hexdigest()) for m, p in b[s].parts], s
+    subprocess.check_call([CLI, "decompress"] + ([] if stored else ["-G", gen]) + [arc, out])
+    assert sha(out) == exp["decompressed_sha256"]
+    if os.path.exists(REF):                                  # and the reference reads it (in the build container)
+        ref_out = str(tmp_path / "r.fastq")
+        subprocess.check_call([REF, "decompress"] + ([] if stored else ["-G", gen]) + [arc, ref_out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        assert sha(ref_out) == exp["decompressed_sha256"]

@@ -4,10 +4,10 @@
 #include <iostream>
 int main(int argc, char** argv)
 {
-	if (argc < 2) { std::cerr << "usage: api_dump archive.colord\n"; return 2; }
+	if (argc < 2) { std::cerr << "usage: api_dump archive.colord [reference_genome]\n"; return 2; }
 	try
 	{
-		colord::DecompressionStream stream(argv[1]);
+		colord::DecompressionStream stream(argv[1], argc > 2 ? argv[2] : "");
 		const colord::Info info = stream.GetInfo();
 		info.ToOstream(std::cerr);
 		std::cerr << "total bases: " << info.totalBases << "\n";
