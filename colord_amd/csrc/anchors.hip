@@ -339,6 +339,7 @@ __global__ __launch_bounds__(64) void k_lis_anchors(Arena A, Arena R, TaskCfg cf
                                                    int* __restrict__ tf, int* __restrict__ ts, int* __restrict__ pred,
                                                    uint32_t* __restrict__ anch, uint32_t* __restrict__ t_nanch, uint32_t* __restrict__ t_tot)
 {
+	__builtin_amdgcn_s_setprio(3);                                          // a launch of this kernel lasts as long as its slowest chain: its waves go first on their SIMDs
 	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= n_tasks) return;
 	const uint64_t a = pair_off[t], b = a + pair_cnt[t];

@@ -192,6 +192,7 @@ __global__ __launch_bounds__(64) void k_dna_walk(const FamTab* __restrict__ ftp,
                                                 uint32_t* __restrict__ counts, uint32_t* __restrict__ hdr_counts, const uint64_t* __restrict__ sym_off,
                                                 uint64_t* __restrict__ key, uint32_t* __restrict__ err)
 {
+	__builtin_amdgcn_s_setprio(3);                                          // a launch of this kernel lasts as long as its slowest chain: its waves go first on their SIMDs
 	__shared__ FamTab ft;
 	for (uint32_t i = threadIdx.x; i < sizeof(FamTab) / 4; i += blockDim.x) ((uint32_t*)&ft)[i] = ((const uint32_t*)ftp)[i];
 	__syncthreads();

@@ -348,6 +348,7 @@ __device__ inline bool wave_gap_finish(wv::WavePool& pool, GapRec& g, const Wave
 __global__ __launch_bounds__(64) void k_align_wave(const uint32_t* __restrict__ list, uint32_t n_list, GapRec* __restrict__ gaps, char* __restrict__ es_pool, ArenaV A, ArenaV R,
                                                   uint8_t* __restrict__ scratch, uint64_t per_wave, unsigned int* __restrict__ next, uint32_t* __restrict__ redo, unsigned int* __restrict__ n_redo, uint32_t dbg_stage, uint32_t* hbt, unsigned long long* prof)
 {
+	__builtin_amdgcn_s_setprio(3);                                          // a launch of this kernel lasts as long as its slowest chain: its waves go first on their SIMDs
 	wv::WavePool pool{ scratch + (uint64_t)blockIdx.x * per_wave, per_wave, 0, false, hbt ? hbt + blockIdx.x : nullptr };
 	pool.prof = prof; if (prof) pool.t_last = wall_clock64();
 	pool.beat(1);
@@ -593,6 +594,7 @@ __global__ void k_pend_list(TreeV T, uint32_t n_reads, const uint64_t* __restric
 __global__ __launch_bounds__(64) void k_estimator(TreeV T, const uint32_t* __restrict__ pack_bounds, uint32_t n_packs, const uint32_t* __restrict__ lens, const uint8_t* __restrict__ has_n,
                                                  const uint32_t* __restrict__ base_counts, const uint64_t* __restrict__ ev_off, const uint32_t* __restrict__ events)
 {
+	__builtin_amdgcn_s_setprio(3);                                          // a launch of this kernel lasts as long as its slowest chain: its waves go first on their SIMDs
 	__shared__ PendRec recs[64];
 	__shared__ uint32_t ev_id[64];
 	const uint32_t pk = blockIdx.x, lane = threadIdx.x;
@@ -688,7 +690,8 @@ __global__ void k_emit_slots(const uint32_t* __restrict__ lens, const uint32_t* 
 }
 __global__ __launch_bounds__(64) void k_emit_count(ArenaV A, const uint32_t* __restrict__ inv, const uint8_t* __restrict__ has_n, TreeV T, uint32_t n_reads, const uint32_t* __restrict__ data,
                                                   const uint64_t* __restrict__ slot_off, EmitCk* __restrict__ cks, uint32_t* __restrict__ sizes, uint32_t* __restrict__ ntuples)
-{	// EMIT_LPW reads per wave: the walk is divergent (every lane is somewhere else in its frame tree), and the machine has
+{
+	__builtin_amdgcn_s_setprio(3);                                          // a launch of this kernel lasts as long as its slowest chain: its waves go first on their SIMDs	// EMIT_LPW reads per wave: the walk is divergent (every lane is somewhere else in its frame tree), and the machine has
 	// far more wave slots than a 64-reads-per-wave launch would use
 	if (threadIdx.x >= EMIT_LPW) return;
 	const uint32_t r = blockIdx.x * EMIT_LPW + threadIdx.x;

@@ -80,6 +80,7 @@ static __global__ __launch_bounds__(64) void k_range_code(const triple_t* __rest
                                                          const uint32_t* __restrict__ part_len, uint32_t n_parts,
                                                          uint8_t* __restrict__ out, const uint64_t* __restrict__ part_out_off, uint64_t* __restrict__ part_size)
 {
+	__builtin_amdgcn_s_setprio(3);                                          // a launch of this kernel lasts as long as its slowest chain: its waves go first on their SIMDs
 	const uint32_t p = blockIdx.x * 64 + threadIdx.x;
 	const bool live = p < n_parts;
 	const uint64_t TOP = 0x00ffffffffffffULL, MASK = 0xff00000000000000ULL;
