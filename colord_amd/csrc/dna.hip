@@ -8,6 +8,7 @@
 // with a stable sort, each model is evolved by one wavefront over its own run, and the interval
 // arithmetic runs one lane per part (rc_dev.hpp).
 #include "common.hpp"
+#include <functional>
 #include "objects.hpp"
 #include "rc_dev.hpp"
 #include <algorithm>
@@ -884,6 +885,16 @@ __global__ void k_last_types(const uint8_t* __restrict__ flag, uint32_t n, uint3
 }
 } // namespace
 
+// The half of cl_dna_encode that needs no model state: the tuple walks of a batch of reads -> read flags, symbol offsets and the
+// (family, context, symbol) key of every coded symbol.  It depends on the tuple streams, the reference reads and two scalars
+// carried from the batch before (types of its last four reads, its read count) — not on the adaptive models — so it can be
+// done for the NEXT batch while the interval coding of the current one, a dependent chain per part, drains (cl_dna_walk_ahead).
+struct DnaWalked {
+	const uint8_t* d_es = nullptr; uint32_t n_reads = 0;                       // identity of the batch
+	uint32_t prev_types_in = 0, cur_read_id_in = 0, prev_types_out = 0;
+	DevBuf<uint8_t> rflag; DevBuf<uint32_t> hdr; DevBuf<uint64_t> sym_off, key;
+	std::vector<uint64_t> h_sym_off;
+};
 struct cl_dna_coder {
 	cl_ctx* ctx = nullptr;
 	FamTab ft;
@@ -891,6 +902,9 @@ struct cl_dna_coder {
 	DevBuf<uint32_t> state;
 	uint32_t cur_read_id = 0;        // CDNACoder::cur_read_id
 	uint32_t prev_types = 0;         // ctx_read_type (types of the last four reads)
+	uint32_t next_read_id = 0, next_prev_types = 0; bool next_valid = false;   // the same after the batch being coded (known once it is walked)
+	std::unique_ptr<DnaWalked> ahead;                                          // the next batch, walked ahead
+	std::function<cl_status()> before_tail;                                    // called by cl_dna_encode before it waits for its last interval coding
 };
 
 // CDNACoder::Init(true, max_no_alt_refs, level, ., start_read_id) (dna_coder.cpp:1242-1340)
@@ -952,31 +966,20 @@ struct PendingGroup {
 };
 } // namespace
 
-// CEntrComprReads::Compress for a batch of whole parts (entr_read.h:56-80)
-extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads* refs, const uint8_t* d_es, const uint64_t* d_es_off,
-                                   const uint32_t* d_es_ntuples, uint32_t n_reads, const uint32_t* h_part_bounds, uint32_t n_parts,
-                                   uint8_t* d_out, uint64_t cap, uint64_t* h_part_sizes, uint64_t* n_out)
+namespace {
+// D1 for ALL reads of a batch at once: the walks are one lane per read and as long as the longest read's chain of tuples takes,
+// whatever the number of reads — so one count pass and one write pass per batch, not per group.
+cl_status dna_walk(cl_ctx* ctx, cl_dna_coder* D, const cl_reads* refs, const uint8_t* d_es, const uint64_t* d_es_off, const uint32_t* d_es_ntuples, uint32_t n_reads,
+                   uint32_t prev_types, uint32_t cur_read_id, DnaWalked& W)
 {
-	if (!ctx || !D || !refs || !d_es || !d_es_off || !d_es_ntuples || !h_part_bounds || !h_part_sizes || !n_out) return cl_fail(ctx, CL_E_INVALID, "cl_dna_encode: null argument");
-	HIP_TRY(ctx, hipSetDevice(ctx->device));
-	for (uint32_t p = 0; p < n_parts; ++p) if (h_part_bounds[p] > h_part_bounds[p + 1]) return cl_fail(ctx, CL_E_INVALID, "cl_dna_encode: part bounds must ascend");
-	if (n_parts && (h_part_bounds[0] != 0 || h_part_bounds[n_parts] != n_reads)) return cl_fail(ctx, CL_E_INVALID, "cl_dna_encode: parts must cover reads [0, n_reads)");
-	*n_out = 0;
-	if (!n_parts) return CL_OK;
 	const FamTab& f = D->ft;
 	RefStore R{ refs->packed.p, refs->word_off.p, refs->lens.p, refs->n_reads };
-	uint64_t written = 0;
-	// D1 for ALL reads at once: the walks are one lane per read and as long as the longest read's chain of tuples takes,
-	// whatever the number of reads — so one count pass and one write pass per call, not per group.  Only what follows
-	// (sort, models, interval arithmetic) is grouped, by the 32-bit symbol / triple indices.
-	DevBuf<uint8_t> rflag; DEV_ALLOC(ctx, rflag, (uint64_t)n_reads + 1);
-	DevBuf<uint32_t> hdr; DEV_ALLOC(ctx, hdr, (uint64_t)n_reads + 1);
-	DevBuf<uint64_t> sym_off; DEV_ALLOC(ctx, sym_off, (uint64_t)n_reads + 1);
+	W.d_es = d_es; W.n_reads = n_reads; W.prev_types_in = prev_types; W.cur_read_id_in = cur_read_id;
+	DevBuf<uint8_t>& rflag = W.rflag; DevBuf<uint32_t>& hdr = W.hdr; DevBuf<uint64_t>& sym_off = W.sym_off; DevBuf<uint64_t>& key = W.key; std::vector<uint64_t>& h_sym_off = W.h_sym_off;
+	DEV_ALLOC(ctx, rflag, (uint64_t)n_reads + 1); DEV_ALLOC(ctx, hdr, (uint64_t)n_reads + 1); DEV_ALLOC(ctx, sym_off, (uint64_t)n_reads + 1);
 	DevBuf<uint32_t> err; DEV_ALLOC(ctx, err, 1);
 	HIP_TRY(ctx, hipMemsetAsync(err.p, 0, 4, ctx->stream));
-	DevBuf<uint64_t> key;
-	std::vector<uint64_t> h_sym_off((size_t)n_reads + 1, 0);
-	TripLayoutDev nolay{ nullptr, nullptr, nullptr, 0 };
+	h_sym_off.assign((size_t)n_reads + 1, 0);
 	if (n_reads)
 	{
 		uint64_t total_syms = 0, h_eb[2] = { 0, 0 };
@@ -994,7 +997,7 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 			DEV_ALLOC(ctx, cks, n_chunks);
 			LAUNCHB(ctx, (double)(h_eb[1] - h_eb[0]) + 8.0 * n_reads + (double)n_chunks * sizeof(WalkCk), (k_dna_walk<false>), grid_for(n_reads, WALK_LPW), 64, /* tuple bytes in, one count and the chunk states out */
 				(const FamTab*)D->d_ft.p, R, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, n_reads,
-				D->prev_types, D->cur_read_id, (const uint64_t*)chunk_off.p, cks.p, (uint32_t)n_chunks, counts.p, hdr.p, (const uint64_t*)nullptr, (uint64_t*)nullptr, err.p);
+				prev_types, cur_read_id, (const uint64_t*)chunk_off.p, cks.p, (uint32_t)n_chunks, counts.p, hdr.p, (const uint64_t*)nullptr, (uint64_t*)nullptr, err.p);
 			HIP_TRY(ctx, hipGetLastError());
 			CL_TRY(dev_exclusive_scan_u64(ctx, counts.p, sym_off.p, n_reads, &total_syms));
 		}
@@ -1006,11 +1009,61 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 		DEV_ALLOC(ctx, key, total_syms);
 		LAUNCHB(ctx, total_syms * 9.0, (k_dna_walk<true>), grid_for(n_chunks, WALK_LPW), 64, /* tuple bytes in (<= 1 per symbol), 8 bytes per symbol out */
 			(const FamTab*)D->d_ft.p, R, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, n_reads,
-			D->prev_types, D->cur_read_id, (const uint64_t*)chunk_off.p, cks.p, (uint32_t)n_chunks, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint64_t*)sym_off.p, key.p, err.p);
+			prev_types, cur_read_id, (const uint64_t*)chunk_off.p, cks.p, (uint32_t)n_chunks, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint64_t*)sym_off.p, key.p, err.p);
 		LAUNCH(ctx, k_dna_plain, grid_for(n_reads, 4), 256, (const FamTab*)D->d_ft.p, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, (const uint32_t*)hdr.p,
 			(const uint64_t*)sym_off.p, 0u, n_reads, key.p);
 		HIP_TRY(ctx, hipGetLastError());
 	}
+	{	// the types of the last four reads: what the batch after this one starts from
+		DevBuf<uint32_t> lt; DEV_ALLOC(ctx, lt, 1);
+		LAUNCH(ctx, k_last_types, 1, 1, (const uint8_t*)rflag.p, n_reads, prev_types, lt.p);
+		HIP_TRY(ctx, hipGetLastError());
+		HIP_TRY(ctx, hipMemcpyAsync(&W.prev_types_out, lt.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	}
+	return CL_OK;
+}
+} // namespace
+
+// Internal (stream.hip): the walk of the batch that FOLLOWS the one being coded, from inside cl_dna_encode's before_tail hook.
+cl_status cl_dna_walk_ahead(cl_ctx* ctx, cl_dna_coder* D, const cl_reads* refs, const uint8_t* d_es, const uint64_t* d_es_off, const uint32_t* d_es_ntuples, uint32_t n_reads)
+{
+	if (!ctx || !D || !refs || !d_es || !d_es_off || !d_es_ntuples || !n_reads) return CL_E_INVALID;
+	if (!D->next_valid) return cl_fail(ctx, CL_E_INVALID, "cl_dna_walk_ahead: only while a batch is being coded");
+	auto W = std::make_unique<DnaWalked>();
+	CL_TRY(dna_walk(ctx, D, refs, d_es, d_es_off, d_es_ntuples, n_reads, D->next_prev_types, D->next_read_id, *W));
+	D->ahead = std::move(W);
+	return CL_OK;
+}
+void cl_dna_set_before_tail(cl_dna_coder* D, std::function<cl_status()> fn) { if (D) D->before_tail = std::move(fn); }
+
+// CEntrComprReads::Compress for a batch of whole parts (entr_read.h:56-80)
+extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads* refs, const uint8_t* d_es, const uint64_t* d_es_off,
+                                   const uint32_t* d_es_ntuples, uint32_t n_reads, const uint32_t* h_part_bounds, uint32_t n_parts,
+                                   uint8_t* d_out, uint64_t cap, uint64_t* h_part_sizes, uint64_t* n_out)
+{
+	if (!ctx || !D || !refs || !d_es || !d_es_off || !d_es_ntuples || !h_part_bounds || !h_part_sizes || !n_out) return cl_fail(ctx, CL_E_INVALID, "cl_dna_encode: null argument");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	for (uint32_t p = 0; p < n_parts; ++p) if (h_part_bounds[p] > h_part_bounds[p + 1]) return cl_fail(ctx, CL_E_INVALID, "cl_dna_encode: part bounds must ascend");
+	if (n_parts && (h_part_bounds[0] != 0 || h_part_bounds[n_parts] != n_reads)) return cl_fail(ctx, CL_E_INVALID, "cl_dna_encode: parts must cover reads [0, n_reads)");
+	*n_out = 0;
+	if (!n_parts) return CL_OK;
+	const FamTab& f = D->ft;
+	uint64_t written = 0;
+	// D1 for ALL reads at once: the walks are one lane per read and as long as the longest read's chain of tuples takes,
+	// whatever the number of reads — so one count pass and one write pass per call, not per group.  Only what follows
+	// (sort, models, interval arithmetic) is grouped, by the 32-bit symbol / triple indices.
+	// the state-independent half: walked ahead by the caller of the batch before (cl_dna_walk_ahead), or here
+	std::unique_ptr<DnaWalked> Wp;
+	if (D->ahead && D->ahead->d_es == d_es && D->ahead->n_reads == n_reads && D->ahead->prev_types_in == D->prev_types && D->ahead->cur_read_id_in == D->cur_read_id) Wp = std::move(D->ahead);
+	D->ahead.reset();
+	if (!Wp) { Wp = std::make_unique<DnaWalked>(); CL_TRY(dna_walk(ctx, D, refs, d_es, d_es_off, d_es_ntuples, n_reads, D->prev_types, D->cur_read_id, *Wp)); }
+	DnaWalked& W = *Wp;
+	DevBuf<uint64_t>& sym_off = W.sym_off; DevBuf<uint64_t>& key = W.key; const std::vector<uint64_t>& h_sym_off = W.h_sym_off;
+	DevBuf<uint32_t> err; DEV_ALLOC(ctx, err, 1);
+	HIP_TRY(ctx, hipMemsetAsync(err.p, 0, 4, ctx->stream));
+	D->next_prev_types = W.prev_types_out; D->next_read_id = D->cur_read_id + n_reads; D->next_valid = true;
+	struct NextOff { cl_dna_coder* D; ~NextOff() { D->next_valid = false; } } next_off{ D };
 	std::unique_ptr<PendingGroup> pending;
 	auto finish_group = [&](PendingGroup& g) -> cl_status {
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->side));
@@ -1169,15 +1222,13 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 		pending = std::move(G);
 		p0 = p1;
 	}
+	// the last group's interval coding is one dependent chain per part on the side stream (~0.1 s for a 200-kb read): the caller's
+	// hook runs now, beside it (cl_compressor walks the next chunk's tuples here)
+	if (D->before_tail) { const cl_status hs = D->before_tail(); if (hs != CL_OK) return hs; }
 	if (pending) { CL_TRY(finish_group(*pending)); pending.reset(); }
-	{	// carry the coder state to the next call
-		DevBuf<uint32_t> lt; DEV_ALLOC(ctx, lt, 1);
-		LAUNCH(ctx, k_last_types, 1, 1, (const uint8_t*)rflag.p, n_reads, D->prev_types, lt.p);
-		HIP_TRY(ctx, hipGetLastError());
-		HIP_TRY(ctx, hipMemcpyAsync(&D->prev_types, lt.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-		D->cur_read_id += n_reads;
-	}
+	// carry the coder state to the next call
+	D->prev_types = W.prev_types_out;
+	D->cur_read_id += n_reads;
 	cl_timing_collect(ctx);
 	*n_out = written;
 	return CL_OK;

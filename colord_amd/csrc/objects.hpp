@@ -48,3 +48,10 @@ struct cl_index {
 uint32_t cl_part_shift(uint32_t k);
 cl_status cl_key_histogram(cl_ctx* ctx, const uint64_t* d_kmers, uint64_t n, uint32_t k, std::vector<uint64_t>& h_bins);
 cl_status cl_key_gather(cl_ctx* ctx, const uint64_t* d_kmers, uint64_t n, uint32_t k, uint32_t b0, uint32_t b1, uint64_t* d_out, uint64_t expect);
+
+// the DNA coder's state-independent half ahead of time (dna.hip): stream.hip walks the NEXT chunk's tuples from the hook that
+// cl_dna_encode calls before it waits for its last interval coding
+#include <functional>
+struct cl_dna_coder;
+cl_status cl_dna_walk_ahead(cl_ctx* ctx, cl_dna_coder* D, const cl_reads* refs, const uint8_t* d_es, const uint64_t* d_es_off, const uint32_t* d_es_ntuples, uint32_t n_reads);
+void cl_dna_set_before_tail(cl_dna_coder* D, std::function<cl_status()> fn);

@@ -602,6 +602,20 @@ extern "C" cl_status cl_compressor_encode(cl_compressor* c, const cl_reads* read
 		CL_TRY(stage_a(c, ctx, idx, reads, h_pack_bounds, n_packs, *job));
 	}
 	info->n_anchors = job->n_anchors; info->tuple_bytes = job->es_bytes;
+	// While this chunk's last interval coding drains (a dependent chain per part: ~0.1 s that nothing else on this stream can use),
+	// the tuple walk of the NEXT chunk runs, if an encode lane has its tuple streams ready: that half of the DNA coder needs no
+	// model state (dna.hip, DnaWalked).
+	cl_dna_set_before_tail(c->dna, [c, idx]() -> cl_status {
+		cl_compressor::Prepared* nx = nullptr;
+		{
+			std::lock_guard<std::mutex> l(c->lane_mu);
+			auto it = c->prepared.find(idx + 1);
+			if (it != c->prepared.end() && it->second->done && it->second->status == CL_OK && it->second->reads->n_reads) nx = it->second.get();
+		}
+		if (!nx) return CL_OK;
+		return cl_dna_walk_ahead(c->ctx, c->dna, c->refs, nx->es.p, nx->es_off.p, nx->es_nt.p, nx->reads->n_reads);
+	});
+	struct HookOff { cl_dna_coder* d; ~HookOff() { cl_dna_set_before_tail(d, nullptr); } } hook_off{ c->dna };
 	CL_TRY(cl_dna_encode(ctx, c->dna, c->refs, job->es.p, job->es_off.p, job->es_nt.p, n, h_part_bounds, n_parts, d_dna_out, dna_cap, h_dna_part_sizes, &info->dna_bytes));
 	if (overlap)
 	{
