@@ -74,7 +74,12 @@ __device__ inline uint64_t ref_mmer(const Arena& R, uint32_t id, bool rev, uint3
 // read with the m-mers of the reference and of its reverse complement).
 // A slot is 16 bytes — key and both chain heads in one sector, so an insertion touches two sectors (slot, next), not three.
 struct EncSlot { uint64_t key; uint32_t head[2]; };
+// slot of a hash in a table of tsz slots: tsz is a power of two below one region, else a MULTIPLE of the region size (2 n slots
+// rounded up: powers of two meant 2.5 n .. 5 n slots, 40 - 80 bytes per base written out by every table build), so the index
+// is the high half of hash x tsz rather than a mask
+__device__ inline uint32_t table_slot(uint64_t hash, uint32_t tsz) { return (uint32_t)(((uint64_t)(uint32_t)(hash >> 17) * tsz) >> 32); }
 struct EncTable { EncSlot* slots; const uint64_t* toff; uint32_t* next; const uint64_t* noff; };
+constexpr uint32_t REGION_SLOTS = 2048;                                  // = REGION of the table build below
 constexpr uint64_t KEY_EMPTY = ~0ULL;
 constexpr uint32_t NIL = 0xffffffffu;
 
@@ -88,7 +93,7 @@ __global__ void k_table_sizes(const uint32_t* __restrict__ lens, const uint8_t* 
 	bool active = ncand[r] > 0 && !has_n[r] && len >= m;
 	uint32_t n = active ? len - m + 1 : 0;
 	uint32_t t = 0;
-	if (n) { t = 16; while (t < 2 * n + n / 2) t <<= 1; }
+	if (n) { t = 16; while (t < 2 * n + n / 2 && t < REGION_SLOTS) t <<= 1; if (t >= REGION_SLOTS) t = (2 * n + REGION_SLOTS - 1) / REGION_SLOTS * REGION_SLOTS; }
 	tsize[r - r0] = t; nsize[r - r0] = n;
 }
 // Table build, one block of 16 waves per read.  Inserting straight into the table in HBM costs a random 128-byte line
@@ -96,7 +101,7 @@ __global__ void k_table_sizes(const uint32_t* __restrict__ lens, const uint8_t* 
 // (REGION slots = 32 KB) in LDS and written out once, coalesced: the read's positions are first binned by the region of
 // their slot (counting sort through a scratch list), then every region is filled with LDS atomics.  Probing wraps
 // inside the region, here and in table_heads.
-constexpr uint32_t REGION = 2048, INS_T = 256;
+constexpr uint32_t REGION = REGION_SLOTS, INS_T = 256;
 __global__ __launch_bounds__(INS_T) void k_table_insert(Arena A, uint32_t r0, uint32_t r1, uint32_t m, EncTable T, uint32_t* __restrict__ n_distinct,
                                                        uint2* __restrict__ bins /* per position: (position, slot), grouped by region */, uint32_t* __restrict__ err)
 {
@@ -120,7 +125,7 @@ __global__ __launch_bounds__(INS_T) void k_table_insert(Arena A, uint32_t r0, ui
 		for (uint32_t p = threadIdx.x; p < n; p += INS_T)
 		{
 			const uint64_t xf = mmer_at(A, wb, p, m), xr = revcomp_m(xf, m), x = xf < xr ? xf : xr;
-			const uint32_t h = (uint32_t)(hash_mm(x) >> 17) & (tsz - 1), rg = (h >> rshift) - rg0;
+			const uint32_t h = table_slot(hash_mm(x), tsz), rg = (h >> rshift) - rg0;
 			if (rg < nr) atomicAdd(&cnt[rg], 1u);
 		}
 		__syncthreads();
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(INS_T) void k_table_insert(Arena A, uint32_t r0, ui
 		for (uint32_t p = threadIdx.x; p < n; p += INS_T)
 		{
 			const uint64_t xf = mmer_at(A, wb, p, m), xr = revcomp_m(xf, m), x = xf < xr ? xf : xr;
-			const uint32_t h = (uint32_t)(hash_mm(x) >> 17) & (tsz - 1), rg = (h >> rshift) - rg0;
+			const uint32_t h = table_slot(hash_mm(x), tsz), rg = (h >> rshift) - rg0;
 			if (rg < nr) bin[start[rg] + atomicAdd(&cnt[rg], 1u)] = make_uint2(p, h);
 		}
 		__syncthreads();
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(INS_T) void k_table_insert(Arena A, uint32_t r0, ui
 // both chain heads of canonical m-mer x (NIL, NIL when absent)
 __device__ inline uint2 table_heads(const EncTable& T, uint64_t t0, uint32_t tsz, uint64_t x, uint64_t hash)
 {
-	uint32_t h = (uint32_t)(hash >> 17) & (tsz - 1);
+	uint32_t h = table_slot(hash, tsz);
 	const uint32_t rmask = (tsz < REGION ? tsz : REGION) - 1;           // probing wraps inside the region the table was built by
 	for (;;)
 	{
