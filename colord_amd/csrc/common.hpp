@@ -26,15 +26,15 @@ struct KernelTime { double ms = 0; uint32_t launches = 0; double bytes = 0; };  
 // for tens of GB) and synchronise the device, and a cache of whole hipMalloc blocks keyed by size wastes HBM exactly where
 // this pipeline needs it (stages ask for 34, 19, 16, 15, 10, 9 ... GB one after the other; a block kept for one size serves
 // the next badly).  So: blocks are carved best-fit, at their exact size, out of slabs obtained from the driver; free extents
-// coalesce; a request no extent holds adds a slab (its own size if it is large, else about what the pool holds already, up
-// to 16 GB).  Several contexts work on one GPU at a time (the quality stream's, the encode lanes of cl_compressor), each with
+// coalesce; a request no extent holds adds a slab (its own size if it is large, else a quarter of what the pool holds already,
+// 256 MB to 4 GB).  Several contexts work on one GPU at a time (the quality stream's, the encode lanes of cl_compressor), each with
 // its own pool: when the device runs short, slabs that are entirely free are given back — this pool's first, then the others'.
 struct DevPool {
 	struct Slab { char* base = nullptr; uint64_t size = 0, free_bytes = 0; std::map<uint64_t, uint64_t> ext; };   // ext: offset -> length of free extents
 	std::mutex mu;                                // a buffer made on one thread (an encode lane of cl_compressor) may be released on another
 	std::vector<Slab> slabs;
 	uint64_t reserved = 0, live_bytes = 0, peak_live = 0, peak_total = 0; uint32_t n_mallocs = 0;   // (statistics for COLORD_HIP_POOL_DEBUG)
-	static constexpr uint64_t ALIGN = 256, PAD = 256, SLAB_MIN = 256ull << 20, SLAB_MAX = 16ull << 30;
+	static constexpr uint64_t ALIGN = 256, PAD = 256, SLAB_MIN = 256ull << 20, SLAB_MAX = 4ull << 30;
 	static std::mutex& reg_mu() { static std::mutex* m = new std::mutex; return *m; }          // (never destroyed: contexts may outlive static destruction)
 	static std::vector<DevPool*>& registry() { static std::vector<DevPool*>* r = new std::vector<DevPool*>; return *r; }
 	DevPool() { std::lock_guard<std::mutex> l(reg_mu()); registry().push_back(this); }
@@ -98,7 +98,7 @@ struct DevPool {
 		if (!carve(r, out))
 		{
 			const uint64_t g = 2ull << 20;
-			uint64_t sz = std::max<uint64_t>(r, std::min<uint64_t>(std::max<uint64_t>(reserved, SLAB_MIN), SLAB_MAX));
+			uint64_t sz = std::max<uint64_t>(r, std::min<uint64_t>(std::max<uint64_t>(reserved / 4, SLAB_MIN), SLAB_MAX));
 			sz = (sz + g - 1) / g * g;
 			if (sz >= (4ull << 30))
 			{	// a large slab joins: smaller slabs that lie entirely free did not serve this request and rarely serve the next
