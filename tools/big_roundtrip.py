@@ -26,4 +26,6 @@ with tempfile.TemporaryDirectory() as tmp:
         print("stream %-8s parts %5d  %s" % (name, len(a[name].parts), "identical" if same else ("DIFFERENT" if name != "info" else "differs (time stamp)")), flush=True)
     t = time.time(); subprocess.check_call([REF, "decompress", my_arc, my_out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL); print("reference decompress of the GPU archive %.1f s" % (time.time() - t), flush=True)
     subprocess.check_call([REF, "decompress", ref_arc, ref_out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    own_out = os.path.join(tmp, "own.fastq")
+    t = time.time(); subprocess.check_call([CLI, "decompress", my_arc, own_out]); print("colord_hip decompress of the GPU archive %.1f s (host decoders)" % (time.time() - t), "; == the reference's output:", sha(own_out) == sha(ref_out), flush=True)
     print("decoded FASTQ == what the reference decodes from its own archive:", sha(my_out) == sha(ref_out), "; == input FASTQ (lossless modes):", sha(my_out) == sha(fq))
