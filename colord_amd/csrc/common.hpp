@@ -168,6 +168,7 @@ struct cl_ctx {
 	double next_bytes = 0;                       // algorithmic bytes of the next LAUNCH (set by LAUNCHB)
 	std::vector<hipEvent_t> ev_pool;
 	int n_cu = 256;
+	uint64_t* inv_tab = nullptr;                 // floor((2^64-1) / t) for t < 2^21: the interval coder's division table (rc_dev.hpp), made at first use
 	std::vector<cl_ctx*> lanes;                  // encode lanes of cl_compressor (contexts of their own; kept for the next compressor, freed with this context)
 };
 

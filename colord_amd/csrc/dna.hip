@@ -1050,6 +1050,8 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 	if (!n_parts) return CL_OK;
 	const FamTab& f = D->ft;
 	uint64_t written = 0;
+	const uint64_t* inv_tab = nullptr;
+	CL_TRY(cl_inv_table(ctx, &inv_tab));
 	// D1 for ALL reads at once: the walks are one lane per read and as long as the longest read's chain of tuples takes,
 	// whatever the number of reads — so one count pass and one write pass per call, not per group.  Only what follows
 	// (sort, models, interval arithmetic) is grouped, by the 32-bit symbol / triple indices.
@@ -1138,7 +1140,7 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 			CL_TRY(dev_exclusive_scan_u32(ctx, hf.p, n_syms, &n_seg));
 			DevBuf<uint32_t> seg; DEV_ALLOC(ctx, seg, n_seg + 1);
 			LAUNCH(ctx, k_seg_starts, grid_for(n_syms, 256), 256, (const uint32_t*)hf.p, n_syms, n_seg, seg.p);
-			LAUNCHB(ctx, n_syms * 28.0, k_dna_evolve, grid_for(n_seg, 4), 256, (const FamTab*)D->d_ft.p, (const uint64_t*)gkey, (const uint32_t*)sidx.p, (const uint32_t*)seg.p,
+			LAUNCHB(ctx, n_syms * 20.0, k_dna_evolve, grid_for(n_seg, 4), 256, (const FamTab*)D->d_ft.p, (const uint64_t*)gkey, (const uint32_t*)sidx.p, (const uint32_t*)seg.p,
 				(uint32_t)n_seg, D->state.p, trip.p);
 			HIP_TRY(ctx, hipGetLastError());
 			{	// long runs of the models with up to 32 symbols (k_dna_evolve skipped them)
@@ -1178,7 +1180,7 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 						LAUNCH(ctx, (k_long_groups<8>), nlr, 64, cr, nlr, group_pfx.p);
 						LAUNCH(ctx, (k_long_epochs<8>), nlr, 64, (const FamTab*)D->d_ft.p, cr, nlr, (const uint64_t*)gkey, (const uint32_t*)step_pfx.p, (const uint32_t*)group_pfx.p,
 							D->state.p, (EpochRec<8>*)epochs.p, d_ne.p, group_epoch.p, err.p);
-						LAUNCHB(ctx, steps * 64 * 28.0, (k_long_apply<8>), grid_for(steps * 64, 256), 256, cr, nlr, steps, (const uint64_t*)gkey, (const uint32_t*)sidx.p,
+						LAUNCHB(ctx, steps * 64 * 20.0, (k_long_apply<8>), grid_for(steps * 64, 256), 256, cr, nlr, steps, (const uint64_t*)gkey, (const uint32_t*)sidx.p,
 							(const uint32_t*)step_pfx.p, (const uint32_t*)group_pfx.p, (const EpochRec<8>*)epochs.p, (const uint32_t*)d_ne.p, (const uint32_t*)group_epoch.p, (const FamTab*)D->d_ft.p, trip.p);
 					}
 					else
@@ -1187,7 +1189,7 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 						LAUNCH(ctx, (k_long_groups<32>), nlr, 64, cr, nlr, group_pfx.p);
 						LAUNCH(ctx, (k_long_epochs<32>), nlr, 64, (const FamTab*)D->d_ft.p, cr, nlr, (const uint64_t*)gkey, (const uint32_t*)step_pfx.p, (const uint32_t*)group_pfx.p,
 							D->state.p, (EpochRec<32>*)epochs.p, d_ne.p, group_epoch.p, err.p);
-						LAUNCHB(ctx, steps * 64 * 28.0, (k_long_apply<32>), grid_for(steps * 64, 256), 256, cr, nlr, steps, (const uint64_t*)gkey, (const uint32_t*)sidx.p,
+						LAUNCHB(ctx, steps * 64 * 20.0, (k_long_apply<32>), grid_for(steps * 64, 256), 256, cr, nlr, steps, (const uint64_t*)gkey, (const uint32_t*)sidx.p,
 							(const uint32_t*)step_pfx.p, (const uint32_t*)group_pfx.p, (const EpochRec<32>*)epochs.p, (const uint32_t*)d_ne.p, (const uint32_t*)group_epoch.p, (const FamTab*)D->d_ft.p, trip.p);
 					}
 					HIP_TRY(ctx, hipGetLastError());
@@ -1214,7 +1216,7 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 			ctx->stream = ctx->side;                                              // (launch + timing events on the side stream)
 			G->sync.s = ctx->side;
 			hipError_t e1 = hipMemcpyAsync(G->d_out_off.p, G->out_off.data(), (np + 1) * 8, hipMemcpyHostToDevice, ctx->side);
-			LAUNCHB(ctx, n_syms * 16.0, k_range_code, ng, 64, (const triple_t*)trip.p, (const uint64_t*)d_gbase.p, (const uint32_t*)d_plen.p, np, G->tmp.p, (const uint64_t*)G->d_out_off.p, G->d_size.p);
+			LAUNCHB(ctx, n_syms * 8.0, k_range_code, ng, 64, (const triple_t*)trip.p, (const uint64_t*)d_gbase.p, (const uint32_t*)d_plen.p, np, G->tmp.p, (const uint64_t*)G->d_out_off.p, G->d_size.p, inv_tab);
 			hipError_t e2 = hipGetLastError();
 			ctx->stream = main_stream;
 			HIP_TRY(ctx, e1); HIP_TRY(ctx, e2);

@@ -487,6 +487,8 @@ extern "C" cl_status cl_qual_encode(cl_ctx* ctx, cl_qual_coder* Q, const cl_read
 		HIP_TRY(ctx, hipMemcpyAsync(d_pfirst.p, pfirst.data(), (np + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
 		TripLayoutDev lay{ d_pfirst.p, d_sym_start.p, d_gbase.p, np, d_rank.p };
 		DevBuf<triple_t> trip; DEV_ALLOC(ctx, trip, gbase[ng]);
+		const uint64_t* inv_tab = nullptr;
+		CL_TRY(cl_inv_table(ctx, &inv_tab));
 		{
 			DevBuf<uint32_t> key, sidx, bkey, bsidx;
 			DEV_ALLOC(ctx, key, per_base ? n_base : 0); DEV_ALLOC(ctx, sidx, per_base ? n_base : 0);
@@ -506,10 +508,10 @@ extern "C" cl_status cl_qual_encode(cl_ctx* ctx, cl_qual_coder* Q, const cl_read
 				const uint32_t g = grid_for(c.n_ctx, 4);
 				switch (c.n_sym)
 				{
-				case 2: LAUNCHB(ctx, n_base * 24.0, (k_evolve_small<2>), g, 256, (const uint32_t*)key.p, (const uint32_t*)sidx.p, (const uint32_t*)ss.p, (const uint32_t*)se.p, c.n_ctx, c.sym_bits, c.max_total, c.adder, Q->state.p, trip.p); break;
-				case 4: LAUNCHB(ctx, n_base * 24.0, (k_evolve_small<4>), g, 256, (const uint32_t*)key.p, (const uint32_t*)sidx.p, (const uint32_t*)ss.p, (const uint32_t*)se.p, c.n_ctx, c.sym_bits, c.max_total, c.adder, Q->state.p, trip.p); break;
-				case 5: LAUNCHB(ctx, n_base * 24.0, (k_evolve_small<5>), g, 256, (const uint32_t*)key.p, (const uint32_t*)sidx.p, (const uint32_t*)ss.p, (const uint32_t*)se.p, c.n_ctx, c.sym_bits, c.max_total, c.adder, Q->state.p, trip.p); break;
-				default: LAUNCHB(ctx, n_base * 24.0, k_evolve_large, g, 256, (const uint32_t*)key.p, (const uint32_t*)sidx.p, (const uint32_t*)ss.p, (const uint32_t*)se.p, c.n_ctx, c.n_sym, c.sym_bits, c.max_total, c.adder, Q->state.p, trip.p); break;
+				case 2: LAUNCHB(ctx, n_base * 16.0, (k_evolve_small<2>), g, 256, (const uint32_t*)key.p, (const uint32_t*)sidx.p, (const uint32_t*)ss.p, (const uint32_t*)se.p, c.n_ctx, c.sym_bits, c.max_total, c.adder, Q->state.p, trip.p); break;
+				case 4: LAUNCHB(ctx, n_base * 16.0, (k_evolve_small<4>), g, 256, (const uint32_t*)key.p, (const uint32_t*)sidx.p, (const uint32_t*)ss.p, (const uint32_t*)se.p, c.n_ctx, c.sym_bits, c.max_total, c.adder, Q->state.p, trip.p); break;
+				case 5: LAUNCHB(ctx, n_base * 16.0, (k_evolve_small<5>), g, 256, (const uint32_t*)key.p, (const uint32_t*)sidx.p, (const uint32_t*)ss.p, (const uint32_t*)se.p, c.n_ctx, c.sym_bits, c.max_total, c.adder, Q->state.p, trip.p); break;
+				default: LAUNCHB(ctx, n_base * 16.0, k_evolve_large, g, 256, (const uint32_t*)key.p, (const uint32_t*)sidx.p, (const uint32_t*)ss.p, (const uint32_t*)se.p, c.n_ctx, c.n_sym, c.sym_bits, c.max_total, c.adder, Q->state.p, trip.p); break;
 				}
 				HIP_TRY(ctx, hipGetLastError());
 				HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -539,7 +541,7 @@ extern "C" cl_status cl_qual_encode(cl_ctx* ctx, cl_qual_coder* Q, const cl_read
 		DevBuf<uint64_t> d_out_off, d_size, d_dst_off;
 		DEV_ALLOC(ctx, d_out_off, np + 1); DEV_ALLOC(ctx, d_size, np); DEV_ALLOC(ctx, d_dst_off, np);
 		HIP_TRY(ctx, hipMemcpyAsync(d_out_off.p, out_off.data(), (np + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-		LAUNCHB(ctx, n_syms * 16.0, k_range_code, ng, 64, (const triple_t*)trip.p, (const uint64_t*)d_gbase.p, (const uint32_t*)d_plen.p, np, tmp.p, (const uint64_t*)d_out_off.p, d_size.p);
+		LAUNCHB(ctx, n_syms * 8.0, k_range_code, ng, 64, (const triple_t*)trip.p, (const uint64_t*)d_gbase.p, (const uint32_t*)d_plen.p, np, tmp.p, (const uint64_t*)d_out_off.p, d_size.p, inv_tab);
 		HIP_TRY(ctx, hipGetLastError());
 		std::vector<uint64_t> size_r(np);                                       // by place
 		HIP_TRY(ctx, hipMemcpyAsync(size_r.data(), d_size.p, np * 8, hipMemcpyDeviceToHost, ctx->stream));

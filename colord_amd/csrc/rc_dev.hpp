@@ -8,14 +8,34 @@
 #pragma once
 #include "common.hpp"
 
-// A coded symbol as the interval coder needs it: x = cum << 42 | freq << 21 | tot, y = floor((2^64-1) / tot).
-// The reciprocal is computed where parallelism is abundant (model evolution) so that the dependent chain
-// of the coder contains no division.
-typedef ulonglong2 triple_t;
+// A coded symbol as the interval coder needs it: cum << 42 | freq << 21 | tot in ONE 64-bit word (totals stay below 2^21).
+// The coder divides by tot through a multiplication with floor((2^64-1) / tot); that reciprocal used to travel with every
+// symbol (16-byte triples: a 64-bit division per symbol in the model kernels, twice the memory and twice the coder's
+// fetches).  It now comes from a table of the 2^21 possible totals (16 MB per context, filled once; the totals in use are a few
+// thousand neighbouring values, L2-resident), looked up one step ahead of the dependent chain.
+typedef uint64_t triple_t;
 __device__ inline triple_t pack_triple(uint32_t cum, uint32_t freq, uint32_t tot)
 {
-	triple_t t; t.x = ((uint64_t)cum << 42) | ((uint64_t)freq << 21) | tot; t.y = ~0ULL / (uint64_t)tot;
-	return t;
+	return ((uint64_t)cum << 42) | ((uint64_t)freq << 21) | tot;
+}
+constexpr uint32_t INV_TABLE_SIZE = 1u << 21;
+static __global__ void k_fill_inv_table(uint64_t* __restrict__ tab)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < INV_TABLE_SIZE) tab[i] = i ? ~0ULL / (uint64_t)i : ~0ULL;
+}
+// the context's reciprocal table (made at first use)
+static inline cl_status cl_inv_table(cl_ctx* ctx, const uint64_t** out)
+{
+	if (!ctx->inv_tab)
+	{
+		HIP_TRY(ctx, hipMalloc((void**)&ctx->inv_tab, (uint64_t)INV_TABLE_SIZE * 8));
+		hipLaunchKernelGGL(k_fill_inv_table, dim3(INV_TABLE_SIZE / 256), dim3(256), 0, ctx->stream, ctx->inv_tab);
+		HIP_TRY(ctx, hipGetLastError());
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	}
+	*out = ctx->inv_tab;
+	return CL_OK;
 }
 
 struct TripLayoutDev {
@@ -78,7 +98,8 @@ struct ByteSink {
 // one lane per part, one wave per group of 64 parts (sub_rc.h:72-100,203-210)
 static __global__ __launch_bounds__(64) void k_range_code(const triple_t* __restrict__ trip, const uint64_t* __restrict__ group_base,
                                                          const uint32_t* __restrict__ part_len, uint32_t n_parts,
-                                                         uint8_t* __restrict__ out, const uint64_t* __restrict__ part_out_off, uint64_t* __restrict__ part_size)
+                                                         uint8_t* __restrict__ out, const uint64_t* __restrict__ part_out_off, uint64_t* __restrict__ part_size,
+                                                         const uint64_t* __restrict__ inv_tab)
 {
 	__builtin_amdgcn_s_setprio(3);                                          // a launch of this kernel lasts as long as its slowest chain: its waves go first on their SIMDs
 	const uint32_t p = blockIdx.x * 64 + threadIdx.x;
@@ -93,22 +114,28 @@ static __global__ __launch_bounds__(64) void k_range_code(const triple_t* __rest
 	if (lmax == 0) { if (live) { sink.put_top(0, 8); sink.flush(); part_size[p] = sink.n; } return; }
 	const triple_t* src = trip + group_base[blockIdx.x] + threadIdx.x;
 	constexpr uint32_t U = 8;
-	triple_t cur[U], nxt[U];
+	// three stages ahead of the chain: symbols two rounds ahead (far[]), their reciprocals one round ahead (inv1[] from nxt[]),
+	// the round being coded (cur[], inv0[])
+	triple_t cur[U], nxt[U], far[U]; uint64_t inv0[U], inv1[U];
 	// a lane whose part is shorter than the group's longest keeps stepping with the neutral symbol
 	// (cum 0, freq 1, total 1): range / 1 * 1 and low + 0 leave the coder untouched.
 	const uint64_t NEUTRAL_X = (1ULL << 21) | 1ULL, NEUTRAL_Y = ~0ULL;
 	const uint32_t last = lmax - 1;
 #pragma unroll
-	for (uint32_t u = 0; u < U; ++u) cur[u] = src[(uint64_t)(u < last ? u : last) * 64];
+	for (uint32_t u = 0; u < U; ++u) { cur[u] = src[(uint64_t)(u < last ? u : last) * 64]; nxt[u] = src[(uint64_t)(U + u < last ? U + u : last) * 64]; }
+#pragma unroll
+	for (uint32_t u = 0; u < U; ++u) inv0[u] = inv_tab[cur[u] & 0x1fffff];
 	for (uint32_t pos = 0; pos < lmax; pos += U)
 	{
 #pragma unroll
-		for (uint32_t u = 0; u < U; ++u) { uint32_t q = pos + U + u; nxt[u] = src[(uint64_t)(q < last ? q : last) * 64]; }   // prefetch (index clamped, never a pointer select)
+		for (uint32_t u = 0; u < U; ++u) { uint32_t q = pos + 2 * U + u; far[u] = src[(uint64_t)(q < last ? q : last) * 64]; }   // prefetch (index clamped, never a pointer select)
+#pragma unroll
+		for (uint32_t u = 0; u < U; ++u) inv1[u] = inv_tab[nxt[u] & 0x1fffff];
 #pragma unroll
 		for (uint32_t u = 0; u < U; ++u)
 		{
 			const bool act = pos + u < len;
-			const uint64_t tx = act ? cur[u].x : NEUTRAL_X, inv = act ? cur[u].y : NEUTRAL_Y;
+			const uint64_t tx = act ? cur[u] : NEUTRAL_X, inv = act ? inv0[u] : NEUTRAL_Y;
 			const uint32_t tot = (uint32_t)(tx & 0x1fffff), freq = (uint32_t)((tx >> 21) & 0x1fffff), cum = (uint32_t)(tx >> 42);
 			uint64_t q = __umul64hi(range, inv);
 			uint64_t r = range - q * tot;
@@ -128,7 +155,7 @@ static __global__ __launch_bounds__(64) void k_range_code(const triple_t* __rest
 			sink.put_top(low0, nb);
 		}
 #pragma unroll
-		for (uint32_t u = 0; u < U; ++u) cur[u] = nxt[u];
+		for (uint32_t u = 0; u < U; ++u) { cur[u] = nxt[u]; nxt[u] = far[u]; inv0[u] = inv1[u]; }
 	}
 	if (!live) return;
 	sink.put_top(low, 8);                                                    // End(): 8 bytes of low (sub_rc.h:203-210)
