@@ -114,28 +114,29 @@ static __global__ __launch_bounds__(64) void k_range_code(const triple_t* __rest
 	if (lmax == 0) { if (live) { sink.put_top(0, 8); sink.flush(); part_size[p] = sink.n; } return; }
 	const triple_t* src = trip + group_base[blockIdx.x] + threadIdx.x;
 	constexpr uint32_t U = 8;
-	// three stages ahead of the chain: symbols two rounds ahead (far[]), their reciprocals one round ahead (inv1[] from nxt[]),
-	// the round being coded (cur[], inv0[])
-	triple_t cur[U], nxt[U], far[U]; uint64_t inv0[U], inv1[U];
+	// three stages ahead of the chain: symbols two rounds ahead, their reciprocals one round ahead (looked up from the symbols
+	// fetched the round before), the round being coded.  The three register sets trade roles from round to round (no copies).
+	triple_t A[U], B[U], C[U]; uint64_t iA[U], iB[U], iC[U];
 	// a lane whose part is shorter than the group's longest keeps stepping with the neutral symbol
 	// (cum 0, freq 1, total 1): range / 1 * 1 and low + 0 leave the coder untouched.
 	const uint64_t NEUTRAL_X = (1ULL << 21) | 1ULL, NEUTRAL_Y = ~0ULL;
 	const uint32_t last = lmax - 1;
 #pragma unroll
-	for (uint32_t u = 0; u < U; ++u) { cur[u] = src[(uint64_t)(u < last ? u : last) * 64]; nxt[u] = src[(uint64_t)(U + u < last ? U + u : last) * 64]; }
+	for (uint32_t u = 0; u < U; ++u) { A[u] = src[(uint64_t)(u < last ? u : last) * 64]; B[u] = src[(uint64_t)(U + u < last ? U + u : last) * 64]; }
 #pragma unroll
-	for (uint32_t u = 0; u < U; ++u) inv0[u] = inv_tab[cur[u] & 0x1fffff];
-	for (uint32_t pos = 0; pos < lmax; pos += U)
+	for (uint32_t u = 0; u < U; ++u) iA[u] = inv_tab[A[u] & 0x1fffff];
+	// one round: fetch `far` (two rounds ahead), look up the reciprocals of `nxt`, code `cur` with `icur`
+	auto round = [&](uint32_t pos, const triple_t (&cur)[U], const uint64_t (&icur)[U], const triple_t (&nxt)[U], uint64_t (&inxt)[U], triple_t (&far)[U])
 	{
 #pragma unroll
 		for (uint32_t u = 0; u < U; ++u) { uint32_t q = pos + 2 * U + u; far[u] = src[(uint64_t)(q < last ? q : last) * 64]; }   // prefetch (index clamped, never a pointer select)
 #pragma unroll
-		for (uint32_t u = 0; u < U; ++u) inv1[u] = inv_tab[nxt[u] & 0x1fffff];
+		for (uint32_t u = 0; u < U; ++u) inxt[u] = inv_tab[nxt[u] & 0x1fffff];
 #pragma unroll
 		for (uint32_t u = 0; u < U; ++u)
 		{
 			const bool act = pos + u < len;
-			const uint64_t tx = act ? cur[u] : NEUTRAL_X, inv = act ? inv0[u] : NEUTRAL_Y;
+			const uint64_t tx = act ? cur[u] : NEUTRAL_X, inv = act ? icur[u] : NEUTRAL_Y;
 			const uint32_t tot = (uint32_t)(tx & 0x1fffff), freq = (uint32_t)((tx >> 21) & 0x1fffff), cum = (uint32_t)(tx >> 42);
 			uint64_t q = __umul64hi(range, inv);
 			uint64_t r = range - q * tot;
@@ -154,8 +155,14 @@ static __global__ __launch_bounds__(64) void k_range_code(const triple_t* __rest
 			}
 			sink.put_top(low0, nb);
 		}
-#pragma unroll
-		for (uint32_t u = 0; u < U; ++u) { cur[u] = nxt[u]; nxt[u] = far[u]; inv0[u] = inv1[u]; }
+	};
+	for (uint32_t pos = 0; pos < lmax; pos += 3 * U)
+	{
+		round(pos, A, iA, B, iB, C);
+		if (pos + U >= lmax) break;
+		round(pos + U, B, iB, C, iC, A);
+		if (pos + 2 * U >= lmax) break;
+		round(pos + 2 * U, C, iC, A, iA, B);
 	}
 	if (!live) return;
 	sink.put_top(low, 8);                                                    // End(): 8 bytes of low (sub_rc.h:203-210)
