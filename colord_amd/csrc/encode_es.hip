@@ -183,7 +183,7 @@ __device__ inline bool align_wave_gap(wv::WavePool& pool, GapRec& g, const Arena
 	pool.lap(1);
 	if (dbg_stage == 1) return true;
 	wv::Ops ops{ opsbuf, 0 };
-	const uint8_t* Q; const uint8_t* T; uint32_t n, m; bool rows_ref; uint32_t ref_end = 0;
+	const uint8_t* Q; const uint8_t* T; uint32_t n, m; uint32_t ref_end = 0;
 	// when edlib would keep the whole history anyway (it decides on the truncated target, which is never longer), one
 	// sweep delivers both the score / end position and the history; else score sweep first, then divide and conquer
 	if (g.kind == GK_FLANK_TINY && g.use == 1 && g.ne >= 1)
@@ -191,7 +191,7 @@ __device__ inline bool align_wave_gap(wv::WavePool& pool, GapRec& g, const Arena
 		// slowest gap of its launch).  find_edit_dist (edit_script.h:156-239) on one row: c[1][j] = j - 1 once the symbol has
 		// occurred among the first j read symbols, else j; its traceback (up, else left, else diagonal) walks left to the FIRST
 		// occurrence and matches there — or, without any occurrence, substitutes the first read symbol.
-		Q = r2; T = e2; n = 1; m = g.ne; rows_ref = true; ref_end = 0;
+		Q = r2; T = e2; n = 1; m = g.ne; ref_end = 0;
 		const uint32_t lane = threadIdx.x & 63;
 		const uint32_t qs = Q[0];
 		uint32_t first = m;
@@ -212,7 +212,6 @@ __device__ inline bool align_wave_gap(wv::WavePool& pool, GapRec& g, const Arena
 	{
 		if (g.kind == GK_INNER) { Q = rbuf; n = g.nr; T = ebuf; m = g.ne; }
 		else { Q = r2; n = g.use; T = e2; m = g.ne; ref_end = g.use - 1; }
-		rows_ref = true;
 		if (n && m && wv::wave_direct_fits(n, m))
 		{
 			wv::wave_align_direct(pool, Q, n, T, m, false, ops);
@@ -229,7 +228,7 @@ __device__ inline bool align_wave_gap(wv::WavePool& pool, GapRec& g, const Arena
 	}
 	else
 	{
-		Q = e2; n = g.ne; T = r2; rows_ref = false;
+		Q = e2; n = g.ne; T = r2;
 		if (n && g.use && wv::wave_direct_fits(n, g.use))
 		{
 			const wv::Sweep sw = wv::wave_align_direct(pool, Q, n, T, g.use, true, ops);
