@@ -239,3 +239,29 @@ def test_cli_reference_genome_mode_equals_the_reference(tmp_path, stored):
         ref_out = str(tmp_path / "r.fastq")
         subprocess.check_call([REF, "decompress"] + ([] if stored else ["-G", gen]) + [arc, ref_out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         assert sha(ref_out) == exp["decompressed_sha256"]
+
+
+@pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(CLI)), reason="needs oracle/_ref/colord and colord_amd/colord_hip")
+def test_cli_250_mbases_of_the_bench_recipe_equal_the_reference(tmp_path):
+    """The recipe of config 5 (BASELINE.json: synthetic ONT, N50 ~ 20 kb, reads up to 200 kb, 4-avg qualities) at a size where
+    every mechanism of the 50-Gbase run is in play — several chunks, both encode lanes with look-ahead, the walk of the next chunk
+    in the coding tail, anchor batches, all four recursion levels, the four-per-wave and the wave-per-gap aligners, long context
+    runs — against the unmodified reference on the same FASTQ: `meta`, `dna`, `qual`, `header` byte-identical, and this build's
+    decompressor returns what the reference returns."""
+    from colord_amd import ontsim
+    table = ontsim.ReadTable(seed=29, genome_len=15_000_000, target_bases=250_000_000)
+    fq = str(tmp_path / "in.fastq")
+    n_bases = ontsim.write_fastq(table, fq)
+    assert n_bases >= 240_000_000 and int(table.len_src.max()) >= 150_000          # (errors shorten the source lengths a little)
+    ref_arc, my_arc, ref_out, my_out = (str(tmp_path / x) for x in ("ref.colord", "gpu.colord", "ref.fastq", "gpu.fastq"))
+    subprocess.check_call([REF, "compress-ont", "-t", str(os.cpu_count() or 8), fq, ref_arc], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.check_call([CLI, "compress-ont", "--chunk-bases", "60000000", fq, my_arc])              # five chunks
+    a, b = AR.read_archive(ref_arc), AR.read_archive(my_arc)
+    assert set(a) == set(b)
+    for name in a:
+        if name != "info":
+            assert [(m, hashlib.sha256(p).hexdigest()) for m, p in a[name].parts] == [(m, hashlib.sha256(p).hexdigest()) for m, p in b[name].parts], name
+    assert len(a["dna"].parts) > 50
+    subprocess.check_call([REF, "decompress", ref_arc, ref_out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.check_call([CLI, "decompress", my_arc, my_out])
+    assert sha(my_out) == sha(ref_out)
