@@ -66,6 +66,7 @@ def parse():
                          "is cut to a prefix of the file that can, and `config.workload` says so")
     ap.add_argument("--no-qual", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ref-cut", action="store_true", help="skip the extra pass with the reference's 4-Mi-symbol coder parts (the byte-identical mode)")
     return ap.parse_args()
 
 
@@ -184,8 +185,9 @@ def _device_lengths(table, device, r0, r1):
     return out.cpu().numpy().view(np.uint32)
 
 
-def hot_path_step(ctx, qctx, shard: Shard, prm: dict, with_qual: bool, exchange, dna_out, qual_out, expected_bases: int):
-    """One pass of the whole compress data path over the shard (all chunks).  Returns sizes for reporting."""
+def hot_path_step(ctx, qctx, shard: Shard, prm: dict, with_qual: bool, exchange, dna_out, qual_out, expected_bases: int, ref_cut: bool = False):
+    """One pass of the whole compress data path over the shard (all chunks).  Returns sizes for reporting.
+    ref_cut: the coder parts are the reference's reader packs (4 Mi symbols) instead of the bench's --pack-symbols."""
     from colord_amd import parallel as par
     qa = (2, 0, 1, (7, 14, 26), ()) if with_qual else None       # ONT default: 4-avg at level 1 (arg_parse.cpp:410-450)
     cmp_ = ctx.compressor(prm, qa, qctx, exchange, expected_bases=expected_bases)
@@ -202,7 +204,7 @@ def hot_path_step(ctx, qctx, shard: Shard, prm: dict, with_qual: bool, exchange,
             for ch in shard.chunks:                          # every chunk is resident: announce them all, the lanes keep lanes + 1 ahead
                 cmp_.prepare(ch[0], ch[2])
         for arena, parts, est, quals, off in shard.chunks:
-            _, _, _, _, inf = cmp_.encode(arena, parts, est, quals, off, dna_out[do:], qual_out[qo:] if with_qual else None)
+            _, _, _, _, inf = cmp_.encode(arena, est if ref_cut else parts, est, quals, off, dna_out[do:], qual_out[qo:] if with_qual else None)
             do += inf["dna_bytes"]; qo += inf["qual_bytes"]
             for k_ in tot:
                 tot[k_] += inf[k_]
@@ -400,6 +402,21 @@ def main():
         roof["kernel_achieved_GBps"] = {n: round(times.bytes[n] / (times.ms[n] * 1e-3) / 1e9, 1) for n in order if times.bytes.get(n, 0) > 0 and times.ms[n] > 0}
         # compulsory floor of the whole path (3.2 B/base) against the step time
         roof["whole_path_floor_frac"] = 3.2 * total_bases * args.steps / dt / 1e9 / (HBM_PEAK_GBS * world)
+        # the same input once more in the byte-identical mode: coder parts = the reference's reader packs (4 Mi symbols; each part is
+        # one dependent chain of the interval coder, 64 times longer than with the bench's default cut) — when the deadline allows
+        ref_cut = None
+        if world == 1 and not args.no_ref_cut and args.pack_symbols != (1 << 22):
+            left = args.deadline_s - (time.time() - T_PROCESS_START) - reserve_s
+            if left > 4.0 * (dt / args.steps):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                inf2 = hot_path_step(ctx, qctx, shard, prm, not args.no_qual, None, dna_out, qual_out, shard.n_bases, ref_cut=True)
+                torch.cuda.synchronize()
+                dt2 = time.perf_counter() - t1
+                ref_cut = {"part_symbols": 1 << 22, "ms_per_step": dt2 * 1e3, "value": total_bases / dt2 / 1e9, "unit": "Gbases/s", "steps": 1,
+                           "dna_bytes": inf2["dna_bytes"], "qual_bytes": inf2["qual_bytes"], "parts": sum(len(c[2]) - 1 for c in shard.chunks),
+                           "stream_bytes_vs_default_cut": (inf2["dna_bytes"] + inf2["qual_bytes"]) / max(1, total_dna + total_qual),
+                           "note": "same input, one pass, coder parts = the reference's reader packs: the streams are the reference's bytes (size_check.streams_vs_ref_ref_cut)"}
         cb, size = (None, None)
         if not args.no_cpu_baseline and world == 1:
             shard.free()                                    # the sample runs (and the command-line compressor) need the memory:
@@ -430,7 +447,7 @@ def main():
                        "dna_bytes": total_dna, "qual_bytes": total_qual,
                        "parallelism": f"reads sharded x{world} in file order, k-mer set + reference reads + index replicated (RCCL), one model domain per GPU" if world > 1 else "single GPU",
                        "input_generation_s": round(t_gen, 1), "rank0_sizes": info},
-            "roofline": roof, "cpu_baseline": cb, "size_check": size,
+            "roofline": roof, "cpu_baseline": cb, "size_check": size, "ref_cut": ref_cut,
         }
         print(json.dumps(line))
     else:
