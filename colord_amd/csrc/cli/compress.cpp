@@ -264,6 +264,7 @@ int run_compress(int argc, char** argv)
 	for (size_t i = 0; i < qd.fwd.size(); ++i) if (qd.fwd[i] > 95 || (i && qd.fwd[i] < qd.fwd[i - 1])) die("quality thresholds must be ascending values in [0, 95]");
 
 	const auto t0 = std::chrono::steady_clock::now();
+	auto lap = [&](const char* what) { if (O.verbose) fprintf(stderr, "[%7.2f s] %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), what); };
 	hipck(hipSetDevice(O.gpu), "hipSetDevice");
 	Reader R; R.open(O.in);
 	// k-mer / anchor length from the estimated number of bases (adjustKmerAndAnchorLen, compression.cpp:42-95)
@@ -332,6 +333,7 @@ int run_compress(int argc, char** argv)
 		chunks.push_back(std::move(dc));
 	}
 	host.release();
+	lap("input parsed, uploaded and scanned (pass 1)");
 	const uint32_t n = (uint32_t)R.n_reads; const uint64_t total = R.n_bases;
 	if (!n) die("no reads in " + O.in);
 	// the header stream on a host thread, next to the GPU path (CEntrComprHeaders, entr_header.cpp:23-45)
@@ -355,6 +357,7 @@ int run_compress(int argc, char** argv)
 	});
 	cl_kmer_stats ks{};
 	ck(ctx, cl_compressor_count_finish(cmp, &ks), "k-mer counting");
+	lap("k-mers counted");
 	uint32_t genome_read_len = 0, n_pseudo = 0; const uint32_t genome_overlap = (k - 1) * 10;     // compression.cpp:407,447
 	if (with_genome)
 	{
@@ -372,6 +375,7 @@ int run_compress(int argc, char** argv)
 	}
 	for (auto& dc : chunks) ck(ctx, cl_compressor_refs_add(cmp, dc.reads), "reference reads");
 	ck(ctx, cl_compressor_refs_finish(cmp), "reference index");
+	lap("reference reads and index");
 	uint64_t mean_read_len = 0; uint32_t sparse_range = 0, n_refs = 0;
 	ck(ctx, cl_compressor_info(cmp, nullptr, nullptr, nullptr, &mean_read_len, &sparse_range, &n_refs), "cl_compressor_info");
 	if (O.verbose) fprintf(stderr, "k=%u a=%u; %llu k-mers, %llu kept; %u reference reads; sparse range %u\n", k, a, (unsigned long long)ks.tot_kmers, (unsigned long long)ks.n_unique_counted, n_refs, sparse_range);
@@ -411,7 +415,9 @@ int run_compress(int argc, char** argv)
 		}
 		(void)hipFree(d_dna); if (d_qual) (void)hipFree(d_qual);
 	}
+	lap("pass 2 (dna + qual parts written)");
 	hdr.join();
+	lap("header stream");
 	if (!hdr_err.empty()) die("header stream: " + hdr_err);
 	for (size_t p = 0; p < hdr_parts.size(); ++p) ar.add(s_header, hdr_parts[p].data(), hdr_parts[p].size(), hdr_counts[p]);
 
