@@ -31,6 +31,9 @@ CONFIGS = {
     "s6m_ont": dict(args=["compress-ont"], synth=dict(seed=1, genome_len=200_000, target_bases=6_000_000)),
     "s3m_ont_n_ratio": dict(args=["compress-ont", "-p", "ratio"], synth=dict(seed=7, genome_len=100_000, target_bases=3_000_000, n_frac=0.2, mean_scale=8000.0)),
     "s5m_hifi": dict(args=["compress-pbhifi"], synth=dict(seed=3, genome_len=150_000, target_bases=5_000_000, mean_scale=12000.0)),
+    # the parameters the reference picks for config 5's 50 Gbases (compression.cpp:84-88): 50-bit k-mers, 44-bit m-mers
+    "s6m_ont_k25": dict(args=["compress-ont", "-k", "25", "-a", "22"], synth=dict(seed=11, genome_len=200_000, target_bases=6_000_000)),
+    "s4m_ont_k23_balanced": dict(args=["compress-ont", "-k", "23", "-a", "21", "-p", "balanced"], synth=dict(seed=12, genome_len=120_000, target_bases=4_000_000, mean_scale=9000.0)),
 }
 
 

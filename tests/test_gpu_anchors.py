@@ -25,7 +25,7 @@ def hifi_args(ctx, g, c):
     return (g.p("k"), g.p("f"), torch.from_numpy(off).to(ctx.device), torch.from_numpy(common.view(np.int64).copy()).to(ctx.device))
 
 
-@pytest.mark.parametrize("cfg", ["c3_clr_ratio", "s6m_ont", "s3m_ont_n_ratio", "s5m_hifi", "c7_hifi_balanced", "c2_hifi_org"])
+@pytest.mark.parametrize("cfg", ["c3_clr_ratio", "s6m_ont", "s3m_ont_n_ratio", "s5m_hifi", "c7_hifi_balanced", "c2_hifi_org", "s6m_ont_k25", "s4m_ont_k23_balanced"])
 def test_anchor_candidates_equal_oracle(ctx, cfg):
     g = golden(cfg)
     rs = g.reads

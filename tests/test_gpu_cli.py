@@ -44,7 +44,7 @@ def test_cli_archive_decoded_by_reference(tmp_path, mode, prio, seed):
 
 
 @pytest.mark.skipif(not os.path.exists(CLI), reason="needs colord_amd/colord_hip")
-@pytest.mark.parametrize("cfg", ["c1_ont_default", "c2_hifi_org", "c3_clr_ratio", "c6_ont_org", "c7_hifi_balanced", "s6m_ont", "s3m_ont_n_ratio", "s5m_hifi"])
+@pytest.mark.parametrize("cfg", ["c1_ont_default", "c2_hifi_org", "c3_clr_ratio", "c6_ont_org", "c7_hifi_balanced", "s6m_ont", "s3m_ont_n_ratio", "s5m_hifi", "s6m_ont_k25", "s4m_ont_k23_balanced"])
 def test_cli_round_trip_on_goldens(tmp_path, cfg):
     """compress on the GPU, decompress with this build's decoders: the output is what the reference returns for the same input
     (`decompressed_sha256` of the golden vectors: the input itself for -q org, the quantised qualities otherwise)."""
@@ -242,20 +242,23 @@ def test_cli_reference_genome_mode_equals_the_reference(tmp_path, stored):
 
 
 @pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(CLI)), reason="needs oracle/_ref/colord and colord_amd/colord_hip")
-def test_cli_250_mbases_of_the_bench_recipe_equal_the_reference(tmp_path):
+@pytest.mark.parametrize("extra", [[], ["-k", "25", "-a", "22"], ["-k", "23", "-a", "21"]], ids=["auto_k20_a16", "k25_a22", "k23_a21"])
+def test_cli_250_mbases_of_the_bench_recipe_equal_the_reference(tmp_path, extra):
     """The recipe of config 5 (BASELINE.json: synthetic ONT, N50 ~ 20 kb, reads up to 200 kb, 4-avg qualities) at a size where
     every mechanism of the 50-Gbase run is in play — several chunks, both encode lanes with look-ahead, the walk of the next chunk
     in the coding tail, anchor batches, all four recursion levels, the four-per-wave and the wave-per-gap aligners, long context
     runs — against the unmodified reference on the same FASTQ: `meta`, `dna`, `qual`, `header` byte-identical, and this build's
-    decompressor returns what the reference returns."""
+    decompressor returns what the reference returns.  `extra`: the k-mer / anchor lengths the reference picks by input size
+    (compression.cpp:62-93) forced to config 5's own (k = 25, a = 22 at 50 Gbases: 50-bit k-mers, 44-bit m-mers) and to the
+    16-Gbase tier's (k = 23, a = 21)."""
     from colord_amd import ontsim
     table = ontsim.ReadTable(seed=29, genome_len=15_000_000, target_bases=250_000_000)
     fq = str(tmp_path / "in.fastq")
     n_bases = ontsim.write_fastq(table, fq)
     assert n_bases >= 240_000_000 and int(table.len_src.max()) >= 150_000          # (errors shorten the source lengths a little)
     ref_arc, my_arc, ref_out, my_out = (str(tmp_path / x) for x in ("ref.colord", "gpu.colord", "ref.fastq", "gpu.fastq"))
-    subprocess.check_call([REF, "compress-ont", "-t", str(os.cpu_count() or 8), fq, ref_arc], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    subprocess.check_call([CLI, "compress-ont", "--chunk-bases", "60000000", fq, my_arc])              # five chunks
+    subprocess.check_call([REF, "compress-ont", "-t", str(os.cpu_count() or 8)] + extra + [fq, ref_arc], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.check_call([CLI, "compress-ont", "--chunk-bases", "60000000"] + extra + [fq, my_arc])   # five chunks
     a, b = AR.read_archive(ref_arc), AR.read_archive(my_arc)
     assert set(a) == set(b)
     for name in a:

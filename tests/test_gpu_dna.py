@@ -95,7 +95,7 @@ def test_plain_tuple_streams_match_reference(ctx):
         reads.free()
 
 
-@pytest.mark.parametrize("cfg", ["s6m_ont", "c3_clr_ratio", "s5m_hifi"])
+@pytest.mark.parametrize("cfg", ["s6m_ont", "c3_clr_ratio", "s5m_hifi", "s6m_ont_k25", "s4m_ont_k23_balanced"])
 @pytest.mark.parametrize("long_run", ["4096", "50000"])
 def test_long_context_runs_take_the_parallel_path(ctx, cfg, long_run, monkeypatch):
     """Long runs of one context are evolved by the prefix-count + rescale-chain kernels (k_long_*); with the threshold
@@ -108,7 +108,7 @@ def test_long_context_runs_take_the_parallel_path(ctx, cfg, long_run, monkeypatc
     assert got == g.spec["streams"]["dna"]["parts"]
 
 
-@pytest.mark.parametrize("cfg", ["s6m_ont", "c3_clr_ratio", "s5m_hifi"])
+@pytest.mark.parametrize("cfg", ["s6m_ont", "c3_clr_ratio", "s5m_hifi", "s6m_ont_k25", "s4m_ont_k23_balanced"])
 @pytest.mark.parametrize("chunk,warm", [("32", "16"), ("64", "0"), ("256", "4"), ("1000", "128")])
 def test_walk_chunks_resume_the_same_walk(ctx, cfg, chunk, warm, monkeypatch):
     """The write pass of the tuple walk resumes from states the count pass saved every `chunk` tuples, and the count pass

@@ -37,7 +37,7 @@ def gpu_streams(ctx, g, pack_bounds=None):
     return es, off, nt
 
 
-@pytest.mark.parametrize("cfg", ["c3_clr_ratio", "s6m_ont", "s3m_ont_n_ratio", "c1_ont_default", "c6_ont_org", "s5m_hifi", "c7_hifi_balanced", "c2_hifi_org"])
+@pytest.mark.parametrize("cfg", ["c3_clr_ratio", "s6m_ont", "s3m_ont_n_ratio", "c1_ont_default", "c6_ont_org", "s5m_hifi", "c7_hifi_balanced", "c2_hifi_org", "s6m_ont_k25", "s4m_ont_k23_balanced"])
 def test_tuple_streams_equal_reference(ctx, cfg):
     g = golden(cfg)
     es, off, nt = gpu_streams(ctx, g)
@@ -49,11 +49,11 @@ def test_tuple_streams_equal_reference(ctx, cfg):
             bad.append(i)
         n_es += len(got) > 0 and got[0] >> 4 == 10
     assert not bad, f"{len(bad)} of {g.reads.n_reads} reads differ, first {bad[:10]}"
-    if cfg in ("c3_clr_ratio", "s6m_ont", "s3m_ont_n_ratio", "s5m_hifi", "c7_hifi_balanced"):
+    if cfg in ("c3_clr_ratio", "s6m_ont", "s3m_ont_n_ratio", "s5m_hifi", "c7_hifi_balanced", "s6m_ont_k25", "s4m_ont_k23_balanced"):
         assert n_es > 10                                    # the edit-script path is really exercised
 
 
-@pytest.mark.parametrize("cfg", ["c3_clr_ratio", "s6m_ont", "s3m_ont_n_ratio", "c1_ont_default", "s5m_hifi", "c7_hifi_balanced", "c2_hifi_org"])
+@pytest.mark.parametrize("cfg", ["c3_clr_ratio", "s6m_ont", "s3m_ont_n_ratio", "c1_ont_default", "s5m_hifi", "c7_hifi_balanced", "c2_hifi_org", "s6m_ont_k25", "s4m_ont_k23_balanced"])
 def test_whole_dna_path_byte_identical_to_reference(ctx, cfg):
     """Read bases (and qualities) in, `dna` and `qual` stream parts out, every stage on the GPU (a1-a16): the parts must
     have the sizes and SHA-256 of the parts the unmodified reference wrote for the same file."""
@@ -137,7 +137,7 @@ def sparse_g(g):
     return 1.0
 
 
-@pytest.mark.parametrize("cfg", ["c1_ont_default", "c2_hifi_org", "c3_clr_ratio", "s6m_ont", "s3m_ont_n_ratio", "s5m_hifi", "c7_hifi_balanced"])
+@pytest.mark.parametrize("cfg", ["c1_ont_default", "c2_hifi_org", "c3_clr_ratio", "s6m_ont", "s3m_ont_n_ratio", "s5m_hifi", "c7_hifi_balanced", "s6m_ont_k25", "s4m_ont_k23_balanced"])
 def test_compress_shard_one_call_equals_reference(ctx, cfg):
     """cl_compress_shard — the C++ wiring of all stages (runCompression's data path) — from read bases and qualities to
     the parts of both streams in one native call: sizes and SHA-256 of the unmodified reference's parts."""
