@@ -46,20 +46,27 @@ struct ArchiveWriter {
 struct ArchiveReader {
 	struct Part { uint64_t off, size; };
 	struct Stream { std::string name; uint64_t raw_size = 0; std::vector<Part> parts; size_t next = 0; };
-	FILE* f = nullptr; std::vector<Stream> streams;
+	FILE* f = nullptr; std::vector<Stream> streams; uint64_t file_size = 0;
 	bool open(const std::string& path)
 	{
 		f = fopen(path.c_str(), "rb");
 		if (!f) return false;
+		const bool ok_ = parse_footer();
+		if (!ok_) close();                                                 // (no descriptor left behind by a file that is not an archive)
+		return ok_;
+	}
+	bool parse_footer()
+	{
 		if (fseeko(f, 0, SEEK_END) != 0) return false;
-		const uint64_t fs = (uint64_t)ftello(f);
-		if (fs < 8) return false;
-		uint8_t sz[8]; fseeko(f, (off_t)(fs - 8), SEEK_SET);
-		if (fread(sz, 1, 8, f) != 8) return false;
+		const off_t end = ftello(f);
+		if (end < 8) return false;
+		const uint64_t fs = file_size = (uint64_t)end;
+		uint8_t sz[8];
+		if (fseeko(f, (off_t)(fs - 8), SEEK_SET) != 0 || fread(sz, 1, 8, f) != 8) return false;
 		uint64_t n = 0; for (int i = 0; i < 8; ++i) n |= (uint64_t)sz[i] << (8 * i);
 		if (n > fs - 8) return false;
-		std::vector<uint8_t> ft(n); fseeko(f, (off_t)(fs - 8 - n), SEEK_SET);
-		if (n && fread(ft.data(), 1, n, f) != n) return false;
+		std::vector<uint8_t> ft(n);
+		if (fseeko(f, (off_t)(fs - 8 - n), SEEK_SET) != 0 || (n && fread(ft.data(), 1, n, f) != n)) return false;
 		size_t p = 0; bool ok = true;
 		auto vi = [&]() -> uint64_t { if (p >= ft.size()) { ok = false; return 0; } const int k = ft[p++]; uint64_t v = 0; for (int i = 0; i < k; ++i) { if (p >= ft.size()) { ok = false; return 0; } v = (v << 8) | ft[p++]; } return v; };
 		const uint64_t ns = vi();
@@ -69,7 +76,13 @@ struct ArchiveReader {
 			while (p < ft.size() && ft[p]) st.name.push_back((char)ft[p++]);
 			++p;
 			const uint64_t np = vi(); st.raw_size = vi();
-			for (uint64_t i = 0; i < np && ok; ++i) { Part pt; pt.off = vi(); pt.size = vi(); st.parts.push_back(pt); }
+			if (np > ft.size()) ok = false;                                  // (a part costs at least two footer bytes)
+			for (uint64_t i = 0; i < np && ok; ++i)
+			{	// a part lies inside the file, before the footer: offsets and sizes of a crafted footer never reach resize() / pread()
+				Part pt; pt.off = vi(); pt.size = vi();
+				if (pt.off > fs || pt.size > fs - pt.off) ok = false;
+				st.parts.push_back(pt);
+			}
 			streams.push_back(std::move(st));
 		}
 		return ok;
@@ -90,6 +103,7 @@ inline bool ArchiveReader::part(int s, size_t i, std::vector<uint8_t>& data, uin
 	if (got < 1) return false;
 	const int k = h[0]; if (k > 8 || got < 1 + k) return false;
 	meta = 0; for (int j = 0; j < k; ++j) meta = (meta << 8) | h[1 + j];
+	if (pt.off > file_size || 1ull + k > file_size - pt.off || pt.size > file_size - pt.off - 1 - k) return false;
 	data.resize(pt.size);
 	uint64_t done = 0;
 	while (done < pt.size)

@@ -81,6 +81,9 @@ class RecordStream {
 	std::thread t_dna, t_qual, t_hdr;
 	ReadPart rp, qp; HeaderPart hp; size_t ri = 0, hi = 0; bool have_r = false, have_h = false;
 	bool is_domain_start(size_t part) const { for (uint64_t f : domain_first_part) if (f == part) return true; return false; }
+	// Part metadata is a record count read from the file: it sizes vectors, so it is checked before any allocation — against
+	// 2^32 (the decoders count in 32 bits) and against the archive's own total (`info` stream) when there is one.
+	bool count_ok(uint64_t n) const { return n <= 0xffffffffull && (I.total_reads == 0 || n <= I.total_reads); }
 	void start();
 	void join() { if (t_dna.joinable()) t_dna.join(); if (t_qual.joinable()) t_qual.join(); if (t_hdr.joinable()) t_hdr.join(); }
 public:
@@ -149,6 +152,7 @@ inline void RecordStream::start()
 	const size_t n_parts = ar.n_parts(s_dna);
 	t_dna = std::thread([this, n_parts]() {
 		cl_dna_decoder* d = nullptr;
+		try {
 		if (cl_dna_decoder_create(M.max_candidates, M.level, M.n_pseudo, M.n_pseudo, M.ref_mode == 0, M.sparse_range, M.sparse_exp, &d) != CL_OK) { err_dna = "cl_dna_decoder_create"; }
 		for (size_t i = 0; d && i + 1 < pseudo.off.size(); ++i)                    // decompression_common.cpp:287-292
 			if (cl_dna_decoder_add_ref(d, pseudo.codes.data() + pseudo.off[i], (uint32_t)(pseudo.off[i + 1] - pseudo.off[i])) != CL_OK) { err_dna = "cl_dna_decoder_add_ref"; break; }
@@ -157,6 +161,7 @@ inline void RecordStream::start()
 		for (size_t p = 0; d && p < n_parts; ++p)
 		{
 			if (!ar.part(s_dna, p, in, n_reads)) { err_dna = "cannot read a `dna` part"; break; }
+			if (!count_ok(n_reads)) { err_dna = "a `dna` part claims more reads than the archive holds"; break; }
 			if (is_domain_start(p)) cl_dna_decoder_new_domain(d);
 			ReadPart x; x.off.resize(n_reads + 1);
 			uint64_t cap = std::max<uint64_t>(in.size() * 8, 1 << 20), got = 0;
@@ -168,6 +173,7 @@ inline void RecordStream::start()
 			if (fastq) { ReadPart cp; cp.bases = x.bases; cp.off = x.off; q_bases_for_qual.push(std::move(cp)); }
 			q_reads.push(std::move(x));
 		}
+		} catch (const std::exception& e) { err_dna = std::string("corrupt `dna` part (") + e.what() + ")"; }
 		if (d) cl_dna_decoder_free(d);
 		q_bases_for_qual.finish(); q_reads.finish();
 	});
@@ -178,6 +184,7 @@ inline void RecordStream::start()
 		cl_qual_decoder* q = nullptr;
 		if (cl_qual_decoder_create(&qpar, &q) != CL_OK) { err_qual = "cl_qual_decoder_create"; }
 		ReadPart x; std::vector<uint8_t> in; uint64_t meta = 0; size_t p = 0;
+		try {
 		while (q && q_bases_for_qual.pop(x))
 		{
 			if (!ar.part(s_qual, p, in, meta)) { err_qual = "cannot read a `qual` part"; break; }
@@ -188,6 +195,7 @@ inline void RecordStream::start()
 			q_quals.push(std::move(x));
 			++p;
 		}
+		} catch (const std::exception& e) { err_qual = std::string("corrupt `qual` part (") + e.what() + ")"; }
 		while (q_bases_for_qual.pop(x)) {}                                    // drain after an error so that the producer can finish
 		if (q) cl_qual_decoder_free(q);
 		q_quals.finish();
@@ -196,9 +204,11 @@ inline void RecordStream::start()
 		cl_id_decoder* c = nullptr;
 		if (cl_id_decoder_create(M.header_mode, &c) != CL_OK) { err_hdr = "cl_id_decoder_create"; }
 		std::vector<uint8_t> in; uint64_t n = 0;
+		try {
 		for (size_t p = 0; c && p < ar.n_parts(s_hdr); ++p)
 		{
 			if (!ar.part(s_hdr, p, in, n)) { err_hdr = "cannot read a `header` part"; break; }
+			if (!count_ok(n)) { err_hdr = "a `header` part claims more records than the archive holds"; break; }
 			HeaderPart x; x.off.resize(n + 1); x.plus.resize(n);
 			uint64_t cap = std::max<uint64_t>(in.size() * 64, 1 << 20), got = 0;
 			x.ids.resize(cap);
@@ -208,6 +218,7 @@ inline void RecordStream::start()
 			x.ids.resize(got);
 			q_hdr.push(std::move(x));
 		}
+		} catch (const std::exception& e) { err_hdr = std::string("corrupt `header` part (") + e.what() + ")"; }
 		if (c) cl_id_decoder_free(c);
 		q_hdr.finish();
 	});

@@ -123,11 +123,15 @@ struct cl_dna_decoder {
 		ctx += (uint64_t)base << shift; shift += 2;
 		return ctx + ((ctx_tuple_type & 07777) << shift);
 	}
-	uint32_t dec_anchor_len() { uint32_t len = 0; for (uint64_t part = 0;; ++part) { const uint32_t x = m_anchor_len.decode(rc, part); if (x < 23) return len + x; len += 22; } }   // :981-1001
+	// A corrupt stream must end in an error, not in unbounded output: run lengths are 28-bit in the tuple format (utils.h:53), a read
+	// is bounded, and the continuation loops of the length codes stop at those bounds.
+	static constexpr uint32_t MAX_RUN = 1u << 28; static constexpr uint64_t MAX_READ_BASES = 1ull << 31;
+	bool bad_len = false;
+	uint32_t dec_anchor_len() { uint32_t len = 0; for (uint64_t part = 0;; ++part) { const uint32_t x = m_anchor_len.decode(rc, part); if (x < 23) return len + x; len += 22; if (len > MAX_RUN) { bad_len = true; return 0; } } }   // :981-1001
 	uint32_t dec_skip_len(bool local)                                // :1141-1175
 	{
 		uint32_t len = 0;
-		if (local) { for (uint64_t part = 0;; ++part) { const uint32_t x = m_skip_local.decode(rc, part); if (x < 255) return len + x; len += 254; } }
+		if (local) { for (uint64_t part = 0;; ++part) { const uint32_t x = m_skip_local.decode(rc, part); if (x < 255) return len + x; len += 254; if (len > MAX_RUN) { bad_len = true; return 0; } } }
 		for (int i = 3; i >= 0; --i) len = (len << 8) + m_skip_distant.decode(rc, (uint64_t)i * 64 + ilog2_(len));
 		return len;
 	}
@@ -141,6 +145,7 @@ bool cl_dna_decoder::decode_read(std::vector<uint8_t>& out)           // CDNACod
 	const uint32_t flag = m_read_type.decode(rc, ctx_read_type);      // decode_read_flag (:466-486)
 	ctx_read_type = ((ctx_read_type << 2) + flag) & 0xff;
 	const uint32_t read_len = dec_read_len();
+	if (read_len > MAX_READ_BASES) { err = "dna stream: implausible read length"; return false; }
 	bool accept = flag != 1;
 	if (!accept_all) accept &= should_add(cur_read_id);               // (the draw happens for every read, `&=` does not short-circuit)
 	const size_t o0 = out.size();
@@ -164,12 +169,13 @@ bool cl_dna_decoder::decode_read(std::vector<uint8_t>& out)           // CDNACod
 	int64_t ref_pos = 0, alt_pos = 0;
 	cur_ref_delta = 0;
 	std::vector<uint8_t> plain;                                       // read_without_flags
-	plain.reserve(read_len);
+	plain.reserve(std::min<uint32_t>(read_len, 1u << 24));                 // (a decoded value: a hint, never trusted with memory)
 	auto emit = [&](uint32_t b, uint8_t fl) { out.push_back((uint8_t)(b | fl)); plain.push_back((uint8_t)b); };
 	for (uint32_t t_i = 0; t_i < read_len; ++t_i)
 	{
 		const uint32_t ref_symbol = is_main ? ref_at(ref_id, ref_rev, ref_pos) : ref_at(alt_id, alt_rev, alt_pos);
 		const uint32_t t = dec_tuple_type(ref_symbol, last, t_i == 0);
+		if (bad_len || out.size() - o0 > MAX_READ_BASES) { err = "dna stream: run or read longer than the format allows"; return false; }
 		switch (t)
 		{
 		case T_ALT_ID:

@@ -69,6 +69,41 @@ def test_corrupt_part_is_an_error_not_a_crash(tmp_path):
     assert r.returncode in (0, 1)                            # garbage in: either a reported stream error or garbage bases, never a hang / signal
 
 
+@pytest.mark.parametrize("stream,meta", [("dna", 1 << 62), ("dna", (1 << 32) + 24), ("dna", 25), ("header", 1 << 61), ("header", (1 << 32) + 24), ("qual", 1 << 40)])
+def test_crafted_part_metadata_is_an_error_not_a_crash(tmp_path, stream, meta):
+    """Part metadata (a record count read from the file) sizes vectors in the reader: a crafted value must end in the tool's
+    error exit — no std::terminate, no multi-GB allocation, no hang (ADVICE r2: reader.hpp resize from untrusted metadata)."""
+    arc = AR.read_archive(os.path.join(ARC, "bovis24_q_4-avg_balanced.colord"))
+    st = arc[stream]
+    st.parts[0] = (meta, st.parts[0][1])
+    bad = str(tmp_path / "bad.colord")
+    AR.write_archive(bad, list(arc.values()))
+    r = subprocess.run([CLI, "decompress", bad, str(tmp_path / "o.fastq")], capture_output=True, text=True, timeout=60)
+    assert r.returncode in (0, 1), (r.returncode, r.stderr[-300:])       # (qual metadata is unused: 0)
+    if stream != "qual":
+        assert r.returncode == 1 and "colord_hip:" in r.stderr
+
+
+def test_crafted_footer_is_an_error_not_a_crash(tmp_path):
+    """Part offsets / sizes of the footer beyond the file, and a footer length beyond the file: refused when the archive is opened."""
+    src = open(os.path.join(ARC, "c1_ont_default.colord"), "rb").read()
+    n = int.from_bytes(src[-8:], "little")
+    footer = bytearray(src[-8 - n:-8])
+    # the first part entry after the first stream's name, part count and raw size: make its size field huge
+    i = footer.index(0) + 1                                   # past n_streams varint? (footer[0] is the varint length byte of n_streams)
+    cases = []
+    big = bytearray(footer); big[-1] ^= 0xff; big[-2] ^= 0xff  # last part's size bytes
+    cases.append(bytes(src[:-8 - n]) + bytes(big) + src[-8:])
+    cases.append(src[:-8] + (1 << 40).to_bytes(8, "little"))    # footer longer than the file
+    cases.append(src[:len(src) // 2])                           # truncated file
+    for k, blob in enumerate(cases):
+        bad = tmp_path / f"bad{k}.colord"
+        bad.write_bytes(blob)
+        for cmd in (["decompress", str(bad), str(tmp_path / "o.fastq")], ["info", str(bad)]):
+            r = subprocess.run([CLI] + cmd, capture_output=True, text=True, timeout=60)
+            assert r.returncode in (0, 1), (k, cmd, r.returncode, r.stderr[-300:])
+
+
 def test_reference_genome_archives_need_the_right_genome(tmp_path):
     """-G without -s (decompression_common.cpp:262-281): no genome -> refused; another genome -> refused by its checksum."""
     arc = os.path.join(ARC, "c4_ont_genome_external.colord")
