@@ -45,99 +45,164 @@ __device__ inline uint32_t bcast_first(uint32_t v) { return __builtin_amdgcn_rea
 __device__ inline int shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
 __device__ inline uint32_t shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }
 
-struct Hist { uint64_t* P; uint64_t* H; uint32_t W, m; };       // cell (tile, s, lane) at ((tile * (m + 64)) + s) * W + lane
+struct Hist { uint64_t* P; uint64_t* H; uint32_t W, m, rows; };  // cell (tile, s, lane) at ((tile * (m + 64)) + s) * W + lane; rows: the rows the sweep computed (sat_rows)
 __device__ inline uint64_t hist_words(uint32_t nb, uint32_t m) { const uint32_t tiles = (nb + 63) / 64, W = nb < 64 ? nb : 64; return (uint64_t)tiles * (m + 64) * W; }
 
 struct Sweep { uint32_t score; uint32_t best; int32_t end; };
-// Sweeps all columns.  q/t: byte sequences with steps +-1.  hist: where to keep (vertical +1, horizontal +1) bit-vectors
-// per cell, or null.  lastcol: n + 1 values D[i][m], or null.  shw: track min over columns of D[n][j] (first minimum;
-// end = -1 a candidate when n % 64 != 0).  score = D[n][m].
-__device__ inline Sweep wave_sweep(WavePool& pool, const uint8_t* q, int qstep, uint32_t n, const uint8_t* t, int tstep, uint32_t m, bool shw, const Hist* hist, int32_t* lastcol)
+
+// ---- saturation: the rows a sweep has to compute ---------------------------------------------------------------------------
+// D[i][j] >= i - j (a column absorbs at most one row on a diagonal), with equality exactly when t[0..j) is a SUBSEQUENCE of
+// q[0..i).  Let s_j be the row where the greedy embedding of t[0..j) in q ends (s_0 = 0 < s_1 < ...).  Then for every row
+// i >= s_j: D[i][j] = i - j, so below row s_j the column is known without any recurrence — vertical delta +1, horizontal delta
+// -1.  The typical gap of the wave class is a read flank of 10^3..10^5 symbols against the few hundred symbols that are left of
+// the reference read (encoder.cpp:1262-1273: at most 2 x the flank, but the reference read ends): rows >> columns, and the rows
+// below s_m (about 1.2 m for related sequences, about 4 m for unrelated ones) were 90..99 % of the swept cells.
+// Returns the number of rows to compute: n itself, or a multiple of 64 with s_m <= rows < n (then the rest is closed form).
+__device__ inline uint32_t sat_rows(const uint8_t* q, int qstep, uint32_t n, const uint8_t* t, int tstep, uint32_t m)
+{
+	if (n < m + 64) return n;
+	const uint32_t lane = lane_id();
+	uint32_t p = 0;                                                             // symbols of t embedded so far (wave-uniform)
+	uint32_t tch = lane < m ? (uint32_t)(t[(int64_t)lane * tstep] & 3) : 0u;    // lanes hold t[(p & ~63) + lane]
+	for (uint32_t i0 = 0; i0 < n; i0 += 64)
+	{
+		const uint32_t i = i0 + lane;
+		const uint32_t s = i < n ? (uint32_t)(q[(int64_t)i * qstep] & 3) : 4u;
+		const uint64_t e0 = __ballot(s == 0), e1 = __ballot(s == 1), e2 = __ballot(s == 2), e3 = __ballot(s == 3);
+		uint32_t pos = 0;                                                       // rows of this chunk consumed
+		while (p < m)
+		{
+			const uint32_t c = bcast(tch, p & 63);
+			uint64_t mk = c == 0 ? e0 : c == 1 ? e1 : c == 2 ? e2 : e3;
+			mk &= ~0ull << pos;
+			if (!mk) break;
+			pos = (uint32_t)__builtin_ctzll(mk) + 1; ++p;
+			if ((p & 63) == 0) { const uint32_t j = p + lane; tch = j < m ? (uint32_t)(t[(int64_t)j * tstep] & 3) : 0u; }
+			if (pos == 64) break;
+		}
+		if (p == m) return i0 + 64 < n ? i0 + 64 : n;
+	}
+	return n;
+}
+
+// One tile (64 row blocks, one per lane) of a sweep over all columns; the tiles of a sweep hand the horizontal deltas of their
+// last block over through byte arrays.  `prog_in` / `prog_out` (team sweeps, align_team.hpp: the tiles of one sweep run on
+// different waves of a work-group, each a little behind the one above it): LDS words counting the columns whose deltas
+// are written — waited for before a 64-column chunk of `hin` is read, published every 64 steps.
+struct TileState { uint32_t sc, best; int32_t end; };                         // meaningful in the lane that owns the last block
+__device__ inline void sweep_tile(uint32_t tile, const uint8_t* q, int qstep, uint32_t n, uint32_t ne, const uint8_t* t, int tstep, uint32_t m, bool shw, bool sat,
+                                  const Hist* hist, int32_t* lastcol, const int8_t* hin_arr, int8_t* hout_arr, volatile uint32_t* prog_in, volatile uint32_t* prog_out, TileState& st)
 {
 	const uint32_t lane = lane_id();
-	const uint32_t nb = (n + 63) / 64, tiles = (nb + 63) / 64;
+	const uint32_t nb = (ne + 63) / 64;
+	const uint32_t lastbit = (n - 1) & 63;
+	const uint32_t b = tile * 64 + lane; const bool act = b < nb;
+	const uint32_t W = nb - tile * 64 < 64 ? nb - tile * 64 : 64;
+	uint64_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+	for (uint32_t bb = 0; bb < W; ++bb)
+	{	// the match masks of block tile * 64 + bb: one coalesced load of its 64 row symbols, four ballots; lane bb keeps them
+		const uint32_t i = (tile * 64 + bb) * 64 + lane;
+		const uint32_t s = i < ne ? (uint32_t)(q[(int64_t)i * qstep] & 3) : 4u;
+		const uint64_t m0 = __ballot(s == 0), m1 = __ballot(s == 1), m2 = __ballot(s == 2), m3 = __ballot(s == 3);
+		if (lane == bb) { e0 = m0; e1 = m1; e2 = m2; e3 = m3; }
+	}
+	uint64_t Pv = ~0ull, Mv = 0; int32_t S = (int32_t)((b + 1) * 64);
+	const bool owner = !sat && act && b == nb - 1;
+	uint32_t c = 0; int hout = 0; uint32_t tchunk = 0; int hchunk = 1;
+	const uint32_t steps = m + W - 1;
+	for (uint32_t s = 0; s < steps; ++s)
+	{
+		if ((s & 63) == 0)
+		{
+			const uint32_t j0 = s + lane;
+			tchunk = j0 < m ? (uint32_t)(t[(int64_t)j0 * tstep] & 3) : 0u;
+			if (prog_in && s < m)
+			{	// the tile above has to be through columns s .. s + 63
+				const uint32_t need = s + 64 < m ? s + 64 : m;
+				while (*prog_in < need) __builtin_amdgcn_s_sleep(4);
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+			}
+			hchunk = hin_arr ? (j0 < m ? (int)hin_arr[j0] : 0) : 1;
+		}
+		const uint32_t c_new = bcast(tchunk, s & 63); const int h_new = bcast(hchunk, s & 63);
+		const uint32_t c_up = shr1(c); const int h_up = shr1(hout);
+		c = lane == 0 ? c_new : c_up;
+		const int hin = lane == 0 ? h_new : h_up;
+		const bool valid = act && s >= lane && s - lane < m;
+		hout = 0;
+		if (valid)
+		{
+			uint64_t Eq = c == 0 ? e0 : c == 1 ? e1 : c == 2 ? e2 : e3;
+			const uint64_t hneg = hin < 0 ? 1ull : 0ull;
+			const uint64_t Xv = Eq | Mv;
+			Eq |= hneg;
+			const uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+			uint64_t Ph = Mv | ~(Xh | Pv);
+			uint64_t Mh = Pv & Xh;
+			const uint64_t ph_rows = Ph;
+			if (owner)
+			{
+				st.sc += (uint32_t)((Ph >> lastbit) & 1) - (uint32_t)((Mh >> lastbit) & 1);
+				if (shw && st.sc < st.best) { st.best = st.sc; st.end = (int32_t)(s - lane); }
+			}
+			hout = (int)(Ph >> 63) - (int)(Mh >> 63);
+			Ph <<= 1; Mh <<= 1;
+			Mh |= hneg; Ph |= hin > 0 ? 1ull : 0ull;
+			Pv = Mh | ~(Xv | Ph);
+			Mv = Ph & Xv;
+			S += hout;
+			if (hist) { const uint64_t idx = ((uint64_t)tile * (m + 64) + s) * hist->W + lane; hist->P[idx] = Pv; hist->H[idx] = ph_rows; }
+			if (hout_arr && lane == W - 1) hout_arr[s - lane] = (int8_t)hout;
+		}
+		if (prog_out && (s & 63) == 63)
+		{	// after step s the last block is through column s - (W - 1)
+			__builtin_amdgcn_s_waitcnt(0);
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			if (lane == 0) *prog_out = s + 2 > W ? s + 2 - W : 0u;
+		}
+	}
+	if (lastcol && act)
+	{	// column m of this block, bottom row upwards
+		const uint32_t lo = b * 64; int32_t v = S;
+		for (int r = 63; r >= 0; --r)
+		{
+			const uint32_t i = lo + (uint32_t)r + 1;
+			if (i <= ne) lastcol[i] = v;
+			v -= (int32_t)((Pv >> r) & 1); v += (int32_t)((Mv >> r) & 1);
+		}
+	}
+	__builtin_amdgcn_s_waitcnt(0);          // the next tile reads what this one wrote
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	if (prog_out && lane == 0) *prog_out = m;
+}
+
+// Sweeps all columns.  q/t: byte sequences with steps +-1.  ne: the rows to compute (sat_rows: n, or a multiple of 64 below
+// which every column is i - j).  hist: where to keep (vertical +1, horizontal +1) bit-vectors per cell of the ne rows, or
+// null.  lastcol: ne + 1 values D[i][m], or null.  shw: track min over columns of D[n][j] (first minimum; end = -1 a
+// candidate when n % 64 != 0).  score = D[n][m].
+__device__ inline Sweep wave_sweep(WavePool& pool, const uint8_t* q, int qstep, uint32_t n, uint32_t ne, const uint8_t* t, int tstep, uint32_t m, bool shw, const Hist* hist, int32_t* lastcol)
+{
+	const uint32_t lane = lane_id();
+	const bool sat = ne < n;
+	Sweep out{ n, 0xffffffffu, (int32_t)m - 1 };
+	if (sat)
+	{	// row n is i - j in every column: D[n][j] = n - j falls strictly, the first minimum is the last column
+		out.score = n - m; out.best = n - m; out.end = (int32_t)m - 1;
+		if (!hist && !lastcol) return out;
+	}
+	const uint32_t nb = (ne + 63) / 64, tiles = (nb + 63) / 64;
 	const uint64_t mk = pool.mark();
 	int8_t* hb_a = (int8_t*)pool.alloc(m + 64ull); int8_t* hb_b = (int8_t*)pool.alloc(m + 64ull);
-	Sweep out{ n, 0xffffffffu, (int32_t)m - 1 };
 	if (pool.overflow) { pool.release(mk); return out; }
-	if (shw && (n & 63)) { out.best = n; out.end = -1; }
-	const uint32_t lastbit = (n - 1) & 63;
-	uint32_t sc = n, best = out.best; int32_t end = out.end;             // meaningful in the lane that owns the last block
+	if (!sat && shw && (n & 63)) { out.best = n; out.end = -1; }
+	TileState st{ n, out.best, out.end };
 	if (lastcol && lane == 0) lastcol[0] = (int32_t)m;
 	for (uint32_t tile = 0; tile < tiles; ++tile)
 	{
-		const uint32_t b = tile * 64 + lane; const bool act = b < nb;
-		const uint32_t W = nb - tile * 64 < 64 ? nb - tile * 64 : 64;
-		uint64_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
-		if (act)
-		{
-			const uint32_t lo = b * 64, hi = n < lo + 64 ? n : lo + 64;
-			for (uint32_t i = lo; i < hi; ++i)
-			{
-				const uint32_t s = q[(int64_t)i * qstep] & 3; const uint64_t bit = 1ull << (i - lo);
-				e0 |= s == 0 ? bit : 0; e1 |= s == 1 ? bit : 0; e2 |= s == 2 ? bit : 0; e3 |= s == 3 ? bit : 0;
-			}
-		}
-		uint64_t Pv = ~0ull, Mv = 0; int32_t S = (int32_t)((b + 1) * 64);
-		const int8_t* hin_arr = tile ? hb_a : nullptr; int8_t* hout_arr = tile + 1 < tiles ? hb_b : nullptr;
-		const bool owner = act && b == nb - 1;
-		uint32_t c = 0; int hout = 0; uint32_t tchunk = 0; int hchunk = 1;
-		const uint32_t steps = m + W - 1;
-		for (uint32_t s = 0; s < steps; ++s)
-		{
-			if ((s & 63) == 0)
-			{
-				const uint32_t j0 = s + lane;
-				tchunk = j0 < m ? (uint32_t)(t[(int64_t)j0 * tstep] & 3) : 0u;
-				hchunk = hin_arr ? (j0 < m ? (int)hin_arr[j0] : 0) : 1;
-			}
-			const uint32_t c_new = bcast(tchunk, s & 63); const int h_new = bcast(hchunk, s & 63);
-			const uint32_t c_up = shr1(c); const int h_up = shr1(hout);
-			c = lane == 0 ? c_new : c_up;
-			const int hin = lane == 0 ? h_new : h_up;
-			const bool valid = act && s >= lane && s - lane < m;
-			hout = 0;
-			if (valid)
-			{
-				uint64_t Eq = c == 0 ? e0 : c == 1 ? e1 : c == 2 ? e2 : e3;
-				const uint64_t hneg = hin < 0 ? 1ull : 0ull;
-				const uint64_t Xv = Eq | Mv;
-				Eq |= hneg;
-				const uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
-				uint64_t Ph = Mv | ~(Xh | Pv);
-				uint64_t Mh = Pv & Xh;
-				const uint64_t ph_rows = Ph;
-				if (owner)
-				{
-					sc += (uint32_t)((Ph >> lastbit) & 1) - (uint32_t)((Mh >> lastbit) & 1);
-					if (shw && sc < best) { best = sc; end = (int32_t)(s - lane); }
-				}
-				hout = (int)(Ph >> 63) - (int)(Mh >> 63);
-				Ph <<= 1; Mh <<= 1;
-				Mh |= hneg; Ph |= hin > 0 ? 1ull : 0ull;
-				Pv = Mh | ~(Xv | Ph);
-				Mv = Ph & Xv;
-				S += hout;
-				if (hist) { const uint64_t idx = ((uint64_t)tile * (m + 64) + s) * hist->W + lane; hist->P[idx] = Pv; hist->H[idx] = ph_rows; }
-				if (hout_arr && lane == W - 1) hout_arr[s - lane] = (int8_t)hout;
-			}
-		}
-		if (lastcol && act)
-		{	// column m of this block, bottom row upwards
-			const uint32_t lo = b * 64; int32_t v = S;
-			for (int r = 63; r >= 0; --r)
-			{
-				const uint32_t i = lo + (uint32_t)r + 1;
-				if (i <= n) lastcol[i] = v;
-				v -= (int32_t)((Pv >> r) & 1); v += (int32_t)((Mv >> r) & 1);
-			}
-		}
+		sweep_tile(tile, q, qstep, n, ne, t, tstep, m, shw, sat, hist, lastcol, tile ? hb_a : nullptr, tile + 1 < tiles ? hb_b : nullptr, nullptr, nullptr, st);
 		{ int8_t* x = hb_a; hb_a = hb_b; hb_b = x; }
-		__builtin_amdgcn_s_waitcnt(0);          // the next tile reads what this one wrote
-		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 	}
-	const uint32_t own_lane = (nb - 1) & 63;
-	out.score = bcast(sc, own_lane); out.best = bcast(best, own_lane); out.end = bcast(end, own_lane);
+	if (!sat) { const uint32_t own_lane = (nb - 1) & 63; out.score = bcast(st.sc, own_lane); out.best = bcast(st.best, own_lane); out.end = bcast(st.end, own_lane); }
 	pool.release(mk);
 	return out;
 }
@@ -150,6 +215,12 @@ __device__ inline void wave_walk(WavePool& pool, const Hist& h, const uint8_t* q
 	const uint32_t lane = lane_id();
 	const uint32_t m = h.m;
 	uint32_t i = n, j = j_start; uint64_t k = 0;
+	if (n > h.rows)
+	{	// rows the sweep left out (sat_rows): vertical delta +1 in every column, the walk goes straight up through them
+		const uint32_t run = n - h.rows;
+		for (uint32_t x = lane; x < run; x += 64) rev[x] = 1;
+		i = h.rows; k = run;
+	}
 	// window: lanes hold (P, H) of block wb for columns wj0 - lane (1-based column wj0 at lane 0, descending)
 	uint32_t wb = 0xffffffffu, wj0 = 0; uint64_t wP = 0, wH = 0; uint32_t wt = 0;
 	uint32_t wi0 = 0, wq = 0;                                                // lanes hold q[wi0 - 1 - lane]
@@ -304,13 +375,14 @@ __device__ inline bool wave_direct_fits(uint32_t n, uint32_t m)
 __device__ inline Sweep wave_align_direct(WavePool& pool, const uint8_t* q, uint32_t n, const uint8_t* t, uint32_t m, bool shw, Ops& out)
 {
 	const uint64_t mk = pool.mark();
-	const uint32_t nb = (n + 63) / 64;
+	const uint32_t ne = sat_rows(q, 1, n, t, 1, m);
+	const uint32_t nb = (ne + 63) / 64;
 	const uint64_t hw = hist_words(nb, m);
-	Hist h{ (uint64_t*)pool.alloc(hw * 8), (uint64_t*)pool.alloc(hw * 8), nb < 64 ? nb : 64, m };
+	Hist h{ (uint64_t*)pool.alloc(hw * 8), (uint64_t*)pool.alloc(hw * 8), nb < 64 ? nb : 64, m, ne };
 	uint8_t* rev = (uint8_t*)pool.alloc((uint64_t)n + m + 64);
 	Sweep sw{ n, 0xffffffffu, (int32_t)m - 1 };
 	if (pool.overflow) { pool.release(mk); return sw; }
-	sw = wave_sweep(pool, q, 1, n, t, 1, m, shw, &h, nullptr);
+	sw = wave_sweep(pool, q, 1, n, ne, t, 1, m, shw, &h, nullptr);
 	if (pool.overflow) { pool.release(mk); return sw; }
 	__builtin_amdgcn_s_waitcnt(0);
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -320,6 +392,44 @@ __device__ inline Sweep wave_align_direct(WavePool& pool, const uint8_t* q, uint
 }
 // traceback of q[0..n) x t[0..m) (forward byte sequences) on a fresh history; appends n..n+m ops
 __device__ inline void wave_traceback(WavePool& pool, const uint8_t* q, uint32_t n, const uint8_t* t, uint32_t m, Ops& out) { wave_align_direct(pool, q, n, t, m, false, out); }
+
+// Hirschberg's split row (edlib.cpp:1317-1356): the smallest i in 1..n-1 with left[i] + right[n - i] == best, else the empty
+// prefix (0), else the whole query (n); -1: none.  left / right: the last columns of the two half sweeps, neL + 1 and neR + 1
+// values; rows the sweeps left out (sat_rows) are closed form — left[i] = i - L, right[x] = x - R — and where both are, the sum
+// is n - m for every i.  ls, rs: the two scores at the split.
+__device__ inline int64_t hirschberg_split(const int32_t* left, uint32_t neL, uint32_t L, const int32_t* right, uint32_t neR, uint32_t R, uint32_t n, uint32_t best, uint32_t& ls, uint32_t& rs)
+{
+	const uint32_t lane = lane_id();
+	auto Lv = [&](uint32_t i) -> uint32_t { return i <= neL ? (uint32_t)left[i] : i - L; };
+	auto Rv = [&](uint32_t x) -> uint32_t { return x <= neR ? (uint32_t)right[x] : x - R; };
+	int64_t found = -1;
+	auto scan = [&](uint32_t a, uint32_t b) {                                        // i in [a, b], ascending
+		for (uint32_t base = a; base <= b && found < 0; base += 256)
+		{	// four 64-row steps per round trip (the eight loads are independent)
+			bool hit[4];
+#pragma unroll
+			for (uint32_t u = 0; u < 4; ++u) { const uint32_t i = base + u * 64 + lane; hit[u] = i <= b && Lv(i) + Rv(n - i) == best; }
+#pragma unroll
+			for (uint32_t u = 0; u < 4; ++u)
+			{
+				const uint64_t bal = __ballot(hit[u]);
+				if (bal && found < 0) { const uint32_t f = (uint32_t)__builtin_ctzll(bal); found = base + u * 64 + f; }
+			}
+		}
+	};
+	if (n >= 2)
+	{
+		const uint32_t z1 = neL < n - 1 ? neL : n - 1;                               // left explicit up to here
+		scan(1, z1);
+		const uint32_t z3 = (n > neR && n - neR > z1 + 1) ? n - neR : z1 + 1;        // right explicit from here
+		if (found < 0 && z3 > z1 + 1 && n - (L + R) == best) found = z1 + 1;         // both closed form in (z1, z3)
+		if (found < 0 && z3 <= n - 1) scan(z3, n - 1);
+	}
+	if (found >= 0) { ls = bcast_first(Lv((uint32_t)found)); rs = bcast_first(Rv(n - (uint32_t)found)); }
+	if (found < 0 && L + bcast_first(Rv(n)) == best) { found = 0; ls = L; rs = bcast_first(Rv(n)); }
+	if (found < 0 && bcast_first(Lv(n)) + R == best) { found = n; ls = bcast_first(Lv(n)); rs = R; }
+	return found;
+}
 
 // obtainAlignment (edlib.cpp:1164-1215): optimal path of q (rows) against t (columns) given the optimal score
 __device__ inline void wave_path(WavePool& pool, const uint8_t* q, uint32_t n, const uint8_t* t, uint32_t m, uint32_t best, Ops& out)
@@ -349,31 +459,17 @@ __device__ inline void wave_path(WavePool& pool, const uint8_t* q, uint32_t n, c
 		if (wave_direct_fits(jb.n, jb.m)) { wave_traceback(pool, q + jb.qo, jb.n, t + jb.to, jb.m, out); continue; }
 		const uint32_t L = jb.m / 2, R = jb.m - L;
 		const uint64_t mk = pool.mark();
-		int32_t* left = (int32_t*)pool.alloc(((uint64_t)jb.n + 1) * 4);
-		int32_t* right = (int32_t*)pool.alloc(((uint64_t)jb.n + 1) * 4);
+		const uint32_t neL = sat_rows(q + jb.qo, 1, jb.n, t + jb.to, 1, L), neR = sat_rows(q + jb.qo + jb.n - 1, -1, jb.n, t + jb.to + jb.m - 1, -1, R);
+		int32_t* left = (int32_t*)pool.alloc(((uint64_t)neL + 1) * 4);
+		int32_t* right = (int32_t*)pool.alloc(((uint64_t)neR + 1) * 4);
 		if (pool.overflow) break;
-		wave_sweep(pool, q + jb.qo, 1, jb.n, t + jb.to, 1, L, false, nullptr, left);
-		wave_sweep(pool, q + jb.qo + jb.n - 1, -1, jb.n, t + jb.to + jb.m - 1, -1, R, false, nullptr, right);
+		wave_sweep(pool, q + jb.qo, 1, jb.n, neL, t + jb.to, 1, L, false, nullptr, left);
+		wave_sweep(pool, q + jb.qo + jb.n - 1, -1, jb.n, neR, t + jb.to + jb.m - 1, -1, R, false, nullptr, right);
 		if (pool.overflow) break;
 		__builtin_amdgcn_s_waitcnt(0);
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-		// smallest i in 1..n-1 with left[i] + right[n - i] == best, else the empty prefix, else the whole query
-		int64_t found = -1; uint32_t ls = 0, rs = 0;
-		for (uint32_t base = 1; base + 1 <= jb.n && found < 0; base += 256)
-		{	// four 64-row steps per round trip (the eight loads are independent)
-			bool hit[4];
-#pragma unroll
-			for (uint32_t u = 0; u < 4; ++u) { const uint32_t i = base + u * 64 + lane; hit[u] = i + 1 <= jb.n && (uint32_t)(left[i] + right[jb.n - i]) == jb.best; }
-#pragma unroll
-			for (uint32_t u = 0; u < 4; ++u)
-			{
-				const uint64_t bal = __ballot(hit[u]);
-				if (bal && found < 0) { const uint32_t f = (uint32_t)__builtin_ctzll(bal); found = base + u * 64 + f; }
-			}
-		}
-		if (found >= 0) { ls = bcast_first((uint32_t)left[found]); rs = bcast_first((uint32_t)right[jb.n - (uint32_t)found]); }
-		if (found < 0 && L + (uint32_t)bcast_first((uint32_t)right[jb.n]) == jb.best) { found = 0; ls = L; rs = bcast_first((uint32_t)right[jb.n]); }
-		if (found < 0 && (uint32_t)bcast_first((uint32_t)left[jb.n]) + R == jb.best) { found = jb.n; ls = bcast_first((uint32_t)left[jb.n]); rs = R; }
+		uint32_t ls = 0, rs = 0;
+		const int64_t found = hirschberg_split(left, neL, L, right, neR, R, jb.n, jb.best, ls, rs);
 		pool.release(mk);
 		if (found < 0 || sp + 2 > 128) { pool.overflow = true; break; }
 		if (lane == 0)

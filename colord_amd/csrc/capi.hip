@@ -31,6 +31,7 @@ extern "C" void cl_ctx_destroy(cl_ctx* c)
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	if (c->side) (void)hipStreamDestroy(c->side);
 	if (c->side2) (void)hipStreamDestroy(c->side2);
+	if (c->side3) (void)hipStreamDestroy(c->side3);
 	if (c->inv_tab) (void)hipFree(c->inv_tab);
 	c->pool.trim();
 	delete c;

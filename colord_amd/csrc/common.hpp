@@ -160,6 +160,7 @@ struct cl_ctx {
 	hipStream_t stream = nullptr;
 	hipStream_t side = nullptr;                  // second stream for chains that would leave the machine idle (created on first use)
 	hipStream_t side2 = nullptr;                 // third stream: the four-per-wave aligner next to the tail-bound wave-per-gap one
+	hipStream_t side3 = nullptr;                 // fourth stream: the work-group-per-gap aligner of the giant gaps
 	std::string err;
 	bool timing = false;
 	std::map<std::string, KernelTime> times;     // per-kernel accumulated HIP-event time of the last API call

@@ -10,6 +10,7 @@
 #include "objects.hpp"
 #include "encode_core.hpp"
 #include "align_wave.hpp"
+#include "align_team.hpp"
 #include <algorithm>
 #include <memory>
 #include <vector>
@@ -219,7 +220,7 @@ __device__ inline bool align_wave_gap(wv::WavePool& pool, GapRec& g, const Arena
 		}
 		else
 		{
-			const wv::Sweep sw = wv::wave_sweep(pool, Q, 1, n, T, 1, m, false, nullptr, nullptr);
+			const wv::Sweep sw = wv::wave_sweep(pool, Q, 1, n, wv::sat_rows(Q, 1, n, T, 1, m), T, 1, m, false, nullptr, nullptr);
 			if (pool.overflow) return false;
 			pool.lap(2);
 			if (dbg_stage == 2) return true;
@@ -237,7 +238,7 @@ __device__ inline bool align_wave_gap(wv::WavePool& pool, GapRec& g, const Arena
 		}
 		else
 		{
-			const wv::Sweep sw = wv::wave_sweep(pool, Q, 1, n, T, 1, g.use, true, nullptr, nullptr);
+			const wv::Sweep sw = wv::wave_sweep(pool, Q, 1, n, wv::sat_rows(Q, 1, n, T, 1, g.use), T, 1, g.use, true, nullptr, nullptr);
 			if (pool.overflow) return false;
 			ref_end = (uint32_t)sw.end; m = (uint32_t)(sw.end + 1);
 			pool.lap(2);
@@ -327,7 +328,58 @@ __device__ inline bool wave_gap_finish(wv::WavePool& pool, GapRec& g, const Wave
 	__builtin_amdgcn_s_waitcnt(0);
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 #endif
-	if (!wv::wave_refactor(pool, dst, k, rf, ebuf)) return false;
+	// A flank whose read side is much longer than what is left of the reference read ends (right flank) or starts (left flank:
+	// the script of the reversed sequences is written reversed) in ONE run of inserted letters as long as the excess — the rows
+	// the sweeps leave out (wv::sat_rows).  Both passes are the identity on such a run: pass 1 breaks at every insertion, and a
+	// pass-2 region without a match is rewritten as itself.  A pass-2 region may reach into the run as far as the run's first
+	// (last) letter repeats, so the passes look at the rest of the script plus that stretch — not at 10^5 letters.
+	uint32_t ra = 0, rb = k;
+	if (k >= 256)
+	{
+		auto is_ins = [](char c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; };
+		uint32_t b0 = k;                                                        // start of the maximal suffix of inserted letters
+		while (b0 > 0)
+		{
+			const uint32_t lo = b0 >= 64 ? b0 - 64 : 0, x = lo + lane;
+			const uint64_t non = __ballot(x < b0 && !is_ins(dst[x]));
+			if (non) { b0 = lo + (63 - (uint32_t)__builtin_clzll(non)) + 1; break; }
+			b0 = lo;
+		}
+		if (b0 < k)
+		{	// ... plus the stretch over which its first letter repeats
+			const char c0 = dst[b0];
+			rb = k;
+			for (uint32_t x0 = b0; x0 < k; x0 += 64)
+			{
+				const uint32_t x = x0 + lane;
+				const uint64_t dif = __ballot(x < k && dst[x] != c0);
+				if (dif) { rb = x0 + (uint32_t)__builtin_ctzll(dif); break; }
+			}
+		}
+		uint32_t a0 = 0;                                                        // length of the maximal prefix of inserted letters
+		for (; a0 < rb; )
+		{
+			const uint32_t x = a0 + lane;
+			const uint64_t non = __ballot(x < rb && !is_ins(dst[x]));
+			if (non) { a0 += (uint32_t)__builtin_ctzll(non); break; }
+			a0 = a0 + 64 < rb ? a0 + 64 : rb;
+		}
+		if (a0 >= rb) ra = rb;                                                  // nothing but insertions: both passes are the identity
+		else if (a0 > 0)
+		{	// ... minus the stretch over which its last letter repeats
+			const char c1 = dst[a0 - 1];
+			ra = 0;
+			for (uint32_t hi = a0; hi > 0; )
+			{
+				const uint32_t lo = hi >= 64 ? hi - 64 : 0, x = lo + lane;
+				const uint64_t dif = __ballot(x < hi && dst[x] != c1);
+				if (dif) { ra = lo + (63 - (uint32_t)__builtin_clzll(dif)) + 1; break; }
+				hi = lo;
+			}
+		}
+	}
+	// (the skipped prefix consumes no reference symbol and `ra` read symbols)
+	if (rb > ra && !wv::wave_refactor(pool, dst + ra, rb - ra, rf, ebuf + ra)) return false;
 #ifdef CL_DEBUG_REFACTOR
 	if (lane == 0)
 	{
@@ -384,6 +436,95 @@ __global__ __launch_bounds__(64) void k_align_wave(const uint32_t* __restrict__ 
 	pool.beat(9);
 }
 
+// giant gaps: one WORK-GROUP per gap (align_team.hpp): the tiles of a sweep as a pipeline over the waves, the sub-problems of a
+// Hirschberg level side by side.  Same steps as align_wave_gap; what fails here (pool, more than 64 tiles) goes to `redo`.
+__device__ inline bool align_team_gap(wt::Team& T, GapRec& g, const ArenaV& A, const ArenaV& R, char* dst)
+{
+	const uint32_t lane = threadIdx.x & 63, tid = threadIdx.x;
+	g.es_len = 0; g.d_before = 0;
+	WaveGap W;
+	wv::WavePool& pool = T.shared;
+	const uint32_t ref_id = g.ref_rev & 0x7fffffffu; const bool rev = g.ref_rev >> 31;
+	const uint64_t rwb = R.word_off[ref_id], ewb = A.word_off[g.read]; const uint32_t rlen = R.lens[ref_id];
+	const bool left = g.left != 0;
+	W.left = left;
+	W.rbuf = (uint8_t*)pool.alloc(g.use + 64ull); W.ebuf = (uint8_t*)pool.alloc(g.ne + 64ull);
+	W.r2 = (uint8_t*)pool.alloc(g.use + 64ull); W.e2 = (uint8_t*)pool.alloc(g.ne + 64ull);
+	W.opsbuf = (uint8_t*)pool.alloc((uint64_t)g.use + g.ne + 64);
+	uint8_t* sparse = (uint8_t*)pool.alloc((uint64_t)g.use + g.ne + 64);
+	if (pool.overflow) return false;
+	const uint32_t lo = left ? g.nr - g.use : 0;
+	for (uint32_t i = tid; i < g.use; i += 64 * wt::TW) { const uint8_t v = (uint8_t)ref_sym(R, rwb, rlen, rev, g.cur_ref + lo + i); W.rbuf[i] = v; W.r2[left ? g.use - 1 - i : i] = v; }
+	for (uint32_t i = tid; i < g.ne; i += 64 * wt::TW) { const uint8_t v = (uint8_t)arena_base_at(A, ewb, g.enc_start + i); W.ebuf[i] = v; W.e2[left ? g.ne - 1 - i : i] = v; }
+	if (g.kind == GK_INNER) { W.Q = W.rbuf; W.n = g.nr; W.T = W.ebuf; W.m = g.ne; W.rows_ref = true; W.shw = false; }
+	else if (g.kind == GK_FLANK_TINY) { W.Q = W.r2; W.n = g.use; W.T = W.e2; W.m = g.ne; W.rows_ref = true; W.shw = false; }
+	else { W.Q = W.e2; W.n = g.ne; W.T = W.r2; W.m = g.use; W.rows_ref = false; W.shw = true; }
+	T.barrier();
+	// score (and, for a flank, where the alignment ends in the reference) by the whole team
+	const uint32_t n = W.n, mc = W.m;
+	const uint32_t ne = wv::sat_rows(W.Q, 1, n, W.T, 1, mc);
+	uint32_t score = n - mc, best = n - mc; int32_t end = (int32_t)mc - 1;
+	if (ne == n)
+	{
+		const uint32_t tiles = ((ne + 63) / 64 + 63) / 64;
+		const uint64_t mk = pool.mark();
+		int8_t* hb = (int8_t*)pool.alloc((uint64_t)tiles * (mc + 64));
+		if (pool.overflow || tiles > wt::MAX_TILES) return false;
+		for (uint32_t x = tid; x < 2 * wt::MAX_TILES; x += 64 * wt::TW) T.lds->prog[x] = 0;
+		T.barrier();
+		wt::team_sweep(T, 0, wt::TW, W.Q, 1, n, ne, W.T, 1, mc, W.shw, nullptr, nullptr, hb, T.lds->prog, true);
+		T.barrier();
+		score = T.lds->res[0]; best = T.lds->res[1]; end = (int32_t)T.lds->res[2];
+		T.barrier();
+		pool.release(mk);
+	}
+	wv::Ops ops{ W.opsbuf, 0 };
+	uint32_t ref_end = 0;
+	bool ok;
+	if (!W.shw) { if (g.kind == GK_FLANK_TINY) ref_end = g.use - 1; ok = wt::team_path(T, W.Q, n, W.T, mc, score, sparse, ops); }
+	else { ref_end = (uint32_t)end; ok = wt::team_path(T, W.Q, n, W.T, (uint32_t)(end + 1), best, sparse, ops); }
+	if (!ok) return false;
+	if (T.w == 0)
+	{
+		T.own.top = 0; T.own.overflow = false;
+		const bool fin = wave_gap_finish(T.own, g, W, ops, ref_end, dst, 0);
+		if (lane == 0) T.lds->fail = fin ? 0u : 5u;
+	}
+	T.barrier();
+	const bool done = T.lds->fail == 0;
+	T.barrier();
+	return done;
+}
+__global__ __launch_bounds__(64 * wt::TW) void k_align_team(const uint32_t* __restrict__ list, uint32_t n_list, GapRec* __restrict__ gaps, char* __restrict__ es_pool, ArenaV A, ArenaV R,
+                                                           uint8_t* __restrict__ scratch, uint64_t per_team, uint64_t own_bytes, unsigned int* __restrict__ next, uint32_t* __restrict__ redo, unsigned int* __restrict__ n_redo)
+{
+	__builtin_amdgcn_s_setprio(3);
+	__shared__ wt::TeamLds lds;
+	wt::Team T;
+	T.w = threadIdx.x >> 6; T.lds = &lds;
+	uint8_t* base = scratch + (uint64_t)blockIdx.x * per_team;
+	T.own = wv::WavePool{ base + (uint64_t)T.w * own_bytes, own_bytes, 0, false, nullptr };
+	T.shared = wv::WavePool{ base + (uint64_t)wt::TW * own_bytes, per_team - (uint64_t)wt::TW * own_bytes, 0, false, nullptr };
+	for (;;)
+	{
+		if (threadIdx.x == 0) lds.gap = atomicAdd(next, 1u);
+		__syncthreads();
+		const uint32_t slot = lds.gap;
+		__syncthreads();
+		if (slot >= n_list) break;
+		const uint32_t gi = list[n_list - 1 - slot];                            // ascending by work: largest first
+		T.shared.top = 0; T.shared.overflow = false; T.own.top = 0; T.own.overflow = false;
+		GapRec g = gaps[gi];
+		const bool ok = align_team_gap(T, g, A, R, es_pool + g.es_off);
+		if (threadIdx.x == 0)
+		{
+			if (ok) { gaps[gi].es_len = g.es_len; gaps[gi].d_before = g.d_before; }
+			else redo[atomicAdd(n_redo, 1u)] = gi;
+		}
+		__syncthreads();
+	}
+}
+
 // gaps of up to 16 row blocks whose history fits a wave's pool: FOUR per wave (wv::quad_sweep), largest first; what does not
 // fit a wave's pool goes to `redo` (k_align_wave takes it)
 __global__ __launch_bounds__(64) void k_align_quad(const uint32_t* __restrict__ list, uint32_t n_list, GapRec* __restrict__ gaps, char* __restrict__ es_pool, ArenaV A, ArenaV R,
@@ -430,7 +571,7 @@ __global__ __launch_bounds__(64) void k_align_quad(const uint32_t* __restrict__ 
 			{
 				const int32_t end = wv::bcast(sw.end, 16u * j);
 				wv::Ops ops{ W[j].opsbuf, 0 };
-				const wv::Hist h{ P[j], H[j], (W[j].n + 63) / 64, W[j].m };
+				const wv::Hist h{ P[j], H[j], (W[j].n + 63) / 64, W[j].m, W[j].n };
 				wv::wave_walk(pool, h, W[j].Q, W[j].n, W[j].T, W[j].shw ? (uint32_t)(end + 1) : W[j].m, rev[j], ops);
 				const uint32_t ref_end = W[j].shw ? (uint32_t)end : g[j].kind == GK_FLANK_TINY ? g[j].use - 1 : 0u;
 				const uint64_t mk = pool.mark();
@@ -865,6 +1006,27 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 			ctx->stream = main_stream;
 			HIP_TRY(ctx, hipGetLastError());
 		}
+		// giant gaps: a work-group each, on a stream of their own, started before the wave-per-gap kernel (they are its former tail)
+		DevBuf<uint32_t> team_redo; uint32_t n_team_redo = 0;
+		DevBuf<uint8_t> team_scratch; DevBuf<unsigned int> tc;
+		Side2Join team_join;
+		if (hb[8] > hb[7] && !getenv("COLORD_HIP_NO_TEAM_ALIGN"))
+		{
+			const uint32_t n_list = hb[8] - hb[7];
+			const uint64_t own_bytes = 3ull << 20, per_team = wt::TW * own_bytes + (40ull << 20);
+			const uint32_t teams = std::min<uint32_t>(n_list, 64);
+			DEV_ALLOC(ctx, team_scratch, per_team * teams);
+			DEV_ALLOC(ctx, tc, 2);
+			DEV_ALLOC(ctx, team_redo, (uint64_t)n_list + 1);
+			if (!ctx->side3) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side3, hipStreamNonBlocking));
+			team_join.s = ctx->side3;
+			HIP_TRY(ctx, hipMemsetAsync(tc.p, 0, 8, ctx->side3));
+			hipStream_t main_stream = ctx->stream;
+			ctx->stream = ctx->side3;
+			LAUNCHB(ctx, 1.25 * (double)h_cb[7], k_align_team, teams, 64 * wt::TW, (const uint32_t*)ids.p + hb[7], n_list, L.gaps.p, L.es.p, A, R, team_scratch.p, per_team, own_bytes, tc.p, team_redo.p, tc.p + 1);
+			ctx->stream = main_stream;
+			HIP_TRY(ctx, hipGetLastError());
+		}
 		// large gaps, in rounds of growing lane pools
 		auto run_large = [&](const uint32_t* list, uint32_t n_list, double alg_bytes) -> cl_status
 		{
@@ -953,6 +1115,17 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 			n_quad_redo = hc[1];
 		}
 		if (n_quad_redo) CL_TRY(run_large(quad_redo.p, n_quad_redo, 0.0));
+		if (team_join.s)
+		{
+			unsigned int hc[2];
+			HIP_TRY(ctx, hipMemcpyAsync(hc, tc.p, 8, hipMemcpyDeviceToHost, ctx->side3));
+			HIP_TRY(ctx, hipStreamSynchronize(ctx->side3));
+			team_join.s = nullptr;
+			n_team_redo = hc[1];
+			if (getenv("COLORD_HIP_GAP_DEBUG")) fprintf(stderr, "[gaps] level %u: %u giant gaps by teams, %u back to the wave kernel\n", lv, hb[8] - hb[7], n_team_redo);
+		}
+		else if (hb[8] > hb[7]) CL_TRY(run_large(ids.p + hb[7], hb[8] - hb[7], 1.25 * (double)h_cb[7]));   // (COLORD_HIP_NO_TEAM_ALIGN)
+		if (n_team_redo) CL_TRY(run_large(team_redo.p, n_team_redo, 0.0));
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->side));                           // the small gaps are through
 		// statistics / decisions, children
 		DevBuf<uint32_t> sflag, sncand; DEV_ALLOC(ctx, sflag, ng + 1); DEV_ALLOC(ctx, sncand, ng + 1);
