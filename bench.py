@@ -202,7 +202,7 @@ def hot_path_step(ctx, qctx, shard: Shard, prm: dict, with_qual: bool, exchange,
         tot = dict(n_anchors=0, tuple_bytes=0, dna_bytes=0, qual_bytes=0)
         if not os.environ.get("BENCH_NO_LOOKAHEAD"):
             for ch in shard.chunks:                          # every chunk is resident: announce them all, the lanes keep lanes + 1 ahead
-                cmp_.prepare(ch[0], ch[2])
+                cmp_.prepare(ch[0], ch[2], ch[2] if ref_cut else ch[1], ch[3] if with_qual else None, ch[4])
         for arena, parts, est, quals, off in shard.chunks:
             _, _, _, _, inf = cmp_.encode(arena, est if ref_cut else parts, est, quals, off, dna_out[do:], qual_out[qo:] if with_qual else None)
             do += inf["dna_bytes"]; qo += inf["qual_bytes"]

@@ -139,6 +139,7 @@ _SIG = {
     "cl_genome_decode": (C.c_int32, [_P, C.c_uint64, C.c_uint32, _P, C.c_uint64, _P, C.POINTER(C.c_uint64)]),
     "cl_genome_md5": (C.c_int32, [_P, _P, C.c_uint32, _P]),
     "cl_compressor_prepare": (C.c_int32, [_P, _P, _P, C.c_uint32]),
+    "cl_compressor_prepare_parts": (C.c_int32, [_P, _P, _P, C.c_uint32, _P, C.c_uint32, _P, _P]),
     "cl_compressor_info": (C.c_int32, [_P, C.POINTER(KmerStats), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "cl_dna_decoder_create": (C.c_int32, [C.c_uint32, C.c_int32, C.c_uint32, C.c_uint32, C.c_int32, C.c_uint32, C.c_double, C.POINTER(_P)]),
     "cl_dna_decoder_free": (None, [_P]),

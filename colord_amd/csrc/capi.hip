@@ -25,6 +25,8 @@ extern "C" void cl_ctx_destroy(cl_ctx* c)
 	if (!c) return;
 	for (cl_ctx* l : c->lanes) cl_ctx_destroy(l);
 	c->lanes.clear();
+	if (c->prep) { cl_ctx_destroy(c->prep); c->prep = nullptr; }
+	if (c->qprep) { cl_ctx_destroy(c->qprep); c->qprep = nullptr; }
 	(void)hipSetDevice(c->device);
 	for (auto& p : c->pending) { (void)hipEventDestroy(p.second.first); (void)hipEventDestroy(p.second.second); }
 	for (auto e : c->ev_pool) (void)hipEventDestroy(e);

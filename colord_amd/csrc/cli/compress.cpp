@@ -399,7 +399,8 @@ int run_compress(int argc, char** argv)
 		std::vector<uint8_t> h_dna, h_qual;
 		// every chunk is resident: announce them, so that candidates / anchors / edit scripts of the next chunks are computed on the
 		// compressor's encode lanes while this thread codes and writes the parts of the chunks before them
-		for (auto& dc : chunks) ck(ctx, cl_compressor_prepare(cmp, dc.reads, dc.packs.data(), (uint32_t)dc.packs.size() - 1), "look-ahead");
+		// (the coder parts are the reader packs: with them the `dna` coder's walks and sort of the next chunk are made ahead too)
+		for (auto& dc : chunks) ck(ctx, cl_compressor_prepare_parts(cmp, dc.reads, dc.packs.data(), (uint32_t)dc.packs.size() - 1, dc.packs.data(), (uint32_t)dc.packs.size() - 1, dc.d_quals, dc.d_off), "look-ahead");
 		for (auto& dc : chunks)
 		{
 			const uint32_t np = (uint32_t)dc.packs.size() - 1;

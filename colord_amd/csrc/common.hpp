@@ -171,6 +171,8 @@ struct cl_ctx {
 	int n_cu = 256;
 	uint64_t* inv_tab = nullptr;                 // floor((2^64-1) / t) for t < 2^21: the interval coder's division table (rc_dev.hpp), made at first use
 	std::vector<cl_ctx*> lanes;                  // encode lanes of cl_compressor (contexts of their own; kept for the next compressor, freed with this context)
+	cl_ctx* prep = nullptr;                      // context of cl_compressor's DNA preparation thread (same life cycle)
+	cl_ctx* qprep = nullptr;                     // ... and of its quality preparation thread
 };
 
 static inline cl_status cl_fail(cl_ctx* c, cl_status s, const std::string& msg)

@@ -889,11 +889,20 @@ __global__ void k_last_types(const uint8_t* __restrict__ flag, uint32_t n, uint3
 // (family, context, symbol) key of every coded symbol.  It depends on the tuple streams, the reference reads and two scalars
 // carried from the batch before (types of its last four reads, its read count) — not on the adaptive models — so it can be
 // done for the NEXT batch while the interval coding of the current one, a dependent chain per part, drains (cl_dna_walk_ahead).
+// ... and, when the part bounds are known ahead as well, the other model-independent half of a group of parts: its place in the
+// interleaved triple layout, the triple slot of every symbol, the stable sort by (family, context) and the context runs.
+struct DnaGroupPrep {
+	uint32_t p0 = 0, p1 = 0, r0 = 0, r1 = 0; uint64_t s0 = 0, n_syms = 0, n_seg = 0, trip_words = 0;
+	std::vector<uint32_t> rank, plen_r;                                           // part -> place (descending length); lengths by place
+	DevBuf<uint64_t> d_gbase; DevBuf<uint32_t> d_plen;
+	DevBuf<uint32_t> sidx, seg;
+};
 struct DnaWalked {
 	const uint8_t* d_es = nullptr; uint32_t n_reads = 0;                       // identity of the batch
 	uint32_t prev_types_in = 0, cur_read_id_in = 0, prev_types_out = 0;
 	DevBuf<uint8_t> rflag; DevBuf<uint32_t> hdr; DevBuf<uint64_t> sym_off, key;
 	std::vector<uint64_t> h_sym_off;
+	bool presorted = false; std::vector<uint32_t> part_bounds; std::vector<std::unique_ptr<DnaGroupPrep>> groups;   // (keys sorted group by group, in place)
 };
 struct cl_dna_coder {
 	cl_ctx* ctx = nullptr;
@@ -1025,6 +1034,100 @@ cl_status dna_walk(cl_ctx* ctx, cl_dna_coder* D, const cl_reads* refs, const uin
 }
 } // namespace
 
+namespace {
+// The model-independent half of a group of parts starting at part p0 (as many parts as the 31-bit symbol indices and the memory
+// for the triples allow): layout, triple slots, stable sort of (key, slot) by (family, context), context runs.
+cl_status dna_group_prepare(cl_ctx* ctx, cl_dna_coder* D, DnaWalked& W, uint32_t p0, const uint32_t* h_part_bounds, uint32_t n_parts, DnaGroupPrep& G)
+{
+	const FamTab& f = D->ft;
+	const std::vector<uint64_t>& h_sym_off = W.h_sym_off;
+	const uint64_t GROUP_SYMS = 5ull << 28;
+	uint32_t p1 = p0; const uint32_t r0 = h_part_bounds[p0];
+	while (p1 < n_parts)
+	{
+		const uint64_t pl = h_sym_off[h_part_bounds[p1 + 1]] - h_sym_off[h_part_bounds[p1]];
+		if (pl >= (1ull << 31) - 64) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_dna_encode: one part has >= 2^31 symbols");
+		if (p1 > p0 && h_sym_off[h_part_bounds[p1 + 1]] - h_sym_off[r0] >= GROUP_SYMS) break;
+		++p1;
+	}
+	const uint32_t r1 = h_part_bounds[p1], nr = r1 - r0, np = p1 - p0, ng = (np + 63) / 64;
+	const uint64_t s0 = h_sym_off[r0], n_syms = h_sym_off[r1] - s0;
+	G.p0 = p0; G.p1 = p1; G.r0 = r0; G.r1 = r1; G.s0 = s0; G.n_syms = n_syms;
+	// part geometry
+	std::vector<uint64_t> sym_start(np + 1);
+	std::vector<uint32_t> plen(np), pfirst(np + 1);
+	for (uint32_t p = 0; p <= np; ++p) { pfirst[p] = h_part_bounds[p0 + p]; sym_start[p] = h_sym_off[pfirst[p]] - s0; }
+	for (uint32_t p = 0; p < np; ++p) plen[p] = (uint32_t)(sym_start[p + 1] - sym_start[p]);
+	// places in the interleaved layout by descending length: the 64 parts of a wave of the interval coder are alike, and no
+	// slots are wasted on the longest part of a group (parts hold whole reads: 65 k to 265 k symbols in one group otherwise)
+	std::vector<uint32_t> order(np); std::vector<uint32_t>& rank = G.rank; std::vector<uint32_t>& plen_r = G.plen_r;
+	rank.resize(np); plen_r.resize(np);
+	for (uint32_t p = 0; p < np; ++p) order[p] = p;
+	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return plen[a] > plen[b]; });
+	for (uint32_t i = 0; i < np; ++i) { rank[order[i]] = i; plen_r[i] = plen[order[i]]; }
+	std::vector<uint64_t> gbase(ng + 1, 0);
+	for (uint32_t g = 0; g < ng; ++g) gbase[g + 1] = gbase[g] + (uint64_t)plen_r[g * 64] * 64;
+	if (gbase[ng] >= (1ull << 32)) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_dna_encode: group too large for 32-bit triple indices");
+	G.trip_words = gbase[ng];
+	DevBuf<uint64_t> d_sym_start; DevBuf<uint32_t> d_pfirst, d_rank;
+	DEV_ALLOC(ctx, d_rank, np);
+	HIP_TRY(ctx, hipMemcpyAsync(d_rank.p, rank.data(), np * 4, hipMemcpyHostToDevice, ctx->stream));
+	DEV_ALLOC(ctx, d_sym_start, np + 1); DEV_ALLOC(ctx, G.d_gbase, ng + 1); DEV_ALLOC(ctx, G.d_plen, np); DEV_ALLOC(ctx, d_pfirst, np + 1);
+	HIP_TRY(ctx, hipMemcpyAsync(d_sym_start.p, sym_start.data(), (np + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(G.d_gbase.p, gbase.data(), (ng + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(G.d_plen.p, plen_r.data(), np * 4, hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(d_pfirst.p, pfirst.data(), (np + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+	TripLayoutDev lay{ d_pfirst.p, d_sym_start.p, G.d_gbase.p, np, d_rank.p };
+	if (n_syms)
+	{
+		uint64_t* const gkey = W.key.p + s0;                                     // this group's keys (written by the walk)
+		DEV_ALLOC(ctx, G.sidx, n_syms);
+		LAUNCHB(ctx, n_syms * 4.0, k_fill_sidx, grid_for(nr, 4), 256, (const uint64_t*)W.sym_off.p, s0, r0, r1, lay, G.sidx.p);
+		HIP_TRY(ctx, hipGetLastError());
+		uint32_t cbits = 1; while ((1ull << cbits) < f.ctx_base[N_FAM]) ++cbits;
+		CL_TRY(dev_sort_pairs(ctx, gkey, G.sidx.p, n_syms, 16, 16 + cbits));
+		DevBuf<uint32_t> hf; DEV_ALLOC(ctx, hf, n_syms);
+		LAUNCH(ctx, k_ctx_heads, grid_for(n_syms, 256), 256, (const uint64_t*)gkey, n_syms, hf.p);
+		CL_TRY(dev_exclusive_scan_u32(ctx, hf.p, n_syms, &G.n_seg));
+		DEV_ALLOC(ctx, G.seg, G.n_seg + 1);
+		LAUNCH(ctx, k_seg_starts, grid_for(n_syms, 256), 256, (const uint32_t*)hf.p, n_syms, G.n_seg, G.seg.p);
+		HIP_TRY(ctx, hipGetLastError());
+	}
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                             // (the uploads above read host vectors of this frame)
+	return CL_OK;
+}
+} // namespace
+
+// Internal (stream.hip): everything of a batch that needs no model state — the walks and, with part bounds, the sorted groups — on
+// ANY context (the compressor runs it on a context and thread of its own beside the coding of the batch before).  The two scalars
+// the walk starts from chain batch to batch: the caller keeps them (cl_dna_coder_state for the first batch).
+cl_status cl_dna_prepare_batch(cl_ctx* ctx, cl_dna_coder* D, const cl_reads* refs, const uint8_t* d_es, const uint64_t* d_es_off, const uint32_t* d_es_ntuples, uint32_t n_reads,
+                               uint32_t prev_types, uint32_t read_id, const uint32_t* h_part_bounds, uint32_t n_parts, DnaWalked** out, uint32_t* prev_types_out)
+{
+	if (!ctx || !D || !refs || !d_es || !d_es_off || !d_es_ntuples || !n_reads || !out) return CL_E_INVALID;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	auto W = std::make_unique<DnaWalked>();
+	CL_TRY(dna_walk(ctx, D, refs, d_es, d_es_off, d_es_ntuples, n_reads, prev_types, read_id, *W));
+	if (h_part_bounds && n_parts && h_part_bounds[0] == 0 && h_part_bounds[n_parts] == n_reads)
+	{
+		W->part_bounds.assign(h_part_bounds, h_part_bounds + n_parts + 1);
+		for (uint32_t p0 = 0; p0 < n_parts; )
+		{
+			auto G = std::make_unique<DnaGroupPrep>();
+			CL_TRY(dna_group_prepare(ctx, D, *W, p0, h_part_bounds, n_parts, *G));
+			p0 = G->p1;
+			W->groups.push_back(std::move(G));
+		}
+		W->presorted = true;
+	}
+	if (prev_types_out) *prev_types_out = W->prev_types_out;
+	*out = W.release();
+	return CL_OK;
+}
+void cl_dna_walked_free(DnaWalked* W) { delete W; }
+void cl_dna_set_ahead(cl_dna_coder* D, DnaWalked* W) { if (D) D->ahead.reset(W); else delete W; }
+void cl_dna_coder_state(const cl_dna_coder* D, uint32_t* prev_types, uint32_t* read_id) { if (prev_types) *prev_types = D->prev_types; if (read_id) *read_id = D->cur_read_id; }
+
 // Internal (stream.hip): the walk of the batch that FOLLOWS the one being coded, from inside cl_dna_encode's before_tail hook.
 cl_status cl_dna_walk_ahead(cl_ctx* ctx, cl_dna_coder* D, const cl_reads* refs, const uint8_t* d_es, const uint64_t* d_es_off, const uint32_t* d_es_ntuples, uint32_t n_reads)
 {
@@ -1059,9 +1162,11 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 	std::unique_ptr<DnaWalked> Wp;
 	if (D->ahead && D->ahead->d_es == d_es && D->ahead->n_reads == n_reads && D->ahead->prev_types_in == D->prev_types && D->ahead->cur_read_id_in == D->cur_read_id) Wp = std::move(D->ahead);
 	D->ahead.reset();
+	// (groups sorted ahead hold for the part bounds they were made for; the keys are sorted in place, so with other bounds the walk is redone)
+	if (Wp && Wp->presorted && (Wp->part_bounds.size() != (size_t)n_parts + 1 || memcmp(Wp->part_bounds.data(), h_part_bounds, ((size_t)n_parts + 1) * 4) != 0)) Wp.reset();
 	if (!Wp) { Wp = std::make_unique<DnaWalked>(); CL_TRY(dna_walk(ctx, D, refs, d_es, d_es_off, d_es_ntuples, n_reads, D->prev_types, D->cur_read_id, *Wp)); }
 	DnaWalked& W = *Wp;
-	DevBuf<uint64_t>& sym_off = W.sym_off; DevBuf<uint64_t>& key = W.key; const std::vector<uint64_t>& h_sym_off = W.h_sym_off;
+	DevBuf<uint64_t>& key = W.key;
 	DevBuf<uint32_t> err; DEV_ALLOC(ctx, err, 1);
 	HIP_TRY(ctx, hipMemsetAsync(err.p, 0, 4, ctx->stream));
 	D->next_prev_types = W.prev_types_out; D->next_read_id = D->cur_read_id + n_reads; D->next_valid = true;
@@ -1084,62 +1189,24 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 		written = w;
 		return CL_OK;
 	};
-	uint32_t p0 = 0;
+	uint32_t p0 = 0; size_t gi = 0;
 	while (p0 < n_parts)
 	{
-		// the group: as many parts as the symbol indices (31 bits) and the memory for the triples (16 bytes a symbol) allow
-		const uint64_t GROUP_SYMS = 5ull << 28;
-		uint32_t p1 = p0; const uint32_t r0 = h_part_bounds[p0];
-		std::vector<uint64_t> gbase(1, 0);
-		while (p1 < n_parts)
-		{
-			const uint64_t pl = h_sym_off[h_part_bounds[p1 + 1]] - h_sym_off[h_part_bounds[p1]];
-			if (pl >= (1ull << 31) - 64) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_dna_encode: one part has >= 2^31 symbols");
-			if (p1 > p0 && h_sym_off[h_part_bounds[p1 + 1]] - h_sym_off[r0] >= GROUP_SYMS) break;
-			++p1;
-		}
-		const uint32_t r1 = h_part_bounds[p1], nr = r1 - r0, np = p1 - p0, ng = (np + 63) / 64;
-		const uint64_t s0 = h_sym_off[r0], n_syms = h_sym_off[r1] - s0;
-		// part geometry
-		std::vector<uint64_t> sym_start(np + 1);
-		std::vector<uint32_t> plen(np), pfirst(np + 1);
-		for (uint32_t p = 0; p <= np; ++p) { pfirst[p] = h_part_bounds[p0 + p]; sym_start[p] = h_sym_off[pfirst[p]] - s0; }
-		for (uint32_t p = 0; p < np; ++p) plen[p] = (uint32_t)(sym_start[p + 1] - sym_start[p]);
-		// places in the interleaved layout by descending length: the 64 parts of a wave of the interval coder are alike, and no
-		// slots are wasted on the longest part of a group (parts hold whole reads: 65 k to 265 k symbols in one group otherwise)
-		std::vector<uint32_t> order(np), rank(np), plen_r(np);
-		for (uint32_t p = 0; p < np; ++p) order[p] = p;
-		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return plen[a] > plen[b]; });
-		for (uint32_t i = 0; i < np; ++i) { rank[order[i]] = i; plen_r[i] = plen[order[i]]; }
-		gbase.assign(ng + 1, 0);
-		for (uint32_t g = 0; g < ng; ++g) gbase[g + 1] = gbase[g] + (uint64_t)plen_r[g * 64] * 64;
-		if (gbase[ng] >= (1ull << 32)) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_dna_encode: group too large for 32-bit triple indices");
+		// the group's model-independent half: made ahead (cl_dna_prepare_batch) or here
+		std::unique_ptr<DnaGroupPrep> GP;
+		if (W.presorted) { if (gi >= W.groups.size() || !W.groups[gi] || W.groups[gi]->p0 != p0) return cl_fail(ctx, CL_E_INVALID, "cl_dna_encode: prepared groups do not match"); GP = std::move(W.groups[gi++]); }
+		else { GP = std::make_unique<DnaGroupPrep>(); CL_TRY(dna_group_prepare(ctx, D, W, p0, h_part_bounds, n_parts, *GP)); }
+		const uint32_t p1 = GP->p1, np = p1 - p0, ng = (np + 63) / 64;
+		const uint64_t s0 = GP->s0, n_syms = GP->n_syms;
+		const std::vector<uint32_t>& rank = GP->rank; const std::vector<uint32_t>& plen_r = GP->plen_r;
 		auto G = std::make_unique<PendingGroup>(); G->p0 = p0; G->np = np; G->rank = rank;
+		G->d_gbase = std::move(GP->d_gbase); G->d_plen = std::move(GP->d_plen);
 		DevBuf<uint64_t>& d_gbase = G->d_gbase; DevBuf<uint32_t>& d_plen = G->d_plen; DevBuf<triple_t>& trip = G->trip;
-		DevBuf<uint64_t> d_sym_start; DevBuf<uint32_t> d_pfirst, d_rank;
-		DEV_ALLOC(ctx, d_rank, np);
-		HIP_TRY(ctx, hipMemcpyAsync(d_rank.p, rank.data(), np * 4, hipMemcpyHostToDevice, ctx->stream));
-		DEV_ALLOC(ctx, d_sym_start, np + 1); DEV_ALLOC(ctx, d_gbase, ng + 1); DEV_ALLOC(ctx, d_plen, np); DEV_ALLOC(ctx, d_pfirst, np + 1);
-		HIP_TRY(ctx, hipMemcpyAsync(d_sym_start.p, sym_start.data(), (np + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-		HIP_TRY(ctx, hipMemcpyAsync(d_gbase.p, gbase.data(), (ng + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-		HIP_TRY(ctx, hipMemcpyAsync(d_plen.p, plen_r.data(), np * 4, hipMemcpyHostToDevice, ctx->stream));
-		HIP_TRY(ctx, hipMemcpyAsync(d_pfirst.p, pfirst.data(), (np + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-		TripLayoutDev lay{ d_pfirst.p, d_sym_start.p, d_gbase.p, np, d_rank.p };
-		DEV_ALLOC(ctx, trip, gbase[ng]);
+		DEV_ALLOC(ctx, trip, GP->trip_words);
 		if (n_syms)
 		{
-			uint64_t* const gkey = key.p + s0;                                       // this group's keys (written by the walk above)
-			DevBuf<uint32_t> sidx; DEV_ALLOC(ctx, sidx, n_syms);
-			LAUNCHB(ctx, n_syms * 4.0, k_fill_sidx, grid_for(nr, 4), 256, (const uint64_t*)sym_off.p, s0, r0, r1, lay, sidx.p);
-			HIP_TRY(ctx, hipGetLastError());
-			uint32_t cbits = 1; while ((1ull << cbits) < f.ctx_base[N_FAM]) ++cbits;
-			CL_TRY(dev_sort_pairs(ctx, gkey, sidx.p, n_syms, 16, 16 + cbits));
-			DevBuf<uint32_t> hf; DEV_ALLOC(ctx, hf, n_syms);
-			LAUNCH(ctx, k_ctx_heads, grid_for(n_syms, 256), 256, (const uint64_t*)gkey, n_syms, hf.p);
-			uint64_t n_seg = 0;
-			CL_TRY(dev_exclusive_scan_u32(ctx, hf.p, n_syms, &n_seg));
-			DevBuf<uint32_t> seg; DEV_ALLOC(ctx, seg, n_seg + 1);
-			LAUNCH(ctx, k_seg_starts, grid_for(n_syms, 256), 256, (const uint32_t*)hf.p, n_syms, n_seg, seg.p);
+			uint64_t* const gkey = key.p + s0;                                       // this group's keys, sorted
+			DevBuf<uint32_t>& sidx = GP->sidx; DevBuf<uint32_t>& seg = GP->seg; const uint64_t n_seg = GP->n_seg;
 			LAUNCHB(ctx, n_syms * 20.0, k_dna_evolve, grid_for(n_seg, 4), 256, (const FamTab*)D->d_ft.p, (const uint64_t*)gkey, (const uint32_t*)sidx.p, (const uint32_t*)seg.p,
 				(uint32_t)n_seg, D->state.p, trip.p);
 			HIP_TRY(ctx, hipGetLastError());

@@ -11,6 +11,7 @@
 #include "encode_core.hpp"
 #include "align_wave.hpp"
 #include "align_team.hpp"
+#include "emit_wave.hpp"
 #include <algorithm>
 #include <memory>
 #include <vector>
@@ -613,12 +614,25 @@ __global__ void k_gap_stats(LevelV L, ArenaV A, EncCfg cfg, const uint32_t* __re
 	spawn_flag[gi] = gap_finish(L, gi, A, cfg, pend_idx[gi]) ? 1u : 0u;
 }
 // run summaries of the scripts for the count pass of the tuple emission: one lane per gap
-__global__ void k_gap_sums(LevelV L, GapSum* __restrict__ sums)
+__global__ void k_gap_sums(LevelV L, GapSum* __restrict__ sums, uint32_t* __restrict__ long_ids, unsigned int* __restrict__ n_long)
 {
 	const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
 	if (gi >= L.n_gaps) return;
 	const uint32_t k = L.gaps[gi].es_len;
 	if (k && k <= SUM_LIMIT) sums[gi] = gap_summary(L.es + L.gaps[gi].es_off, k);
+	else if (k) long_ids[atomicAdd(n_long, 1u)] = gi;                          // (k_gap_sums_long)
+}
+// ... and of the long scripts by a wave each (the wave-per-read emission works from summaries alone; a lane would take a
+// millisecond for the 10^5 symbols of a long flank and hold its launch that long)
+__global__ __launch_bounds__(256) void k_gap_sums_long(LevelV L, GapSum* __restrict__ sums, const uint32_t* __restrict__ long_ids, const unsigned int* __restrict__ n_long)
+{
+	const uint32_t n = *n_long, n_waves = gridDim.x * 4;
+	for (uint32_t idx = blockIdx.x * 4 + (threadIdx.x >> 6); idx < n; idx += n_waves)
+	{
+		const uint32_t gi = long_ids[idx];
+		const RunEl a = run_of_script_wave(L.es + L.gaps[gi].es_off, L.gaps[gi].es_len);
+		if ((threadIdx.x & 63) == 0) sums[gi] = GapSum{ a.hl, a.tl, a.mb, a.mt, a.hs | (a.ts << 8) | (a.single ? 1u << 16 : 0u) };
+	}
 }
 // long gaps: the static entropy test (EncodeWithEditScript, encoder.cpp:1315-1327; CEntropy, utils.h:706-752) by one wave
 __global__ __launch_bounds__(256) void k_gap_stats_long(LevelV L, ArenaV A, EncCfg cfg, const uint32_t* __restrict__ long_list, uint32_t n_long, uint32_t* __restrict__ spawn_flag)
@@ -850,6 +864,20 @@ __global__ __launch_bounds__(64) void k_emit_write(ArenaV A, const uint32_t* __r
 	if (!k->used) return;
 	emit_read<true>(A, inv, has_n, T, k->read, data, nullptr, nullptr, es_off, out, nullptr, 0, EMIT_CHUNK, k);
 }
+// the same two passes by one WAVE per read (emit_wave.hpp): the lanes take 64 fragments of a frame at a time
+__global__ __launch_bounds__(256) void k_emit_count_wave(ArenaV A, TreeV T, uint32_t n_reads, const uint32_t* __restrict__ data, uint32_t* __restrict__ sizes, uint32_t* __restrict__ ntuples)
+{
+	const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (r >= n_reads) return;
+	if (T.frame_of_read[r] == 0xffffffffu) { if ((threadIdx.x & 63) == 0) { sizes[r] = A.lens[r] + 1; ntuples[r] = A.lens[r] + 1; } return; }   // a start tuple and one tuple per base
+	emit_read_wave<false>(A, T, r, data, sizes, ntuples, nullptr, nullptr);
+}
+__global__ __launch_bounds__(256) void k_emit_write_wave(ArenaV A, TreeV T, uint32_t n_reads, const uint32_t* __restrict__ data, const uint64_t* __restrict__ es_off, uint8_t* __restrict__ out)
+{
+	const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (r >= n_reads || T.frame_of_read[r] == 0xffffffffu) return;
+	emit_read_wave<true>(A, T, r, data, nullptr, nullptr, es_off, out);
+}
 __global__ __launch_bounds__(256) void k_emit_plain(ArenaV A, const uint32_t* __restrict__ inv, const uint8_t* __restrict__ has_n, const uint32_t* __restrict__ frame_of_read, uint32_t n_reads,
                                                    const uint64_t* __restrict__ es_off, uint8_t* __restrict__ out)
 {	// AddPlainRead / AddPlainReadWithN (encoder.cpp:663-681): a start tuple, then one tuple per base
@@ -993,7 +1021,7 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 		{
 			const uint32_t n_list = hb[6] - hb[5];
 			const uint64_t per_wave = 9ull << 18;                                 // 2.25 MB: four histories of at most 512 KB + the sequences and scripts of four gaps
-			const uint32_t waves = std::min<uint32_t>((n_list + 3) / 4, 4096);
+			const uint32_t waves = std::min<uint32_t>((n_list + 3) / 4, 2048);      // (4.7 GB; 4096 waves were no faster beside the other streams)
 			DEV_ALLOC(ctx, quad_scratch, per_wave * waves);
 			DEV_ALLOC(ctx, qc, 2);
 			DEV_ALLOC(ctx, quad_redo, (uint64_t)n_list + 1);
@@ -1014,7 +1042,7 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 		{
 			const uint32_t n_list = hb[8] - hb[7];
 			const uint64_t own_bytes = 3ull << 20, per_team = wt::TW * own_bytes + (40ull << 20);
-			const uint32_t teams = std::min<uint32_t>(n_list, 64);
+			const uint32_t teams = std::min<uint32_t>(n_list, 32);
 			DEV_ALLOC(ctx, team_scratch, per_team * teams);
 			DEV_ALLOC(ctx, tc, 2);
 			DEV_ALLOC(ctx, team_redo, (uint64_t)n_list + 1);
@@ -1054,7 +1082,9 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 			}
 			DevBuf<uint32_t> todo, redo; DEV_ALLOC(ctx, todo, (uint64_t)n_list + 1); DEV_ALLOC(ctx, redo, (uint64_t)n_list + 1);
 			DevBuf<unsigned int> cnt; DEV_ALLOC(ctx, cnt, 2);
-			uint64_t per_lane = 6ull << 20; uint32_t max_lanes = 2048;           // waves (k_align_wave) / lanes (k_align_large): a read of 200 kb fits the first round
+			// waves (k_align_wave) / lanes (k_align_large).  3 MB a wave: since the sweeps stop at the saturation row, sequences + operations
+			// + history of nearly every gap fit (a read flank of 200 kb: 1.6 MB); the few others come back in the next round (x 8)
+			uint64_t per_lane = 3ull << 20; uint32_t max_lanes = 2048;
 			const bool use_wave = getenv("COLORD_HIP_NO_WAVE_ALIGN") == nullptr;
 			DevBuf<unsigned long long> prof;
 			if (getenv("COLORD_HIP_WAVE_PROFILE")) { DEV_ALLOC(ctx, prof, 16); HIP_TRY(ctx, hipMemsetAsync(prof.p, 0, 128, st)); }
@@ -1134,7 +1164,10 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 		LAUNCH(ctx, k_gap_stats, grid_for(ng, 64), 64, V, A, cfg, (const uint32_t*)pflag.p, sflag.p, long_list.p);
 		if (n_long) LAUNCH(ctx, k_gap_stats_long, grid_for((uint64_t)n_long * 64, 256), 256, V, A, cfg, (const uint32_t*)long_list.p, n_long, sflag.p);
 		DEV_ALLOC(ctx, L.sums, ng + 1);
-		LAUNCH(ctx, k_gap_sums, grid_for(ng, 64), 64, V, L.sums.p);
+		DevBuf<uint32_t> sum_long; DEV_ALLOC(ctx, sum_long, ng + 2);                // ids of the gaps with long scripts, their number in the last word
+		HIP_TRY(ctx, hipMemsetAsync(sum_long.p + ng + 1, 0, 4, st));
+		LAUNCH(ctx, k_gap_sums, grid_for(ng, 64), 64, V, L.sums.p, sum_long.p, (unsigned int*)(sum_long.p + ng + 1));
+		LAUNCH(ctx, k_gap_sums_long, 1024, 256, V, L.sums.p, (const uint32_t*)sum_long.p, (const unsigned int*)(sum_long.p + ng + 1));
 		LAUNCH(ctx, k_spawn_mark, grid_for(ng, 64), 64, V, AV.data, cfg, sflag.p, sncand.p);      // refuses beyond max_rec: those gaps become literals
 		HIP_TRY(ctx, hipGetLastError());
 		if (lv >= max_rec || lv + 1 >= 10) { HIP_TRY(ctx, hipStreamSynchronize(st)); break; }
@@ -1173,22 +1206,34 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 	LAUNCH(ctx, k_pend_list, grid_for(nr, 64), 64, T, nr, (const uint64_t*)ev_off.p, events.p);
 	if (n_packs) LAUNCH(ctx, k_estimator, n_packs, 64, T, (const uint32_t*)d_pb.p, n_packs, (const uint32_t*)reads->lens.p, has_n, (const uint32_t*)base_counts.p, (const uint64_t*)ev_off.p, (const uint32_t*)events.p);
 	DevBuf<uint32_t> sizes; DEV_ALLOC(ctx, sizes, nr);
-	DevBuf<uint64_t> slot_off; DEV_ALLOC(ctx, slot_off, (uint64_t)nr + 1);
-	uint64_t n_slots = 0;
-	LAUNCH(ctx, k_emit_slots, grid_for(nr, 256), 256, (const uint32_t*)reads->lens.p, (const uint32_t*)frame_of_read.p, nr, sizes.p);
-	CL_TRY(dev_exclusive_scan_u64(ctx, sizes.p, slot_off.p, nr, &n_slots));
-	DevBuf<EmitCk> cks; DEV_ALLOC(ctx, cks, n_slots + 1);
-	HIP_TRY(ctx, hipMemsetAsync(cks.p, 0, (n_slots + 1) * sizeof(EmitCk), st));
-	LAUNCHB(ctx, reads->total_bases * 1.25, k_emit_count, grid_for(nr, EMIT_LPW), 64, /* 2 bits per base + at most one script byte per base in */ A, (const uint32_t*)reads->inv.p, has_n, T, nr, AV.data, (const uint64_t*)slot_off.p, cks.p, sizes.p, d_es_ntuples);
-	HIP_TRY(ctx, hipGetLastError());
 	uint64_t total = 0;
-	CL_TRY(dev_exclusive_scan_u64(ctx, sizes.p, d_es_off, nr, &total));
-	*n_out = total;
-	if (total > cap || (total && !d_es)) return cl_fail(ctx, CL_E_CAPACITY, "cl_encode_reads: need " + std::to_string(total) + " bytes");
-	if (n_slots) LAUNCHB(ctx, reads->total_bases * 1.25 + (double)total, k_emit_write, grid_for(n_slots, EMIT_WPW), 64, /* the same in + the tuple bytes out */ A, (const uint32_t*)reads->inv.p, has_n, T, AV.data, (const EmitCk*)cks.p, n_slots, (const uint64_t*)d_es_off, d_es);
-#ifdef CL_EMIT_DEBUG
-	{ (void)hipDeviceSynchronize(); unsigned long long h[2]; (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(enc::g_emit_dbg), 16); fprintf(stderr, "[emit dbg] bytes written by chunk lanes %llu in %llu chunks; total output %llu\n", h[0], h[1], (unsigned long long)total); }
-#endif
+	if (!getenv("COLORD_HIP_OLD_EMIT"))
+	{	// one wave per read, the lanes over the fragments of a frame (emit_wave.hpp)
+		LAUNCHB(ctx, reads->total_bases * 1.25, k_emit_count_wave, grid_for(nr, 4), 256, A, T, nr, AV.data, sizes.p, d_es_ntuples);
+		HIP_TRY(ctx, hipGetLastError());
+		CL_TRY(dev_exclusive_scan_u64(ctx, sizes.p, d_es_off, nr, &total));
+		*n_out = total;
+		if (total > cap || (total && !d_es)) return cl_fail(ctx, CL_E_CAPACITY, "cl_encode_reads: need " + std::to_string(total) + " bytes");
+		LAUNCHB(ctx, reads->total_bases * 1.25 + (double)total, k_emit_write_wave, grid_for(nr, 4), 256, A, T, nr, AV.data, (const uint64_t*)d_es_off, d_es);
+	}
+	else
+	{
+		DevBuf<uint64_t> slot_off; DEV_ALLOC(ctx, slot_off, (uint64_t)nr + 1);
+		uint64_t n_slots = 0;
+		LAUNCH(ctx, k_emit_slots, grid_for(nr, 256), 256, (const uint32_t*)reads->lens.p, (const uint32_t*)frame_of_read.p, nr, sizes.p);
+		CL_TRY(dev_exclusive_scan_u64(ctx, sizes.p, slot_off.p, nr, &n_slots));
+		DevBuf<EmitCk> cks; DEV_ALLOC(ctx, cks, n_slots + 1);
+		HIP_TRY(ctx, hipMemsetAsync(cks.p, 0, (n_slots + 1) * sizeof(EmitCk), st));
+		LAUNCHB(ctx, reads->total_bases * 1.25, k_emit_count, grid_for(nr, EMIT_LPW), 64, /* 2 bits per base + at most one script byte per base in */ A, (const uint32_t*)reads->inv.p, has_n, T, nr, AV.data, (const uint64_t*)slot_off.p, cks.p, sizes.p, d_es_ntuples);
+		HIP_TRY(ctx, hipGetLastError());
+			CL_TRY(dev_exclusive_scan_u64(ctx, sizes.p, d_es_off, nr, &total));
+		*n_out = total;
+		if (total > cap || (total && !d_es)) return cl_fail(ctx, CL_E_CAPACITY, "cl_encode_reads: need " + std::to_string(total) + " bytes");
+		if (n_slots) LAUNCHB(ctx, reads->total_bases * 1.25 + (double)total, k_emit_write, grid_for(n_slots, EMIT_WPW), 64, /* the same in + the tuple bytes out */ A, (const uint32_t*)reads->inv.p, has_n, T, AV.data, (const EmitCk*)cks.p, n_slots, (const uint64_t*)d_es_off, d_es);
+	#ifdef CL_EMIT_DEBUG
+		{ (void)hipDeviceSynchronize(); unsigned long long h[2]; (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(enc::g_emit_dbg), 16); fprintf(stderr, "[emit dbg] bytes written by chunk lanes %llu in %llu chunks; total output %llu\n", h[0], h[1], (unsigned long long)total); }
+	#endif
+	}
 	LAUNCH(ctx, k_emit_plain, grid_for(nr, 4), 256, A, (const uint32_t*)reads->inv.p, has_n, (const uint32_t*)frame_of_read.p, nr, (const uint64_t*)d_es_off, d_es);
 	HIP_TRY(ctx, hipGetLastError());
 	HIP_TRY(ctx, hipStreamSynchronize(st));

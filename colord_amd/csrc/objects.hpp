@@ -55,3 +55,16 @@ cl_status cl_key_gather(cl_ctx* ctx, const uint64_t* d_kmers, uint64_t n, uint32
 struct cl_dna_coder;
 cl_status cl_dna_walk_ahead(cl_ctx* ctx, cl_dna_coder* D, const cl_reads* refs, const uint8_t* d_es, const uint64_t* d_es_off, const uint32_t* d_es_ntuples, uint32_t n_reads);
 void cl_dna_set_before_tail(cl_dna_coder* D, std::function<cl_status()> fn);
+// the model-independent half of a batch (walks; with part bounds also layout, sort and context runs) on any context — see dna.hip
+struct DnaWalked;
+cl_status cl_dna_prepare_batch(cl_ctx* ctx, cl_dna_coder* D, const cl_reads* refs, const uint8_t* d_es, const uint64_t* d_es_off, const uint32_t* d_es_ntuples, uint32_t n_reads,
+                               uint32_t prev_types, uint32_t read_id, const uint32_t* h_part_bounds, uint32_t n_parts, DnaWalked** out, uint32_t* prev_types_out);
+void cl_dna_walked_free(DnaWalked* W);
+void cl_dna_set_ahead(cl_dna_coder* D, DnaWalked* W);               // takes W: the next cl_dna_encode uses it if it is the batch it was made for
+void cl_dna_coder_state(const cl_dna_coder* D, uint32_t* prev_types, uint32_t* read_id);
+// the same for the quality coder (qual.hip): symbols, sort by context, context runs of a batch, on any context
+struct QualPrepared;
+cl_status cl_qual_prepare_batch(cl_ctx* ctx, cl_qual_coder* Q, const cl_reads* R, const uint8_t* d_quals, const uint64_t* d_qual_off,
+                                const uint8_t* d_flags, const uint32_t* h_part_bounds, uint32_t n_parts, QualPrepared** out);
+void cl_qual_prepared_free(QualPrepared* P);
+void cl_qual_set_ahead(cl_qual_coder* Q, QualPrepared* P);

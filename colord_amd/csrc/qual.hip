@@ -35,6 +35,20 @@ struct QualCfg {
 
 } // namespace
 
+// The model-independent half of cl_qual_encode for a batch of parts: per group of parts the interleaved triple layout, the
+// (context, symbol) key and triple slot of every coded symbol, the stable sort by context and the context runs.  It depends on the
+// input only (qualities, bases, flags), so the compressor makes it ahead, on a context and thread of its own, beside the model
+// evolution and interval coding of the batch before (cl_qual_prepare_batch).
+struct QualGroupPrep {
+	uint32_t p0 = 0, p1 = 0, np = 0, ng = 0; uint64_t n_base = 0, n_syms = 0, n_byte = 0, trip_words = 0;
+	std::vector<uint32_t> rank, plen_r;
+	DevBuf<uint64_t> d_gbase; DevBuf<uint32_t> d_plen;
+	DevBuf<uint32_t> key, sidx, bkey, bsidx, ss, se, bss, bse;
+};
+struct QualPrepared {
+	const cl_reads* R = nullptr; const uint8_t* d_quals = nullptr; std::vector<uint32_t> part_bounds;
+	std::vector<std::unique_ptr<QualGroupPrep>> groups;
+};
 struct cl_qual_coder {
 	cl_ctx* ctx = nullptr;
 	QualCfg cfg;
@@ -42,6 +56,7 @@ struct cl_qual_coder {
 	DevBuf<uint32_t> state;       // per-base family: n_ctx * (n_sym + 1)  (counters..., total)
 	DevBuf<uint32_t> bstate;      // byte family: 896 * 257
 	uint64_t symbols_coded = 0;
+	std::unique_ptr<QualPrepared> ahead;   // the next batch, prepared ahead
 };
 
 namespace {
@@ -398,26 +413,12 @@ __global__ __launch_bounds__(256) void k_qual_check(const uint8_t* __restrict__ 
 	if (__ballot(b) && (threadIdx.x & 63) == 0) atomicOr(bad, 1u);
 }
 } // namespace
-extern "C" cl_status cl_qual_encode(cl_ctx* ctx, cl_qual_coder* Q, const cl_reads* R, const uint8_t* d_quals, const uint64_t* d_qual_off,
-                                    const uint8_t* d_flags, const uint32_t* h_part_bounds, uint32_t n_parts,
-                                    uint8_t* d_out, uint64_t cap, uint64_t* h_part_sizes, uint64_t* n_out)
+namespace {
+cl_status qual_prepare(cl_ctx* ctx, cl_qual_coder* Q, const cl_reads* R, const uint8_t* d_quals, const uint64_t* d_qual_off,
+                       const uint8_t* d_flags, const uint32_t* h_part_bounds, uint32_t n_parts, QualPrepared& P)
 {
-	if (!ctx || !Q || !R || !d_qual_off || !h_part_bounds || !h_part_sizes || !n_out) return cl_fail(ctx, CL_E_INVALID, "cl_qual_encode: null argument");
-	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	const QualCfg& c = Q->cfg;
-	for (uint32_t p = 0; p < n_parts; ++p) if (h_part_bounds[p] > h_part_bounds[p + 1]) return cl_fail(ctx, CL_E_INVALID, "cl_qual_encode: part bounds must ascend");
-	if (n_parts && h_part_bounds[n_parts] > R->n_reads) return cl_fail(ctx, CL_E_INVALID, "cl_qual_encode: part bound beyond the arena");
-	*n_out = 0;
-	if (!n_parts) return CL_OK;
-	if (c.mode == QM_NONE)
-	{	// nothing is coded: every part is the 8 flush bytes of an untouched coder (zeros)
-		if (cap < 8ull * n_parts) { *n_out = 8ull * n_parts; return cl_fail(ctx, CL_E_CAPACITY, "cl_qual_encode: output capacity"); }
-		HIP_TRY(ctx, hipMemsetAsync(d_out, 0, 8ull * n_parts, ctx->stream));
-		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-		for (uint32_t p = 0; p < n_parts; ++p) h_part_sizes[p] = 8;
-		*n_out = 8ull * n_parts;
-		return CL_OK;
-	}
+	P.R = R; P.d_quals = d_quals; P.part_bounds.assign(h_part_bounds, h_part_bounds + n_parts + 1);
 	// host copy of the quality offsets at part boundaries
 	std::vector<uint64_t> qo(n_parts + 1);
 	{
@@ -439,8 +440,6 @@ extern "C" cl_status cl_qual_encode(cl_ctx* ctx, cl_qual_coder* Q, const cl_read
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 		if (h_bad) return cl_fail(ctx, CL_E_INVALID, "cl_qual_encode: quality byte outside '!'..'~'+1 (Phred+33 values 0..95)");
 	}
-	const uint32_t bits_max = c.max_total == (1u << 20) ? 20 : 18;
-	uint64_t written = 0;
 	// process groups of parts so that one group's symbol stream stays below 2^31
 	// One group of parts = one sort + one range-coding launch.  The per-part interval chain is latency bound (its
 	// duration is set by the longest part, not by the number of parts), so groups are made as large as 32-bit
@@ -449,6 +448,7 @@ extern "C" cl_status cl_qual_encode(cl_ctx* ctx, cl_qual_coder* Q, const cl_read
 	uint32_t p0 = 0;
 	while (p0 < n_parts)
 	{
+		auto Gp = std::make_unique<QualGroupPrep>(); QualGroupPrep& G = *Gp;
 		uint32_t p1 = p0 + 1;
 		const bool per_base = !(c.mode == QM_AVERAGE);
 		auto syms_of = [&](uint32_t a, uint32_t b) { return (per_base ? (qo[b] - qo[a]) : 0) + (uint64_t)(h_part_bounds[b] - h_part_bounds[a]) * c.navg; };
@@ -459,6 +459,7 @@ extern "C" cl_status cl_qual_encode(cl_ctx* ctx, cl_qual_coder* Q, const cl_read
 		const uint32_t np = p1 - p0;
 		// interleaved triple layout: groups of 64 parts, padded to the longest part of the group
 		const uint32_t ng = (np + 63) / 64;
+		G.p0 = p0; G.p1 = p1; G.np = np; G.ng = ng; G.n_base = per_base ? n_base : 0; G.n_syms = n_syms; G.n_byte = n_byte;
 		std::vector<uint64_t> sym_start(np + 1), gbase(ng + 1);
 		std::vector<uint32_t> plen(np), pfirst(np + 1);
 		sym_start[0] = 0;
@@ -471,63 +472,125 @@ extern "C" cl_status cl_qual_encode(cl_ctx* ctx, cl_qual_coder* Q, const cl_read
 		pfirst[np] = h_part_bounds[p1];
 		// places in the interleaved layout by descending length (as in cl_dna_encode): the 64 parts of a wave of the interval
 		// coder are alike and no slots are wasted on the longest part of a group
-		std::vector<uint32_t> order(np), rank(np), plen_r(np);
+		std::vector<uint32_t> order(np); std::vector<uint32_t>& rank = G.rank; std::vector<uint32_t>& plen_r = G.plen_r;
+		rank.resize(np); plen_r.resize(np);
 		for (uint32_t p = 0; p < np; ++p) order[p] = p;
 		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return plen[a] > plen[b]; });
 		for (uint32_t i = 0; i < np; ++i) { rank[order[i]] = i; plen_r[i] = plen[order[i]]; }
 		gbase[0] = 0;
 		for (uint32_t g = 0; g < ng; ++g) gbase[g + 1] = gbase[g] + (uint64_t)plen_r[g * 64] * 64;
 		if (gbase[ng] >= (1ull << 32)) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_qual_encode: group too large for 32-bit triple indices");
-		DevBuf<uint64_t> d_sym_start, d_gbase; DevBuf<uint32_t> d_plen, d_pfirst, d_rank;
-		DEV_ALLOC(ctx, d_sym_start, np + 1); DEV_ALLOC(ctx, d_gbase, ng + 1); DEV_ALLOC(ctx, d_plen, np); DEV_ALLOC(ctx, d_pfirst, np + 1); DEV_ALLOC(ctx, d_rank, np);
+		G.trip_words = gbase[ng];
+		DevBuf<uint64_t> d_sym_start; DevBuf<uint32_t> d_pfirst, d_rank;
+		DEV_ALLOC(ctx, d_sym_start, np + 1); DEV_ALLOC(ctx, G.d_gbase, ng + 1); DEV_ALLOC(ctx, G.d_plen, np); DEV_ALLOC(ctx, d_pfirst, np + 1); DEV_ALLOC(ctx, d_rank, np);
 		HIP_TRY(ctx, hipMemcpyAsync(d_rank.p, rank.data(), np * 4, hipMemcpyHostToDevice, ctx->stream));
 		HIP_TRY(ctx, hipMemcpyAsync(d_sym_start.p, sym_start.data(), (np + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-		HIP_TRY(ctx, hipMemcpyAsync(d_gbase.p, gbase.data(), (ng + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-		HIP_TRY(ctx, hipMemcpyAsync(d_plen.p, plen_r.data(), np * 4, hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(ctx, hipMemcpyAsync(G.d_gbase.p, gbase.data(), (ng + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(ctx, hipMemcpyAsync(G.d_plen.p, plen_r.data(), np * 4, hipMemcpyHostToDevice, ctx->stream));
 		HIP_TRY(ctx, hipMemcpyAsync(d_pfirst.p, pfirst.data(), (np + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-		TripLayoutDev lay{ d_pfirst.p, d_sym_start.p, d_gbase.p, np, d_rank.p };
-		DevBuf<triple_t> trip; DEV_ALLOC(ctx, trip, gbase[ng]);
-		const uint64_t* inv_tab = nullptr;
-		CL_TRY(cl_inv_table(ctx, &inv_tab));
+		TripLayoutDev lay{ d_pfirst.p, d_sym_start.p, G.d_gbase.p, np, d_rank.p };
+		DevBuf<uint32_t>& key = G.key; DevBuf<uint32_t>& sidx = G.sidx; DevBuf<uint32_t>& bkey = G.bkey; DevBuf<uint32_t>& bsidx = G.bsidx;
+		DEV_ALLOC(ctx, key, per_base ? n_base : 0); DEV_ALLOC(ctx, sidx, per_base ? n_base : 0);
+		DEV_ALLOC(ctx, bkey, n_byte); DEV_ALLOC(ctx, bsidx, n_byte);
+		if (r1 > r0)
+			LAUNCHB(ctx, n_base * (1.0 + 0.25 + 8.0) + n_byte * 8.0, k_qual_symbols, grid_for(r1 - r0, 4), 256, (const QualCfg*)Q->d_cfg.p, (const uint64_t*)R->packed.p, (const uint64_t*)R->word_off.p,
+				d_quals, d_qual_off, d_flags, r0, r1, qo[p0], lay, key.p, sidx.p, bkey.p, bsidx.p);
+		HIP_TRY(ctx, hipGetLastError());
+		const uint32_t total_ctx_bits = c.ctx_bits + c.base_bits + (c.level > 1 ? 2 : 0);
+		if (per_base && n_base)
 		{
-			DevBuf<uint32_t> key, sidx, bkey, bsidx;
-			DEV_ALLOC(ctx, key, per_base ? n_base : 0); DEV_ALLOC(ctx, sidx, per_base ? n_base : 0);
-			DEV_ALLOC(ctx, bkey, n_byte); DEV_ALLOC(ctx, bsidx, n_byte);
-			if (r1 > r0)
-				LAUNCHB(ctx, n_base * (1.0 + 0.25 + 8.0) + n_byte * 8.0, k_qual_symbols, grid_for(r1 - r0, 4), 256, (const QualCfg*)Q->d_cfg.p, (const uint64_t*)R->packed.p, (const uint64_t*)R->word_off.p,
-					d_quals, d_qual_off, d_flags, r0, r1, qo[p0], lay, key.p, sidx.p, bkey.p, bsidx.p);
+			CL_TRY(dev_sort_keys32_pairs(ctx, key.p, sidx.p, n_base, c.sym_bits, c.sym_bits + total_ctx_bits));
+			DEV_ALLOC(ctx, G.ss, c.n_ctx); DEV_ALLOC(ctx, G.se, c.n_ctx);
+			HIP_TRY(ctx, hipMemsetAsync(G.ss.p, 0, (uint64_t)c.n_ctx * 4, ctx->stream));
+			HIP_TRY(ctx, hipMemsetAsync(G.se.p, 0, (uint64_t)c.n_ctx * 4, ctx->stream));
+			LAUNCH(ctx, k_seg_bounds, grid_for(n_base, 256), 256, (const uint32_t*)key.p, n_base, c.sym_bits, G.ss.p, G.se.p);
 			HIP_TRY(ctx, hipGetLastError());
-			const uint32_t total_ctx_bits = c.ctx_bits + c.base_bits + (c.level > 1 ? 2 : 0);
-			if (per_base && n_base)
+		}
+		if (n_byte)
+		{
+			CL_TRY(dev_sort_keys32_pairs(ctx, bkey.p, bsidx.p, n_byte, 8, 8 + 10));
+			DEV_ALLOC(ctx, G.bss, BYTE_CTX); DEV_ALLOC(ctx, G.bse, BYTE_CTX);
+			HIP_TRY(ctx, hipMemsetAsync(G.bss.p, 0, BYTE_CTX * 4, ctx->stream));
+			HIP_TRY(ctx, hipMemsetAsync(G.bse.p, 0, BYTE_CTX * 4, ctx->stream));
+			LAUNCH(ctx, k_seg_bounds, grid_for(n_byte, 256), 256, (const uint32_t*)bkey.p, n_byte, 8u, G.bss.p, G.bse.p);
+			HIP_TRY(ctx, hipGetLastError());
+		}
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                         // (the uploads above read host vectors of this frame)
+		P.groups.push_back(std::move(Gp));
+		p0 = p1;
+	}
+	return CL_OK;
+}
+} // namespace
+// Internal (stream.hip): the model-independent half of cl_qual_encode for a batch, on any context; cl_qual_set_ahead hands it to
+// the coder, whose next cl_qual_encode uses it if it is the batch (arena, qualities, part bounds) it was made for.
+cl_status cl_qual_prepare_batch(cl_ctx* ctx, cl_qual_coder* Q, const cl_reads* R, const uint8_t* d_quals, const uint64_t* d_qual_off,
+                                const uint8_t* d_flags, const uint32_t* h_part_bounds, uint32_t n_parts, QualPrepared** out)
+{
+	if (!ctx || !Q || !R || !d_qual_off || !h_part_bounds || !n_parts || !out || Q->cfg.mode == QM_NONE) return CL_E_INVALID;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	for (uint32_t p = 0; p < n_parts; ++p) if (h_part_bounds[p] > h_part_bounds[p + 1]) return CL_E_INVALID;
+	if (h_part_bounds[n_parts] > R->n_reads) return CL_E_INVALID;
+	auto P = std::make_unique<QualPrepared>();
+	CL_TRY(qual_prepare(ctx, Q, R, d_quals, d_qual_off, d_flags, h_part_bounds, n_parts, *P));
+	*out = P.release();
+	return CL_OK;
+}
+void cl_qual_prepared_free(QualPrepared* P) { delete P; }
+void cl_qual_set_ahead(cl_qual_coder* Q, QualPrepared* P) { if (Q) Q->ahead.reset(P); else delete P; }
+
+extern "C" cl_status cl_qual_encode(cl_ctx* ctx, cl_qual_coder* Q, const cl_reads* R, const uint8_t* d_quals, const uint64_t* d_qual_off,
+                                    const uint8_t* d_flags, const uint32_t* h_part_bounds, uint32_t n_parts,
+                                    uint8_t* d_out, uint64_t cap, uint64_t* h_part_sizes, uint64_t* n_out)
+{
+	if (!ctx || !Q || !R || !d_qual_off || !h_part_bounds || !h_part_sizes || !n_out) return cl_fail(ctx, CL_E_INVALID, "cl_qual_encode: null argument");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	const QualCfg& c = Q->cfg;
+	for (uint32_t p = 0; p < n_parts; ++p) if (h_part_bounds[p] > h_part_bounds[p + 1]) return cl_fail(ctx, CL_E_INVALID, "cl_qual_encode: part bounds must ascend");
+	if (n_parts && h_part_bounds[n_parts] > R->n_reads) return cl_fail(ctx, CL_E_INVALID, "cl_qual_encode: part bound beyond the arena");
+	*n_out = 0;
+	std::unique_ptr<QualPrepared> Pp = std::move(Q->ahead);
+	if (!n_parts) return CL_OK;
+	if (c.mode == QM_NONE)
+	{	// nothing is coded: every part is the 8 flush bytes of an untouched coder (zeros)
+		if (cap < 8ull * n_parts) { *n_out = 8ull * n_parts; return cl_fail(ctx, CL_E_CAPACITY, "cl_qual_encode: output capacity"); }
+		HIP_TRY(ctx, hipMemsetAsync(d_out, 0, 8ull * n_parts, ctx->stream));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		for (uint32_t p = 0; p < n_parts; ++p) h_part_sizes[p] = 8;
+		*n_out = 8ull * n_parts;
+		return CL_OK;
+	}
+	// the model-independent half: made ahead (cl_qual_prepare_batch) for exactly this batch, or here
+	if (Pp && !(Pp->R == R && Pp->d_quals == d_quals && Pp->part_bounds.size() == (size_t)n_parts + 1 && memcmp(Pp->part_bounds.data(), h_part_bounds, ((size_t)n_parts + 1) * 4) == 0)) Pp.reset();
+	if (!Pp) { Pp = std::make_unique<QualPrepared>(); CL_TRY(qual_prepare(ctx, Q, R, d_quals, d_qual_off, d_flags, h_part_bounds, n_parts, *Pp)); }
+	const uint32_t bits_max = c.max_total == (1u << 20) ? 20 : 18;
+	uint64_t written = 0;
+	const uint64_t* inv_tab = nullptr;
+	CL_TRY(cl_inv_table(ctx, &inv_tab));
+	for (auto& Gp : Pp->groups)
+	{
+		QualGroupPrep& G = *Gp;
+		const uint32_t p0 = G.p0, np = G.np, ng = G.ng;
+		const uint64_t n_base = G.n_base, n_syms = G.n_syms, n_byte = G.n_byte;
+		const std::vector<uint32_t>& rank = G.rank; const std::vector<uint32_t>& plen_r = G.plen_r;
+		DevBuf<triple_t> trip; DEV_ALLOC(ctx, trip, G.trip_words);
+		if (n_base)
+		{
+			const uint32_t g = grid_for(c.n_ctx, 4);
+			switch (c.n_sym)
 			{
-				CL_TRY(dev_sort_keys32_pairs(ctx, key.p, sidx.p, n_base, c.sym_bits, c.sym_bits + total_ctx_bits));
-				DevBuf<uint32_t> ss, se; DEV_ALLOC(ctx, ss, c.n_ctx); DEV_ALLOC(ctx, se, c.n_ctx);
-				HIP_TRY(ctx, hipMemsetAsync(ss.p, 0, (uint64_t)c.n_ctx * 4, ctx->stream));
-				HIP_TRY(ctx, hipMemsetAsync(se.p, 0, (uint64_t)c.n_ctx * 4, ctx->stream));
-				LAUNCH(ctx, k_seg_bounds, grid_for(n_base, 256), 256, (const uint32_t*)key.p, n_base, c.sym_bits, ss.p, se.p);
-				const uint32_t g = grid_for(c.n_ctx, 4);
-				switch (c.n_sym)
-				{
-				case 2: LAUNCHB(ctx, n_base * 16.0, (k_evolve_small<2>), g, 256, (const uint32_t*)key.p, (const uint32_t*)sidx.p, (const uint32_t*)ss.p, (const uint32_t*)se.p, c.n_ctx, c.sym_bits, c.max_total, c.adder, Q->state.p, trip.p); break;
-				case 4: LAUNCHB(ctx, n_base * 16.0, (k_evolve_small<4>), g, 256, (const uint32_t*)key.p, (const uint32_t*)sidx.p, (const uint32_t*)ss.p, (const uint32_t*)se.p, c.n_ctx, c.sym_bits, c.max_total, c.adder, Q->state.p, trip.p); break;
-				case 5: LAUNCHB(ctx, n_base * 16.0, (k_evolve_small<5>), g, 256, (const uint32_t*)key.p, (const uint32_t*)sidx.p, (const uint32_t*)ss.p, (const uint32_t*)se.p, c.n_ctx, c.sym_bits, c.max_total, c.adder, Q->state.p, trip.p); break;
-				default: LAUNCHB(ctx, n_base * 16.0, k_evolve_large, g, 256, (const uint32_t*)key.p, (const uint32_t*)sidx.p, (const uint32_t*)ss.p, (const uint32_t*)se.p, c.n_ctx, c.n_sym, c.sym_bits, c.max_total, c.adder, Q->state.p, trip.p); break;
-				}
-				HIP_TRY(ctx, hipGetLastError());
-				HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+			case 2: LAUNCHB(ctx, n_base * 16.0, (k_evolve_small<2>), g, 256, (const uint32_t*)G.key.p, (const uint32_t*)G.sidx.p, (const uint32_t*)G.ss.p, (const uint32_t*)G.se.p, c.n_ctx, c.sym_bits, c.max_total, c.adder, Q->state.p, trip.p); break;
+			case 4: LAUNCHB(ctx, n_base * 16.0, (k_evolve_small<4>), g, 256, (const uint32_t*)G.key.p, (const uint32_t*)G.sidx.p, (const uint32_t*)G.ss.p, (const uint32_t*)G.se.p, c.n_ctx, c.sym_bits, c.max_total, c.adder, Q->state.p, trip.p); break;
+			case 5: LAUNCHB(ctx, n_base * 16.0, (k_evolve_small<5>), g, 256, (const uint32_t*)G.key.p, (const uint32_t*)G.sidx.p, (const uint32_t*)G.ss.p, (const uint32_t*)G.se.p, c.n_ctx, c.sym_bits, c.max_total, c.adder, Q->state.p, trip.p); break;
+			default: LAUNCHB(ctx, n_base * 16.0, k_evolve_large, g, 256, (const uint32_t*)G.key.p, (const uint32_t*)G.sidx.p, (const uint32_t*)G.ss.p, (const uint32_t*)G.se.p, c.n_ctx, c.n_sym, c.sym_bits, c.max_total, c.adder, Q->state.p, trip.p); break;
 			}
-			if (n_byte)
-			{
-				CL_TRY(dev_sort_keys32_pairs(ctx, bkey.p, bsidx.p, n_byte, 8, 8 + 10));
-				DevBuf<uint32_t> ss, se; DEV_ALLOC(ctx, ss, BYTE_CTX); DEV_ALLOC(ctx, se, BYTE_CTX);
-				HIP_TRY(ctx, hipMemsetAsync(ss.p, 0, BYTE_CTX * 4, ctx->stream));
-				HIP_TRY(ctx, hipMemsetAsync(se.p, 0, BYTE_CTX * 4, ctx->stream));
-				LAUNCH(ctx, k_seg_bounds, grid_for(n_byte, 256), 256, (const uint32_t*)bkey.p, n_byte, 8u, ss.p, se.p);
-				LAUNCH(ctx, k_evolve_large, grid_for(BYTE_CTX, 4), 256, (const uint32_t*)bkey.p, (const uint32_t*)bsidx.p, (const uint32_t*)ss.p, (const uint32_t*)se.p,
-					BYTE_CTX, 256u, 8u, 1u << 18, 8u, Q->bstate.p, trip.p);
-				HIP_TRY(ctx, hipGetLastError());
-				HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-			}
+			HIP_TRY(ctx, hipGetLastError());
+		}
+		if (n_byte)
+		{
+			LAUNCH(ctx, k_evolve_large, grid_for(BYTE_CTX, 4), 256, (const uint32_t*)G.bkey.p, (const uint32_t*)G.bsidx.p, (const uint32_t*)G.bss.p, (const uint32_t*)G.bse.p,
+				BYTE_CTX, 256u, 8u, 1u << 18, 8u, Q->bstate.p, trip.p);
+			HIP_TRY(ctx, hipGetLastError());
 		}
 		// range coding: worst case bits_max bits per symbol + 8 flush bytes, rounded to 8-byte aligned regions
 		std::vector<uint64_t> out_off(np + 1);
@@ -541,11 +604,12 @@ extern "C" cl_status cl_qual_encode(cl_ctx* ctx, cl_qual_coder* Q, const cl_read
 		DevBuf<uint64_t> d_out_off, d_size, d_dst_off;
 		DEV_ALLOC(ctx, d_out_off, np + 1); DEV_ALLOC(ctx, d_size, np); DEV_ALLOC(ctx, d_dst_off, np);
 		HIP_TRY(ctx, hipMemcpyAsync(d_out_off.p, out_off.data(), (np + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-		LAUNCHB(ctx, n_syms * 8.0, k_range_code, ng, 64, (const triple_t*)trip.p, (const uint64_t*)d_gbase.p, (const uint32_t*)d_plen.p, np, tmp.p, (const uint64_t*)d_out_off.p, d_size.p, inv_tab);
+		LAUNCHB(ctx, n_syms * 8.0, k_range_code, ng, 64, (const triple_t*)trip.p, (const uint64_t*)G.d_gbase.p, (const uint32_t*)G.d_plen.p, np, tmp.p, (const uint64_t*)d_out_off.p, d_size.p, inv_tab);
 		HIP_TRY(ctx, hipGetLastError());
 		std::vector<uint64_t> size_r(np);                                       // by place
 		HIP_TRY(ctx, hipMemcpyAsync(size_r.data(), d_size.p, np * 8, hipMemcpyDeviceToHost, ctx->stream));
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		G.key.release(); G.sidx.release(); G.bkey.release(); G.bsidx.release();   // (the models are through with them)
 		for (uint32_t p = 0; p < np; ++p)
 		{
 			h_part_sizes[p0 + p] = size_r[rank[p]];
@@ -561,7 +625,6 @@ extern "C" cl_status cl_qual_encode(cl_ctx* ctx, cl_qual_coder* Q, const cl_read
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 		written = w;
 		Q->symbols_coded += n_syms;
-		p0 = p1;
 	}
 	cl_timing_collect(ctx);
 	*n_out = written;

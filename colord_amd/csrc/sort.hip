@@ -1,4 +1,4 @@
-// sort.hip — in-tree stable LSD radix sort (8-bit digits) for uint32/uint64 keys with an optional
+// sort.hip — in-tree stable LSD radix sort (8- to 10-bit digits) for uint32/uint64 keys with an optional
 // uint32 payload.  Per pass: per-tile digit histogram -> device-wide exclusive scan (digit-major) ->
 // stable scatter.  Ranking inside a wavefront uses 64-lane ballots ("match-any" over the 8 digit bits)
 // so equal digits keep their input order without a second local sort.
@@ -11,25 +11,28 @@ constexpr uint32_t ST = 256;            // threads per block
 constexpr uint32_t SI = 16;             // keys per thread
 constexpr uint32_t STILE = ST * SI;     // 4096 keys per tile
 
-template<typename K>
+// DB = digit bits of the pass (8, 9 or 10): the passes of a sort share the key bits evenly, so 17 bits take two passes (9 + 8),
+// not three, and 20 bits two of 10.
+template<typename K, uint32_t DB>
 __global__ __launch_bounds__(ST) void k_sort_hist(const K* __restrict__ keys, uint64_t n, uint32_t shift,
                                                   uint32_t* __restrict__ hist, uint32_t nb)
 {
-	__shared__ uint32_t h[256];
-	h[threadIdx.x] = 0;
+	constexpr uint32_t ND = 1u << DB;
+	__shared__ uint32_t h[ND];
+	for (uint32_t i = threadIdx.x; i < ND; i += ST) h[i] = 0;
 	__syncthreads();
 	uint64_t base = (uint64_t)blockIdx.x * STILE;
 #pragma unroll
 	for (uint32_t i = 0; i < SI; ++i)
 	{
 		uint64_t idx = base + (uint64_t)i * ST + threadIdx.x;
-		if (idx < n) atomicAdd(&h[(uint32_t)(keys[idx] >> shift) & 255u], 1u);
+		if (idx < n) atomicAdd(&h[(uint32_t)(keys[idx] >> shift) & (ND - 1)], 1u);
 	}
 	__syncthreads();
-	hist[(uint64_t)threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
+	for (uint32_t i = threadIdx.x; i < ND; i += ST) hist[(uint64_t)i * nb + blockIdx.x] = h[i];
 }
 
-template<typename K, bool HAS_V>
+template<typename K, bool HAS_V, uint32_t DB>
 __global__ __launch_bounds__(ST) void k_sort_scatter(const K* __restrict__ kin, const uint32_t* __restrict__ vin,
                                                      K* __restrict__ kout, uint32_t* __restrict__ vout,
                                                      uint64_t n, uint32_t shift, const uint32_t* __restrict__ offs, uint32_t nb)
@@ -37,29 +40,36 @@ __global__ __launch_bounds__(ST) void k_sort_scatter(const K* __restrict__ kin, 
 	// The tile is first ordered by digit in LDS (stable: wave by wave, ballot ranks inside a wave), then written out
 	// linearly: consecutive threads write consecutive elements of a bucket, so a bucket's share of the tile (16 keys on
 	// average) leaves as whole lines instead of one 4/8-byte store per lane and bucket.
-	__shared__ uint32_t wh[4][256];          // per wave and digit: count, then the wave's first place in the ordered tile
-	__shared__ uint32_t lstart[257];         // first place of a digit in the ordered tile
-	__shared__ uint32_t gdelta[256];         // global position of a digit's first tile element minus lstart
+	constexpr uint32_t ND = 1u << DB, PER = ND / ST;   // digits; digits per thread in the scan (1, 2, 4)
+	__shared__ uint32_t wh[4][ND];           // per wave and digit: count, then the wave's first place in the ordered tile
+	__shared__ uint32_t lstart[ND + 1];      // first place of a digit in the ordered tile
+	__shared__ uint32_t gdelta[ND];          // global position of a digit's first tile element minus lstart
 	__shared__ uint32_t wtot[4];
 	__shared__ K skey[STILE];
 	__shared__ uint32_t sval[HAS_V ? STILE : 1];
 	const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	for (uint32_t i = threadIdx.x; i < 4 * 256; i += ST) (&wh[0][0])[i] = 0;
+	for (uint32_t i = threadIdx.x; i < 4 * ND; i += ST) (&wh[0][0])[i] = 0;
 	__syncthreads();
 
 	const uint64_t tbase = (uint64_t)blockIdx.x * STILE, wbase = tbase + (uint64_t)w * (64 * SI);
-	K key[SI]; uint32_t rank[SI];
+	K key[SI]; uint32_t rank[SI]; uint32_t val[HAS_V ? SI : 1];
 	const uint64_t lt = (1ULL << lane) - 1;
 #pragma unroll
 	for (uint32_t r = 0; r < SI; ++r)
 	{
 		uint64_t idx = wbase + (uint64_t)r * 64 + lane;
+		key[r] = idx < n ? kin[idx] : (K)0;
+		if (HAS_V) val[r] = idx < n ? vin[idx] : 0u;                           // (with the keys: not a second round trip later)
+	}
+#pragma unroll
+	for (uint32_t r = 0; r < SI; ++r)
+	{
+		uint64_t idx = wbase + (uint64_t)r * 64 + lane;
 		bool valid = idx < n;
-		key[r] = valid ? kin[idx] : (K)0;
-		uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
+		uint32_t d = (uint32_t)(key[r] >> shift) & (ND - 1);
 		uint64_t peers = __ballot(valid);
 #pragma unroll
-		for (uint32_t b = 0; b < 8; ++b)
+		for (uint32_t b = 0; b < DB; ++b)
 		{
 			bool bit = (d >> b) & 1u;
 			uint64_t m = __ballot(valid && bit);
@@ -72,21 +82,32 @@ __global__ __launch_bounds__(ST) void k_sort_scatter(const K* __restrict__ kin, 
 		__builtin_amdgcn_wave_barrier();
 	}
 	__syncthreads();
-	{	// thread d: digit totals -> exclusive scan over the digits -> places of the waves' shares
-		const uint32_t d = threadIdx.x;
-		const uint32_t c0 = wh[0][d], c1 = wh[1][d], c2 = wh[2][d], c3 = wh[3][d], tot = c0 + c1 + c2 + c3;
-		uint32_t incl = tot;
+	{	// thread t: digits t * PER .. t * PER + PER - 1: totals -> exclusive scan over the digits -> places of the waves' shares
+		uint32_t c[PER][4], tot[PER], mine = 0;
+#pragma unroll
+		for (uint32_t k = 0; k < PER; ++k)
+		{
+			const uint32_t d = threadIdx.x * PER + k;
+			c[k][0] = wh[0][d]; c[k][1] = wh[1][d]; c[k][2] = wh[2][d]; c[k][3] = wh[3][d];
+			tot[k] = c[k][0] + c[k][1] + c[k][2] + c[k][3]; mine += tot[k];
+		}
+		uint32_t incl = mine;
 #pragma unroll
 		for (uint32_t o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
 		if (lane == 63) wtot[w] = incl;
 		__syncthreads();
-		uint32_t before = 0;
-		for (uint32_t i = 0; i < w; ++i) before += wtot[i];
-		const uint32_t ls = before + incl - tot;
-		lstart[d] = ls;
-		if (d == 255) lstart[256] = ls + tot;
-		gdelta[d] = offs[(uint64_t)d * nb + blockIdx.x] - ls;
-		wh[0][d] = ls; wh[1][d] = ls + c0; wh[2][d] = ls + c0 + c1; wh[3][d] = ls + c0 + c1 + c2;
+		uint32_t ls = incl - mine;
+		for (uint32_t i = 0; i < w; ++i) ls += wtot[i];
+#pragma unroll
+		for (uint32_t k = 0; k < PER; ++k)
+		{
+			const uint32_t d = threadIdx.x * PER + k;
+			lstart[d] = ls;
+			if (d == ND - 1) lstart[ND] = ls + tot[k];
+			gdelta[d] = offs[(uint64_t)d * nb + blockIdx.x] - ls;
+			wh[0][d] = ls; wh[1][d] = ls + c[k][0]; wh[2][d] = ls + c[k][0] + c[k][1]; wh[3][d] = ls + c[k][0] + c[k][1] + c[k][2];
+			ls += tot[k];
+		}
 	}
 	__syncthreads();
 #pragma unroll
@@ -95,21 +116,33 @@ __global__ __launch_bounds__(ST) void k_sort_scatter(const K* __restrict__ kin, 
 		uint64_t idx = wbase + (uint64_t)r * 64 + lane;
 		if (idx < n)
 		{
-			uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
+			uint32_t d = (uint32_t)(key[r] >> shift) & (ND - 1);
 			uint32_t lp = wh[w][d] + rank[r];
 			skey[lp] = key[r];
-			if (HAS_V) sval[lp] = vin[idx];
+			if (HAS_V) sval[lp] = val[r];
 		}
 	}
 	__syncthreads();
-	const uint32_t tile_n = lstart[256];
+	const uint32_t tile_n = lstart[ND];
 	for (uint32_t j = threadIdx.x; j < tile_n; j += ST)
 	{
 		const K k = skey[j];
-		const uint32_t pos = gdelta[(uint32_t)(k >> shift) & 255u] + j;
+		const uint32_t pos = gdelta[(uint32_t)(k >> shift) & (ND - 1)] + j;
 		kout[pos] = k;
 		if (HAS_V) vout[pos] = sval[j];
 	}
+}
+
+template<typename K, uint32_t DB>
+cl_status sort_pass(cl_ctx* ctx, const K* kin, const uint32_t* vin, K* kout, uint32_t* vout, uint64_t n, uint32_t shift, uint32_t* hist, uint32_t nb)
+{
+	LAUNCHB(ctx, n * sizeof(K), (k_sort_hist<K, DB>), nb, ST, kin, n, shift, hist, nb);
+	HIP_TRY(ctx, hipGetLastError());
+	CL_TRY(dev_exclusive_scan_u32(ctx, hist, (uint64_t)(1u << DB) * nb, nullptr));
+	if (vin) LAUNCHB(ctx, n * (2 * sizeof(K) + 8), (k_sort_scatter<K, true, DB>), nb, ST, kin, vin, kout, vout, n, shift, (const uint32_t*)hist, nb);
+	else LAUNCHB(ctx, n * 2 * sizeof(K), (k_sort_scatter<K, false, DB>), nb, ST, kin, (const uint32_t*)nullptr, kout, (uint32_t*)nullptr, n, shift, (const uint32_t*)hist, nb);
+	HIP_TRY(ctx, hipGetLastError());
+	return CL_OK;
 }
 
 template<typename K>
@@ -118,36 +151,34 @@ cl_status sort_impl(cl_ctx* ctx, K* d_keys, uint32_t* d_vals, uint64_t n, uint32
 	if (n <= 1 || end_bit <= begin_bit) return CL_OK;
 	if (n >= (1ULL << 32)) return cl_fail(ctx, CL_E_UNSUPPORTED, "radix sort: n must be < 2^32 per call");
 	const uint32_t nb = grid_for(n, STILE);
+	// passes of at most 10 bits each, the bits shared evenly (8-bit digits when that takes no more passes)
+	const uint32_t bits = end_bit - begin_bit;
+	const uint32_t n_pass_real = (bits + 7) / 8 == (bits + 9) / 10 ? (bits + 7) / 8 : (bits + 9) / 10;
+	const uint32_t db_hi = (bits + n_pass_real - 1) / n_pass_real;               // digit bits of the first passes (8, 9 or 10; 1..8 when one pass does it)
 	// ping-pong between the caller's arrays and a temporary; with an ODD number of passes a second temporary takes the
 	// first pass, so that the last one lands in the caller's arrays without a copy back
-	const uint32_t n_pass_real = (end_bit - begin_bit + 7) / 8;
 	// (the second temporary only while it is small: on the largest sorts its footprint costs more than the copy)
 	const bool third = (n_pass_real & 1) && n_pass_real > 1 && n * (sizeof(K) + (d_vals ? 4 : 0)) <= (2ull << 30);
 	const uint32_t n_pass = third ? n_pass_real : (n_pass_real + 1) & ~1u;          // even: plain ping-pong (+ copy back if the real count is odd)
 	DevBuf<K> ktmp, ktmp2; DEV_ALLOC(ctx, ktmp, n);
 	DevBuf<uint32_t> vtmp, vtmp2; if (d_vals) DEV_ALLOC(ctx, vtmp, n);
 	if (n_pass & 1) { DEV_ALLOC(ctx, ktmp2, n); if (d_vals) DEV_ALLOC(ctx, vtmp2, n); }
-	DevBuf<uint32_t> hist; DEV_ALLOC(ctx, hist, (uint64_t)256 * nb);
+	DevBuf<uint32_t> hist; DEV_ALLOC(ctx, hist, (uint64_t)(1u << std::max(8u, db_hi)) * nb);
 	K* kin = d_keys; uint32_t* vin = d_vals;
 	uint32_t pass = 0;
-	for (uint32_t shift = begin_bit; shift < end_bit; shift += 8, ++pass)
+	for (uint32_t shift = begin_bit; shift < end_bit; ++pass)
 	{
 		// destinations: even count: tmp, keys, tmp, keys ...; odd count: tmp2, tmp, keys, tmp, keys ...
 		K* kout; uint32_t* vout;
 		if (n_pass & 1) { kout = pass == 0 ? ktmp2.p : (pass & 1) ? ktmp.p : d_keys; vout = pass == 0 ? vtmp2.p : (pass & 1) ? vtmp.p : d_vals; }
 		else { kout = (pass & 1) ? d_keys : ktmp.p; vout = (pass & 1) ? d_vals : vtmp.p; }
-		{
-			LAUNCHB(ctx, n * sizeof(K), (k_sort_hist<K>), nb, ST, (const K*)kin, n, shift, hist.p, nb);
-		}
-		HIP_TRY(ctx, hipGetLastError());
-		CL_TRY(dev_exclusive_scan_u32(ctx, hist.p, (uint64_t)256 * nb, nullptr));
-		{
-			if (d_vals)
-				LAUNCHB(ctx, n * (2 * sizeof(K) + 8), (k_sort_scatter<K, true>), nb, ST, (const K*)kin, (const uint32_t*)vin, kout, vout, n, shift, (const uint32_t*)hist.p, nb);
-			else
-				LAUNCHB(ctx, n * 2 * sizeof(K), (k_sort_scatter<K, false>), nb, ST, (const K*)kin, (const uint32_t*)nullptr, kout, (uint32_t*)nullptr, n, shift, (const uint32_t*)hist.p, nb);
-		}
-		HIP_TRY(ctx, hipGetLastError());
+		const uint32_t left = end_bit - shift, passes_left = n_pass_real - pass;
+		const uint32_t db = std::max(8u, (left + passes_left - 1) / passes_left); // (bits above end_bit in a digit are harmless only if they are equal: callers' keys are zero there or sorted on them anyway)
+		const uint32_t use = std::min(db, 10u);
+		if (use == 10) CL_TRY((sort_pass<K, 10>(ctx, kin, vin, kout, vout, n, shift, hist.p, nb)));
+		else if (use == 9) CL_TRY((sort_pass<K, 9>(ctx, kin, vin, kout, vout, n, shift, hist.p, nb)));
+		else CL_TRY((sort_pass<K, 8>(ctx, kin, vin, kout, vout, n, shift, hist.p, nb)));
+		shift += use;
 		kin = kout; vin = vout;
 	}
 	if (kin != d_keys)

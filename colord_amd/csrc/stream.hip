@@ -93,17 +93,28 @@ struct cl_compressor {
 		cl_status status = CL_OK; std::string err;
 		std::map<std::string, KernelTime> times;      // kernel times of the lane for this chunk (merged into the caller's context)
 		bool done = false;
+		// the model-independent half of the DNA coder for this chunk (tuple walks, and with part bounds the sort by context), made by
+		// the compressor's preparation thread beside the coding of the chunk before (cl_dna_prepare_batch)
+		std::vector<uint32_t> parts; DnaWalked* walked = nullptr; bool dna_done = false; std::map<std::string, KernelTime> dna_times;
+		// ... and of the quality coder (symbols, sort by context), which needs the input only (level 1: no flags from the edit scripts)
+		const uint8_t* d_quals = nullptr; const uint64_t* d_base_off = nullptr; QualPrepared* qprep = nullptr; bool q_done = false; std::map<std::string, KernelTime> q_times;
+		~Prepared() { if (walked) cl_dna_walked_free(walked); if (qprep) cl_qual_prepared_free(qprep); }
 	};
 	std::mutex lane_mu; std::condition_variable lane_cv;
 	std::deque<size_t> lane_queue;                   // announced chunk indices not yet started, ascending
 	std::map<size_t, std::unique_ptr<Prepared>> prepared;
 	std::vector<std::thread> lane_threads; std::vector<cl_ctx*> lane_ctx;
 	size_t n_announced = 0; bool lane_stop = false;
+	// DNA preparation thread: walks (and sorts) the chunks in order, one or two ahead of the coders, on a context of its own
+	std::thread prep_thread; cl_ctx* prep_ctx = nullptr; size_t prep_next = 0; bool prep_on = false, prep_broken = false; uint32_t prep_types = 0, prep_read_id = 0;
+	std::thread qprep_thread; cl_ctx* qprep_ctx = nullptr; size_t qprep_next = 0; bool qprep_on = false;
 	void stop_lanes()
 	{
 		{ std::lock_guard<std::mutex> l(lane_mu); lane_stop = true; }
 		lane_cv.notify_all();
 		for (auto& t : lane_threads) if (t.joinable()) t.join();
+		if (prep_thread.joinable()) prep_thread.join();
+		if (qprep_thread.joinable()) qprep_thread.join();
 		lane_threads.clear();
 		prepared.clear();                                // (buffers go back to the lanes' pools)
 		lane_ctx.clear();                                // the contexts stay with ctx for the next compressor (their pools are warm)
@@ -516,7 +527,98 @@ static void lane_main(cl_compressor* c, cl_ctx* lane)
 	}
 }
 
+// The DNA coder's chain per chunk was: tuple walks -> triple slots -> stable sort by (family, context) -> context runs -> model
+// evolution -> interval coding, all on the caller's stream — after the aligner work of round 3 THE critical chain of a pass
+// (22.5 of 25.7 s busy).  Everything before the model evolution depends on the tuple streams only (and on two scalars that chain
+// from walk to walk), so this thread does it for the chunks ahead, in order, on a context of its own; the caller's stream keeps
+// evolution and coding.
+static void prep_main(cl_compressor* c)
+{
+	cl_ctx* ctx = c->prep_ctx;
+	for (;;)
+	{
+		size_t idx; cl_compressor::Prepared* job;
+		{
+			std::unique_lock<std::mutex> l(c->lane_mu);
+			c->lane_cv.wait(l, [&]() {
+				if (c->lane_stop || c->prep_broken) return true;
+				if (c->prep_next < c->enc_chunk) return true;                        // (a chunk was coded without this thread: the chain of walk scalars is lost)
+				auto it = c->prepared.find(c->prep_next);
+				return it != c->prepared.end() && it->second->done && c->prep_next <= c->enc_chunk + 1;
+			});
+			if (c->lane_stop || c->prep_broken) return;
+			if (c->prep_next < c->enc_chunk) { c->prep_broken = true; c->lane_cv.notify_all(); return; }
+			idx = c->prep_next; job = c->prepared[idx].get();
+		}
+		DnaWalked* W = nullptr; uint32_t types_out = c->prep_types; cl_status s = CL_OK;
+		const uint32_t n = job->reads->n_reads;
+		if (job->status == CL_OK && n)
+		{
+			ctx->timing = c->ctx->timing;
+			s = cl_dna_prepare_batch(ctx, c->dna, c->refs, job->es.p, job->es_off.p, job->es_nt.p, n, c->prep_types, c->prep_read_id,
+			                         job->parts.empty() ? nullptr : job->parts.data(), job->parts.empty() ? 0u : (uint32_t)job->parts.size() - 1, &W, &types_out);
+			cl_timing_collect(ctx);
+		}
+		{
+			std::lock_guard<std::mutex> l(c->lane_mu);
+			if (s == CL_OK && job->status == CL_OK) { job->walked = W; c->prep_types = types_out; c->prep_read_id += n; }
+			else { if (W) cl_dna_walked_free(W); if (job->status == CL_OK) c->prep_broken = true; }   // (the caller's thread walks this chunk itself and reports what fails)
+			job->dna_times.swap(ctx->times); ctx->times.clear();
+			job->dna_done = true;
+			c->prep_next = idx + 1;
+		}
+		c->lane_cv.notify_all();
+	}
+}
+
+// The quality coder's chain per chunk — symbols -> stable sort by context -> context runs -> model evolution -> interval coding —
+// became the critical one once the DNA coder's first half had moved to prep_main.  Its first three steps depend on the input only:
+// this thread makes them for the chunks ahead (one or two), on a context of its own.
+static void qprep_main(cl_compressor* c)
+{
+	cl_ctx* ctx = c->qprep_ctx;
+	for (;;)
+	{
+		size_t idx; cl_compressor::Prepared* job;
+		{
+			std::unique_lock<std::mutex> l(c->lane_mu);
+			c->lane_cv.wait(l, [&]() {
+				if (c->lane_stop) return true;
+				if (c->qprep_next < c->enc_chunk) return true;
+				auto it = c->prepared.find(c->qprep_next);
+				return it != c->prepared.end() && c->qprep_next <= c->enc_chunk + 1;
+			});
+			if (c->lane_stop) return;
+			if (c->qprep_next < c->enc_chunk) { c->qprep_next = c->enc_chunk; continue; }   // (chunks coded without an announcement: nothing chains here, catch up)
+			idx = c->qprep_next; job = c->prepared[idx].get();
+		}
+		QualPrepared* P = nullptr;
+		if (job->d_quals && job->d_base_off && !job->parts.empty() && job->reads->n_reads)
+		{
+			ctx->timing = c->ctx->timing;
+			const cl_status s = cl_qual_prepare_batch(ctx, c->qual, job->reads, job->d_quals, job->d_base_off, nullptr, job->parts.data(), (uint32_t)job->parts.size() - 1, &P);
+			cl_timing_collect(ctx);
+			if (s != CL_OK) P = nullptr;                                             // (the caller's thread prepares this chunk itself and reports what fails)
+		}
+		{
+			std::lock_guard<std::mutex> l(c->lane_mu);
+			job->qprep = P;
+			job->q_times.swap(ctx->times); ctx->times.clear();
+			job->q_done = true;
+			c->qprep_next = idx + 1;
+		}
+		c->lane_cv.notify_all();
+	}
+}
+
+extern "C" cl_status cl_compressor_prepare_parts(cl_compressor* c, const cl_reads* reads, const uint32_t* h_pack_bounds, uint32_t n_packs, const uint32_t* h_part_bounds, uint32_t n_parts,
+                                                 const uint8_t* d_quals, const uint64_t* d_base_off);
 extern "C" cl_status cl_compressor_prepare(cl_compressor* c, const cl_reads* reads, const uint32_t* h_pack_bounds, uint32_t n_packs)
+{
+	return cl_compressor_prepare_parts(c, reads, h_pack_bounds, n_packs, nullptr, 0, nullptr, nullptr);
+}
+extern "C" cl_status cl_compressor_prepare_parts(cl_compressor* c, const cl_reads* reads, const uint32_t* h_pack_bounds, uint32_t n_packs, const uint32_t* h_part_bounds, uint32_t n_parts,
+                                                 const uint8_t* d_quals, const uint64_t* d_base_off)
 {
 	if (!c || !reads || !h_pack_bounds) return CL_E_INVALID;
 	cl_ctx* ctx = c->ctx;
@@ -538,9 +640,38 @@ extern "C" cl_status cl_compressor_prepare(cl_compressor* c, const cl_reads* rea
 		}
 		c->lane_ctx.assign(ctx->lanes.begin(), ctx->lanes.begin() + lanes);
 		for (cl_ctx* x : c->lane_ctx) c->lane_threads.emplace_back(lane_main, c, x);
+		// the DNA preparation thread: only from the first chunk on (its walk scalars chain from chunk to chunk)
+		if (idx == 0 && c->enc_chunk == 0 && !getenv("COLORD_HIP_NO_DNA_PREP"))
+		{
+			if (!ctx->prep)
+			{
+				cl_ctx* x = nullptr;
+				const cl_status s = cl_ctx_create(ctx->device, &x);
+				if (s != CL_OK) return cl_fail(ctx, s, "cl_compressor_prepare: no context for the DNA preparation thread");
+				ctx->prep = x;
+			}
+			c->prep_ctx = ctx->prep; c->prep_next = 0; c->prep_on = true;
+			cl_dna_coder_state(c->dna, &c->prep_types, &c->prep_read_id);
+			c->prep_thread = std::thread(prep_main, c);
+		}
+		// the quality preparation thread: level 1 only (above, the contexts take flags from the edit scripts), quality context of its own
+		if (c->qual && c->P.level <= 1 && c->qctx && c->qctx != ctx && !getenv("COLORD_HIP_NO_QUAL_PREP"))
+		{
+			if (!ctx->qprep)
+			{
+				cl_ctx* x = nullptr;
+				const cl_status s = cl_ctx_create(ctx->device, &x);
+				if (s != CL_OK) return cl_fail(ctx, s, "cl_compressor_prepare: no context for the quality preparation thread");
+				ctx->qprep = x;
+			}
+			c->qprep_ctx = ctx->qprep; c->qprep_next = idx; c->qprep_on = true;
+			c->qprep_thread = std::thread(qprep_main, c);
+		}
 	}
 	auto job = std::make_unique<cl_compressor::Prepared>();
 	job->reads = reads; job->packs.assign(h_pack_bounds, h_pack_bounds + n_packs + 1);
+	if (h_part_bounds && n_parts) job->parts.assign(h_part_bounds, h_part_bounds + n_parts + 1);
+	job->d_quals = d_quals; job->d_base_off = d_base_off;
 	c->prepared[idx] = std::move(job);
 	c->lane_queue.push_back(idx);
 	c->n_announced = idx + 1;
@@ -578,6 +709,8 @@ extern "C" cl_status cl_compressor_encode(cl_compressor* c, const cl_reads* read
 		{
 			if (it->second->reads != reads) return cl_fail(ctx, CL_E_INVALID, "cl_compressor_encode: not the chunk that was announced for this position");
 			c->lane_cv.wait(l, [&]() { return it->second->done; });
+			if (c->prep_on && !c->prep_broken && c->prep_next <= idx) c->lane_cv.wait(l, [&]() { return it->second->dna_done || c->prep_broken; });
+			if (c->qprep_on && c->qprep_next <= idx) c->lane_cv.wait(l, [&]() { return it->second->q_done; });
 			own = std::move(it->second); c->prepared.erase(it);
 			job = own.get();
 		}
@@ -588,12 +721,16 @@ extern "C" cl_status cl_compressor_encode(cl_compressor* c, const cl_reads* read
 	cl_status qstatus = CL_OK;
 	cl_ctx* qctx = c->qual ? cl_qual_coder_ctx(c->qual) : nullptr;
 	const bool overlap = c->qual && P->level <= 1 && qctx && qctx != ctx;
+	if (overlap && job && job->qprep && job->d_quals == d_quals) { cl_qual_set_ahead(c->qual, job->qprep); job->qprep = nullptr; }
+	if (job) for (auto& kv : job->q_times) { auto& t = qctx->times[kv.first]; t.ms += kv.second.ms; t.launches += kv.second.launches; t.bytes += kv.second.bytes; }
 	if (overlap)
 		qjob.t = std::thread([&]() { qstatus = cl_qual_encode(qctx, c->qual, reads, d_quals, d_base_off, nullptr, h_part_bounds, n_parts, d_qual_out, qual_cap, h_qual_part_sizes, &info->qual_bytes); });
 	if (job)
 	{
 		if (job->status != CL_OK) return cl_fail(ctx, job->status, "encode lane: " + job->err);
 		for (auto& kv : job->times) { auto& t = ctx->times[kv.first]; t.ms += kv.second.ms; t.launches += kv.second.launches; t.bytes += kv.second.bytes; }
+		for (auto& kv : job->dna_times) { auto& t = ctx->times[kv.first]; t.ms += kv.second.ms; t.launches += kv.second.launches; t.bytes += kv.second.bytes; }
+		if (job->walked) { cl_dna_set_ahead(c->dna, job->walked); job->walked = nullptr; }
 	}
 	else
 	{
@@ -606,6 +743,7 @@ extern "C" cl_status cl_compressor_encode(cl_compressor* c, const cl_reads* read
 	// the tuple walk of the NEXT chunk runs, if an encode lane has its tuple streams ready: that half of the DNA coder needs no
 	// model state (dna.hip, DnaWalked).
 	cl_dna_set_before_tail(c->dna, [c, idx]() -> cl_status {
+		if (c->prep_on && !c->prep_broken) return CL_OK;                          // (the preparation thread does that, and more)
 		cl_compressor::Prepared* nx = nullptr;
 		{
 			std::lock_guard<std::mutex> l(c->lane_mu);

@@ -469,11 +469,17 @@ class Compressor(_Obj):
     def pseudo_reads(self, pseudo: "Reads"):
         _check(self.ctx, self.ctx.lib.cl_compressor_pseudo_reads(self.h, pseudo.h))
 
-    def prepare(self, reads: "Reads", pack_bounds):
-        """cl_compressor_prepare: announce a chunk of a later encode() call; its candidates / anchors / edit scripts are
-        computed in the background on an encode lane while the chunks before it are coded."""
+    def prepare(self, reads: "Reads", pack_bounds, part_bounds=None, quals: torch.Tensor | None = None, base_off: torch.Tensor | None = None):
+        """cl_compressor_prepare[_parts]: announce a chunk of a later encode() call; its candidates / anchors / edit scripts are
+        computed in the background on an encode lane while the chunks before it are coded — and, with the part bounds of that
+        encode() call, the model-independent half of its `dna` coding (walks, sort by context) on the preparation thread."""
         kb = np.ascontiguousarray(np.asarray(pack_bounds, dtype=np.uint32))
-        _check(self.ctx, self.ctx.lib.cl_compressor_prepare(self.h, reads.h, kb.ctypes.data, len(kb) - 1))
+        if part_bounds is None:
+            _check(self.ctx, self.ctx.lib.cl_compressor_prepare(self.h, reads.h, kb.ctypes.data, len(kb) - 1))
+        else:
+            pb = np.ascontiguousarray(np.asarray(part_bounds, dtype=np.uint32))
+            _check(self.ctx, self.ctx.lib.cl_compressor_prepare_parts(self.h, reads.h, kb.ctypes.data, len(kb) - 1, pb.ctypes.data, len(pb) - 1,
+                                                                      quals.data_ptr() if quals is not None else None, base_off.data_ptr() if (quals is not None and base_off is not None) else None))
 
     def encode(self, reads: "Reads", part_bounds, pack_bounds, quals: torch.Tensor | None = None, base_off: torch.Tensor | None = None,
                dna_out: torch.Tensor | None = None, qual_out: torch.Tensor | None = None):

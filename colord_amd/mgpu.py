@@ -144,7 +144,7 @@ def compress_readset(rs: ReadSet, out_path: str | None, source: int = 0, priorit
         cmp_.refs_finish()
         dna, qual, dsz, qsz, counts = [], [], [], [], []
         for arena, pb, q, off in chunks:                     # resident chunks: the encode lanes work ahead of the coders
-            cmp_.prepare(arena, pb)
+            cmp_.prepare(arena, pb, pb, q, off)
         for arena, pb, q, off in chunks:
             d, ds, qq, qs, _ = cmp_.encode(arena, pb, pb, q, off)
             dna.append(d.clone()); dsz += [int(x) for x in ds]; counts += [int(x) for x in np.diff(pb)]

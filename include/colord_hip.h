@@ -365,6 +365,16 @@ cl_status cl_compressor_pseudo_reads(cl_compressor* c, const cl_reads* pseudo_re
  * thread codes the chunks before it; only the adaptive models of the `dna` / `qual` coders chain chunk to chunk.  The lanes
  * run at most lanes + 2 chunks ahead of the encode calls.  Output bytes are the same with or without announcements. */
 cl_status cl_compressor_prepare(cl_compressor* c, const cl_reads* chunk, const uint32_t* h_pack_bounds, uint32_t n_packs);
+/* The same with the coder parts the chunk will be encoded with (h_part_bounds of the later cl_compressor_encode call): then the half
+ * of the `dna` coder that needs no model state — tuple walks, triple slots, the stable sort by (family, context), context runs;
+ * the reference's CEntrComprReads thread does all of that inline, entr_read.h:56-80 — is made ahead as well, on a preparation
+ * thread and context of the compressor's own, one or two chunks ahead of the encode calls (~15 GB per 1-Gbase chunk ahead); the
+ * caller's stream keeps model evolution and interval coding.  Announcements must start with the first chunk.  With d_quals /
+ * d_base_off (those of the later encode call; null: not prepared) the same for the `qual` coder at level 1: symbols, sort by
+ * context and context runs on a second preparation thread (~8 GB per 1-Gbase chunk ahead).  Bytes unchanged; other part bounds or
+ * buffers at encode time are honoured (the preparation is redone). */
+cl_status cl_compressor_prepare_parts(cl_compressor* c, const cl_reads* chunk, const uint32_t* h_pack_bounds, uint32_t n_packs, const uint32_t* h_part_bounds, uint32_t n_parts,
+                                      const uint8_t* d_quals, const uint64_t* d_base_off);
 /* what the archive's `meta` stream needs (compression.cpp:704-779), valid after count_finish (n_refs_total after refs_finish):
  * first_read = global index of this rank's first read (start of its model domain) */
 cl_status cl_compressor_info(const cl_compressor* c, cl_kmer_stats* stats, uint64_t* first_read, uint64_t* n_reads_total, uint64_t* mean_read_len,
