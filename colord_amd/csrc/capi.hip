@@ -13,12 +13,26 @@ extern "C" cl_status cl_ctx_create(int device, cl_ctx** out)
 	if (e != hipSuccess || n <= 0) { fprintf(stderr, "colord_hip: no HIP device available (%s)\n", hipGetErrorString(e)); return CL_E_HIP; }
 	if (device < 0 || device >= n) return CL_E_INVALID;
 	if (hipSetDevice(device) != hipSuccess) return CL_E_HIP;
-	cl_ctx* c = new cl_ctx(); c->device = device;
+	cl_ctx* c = new cl_ctx(device);
 	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return CL_E_HIP; }
 	hipDeviceProp_t p;
 	if (hipGetDeviceProperties(&p, device) == hipSuccess) c->n_cu = p.multiProcessorCount;
 	*out = c;
 	return CL_OK;
+}
+// every stream of the context (the shared pool calls this before it hands memory the context released to another one)
+void cl_ctx_drain(cl_ctx* c)
+{
+	if (!c) return;
+	(void)hipSetDevice(c->device);
+	for (hipStream_t s : { c->stream, c->side, c->side2, c->side3 }) if (s) (void)hipStreamSynchronize(s);
+}
+int cl_ctx_fence(cl_ctx* c, hipEvent_t* ev)
+{
+	if (!c) return 0;
+	int n = 0;
+	for (hipStream_t s : { c->stream, c->side, c->side2, c->side3 }) if (s && n < 4) { if (hipEventRecord(ev[n], s) == hipSuccess) ++n; else (void)hipGetLastError(); }
+	return n;
 }
 extern "C" void cl_ctx_destroy(cl_ctx* c)
 {
@@ -35,8 +49,10 @@ extern "C" void cl_ctx_destroy(cl_ctx* c)
 	if (c->side2) (void)hipStreamDestroy(c->side2);
 	if (c->side3) (void)hipStreamDestroy(c->side3);
 	if (c->inv_tab) (void)hipFree(c->inv_tab);
-	c->pool.trim();
+	const int dev = c->device;
+	c->pool.drop_owner(c->pool_id);
 	delete c;
+	cl_device_pool_release(dev);
 }
 extern "C" const char* cl_last_error(const cl_ctx* c) { return c ? c->err.c_str() : "null context"; }
 extern "C" void* cl_ctx_stream(cl_ctx* c) { return c ? (void*)c->stream : nullptr; }

@@ -15,6 +15,7 @@
 #include <vector>
 #include <algorithm>
 #include <map>
+#include <deque>
 #include <mutex>
 #include "../../include/colord_hip.h"
 
@@ -27,18 +28,54 @@ struct KernelTime { double ms = 0; uint32_t launches = 0; double bytes = 0; };  
 // this pipeline needs it (stages ask for 34, 19, 16, 15, 10, 9 ... GB one after the other; a block kept for one size serves
 // the next badly).  So: blocks are carved best-fit, at their exact size, out of slabs obtained from the driver; free extents
 // coalesce; a request no extent holds adds a slab (its own size if it is large, else a quarter of what the pool holds already,
-// 256 MB to 4 GB).  Several contexts work on one GPU at a time (the quality stream's, the encode lanes of cl_compressor), each with
-// its own pool: when the device runs short, slabs that are entirely free are given back — this pool's first, then the others'.
+// 256 MB to 4 GB).  Several contexts work on one GPU at a time (the quality stream's, the encode lanes and the preparation threads of
+// cl_compressor): they SHARE the pool of their device (cl_device_pool).  With a pool per context — seven of them by round 3 — the
+// slabs each one kept for its own peak added up to more than the device holds, and every chunk paid hipFree / hipMalloc pairs of
+// several GB (a device-wide synchronisation each: the encode lanes stood still for half of their time).  One pool holds the peak of
+// the SUM of what is live.  When the device runs short all the same, slabs that are entirely free are given back.
+struct cl_ctx;
+void cl_ctx_drain(cl_ctx* c);                  // capi.hip: waits for every stream of the context
+int cl_ctx_fence(cl_ctx* c, hipEvent_t* ev);   // capi.hip: records an event on every stream of the context; returns their number (<= 4)
 struct DevPool {
-	struct Slab { char* base = nullptr; uint64_t size = 0, free_bytes = 0; std::map<uint64_t, uint64_t> ext; };   // ext: offset -> length of free extents
+	// A free extent remembers who released it and when (pool clock).  Its owner may have it back at once — a context's own reuse
+	// is ordered by its streams, as with a pool per context; anybody else only once the owner's streams have drained since
+	// (`drained`): kernels of the owner may still be reading a block it released early.
+	struct Ext { uint64_t len; int32_t owner; uint64_t clock; };
+	struct Slab { char* base = nullptr; uint64_t size = 0, free_bytes = 0; std::map<uint64_t, Ext> ext; };   // ext: offset -> free extent
 	std::mutex mu;                                // a buffer made on one thread (an encode lane of cl_compressor) may be released on another
 	std::vector<Slab> slabs;
-	uint64_t reserved = 0, live_bytes = 0, peak_live = 0, peak_total = 0; uint32_t n_mallocs = 0;   // (statistics for COLORD_HIP_POOL_DEBUG)
+	std::vector<cl_ctx*> owners; std::vector<uint64_t> drained; uint64_t clock = 0;      // by owner id
+	// fences: every few releases of an owner, an event on each of its streams.  What it released before a fence is anybody's once
+	// the fence's events have completed — no need to wait for whatever the owner has started since.
+	struct Fence { uint64_t clock; hipEvent_t ev[4]; int n; };
+	std::vector<std::deque<Fence>> fences; std::vector<uint32_t> since_fence; std::vector<hipEvent_t> spare_events;
+	uint64_t reserved = 0, live_bytes = 0, peak_live = 0, peak_total = 0; uint32_t n_mallocs = 0, n_drains = 0;   // (statistics for COLORD_HIP_POOL_DEBUG)
 	static constexpr uint64_t ALIGN = 256, PAD = 256, SLAB_MIN = 256ull << 20, SLAB_MAX = 4ull << 30;
-	static std::mutex& reg_mu() { static std::mutex* m = new std::mutex; return *m; }          // (never destroyed: contexts may outlive static destruction)
-	static std::vector<DevPool*>& registry() { static std::vector<DevPool*>* r = new std::vector<DevPool*>; return *r; }
-	DevPool() { std::lock_guard<std::mutex> l(reg_mu()); registry().push_back(this); }
-	~DevPool() { std::lock_guard<std::mutex> l(reg_mu()); auto& r = registry(); for (size_t i = 0; i < r.size(); ++i) if (r[i] == this) { r.erase(r.begin() + i); break; } }
+	int32_t add_owner(cl_ctx* c) { std::lock_guard<std::mutex> l(mu); owners.push_back(c); drained.push_back(0); fences.emplace_back(); since_fence.push_back(0); return (int32_t)owners.size() - 1; }
+	void drop_owner(int32_t id)
+	{	// (its streams are gone: nothing of it is in flight)
+		std::lock_guard<std::mutex> l(mu);
+		if (id < 0 || (size_t)id >= owners.size()) return;
+		owners[id] = nullptr; drained[id] = ~0ull;
+		for (auto& f : fences[id]) for (int i = 0; i < f.n; ++i) spare_events.push_back(f.ev[i]);
+		fences[id].clear();
+	}
+	// the fences of `id` whose events have completed move `drained` forward
+	void poll_fences_locked(int32_t id)
+	{
+		auto& q = fences[id];
+		while (!q.empty())
+		{
+			bool done = true;
+			for (int i = 0; i < q.front().n && done; ++i) done = hipEventQuery(q.front().ev[i]) == hipSuccess;
+			if (!done) { (void)hipGetLastError(); break; }
+			if (drained[id] < q.front().clock) drained[id] = q.front().clock;
+			for (int i = 0; i < q.front().n; ++i) spare_events.push_back(q.front().ev[i]);
+			q.pop_front();
+		}
+	}
+	bool clean(const Ext& e) const { return e.owner < 0 || e.clock <= drained[e.owner]; }
+	bool usable(const Ext& e, int32_t who) const { return e.owner == who || clean(e); }
 	// gives entirely free slabs back to the driver, largest first, until `want` bytes are freed; returns the bytes freed
 	uint64_t shed_locked(uint64_t want)
 	{
@@ -48,105 +85,156 @@ struct DevPool {
 			size_t best = slabs.size();
 			for (size_t i = 0; i < slabs.size(); ++i) if (slabs[i].free_bytes == slabs[i].size && (best == slabs.size() || slabs[i].size > slabs[best].size)) best = i;
 			if (best == slabs.size()) break;
-			(void)hipFree(slabs[best].base); freed += slabs[best].size; reserved -= slabs[best].size;
+			(void)hipFree(slabs[best].base); freed += slabs[best].size; reserved -= slabs[best].size;     // (hipFree waits for the device: whatever was in flight on the slab is through)
 			slabs.erase(slabs.begin() + best);
 		}
 		return freed;
 	}
-	// makes room for a new slab of r bytes when the device is short of it: this pool's free slabs first, then the others'
-	void make_room(std::unique_lock<std::mutex>& lock, uint64_t r, bool dbg)
+	// makes room for a new slab of r bytes when the device is short of it
+	void make_room(uint64_t r, bool dbg)
 	{
 		size_t fr = 0, tot = 0;
 		if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return; }
 		const uint64_t need = r + (1ull << 30);
 		if (fr >= need) return;
-		uint64_t freed = shed_locked(need - fr);
-		if (fr + freed < need)
-		{
-			lock.unlock();
-			{
-				std::lock_guard<std::mutex> l(reg_mu());
-				for (DevPool* p : registry()) if (p != this && fr + freed < need) { std::lock_guard<std::mutex> pl(p->mu); freed += p->shed_locked(need - fr - freed); }
-			}
-			lock.lock();
-		}
+		const uint64_t freed = shed_locked(need - fr);                          // (pools of other devices hold nothing this device could use)
 		if (dbg) fprintf(stderr, "[pool] device has %.1f GB free, %.3f GB wanted: gave back %.3f GB of free slabs\n", fr / 1e9, r / 1e9, freed / 1e9);
 	}
-	bool carve(uint64_t r, void** out)
+	// neighbours that have become compatible since they were released (their owners drained) are joined
+	void coalesce_locked()
+	{
+		for (Slab& S : slabs)
+			for (auto it = S.ext.begin(); it != S.ext.end();)
+			{
+				auto nx = std::next(it);
+				if (nx == S.ext.end()) break;
+				if (it->first + it->second.len == nx->first && (it->second.owner == nx->second.owner || (clean(it->second) && clean(nx->second))))
+				{
+					if (it->second.owner != nx->second.owner) { it->second.owner = -1; it->second.clock = 0; } else it->second.clock = std::max(it->second.clock, nx->second.clock);
+					it->second.len += nx->second.len; S.ext.erase(nx);
+				}
+				else it = nx;
+			}
+	}
+	// best fit among the extents `who` may use; *foreign: the owner of a fitting extent it may not use yet (or -1)
+	bool carve(uint64_t r, int32_t who, void** out, int32_t* foreign)
 	{
 		size_t bs = slabs.size(); uint64_t boff = 0, blen = ~0ull;
+		if (foreign) *foreign = -1;
 		for (size_t i = 0; i < slabs.size(); ++i)
 		{
 			if (slabs[i].free_bytes < r) continue;
-			for (auto& e : slabs[i].ext) if (e.second >= r && e.second < blen) { bs = i; boff = e.first; blen = e.second; if (blen == r) break; }
+			for (auto& e : slabs[i].ext)
+			{
+				if (e.second.len < r) continue;
+				if (!usable(e.second, who)) { if (foreign && *foreign < 0) *foreign = e.second.owner; continue; }
+				if (e.second.len < blen) { bs = i; boff = e.first; blen = e.second.len; if (blen == r) break; }
+			}
 			if (blen == r) break;
 		}
 		if (bs == slabs.size()) return false;
 		Slab& S = slabs[bs];
+		const Ext old = S.ext[boff];
 		S.ext.erase(boff);
-		if (blen > r) S.ext.emplace(boff + r, blen - r);
+		if (blen > r) S.ext.emplace(boff + r, Ext{ blen - r, old.owner, old.clock });
 		S.free_bytes -= r;
 		*out = S.base + boff;
 		return true;
 	}
-	hipError_t get(uint64_t bytes, void** out, uint64_t* got)
+	hipError_t get(uint64_t bytes, void** out, uint64_t* got, int32_t who)
 	{
 		static const bool dbg = getenv("COLORD_HIP_POOL_DEBUG") != nullptr;
 		std::unique_lock<std::mutex> lock(mu);
 		const uint64_t r = (bytes + ALIGN - 1) / ALIGN * ALIGN + PAD;          // (the pad keeps a kernel's vector load past its last element inside the block)
 		*got = r;
-		if (!carve(r, out))
+		int32_t foreign = -1;
+		bool ok = carve(r, who, out, &foreign);
+		if (!ok)
+		{
+			for (size_t i = 0; i < owners.size(); ++i) if (owners[i]) poll_fences_locked((int32_t)i);
+			coalesce_locked();
+			ok = carve(r, who, out, &foreign);
+		}
+		for (int tries = 0; !ok && foreign >= 0 && tries < 8; ++tries)
+		{	// memory that would do was released by another context whose kernels may still be using it: wait for that context's streams
+			// (not the device), then it is anybody's
+			cl_ctx* oc = owners[foreign];
+			const uint64_t upto = clock;
+			++n_drains;
+			lock.unlock();
+			if (oc) cl_ctx_drain(oc);
+			lock.lock();
+			if (drained[foreign] < upto) drained[foreign] = upto;
+			coalesce_locked();
+			ok = carve(r, who, out, &foreign);
+		}
+		if (!ok)
 		{
 			const uint64_t g = 2ull << 20;
-			uint64_t sz = std::max<uint64_t>(r, std::min<uint64_t>(std::max<uint64_t>(reserved / 4, SLAB_MIN), SLAB_MAX));
-			sz = (sz + g - 1) / g * g;
-			if (sz >= (4ull << 30))
-			{	// a large slab joins: smaller slabs that lie entirely free did not serve this request and rarely serve the next
-				for (size_t i = slabs.size(); i-- > 0;) if (slabs[i].free_bytes == slabs[i].size && slabs[i].size < sz)
-				{ (void)hipFree(slabs[i].base); reserved -= slabs[i].size; slabs.erase(slabs.begin() + i); }
+			// Few, large slabs: a new one is as large as everything the pool holds already (1 GB at least, 48 GB at most, a
+			// large request with an eighth to spare: request sizes creep from chunk to chunk), within what the device has free.
+			uint64_t sz = std::max<uint64_t>(r + r / 8, std::min<uint64_t>(std::max<uint64_t>(reserved, 1ull << 30), 48ull << 30));
+			{
+				size_t fr = 0, tot = 0;
+				if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr > (3ull << 30) && sz > fr - (2ull << 30)) sz = std::max<uint64_t>(r, fr - (2ull << 30));
+				else (void)hipGetLastError();
 			}
-			make_room(lock, sz, dbg);
-			if (carve(r, out)) { live_bytes += r; if (live_bytes > peak_live) peak_live = live_bytes; return hipSuccess; }      // (another thread may have released memory meanwhile)
+			sz = (sz + g - 1) / g * g;
+			make_room(sz, dbg);
 			void* base = nullptr;
 			hipError_t e = hipMalloc(&base, sz);
 			if (e != hipSuccess && sz > r + g)
 			{	// not even after making room: the request alone
 				(void)hipGetLastError();
 				sz = (r + g - 1) / g * g;
-				make_room(lock, sz, dbg);
+				make_room(sz, dbg);
 				e = hipMalloc(&base, sz);
 			}
 			++n_mallocs;
 			if (dbg) fprintf(stderr, "[pool] slab of %.3f GB (%s) for a block of %.3f GB; live %.3f GB, reserved %.3f GB in %zu slabs\n", sz / 1e9, e == hipSuccess ? "ok" : "failed", r / 1e9, live_bytes / 1e9, reserved / 1e9, slabs.size());
 			if (e != hipSuccess) { (void)hipGetLastError(); return e; }
-			Slab S; S.base = (char*)base; S.size = sz; S.free_bytes = sz; S.ext.emplace(0, sz);
+			Slab S; S.base = (char*)base; S.size = sz; S.free_bytes = sz; S.ext.emplace(0, Ext{ sz, -1, 0 });
 			slabs.push_back(std::move(S));
 			reserved += sz; if (reserved > peak_total) peak_total = reserved;
-			if (!carve(r, out)) return hipErrorOutOfMemory;
+			if (!carve(r, who, out, nullptr)) return hipErrorOutOfMemory;
 		}
 		live_bytes += r; if (live_bytes > peak_live) peak_live = live_bytes;
 		return hipSuccess;
 	}
-	void put(void* p, uint64_t r)
+	void put(void* p, uint64_t r, int32_t who)
 	{
 		std::lock_guard<std::mutex> lock(mu);
 		for (Slab& S : slabs)
 		{
 			if ((char*)p < S.base || (char*)p >= S.base + S.size) continue;
-			uint64_t off = (uint64_t)((char*)p - S.base), len = r;
+			uint64_t off = (uint64_t)((char*)p - S.base);
+			Ext me{ r, who, ++clock };
 			auto nx = S.ext.lower_bound(off);
-			if (nx != S.ext.begin()) { auto pv = std::prev(nx); if (pv->first + pv->second == off) { off = pv->first; len += pv->second; S.ext.erase(pv); } }
-			if (nx != S.ext.end() && off + len == nx->first) { len += nx->second; S.ext.erase(nx); }
-			S.ext.emplace(off, len);
+			if (nx != S.ext.begin()) { auto pv = std::prev(nx); if (pv->first + pv->second.len == off && pv->second.owner == who) { off = pv->first; me.len += pv->second.len; S.ext.erase(pv); } }
+			if (nx != S.ext.end() && off + me.len == nx->first && nx->second.owner == who) { me.len += nx->second.len; S.ext.erase(nx); }
+			S.ext.emplace(off, me);
 			S.free_bytes += r; live_bytes -= r;
+			if (who >= 0 && owners[who] && (++since_fence[who] >= 8 || r >= (64ull << 20)))
+			{
+				since_fence[who] = 0;
+				poll_fences_locked(who);
+				if (fences[who].size() < 64)
+				{
+					Fence f; f.clock = clock; f.n = 0;
+					for (int i = 0; i < 4; ++i) { if (spare_events.empty()) { hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); break; } spare_events.push_back(e); } f.ev[i] = spare_events.back(); spare_events.pop_back(); }
+					f.n = cl_ctx_fence(owners[who], f.ev);
+					for (int i = f.n; i < 4; ++i) spare_events.push_back(f.ev[i]);
+					if (f.n > 0) fences[who].push_back(f);
+				}
+			}
 			return;
 		}
-		fprintf(stderr, "colord_hip: pool released a block it does not own\n");
+		if (reserved) fprintf(stderr, "colord_hip: pool released a block it does not own\n");
 	}
 	void trim()
 	{
 		std::lock_guard<std::mutex> lock(mu);
-		if (getenv("COLORD_HIP_POOL_DEBUG")) fprintf(stderr, "[pool] at trim: peak live %.1f GB, peak reserved %.1f GB, reserved %.1f GB in %zu slabs, %u hipMalloc calls, still live %.3f GB\n", peak_live / 1e9, peak_total / 1e9, reserved / 1e9, slabs.size(), n_mallocs, live_bytes / 1e9);
+		if (getenv("COLORD_HIP_POOL_DEBUG")) fprintf(stderr, "[pool] at trim: peak live %.1f GB, peak reserved %.1f GB, reserved %.1f GB in %zu slabs, %u hipMalloc calls, %u waits for another context's streams, still live %.3f GB\n", peak_live / 1e9, peak_total / 1e9, reserved / 1e9, slabs.size(), n_mallocs, n_drains, live_bytes / 1e9);
 		for (auto& S : slabs) (void)hipFree(S.base);
 		slabs.clear(); reserved = 0;
 	}
@@ -154,9 +242,32 @@ struct DevPool {
 
 static inline bool cl_pool_debug() { static const bool dbg = getenv("COLORD_HIP_POOL_DEBUG") != nullptr; return dbg; }
 
+// the pool of a device, shared by every context on it; given back to the driver when the last of them goes
+struct DevicePools { std::mutex mu; std::map<int, std::pair<DevPool*, int>> by_dev; };
+inline DevicePools& cl_device_pools() { static DevicePools* p = new DevicePools; return *p; }
+inline DevPool& cl_device_pool_acquire(int device)
+{
+	DevicePools& D = cl_device_pools();
+	std::lock_guard<std::mutex> l(D.mu);
+	auto& e = D.by_dev[device];
+	if (!e.first) e.first = new DevPool();
+	++e.second;
+	return *e.first;
+}
+inline void cl_device_pool_release(int device)
+{
+	DevicePools& D = cl_device_pools();
+	std::lock_guard<std::mutex> l(D.mu);
+	auto it = D.by_dev.find(device);
+	if (it == D.by_dev.end()) return;
+	if (--it->second.second == 0) it->second.first->trim();                   // (the pool object stays: buffers released late still find it)
+}
+
 struct cl_ctx {
-	DevPool pool;
+	DevPool& pool;
 	int device = 0;
+	int32_t pool_id = -1;                        // this context as an owner of free extents of the shared pool
+	explicit cl_ctx(int dev) : pool(cl_device_pool_acquire(dev)), device(dev) { pool_id = pool.add_owner(this); }
 	hipStream_t stream = nullptr;
 	hipStream_t side = nullptr;                  // second stream for chains that would leave the machine idle (created on first use)
 	hipStream_t side2 = nullptr;                 // third stream: the four-per-wave aligner next to the tail-bound wave-per-gap one
@@ -187,21 +298,21 @@ static inline cl_status cl_fail(cl_ctx* c, cl_status s, const std::string& msg)
 
 // ---- device buffers (RAII, freed with the owning object) -----------------------------------------
 template<typename T> struct DevBuf {
-	T* p = nullptr; uint64_t n = 0; uint64_t bytes = 0; DevPool* pool = nullptr;
+	T* p = nullptr; uint64_t n = 0; uint64_t bytes = 0; DevPool* pool = nullptr; int32_t owner = -1;
 	DevBuf() = default;
 	DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
-	DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n), bytes(o.bytes), pool(o.pool) { o.p = nullptr; o.n = 0; }
-	DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; bytes = o.bytes; pool = o.pool; o.p = nullptr; o.n = 0; } return *this; }
+	DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n), bytes(o.bytes), pool(o.pool), owner(o.owner) { o.p = nullptr; o.n = 0; }
+	DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; bytes = o.bytes; pool = o.pool; owner = o.owner; o.p = nullptr; o.n = 0; } return *this; }
 	~DevBuf() { release(); }
-	void release() { if (p) { if (pool) pool->put(p, bytes); else (void)hipFree(p); } p = nullptr; n = 0; }
+	void release() { if (p) { if (pool) pool->put(p, bytes, owner); else (void)hipFree(p); } p = nullptr; n = 0; }
 	hipError_t alloc(cl_ctx* c, uint64_t count);
 };
 template<typename T> hipError_t DevBuf<T>::alloc(cl_ctx* c, uint64_t count)
 {
 	release(); n = count; if (!count) count = 1;
-	pool = &c->pool;
+	pool = &c->pool; owner = c->pool_id;
 	void* q = nullptr;
-	hipError_t e = pool->get(count * sizeof(T), &q, &bytes);
+	hipError_t e = pool->get(count * sizeof(T), &q, &bytes, owner);
 	p = (T*)q;
 	if (e != hipSuccess) { p = nullptr; n = 0; }
 	return e;
