@@ -8,9 +8,13 @@ plus raw quality bytes (cut in chunks of ~1 Gbase, the unit the streaming compre
     pass 2a  a4 accepted k-mers, a6 acceptor, a7 reference-read store, a5 k-mer -> reference-reads index over the whole input
     pass 2b  per chunk: a5 candidates, a8 m-mer anchors, a10/a11 gap alignment + cost decisions + recursion, a12 tuples,
              a14/a16 `dna` stream parts, a13/a15 `qual` stream parts (4-avg, level 1) with coders that persist across chunks
+The step ends with every compressed part in (pinned) HOST memory — SURVEY §8d's T_core: each chunk's parts are copied out while the
+next chunk is coded (double-buffered staging on the device, a copy stream).
 With N > 1 the reads are sharded in file order (total work fixed: "scaling": "strong"), the k-mer set, the reference reads and
 the index are replicated through the two exchanges of SURVEY.md §8e (RCCL via torch.distributed), and the compressed parts
 are gathered to rank 0 inside the step.  Not in the step: FASTQ parsing, the header (ID) stream, the archive container.
+After the timed steps the output is checked: the first `dna` parts of the last pass are decoded by the library's host decoder
+(cl_dna_decode_part) and compared with the generator's bases (`round_trip_checked`).
 
 Also in the JSON line: `archive_vs_ref` — on a bounded sample of the same recipe, written as FASTQ by the host form of the
 generator (bit-identical to the device form), the archive of `colord_amd/colord_hip` (same library, reference part cut)
@@ -32,7 +36,7 @@ T_PROCESS_START = time.time()
 # The pipeline keeps up to ten HIP streams busy (three contexts with side streams, the encode lane); with the runtime's default
 # of 4 hardware queues, streams that share a queue serialise (measured at 50 Gbases: 41.4 s/step with 4, 39.6 with 8, 39.3 with
 # 16).  Read by the HIP runtime when it initialises, so it has to be in the environment before the first HIP call.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -55,7 +59,7 @@ def parse():
     ap.add_argument("--chunk-bases", type=float, default=1.0e9, help="bases per chunk of the streaming compressor")
     ap.add_argument("--k", type=int, default=0, help="k-mer length; 0 = the reference's choice for this input size (compression.cpp:62-93)")
     ap.add_argument("--a", type=int, default=0, help="anchor length; 0 = the reference's choice")
-    ap.add_argument("--cpu-sample-bases", type=float, default=3.0e8)
+    ap.add_argument("--cpu-sample-bases", type=float, default=1.0e9, help="bases of the sample the reference (CPU baseline) and the archive-size check run on, at the k / a of the main run")
     ap.add_argument("--pack-symbols", type=int, default=1 << 16,
                     help="part (= range-coder restart) size in symbols.  4194304 reproduces the reference's packs (defs.h:45) and its exact "
                          "bytes; smaller parts are equally valid archives (the reference decoder follows the part table), cost 8 flush "
@@ -185,9 +189,49 @@ def _device_lengths(table, device, r0, r1):
     return out.cpu().numpy().view(np.uint32)
 
 
-def hot_path_step(ctx, qctx, shard: Shard, prm: dict, with_qual: bool, exchange, dna_out, qual_out, expected_bases: int, ref_cut: bool = False):
+class HostSink:
+    """Where the parts of a pass end up: pinned host buffers, filled chunk by chunk from two staging buffers per stream on the
+    device while the next chunk is coded (a copy stream of its own; a staging buffer is reused two chunks later, after its copy)."""
+
+    def __init__(self, device, dna_cap: int, qual_cap: int, stage_dna: int, stage_qual: int):
+        self.device = device
+        self.h_dna = torch.empty(dna_cap, dtype=torch.uint8, pin_memory=True)
+        self.h_qual = torch.empty(qual_cap, dtype=torch.uint8, pin_memory=True) if qual_cap else None
+        self.d_dna = [torch.empty(stage_dna, dtype=torch.uint8, device=device) for _ in range(2)]
+        self.d_qual = [torch.empty(stage_qual, dtype=torch.uint8, device=device) for _ in range(2)] if qual_cap else None
+        self.stream = torch.cuda.Stream(device)
+        self.events = [None, None]
+        self.reset()
+
+    def reset(self):
+        self.do = self.qo = self.i = 0
+        self.dna_sizes, self.qual_sizes = [], []
+
+    def stage(self):
+        k = self.i & 1
+        if self.events[k] is not None:
+            self.events[k].synchronize()                    # the copy out of this buffer, two chunks ago
+        return self.d_dna[k], (self.d_qual[k] if self.d_qual is not None else None)
+
+    def take(self, n_dna: int, n_qual: int, dsz, qsz):
+        k = self.i & 1
+        with torch.cuda.stream(self.stream):                 # (encode() returned: the parts are complete)
+            self.h_dna[self.do:self.do + n_dna].copy_(self.d_dna[k][:n_dna], non_blocking=True)
+            if self.h_qual is not None and n_qual:
+                self.h_qual[self.qo:self.qo + n_qual].copy_(self.d_qual[k][:n_qual], non_blocking=True)
+            ev = torch.cuda.Event(); ev.record(self.stream)
+        self.events[k] = ev
+        self.do += n_dna; self.qo += n_qual; self.i += 1
+        self.dna_sizes.append(np.array(dsz, dtype=np.uint64)); self.qual_sizes.append(np.array(qsz, dtype=np.uint64))
+
+    def finish(self):
+        self.stream.synchronize()
+
+
+def hot_path_step(ctx, qctx, shard: Shard, prm: dict, with_qual: bool, exchange, dna_out, qual_out, expected_bases: int, ref_cut: bool = False, sink: "HostSink | None" = None):
     """One pass of the whole compress data path over the shard (all chunks).  Returns sizes for reporting.
-    ref_cut: the coder parts are the reference's reader packs (4 Mi symbols) instead of the bench's --pack-symbols."""
+    ref_cut: the coder parts are the reference's reader packs (4 Mi symbols) instead of the bench's --pack-symbols.
+    sink: the parts go to host memory chunk by chunk (T_core); else they stay in dna_out / qual_out on the device."""
     from colord_amd import parallel as par
     qa = (2, 0, 1, (7, 14, 26), ()) if with_qual else None       # ONT default: 4-avg at level 1 (arg_parse.cpp:410-450)
     cmp_ = ctx.compressor(prm, qa, qctx, exchange, expected_bases=expected_bases)
@@ -200,14 +244,24 @@ def hot_path_step(ctx, qctx, shard: Shard, prm: dict, with_qual: bool, exchange,
         cmp_.refs_finish()
         do, qo = 0, 0
         tot = dict(n_anchors=0, tuple_bytes=0, dna_bytes=0, qual_bytes=0)
+        if sink is not None:
+            sink.reset()
         if not os.environ.get("BENCH_NO_LOOKAHEAD"):
             for ch in shard.chunks:                          # every chunk is resident: announce them all, the lanes keep lanes + 1 ahead
                 cmp_.prepare(ch[0], ch[2], ch[2] if ref_cut else ch[1], ch[3] if with_qual else None, ch[4])
         for arena, parts, est, quals, off in shard.chunks:
-            _, _, _, _, inf = cmp_.encode(arena, est if ref_cut else parts, est, quals, off, dna_out[do:], qual_out[qo:] if with_qual else None)
+            if sink is not None:
+                d_dst, q_dst = sink.stage()
+            else:
+                d_dst, q_dst = dna_out[do:], (qual_out[qo:] if with_qual else None)
+            _, dsz, _, qsz, inf = cmp_.encode(arena, est if ref_cut else parts, est, quals, off, d_dst, q_dst if with_qual else None)
+            if sink is not None:
+                sink.take(inf["dna_bytes"], inf["qual_bytes"], dsz, qsz)
             do += inf["dna_bytes"]; qo += inf["qual_bytes"]
             for k_ in tot:
                 tot[k_] += inf[k_]
+        if sink is not None:
+            sink.finish()
         info = cmp_.info()
     except Exception:
         if exchange is not None and exchange.err is not None:
@@ -224,10 +278,46 @@ def hot_path_step(ctx, qctx, shard: Shard, prm: dict, with_qual: bool, exchange,
                 anchors=tot["n_anchors"], tuple_bytes=tot["tuple_bytes"], dna_bytes=tot["dna_bytes"], qual_bytes=tot["qual_bytes"], parts=shard.n_parts, chunks=len(shard.chunks))
 
 
-def cpu_baseline_and_size_check(ctx, qctx, sample_bases: float, coverage: float, pack_symbols: int):
+def round_trip_check(ctx, table, shard: Shard, sink: HostSink, prm: dict, info: dict, r0: int, max_bases: float = 3.0e8):
+    """Decodes the first `dna` parts of the pass that is in `sink` (host memory) with the library's host decoder — the inverse
+    path, csrc/decode.hip — and compares the bases with the generator's.  (A part needs every reference read before it, so the
+    check runs from the start of the stream; its length is bounded by the decoder's speed, ~40 Mbases/s on one host thread.)"""
+    import ctypes as C
+    from colord_amd import _native as N, ontsim
+    lib = N.load()
+    d = N._P()
+    if lib.cl_dna_decoder_create(prm["c"], prm["level"], 0, 0, 0 if prm["sparse"] else 1, int(info["sparse_range"]), float(prm["sparse_exponent"]), C.byref(d)) != 0:
+        return {"ok": False, "why": "cl_dna_decoder_create"}
+    arena, parts = shard.chunks[0][0], shard.chunks[0][1]
+    sizes = sink.dna_sizes[0]
+    h = sink.h_dna.numpy()
+    t0 = time.time()
+    o = 0; n_reads = 0; n_bases = 0; ok = True; why = ""
+    codes, off, _ = ontsim.device_reads(table, ctx.device, r0, r0 + int(arena.n_reads), with_quals=False)
+    codes, off = codes.cpu().numpy(), off.cpu().numpy()
+    for p in range(len(parts) - 1):
+        nr = int(parts[p + 1] - parts[p]); sz = int(sizes[p])
+        exp = codes[off[parts[p]]:off[parts[p + 1]]]
+        buf = np.ascontiguousarray(h[o:o + sz])
+        out = np.empty(len(exp) + 64, np.uint8); offs = np.zeros(nr + 1, np.uint64); got = C.c_uint64(0)
+        st = lib.cl_dna_decode_part(d, buf.ctypes.data, sz, nr, out.ctypes.data, len(out), offs.ctypes.data, C.byref(got))
+        if st != 0 or got.value != len(exp) or not np.array_equal(out[:len(exp)] & 7, exp):
+            ok = False; why = f"part {p}: status {st}, {got.value} bases decoded, {len(exp)} expected"
+            break
+        o += sz; n_reads += nr; n_bases += len(exp)
+        if n_bases >= max_bases:
+            break
+    lib.cl_dna_decoder_free(d)
+    return {"ok": ok, "why": why, "parts": p + 1, "reads": n_reads, "bases": n_bases, "seconds": round(time.time() - t0, 1),
+            "what": "the first `dna` parts of the last timed pass, host memory -> cl_dna_decode_part -> compared with the generator's bases"}
+
+
+def cpu_baseline_and_size_check(ctx, qctx, sample_bases: float, coverage: float, pack_symbols: int, k: int, a: int):
     """The UNMODIFIED reference binary (oracle/_ref/colord, built by oracle/Makefile.ref) timed on this host's cores on a
     bounded sample of the same synthetic recipe, and — on the very same FASTQ — the archive of colord_hip (this library)
-    against the reference's archive: the second half of the metric."""
+    against the reference's archive: the second half of the metric.  Both compressors get the k-mer and anchor lengths of the main
+    run (`-k`, `-a`: at 50 Gbases the reference picks k = 25 / a = 22, compression.cpp:84-88; for the sample's own size it would
+    pick shorter ones), so the archive comparison and the baseline are at the parameters the headline number is measured with."""
     from colord_amd import ontsim, archive as AR
     ref = os.path.join(ROOT, "oracle", "_ref", "colord")
     ours = os.path.join(ROOT, "colord_amd", "colord_hip")
@@ -239,19 +329,20 @@ def cpu_baseline_and_size_check(ctx, qctx, sample_bases: float, coverage: float,
         fq = os.path.join(tmp, "sample.fastq")
         n_bases = ontsim.write_fastq(table, fq)
         t0 = time.time()
-        subprocess.check_call([ref, "compress-ont", "-t", str(cores), fq, os.path.join(tmp, "ref.colord")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        ka = ["-k", str(k), "-a", str(a)]
+        subprocess.check_call([ref, "compress-ont", "-t", str(cores)] + ka + [fq, os.path.join(tmp, "ref.colord")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         dt = time.time() - t0
         ref_size = os.path.getsize(os.path.join(tmp, "ref.colord"))
         ref_arc = AR.read_archive(os.path.join(tmp, "ref.colord"))
         ref_streams = {n: sum(len(p) for _, p in s.parts) for n, s in ref_arc.items()}
         cb = {"value": n_bases / dt / 1e9, "unit": "Gbases/s", "cores": cores, "kind": "reference",
-              "sample": f"oracle/_ref/colord compress-ont -t {cores} on {n_bases} synthetic ONT bases ({table.n_reads} reads, same recipe, genome {table.genome_len} bp), "
+              "sample": f"oracle/_ref/colord compress-ont -t {cores} -k {k} -a {a} on {n_bases} synthetic ONT bases ({table.n_reads} reads, same recipe, genome {table.genome_len} bp), "
                         f"whole compressor (parsing, header stream and archive included); {dt:.2f} s wall, archive {ref_size} B = {ref_size / n_bases:.4f} B/base"}
-        size = {"sample_bases": n_bases, "ref_archive_bytes": ref_size, "ref_dna_bytes": ref_streams.get("dna"), "ref_qual_bytes": ref_streams.get("qual")}
+        size = {"sample_bases": n_bases, "k": k, "a": a, "ref_archive_bytes": ref_size, "ref_dna_bytes": ref_streams.get("dna"), "ref_qual_bytes": ref_streams.get("qual")}
         # (1) the command-line compressor of this build on the same file: whole archive, reference part cut
         if os.path.exists(ours):
             t0 = time.time()
-            r = subprocess.run([ours, "compress-ont", fq, os.path.join(tmp, "hip.colord")], capture_output=True, text=True)
+            r = subprocess.run([ours, "compress-ont"] + ka + [fq, os.path.join(tmp, "hip.colord")], capture_output=True, text=True)
             if r.returncode == 0:
                 hs = os.path.getsize(os.path.join(tmp, "hip.colord"))
                 arc = AR.read_archive(os.path.join(tmp, "hip.colord"))
@@ -261,7 +352,6 @@ def cpu_baseline_and_size_check(ctx, qctx, sample_bases: float, coverage: float,
             else:
                 size["cli_error"] = (r.stderr or r.stdout)[-300:]
         # (2) the bench path itself (device generator, chunked compressor) on the same reads, with the bench's part cut and with the reference's
-        k, a = kmer_anchor_len(0.49 * os.path.getsize(fq))
         for cut, name in ((1 << 22, "ref_cut"), (pack_symbols, f"cut_{pack_symbols}")):
             shard = Shard(ctx, table, 0, table.n_reads, 1e9, cut, True)
             dna_out = torch.empty(int(shard.n_bases * 0.5) + (1 << 20), dtype=torch.uint8, device=ctx.device)
@@ -334,8 +424,16 @@ def main():
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_gen
     torch.cuda.empty_cache()                                # the generator's temporaries go back to the device (the library has its own pools)
-    dna_out = torch.empty(int(shard.n_bases * 0.20) + (1 << 26), dtype=torch.uint8, device=ctx.device)
-    qual_out = None if args.no_qual else torch.empty(int(shard.n_bases * 0.26) + (1 << 26), dtype=torch.uint8, device=ctx.device)
+    # where the parts go: at N = 1 to pinned host memory chunk by chunk, through two staging buffers per stream on the device (the step
+    # ends with the parts in host memory); at N > 1 they stay on the device for the gather to rank 0
+    sink, dna_out, qual_out = None, None, None
+    if world == 1:
+        cb = max((int(c[0].total_bases) for c in shard.chunks), default=0)
+        sink = HostSink(ctx.device, int(shard.n_bases * 0.20) + (1 << 26), 0 if args.no_qual else int(shard.n_bases * 0.26) + (1 << 26),
+                        int(cb * 0.30) + (1 << 24), int(cb * 0.36) + (1 << 24))
+    else:
+        dna_out = torch.empty(int(shard.n_bases * 0.20) + (1 << 26), dtype=torch.uint8, device=ctx.device)
+        qual_out = None if args.no_qual else torch.empty(int(shard.n_bases * 0.26) + (1 << 26), dtype=torch.uint8, device=ctx.device)
     exchange = par.TorchExchange(ctx.device) if world > 1 else None
     prm = params_for(k, a)
 
@@ -346,7 +444,7 @@ def main():
             torch.cuda.synchronize()
 
     def step():
-        return hot_path_step(ctx, qctx, shard, prm, not args.no_qual, exchange, dna_out, qual_out, shard.n_bases)
+        return hot_path_step(ctx, qctx, shard, prm, not args.no_qual, exchange, dna_out, qual_out, shard.n_bases, sink=sink)
 
     for w in range(args.warmup):
         t_w = time.perf_counter()
@@ -405,29 +503,35 @@ def main():
         # the same input once more in the byte-identical mode: coder parts = the reference's reader packs (4 Mi symbols; each part is
         # one dependent chain of the interval coder, 64 times longer than with the bench's default cut) — when the deadline allows
         ref_cut = None
+        rt = None
         if world == 1 and not args.no_ref_cut and args.pack_symbols != (1 << 22):
             left = args.deadline_s - (time.time() - T_PROCESS_START) - reserve_s
             if left > 4.0 * (dt / args.steps):
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                inf2 = hot_path_step(ctx, qctx, shard, prm, not args.no_qual, None, dna_out, qual_out, shard.n_bases, ref_cut=True)
+                rt = round_trip_check(ctx, table, shard, sink, prm, info, r0) if sink is not None else None   # (before the sink is overwritten)
+                inf2 = hot_path_step(ctx, qctx, shard, prm, not args.no_qual, None, dna_out, qual_out, shard.n_bases, ref_cut=True, sink=sink)
                 torch.cuda.synchronize()
                 dt2 = time.perf_counter() - t1
                 ref_cut = {"part_symbols": 1 << 22, "ms_per_step": dt2 * 1e3, "value": total_bases / dt2 / 1e9, "unit": "Gbases/s", "steps": 1,
                            "dna_bytes": inf2["dna_bytes"], "qual_bytes": inf2["qual_bytes"], "parts": sum(len(c[2]) - 1 for c in shard.chunks),
                            "stream_bytes_vs_default_cut": (inf2["dna_bytes"] + inf2["qual_bytes"]) / max(1, total_dna + total_qual),
                            "note": "same input, one pass, coder parts = the reference's reader packs: the streams are the reference's bytes (size_check.streams_vs_ref_ref_cut)"}
+        if rt is None and sink is not None:
+            rt = round_trip_check(ctx, table, shard, sink, prm, info, r0)
+        timer_txt = ("T_core (SURVEY 8d): packed bases + quality bytes resident in HBM -> every compressed part in pinned host memory" if sink is not None
+                     else "packed bases + quality bytes resident in HBM -> every compressed part gathered to rank 0 (device)")
         cb, size = (None, None)
         if not args.no_cpu_baseline and world == 1:
             shard.free()                                    # the sample runs (and the command-line compressor) need the memory:
-            del dna_out, qual_out                           # give everything back, pools included, and start from fresh contexts
+            del dna_out, qual_out, sink                     # give everything back, pools included, and start from fresh contexts
             ctx.close()
             if qctx is not None:
                 qctx.close()
             torch.cuda.empty_cache()
             ctx = Context(local)
             qctx = Context(local) if qctx is not None else None
-            cb, size = cpu_baseline_and_size_check(ctx, qctx, args.cpu_sample_bases, args.coverage, args.pack_symbols)
+            cb, size = cpu_baseline_and_size_check(ctx, qctx, args.cpu_sample_bases, args.coverage, args.pack_symbols, k, a)
         value = total_bases * args.steps / dt / 1e9
         line = {
             "metric": "input Gbases/s + archive size vs ref, ONT 50 Gb at 1/2/4/8 MI355X", "value": value,
@@ -436,6 +540,8 @@ def main():
             "vs_baseline_note": "BASELINE.md §1: 0.030 Gbases/s derived from the reference README's time and size for its `memory` preset (human ONT, "
                                 "whole program, hardware not stated) — the only published figure; the measured reference on this host is `cpu_baseline`",
             "archive_vs_ref": (size or {}).get("archive_vs_ref"),
+            "round_trip_checked": bool(rt and rt.get("ok")), "round_trip": rt,
+            "timer": timer_txt,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"synthetic ONT {total_bases / 1e9:.2f} Gbases ({total_reads} reads, N50~20kb, 4-avg quals), genome {genome_len} bp, "
                                    f"k={k} a={a} f={PRESET['f']} ci={PRESET['ci']} cs={PRESET['cs']} c={PRESET['c']} (compress-ont default preset)"

@@ -9,7 +9,7 @@ import os
 
 # more hardware queues than the HIP runtime's default of 4: the contexts of one compressor keep up to ten streams busy and
 # streams that share a queue serialise (bench.py has the measurement); only effective before the runtime initialises
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcolord_hip.so")
 

@@ -11,7 +11,7 @@ int run_info(int argc, char** argv);
 
 int main(int argc, char** argv)
 {
-	setenv("GPU_MAX_HW_QUEUES", "16", 0);            // before the HIP runtime starts: the compressor's contexts keep more than 4 streams busy
+	setenv("GPU_MAX_HW_QUEUES", "32", 0);            // before the HIP runtime starts: the compressor's contexts keep more than 4 streams busy
 	const std::string cmd = argc >= 2 ? argv[1] : "";
 	if (cmd == "decompress") return run_decompress(argc, argv);
 	if (cmd == "info") return run_info(argc, argv);

@@ -629,7 +629,14 @@ extern "C" cl_status cl_compressor_prepare_parts(cl_compressor* c, const cl_read
 		return cl_fail(ctx, CL_E_INVALID, "cl_compressor_prepare: chunks must be announced in the order and sizes of pass 1, before they are encoded");
 	if (c->lane_ctx.empty())
 	{
+		// two lanes, a third when the device has the memory for it (~25 GB per lane and 1-Gbase chunk; measured at 50 Gbases: 20.5 s per
+		// pass with two, 19.3 with three, out of memory with four)
 		uint32_t lanes = 2;
+		{
+			size_t fr = 0, tot = 0;
+			if (hipMemGetInfo(&fr, &tot) == hipSuccess) { const uint64_t avail = fr + (ctx->pool.reserved - std::min(ctx->pool.reserved, ctx->pool.live_bytes)); if (avail > (80ull << 30)) lanes = 3; }
+			else (void)hipGetLastError();
+		}
 		if (const char* e = getenv("COLORD_HIP_ENCODE_LANES")) lanes = (uint32_t)std::min(4, std::max(1, atoi(e)));
 		while (ctx->lanes.size() < lanes)
 		{
