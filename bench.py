@@ -480,6 +480,11 @@ def main():
     dt = float(tdev.item())
     total_bases, total_dna, total_qual, total_reads = (int(x) for x in tb.tolist())
 
+    from colord_amd.device import _check
+    torch.cuda.synchronize()
+    for c_ in (ctx, qctx):                                  # (the kernel times of what completed last: collection never waits)
+        if c_ is not None:
+            _check(c_, 0)
     times = StepTimes(ctx, qctx)
     if rank == 0:
         # dominant kernel by measured HIP-event time on the context streams; `achieved` = the library's algorithmic HBM

@@ -70,7 +70,7 @@ extern "C" cl_status cl_ctx_last_kernel_ms(const cl_ctx* c, const char* kernel, 
 extern "C" cl_status cl_ctx_kernel_times(cl_ctx* c, char* buf, uint64_t cap, uint64_t* needed)
 {
 	if (!c) return CL_E_INVALID;
-	cl_timing_collect(c);
+	cl_timing_collect(c);                                                      // (what has completed: never a wait — callers ask after every stage, and a coder of the next chunk may be running)
 	std::string out;
 	for (auto& kv : c->times) out += kv.first + "\t" + std::to_string(kv.second.ms) + "\t" + std::to_string(kv.second.launches) + "\t" + std::to_string(kv.second.bytes) + "\n";
 	if (needed) *needed = out.size() + 1;

@@ -17,6 +17,8 @@
 #include <map>
 #include <deque>
 #include <mutex>
+#include <thread>
+#include <chrono>
 #include "../../include/colord_hip.h"
 
 #define CL_WAVE 64
@@ -192,7 +194,32 @@ struct DevPool {
 			}
 			++n_mallocs;
 			if (dbg) fprintf(stderr, "[pool] slab of %.3f GB (%s) for a block of %.3f GB; live %.3f GB, reserved %.3f GB in %zu slabs\n", sz / 1e9, e == hipSuccess ? "ok" : "failed", r / 1e9, live_bytes / 1e9, reserved / 1e9, slabs.size());
-			if (e != hipSuccess) { (void)hipGetLastError(); return e; }
+			if (e != hipSuccess)
+			{	// The device is full.  Other contexts of this process hold most of it for a moment only (the look-ahead stages of
+				// cl_compressor): wait for what they release — up to a few seconds — before this becomes the caller's error.
+				(void)hipGetLastError();
+				bool got_it = false;
+				for (int tries = 0; tries < 150 && !got_it; ++tries)
+				{
+					lock.unlock();
+					std::this_thread::sleep_for(std::chrono::milliseconds(20));
+					lock.lock();
+					for (size_t i = 0; i < owners.size(); ++i) if (owners[i]) poll_fences_locked((int32_t)i);
+					coalesce_locked();
+					int32_t fo = -1;
+					got_it = carve(r, who, out, &fo);
+					if (!got_it && fo >= 0 && (tries & 7) == 7)
+					{	// (something fits but its owner has not passed a fence since: wait for that owner's streams)
+						cl_ctx* oc = owners[fo]; const uint64_t upto = clock;
+						lock.unlock(); if (oc) cl_ctx_drain(oc); lock.lock();
+						if (drained[fo] < upto) drained[fo] = upto;
+					}
+				}
+				if (!got_it) return e;
+				if (dbg) fprintf(stderr, "[pool] no slab of %.3f GB to be had: waited for a block of %.3f GB\n", sz / 1e9, r / 1e9);
+				live_bytes += r; if (live_bytes > peak_live) peak_live = live_bytes;
+				return hipSuccess;
+			}
 			Slab S; S.base = (char*)base; S.size = sz; S.free_bytes = sz; S.ext.emplace(0, Ext{ sz, -1, 0 });
 			slabs.push_back(std::move(S));
 			reserved += sz; if (reserved > peak_total) peak_total = reserved;
@@ -350,20 +377,32 @@ struct KernelTimer {
 #define LAUNCHB_SHM(ctx, bytes, kernel, grid, block, shm, ...) do { (ctx)->next_bytes = (double)(bytes); KernelTimer _kt((ctx), #kernel); \
 	hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (shm), (ctx)->stream, __VA_ARGS__); } while (0)
 static inline void cl_timing_begin(cl_ctx*) {}   // times accumulate until cl_ctx_kernel_times reports them
-static inline void cl_timing_collect(cl_ctx* c)
+// Adds what has COMPLETED to the kernel times (wait = true: everything; cl_ctx_kernel_times).  Never a wait by default: the events
+// of an interval coder that is still running for the next batch (cl_dna_evolve_ahead) stay pending — waiting for them here, at
+// the end of every stage, serialised the coders of consecutive chunks.
+static inline void cl_timing_collect(cl_ctx* c, bool wait = false)
 {
 	if (!c->timing) return;
-	size_t pi = 0;
-	for (auto& p : c->pending)
+	size_t keep = 0;
+	for (size_t i = 0; i < c->pending.size(); ++i)
 	{
-		(void)hipEventSynchronize(p.second.second);
+		auto& p = c->pending[i];
+		bool done = true;
+		if (wait) (void)hipEventSynchronize(p.second.second);
+		else if (hipEventQuery(p.second.second) != hipSuccess) { (void)hipGetLastError(); done = false; }
+		if (!done)
+		{
+			if (keep != i) { c->pending[keep] = std::move(p); c->pending_bytes[keep] = c->pending_bytes[i]; }
+			++keep;
+			continue;
+		}
 		float ms = 0; (void)hipEventElapsedTime(&ms, p.second.first, p.second.second);
 		std::string nm = p.first;
 		if (!nm.empty() && nm.front() == '(' && nm.back() == ')') nm = nm.substr(1, nm.size() - 2);
-		auto& t = c->times[nm]; t.ms += ms; t.launches += 1; t.bytes += c->pending_bytes[pi++];
+		auto& t = c->times[nm]; t.ms += ms; t.launches += 1; t.bytes += c->pending_bytes[i];
 		c->ev_pool.push_back(p.second.first); c->ev_pool.push_back(p.second.second);
 	}
-	c->pending.clear(); c->pending_bytes.clear();
+	c->pending.resize(keep); c->pending_bytes.resize(keep);
 }
 
 // ---- device primitives ---------------------------------------------------------------------------

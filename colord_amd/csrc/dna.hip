@@ -12,6 +12,9 @@
 #include "objects.hpp"
 #include "rc_dev.hpp"
 #include <algorithm>
+#include <deque>
+#include <thread>
+#include <chrono>
 
 namespace {
 enum { T_INS = 0, T_DEL, T_MATCH, T_SUBST, T_ANCHOR, T_SKIP, T_ALT_ID, T_MAIN_REF, T_PLAIN, T_START_PLAIN, T_START_ES, T_START_PLAIN_N, T_NONE };
@@ -914,6 +917,10 @@ struct cl_dna_coder {
 	uint32_t next_read_id = 0, next_prev_types = 0; bool next_valid = false;   // the same after the batch being coded (known once it is walked)
 	std::unique_ptr<DnaWalked> ahead;                                          // the next batch, walked ahead
 	std::function<cl_status()> before_tail;                                    // called by cl_dna_encode before it waits for its last interval coding
+	std::deque<std::unique_ptr<struct DnaEvolved>> evolved;                    // the next batches, their models evolved and their interval coders running (cl_dna_evolve_ahead)
+	uint32_t ahead_prev_types = 0, ahead_read_id = 0;                          // the walk scalars after the last batch evolved ahead
+	std::vector<hipStream_t> cstreams; uint32_t next_cstream = 0;              // streams of the interval coders: those of consecutive batches run side by side
+	~cl_dna_coder();
 };
 
 // CDNACoder::Init(true, max_no_alt_refs, level, ., start_read_id) (dna_coder.cpp:1242-1340)
@@ -971,9 +978,19 @@ struct SideSync { hipStream_t s = nullptr; ~SideSync() { if (s) (void)hipStreamS
 struct PendingGroup {
 	DevBuf<triple_t> trip; DevBuf<uint64_t> d_gbase, d_out_off, d_size, d_dst_off; DevBuf<uint32_t> d_plen; DevBuf<uint8_t> tmp;
 	std::vector<uint64_t> out_off; std::vector<uint32_t> rank; uint32_t p0 = 0, np = 0;   // rank: part -> place (descending length)
+	hipStream_t stream = nullptr;                   // where its interval coder runs
 	SideSync sync;                                  // destroyed first: nothing above is released while the side stream runs
 };
 } // namespace
+// A batch after the half of cl_dna_encode that touches the models: every group's triples are made and its interval coder is
+// running on a stream of the coder.  The interval arithmetic changes no model, so the NEXT batch can be taken this far while the
+// coders of this one — one dependent chain per part, 1.3 s for the reference's parts of 4 Mi symbols — are still at work.
+struct DnaEvolved {
+	const uint8_t* d_es = nullptr; uint32_t n_reads = 0, prev_types_in = 0, read_id_in = 0, prev_types_out = 0;
+	std::vector<uint32_t> part_bounds;
+	std::vector<std::unique_ptr<PendingGroup>> groups;
+};
+cl_dna_coder::~cl_dna_coder() { evolved.clear(); for (hipStream_t s : cstreams) (void)hipStreamDestroy(s); }
 
 namespace {
 // D1 for ALL reads of a batch at once: the walks are one lane per read and as long as the longest read's chain of tuples takes,
@@ -1140,55 +1157,24 @@ cl_status cl_dna_walk_ahead(cl_ctx* ctx, cl_dna_coder* D, const cl_reads* refs, 
 }
 void cl_dna_set_before_tail(cl_dna_coder* D, std::function<cl_status()> fn) { if (D) D->before_tail = std::move(fn); }
 
-// CEntrComprReads::Compress for a batch of whole parts (entr_read.h:56-80)
-extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads* refs, const uint8_t* d_es, const uint64_t* d_es_off,
-                                   const uint32_t* d_es_ntuples, uint32_t n_reads, const uint32_t* h_part_bounds, uint32_t n_parts,
-                                   uint8_t* d_out, uint64_t cap, uint64_t* h_part_sizes, uint64_t* n_out)
+namespace {
+// The model half of a batch: (walk and group preparation unless made ahead,) model evolution group by group, every group's
+// interval coder started on a stream of the coder.
+cl_status dna_evolve_batch(cl_ctx* ctx, cl_dna_coder* D, const cl_reads* refs, const uint8_t* d_es, const uint64_t* d_es_off, const uint32_t* d_es_ntuples, uint32_t n_reads,
+                           const uint32_t* h_part_bounds, uint32_t n_parts, std::unique_ptr<DnaWalked> Wp, uint32_t prev_types, uint32_t read_id, DnaEvolved& E)
 {
-	if (!ctx || !D || !refs || !d_es || !d_es_off || !d_es_ntuples || !h_part_bounds || !h_part_sizes || !n_out) return cl_fail(ctx, CL_E_INVALID, "cl_dna_encode: null argument");
-	HIP_TRY(ctx, hipSetDevice(ctx->device));
-	for (uint32_t p = 0; p < n_parts; ++p) if (h_part_bounds[p] > h_part_bounds[p + 1]) return cl_fail(ctx, CL_E_INVALID, "cl_dna_encode: part bounds must ascend");
-	if (n_parts && (h_part_bounds[0] != 0 || h_part_bounds[n_parts] != n_reads)) return cl_fail(ctx, CL_E_INVALID, "cl_dna_encode: parts must cover reads [0, n_reads)");
-	*n_out = 0;
-	if (!n_parts) return CL_OK;
 	const FamTab& f = D->ft;
-	uint64_t written = 0;
 	const uint64_t* inv_tab = nullptr;
 	CL_TRY(cl_inv_table(ctx, &inv_tab));
-	// D1 for ALL reads at once: the walks are one lane per read and as long as the longest read's chain of tuples takes,
-	// whatever the number of reads — so one count pass and one write pass per call, not per group.  Only what follows
-	// (sort, models, interval arithmetic) is grouped, by the 32-bit symbol / triple indices.
-	// the state-independent half: walked ahead by the caller of the batch before (cl_dna_walk_ahead), or here
-	std::unique_ptr<DnaWalked> Wp;
-	if (D->ahead && D->ahead->d_es == d_es && D->ahead->n_reads == n_reads && D->ahead->prev_types_in == D->prev_types && D->ahead->cur_read_id_in == D->cur_read_id) Wp = std::move(D->ahead);
-	D->ahead.reset();
 	// (groups sorted ahead hold for the part bounds they were made for; the keys are sorted in place, so with other bounds the walk is redone)
 	if (Wp && Wp->presorted && (Wp->part_bounds.size() != (size_t)n_parts + 1 || memcmp(Wp->part_bounds.data(), h_part_bounds, ((size_t)n_parts + 1) * 4) != 0)) Wp.reset();
-	if (!Wp) { Wp = std::make_unique<DnaWalked>(); CL_TRY(dna_walk(ctx, D, refs, d_es, d_es_off, d_es_ntuples, n_reads, D->prev_types, D->cur_read_id, *Wp)); }
+	if (!Wp) { Wp = std::make_unique<DnaWalked>(); CL_TRY(dna_walk(ctx, D, refs, d_es, d_es_off, d_es_ntuples, n_reads, prev_types, read_id, *Wp)); }
 	DnaWalked& W = *Wp;
 	DevBuf<uint64_t>& key = W.key;
 	DevBuf<uint32_t> err; DEV_ALLOC(ctx, err, 1);
 	HIP_TRY(ctx, hipMemsetAsync(err.p, 0, 4, ctx->stream));
-	D->next_prev_types = W.prev_types_out; D->next_read_id = D->cur_read_id + n_reads; D->next_valid = true;
-	struct NextOff { cl_dna_coder* D; ~NextOff() { D->next_valid = false; } } next_off{ D };
-	std::unique_ptr<PendingGroup> pending;
-	auto finish_group = [&](PendingGroup& g) -> cl_status {
-		HIP_TRY(ctx, hipStreamSynchronize(ctx->side));
-		g.sync.s = nullptr;
-		std::vector<uint64_t> size_r(g.np);                                      // by place
-		HIP_TRY(ctx, hipMemcpy(size_r.data(), g.d_size.p, g.np * 8, hipMemcpyDeviceToHost));   // (a copy to pageable memory queued behind the kernel would block the host there)
-		for (uint32_t p = 0; p < g.np; ++p) { h_part_sizes[g.p0 + p] = size_r[g.rank[p]]; if (h_part_sizes[g.p0 + p] == ~0ULL) return cl_fail(ctx, CL_E_CAPACITY, "cl_dna_encode: internal part buffer overflow"); }
-		std::vector<uint64_t> dst_off(g.np);                                     // by place, the bytes in part order
-		uint64_t w = written;
-		for (uint32_t p = 0; p < g.np; ++p) { dst_off[g.rank[p]] = w; w += h_part_sizes[g.p0 + p]; }
-		if (w > cap) { *n_out = w; return cl_fail(ctx, CL_E_CAPACITY, "cl_dna_encode: output capacity " + std::to_string(cap) + " too small"); }
-		HIP_TRY(ctx, hipMemcpyAsync(g.d_dst_off.p, dst_off.data(), g.np * 8, hipMemcpyHostToDevice, ctx->stream));
-		LAUNCH(ctx, k_gather_bytes2, g.np, 256, (const uint8_t*)g.tmp.p, (const uint64_t*)g.d_out_off.p, (const uint64_t*)g.d_dst_off.p, (const uint64_t*)g.d_size.p, d_out);
-		HIP_TRY(ctx, hipGetLastError());
-		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                         // (dst_off is read by the copy above)
-		written = w;
-		return CL_OK;
-	};
+	E.d_es = d_es; E.n_reads = n_reads; E.prev_types_in = prev_types; E.read_id_in = read_id; E.prev_types_out = W.prev_types_out;
+	E.part_bounds.assign(h_part_bounds, h_part_bounds + n_parts + 1);
 	uint32_t p0 = 0; size_t gi = 0;
 	while (p0 < n_parts)
 	{
@@ -1269,9 +1255,9 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 		HIP_TRY(ctx, hipMemcpy(&herr, err.p, 4, hipMemcpyDeviceToHost));
 		if (herr & 8) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_dna_encode: epoch table of a long context run too small");
 		if (herr) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_dna_encode: a read uses more than 64 alternative references");
-		// interval arithmetic per part: on the side stream; the previous group's result is collected first
-		if (pending) { CL_TRY(finish_group(*pending)); pending.reset(); }
-		if (!ctx->side) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+		// interval arithmetic per part: on a stream of the coder's own, beside whatever follows on this one
+		if (D->cstreams.size() < 4) { hipStream_t ns = nullptr; HIP_TRY(ctx, hipStreamCreateWithFlags(&ns, hipStreamNonBlocking)); D->cstreams.push_back(ns); }
+		G->stream = D->cstreams[D->next_cstream++ % D->cstreams.size()];
 		G->out_off.resize(np + 1);
 		G->out_off[0] = 0;
 		for (uint32_t p = 0; p < np; ++p) { uint64_t sy = plen_r[p]; G->out_off[p + 1] = G->out_off[p] + ((sy * 18 + 7) / 8 + sy / 16 + 64 + 7) / 8 * 8; }
@@ -1280,23 +1266,109 @@ extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads*
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                         // the triples are complete
 		{
 			hipStream_t main_stream = ctx->stream;
-			ctx->stream = ctx->side;                                              // (launch + timing events on the side stream)
-			G->sync.s = ctx->side;
-			hipError_t e1 = hipMemcpyAsync(G->d_out_off.p, G->out_off.data(), (np + 1) * 8, hipMemcpyHostToDevice, ctx->side);
+			ctx->stream = G->stream;                                              // (launch + timing events on the coder's stream)
+			G->sync.s = G->stream;
+			hipError_t e1 = hipMemcpyAsync(G->d_out_off.p, G->out_off.data(), (np + 1) * 8, hipMemcpyHostToDevice, G->stream);
 			LAUNCHB(ctx, n_syms * 8.0, k_range_code, ng, 64, (const triple_t*)trip.p, (const uint64_t*)d_gbase.p, (const uint32_t*)d_plen.p, np, G->tmp.p, (const uint64_t*)G->d_out_off.p, G->d_size.p, inv_tab);
 			hipError_t e2 = hipGetLastError();
 			ctx->stream = main_stream;
 			HIP_TRY(ctx, e1); HIP_TRY(ctx, e2);
 		}
-		pending = std::move(G);
+		E.groups.push_back(std::move(G));
 		p0 = p1;
 	}
-	// the last group's interval coding is one dependent chain per part on the side stream (~0.1 s for a 200-kb read): the caller's
-	// hook runs now, beside it (cl_compressor walks the next chunk's tuples here)
-	if (D->before_tail) { const cl_status hs = D->before_tail(); if (hs != CL_OK) return hs; }
-	if (pending) { CL_TRY(finish_group(*pending)); pending.reset(); }
+	return CL_OK;
+}
+} // namespace
+
+// Internal (stream.hip): the model half of the batch that FOLLOWS the one being coded, from inside cl_dna_encode's before_tail hook:
+// W is that batch, walked (and sorted) ahead by cl_dna_prepare_batch; the next cl_dna_encode finds its coders running already.
+cl_status cl_dna_evolve_ahead(cl_ctx* ctx, cl_dna_coder* D, const cl_reads* refs, const uint8_t* d_es, const uint64_t* d_es_off, const uint32_t* d_es_ntuples, uint32_t n_reads,
+                              const uint32_t* h_part_bounds, uint32_t n_parts, DnaWalked* W)
+{
+	std::unique_ptr<DnaWalked> Wp(W);
+	if (!ctx || !D || !refs || !d_es || !h_part_bounds || !n_parts || !W) return CL_E_INVALID;
+	if (!D->next_valid || D->evolved.size() >= 4) return cl_fail(ctx, CL_E_INVALID, "cl_dna_evolve_ahead: only while a batch is being coded, at most four batches ahead");
+	const uint32_t pt = D->evolved.empty() ? D->next_prev_types : D->ahead_prev_types, rid = D->evolved.empty() ? D->next_read_id : D->ahead_read_id;
+	if (W->prev_types_in != pt || W->cur_read_id_in != rid || W->d_es != d_es || W->n_reads != n_reads) return cl_fail(ctx, CL_E_INVALID, "cl_dna_evolve_ahead: not the batch that follows");
+	auto E = std::make_unique<DnaEvolved>();
+	CL_TRY(dna_evolve_batch(ctx, D, refs, d_es, d_es_off, d_es_ntuples, n_reads, h_part_bounds, n_parts, std::move(Wp), pt, rid, *E));
+	D->ahead_prev_types = E->prev_types_out; D->ahead_read_id = rid + n_reads;
+	D->evolved.push_back(std::move(E));
+	return CL_OK;
+}
+
+// CEntrComprReads::Compress for a batch of whole parts (entr_read.h:56-80)
+extern "C" cl_status cl_dna_encode(cl_ctx* ctx, cl_dna_coder* D, const cl_reads* refs, const uint8_t* d_es, const uint64_t* d_es_off,
+                                   const uint32_t* d_es_ntuples, uint32_t n_reads, const uint32_t* h_part_bounds, uint32_t n_parts,
+                                   uint8_t* d_out, uint64_t cap, uint64_t* h_part_sizes, uint64_t* n_out)
+{
+	if (!ctx || !D || !refs || !d_es || !d_es_off || !d_es_ntuples || !h_part_bounds || !h_part_sizes || !n_out) return cl_fail(ctx, CL_E_INVALID, "cl_dna_encode: null argument");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	for (uint32_t p = 0; p < n_parts; ++p) if (h_part_bounds[p] > h_part_bounds[p + 1]) return cl_fail(ctx, CL_E_INVALID, "cl_dna_encode: part bounds must ascend");
+	if (n_parts && (h_part_bounds[0] != 0 || h_part_bounds[n_parts] != n_reads)) return cl_fail(ctx, CL_E_INVALID, "cl_dna_encode: parts must cover reads [0, n_reads)");
+	*n_out = 0;
+	if (!n_parts) return CL_OK;
+	uint64_t written = 0;
+	// D1 for ALL reads at once: the walks are one lane per read and as long as the longest read's chain of tuples takes,
+	// whatever the number of reads — so one count pass and one write pass per call, not per group.  Only what follows
+	// (sort, models, interval arithmetic) is grouped, by the 32-bit symbol / triple indices.
+	// The model half of this batch: done ahead (cl_dna_evolve_ahead, in the tail of the call before), or now — with the
+	// state-independent half made ahead (cl_dna_prepare_batch / cl_dna_walk_ahead), or made now as well.
+	std::unique_ptr<DnaEvolved> Ep;
+	if (!D->evolved.empty()) { Ep = std::move(D->evolved.front()); D->evolved.pop_front(); }
+	if (Ep)
+	{	// (the models are evolved with it already: it has to be this batch)
+		if (Ep->d_es != d_es || Ep->n_reads != n_reads || Ep->prev_types_in != D->prev_types || Ep->read_id_in != D->cur_read_id || Ep->part_bounds.size() != (size_t)n_parts + 1 ||
+		    memcmp(Ep->part_bounds.data(), h_part_bounds, ((size_t)n_parts + 1) * 4) != 0)
+			return cl_fail(ctx, CL_E_INVALID, "cl_dna_encode: the batch evolved ahead is not the one encoded next");
+		D->ahead.reset();
+	}
+	else
+	{
+		std::unique_ptr<DnaWalked> Wp;
+		if (D->ahead && D->ahead->d_es == d_es && D->ahead->n_reads == n_reads && D->ahead->prev_types_in == D->prev_types && D->ahead->cur_read_id_in == D->cur_read_id) Wp = std::move(D->ahead);
+		D->ahead.reset();
+		Ep = std::make_unique<DnaEvolved>();
+		CL_TRY(dna_evolve_batch(ctx, D, refs, d_es, d_es_off, d_es_ntuples, n_reads, h_part_bounds, n_parts, std::move(Wp), D->prev_types, D->cur_read_id, *Ep));
+	}
+	DnaEvolved& E = *Ep;
+	D->next_prev_types = E.prev_types_out; D->next_read_id = D->cur_read_id + n_reads; D->next_valid = true;
+	struct NextOff { cl_dna_coder* D; ~NextOff() { D->next_valid = false; } } next_off{ D };
+	auto finish_group = [&](PendingGroup& g) -> cl_status {
+		HIP_TRY(ctx, hipStreamSynchronize(g.stream));
+		g.sync.s = nullptr;
+		std::vector<uint64_t> size_r(g.np);                                      // by place
+		HIP_TRY(ctx, hipMemcpy(size_r.data(), g.d_size.p, g.np * 8, hipMemcpyDeviceToHost));   // (a copy to pageable memory queued behind the kernel would block the host there)
+		for (uint32_t p = 0; p < g.np; ++p) { h_part_sizes[g.p0 + p] = size_r[g.rank[p]]; if (h_part_sizes[g.p0 + p] == ~0ULL) return cl_fail(ctx, CL_E_CAPACITY, "cl_dna_encode: internal part buffer overflow"); }
+		std::vector<uint64_t> dst_off(g.np);                                     // by place, the bytes in part order
+		uint64_t w = written;
+		for (uint32_t p = 0; p < g.np; ++p) { dst_off[g.rank[p]] = w; w += h_part_sizes[g.p0 + p]; }
+		if (w > cap) { *n_out = w; return cl_fail(ctx, CL_E_CAPACITY, "cl_dna_encode: output capacity " + std::to_string(cap) + " too small"); }
+		HIP_TRY(ctx, hipMemcpyAsync(g.d_dst_off.p, dst_off.data(), g.np * 8, hipMemcpyHostToDevice, ctx->stream));
+		LAUNCH(ctx, k_gather_bytes2, g.np, 256, (const uint8_t*)g.tmp.p, (const uint64_t*)g.d_out_off.p, (const uint64_t*)g.d_dst_off.p, (const uint64_t*)g.d_size.p, d_out);
+		HIP_TRY(ctx, hipGetLastError());
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                         // (dst_off is read by the copy above)
+		written = w;
+		return CL_OK;
+	};
+	// this batch's interval coders are one dependent chain per part (~0.1 s for a 200-kb read, 1.3 s for a part of 4 Mi symbols): the
+	// caller's hook runs now, beside them (cl_compressor takes the NEXT chunk through its model half here: cl_dna_evolve_ahead)
+	if (D->before_tail)
+		for (;;)
+		{	// (the hook answers CL_HOOK_RETRY while the next batch is not prepared yet: asked again as long as this batch's coders run)
+			const cl_status hs = D->before_tail();
+			if (hs == CL_OK) break;
+			if (hs != CL_HOOK_RETRY) return hs;
+			bool running = false;
+			for (auto& g : E.groups) if (hipStreamQuery(g->stream) == hipErrorNotReady) running = true;
+			(void)hipGetLastError();
+			if (!running) break;
+			std::this_thread::sleep_for(std::chrono::milliseconds(1));
+		}
+	for (auto& g : E.groups) CL_TRY(finish_group(*g));
 	// carry the coder state to the next call
-	D->prev_types = W.prev_types_out;
+	D->prev_types = E.prev_types_out;
 	D->cur_read_id += n_reads;
 	cl_timing_collect(ctx);
 	*n_out = written;

@@ -68,3 +68,9 @@ cl_status cl_qual_prepare_batch(cl_ctx* ctx, cl_qual_coder* Q, const cl_reads* R
                                 const uint8_t* d_flags, const uint32_t* h_part_bounds, uint32_t n_parts, QualPrepared** out);
 void cl_qual_prepared_free(QualPrepared* P);
 void cl_qual_set_ahead(cl_qual_coder* Q, QualPrepared* P);
+// the model half of the NEXT batch (takes W / P) while the interval coders of the current one run: from the coders' before_tail hooks
+cl_status cl_dna_evolve_ahead(cl_ctx* ctx, cl_dna_coder* D, const cl_reads* refs, const uint8_t* d_es, const uint64_t* d_es_off, const uint32_t* d_es_ntuples, uint32_t n_reads,
+                              const uint32_t* h_part_bounds, uint32_t n_parts, DnaWalked* W);
+cl_status cl_qual_evolve_ahead(cl_ctx* ctx, cl_qual_coder* Q, const cl_reads* R, const uint8_t* d_quals, const uint64_t* d_qual_off, const uint32_t* h_part_bounds, uint32_t n_parts, QualPrepared* P);
+void cl_qual_set_before_tail(cl_qual_coder* Q, std::function<cl_status()> fn);
+constexpr cl_status CL_HOOK_RETRY = (cl_status)1000;     // a before_tail hook: "nothing to do yet" — asked again while the batch's interval coders run

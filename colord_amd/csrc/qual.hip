@@ -13,6 +13,10 @@
 // would have used.  The interval arithmetic itself (sub_rc.h:83-100) is a dependent chain; it restarts
 // per part (entr_qual.h:68-79), so one lane codes one part and all parts of a batch run concurrently.
 #include "common.hpp"
+#include <functional>
+#include <deque>
+#include <thread>
+#include <chrono>
 #include "objects.hpp"
 #include "rc_dev.hpp"
 #include <algorithm>
@@ -57,7 +61,23 @@ struct cl_qual_coder {
 	DevBuf<uint32_t> bstate;      // byte family: 896 * 257
 	uint64_t symbols_coded = 0;
 	std::unique_ptr<QualPrepared> ahead;   // the next batch, prepared ahead
+	std::deque<std::unique_ptr<struct QualEvolved>> evolved;   // the next batches, their models evolved and their interval coders running (cl_qual_evolve_ahead)
+	std::function<cl_status()> before_tail;        // called by cl_qual_encode before it waits for the interval coders of its batch
+	std::vector<hipStream_t> cstreams; uint32_t next_cstream = 0;
+	~cl_qual_coder();
 };
+// a group whose interval coder is running (as PendingGroup of dna.hip)
+struct QualPending {
+	DevBuf<triple_t> trip; DevBuf<uint64_t> d_gbase, d_out_off, d_size, d_dst_off; DevBuf<uint32_t> d_plen; DevBuf<uint8_t> tmp;
+	std::vector<uint32_t> rank; uint32_t p0 = 0, np = 0; uint64_t n_syms = 0;
+	hipStream_t stream = nullptr;
+	~QualPending() { if (stream) (void)hipStreamSynchronize(stream); }            // (nothing above is released while the coder runs)
+};
+struct QualEvolved {
+	const cl_reads* R = nullptr; const uint8_t* d_quals = nullptr; std::vector<uint32_t> part_bounds;
+	std::vector<std::unique_ptr<QualPending>> groups;
+};
+cl_qual_coder::~cl_qual_coder() { evolved.clear(); for (hipStream_t s : cstreams) (void)hipStreamDestroy(s); }
 
 namespace {
 constexpr uint32_t BYTE_CTX = 5 * 128 + 256;      // (bin, floor(prev avg)) and 0x100 + high byte (quality_coder_impl.cpp:821-834)
@@ -539,41 +559,28 @@ cl_status cl_qual_prepare_batch(cl_ctx* ctx, cl_qual_coder* Q, const cl_reads* R
 void cl_qual_prepared_free(QualPrepared* P) { delete P; }
 void cl_qual_set_ahead(cl_qual_coder* Q, QualPrepared* P) { if (Q) Q->ahead.reset(P); else delete P; }
 
-extern "C" cl_status cl_qual_encode(cl_ctx* ctx, cl_qual_coder* Q, const cl_reads* R, const uint8_t* d_quals, const uint64_t* d_qual_off,
-                                    const uint8_t* d_flags, const uint32_t* h_part_bounds, uint32_t n_parts,
-                                    uint8_t* d_out, uint64_t cap, uint64_t* h_part_sizes, uint64_t* n_out)
+namespace {
+// the model half of a batch: model evolution group by group, every group's interval coder started on a stream of the coder
+cl_status qual_evolve_batch(cl_ctx* ctx, cl_qual_coder* Q, const cl_reads* R, const uint8_t* d_quals, const uint64_t* d_qual_off, const uint8_t* d_flags,
+                            const uint32_t* h_part_bounds, uint32_t n_parts, std::unique_ptr<QualPrepared> Pp, QualEvolved& E)
 {
-	if (!ctx || !Q || !R || !d_qual_off || !h_part_bounds || !h_part_sizes || !n_out) return cl_fail(ctx, CL_E_INVALID, "cl_qual_encode: null argument");
-	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	const QualCfg& c = Q->cfg;
-	for (uint32_t p = 0; p < n_parts; ++p) if (h_part_bounds[p] > h_part_bounds[p + 1]) return cl_fail(ctx, CL_E_INVALID, "cl_qual_encode: part bounds must ascend");
-	if (n_parts && h_part_bounds[n_parts] > R->n_reads) return cl_fail(ctx, CL_E_INVALID, "cl_qual_encode: part bound beyond the arena");
-	*n_out = 0;
-	std::unique_ptr<QualPrepared> Pp = std::move(Q->ahead);
-	if (!n_parts) return CL_OK;
-	if (c.mode == QM_NONE)
-	{	// nothing is coded: every part is the 8 flush bytes of an untouched coder (zeros)
-		if (cap < 8ull * n_parts) { *n_out = 8ull * n_parts; return cl_fail(ctx, CL_E_CAPACITY, "cl_qual_encode: output capacity"); }
-		HIP_TRY(ctx, hipMemsetAsync(d_out, 0, 8ull * n_parts, ctx->stream));
-		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-		for (uint32_t p = 0; p < n_parts; ++p) h_part_sizes[p] = 8;
-		*n_out = 8ull * n_parts;
-		return CL_OK;
-	}
 	// the model-independent half: made ahead (cl_qual_prepare_batch) for exactly this batch, or here
 	if (Pp && !(Pp->R == R && Pp->d_quals == d_quals && Pp->part_bounds.size() == (size_t)n_parts + 1 && memcmp(Pp->part_bounds.data(), h_part_bounds, ((size_t)n_parts + 1) * 4) == 0)) Pp.reset();
 	if (!Pp) { Pp = std::make_unique<QualPrepared>(); CL_TRY(qual_prepare(ctx, Q, R, d_quals, d_qual_off, d_flags, h_part_bounds, n_parts, *Pp)); }
+	E.R = R; E.d_quals = d_quals; E.part_bounds.assign(h_part_bounds, h_part_bounds + n_parts + 1);
 	const uint32_t bits_max = c.max_total == (1u << 20) ? 20 : 18;
-	uint64_t written = 0;
 	const uint64_t* inv_tab = nullptr;
 	CL_TRY(cl_inv_table(ctx, &inv_tab));
 	for (auto& Gp : Pp->groups)
 	{
 		QualGroupPrep& G = *Gp;
-		const uint32_t p0 = G.p0, np = G.np, ng = G.ng;
+		const uint32_t np = G.np, ng = G.ng;
 		const uint64_t n_base = G.n_base, n_syms = G.n_syms, n_byte = G.n_byte;
-		const std::vector<uint32_t>& rank = G.rank; const std::vector<uint32_t>& plen_r = G.plen_r;
-		DevBuf<triple_t> trip; DEV_ALLOC(ctx, trip, G.trip_words);
+		auto Pn = std::make_unique<QualPending>(); QualPending& PG = *Pn;
+		PG.p0 = G.p0; PG.np = np; PG.rank = G.rank; PG.n_syms = n_syms;
+		PG.d_gbase = std::move(G.d_gbase); PG.d_plen = std::move(G.d_plen);
+		DevBuf<triple_t>& trip = PG.trip; DEV_ALLOC(ctx, trip, G.trip_words);
 		if (n_base)
 		{
 			const uint32_t g = grid_for(c.n_ctx, 4);
@@ -597,34 +604,108 @@ extern "C" cl_status cl_qual_encode(cl_ctx* ctx, cl_qual_coder* Q, const cl_read
 		out_off[0] = 0;
 		for (uint32_t p = 0; p < np; ++p)
 		{
-			uint64_t s = plen_r[p];                                             // (by place)
+			uint64_t s = G.plen_r[p];                                           // (by place)
 			out_off[p + 1] = out_off[p] + ((s * bits_max + 7) / 8 + s / 16 + 64 + 7) / 8 * 8;
 		}
-		DevBuf<uint8_t> tmp; DEV_ALLOC(ctx, tmp, out_off[np]);
-		DevBuf<uint64_t> d_out_off, d_size, d_dst_off;
-		DEV_ALLOC(ctx, d_out_off, np + 1); DEV_ALLOC(ctx, d_size, np); DEV_ALLOC(ctx, d_dst_off, np);
-		HIP_TRY(ctx, hipMemcpyAsync(d_out_off.p, out_off.data(), (np + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-		LAUNCHB(ctx, n_syms * 8.0, k_range_code, ng, 64, (const triple_t*)trip.p, (const uint64_t*)G.d_gbase.p, (const uint32_t*)G.d_plen.p, np, tmp.p, (const uint64_t*)d_out_off.p, d_size.p, inv_tab);
-		HIP_TRY(ctx, hipGetLastError());
-		std::vector<uint64_t> size_r(np);                                       // by place
-		HIP_TRY(ctx, hipMemcpyAsync(size_r.data(), d_size.p, np * 8, hipMemcpyDeviceToHost, ctx->stream));
-		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		DEV_ALLOC(ctx, PG.tmp, out_off[np]);
+		DEV_ALLOC(ctx, PG.d_out_off, np + 1); DEV_ALLOC(ctx, PG.d_size, np); DEV_ALLOC(ctx, PG.d_dst_off, np);
+		HIP_TRY(ctx, hipMemcpyAsync(PG.d_out_off.p, out_off.data(), (np + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                         // the triples are complete (and out_off is read)
 		G.key.release(); G.sidx.release(); G.bkey.release(); G.bsidx.release();   // (the models are through with them)
+		// the interval arithmetic, one dependent chain per part, on a stream of the coder's own: the model half of the next batch
+		// runs beside it (cl_qual_evolve_ahead)
+		if (Q->cstreams.size() < 4) { hipStream_t ns = nullptr; HIP_TRY(ctx, hipStreamCreateWithFlags(&ns, hipStreamNonBlocking)); Q->cstreams.push_back(ns); }
+		PG.stream = Q->cstreams[Q->next_cstream++ % Q->cstreams.size()];
+		{
+			hipStream_t main_stream = ctx->stream;
+			ctx->stream = PG.stream;                                             // (launch + timing events on the coder's stream)
+			LAUNCHB(ctx, n_syms * 8.0, k_range_code, ng, 64, (const triple_t*)trip.p, (const uint64_t*)PG.d_gbase.p, (const uint32_t*)PG.d_plen.p, np, PG.tmp.p, (const uint64_t*)PG.d_out_off.p, PG.d_size.p, inv_tab);
+			hipError_t e2 = hipGetLastError();
+			ctx->stream = main_stream;
+			HIP_TRY(ctx, e2);
+		}
+		E.groups.push_back(std::move(Pn));
+	}
+	return CL_OK;
+}
+} // namespace
+// Internal (stream.hip): the model half of the batch that FOLLOWS the one being coded, from cl_qual_encode's before_tail hook
+cl_status cl_qual_evolve_ahead(cl_ctx* ctx, cl_qual_coder* Q, const cl_reads* R, const uint8_t* d_quals, const uint64_t* d_qual_off, const uint32_t* h_part_bounds, uint32_t n_parts, QualPrepared* P)
+{
+	std::unique_ptr<QualPrepared> Pp(P);
+	if (!ctx || !Q || !R || !h_part_bounds || !n_parts || Q->evolved.size() >= 4 || Q->cfg.mode == QM_NONE) return CL_E_INVALID;
+	auto E = std::make_unique<QualEvolved>();
+	CL_TRY(qual_evolve_batch(ctx, Q, R, d_quals, d_qual_off, nullptr, h_part_bounds, n_parts, std::move(Pp), *E));
+	Q->evolved.push_back(std::move(E));
+	return CL_OK;
+}
+void cl_qual_set_before_tail(cl_qual_coder* Q, std::function<cl_status()> fn) { if (Q) Q->before_tail = std::move(fn); }
+
+extern "C" cl_status cl_qual_encode(cl_ctx* ctx, cl_qual_coder* Q, const cl_reads* R, const uint8_t* d_quals, const uint64_t* d_qual_off,
+                                    const uint8_t* d_flags, const uint32_t* h_part_bounds, uint32_t n_parts,
+                                    uint8_t* d_out, uint64_t cap, uint64_t* h_part_sizes, uint64_t* n_out)
+{
+	if (!ctx || !Q || !R || !d_qual_off || !h_part_bounds || !h_part_sizes || !n_out) return cl_fail(ctx, CL_E_INVALID, "cl_qual_encode: null argument");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	const QualCfg& c = Q->cfg;
+	for (uint32_t p = 0; p < n_parts; ++p) if (h_part_bounds[p] > h_part_bounds[p + 1]) return cl_fail(ctx, CL_E_INVALID, "cl_qual_encode: part bounds must ascend");
+	if (n_parts && h_part_bounds[n_parts] > R->n_reads) return cl_fail(ctx, CL_E_INVALID, "cl_qual_encode: part bound beyond the arena");
+	*n_out = 0;
+	std::unique_ptr<QualPrepared> Pp = std::move(Q->ahead);
+	std::unique_ptr<QualEvolved> Ep;
+	if (!Q->evolved.empty()) { Ep = std::move(Q->evolved.front()); Q->evolved.pop_front(); }
+	if (!n_parts) return Ep ? cl_fail(ctx, CL_E_INVALID, "cl_qual_encode: the batch evolved ahead is not the one encoded next") : CL_OK;
+	if (c.mode == QM_NONE)
+	{	// nothing is coded: every part is the 8 flush bytes of an untouched coder (zeros)
+		if (cap < 8ull * n_parts) { *n_out = 8ull * n_parts; return cl_fail(ctx, CL_E_CAPACITY, "cl_qual_encode: output capacity"); }
+		HIP_TRY(ctx, hipMemsetAsync(d_out, 0, 8ull * n_parts, ctx->stream));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		for (uint32_t p = 0; p < n_parts; ++p) h_part_sizes[p] = 8;
+		*n_out = 8ull * n_parts;
+		return CL_OK;
+	}
+	if (Ep)
+	{	// (the models are evolved with it already: it has to be this batch)
+		if (!(Ep->R == R && Ep->d_quals == d_quals && Ep->part_bounds.size() == (size_t)n_parts + 1 && memcmp(Ep->part_bounds.data(), h_part_bounds, ((size_t)n_parts + 1) * 4) == 0))
+			return cl_fail(ctx, CL_E_INVALID, "cl_qual_encode: the batch evolved ahead is not the one encoded next");
+	}
+	else { Ep = std::make_unique<QualEvolved>(); CL_TRY(qual_evolve_batch(ctx, Q, R, d_quals, d_qual_off, d_flags, h_part_bounds, n_parts, std::move(Pp), *Ep)); }
+	// this batch's interval coders run; the caller's hook may take the next batch through its model half beside them
+	if (Q->before_tail)
+		for (;;)
+		{	// (CL_HOOK_RETRY: the next batch is not prepared yet — asked again as long as this batch's coders run)
+			const cl_status hs = Q->before_tail();
+			if (hs == CL_OK) break;
+			if (hs != CL_HOOK_RETRY) return hs;
+			bool running = false;
+			for (auto& g : Ep->groups) if (hipStreamQuery(g->stream) == hipErrorNotReady) running = true;
+			(void)hipGetLastError();
+			if (!running) break;
+			std::this_thread::sleep_for(std::chrono::milliseconds(1));
+		}
+	uint64_t written = 0;
+	for (auto& Pn : Ep->groups)
+	{
+		QualPending& PG = *Pn;
+		const uint32_t p0 = PG.p0, np = PG.np;
+		HIP_TRY(ctx, hipStreamSynchronize(PG.stream));
+		std::vector<uint64_t> size_r(np);                                       // by place
+		HIP_TRY(ctx, hipMemcpy(size_r.data(), PG.d_size.p, np * 8, hipMemcpyDeviceToHost));
 		for (uint32_t p = 0; p < np; ++p)
 		{
-			h_part_sizes[p0 + p] = size_r[rank[p]];
+			h_part_sizes[p0 + p] = size_r[PG.rank[p]];
 			if (h_part_sizes[p0 + p] == ~0ULL) return cl_fail(ctx, CL_E_CAPACITY, "cl_qual_encode: internal part buffer overflow (pathological interval clamping)");
 		}
 		std::vector<uint64_t> dst_off(np);                                      // by place, the bytes in part order
 		uint64_t w = written;
-		for (uint32_t p = 0; p < np; ++p) { dst_off[rank[p]] = w; w += h_part_sizes[p0 + p]; }
+		for (uint32_t p = 0; p < np; ++p) { dst_off[PG.rank[p]] = w; w += h_part_sizes[p0 + p]; }
 		if (w > cap) { *n_out = w; return cl_fail(ctx, CL_E_CAPACITY, "cl_qual_encode: output capacity " + std::to_string(cap) + " too small"); }
-		HIP_TRY(ctx, hipMemcpyAsync(d_dst_off.p, dst_off.data(), np * 8, hipMemcpyHostToDevice, ctx->stream));
-		LAUNCH(ctx, k_gather_bytes, np, 256, (const uint8_t*)tmp.p, (const uint64_t*)d_out_off.p, (const uint64_t*)d_dst_off.p, (const uint64_t*)d_size.p, d_out);
+		HIP_TRY(ctx, hipMemcpyAsync(PG.d_dst_off.p, dst_off.data(), np * 8, hipMemcpyHostToDevice, ctx->stream));
+		LAUNCH(ctx, k_gather_bytes, np, 256, (const uint8_t*)PG.tmp.p, (const uint64_t*)PG.d_out_off.p, (const uint64_t*)PG.d_dst_off.p, (const uint64_t*)PG.d_size.p, d_out);
 		HIP_TRY(ctx, hipGetLastError());
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 		written = w;
-		Q->symbols_coded += n_syms;
+		Q->symbols_coded += PG.n_syms;
 	}
 	cl_timing_collect(ctx);
 	*n_out = written;

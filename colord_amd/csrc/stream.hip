@@ -108,6 +108,10 @@ struct cl_compressor {
 	// DNA preparation thread: walks (and sorts) the chunks in order, one or two ahead of the coders, on a context of its own
 	std::thread prep_thread; cl_ctx* prep_ctx = nullptr; size_t prep_next = 0; bool prep_on = false, prep_broken = false; uint32_t prep_types = 0, prep_read_id = 0;
 	std::thread qprep_thread; cl_ctx* qprep_ctx = nullptr; size_t qprep_next = 0; bool qprep_on = false;
+	uint32_t n_dna_ahead = 0, n_qual_ahead = 0, n_dna_prep = 0, n_qual_prep = 0;      // (statistics: COLORD_HIP_STREAM_DEBUG)
+	// chunks whose model half is done ahead of their encode call (first not yet done), and how far ahead that may go: with the
+	// reference's parts the interval coders of a chunk take 1.3 s, those of `depth` + 1 chunks run side by side
+	size_t dna_evolved_upto = 0, qual_evolved_upto = 0; uint32_t evolve_depth = 0;
 	void stop_lanes()
 	{
 		{ std::lock_guard<std::mutex> l(lane_mu); lane_stop = true; }
@@ -122,6 +126,7 @@ struct cl_compressor {
 	~cl_compressor()
 	{
 		stop_lanes();
+		if (getenv("COLORD_HIP_STREAM_DEBUG")) fprintf(stderr, "[stream] %zu chunks: dna prepared ahead %u, evolved ahead %u; qual prepared ahead %u, evolved ahead %u; %zu lanes\n", enc_chunk, n_dna_prep, n_dna_ahead, n_qual_prep, n_qual_ahead, lane_ctx.size());
 		for (auto* r : ref_pieces) cl_reads_free(r);
 		if (refs) cl_reads_free(refs);
 		if (index) cl_index_free(index);
@@ -532,6 +537,13 @@ static void lane_main(cl_compressor* c, cl_ctx* lane)
 // (22.5 of 25.7 s busy).  Everything before the model evolution depends on the tuple streams only (and on two scalars that chain
 // from walk to walk), so this thread does it for the chunks ahead, in order, on a context of its own; the caller's stream keeps
 // evolution and coding.
+// what the device could still give this process: free memory + what the shared pool holds without using it
+static uint64_t avail_bytes(cl_ctx* ctx)
+{
+	size_t fr = 0, tot = 0;
+	if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return 0; }
+	return fr + (ctx->pool.reserved - std::min(ctx->pool.reserved, ctx->pool.live_bytes));
+}
 static void prep_main(cl_compressor* c)
 {
 	cl_ctx* ctx = c->prep_ctx;
@@ -544,7 +556,7 @@ static void prep_main(cl_compressor* c)
 				if (c->lane_stop || c->prep_broken) return true;
 				if (c->prep_next < c->enc_chunk) return true;                        // (a chunk was coded without this thread: the chain of walk scalars is lost)
 				auto it = c->prepared.find(c->prep_next);
-				return it != c->prepared.end() && it->second->done && c->prep_next <= c->enc_chunk + 1;
+				return it != c->prepared.end() && it->second->done && c->prep_next <= c->enc_chunk + 1 + c->evolve_depth;     // (far enough ahead for the chunks that may be evolved ahead)
 			});
 			if (c->lane_stop || c->prep_broken) return;
 			if (c->prep_next < c->enc_chunk) { c->prep_broken = true; c->lane_cv.notify_all(); return; }
@@ -586,7 +598,7 @@ static void qprep_main(cl_compressor* c)
 				if (c->lane_stop) return true;
 				if (c->qprep_next < c->enc_chunk) return true;
 				auto it = c->prepared.find(c->qprep_next);
-				return it != c->prepared.end() && c->qprep_next <= c->enc_chunk + 1;
+				return it != c->prepared.end() && c->qprep_next <= c->enc_chunk + 1 + c->evolve_depth;
 			});
 			if (c->lane_stop) return;
 			if (c->qprep_next < c->enc_chunk) { c->qprep_next = c->enc_chunk; continue; }   // (chunks coded without an announcement: nothing chains here, catch up)
@@ -629,15 +641,19 @@ extern "C" cl_status cl_compressor_prepare_parts(cl_compressor* c, const cl_read
 		return cl_fail(ctx, CL_E_INVALID, "cl_compressor_prepare: chunks must be announced in the order and sizes of pass 1, before they are encoded");
 	if (c->lane_ctx.empty())
 	{
-		// two lanes, a third when the device has the memory for it (~25 GB per lane and 1-Gbase chunk; measured at 50 Gbases: 20.5 s per
-		// pass with two, 19.3 with three, out of memory with four)
+		// two lanes.  (A third one was measured at 50 Gbases: once 19.3 against 20.5 s per pass, then — same code but for the coders'
+		// own streams — 23.5 against 20.3 s on one box, twice: the machine is shared by ~20 streams and whatever the lanes gain the
+		// preparation threads lose.  COLORD_HIP_ENCODE_LANES overrides.)
 		uint32_t lanes = 2;
-		{
-			size_t fr = 0, tot = 0;
-			if (hipMemGetInfo(&fr, &tot) == hipSuccess) { const uint64_t avail = fr + (ctx->pool.reserved - std::min(ctx->pool.reserved, ctx->pool.live_bytes)); if (avail > (80ull << 30)) lanes = 3; }
-			else (void)hipGetLastError();
-		}
+		// Long coder parts (the reference's packs of 4 Mi symbols: the byte-identical mode) make the interval coders the bound of a
+		// chunk — a dependent chain of 1.3 s per part: then the model halves of the next two chunks are done ahead so that the coders of
+		// three chunks run side by side, and two lanes feed them easily.  With short parts (the bench's 64 Ki) the coders are no bound
+		// and the memory serves a third lane better.
+		const bool long_parts = h_part_bounds && n_parts && (reads->total_bases + reads->n_reads) / n_parts >= (1u << 19);
+		c->evolve_depth = long_parts ? 2 : 0;
+		if (long_parts) lanes = 2;
 		if (const char* e = getenv("COLORD_HIP_ENCODE_LANES")) lanes = (uint32_t)std::min(4, std::max(1, atoi(e)));
+		if (const char* e = getenv("COLORD_HIP_EVOLVE_DEPTH")) c->evolve_depth = (uint32_t)std::min(3, std::max(0, atoi(e)));
 		while (ctx->lanes.size() < lanes)
 		{
 			cl_ctx* x = nullptr;
@@ -728,8 +744,31 @@ extern "C" cl_status cl_compressor_encode(cl_compressor* c, const cl_reads* read
 	cl_status qstatus = CL_OK;
 	cl_ctx* qctx = c->qual ? cl_qual_coder_ctx(c->qual) : nullptr;
 	const bool overlap = c->qual && P->level <= 1 && qctx && qctx != ctx;
-	if (overlap && job && job->qprep && job->d_quals == d_quals) { cl_qual_set_ahead(c->qual, job->qprep); job->qprep = nullptr; }
+	if (overlap && job && job->qprep && job->d_quals == d_quals) { cl_qual_set_ahead(c->qual, job->qprep); job->qprep = nullptr; ++c->n_qual_prep; }
 	if (job) for (auto& kv : job->q_times) { auto& t = qctx->times[kv.first]; t.ms += kv.second.ms; t.launches += kv.second.launches; t.bytes += kv.second.bytes; }
+	struct QHookOff { cl_qual_coder* q; ~QHookOff() { if (q) cl_qual_set_before_tail(q, nullptr); } } qhook_off{ overlap ? c->qual : nullptr };
+	if (overlap && c->qprep_on)
+		cl_qual_set_before_tail(c->qual, [c, idx, qctx]() -> cl_status {
+			if (getenv("COLORD_HIP_NO_EVOLVE_AHEAD")) return CL_OK;
+			for (;;)
+			{
+				const size_t k = std::max(c->qual_evolved_upto, idx + 1);
+				if (k > idx + c->evolve_depth) return CL_OK;
+				if (avail_bytes(c->ctx) < (24ull << 30)) return CL_OK;
+				cl_compressor::Prepared* nx = nullptr; QualPrepared* P = nullptr;
+				{
+					std::unique_lock<std::mutex> l(c->lane_mu);
+					auto it = c->prepared.find(k);
+					if (it == c->prepared.end() || it->second->parts.empty() || !it->second->d_quals) return CL_OK;
+					if (!it->second->q_done) return c->lane_stop ? CL_OK : CL_HOOK_RETRY;
+					if (!it->second->qprep) return CL_OK;
+					nx = it->second.get(); P = nx->qprep; nx->qprep = nullptr;
+				}
+				const cl_status s = cl_qual_evolve_ahead(qctx, c->qual, nx->reads, nx->d_quals, nx->d_base_off, nx->parts.data(), (uint32_t)nx->parts.size() - 1, P);
+				if (s != CL_OK) return s;
+				++c->n_qual_ahead; c->qual_evolved_upto = k + 1;
+			}
+		});
 	if (overlap)
 		qjob.t = std::thread([&]() { qstatus = cl_qual_encode(qctx, c->qual, reads, d_quals, d_base_off, nullptr, h_part_bounds, n_parts, d_qual_out, qual_cap, h_qual_part_sizes, &info->qual_bytes); });
 	if (job)
@@ -737,7 +776,7 @@ extern "C" cl_status cl_compressor_encode(cl_compressor* c, const cl_reads* read
 		if (job->status != CL_OK) return cl_fail(ctx, job->status, "encode lane: " + job->err);
 		for (auto& kv : job->times) { auto& t = ctx->times[kv.first]; t.ms += kv.second.ms; t.launches += kv.second.launches; t.bytes += kv.second.bytes; }
 		for (auto& kv : job->dna_times) { auto& t = ctx->times[kv.first]; t.ms += kv.second.ms; t.launches += kv.second.launches; t.bytes += kv.second.bytes; }
-		if (job->walked) { cl_dna_set_ahead(c->dna, job->walked); job->walked = nullptr; }
+		if (job->walked) { cl_dna_set_ahead(c->dna, job->walked); job->walked = nullptr; ++c->n_dna_prep; }
 	}
 	else
 	{
@@ -746,11 +785,33 @@ extern "C" cl_status cl_compressor_encode(cl_compressor* c, const cl_reads* read
 		CL_TRY(stage_a(c, ctx, idx, reads, h_pack_bounds, n_packs, *job));
 	}
 	info->n_anchors = job->n_anchors; info->tuple_bytes = job->es_bytes;
-	// While this chunk's last interval coding drains (a dependent chain per part: ~0.1 s that nothing else on this stream can use),
-	// the tuple walk of the NEXT chunk runs, if an encode lane has its tuple streams ready: that half of the DNA coder needs no
-	// model state (dna.hip, DnaWalked).
+	// While this chunk's interval coders run (a dependent chain per part that nothing else on this stream can use: ~0.1 s with parts
+	// of 64 Ki symbols, 1.3 s with the reference's 4 Mi), the NEXT chunk is taken through its model half — evolution of the models,
+	// triples, its own interval coders started (cl_dna_evolve_ahead / cl_qual_evolve_ahead) — when the preparation threads have it
+	// ready; without them only its tuple walk (cl_dna_walk_ahead).
 	cl_dna_set_before_tail(c->dna, [c, idx]() -> cl_status {
-		if (c->prep_on && !c->prep_broken) return CL_OK;                          // (the preparation thread does that, and more)
+		if (c->prep_on && !c->prep_broken)
+		{
+			if (getenv("COLORD_HIP_NO_EVOLVE_AHEAD")) return CL_OK;
+			for (;;)
+			{
+				const size_t k = std::max(c->dna_evolved_upto, idx + 1);
+				if (k > idx + c->evolve_depth) return CL_OK;
+				if (avail_bytes(c->ctx) < (28ull << 30)) return CL_OK;                    // (a chunk ahead holds ~12 GB of triples and coder output)
+				cl_compressor::Prepared* nx = nullptr; DnaWalked* W = nullptr;
+				{
+					std::unique_lock<std::mutex> l(c->lane_mu);
+					auto it = c->prepared.find(k);
+					if (it == c->prepared.end() || it->second->parts.empty()) return CL_OK;
+					if (!it->second->dna_done) return (c->prep_broken || c->lane_stop) ? CL_OK : CL_HOOK_RETRY;     // (never a wait here: the chunk being coded is due)
+					if (!it->second->walked || it->second->status != CL_OK) return CL_OK;
+					nx = it->second.get(); W = nx->walked; nx->walked = nullptr;
+				}
+				const cl_status s = cl_dna_evolve_ahead(c->ctx, c->dna, c->refs, nx->es.p, nx->es_off.p, nx->es_nt.p, nx->reads->n_reads, nx->parts.data(), (uint32_t)nx->parts.size() - 1, W);
+				if (s != CL_OK) return s;
+				++c->n_dna_ahead; c->dna_evolved_upto = k + 1;
+			}
+		}
 		cl_compressor::Prepared* nx = nullptr;
 		{
 			std::lock_guard<std::mutex> l(c->lane_mu);
