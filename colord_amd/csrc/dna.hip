@@ -1197,7 +1197,7 @@ cl_status dna_evolve_batch(cl_ctx* ctx, cl_dna_coder* D, const cl_reads* refs, c
 				(uint32_t)n_seg, D->state.p, trip.p);
 			HIP_TRY(ctx, hipGetLastError());
 			{	// long runs of the models with up to 32 symbols (k_dna_evolve skipped them)
-				const uint32_t RUN_CAP = 4096;
+				const uint32_t RUN_CAP = (uint32_t)std::max<uint64_t>(4096, n_syms / f.long_run + 2);   // (a long run holds at least long_run symbols: never more runs than this)
 				DevBuf<LongRun> runs; DEV_ALLOC(ctx, runs, 2 * RUN_CAP);
 				DevBuf<uint32_t> n_runs; DEV_ALLOC(ctx, n_runs, 2);
 				HIP_TRY(ctx, hipMemsetAsync(n_runs.p, 0, 8, ctx->stream));

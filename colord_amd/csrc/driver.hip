@@ -81,7 +81,7 @@ extern "C" cl_status cl_compress_shard(cl_ctx* ctx, const cl_compress_params* P,
 	// a5: index + candidates (+ shared k-mers for HiFi); a7: reference reads
 	Handle<cl_index, cl_index_free> index;
 	CL_TRY(cl_index_build(ctx, kset, lists, accept.p, 0, P->cs, index.out()));
-	const uint32_t c = P->c;
+	const uint32_t c = std::min<uint32_t>(P->c, 16);                          // (16 candidate views per frame, 8 recursion levels: see stage_a in stream.hip)
 	DevBuf<uint32_t> crefs, votes, cnt; DEV_ALLOC(ctx, crefs, (uint64_t)n * c); DEV_ALLOC(ctx, votes, (uint64_t)n * c); DEV_ALLOC(ctx, cnt, n);
 	CL_TRY(cl_candidates(ctx, index, lists, c, crefs.p, votes.p, cnt.p));
 	DevBuf<uint64_t> common_off, common;
@@ -107,7 +107,7 @@ extern "C" cl_status cl_compress_shard(cl_ctx* ctx, const cl_compress_params* P,
 	const uint64_t es_cap = reads->total_bases + 16ull * n + 4096;
 	DEV_ALLOC(ctx, es, es_cap); DEV_ALLOC(ctx, es_off, (uint64_t)n + 1); DEV_ALLOC(ctx, es_nt, n);
 	uint64_t es_bytes = 0;
-	CL_TRY(cl_encode_reads(ctx, reads, refs, anc, c, P->anchor_len, P->min_part_alt, P->max_rec, P->cost_mult, h_pack_bounds, n_packs, es.p, es_cap, es_off.p, es_nt.p, &es_bytes));
+	CL_TRY(cl_encode_reads(ctx, reads, refs, anc, c, P->anchor_len, P->min_part_alt, std::min<uint32_t>(P->max_rec, 8), P->cost_mult, h_pack_bounds, n_packs, es.p, es_cap, es_off.p, es_nt.p, &es_bytes));
 	info->tuple_bytes = es_bytes;
 	// a14 + a16: DNA stream; a13 + a15: quality stream (levels 2 and 3 take the per-base classes of the scripts)
 	CL_TRY(cl_dna_encode(ctx, dna, refs, es.p, es_off.p, es_nt.p, n, h_part_bounds, n_parts, d_dna_out, dna_cap, h_dna_part_sizes, &info->dna_bytes));

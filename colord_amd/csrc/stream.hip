@@ -316,10 +316,23 @@ extern "C" cl_status cl_compressor_pseudo_reads(cl_compressor* c, const cl_reads
 	if (!c || !pseudo) return CL_E_INVALID;
 	cl_ctx* ctx = c->ctx;
 	if (c->phase != 1 || c->refs_chunk != 0 || c->n_pseudo) return cl_fail(ctx, CL_E_INVALID, "cl_compressor_pseudo_reads: once, after count_finish and before the first refs_add");
-	if (c->world > 1) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_compressor_pseudo_reads: reference-genome mode with sharded reads is not supported");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	const uint32_t n = pseudo->n_reads;
 	if (!n) return CL_OK;
+	// Sharded reads: every rank is given the same pseudo reads; they are reference reads 0 .. n-1 of the replicated store, and rank 0
+	// — whose references come first in the gather of pass 2a — is the one that contributes them and their index entries.  The
+	// other ranks only note their number (reference ids, the coder's first read id and the acceptor's stream start behind them).
+	if (c->world > 1 && c->rank != 0)
+	{
+		c->n_pseudo = n;
+		if (c->P.sparse && c->n_reads_total)
+		{
+			std::vector<uint8_t> all((size_t)n + c->n_reads_total);
+			CL_TRY(cl_ref_accept((uint32_t)c->n_reads_total, n, c->sparse_range, c->P.sparse_exponent, all.data()));
+			std::copy(all.begin() + n + c->first_read, all.begin() + n + c->first_read + c->n_reads_local, c->h_accept.begin());
+		}
+		return CL_OK;
+	}
 	DevBuf<uint8_t> accept; DEV_ALLOC(ctx, accept, n);
 	HIP_TRY(ctx, hipMemsetAsync(accept.p, 1, n, ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -344,7 +357,7 @@ extern "C" cl_status cl_compressor_pseudo_reads(cl_compressor* c, const cl_reads
 	{
 		std::vector<uint8_t> all((size_t)n + c->n_reads_total);
 		CL_TRY(cl_ref_accept((uint32_t)c->n_reads_total, n, c->sparse_range, c->P.sparse_exponent, all.data()));
-		std::copy(all.begin() + n, all.end(), c->h_accept.begin());
+		std::copy(all.begin() + n + c->first_read, all.begin() + n + c->first_read + c->n_reads_local, c->h_accept.begin());
 	}
 	return CL_OK;
 }
@@ -477,7 +490,11 @@ static cl_status stage_a(cl_compressor* c, cl_ctx* ctx, size_t chunk_idx, const 
 	cl_kmer_lists* lists = nullptr;
 	CL_TRY(cl_accepted_kmers(ctx, c->kset, reads, P->k, P->f, &lists));
 	std::unique_ptr<cl_kmer_lists, void (*)(cl_kmer_lists*)> lg(lists, cl_kmer_lists_free);
-	const uint32_t cc = P->c;
+	// more than 16 candidates per read / more than 8 recursion levels (the reference takes any value; its presets stop at 12 and 6): this
+	// build's frames hold 16 candidate views and 10 levels — the read is coded against its 16 best candidates, to depth 8.  Still a
+	// valid archive (the alternative-id model keeps the alphabet of P->c symbols the `meta` stream announces), a little larger than
+	// the reference's would be; never a failed call.
+	const uint32_t cc = std::min<uint32_t>(P->c, 16), max_rec = std::min<uint32_t>(P->max_rec, 8);
 	DevBuf<uint32_t> crefs, votes, cnt; DEV_ALLOC(ctx, crefs, (uint64_t)n * cc); DEV_ALLOC(ctx, votes, (uint64_t)n * cc); DEV_ALLOC(ctx, cnt, n);
 	CL_TRY(cl_candidates_at(ctx, c->index, lists, d_bounds, cc, crefs.p, votes.p, cnt.p));
 	votes.release();
@@ -501,7 +518,7 @@ static cl_status stage_a(cl_compressor* c, cl_ctx* ctx, size_t chunk_idx, const 
 	crefs.release(); cnt.release(); common_off.release(); common.release();
 	const uint64_t es_cap = reads->total_bases + 16ull * n + 4096;
 	DEV_ALLOC(ctx, out.es, es_cap); DEV_ALLOC(ctx, out.es_off, (uint64_t)n + 1); DEV_ALLOC(ctx, out.es_nt, n);
-	CL_TRY(cl_encode_reads(ctx, reads, c->refs, anc, cc, P->anchor_len, P->min_part_alt, P->max_rec, P->cost_mult, h_pack_bounds, n_packs, out.es.p, es_cap, out.es_off.p, out.es_nt.p, &out.es_bytes));
+	CL_TRY(cl_encode_reads(ctx, reads, c->refs, anc, cc, P->anchor_len, P->min_part_alt, max_rec, P->cost_mult, h_pack_bounds, n_packs, out.es.p, es_cap, out.es_off.p, out.es_nt.p, &out.es_bytes));
 	return CL_OK;
 }
 

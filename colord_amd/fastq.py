@@ -108,6 +108,73 @@ def read_fastx(path: str) -> ReadSet:
     return ReadSet(bases, offsets, q, headers, plus_eq, is_fastq)
 
 
+def _record_start(f, pos: int, size: int) -> int:
+    """Offset of the first FASTQ record that starts at or after byte `pos` of a plain 4-line FASTQ: a line that starts with '@'
+    and whose next-but-one line starts with '+' (a quality line may start with '@' too; it is followed by a header, not by a
+    '+' line two lines on... unless that quality line starts with '+' as well, which the check of the line after rules out)."""
+    if pos <= 0:
+        return 0
+    if pos >= size:
+        return size
+    f.seek(pos - 1)
+    buf = f.read(1 << 22)                          # (reads are at most a few hundred kb: four lines fit many times over)
+    i = buf.find(b"\n") + 1                        # first line start at or after pos
+    starts = []
+    while i < len(buf) and len(starts) < 12:
+        starts.append(i)
+        j = buf.find(b"\n", i)
+        if j < 0:
+            break
+        i = j + 1
+    for a in range(len(starts) - 3):
+        l0, l2 = buf[starts[a]:starts[a] + 1], buf[starts[a + 2]:starts[a + 2] + 1]
+        l1 = buf[starts[a + 1]:starts[a + 1] + 1]
+        if l0 == b"@" and l2 == b"+" and l1 not in (b"@", b"+", b""):
+            # the sequence line's length must be the quality line's (rules out a quality line read as a header)
+            seq_len = starts[a + 2] - starts[a + 1]
+            q_end = buf.find(b"\n", starts[a + 3])
+            if q_end < 0 or (q_end + 1 - starts[a + 3]) == seq_len:
+                return pos - 1 + starts[a]
+    return size
+
+
+def read_fastx_range(path: str, rank: int, world: int):
+    """Rank `rank`'s share of a PLAIN (not gzipped) 4-line FASTQ: the records that start in its byte range — no rank reads, parses
+    or holds the whole file.  Returns (ReadSet, file size) or None when the file is not of that kind (gzip, FASTA, multi-line
+    records): then the caller reads everything and keeps its share."""
+    import os
+    with open(path, "rb") as f:
+        magic = f.read(2)
+        if magic[:2] == b"\x1f\x8b" or magic[:1] != b"@":
+            return None
+        size = os.path.getsize(path)
+        a = _record_start(f, size * rank // world, size)
+        b = _record_start(f, size * (rank + 1) // world, size) if rank + 1 < world else size
+        f.seek(a)
+        data = f.read(b - a)
+    lines = data.split(b"\n")
+    if lines and lines[-1] == b"":
+        lines.pop()
+    lines = [l[:-1] if l.endswith(b"\r") else l for l in lines]
+    if len(lines) % 4:
+        return None                                   # (multi-line records or a cut inside a record: not this reader's kind)
+    seqs, quals, headers, plus_eq = [], [], [], []
+    for i in range(0, len(lines), 4):
+        h, s_, p_, q = lines[i:i + 4]
+        if h[:1] != b"@" or p_[:1] != b"+" or len(s_) != len(q):
+            return None
+        if len(p_) > 1 and p_[1:] != h[1:]:
+            raise ValueError("quality header not empty but different than read header")
+        headers.append(h[1:]); plus_eq.append(len(p_) > 1); seqs.append(s_); quals.append(q)
+    lens = np.fromiter((len(x) for x in seqs), dtype=np.int64, count=len(seqs))
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    bases = _CODE[np.frombuffer(b"".join(seqs), dtype=np.uint8)] if seqs else np.zeros(0, np.uint8)
+    if (bases == 255).any():
+        raise ValueError("Only ACGTN symbols supported inside a read")
+    qv = np.frombuffer(b"".join(quals), dtype=np.uint8).copy() if seqs else np.zeros(0, np.uint8)
+    return ReadSet(bases, offsets, qv, headers, plus_eq, True), size
+
+
 def write_fastq(path: str, rs: ReadSet, quals: np.ndarray | None = None) -> None:
     lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
     q = rs.quals if quals is None else quals

@@ -29,7 +29,7 @@ import torch
 import torch.distributed as dist
 
 from . import _native as N, archive as AR, parallel as par
-from .fastq import ReadSet, read_fastx
+from .fastq import ReadSet, read_fastx, read_fastx_range
 
 # arg_parse.cpp:89-408 — [source][priority]: level, ci, cs, f, c, max_rec, min_part_alt, qual_mode, sparse, g
 PRESETS = {
@@ -94,8 +94,11 @@ def encode_headers(headers, plus_eq, header_mode: int):
 
 
 def compress_readset(rs: ReadSet, out_path: str | None, source: int = 0, priority: str = "memory", qual_mode: int | None = None, header_mode: int = 0,
-                     k: int = 0, a: int = 0, chunk_bases: float = 1.0e9, est_bases: float | None = None, command: str = "", file_bytes: int = 0, device: int | None = None):
-    """Compresses `rs` (every rank holds the same ReadSet; each takes its share).  Rank 0 writes out_path and returns a dict of sizes."""
+                     k: int = 0, a: int = 0, chunk_bases: float = 1.0e9, est_bases: float | None = None, command: str = "", file_bytes: int = 0, device: int | None = None,
+                     presharded: bool = False):
+    """Compresses `rs`.  presharded = False: every rank holds the same ReadSet and takes its share (tests); True: `rs` is this
+    rank's OWN contiguous share of the file (read_fastx_range: no rank holds the whole input), totals and headers travel through
+    the process group.  Rank 0 writes out_path and returns a dict of sizes."""
     from .device import Context
     world, rank = par.world(), par.rank()
     local = int(os.environ.get("LOCAL_RANK", "0")) if device is None else device
@@ -104,8 +107,11 @@ def compress_readset(rs: ReadSet, out_path: str | None, source: int = 0, priorit
     level, ci, cs, f, c, max_rec, min_alt, qm, sparse, g = PRESETS[source][priority]
     qm = qm if qual_mode is None else qual_mode
     lens_all = np.diff(rs.offsets).astype(np.int64)
+    tot_reads, tot_bases = rs.n_reads, int(lens_all.sum())
+    if presharded and world > 1:
+        tot_reads, tot_bases = par.all_reduce_sum_ints(rs.n_reads, int(lens_all.sum()))
     if not k:
-        k, a = kmer_anchor_len(est_bases if est_bases is not None else float(lens_all.sum()))
+        k, a = kmer_anchor_len(est_bases if est_bases is not None else float(tot_bases))
     prm = dict(k=k, f=f, ci=ci, cs=cs, c=c, anchor_len=a, min_part_alt=min_alt, max_rec=max_rec, min_anchors=1, level=level, source=source, sparse=sparse,
                sparse_g=float(g), sparse_exponent=1.0, cost_mult=1.0, frac_always=0.9, frac_min=0.5, max_matches_mult=10.0)
     with_qual = rs.is_fastq and rs.quals is not None
@@ -113,8 +119,11 @@ def compress_readset(rs: ReadSet, out_path: str | None, source: int = 0, priorit
     qargs = (qm, source, level, qd[0], qd[1]) if with_qual else None
     # this rank's contiguous share of the file
     acc = np.cumsum(lens_all)
-    r0 = int(np.searchsorted(acc, acc[-1] * rank / world, side="left")) if rank else 0
-    r1 = int(np.searchsorted(acc, acc[-1] * (rank + 1) / world, side="left")) if rank + 1 < world else rs.n_reads
+    if presharded:
+        r0, r1 = 0, rs.n_reads
+    else:
+        r0 = int(np.searchsorted(acc, acc[-1] * rank / world, side="left")) if rank else 0
+        r1 = int(np.searchsorted(acc, acc[-1] * (rank + 1) / world, side="left")) if rank + 1 < world else rs.n_reads
     lens = lens_all[r0:r1]
     packs = _packs(lens)
     cacc = np.concatenate([[0], np.cumsum(lens)])
@@ -167,6 +176,22 @@ def compress_readset(rs: ReadSet, out_path: str | None, source: int = 0, priorit
     g_dna = par.gather_to_root(dna)
     g_qual = par.gather_to_root(qual) if with_qual else None
     g_tab = par.gather_to_root(tab.view(torch.uint8))
+    all_headers, all_plus = rs.headers, rs.plus_eq
+    if presharded and world > 1:
+        # the `header` stream is coded by rank 0 (one id coder over the whole file): the id bytes of every share go there
+        blob = b"".join(rs.headers)
+        hl = np.fromiter((len(x) for x in rs.headers), dtype=np.int64, count=len(rs.headers))
+        pe = np.asarray(rs.plus_eq, dtype=np.uint8)
+        pack = np.concatenate([np.array([len(hl)], np.int64).view(np.uint8), hl.view(np.uint8), pe, np.frombuffer(blob, np.uint8)])
+        g_hdr = par.gather_to_root(torch.from_numpy(pack.copy()).to(ctx.device))
+        if rank == 0:
+            all_headers, all_plus = [], []
+            for t_ in g_hdr:
+                b_ = t_.cpu().numpy()
+                n_ = int(b_[:8].view(np.int64)[0]); hl_ = b_[8:8 + 8 * n_].view(np.int64); pe_ = b_[8 + 8 * n_:8 + 9 * n_]; raw_ = b_[8 + 9 * n_:].tobytes()
+                o_ = 0
+                for L_, e_ in zip(hl_, pe_):
+                    all_headers.append(raw_[o_:o_ + int(L_)]); all_plus.append(bool(e_)); o_ += int(L_)
     res = None
     if rank == 0:
         d_st, q_st = AR.Stream("dna"), AR.Stream("qual")
@@ -184,9 +209,9 @@ def compress_readset(rs: ReadSet, out_path: str | None, source: int = 0, priorit
                 for s_ in qs:
                     q_st.parts.append((0, raw[o:o + int(s_)])); o += int(s_)
             first_read += int(cn.sum()); reads_per_rank.append(int(cn.sum()))
-        assert first_read == rs.n_reads
-        h_st = AR.Stream("header"); h_st.parts = encode_headers(rs.headers, rs.plus_eq, header_mode)
-        n = rs.n_reads
+        assert first_read == tot_reads
+        h_st = AR.Stream("header"); h_st.parts = encode_headers(all_headers, all_plus, header_mode)
+        n = tot_reads
         tot_ref = n
         if sparse:
             accd = np.zeros(n, np.uint8)
@@ -203,7 +228,7 @@ def compress_readset(rs: ReadSet, out_path: str | None, source: int = 0, priorit
         meta += b"\0"
         m_st = AR.Stream("meta"); m_st.parts = [(0, meta)]
         cmd = command.encode()
-        inf = struct.pack("<IIIQQIQI", 1, 2, 1, file_bytes, int(lens_all.sum()), n, int(time.time()), len(cmd)) + cmd      # utils.cpp:326-342
+        inf = struct.pack("<IIIQQIQI", 1, 2, 1, file_bytes, tot_bases, n, int(time.time()), len(cmd)) + cmd      # utils.cpp:326-342
         i_st = AR.Stream("info"); i_st.parts = [(0, inf)]
         streams = [m_st, h_st, d_st] + ([q_st] if with_qual else [])
         if world > 1:
@@ -213,7 +238,7 @@ def compress_readset(rs: ReadSet, out_path: str | None, source: int = 0, priorit
         streams.append(i_st)
         if out_path:
             AR.write_archive(out_path, streams)
-        res = dict(n_reads=n, n_bases=int(lens_all.sum()), k=k, a=a, dna_bytes=sum(len(p) for _, p in d_st.parts), qual_bytes=sum(len(p) for _, p in q_st.parts),
+        res = dict(n_reads=n, n_bases=tot_bases, k=k, a=a, dna_bytes=sum(len(p) for _, p in d_st.parts), qual_bytes=sum(len(p) for _, p in q_st.parts),
                    header_bytes=sum(len(p) for _, p in h_st.parts), dna_parts=len(d_st.parts), refs=info["n_refs_total"], domains=domains, reads_per_rank=reads_per_rank,
                    exchanged_bytes_rank0=exchange.bytes_moved if exchange else 0)
     ctx.close()
@@ -235,8 +260,14 @@ def main(argv=None):
         if x in ("-p", "--priority"):
             prio = argv[i + 1]; i += 2
         elif x in ("-q", "--qual"):
+            if argv[i + 1] not in QUAL_NAMES:
+                print(f"unknown quality mode '{argv[i + 1]}' ({', '.join(QUAL_NAMES)})", file=sys.stderr)
+                return 1
             qm = QUAL_NAMES.index(argv[i + 1]); i += 2
         elif x in ("-i", "--identifier"):
+            if argv[i + 1] not in ("org", "main", "none"):
+                print(f"unknown identifier mode '{argv[i + 1]}' (org, main, none)", file=sys.stderr)
+                return 1
             hm = ["org", "main", "none"].index(argv[i + 1]); i += 2
         elif x in ("-k", "--kmer-len"):
             k = int(argv[i + 1]); i += 2
@@ -248,6 +279,16 @@ def main(argv=None):
             pos.append(x); i += 1
     if len(pos) != 2 or bool(k) != bool(a):
         print("expected input and output paths (and -k together with -a)", file=sys.stderr)
+        return 1
+    # (options are checked before the process group exists: a bad value must not leave the other ranks waiting in a collective)
+    if prio not in PRESETS[source]:
+        print(f"unknown priority '{prio}' (ratio, balanced, memory)", file=sys.stderr)
+        return 1
+    if k and not (15 <= k <= 28 and 10 <= a <= k):
+        print("k-mer length 15..28, anchor length 10..k", file=sys.stderr)
+        return 1
+    if not os.path.isfile(pos[0]):
+        print(f"cannot open {pos[0]}", file=sys.stderr)
         return 1
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
@@ -261,11 +302,23 @@ def main(argv=None):
             torch.cuda.set_device(local % torch.cuda.device_count())
             dist.init_process_group(backend)
     t0 = time.time()
-    rs = read_fastx(pos[0])
     size = os.path.getsize(pos[0])
     gz = open(pos[0], "rb").read(2) == b"\x1f\x8b"
-    est = size * ((2.08 if rs.is_fastq else 3.98) if gz else (0.49 if rs.is_fastq else 0.98))      # compression.cpp:52-61
-    res = compress_readset(rs, pos[1], source, prio, qm, hm, k, a, chunk, est, "colord_amd.mgpu " + " ".join(argv), size)
+    # every rank reads ITS byte range of a plain 4-line FASTQ (no rank parses or holds the whole file); other inputs (gzip, FASTA,
+    # multi-line records) are read whole by every rank, which keeps its share
+    rank_ = int(os.environ.get("RANK", "0"))
+    shard = read_fastx_range(pos[0], rank_, world) if world > 1 else None
+    ok = torch.tensor([1 if (shard is not None or world == 1) else 0], dtype=torch.int64, device=torch.device("cuda", torch.cuda.current_device()) if (world > 1 and dist.get_backend() == "nccl") else "cpu")
+    if world > 1:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)            # (all ranks take the same path)
+    if world > 1 and int(ok.item()) == 1:
+        rs = shard[0]
+        est = size * 0.49
+        res = compress_readset(rs, pos[1], source, prio, qm, hm, k, a, chunk, est, "colord_amd.mgpu " + " ".join(argv), size, presharded=True)
+    else:
+        rs = read_fastx(pos[0])
+        est = size * ((2.08 if rs.is_fastq else 3.98) if gz else (0.49 if rs.is_fastq else 0.98))      # compression.cpp:52-61
+        res = compress_readset(rs, pos[1], source, prio, qm, hm, k, a, chunk, est, "colord_amd.mgpu " + " ".join(argv), size)
     if res is not None:
         print(f"colord_amd.mgpu: {res['n_reads']} reads, {res['n_bases']} bases on {world} GPU(s), k={res['k']} a={res['a']}; dna {res['dna_bytes']} B ({res['dna_parts']} parts), "
               f"qual {res['qual_bytes']} B, header {res['header_bytes']} B; {res['refs']} reference reads; {time.time() - t0:.2f} s", file=sys.stderr)

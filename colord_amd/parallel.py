@@ -52,7 +52,8 @@ def exchange_kmers(kmers: torch.Tensor) -> torch.Tensor:
 
 
 def all_gather_v(t: torch.Tensor) -> list:
-    """Variable-length all-gather (rank order).  Returns the list of per-rank tensors."""
+    """Variable-length all-gather (rank order): the list of per-rank tensors, each at its own size — no padding to the largest
+    shard (one broadcast per source rank into a buffer of exactly its size)."""
     w = world()
     if w == 1:
         return [t]
@@ -62,13 +63,13 @@ def all_gather_v(t: torch.Tensor) -> list:
     n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
     sizes = [torch.zeros_like(n) for _ in range(w)]
     dist.all_gather(sizes, n)
-    sizes = [int(s.item()) for s in sizes]
-    mx = max(max(sizes), 1)
-    pad = torch.zeros(mx, dtype=t.dtype, device=t.device)
-    pad[:t.numel()] = t
-    bufs = [torch.empty_like(pad) for _ in range(w)]
-    dist.all_gather(bufs, pad)
-    return [b[:s].to(dev) for b, s in zip(bufs, sizes)]
+    out = []
+    for r, s_ in enumerate(int(x.item()) for x in sizes):
+        buf = t.contiguous() if r == rank() else torch.empty(s_, dtype=t.dtype, device=t.device)
+        if s_:
+            dist.broadcast(buf, src=r)
+        out.append(buf.to(dev))
+    return out
 
 
 def all_reduce_sum_ints(*vals):
@@ -175,14 +176,20 @@ class TorchExchange:
             rb = [int(h_recv[i]) for i in range(self.world)]
             assert int(send_bytes) == rb[self.rank], "all_gather_v: send size differs from the announced size"
             recv = self._view(d_recv, sum(rb))
-            off = 0
+            offs = [sum(rb[:r]) for r in range(self.world)]
             staged = (not self.host_mem) and _host_staged()
-            for r in range(self.world):                          # one broadcast per source rank, straight into its slice
-                sl = recv[off:off + rb[r]]
-                if rb[r]:
-                    if r == self.rank:
-                        sl.copy_(self._view(d_send, rb[r]))
-                    (v,), _ = self._widen([sl])
+            if rb[self.rank]:
+                recv[offs[self.rank]:offs[self.rank] + rb[self.rank]].copy_(self._view(d_send, rb[self.rank]))
+            if not self.host_mem and not staged and dist.get_backend() == "nccl":
+                # RCCL: ONE grouped call, every rank's share straight into its slice of the receive buffer (uneven sizes: the process
+                # group issues the per-source broadcasts inside one ncclGroup), then one synchronisation for the library's own streams
+                dist.all_gather([recv[offs[r]:offs[r] + rb[r]] for r in range(self.world)], recv[offs[self.rank]:offs[self.rank] + rb[self.rank]])
+                torch.cuda.synchronize()
+            else:
+                for r in range(self.world):                      # gloo (functional tests, CPU suite): one broadcast per source rank
+                    if not rb[r]:
+                        continue
+                    (v,), _ = self._widen([recv[offs[r]:offs[r] + rb[r]]])
                     if staged:
                         h = v.cpu()
                         dist.broadcast(h, src=r)
@@ -190,9 +197,8 @@ class TorchExchange:
                             v.copy_(h)
                     else:
                         dist.broadcast(v, src=r)
-                off += rb[r]
-            if not self.host_mem:
-                torch.cuda.synchronize()
+                if not self.host_mem:
+                    torch.cuda.synchronize()
             self.bytes_moved += sum(rb) - rb[self.rank]
         return self._guard(run)
 

@@ -348,7 +348,9 @@ cl_status cl_compressor_encode(cl_compressor* c, const cl_reads* chunk, const ui
                                const uint32_t* h_part_bounds, uint32_t n_parts, const uint32_t* h_pack_bounds, uint32_t n_packs,
                                uint8_t* d_dna_out, uint64_t dna_cap, uint64_t* h_dna_part_sizes,
                                uint8_t* d_qual_out, uint64_t qual_cap, uint64_t* h_qual_part_sizes, cl_compress_info* info);
-/* Reference-genome mode (`-G`; compression.cpp:405-447, reference_genome.cpp:372-429, reads_sim_graph.cpp:295-322), single GPU:
+/* Reference-genome mode (`-G`; compression.cpp:405-447, reference_genome.cpp:372-429, reads_sim_graph.cpp:295-322).  With reads
+ * sharded over GPUs every rank makes both calls with the SAME sequences / pseudo reads: rank 0 counts the genome's k-mers and
+ * contributes the pseudo reads to the replicated reference store, the other ranks only take note of their number:
  *   cl_compressor_genome_add    before count_finish: the genome's sequences (arenas of ACGT codes, any number of calls) are a second
  *                               input of the k-mer counter; the statistics of count_finish are corrected for them as in the reference;
  *   cl_compressor_pseudo_reads  once, after count_finish and before the first refs_add: the overlapping pieces of the sequences

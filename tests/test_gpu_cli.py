@@ -268,3 +268,21 @@ def test_cli_250_mbases_of_the_bench_recipe_equal_the_reference(tmp_path, extra)
     subprocess.check_call([REF, "decompress", ref_arc, ref_out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     subprocess.check_call([CLI, "decompress", my_arc, my_out])
     assert sha(my_out) == sha(ref_out)
+
+
+@pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(CLI)), reason="needs oracle/_ref/colord and colord_amd/colord_hip")
+def test_cli_more_candidates_and_levels_than_this_build_holds_degrade(tmp_path):
+    """`-c 20 -r 9`: the reference takes any value (arg_parse.cpp:455-640, encoder.cpp:1513-1575); this build's frames hold 16
+    candidate views and recursion to depth 8.  The call must not fail: the reads are coded against their 16 best candidates, the
+    archive announces c = 20 (the alternative-id model's alphabet) and BOTH decompressors return the input's reads."""
+    rs = make_reads(seed=41, genome_len=60_000, target_bases=3_000_000, mean_scale=5000.0)
+    fq = str(tmp_path / "in.fastq")
+    write_fastq(fq, rs)
+    extra = ["-p", "ratio", "-c", "20", "-r", "9", "-q", "org"]
+    ref_arc, ref_out, my_arc, my_out, my_out2 = (str(tmp_path / x) for x in ("ref.colord", "ref.fastq", "gpu.colord", "gpu.fastq", "gpu2.fastq"))
+    subprocess.check_call([REF, "compress-ont", "-t", "4"] + extra + [fq, ref_arc], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.check_call([CLI, "compress-ont"] + extra + [fq, my_arc])
+    subprocess.check_call([REF, "decompress", my_arc, my_out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.check_call([CLI, "decompress", my_arc, my_out2])
+    assert sha(my_out) == sha(fq) and sha(my_out2) == sha(fq)            # -q org: lossless
+    assert os.path.getsize(my_arc) <= os.path.getsize(ref_arc) * 1.02   # at most a little larger than with all 20 candidates

@@ -77,3 +77,45 @@ def test_two_ranks_200_mbases_lossless_and_within_one_percent(tmp_path):
     assert s2 <= s1 * 1.01
     a, b = AR.read_archive(one), AR.read_archive(two)
     assert [m for m, _ in a["dna"].parts] != [] and sum(m for m, _ in a["dna"].parts) == sum(m for m, _ in b["dna"].parts) == t.n_reads
+
+
+def test_rccl_initialises_and_carries_the_exchange_callbacks_on_one_rank(tmp_path):
+    """backend "nccl" (= RCCL) with world = 1: the process group comes up on the GPU and the three cl_exchange callbacks of
+    colord_amd.parallel.TorchExchange (all_gather_host, all_to_all_v, all_gather_v) move device buffers through it — the same code
+    path as on 8 GPUs, minus the peers.  (Multi-rank behaviour is covered with gloo above; RCCL over xGMI needs the 8-GPU node.)"""
+    script = tmp_path / "rccl_self_test.py"
+    script.write_text('''
+import ctypes as C, os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["COLORD_ROOT"])
+from colord_amd import parallel as par
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+X = par.TorchExchange(torch.device("cuda", 0))
+U64P = C.POINTER(C.c_uint64)
+vals = np.arange(5, dtype=np.uint64); out = np.zeros(5, np.uint64)
+assert X._gather_host(None, vals.ctypes.data_as(U64P), 5, out.ctypes.data_as(U64P)) == 0 and (out == vals).all()
+src = torch.arange(1001, dtype=torch.uint8, device="cuda"); dst = torch.zeros(1001, dtype=torch.uint8, device="cuda")
+sb = np.array([1001], np.uint64)
+assert X._all_to_all_v(None, src.data_ptr(), sb.ctypes.data_as(U64P), dst.data_ptr(), sb.ctypes.data_as(U64P)) == 0, X.err
+assert torch.equal(src, dst)
+dst.zero_()
+assert X._all_gather_v(None, src.data_ptr(), 1001, dst.data_ptr(), sb.ctypes.data_as(U64P)) == 0, X.err
+assert torch.equal(src, dst)
+t = torch.ones(4, device="cuda"); dist.all_reduce(t); torch.cuda.synchronize()
+assert par.gather_to_root(src)[0] is src
+dist.destroy_process_group()
+print("rccl self test ok")
+''')
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29655", HSA_ENABLE_IPC_MODE_LEGACY="0", COLORD_ROOT=ROOT)
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "rccl self test ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_bad_options_are_refused_before_the_process_group(tmp_path):
+    from colord_amd import mgpu
+    fq = tmp_path / "x.fastq"; fq.write_text("@a\nACGT\n+\n!!!!\n")
+    assert mgpu.main(["compress-ont", "-p", "fast", str(fq), str(tmp_path / "o")]) == 1
+    assert mgpu.main(["compress-ont", "-q", "7-avg", str(fq), str(tmp_path / "o")]) == 1
+    assert mgpu.main(["compress-ont", "-k", "40", "-a", "22", str(fq), str(tmp_path / "o")]) == 1
+    assert mgpu.main(["compress-ont", str(tmp_path / "missing.fastq"), str(tmp_path / "o")]) == 1
