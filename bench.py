@@ -68,6 +68,7 @@ def parse():
                     help="wall-clock budget of the whole process (the driver stops a run after 1800 s).  If (steps + warmup) passes over --bases "
                          "cannot finish inside it — estimated up front at 1.1 Gbases/s/GPU, then checked against the first warm-up pass — the input "
                          "is cut to a prefix of the file that can, and `config.workload` says so")
+    ap.add_argument("--e2e-bases", type=float, default=5.0e9, help="bases of the FASTQ the command-line compressor is timed on, file to archive (T_e2e); 0: skip")
     ap.add_argument("--no-qual", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ref-cut", action="store_true", help="skip the extra pass with the reference's 4-Mi-symbol coder parts (the byte-identical mode)")
@@ -366,6 +367,31 @@ def cpu_baseline_and_size_check(ctx, qctx, sample_bases: float, coverage: float,
     return cb, size
 
 
+def e2e_cli(bases: float, coverage: float, k: int, a: int):
+    """T_e2e: `colord_hip compress-ont` from open(FASTQ) to close(archive) — parsing, upload, all three passes, the header
+    stream, the archive — on a synthetic FASTQ of the same recipe written by the host generator; the reference's part cut (the
+    archive is the reference's, byte for byte), k / a of the main run."""
+    from colord_amd import ontsim
+    ours = os.path.join(ROOT, "colord_amd", "colord_hip")
+    if not os.path.exists(ours) or bases <= 0:
+        return None
+    table = ontsim.ReadTable(seed=103, genome_len=max(1_000_000, int(bases / coverage)), target_bases=int(bases))
+    with tempfile.TemporaryDirectory() as tmp:
+        fq = os.path.join(tmp, "e2e.fastq")
+        t0 = time.time()
+        n_bases = ontsim.write_fastq(table, fq)
+        t_gen = time.time() - t0
+        t0 = time.time()
+        r = subprocess.run([ours, "compress-ont", "-v", "-k", str(k), "-a", str(a), fq, os.path.join(tmp, "e2e.colord")], capture_output=True, text=True)
+        dt = time.time() - t0
+        if r.returncode != 0:
+            return {"error": (r.stderr or r.stdout)[-300:]}
+        phases = [l.strip() for l in r.stderr.splitlines() if l.strip().startswith("[")][-12:]
+        return {"value": n_bases / dt / 1e9, "unit": "Gbases/s", "seconds": round(dt, 2), "bases": n_bases, "fastq_bytes": os.path.getsize(fq),
+                "archive_bytes": os.path.getsize(os.path.join(tmp, "e2e.colord")), "fastq_written_in_s": round(t_gen, 1), "phases": phases,
+                "what": f"colord_hip compress-ont -k {k} -a {a} file -> archive, whole process (parser thread + mapped file, pinned double buffers, reference part cut)"}
+
+
 def load_traffic(kernel: str):
     """HBM bytes per launch of `kernel` from the committed PMC passes (tools/pmc_traffic.py -> profiles/r02_traffic.json)."""
     path = os.path.join(ROOT, "profiles", "r02_traffic.json")
@@ -526,7 +552,7 @@ def main():
             rt = round_trip_check(ctx, table, shard, sink, prm, info, r0)
         timer_txt = ("T_core (SURVEY 8d): packed bases + quality bytes resident in HBM -> every compressed part in pinned host memory" if sink is not None
                      else "packed bases + quality bytes resident in HBM -> every compressed part gathered to rank 0 (device)")
-        cb, size = (None, None)
+        cb, size, e2e = (None, None, None)
         if not args.no_cpu_baseline and world == 1:
             shard.free()                                    # the sample runs (and the command-line compressor) need the memory:
             del dna_out, qual_out, sink                     # give everything back, pools included, and start from fresh contexts
@@ -537,6 +563,13 @@ def main():
             ctx = Context(local)
             qctx = Context(local) if qctx is not None else None
             cb, size = cpu_baseline_and_size_check(ctx, qctx, args.cpu_sample_bases, args.coverage, args.pack_symbols, k, a)
+            ctx.close()
+            if qctx is not None:
+                qctx.close()
+            torch.cuda.empty_cache()
+            e2e = e2e_cli(args.e2e_bases, args.coverage, k, a)
+            ctx = Context(local)
+            qctx = Context(local) if qctx is not None else None
         value = total_bases * args.steps / dt / 1e9
         line = {
             "metric": "input Gbases/s + archive size vs ref, ONT 50 Gb at 1/2/4/8 MI355X", "value": value,
@@ -558,7 +591,7 @@ def main():
                        "dna_bytes": total_dna, "qual_bytes": total_qual,
                        "parallelism": f"reads sharded x{world} in file order, k-mer set + reference reads + index replicated (RCCL), one model domain per GPU" if world > 1 else "single GPU",
                        "input_generation_s": round(t_gen, 1), "rank0_sizes": info},
-            "roofline": roof, "cpu_baseline": cb, "size_check": size, "ref_cut": ref_cut,
+            "roofline": roof, "cpu_baseline": cb, "size_check": size, "ref_cut": ref_cut, "t_e2e": e2e,
         }
         print(json.dumps(line))
     else:

@@ -15,6 +15,11 @@
 #include <chrono>
 #include <ctime>
 #include <thread>
+#include <sys/mman.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <condition_variable>
+#include <mutex>
 
 namespace {
 struct Preset { int level; uint32_t ci, cs, f, c, max_rec, min_part_alt; int qual_mode; int sparse; double g; };
@@ -84,6 +89,9 @@ struct Chunk {
 };
 struct Reader {
 	gzFile g = nullptr; bool gz = false, fastq = true; uint64_t file_bytes = 0, total_bytes = 0, header_symbols = 0;
+	// plain FASTQ: the file is mapped and its lines go straight from the mapping into the pinned chunk buffers (one copy; the
+	// generic path below copies every byte three times through zlib's buffer and a line string)
+	const uint8_t* map = nullptr; const uint8_t* mp = nullptr; const uint8_t* me = nullptr;
 	std::vector<uint8_t> buf; size_t pos = 0, len = 0; bool eof = false;
 	std::string line[4]; int which = 0;                          // FASTQ record under construction
 	std::string fa_header, fa_seq; int fa_state = 0;            // FASTA: 0 header, 1 EOLs after header, 2 read, 3 EOLs after / inside read
@@ -104,6 +112,49 @@ struct Reader {
 		if (!len) die("file " + path + " is empty");
 		if (buf[0] != '@' && buf[0] != '>') die("unknown file format (the first character must be '@' or '>')");      // in_reads.cpp:256-262
 		fastq = buf[0] == '@';
+		if (!gz && fastq && file_bytes && !getenv("COLORD_HIP_NO_MMAP"))
+		{
+			const int fd = ::open(path.c_str(), O_RDONLY);
+			if (fd >= 0)
+			{
+				void* m = mmap(nullptr, file_bytes, PROT_READ, MAP_PRIVATE, fd, 0);
+				::close(fd);
+				if (m != MAP_FAILED) { (void)madvise(m, file_bytes, MADV_SEQUENTIAL); map = mp = (const uint8_t*)m; me = map + file_bytes; total_bytes = file_bytes; }
+			}
+		}
+	}
+	// one line of the mapping: [a, b) without its end-of-line characters; lines end at '\n' or '\r', empty lines are skipped (in_reads.cpp:188-226)
+	bool map_line(const uint8_t*& a, const uint8_t*& b, bool short_line)
+	{
+		while (mp < me && (*mp == '\n' || *mp == '\r')) ++mp;
+		if (mp >= me) return false;
+		a = mp;
+		const uint8_t* q = (const uint8_t*)memchr(mp, '\n', (size_t)(me - mp));
+		b = q ? q : me;
+		mp = q ? q + 1 : me;
+		if (b > a && b[-1] == '\r') --b;
+		if (short_line) { const uint8_t* r = (const uint8_t*)memchr(a, '\r', (size_t)(b - a)); if (r) { mp = r + 1; b = r; } }   // (a lone '\r' ends a line too; in a sequence or quality line it is refused as a symbol / quality value)
+		return true;
+	}
+	bool next_chunk_mapped(Chunk& ch, uint64_t target)
+	{
+		ch.clear();
+		auto chunk_full = [&]() { return ch.n >= target && ch.pack_acc == 0 && ch.off.size() > 1; };
+		while (!chunk_full())
+		{
+			const uint8_t *h0, *h1, *s0, *s1, *p0, *p1, *q0, *q1;
+			if (!map_line(h0, h1, true)) break;
+			if (!map_line(s0, s1, false) || !map_line(p0, p1, true) || !map_line(q0, q1, false)) die("truncated FASTQ record at the end of the input");
+			if (*h0 != '@') die("FASTQ record does not start with '@'");
+			if (*p0 != '+') die("FASTQ record without '+' line");
+			if (s1 - s0 != q1 - q0) die("sequence and quality lengths differ");
+			header_symbols += (uint64_t)(h1 - h0) + (uint64_t)(p1 - p0);
+			const bool eq = p1 - p0 > 1;
+			if (eq && ((p1 - p0) != (h1 - h0) || memcmp(p0 + 1, h0 + 1, (size_t)(h1 - h0 - 1)) != 0)) die("quality header not empty but different than read header");   // in_reads.cpp:79-92
+			add_record(ch, (const char*)h0 + 1, (size_t)(h1 - h0 - 1), (const char*)s0, (size_t)(s1 - s0), (const char*)q0, eq);
+		}
+		if (ch.off.size() > 1 && ch.packs.back() != ch.off.size() - 1) { ch.packs.push_back((uint32_t)(ch.off.size() - 1)); ch.pack_acc = 0; }
+		return ch.off.size() > 1;
 	}
 	void fill() { const int n = gzread(g, buf.data(), (unsigned)buf.size()); if (n < 0) die("read error (zlib)"); len = (size_t)n; pos = 0; total_bytes += len; if (!n) eof = true; }
 	void add_record(Chunk& ch, const char* id, size_t id_len, const char* seq, size_t seq_len, const char* qual, bool plus_eq)
@@ -136,6 +187,7 @@ struct Reader {
 	// fills `ch` up to the first pack boundary at or after `target` bases; returns false when the input is exhausted and ch is empty
 	bool next_chunk(Chunk& ch, uint64_t target)
 	{
+		if (map) return next_chunk_mapped(ch, target);
 		ch.clear();
 		auto chunk_full = [&]() { return ch.n >= target && ch.pack_acc == 0 && ch.off.size() > 1; };
 		while (!eof && !chunk_full())
@@ -313,14 +365,30 @@ int run_compress(int argc, char** argv)
 	}
 
 	// pass 1 while parsing: every chunk goes to HBM (2-bit arena + quality bytes) and stays there for the three passes
-	std::vector<DevChunk> chunks; Chunk host;
-	while (R.next_chunk(host, (uint64_t)O.chunk_bases))
+	// (the parser fills one pinned buffer on a thread of its own while this thread uploads and scans the other)
+	std::vector<DevChunk> chunks; Chunk hostbuf[2];
+	std::mutex pmu; std::condition_variable pcv; int filled[2] = { 0, 0 };      // 0 free, 1 full, 2 end of input
+	std::thread parser([&]() {
+		for (int i = 0;; i ^= 1)
+		{
+			{ std::unique_lock<std::mutex> l(pmu); pcv.wait(l, [&]() { return filled[i] == 0; }); }
+			const bool ok = R.next_chunk(hostbuf[i], (uint64_t)O.chunk_bases);
+			{ std::lock_guard<std::mutex> l(pmu); filled[i] = ok ? 1 : 2; }
+			pcv.notify_all();
+			if (!ok) break;
+		}
+	});
+	for (int hi = 0;; hi ^= 1)
 	{
+		{ std::unique_lock<std::mutex> l(pmu); pcv.wait(l, [&]() { return filled[hi] != 0; }); }
+		if (filled[hi] == 2) break;
+		Chunk& host = hostbuf[hi];
 		DevChunk dc; dc.n_reads = (uint32_t)(host.off.size() - 1); dc.n_bases = host.n; dc.packs = host.packs;
 		if (with_qual)
 		{	// quality bytes outside 33..128 would index past the coder's tables: the input is rejected, not coded (qualities are Phred+33)
-			uint8_t lo = 255, hi = 0; for (uint64_t i = 0; i < host.n; ++i) { lo = std::min(lo, host.quals[i]); hi = std::max(hi, host.quals[i]); }
-			if (host.n && (lo < 33 || hi > 33 + 95)) die("quality values outside '!'..'~'+1 (Phred+33, 0..95) are not supported");
+			uint8_t lo = 255, hi8 = 0; const uint8_t* qv = host.quals;
+			for (uint64_t i = 0; i < host.n; ++i) { lo = qv[i] < lo ? qv[i] : lo; hi8 = qv[i] > hi8 ? qv[i] : hi8; }
+			if (host.n && (lo < 33 || hi8 > 33 + 95)) die("quality values outside '!'..'~'+1 (Phred+33, 0..95) are not supported");
 		}
 		uint8_t* d_bases = nullptr;
 		hipck(hipMalloc((void**)&d_bases, host.n + 1), "hipMalloc"); hipck(hipMalloc((void**)&dc.d_off, host.off.size() * 8), "hipMalloc");
@@ -331,8 +399,11 @@ int run_compress(int argc, char** argv)
 		hipck(hipFree(d_bases), "hipFree");
 		ck(ctx, cl_compressor_count_add(cmp, dc.reads), "pass 1");
 		chunks.push_back(std::move(dc));
+		{ std::lock_guard<std::mutex> l(pmu); filled[hi] = 0; }
+		pcv.notify_all();
 	}
-	host.release();
+	parser.join();
+	hostbuf[0].release(); hostbuf[1].release();
 	lap("input parsed, uploaded and scanned (pass 1)");
 	const uint32_t n = (uint32_t)R.n_reads; const uint64_t total = R.n_bases;
 	if (!n) die("no reads in " + O.in);
