@@ -393,12 +393,15 @@ def e2e_cli(bases: float, coverage: float, k: int, a: int):
 
 
 def load_traffic(kernel: str):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (tools/pmc_traffic.py -> profiles/r02_traffic.json)."""
-    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    """HBM bytes per launch of `kernel` from the committed PMC passes (tools/pmc_traffic.py -> profiles/r03_traffic.json)."""
+    path = os.path.join(ROOT, "profiles", "r03_traffic.json")
     if not os.path.exists(path):
         return None, None
     t = json.load(open(path))
-    e = t.get("kernels", {}).get(kernel.split("<")[0].strip())
+    key = kernel.split("<")[0].strip()
+    if key == "k_sort_scatter":                             # (with / without a value array: tools/pmc_traffic.py keeps them apart)
+        key += "<true>" if ", true" in kernel else "<false>"
+    e = t.get("kernels", {}).get(key)
     if not e:
         return None, t.get("source")
     return e["hbm_bytes_per_launch"], t.get("source")

@@ -67,7 +67,12 @@ def per_kernel(db_path, counter):
 
 def base_name(full):
     n = re.sub(r"^void\s+", "", full).replace("(anonymous namespace)::", "")
-    return re.split(r"[<(]", n, 1)[0]
+    b = re.split(r"[<(]", n, 1)[0]
+    if b == "k_sort_scatter":                          # (with and without a value array: two different byte counts per key)
+        m = re.search(r"k_sort_scatter<[^,]+,\s*(true|false)", n)
+        if m:
+            return f"k_sort_scatter<{m.group(1)}>"
+    return b
 
 
 def main():
@@ -102,7 +107,7 @@ def main():
         if full in rw:
             e["write_KB"] += rw[full][1]
     for b, e in kernels.items():
-        pr, pw = PATTERN.get(b, ("read_b128", "write_b128"))
+        pr, pw = PATTERN.get(b.split("<")[0], ("read_b128", "write_b128"))
         # FETCH_SIZE under-reports coalesced reads (x2 on gfx950): corrected.  A WRITE_SIZE above the payload (16-byte records to
         # scattered slots: 2x) is real traffic — partial lines go out as 32-byte writes — so it is kept and reported as amplification.
         fr, cw_ = factors.get(pr) or 1.0, factors.get(pw) or 1.0
