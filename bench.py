@@ -544,10 +544,15 @@ def main():
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 rt = round_trip_check(ctx, table, shard, sink, prm, info, r0) if sink is not None else None   # (before the sink is overwritten)
+                warm2 = left > 9.0 * (dt / args.steps)
+                if warm2:                                  # (an untimed pass first, as for the default cut: other buffer sizes, other pool shape)
+                    hot_path_step(ctx, qctx, shard, prm, not args.no_qual, None, dna_out, qual_out, shard.n_bases, ref_cut=True, sink=sink)
+                    torch.cuda.synchronize()
+                t1 = time.perf_counter()
                 inf2 = hot_path_step(ctx, qctx, shard, prm, not args.no_qual, None, dna_out, qual_out, shard.n_bases, ref_cut=True, sink=sink)
                 torch.cuda.synchronize()
                 dt2 = time.perf_counter() - t1
-                ref_cut = {"part_symbols": 1 << 22, "ms_per_step": dt2 * 1e3, "value": total_bases / dt2 / 1e9, "unit": "Gbases/s", "steps": 1,
+                ref_cut = {"part_symbols": 1 << 22, "ms_per_step": dt2 * 1e3, "value": total_bases / dt2 / 1e9, "unit": "Gbases/s", "steps": 1, "warmup": 1 if warm2 else 0,
                            "dna_bytes": inf2["dna_bytes"], "qual_bytes": inf2["qual_bytes"], "parts": sum(len(c[2]) - 1 for c in shard.chunks),
                            "stream_bytes_vs_default_cut": (inf2["dna_bytes"] + inf2["qual_bytes"]) / max(1, total_dna + total_qual),
                            "note": "same input, one pass, coder parts = the reference's reader packs: the streams are the reference's bytes (size_check.streams_vs_ref_ref_cut)"}
