@@ -185,7 +185,9 @@ extern "C" cl_status cl_compressor_genome_add(cl_compressor* c, const cl_reads* 
 	if (!c || !seqs) return CL_E_INVALID;
 	cl_ctx* ctx = c->ctx;
 	if (c->phase != 0) return cl_fail(ctx, CL_E_INVALID, "cl_compressor_genome_add: pass 1 is already finished");
-	if (c->world > 1) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_compressor_genome_add: reference-genome mode with sharded reads is not supported");
+	// Sharded reads: every rank is given the same sequences; rank 0 alone scans them (the k-mers travel to their owners with
+	// the rest in count_finish), the others only note the numbers the statistics are corrected by.
+	if (c->world > 1 && c->rank != 0) { c->genome_seqs += seqs->n_reads; c->genome_len += seqs->total_bases; return CL_OK; }
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	const uint32_t f = c->P.f;
 	uint64_t want = f > 1 ? (uint64_t)(seqs->total_bases / f * 1.15) + 4096 : seqs->total_bases + 64;

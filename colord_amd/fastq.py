@@ -108,6 +108,56 @@ def read_fastx(path: str) -> ReadSet:
     return ReadSet(bases, offsets, q, headers, plus_eq, is_fastq)
 
 
+def read_genome(path: str):
+    """Multi-FASTA (plain or gzip) of a reference genome -> (codes uint8 0..3 back to back, offsets uint64 n + 1): the reader of
+    CReferenceGenome (reference_genome.cpp:106-196, reference_genome.h:50-55; csrc/cli/genome_io.hpp is the C++ form): header
+    lines start a new sequence, only A C G T of either case are kept.  A line starting with '>' right after a header line
+    belongs to the sequence (the reference's state machine looks for headers only after sequence lines)."""
+    with _open(path) as f:
+        data = np.frombuffer(f.read(), dtype=np.uint8)
+    if not data.size:
+        raise ValueError(f"file {path} is empty")
+    if data[0] != ord(">"):
+        raise ValueError("wrong reference genome file format, multi fasta expected")
+    eol = (data == 10) | (data == 13)
+    first_of_line = np.empty(data.size, dtype=bool)
+    first_of_line[0] = True
+    first_of_line[1:] = eol[:-1] & ~eol[1:]
+    cand = np.flatnonzero(first_of_line & (data == ord(">")))
+    eol_pos = np.flatnonzero(eol)
+    lut = np.full(256, 4, dtype=np.uint8)
+    for i, ch in enumerate("ACGT"):
+        lut[ord(ch)] = lut[ord(ch.lower())] = i
+    codes = lut[data]
+    keep = codes < 4
+    starts = []
+    prev_end = -1                                   # end (first EOL) of the last accepted header line
+    for h in cand.tolist():
+        if prev_end >= 0 and not (~eol[prev_end:h]).any():
+            continue                                # only line ends since the last header: this line is sequence data
+        e = int(eol_pos[np.searchsorted(eol_pos, h)]) if eol_pos.size and eol_pos[-1] > h else data.size
+        keep[h:e] = False
+        starts.append(h)
+        prev_end = e
+    kept_before = np.concatenate([[0], np.cumsum(keep, dtype=np.int64)])
+    off = np.array([int(kept_before[h]) for h in starts] + [int(kept_before[-1])], dtype=np.uint64)
+    return np.ascontiguousarray(codes[keep]), off
+
+
+def genome_pseudo_reads(codes: np.ndarray, off: np.ndarray, read_len: int, overlap: int):
+    """Overlapping pieces of the genome's sequences (reference_genome.cpp:391-419): (codes, offsets) of the pseudo reads."""
+    if read_len <= overlap:
+        raise ValueError("reference genome: pseudo-read length does not exceed the overlap")
+    pieces, lens = [], []
+    for s in range(len(off) - 1):
+        b, n = int(off[s]), int(off[s + 1] - off[s])
+        for start in range(0, n, read_len - overlap):
+            e = min(start + read_len, n)
+            pieces.append(codes[b + start:b + e]); lens.append(e - start)
+    out = np.concatenate(pieces) if pieces else np.zeros(0, np.uint8)
+    return out, np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+
+
 def _record_start(f, pos: int, size: int) -> int:
     """Offset of the first FASTQ record that starts at or after byte `pos` of a plain 4-line FASTQ: a line that starts with '@'
     and whose next-but-one line starts with '+' (a quality line may start with '@' too; it is followed by a header, not by a

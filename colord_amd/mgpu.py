@@ -2,7 +2,7 @@
 order, ONE archive written by rank 0.
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 -m colord_amd.mgpu \\
-        compress-ont [-p ratio|balanced|memory] [-q MODE] [--chunk-bases X] input.fastq[.gz] output.colord
+        compress-ont [-p ratio|balanced|memory] [-q MODE] [-G genome.fa [-s]] [--chunk-bases X] input.fastq[.gz] output.colord
 
 What is sharded and what is exchanged (the exchanges themselves are cl_exchange callbacks of the library's
 chunked compressor, csrc/stream.hip, carried out by colord_amd.parallel.TorchExchange):
@@ -15,7 +15,9 @@ chunked compressor, csrc/stream.hip, carried out by colord_amd.parallel.TorchExc
     (u32 n, then per domain u64 first read, u64 first part); `colord_hip decompress` restarts its models there.  With one rank the
     archive is the reference's format byte for byte; with several, the reference's decompressor cannot decode it (it has one
     model set for the whole stream) — this build's decompressor can;
-  * compressed parts are gathered to rank 0 (point-to-point sends), which adds the `header`, `meta` and `info` streams.
+  * compressed parts are gathered to rank 0 (point-to-point sends), which adds the `header`, `meta` and `info` streams;
+  * reference-genome mode (-G, compression.cpp:405-447): every rank reads the genome; rank 0 counts its k-mers and contributes the
+    pseudo reads (reference reads 0 .. n-1 of the replicated store), -s stores the genome in the archive (`ref-genome`).
 Host-side plumbing in Python; every byte of `dna` / `qual` comes from the HIP library, `header` from its host id coder.
 """
 from __future__ import annotations
@@ -29,7 +31,7 @@ import torch
 import torch.distributed as dist
 
 from . import _native as N, archive as AR, parallel as par
-from .fastq import ReadSet, read_fastx, read_fastx_range
+from .fastq import ReadSet, read_fastx, read_fastx_range, read_genome, genome_pseudo_reads
 
 # arg_parse.cpp:89-408 — [source][priority]: level, ci, cs, f, c, max_rec, min_part_alt, qual_mode, sparse, g
 PRESETS = {
@@ -95,7 +97,7 @@ def encode_headers(headers, plus_eq, header_mode: int):
 
 def compress_readset(rs: ReadSet, out_path: str | None, source: int = 0, priority: str = "memory", qual_mode: int | None = None, header_mode: int = 0,
                      k: int = 0, a: int = 0, chunk_bases: float = 1.0e9, est_bases: float | None = None, command: str = "", file_bytes: int = 0, device: int | None = None,
-                     presharded: bool = False):
+                     presharded: bool = False, genome: str | None = None, store_genome: bool = False):
     """Compresses `rs`.  presharded = False: every rank holds the same ReadSet and takes its share (tests); True: `rs` is this
     rank's OWN contiguous share of the file (read_fastx_range: no rank holds the whole input), totals and headers travel through
     the process group.  Rank 0 writes out_path and returns a dict of sizes."""
@@ -144,10 +146,26 @@ def compress_readset(rs: ReadSet, out_path: str | None, source: int = 0, priorit
         q = torch.from_numpy(rs.quals[o0:o1]).to(ctx.device) if with_qual else None
         chunks.append((arena, (packs[ca:cb + 1] - packs[ca]).astype(np.uint32), q, off))
     cmp_ = ctx.compressor(prm, qargs, qctx, exchange, expected_bases=int(lens.sum()))
+    g_codes = g_off = None
+    genome_read_len, genome_overlap, n_pseudo = 0, (k - 1) * 10, 0                               # compression.cpp:407,447
     try:
+        if genome:
+            g_codes, g_off = read_genome(genome)
+            gr = ctx.pack_reads(torch.from_numpy(g_codes), torch.from_numpy(g_off.astype(np.int64)))
+            cmp_.genome_add(gr)                               # (rank 0 scans it; the others note its size)
+            gr.free()
         for ch in chunks:
             cmp_.count_add(ch[0])
         cmp_.count_finish()
+        if genome:
+            genome_read_len = 20 * cmp_.info()["mean_read_len"]
+            if genome_read_len >= 1 << 32:
+                raise ValueError("reference genome: pseudo reads too long")
+            p_codes, p_off = genome_pseudo_reads(g_codes, g_off, genome_read_len, genome_overlap)
+            n_pseudo = len(p_off) - 1
+            pr = ctx.pack_reads(torch.from_numpy(p_codes), torch.from_numpy(p_off))
+            cmp_.pseudo_reads(pr)
+            pr.free()
         for ch in chunks:
             cmp_.refs_add(ch[0])
         cmp_.refs_finish()
@@ -212,10 +230,10 @@ def compress_readset(rs: ReadSet, out_path: str | None, source: int = 0, priorit
         assert first_read == tot_reads
         h_st = AR.Stream("header"); h_st.parts = encode_headers(all_headers, all_plus, header_mode)
         n = tot_reads
-        tot_ref = n
+        tot_ref = n + n_pseudo
         if sparse:
-            accd = np.zeros(n, np.uint8)
-            N.load().cl_ref_accept(n, 0, info["sparse_range"], 1.0, accd.ctypes.data)
+            accd = np.zeros(n + n_pseudo, np.uint8)
+            N.load().cl_ref_accept(n, n_pseudo, info["sparse_range"], 1.0, accd.ctypes.data)
             tot_ref = int(accd.sum())
         meta = struct.pack("<IIiBQ", tot_ref, c, level, source, n * info["mean_read_len"])      # compression.cpp:704-779
         if with_qual:
@@ -225,12 +243,34 @@ def compress_readset(rs: ReadSet, out_path: str | None, source: int = 0, priorit
         meta += bytes([header_mode, 1 if sparse else 0])
         if sparse:
             meta += struct.pack("<Id", info["sparse_range"], 1.0)
-        meta += b"\0"
+        g_st = None
+        if genome:                                                                               # compression.cpp:764-777
+            n_seqs = len(g_off) - 1
+            g_off64 = np.ascontiguousarray(g_off, dtype=np.uint64)
+            meta += bytes([1, 1 if store_genome else 0]) + struct.pack("<III", genome_read_len, genome_overlap, n_pseudo)
+            if store_genome:                                                                     # reference_genome.cpp:325-370
+                cap, got = g_codes.size // 3 + 4096, C.c_uint64(0)
+                while True:
+                    buf = np.empty(cap, np.uint8)
+                    st_ = N.load().cl_genome_encode(g_codes.ctypes.data, g_off64.ctypes.data, n_seqs, buf.ctypes.data, cap, C.byref(got))
+                    if st_ != N.CL_E_CAPACITY:
+                        break
+                    cap = int(got.value)
+                if st_ != 0:
+                    raise RuntimeError("cannot code the reference genome")
+                g_st = AR.Stream("ref-genome"); g_st.parts = [(n_seqs, buf[:got.value].tobytes())]
+            else:
+                md = np.zeros(16, np.uint8)
+                if N.load().cl_genome_md5(g_codes.ctypes.data, g_off64.ctypes.data, n_seqs, md.ctypes.data) != 0:
+                    raise RuntimeError("cannot checksum the reference genome")
+                meta += md.tobytes()
+        else:
+            meta += b"\0"
         m_st = AR.Stream("meta"); m_st.parts = [(0, meta)]
         cmd = command.encode()
         inf = struct.pack("<IIIQQIQI", 1, 2, 1, file_bytes, tot_bases, n, int(time.time()), len(cmd)) + cmd      # utils.cpp:326-342
         i_st = AR.Stream("info"); i_st.parts = [(0, inf)]
-        streams = [m_st, h_st, d_st] + ([q_st] if with_qual else [])
+        streams = [m_st] + ([g_st] if g_st is not None else []) + [h_st, d_st] + ([q_st] if with_qual else [])
         if world > 1:
             dom = AR.Stream("hipdomains")
             dom.parts = [(0, struct.pack("<I", world) + b"".join(struct.pack("<QQ", fr, fp) for fr, fp in domains))]
@@ -239,7 +279,7 @@ def compress_readset(rs: ReadSet, out_path: str | None, source: int = 0, priorit
         if out_path:
             AR.write_archive(out_path, streams)
         res = dict(n_reads=n, n_bases=tot_bases, k=k, a=a, dna_bytes=sum(len(p) for _, p in d_st.parts), qual_bytes=sum(len(p) for _, p in q_st.parts),
-                   header_bytes=sum(len(p) for _, p in h_st.parts), dna_parts=len(d_st.parts), refs=info["n_refs_total"], domains=domains, reads_per_rank=reads_per_rank,
+                   header_bytes=sum(len(p) for _, p in h_st.parts), dna_parts=len(d_st.parts), refs=info["n_refs_total"], domains=domains, reads_per_rank=reads_per_rank, n_pseudo=n_pseudo,
                    exchanged_bytes_rank0=exchange.bytes_moved if exchange else 0)
     ctx.close()
     if qctx is not None:
@@ -253,7 +293,7 @@ def main(argv=None):
         print(__doc__, file=sys.stderr)
         return 1
     source = {"compress-ont": 0, "compress-pbraw": 1, "compress-pbhifi": 2}[argv[0]]
-    prio, qm, hm, chunk, k, a, pos = "memory", None, 0, 1.0e9, 0, 0, []
+    prio, qm, hm, chunk, k, a, pos, genome, store = "memory", None, 0, 1.0e9, 0, 0, [], None, False
     i = 1
     while i < len(argv):
         x = argv[i]
@@ -273,6 +313,10 @@ def main(argv=None):
             k = int(argv[i + 1]); i += 2
         elif x in ("-a", "--anchor-len"):
             a = int(argv[i + 1]); i += 2
+        elif x in ("-G", "--reference-genome"):
+            genome = argv[i + 1]; i += 2
+        elif x in ("-s", "--store-reference"):
+            store = True; i += 1
         elif x == "--chunk-bases":
             chunk = float(argv[i + 1]); i += 2
         else:
@@ -289,6 +333,12 @@ def main(argv=None):
         return 1
     if not os.path.isfile(pos[0]):
         print(f"cannot open {pos[0]}", file=sys.stderr)
+        return 1
+    if genome is not None and not os.path.isfile(genome):
+        print(f"cannot open {genome}", file=sys.stderr)
+        return 1
+    if store and genome is None:
+        print("-s needs -G", file=sys.stderr)
         return 1
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
@@ -314,11 +364,11 @@ def main(argv=None):
     if world > 1 and int(ok.item()) == 1:
         rs = shard[0]
         est = size * 0.49
-        res = compress_readset(rs, pos[1], source, prio, qm, hm, k, a, chunk, est, "colord_amd.mgpu " + " ".join(argv), size, presharded=True)
+        res = compress_readset(rs, pos[1], source, prio, qm, hm, k, a, chunk, est, "colord_amd.mgpu " + " ".join(argv), size, presharded=True, genome=genome, store_genome=store)
     else:
         rs = read_fastx(pos[0])
         est = size * ((2.08 if rs.is_fastq else 3.98) if gz else (0.49 if rs.is_fastq else 0.98))      # compression.cpp:52-61
-        res = compress_readset(rs, pos[1], source, prio, qm, hm, k, a, chunk, est, "colord_amd.mgpu " + " ".join(argv), size)
+        res = compress_readset(rs, pos[1], source, prio, qm, hm, k, a, chunk, est, "colord_amd.mgpu " + " ".join(argv), size, genome=genome, store_genome=store)
     if res is not None:
         print(f"colord_amd.mgpu: {res['n_reads']} reads, {res['n_bases']} bases on {world} GPU(s), k={res['k']} a={res['a']}; dna {res['dna_bytes']} B ({res['dna_parts']} parts), "
               f"qual {res['qual_bytes']} B, header {res['header_bytes']} B; {res['refs']} reference reads; {time.time() - t0:.2f} s", file=sys.stderr)

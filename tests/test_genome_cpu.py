@@ -75,3 +75,31 @@ def test_ragged_sequences_round_trip():
     dec = np.zeros(len(codes) + 1, np.uint8); doff = np.zeros(len(lens) + 1, np.uint64); got = C.c_uint64(0)
     assert lib.cl_genome_decode(out.ctypes.data, n.value, len(lens), dec.ctypes.data, len(dec), doff.ctypes.data, C.byref(got)) == 0
     assert np.array_equal(doff, off) and np.array_equal(dec[:got.value], codes)
+
+
+def test_multi_gpu_drivers_genome_reader_and_pseudo_reads(tmp_path):
+    """colord_amd.fastq.read_genome / genome_pseudo_reads (what `python -m colord_amd.mgpu -G` feeds the library): the checksum of
+    the reference's own archive through them, the state machine's corner cases, and the pseudo-read count the reference wrote."""
+    from colord_amd.fastq import read_genome, genome_pseudo_reads
+    import struct
+    p = tmp_path / "g.fna"
+    p.write_bytes(gzip.open(os.path.join(ROOT, "tests", "data", "M.bovis-reference.fna.gz"), "rb").read())
+    codes, off = read_genome(str(p))
+    c2, o2 = genome()
+    assert np.array_equal(codes, c2) and np.array_equal(off, o2)
+    meta = AR.read_archive(os.path.join(ARC, "c4_ont_genome_external.colord"))["meta"].parts[0][1]
+    read_len, overlap, n_pseudo = struct.unpack("<III", meta[-28:-16])
+    pc, po = genome_pseudo_reads(codes, off, read_len, overlap)
+    assert len(po) - 1 == n_pseudo and int(po[-1]) == len(pc)
+    assert np.array_equal(pc[:read_len], codes[:read_len]) and np.array_equal(pc[read_len:read_len + 10], codes[read_len - overlap:read_len - overlap + 10])
+    # CR LF, lower case, other letters dropped, a '>' line right after a header is sequence data, an empty last sequence is a sequence
+    q = tmp_path / "x.fa"
+    q.write_bytes(b">s1 x\nACGTN\nacgt\r\n>s2\n>ACG\nTT\n\n>s3\n")
+    codes, off = read_genome(str(q))
+    assert codes.tolist() == [0, 1, 2, 3, 0, 1, 2, 3, 0, 1, 2, 3, 3] and off.tolist() == [0, 8, 13, 13]
+    pc, po = genome_pseudo_reads(codes, off, 4, 1)
+    assert po.tolist() == [0, 4, 8, 10, 14, 16]
+    (tmp_path / "bad.fa").write_bytes(b"ACGT\n")
+    import pytest
+    with pytest.raises(ValueError):
+        read_genome(str(tmp_path / "bad.fa"))

@@ -119,3 +119,47 @@ def test_bad_options_are_refused_before_the_process_group(tmp_path):
     assert mgpu.main(["compress-ont", "-q", "7-avg", str(fq), str(tmp_path / "o")]) == 1
     assert mgpu.main(["compress-ont", "-k", "40", "-a", "22", str(fq), str(tmp_path / "o")]) == 1
     assert mgpu.main(["compress-ont", str(tmp_path / "missing.fastq"), str(tmp_path / "o")]) == 1
+
+
+def _m_bovis(tmp_path):
+    import gzip
+    fq, gen = str(tmp_path / "M.bovis.fastq"), str(tmp_path / "M.bovis-reference.fna")
+    open(fq, "wb").write(gzip.open(os.path.join(ROOT, "tests", "data", "M.bovis.fastq.gz"), "rb").read())
+    open(gen, "wb").write(gzip.open(os.path.join(ROOT, "tests", "data", "M.bovis-reference.fna.gz"), "rb").read())
+    return fq, gen
+
+
+@pytest.mark.parametrize("stored", [True, False])
+def test_reference_genome_mode_one_rank_is_the_reference_archive(tmp_path, stored):
+    """`-G genome [-s]` through the multi-GPU driver with one rank: the archive the unmodified reference wrote for config 4
+    (tests/golden/archives/c4_ont_genome_*), every stream but `info`."""
+    from colord_amd import mgpu
+    name = "c4_ont_genome_stored" if stored else "c4_ont_genome_external"
+    fq, gen = _m_bovis(tmp_path)
+    arc = str(tmp_path / "a.colord")
+    assert mgpu.main(["compress-ont", "-G", gen] + (["-s"] if stored else []) + [fq, arc]) == 0
+    a, b = AR.read_archive(os.path.join(ROOT, "tests", "golden", "archives", name + ".colord")), AR.read_archive(arc)
+    assert set(a) == set(b)
+    for s in a:
+        if s != "info":
+            assert [(m, hashlib.sha256(p).hexdigest()) for m, p in a[s].parts] == [(m, hashlib.sha256(p).hexdigest()) for m, p in b[s].parts], s
+
+
+@pytest.mark.parametrize("stored", [True, False])
+def test_reference_genome_mode_with_sharded_reads(tmp_path, stored):
+    """Two ranks, `-G genome [-s]`: rank 0 counts the genome's k-mers and contributes the pseudo reads to the replicated store, the
+    second rank's reads find them (and rank 0's reference reads) as candidates.  The archive decodes to the reference's output
+    and — same tuples, two model domains — stays close to the one-rank archive."""
+    name = "c4_ont_genome_stored" if stored else "c4_ont_genome_external"
+    exp = json.load(open(os.path.join(ROOT, "tests", "golden", "archives", "expected.json")))[name]
+    fq, gen = _m_bovis(tmp_path)
+    arc, out = str(tmp_path / "a.colord"), str(tmp_path / "o.fastq")
+    run_ranks(2, ["compress-ont", "-G", gen] + (["-s"] if stored else []) + ["--chunk-bases", "3e6", fq, arc], 29650 + int(stored))
+    b = AR.read_archive(arc)
+    assert "hipdomains" in b and ("ref-genome" in b) == stored
+    subprocess.check_call([CLI, "decompress"] + ([] if stored else ["-G", gen]) + [arc, out])
+    assert sha(out) == exp["decompressed_sha256"]
+    a = AR.read_archive(os.path.join(ROOT, "tests", "golden", "archives", name + ".colord"))
+    assert a["meta"].parts[0][1] == b["meta"].parts[0][1]                # pseudo-read geometry, reference count, checksum
+    one = sum(len(p) for _, p in a["dna"].parts)
+    assert sum(len(p) for _, p in b["dna"].parts) < one * 1.5           # a genome-less second rank would lose far more than a model restart
