@@ -68,32 +68,13 @@ __device__ inline uint64_t div_by_inv(uint64_t x, uint32_t d, uint64_t inv)
 	return q;
 }
 
-// Output bytes of one part.  The coder emits the top byte of `low` on every renormalisation step and only
-// shifts `low` in between, so the n bytes of one symbol are simply the top n bytes of `low`: they are
-// appended in one operation (big-endian accumulator, 8-byte aligned stores).
-struct ByteSink {
-	uint8_t* p; uint64_t n; uint64_t acc; uint32_t fill; uint64_t cap; bool overflow;
-	// append the top `nb` bytes (0..8) of v
-	__device__ inline void put_top(uint64_t v, uint32_t nb)
-	{
-		if (nb == 0) return;
-		const uint64_t B = v >> (64 - 8 * nb);                      // nb >= 1
-		const uint32_t total = fill + nb;
-		if (total < 8) { acc = (acc << (8 * nb)) | B; fill = total; return; }
-		const uint32_t k = 8 - fill;                                 // bytes that complete the word, 1..8
-		const uint32_t rest = nb - k;                                // 0..7
-		const uint64_t head = rest ? (B >> (8 * rest)) : B;
-		const uint64_t word = (k == 8) ? head : ((acc << (8 * k)) | head);
-		if (n + 8 <= cap) *(uint64_t*)(p + n) = __builtin_bswap64(word); else overflow = true;
-		n += 8;
-		acc = rest ? (B & ((1ULL << (8 * rest)) - 1)) : 0; fill = rest;
-	}
-	__device__ inline void flush()
-	{
-		if (n + fill <= cap) { for (uint32_t i = 0; i < fill; ++i) p[n + i] = (uint8_t)(acc >> (8 * (fill - 1 - i))); } else overflow = true;
-		n += fill; fill = 0; acc = 0;
-	}
-};
+// Output bytes of one part.  The coder emits the top byte of `low` on every renormalisation step and only shifts `low` in
+// between, so the n bytes of one symbol are simply the top n bytes of `low` as it was before the first shift: the whole
+// big-endian word is stored (unaligned) at the part's write position and the position advances by n — the bytes behind
+// them are overwritten by the next symbol's store, and the last store of a part (End(): 8 bytes of low) is exact, so no store
+// ever reaches beyond the part's final size.
+struct __attribute__((packed)) unaligned_u64 { uint64_t v; };
+__device__ inline void store_be64(uint8_t* p, uint64_t v) { ((unaligned_u64*)p)->v = __builtin_bswap64(v); }
 
 // one lane per part, one wave per group of 64 parts (sub_rc.h:72-100,203-210)
 static __global__ __launch_bounds__(64) void k_range_code(const triple_t* __restrict__ trip, const uint64_t* __restrict__ group_base,
@@ -104,14 +85,17 @@ static __global__ __launch_bounds__(64) void k_range_code(const triple_t* __rest
 	__builtin_amdgcn_s_setprio(3);                                          // a launch of this kernel lasts as long as its slowest chain: its waves go first on their SIMDs
 	const uint32_t p = blockIdx.x * 64 + threadIdx.x;
 	const bool live = p < n_parts;
-	const uint64_t TOP = 0x00ffffffffffffULL, MASK = 0xff00000000000000ULL;
+	const uint64_t TOP = 0x00ffffffffffffULL /* 2^48 - 1 */, MASK = 0xff00000000000000ULL;
 	uint64_t low = 0, range = MASK;
-	ByteSink sink{ live ? out + part_out_off[p] : nullptr, 0, 0, 0, live ? part_out_off[p + 1] - part_out_off[p] : 0, false };
+	uint8_t* outp = live ? out + part_out_off[p] : nullptr;
+	const uint64_t cap = live ? part_out_off[p + 1] - part_out_off[p] : 0;
+	const uint32_t cap8 = cap < 8 ? 0u : cap - 8 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)(cap - 8);    // last position an 8-byte store may start at
+	uint32_t n_out = 0; bool overflow = cap < 8 || cap > 0xfffffff0ull;
 	const uint32_t len = live ? part_len[p] : 0;
 	uint32_t lmax = len;
 #pragma unroll
 	for (int d = 32; d > 0; d >>= 1) { uint32_t t = __shfl_xor(lmax, d, 64); lmax = t > lmax ? t : lmax; }
-	if (lmax == 0) { if (live) { sink.put_top(0, 8); sink.flush(); part_size[p] = sink.n; } return; }
+	if (lmax == 0) { if (live) { if (!overflow) store_be64(outp, 0); part_size[p] = overflow ? ~0ULL : 8; } return; }
 	const triple_t* src = trip + group_base[blockIdx.x] + threadIdx.x;
 	constexpr uint32_t U = 8;
 	// three stages ahead of the chain: symbols two rounds ahead, their reciprocals one round ahead (looked up from the symbols
@@ -138,22 +122,42 @@ static __global__ __launch_bounds__(64) void k_range_code(const triple_t* __rest
 			const bool act = pos + u < len;
 			const uint64_t tx = act ? cur[u] : NEUTRAL_X, inv = act ? icur[u] : NEUTRAL_Y;
 			const uint32_t tot = (uint32_t)(tx & 0x1fffff), freq = (uint32_t)((tx >> 21) & 0x1fffff), cum = (uint32_t)(tx >> 42);
+			// range / tot.  With inv = floor((2^64-1) / tot) = (2^64 - 1 - rho) / tot, 0 <= rho < tot:
+			//   range inv / 2^64 = range / tot - (range / 2^64) (1 + rho) / tot > range / tot - 1,
+			// so the high product is the quotient or one below it, the remainder it leaves is below 2 tot < 2^22 and 32-bit
+			// arithmetic finds it exactly.
 			uint64_t q = __umul64hi(range, inv);
-			uint64_t r = range - q * tot;
-			if (r >= tot) { ++q; r -= tot; }
-			if (r >= tot) { ++q; }
-			range = q;
-			low += range * cum;
-			range *= freq;
-			if (range == 0) { sink.overflow = true; range = MASK; }           // only with corrupt triples; keeps the loop finite
+			const uint32_t r = (uint32_t)range - (uint32_t)q * tot;
+			q += (uint32_t)(r >= tot);
+			low += q * cum;
+			range = q * freq;
+			// renormalisation (sub_rc.h:72-100): while range <= TOP, give out the top byte of low; a step whose interval straddles a
+			// top-byte boundary first cuts the range at it.  Every lane takes the steps of the lane that needs most (predicated);
+			// after 8 steps nothing of low is left: a range that is still empty then is 0 (corrupt triples) and stays 0 — seen at the end.
 			const uint64_t low0 = low;
 			uint32_t nb = 0;
-			while (range <= TOP)
+			uint32_t rh = (uint32_t)(range >> 32), rl = (uint32_t)range, lh = (uint32_t)(low >> 32), ll = (uint32_t)low;
+			asm volatile("" : "+v"(rh), "+v"(rl), "+v"(lh), "+v"(ll));                 // (keeps low + range out of the multiply-adds above)
+			auto step = [&]()
+			{	// (32-bit halves: 64-bit shifts and compares are slow instructions)
+				const bool need = rh < 0x00010000u;                                      // range <= TOP = 2^48 - 1
+				const uint32_t sh = lh + rh + (uint32_t)(rl > ~ll);                      // high half of low + range
+				const bool straddle = (lh ^ sh) > 0x00ffffffu;                           // (low ^ (low + range)) & MASK
+				const uint32_t fh = straddle ? (~lh & 0x0000ffffu) : rh, fl = straddle ? ~ll : rl;   // (low | TOP) - low
+				rh = need ? __builtin_amdgcn_alignbit(fh, fl, 24) : rh; rl = need ? fl << 8 : rl;
+				lh = need ? __builtin_amdgcn_alignbit(lh, ll, 24) : lh; ll = need ? ll << 8 : ll;
+				nb += need ? 1u : 0u;
+			};
+			step();                                                                      // (nearly every symbol: some lane of the wave needs one)
+			if (__any(rh < 0x00010000u))
 			{
-				if ((low ^ (low + range)) & MASK) { uint64_t rr = low; range = (rr | TOP) - rr; }
-				low <<= 8; range <<= 8; ++nb;
+#pragma unroll 1
+				for (uint32_t it = 1; it < 8; ++it) { step(); if (!__any(rh < 0x00010000u)) break; }
 			}
-			sink.put_top(low0, nb);
+			range = ((uint64_t)rh << 32) | rl; low = ((uint64_t)lh << 32) | ll;
+			// the bytes: the whole word at the write position (held inside the part's room; a part that outgrows it is seen at the end)
+			if (nb) store_be64(outp + (n_out < cap8 ? n_out : cap8), low0);
+			n_out += nb;
 		}
 	};
 	for (uint32_t pos = 0; pos < lmax; pos += 3 * U)
@@ -165,7 +169,8 @@ static __global__ __launch_bounds__(64) void k_range_code(const triple_t* __rest
 		round(pos + 2 * U, C, iC, A, iA, B);
 	}
 	if (!live) return;
-	sink.put_top(low, 8);                                                    // End(): 8 bytes of low (sub_rc.h:203-210)
-	sink.flush();
-	part_size[p] = sink.overflow ? ~0ULL : sink.n;
+	if ((uint32_t)(range >> 32) < 0x00010000u) overflow = true;                      // (an empty range: corrupt triples)
+	if (n_out <= cap8 && !overflow) store_be64(outp + n_out, low); else overflow = true;       // End(): 8 bytes of low (sub_rc.h:203-210)
+	n_out += 8;
+	part_size[p] = overflow ? ~0ULL : n_out;
 }

@@ -1,0 +1,77 @@
+// Differential test of k_range_code (csrc/rc_dev.hpp) against a plain host loop of the reference's interval arithmetic
+// (sub_rc.h:72-100,203-210) on random triples: sizes and bytes of every part.  Debugging aid:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iinclude tests/tools/rc_kernel_test.hip -o /tmp/rc_test && /tmp/rc_test
+#include "../../colord_amd/csrc/rc_dev.hpp"
+#include <cstdio>
+#include <random>
+#include <vector>
+
+static std::vector<uint8_t> host_code(const std::vector<triple_t>& sy, bool dbg = false)
+{
+	const uint64_t TOP = 0x00ffffffffffffULL, MASK = 0xff00000000000000ULL;
+	uint64_t low = 0, range = MASK; std::vector<uint8_t> out;
+	for (const triple_t& t : sy)
+	{
+		const uint32_t tot = (uint32_t)(t & 0x1fffff), freq = (uint32_t)((t >> 21) & 0x1fffff), cum = (uint32_t)(t >> 42);
+		range /= tot; low += range * cum; range *= freq;
+		uint32_t nb = 0;
+		while (range <= TOP)
+		{
+			if ((low ^ (low + range)) & MASK) { uint64_t r = low; range = (r | TOP) - r; }
+			out.push_back((uint8_t)(low >> 56)); low <<= 8; range <<= 8; ++nb;
+		}
+		if (dbg && (&t - sy.data()) < 40) printf("host %zu: tot %u freq %u cum %u nb %u n_out %zu low %016llx range %016llx\n", (size_t)(&t - sy.data()), tot, freq, cum, nb, out.size() - nb, (unsigned long long)low, (unsigned long long)range);
+	}
+	for (int i = 0; i < 8; ++i) { out.push_back((uint8_t)(low >> 56)); low <<= 8; }
+	return out;
+}
+
+int main()
+{
+	const uint32_t np = 150;                                  // three groups, the last one ragged
+	std::mt19937_64 rng(5);
+	std::vector<std::vector<triple_t>> parts(np);
+	std::vector<uint32_t> plen(np);
+	for (uint32_t p = 0; p < np; ++p)
+	{
+		const uint32_t n = p == 7 ? 0 : (uint32_t)(rng() % 5000) + (p % 3 == 0 ? 20000 : 1);
+		for (uint32_t i = 0; i < n; ++i)
+		{
+			// totals over the whole range, the models' usual ones, and the extremes (1, 2, powers of two, 2^21 - 1) in parts of their own
+			uint32_t tot = (rng() & 1) ? (uint32_t)(rng() % ((1u << 21) - 1)) + 1 : (uint32_t)(rng() % 60000) + 1000;
+			if (p % 10 == 4) { const uint32_t ex[6] = { 1, 2, 3, 1u << (1 + rng() % 20), (1u << 21) - 1, (1u << 21) - 2 }; tot = ex[rng() % 6]; }
+			const uint32_t freq = (rng() % 4 == 0) ? 1 : (uint32_t)(rng() % tot) + 1, cum = (uint32_t)(rng() % (tot - freq + 1));
+			parts[p].push_back(((uint64_t)cum << 42) | ((uint64_t)freq << 21) | tot);
+		}
+		plen[p] = n;
+	}
+	const uint32_t ng = (np + 63) / 64;
+	std::vector<uint64_t> gbase(ng), out_off(np + 1, 0);
+	uint64_t total = 0;
+	for (uint32_t g = 0; g < ng; ++g) { gbase[g] = total; uint32_t m = 0; for (uint32_t p = g * 64; p < np && p < g * 64 + 64; ++p) m = std::max(m, plen[p]); total += (uint64_t)m * 64; }
+	std::vector<triple_t> trip(total + 64, 0xdeadbeefdeadbeefULL);
+	for (uint32_t p = 0; p < np; ++p) for (uint32_t i = 0; i < plen[p]; ++i) trip[gbase[p >> 6] + (uint64_t)i * 64 + (p & 63)] = parts[p][i];
+	for (uint32_t p = 0; p < np; ++p) out_off[p + 1] = out_off[p] + ((uint64_t)plen[p] * 8 + 64 + 7) / 8 * 8;
+	triple_t* d_trip; uint64_t *d_gbase, *d_off, *d_size, *d_inv; uint32_t* d_plen; uint8_t* d_out;
+	hipMalloc((void**)&d_trip, trip.size() * 8); hipMalloc((void**)&d_gbase, ng * 8); hipMalloc((void**)&d_off, (np + 1) * 8); hipMalloc((void**)&d_size, np * 8);
+	hipMalloc((void**)&d_inv, (uint64_t)INV_TABLE_SIZE * 8); hipMalloc((void**)&d_plen, np * 4); hipMalloc((void**)&d_out, out_off[np]);
+	hipMemcpy(d_trip, trip.data(), trip.size() * 8, hipMemcpyHostToDevice); hipMemcpy(d_gbase, gbase.data(), ng * 8, hipMemcpyHostToDevice);
+	hipMemcpy(d_off, out_off.data(), (np + 1) * 8, hipMemcpyHostToDevice); hipMemcpy(d_plen, plen.data(), np * 4, hipMemcpyHostToDevice);
+	hipMemset(d_out, 0xAA, out_off[np]);
+	hipLaunchKernelGGL(k_fill_inv_table, dim3(INV_TABLE_SIZE / 256), dim3(256), 0, 0, d_inv);
+	hipLaunchKernelGGL(k_range_code, dim3(ng), dim3(64), 0, 0, (const triple_t*)d_trip, (const uint64_t*)d_gbase, (const uint32_t*)d_plen, np, d_out, (const uint64_t*)d_off, d_size, (const uint64_t*)d_inv);
+	if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); return 2; }
+	std::vector<uint64_t> size(np); std::vector<uint8_t> out(out_off[np]);
+	hipMemcpy(size.data(), d_size, np * 8, hipMemcpyDeviceToHost); hipMemcpy(out.data(), d_out, out.size(), hipMemcpyDeviceToHost);
+	int bad = 0;
+	if (getenv("RC_DEBUG")) host_code(parts[1], true);
+	for (uint32_t p = 0; p < np; ++p)
+	{
+		const std::vector<uint8_t> e = host_code(parts[p]);
+		if (size[p] != e.size()) { if (bad++ < 10) printf("part %u (%u symbols): size %llu, expected %zu\n", p, plen[p], (unsigned long long)size[p], e.size()); continue; }
+		for (size_t i = 0; i < e.size(); ++i) if (out[out_off[p] + i] != e[i]) { if (bad++ < 10) printf("part %u: byte %zu of %zu differs (%02x, expected %02x)\n", p, i, e.size(), out[out_off[p] + i], e[i]); break; }
+		for (uint64_t i = out_off[p] + e.size(); i < out_off[p + 1]; ++i) if (out[i] != 0xAA) { if (bad++ < 10) printf("part %u: wrote beyond its size (offset %llu of size %zu)\n", p, (unsigned long long)(i - out_off[p]), e.size()); break; }
+	}
+	printf(bad ? "FAILED: %d parts\n" : "ok: %u parts equal the host coder, nothing written beyond a part's size\n", bad ? bad : np);
+	return bad ? 1 : 0;
+}
