@@ -267,6 +267,7 @@ extern "C" cl_status cl_candidates(cl_ctx* ctx, const cl_index* X, const cl_kmer
 	if (X->n_reads != L->n_reads) return cl_fail(ctx, CL_E_INVALID, "cl_candidates: index/lists mismatch");
 	return cl_candidates_at(ctx, X, L, X->ref_rank.p, c, d_refs, d_votes, d_n);
 }
+namespace { __global__ void k_gather_at(const uint64_t* __restrict__ src, const uint64_t* __restrict__ at, uint32_t n, uint64_t* __restrict__ out) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) out[i] = src[at[i]]; } }
 // The query of one CHUNK of reads against an index that covers the reference reads of the whole input: d_bounds[i] =
 // number of reference reads that precede read i of `lists` in file order (read i sees exactly those, App. F1 of SURVEY.md).
 extern "C" cl_status cl_candidates_at(cl_ctx* ctx, const cl_index* X, const cl_kmer_lists* L, const uint32_t* d_bounds, uint32_t c,
@@ -289,22 +290,17 @@ extern "C" cl_status cl_candidates_at(cl_ctx* ctx, const cl_index* X, const cl_k
 	}
 	HIP_TRY(ctx, hipGetLastError());
 	CL_TRY(dev_exclusive_scan_u64(ctx, cnt.p, poff.p, ne, &n_pairs));
-	// host copies of the (small) per-read entry offsets and the pair offsets at read boundaries to cut batches
-	std::vector<uint64_t> h_off((size_t)nr + 1);
-	HIP_TRY(ctx, hipMemcpy(h_off.data(), L->off.p, ((size_t)nr + 1) * 8, hipMemcpyDeviceToHost));
-	std::vector<uint64_t> h_poff_at((size_t)nr + 1);
+	// host copies of the (small) per-read entry offsets and of the pair offsets AT read boundaries to cut batches (gathered on the
+	// device: the whole pair-offset array is 8 bytes per list entry — a quarter to half a gigabyte per 1-Gbase chunk, 30-60 ms of
+	// copy to pageable memory with the lane's stream idle)
+	std::vector<uint64_t> h_off((size_t)nr + 1), h_poff_at((size_t)nr + 1);
 	{
-		// gather poff[h_off[r]] with one strided copy per batch boundary would be slow; copy the whole array when small, else sample
-		std::vector<uint64_t> tmp;
-		const uint64_t CH = 1ull << 24;
-		size_t r = 0;
-		for (uint64_t base = 0; base <= ne; base += CH)
-		{
-			uint64_t len = std::min<uint64_t>(CH, ne + 1 - base);
-			tmp.resize(len);
-			HIP_TRY(ctx, hipMemcpy(tmp.data(), poff.p + base, len * 8, hipMemcpyDeviceToHost));
-			while (r <= nr && h_off[r] < base + len) { h_poff_at[r] = tmp[h_off[r] - base]; ++r; }
-		}
+		DevBuf<uint64_t> at; DEV_ALLOC(ctx, at, (uint64_t)nr + 1);
+		LAUNCH(ctx, k_gather_at, grid_for((uint64_t)nr + 1, 256), 256, (const uint64_t*)poff.p, (const uint64_t*)L->off.p, nr + 1, at.p);
+		HIP_TRY(ctx, hipGetLastError());
+		HIP_TRY(ctx, hipMemcpyAsync(h_off.data(), L->off.p, ((size_t)nr + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(ctx, hipMemcpyAsync(h_poff_at.data(), at.p, ((size_t)nr + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	}
 	const uint64_t MAX_PAIRS = 1ull << 27;                  // pairs per batch (1 GiB of keys + sort scratch)
 	const uint32_t MAX_READS = 1u << (40 - ref_bits > 31 ? 31 : 40 - ref_bits);   // keep keys within 40 bits => 5 radix passes
