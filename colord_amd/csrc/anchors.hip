@@ -85,7 +85,7 @@ constexpr uint32_t NIL = 0xffffffffu;
 
 // ---- A1: table sizes; one wave per read inserts every position --------------------------------------------
 __global__ void k_table_sizes(const uint32_t* __restrict__ lens, const uint8_t* __restrict__ has_n, const uint32_t* __restrict__ ncand,
-                              uint32_t r0, uint32_t r1, uint32_t m, uint32_t* __restrict__ tsize, uint32_t* __restrict__ nsize, uint32_t* __restrict__ err)
+                              uint32_t r0, uint32_t r1, uint32_t m, uint32_t x4, uint32_t* __restrict__ tsize, uint32_t* __restrict__ nsize, uint32_t* __restrict__ err)
 {
 	uint32_t r = r0 + blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= r1) return;
@@ -93,7 +93,7 @@ __global__ void k_table_sizes(const uint32_t* __restrict__ lens, const uint8_t* 
 	bool active = ncand[r] > 0 && !has_n[r] && len >= m;
 	uint32_t n = active ? len - m + 1 : 0;
 	uint32_t t = 0;
-	if (n) { t = 16; while (t < 2 * n + n / 2 && t < REGION_SLOTS) t <<= 1; if (t >= REGION_SLOTS) t = (2 * n + REGION_SLOTS - 1) / REGION_SLOTS * REGION_SLOTS; }
+	if (n) { t = 16; while (t < 2 * n + n / 2 && t < REGION_SLOTS) t <<= 1; if (t >= REGION_SLOTS) t = (uint32_t)(((uint64_t)n * x4 / 4 + REGION_SLOTS - 1) / REGION_SLOTS * REGION_SLOTS); }
 	tsize[r - r0] = t; nsize[r - r0] = n;
 }
 // Table build, one block of 16 waves per read.  Inserting straight into the table in HBM costs a random 128-byte line
@@ -684,7 +684,7 @@ extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* read
 		DevBuf<uint32_t> n_distinct, next, err; DevBuf<uint64_t> toff, noff; DevBuf<EncSlot> slots; DevBuf<uint2> bins;
 		struct SideSync { hipStream_t s = nullptr; ~SideSync() { if (s) (void)hipStreamSynchronize(s); } } sync;   // destroyed first
 	};
-	if (!ctx->side) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+	if (!ctx->side) HIP_TRY(ctx, cl_stream_create(ctx, &ctx->side));
 	auto prepare = [&](uint32_t r0, std::unique_ptr<TableBatch>& out) -> cl_status {
 		out = std::make_unique<TableBatch>();
 		TableBatch& B = *out;
@@ -700,9 +700,10 @@ extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* read
 		B.r0 = r0; B.r1 = r1; B.acc = acc; B.pe = bits_for(mx);
 		if (B.pe + pr_bits + bits_for((r1 - r0) * 2 * c) > 64) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_anchor_candidates: a read and its candidates are too long for 64-bit match keys");
 		const uint32_t nb = r1 - r0;
+		static const uint32_t table_x4 = [] { const char* e = getenv("COLORD_HIP_TABLE_X4"); const int v = e ? atoi(e) : 8; return (uint32_t)(v < 5 ? 5 : v > 16 ? 16 : v); }();   // table slots per m-mer, in quarters (8 = load 0.5)
 		DevBuf<uint32_t> tsize, nsize, err; DEV_ALLOC(ctx, tsize, nb); DEV_ALLOC(ctx, nsize, nb); DEV_ALLOC(ctx, err, 1); DEV_ALLOC(ctx, B.n_distinct, nb);
 		HIP_TRY(ctx, hipMemsetAsync(err.p, 0, 4, ctx->stream));
-		LAUNCH(ctx, k_table_sizes, grid_for(nb, 256), 256, (const uint32_t*)reads->lens.p, (const uint8_t*)reads->has_n.p, d_cand_n, r0, r1, m, tsize.p, nsize.p, err.p);
+		LAUNCH(ctx, k_table_sizes, grid_for(nb, 256), 256, (const uint32_t*)reads->lens.p, (const uint8_t*)reads->has_n.p, d_cand_n, r0, r1, m, table_x4, tsize.p, nsize.p, err.p);
 		DEV_ALLOC(ctx, B.toff, (uint64_t)nb + 1); DEV_ALLOC(ctx, B.noff, (uint64_t)nb + 1);
 		uint64_t tsum = 0;
 		CL_TRY(dev_exclusive_scan_u64(ctx, tsize.p, B.toff.p, nb, &tsum));

@@ -20,6 +20,26 @@ extern "C" cl_status cl_ctx_create(int device, cl_ctx** out)
 	*out = c;
 	return CL_OK;
 }
+// Internal (stream.hip): the context's streams at a priority of the device's range: +1 = highest, -1 = lowest, 0 = default.  Queues of
+// higher priority are served first when waves compete for the machine: the compressor raises its encode lanes (the chain that bounds a
+// pass) above the coders and lowers the preparation threads (which have slack).  Call before the context has done any work.
+void cl_ctx_set_priority(cl_ctx* c, int level)
+{
+	if (!c) return;
+	(void)hipSetDevice(c->device);
+	int least = 0, greatest = 0;
+	if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest) { (void)hipGetLastError(); return; }
+	const int prio = level > 0 ? greatest : level < 0 ? least : 0;
+	if (prio == c->prio) return;
+	c->prio = prio;
+	hipStream_t* all[4] = { &c->stream, &c->side, &c->side2, &c->side3 };
+	for (hipStream_t* s : all)
+		if (*s)
+		{
+			(void)hipStreamSynchronize(*s); (void)hipStreamDestroy(*s); *s = nullptr;
+			if (cl_stream_create(c, s) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
+		}
+}
 // every stream of the context (the shared pool calls this before it hands memory the context released to another one)
 void cl_ctx_drain(cl_ctx* c)
 {

@@ -37,6 +37,7 @@ struct KernelTime { double ms = 0; uint32_t launches = 0; double bytes = 0; };  
 // the SUM of what is live.  When the device runs short all the same, slabs that are entirely free are given back.
 struct cl_ctx;
 void cl_ctx_drain(cl_ctx* c);                  // capi.hip: waits for every stream of the context
+void cl_ctx_set_priority(cl_ctx* c, int level); // capi.hip: +1 highest, -1 lowest, 0 default stream priority of the context
 int cl_ctx_fence(cl_ctx* c, hipEvent_t* ev);   // capi.hip: records an event on every stream of the context; returns their number (<= 4)
 struct DevPool {
 	// A free extent remembers who released it and when (pool clock).  Its owner may have it back at once — a context's own reuse
@@ -296,6 +297,7 @@ struct cl_ctx {
 	int32_t pool_id = -1;                        // this context as an owner of free extents of the shared pool
 	explicit cl_ctx(int dev) : pool(cl_device_pool_acquire(dev)), device(dev) { pool_id = pool.add_owner(this); }
 	hipStream_t stream = nullptr;
+	int prio = 0;                                // priority of this context's streams (cl_ctx_set_priority; 0 = the runtime's default)
 	hipStream_t side = nullptr;                  // second stream for chains that would leave the machine idle (created on first use)
 	hipStream_t side2 = nullptr;                 // third stream: the four-per-wave aligner next to the tail-bound wave-per-gap one
 	hipStream_t side3 = nullptr;                 // fourth stream: the work-group-per-gap aligner of the giant gaps
@@ -376,6 +378,8 @@ struct KernelTimer {
 // the same with dynamic LDS
 #define LAUNCHB_SHM(ctx, bytes, kernel, grid, block, shm, ...) do { (ctx)->next_bytes = (double)(bytes); KernelTimer _kt((ctx), #kernel); \
 	hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (shm), (ctx)->stream, __VA_ARGS__); } while (0)
+// a further stream of the context, at the context's priority
+static inline hipError_t cl_stream_create(cl_ctx* c, hipStream_t* s) { return c->prio ? hipStreamCreateWithPriority(s, hipStreamNonBlocking, c->prio) : hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
 static inline void cl_timing_begin(cl_ctx*) {}   // times accumulate until cl_ctx_kernel_times reports them
 // Adds what has COMPLETED to the kernel times (wait = true: everything; cl_ctx_kernel_times).  Never a wait by default: the events
 // of an interval coder that is still running for the next batch (cl_dna_evolve_ahead) stay pending — waiting for them here, at

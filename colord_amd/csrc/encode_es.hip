@@ -980,7 +980,7 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 		HIP_TRY(ctx, hipStreamSynchronize(st));
 		// small gaps: on the side stream, next to the large ones on the main stream (one wave per SIMD with its state in
 		// LDS here, five waves per SIMD on a bump pool in HBM there: they share the machine well)
-		if (!ctx->side) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+		if (!ctx->side) HIP_TRY(ctx, cl_stream_create(ctx, &ctx->side));
 		struct SideJoin { hipStream_t s; ~SideJoin() { (void)hipStreamSynchronize(s); } };
 		DevBuf<uint64_t> hist;
 		SideJoin side_join{ ctx->side };                                         // (after hist in destruction order: joins first)
@@ -1025,7 +1025,7 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 			DEV_ALLOC(ctx, quad_scratch, per_wave * waves);
 			DEV_ALLOC(ctx, qc, 2);
 			DEV_ALLOC(ctx, quad_redo, (uint64_t)n_list + 1);
-			if (!ctx->side2) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side2, hipStreamNonBlocking));
+			if (!ctx->side2) HIP_TRY(ctx, cl_stream_create(ctx, &ctx->side2));
 			quad_join.s = ctx->side2;
 			HIP_TRY(ctx, hipMemsetAsync(qc.p, 0, 8, ctx->side2));
 			hipStream_t main_stream = ctx->stream;
@@ -1046,7 +1046,7 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 			DEV_ALLOC(ctx, team_scratch, per_team * teams);
 			DEV_ALLOC(ctx, tc, 2);
 			DEV_ALLOC(ctx, team_redo, (uint64_t)n_list + 1);
-			if (!ctx->side3) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side3, hipStreamNonBlocking));
+			if (!ctx->side3) HIP_TRY(ctx, cl_stream_create(ctx, &ctx->side3));
 			team_join.s = ctx->side3;
 			HIP_TRY(ctx, hipMemsetAsync(tc.p, 0, 8, ctx->side3));
 			hipStream_t main_stream = ctx->stream;

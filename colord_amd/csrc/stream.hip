@@ -678,6 +678,7 @@ extern "C" cl_status cl_compressor_prepare_parts(cl_compressor* c, const cl_read
 			cl_ctx* x = nullptr;
 			const cl_status s = cl_ctx_create(ctx->device, &x);
 			if (s != CL_OK) return cl_fail(ctx, s, "cl_compressor_prepare: no context for an encode lane");
+			if (!getenv("COLORD_HIP_NO_STREAM_PRIO")) cl_ctx_set_priority(x, +1);      // the lanes bound a pass: their queues are served first
 			ctx->lanes.push_back(x);
 		}
 		c->lane_ctx.assign(ctx->lanes.begin(), ctx->lanes.begin() + lanes);
@@ -690,6 +691,7 @@ extern "C" cl_status cl_compressor_prepare_parts(cl_compressor* c, const cl_read
 				cl_ctx* x = nullptr;
 				const cl_status s = cl_ctx_create(ctx->device, &x);
 				if (s != CL_OK) return cl_fail(ctx, s, "cl_compressor_prepare: no context for the DNA preparation thread");
+				if (!getenv("COLORD_HIP_NO_STREAM_PRIO")) cl_ctx_set_priority(x, -1);  // (works ahead: takes what the lanes and coders leave)
 				ctx->prep = x;
 			}
 			c->prep_ctx = ctx->prep; c->prep_next = 0; c->prep_on = true;
@@ -704,6 +706,7 @@ extern "C" cl_status cl_compressor_prepare_parts(cl_compressor* c, const cl_read
 				cl_ctx* x = nullptr;
 				const cl_status s = cl_ctx_create(ctx->device, &x);
 				if (s != CL_OK) return cl_fail(ctx, s, "cl_compressor_prepare: no context for the quality preparation thread");
+				if (!getenv("COLORD_HIP_NO_STREAM_PRIO")) cl_ctx_set_priority(x, -1);
 				ctx->qprep = x;
 			}
 			c->qprep_ctx = ctx->qprep; c->qprep_next = idx; c->qprep_on = true;
