@@ -373,6 +373,9 @@ struct KernelTimer {
 // every kernel launch goes through LAUNCH so that per-kernel HIP-event times are complete
 #define LAUNCH(ctx, kernel, grid, block, ...) do { KernelTimer _kt((ctx), #kernel); \
 	hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (ctx)->stream, __VA_ARGS__); } while (0)
+// a template kernel under the name of its instantiation (as rocprofv3 lists it), so that the two sets of times can be laid side by side
+#define LAUNCHB_NAMED(ctx, name, bytes, kernel, grid, block, ...) do { (ctx)->next_bytes = (double)(bytes); KernelTimer _kt((ctx), (name)); \
+	hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (ctx)->stream, __VA_ARGS__); } while (0)
 // LAUNCH with the algorithmic HBM byte count of this launch (for achieved-GB/s reporting)
 #define LAUNCHB(ctx, bytes, kernel, grid, block, ...) do { (ctx)->next_bytes = (double)(bytes); LAUNCH(ctx, kernel, grid, block, __VA_ARGS__); } while (0)
 // the same with dynamic LDS

@@ -5,6 +5,7 @@
 //
 // HBM roofline per pass: 2 key reads + 1 key write (+ payload read/write); n must be < 2^32.
 #include "common.hpp"
+#include <string>
 
 namespace {
 constexpr uint32_t ST = 256;            // threads per block
@@ -136,11 +137,14 @@ __global__ __launch_bounds__(ST) void k_sort_scatter(const K* __restrict__ kin, 
 template<typename K, uint32_t DB>
 cl_status sort_pass(cl_ctx* ctx, const K* kin, const uint32_t* vin, K* kout, uint32_t* vout, uint64_t n, uint32_t shift, uint32_t* hist, uint32_t nb)
 {
-	LAUNCHB(ctx, n * sizeof(K), (k_sort_hist<K, DB>), nb, ST, kin, n, shift, hist, nb);
+	// (names as rocprofv3 prints the instantiations)
+	static const std::string kt = sizeof(K) == 8 ? "unsigned long" : "unsigned int", db = std::to_string(DB) + "u";
+	static const std::string n_hist = "k_sort_hist<" + kt + ", " + db + ">", n_sv = "k_sort_scatter<" + kt + ", true, " + db + ">", n_sk = "k_sort_scatter<" + kt + ", false, " + db + ">";
+	LAUNCHB_NAMED(ctx, n_hist.c_str(), n * sizeof(K), (k_sort_hist<K, DB>), nb, ST, kin, n, shift, hist, nb);
 	HIP_TRY(ctx, hipGetLastError());
 	CL_TRY(dev_exclusive_scan_u32(ctx, hist, (uint64_t)(1u << DB) * nb, nullptr));
-	if (vin) LAUNCHB(ctx, n * (2 * sizeof(K) + 8), (k_sort_scatter<K, true, DB>), nb, ST, kin, vin, kout, vout, n, shift, (const uint32_t*)hist, nb);
-	else LAUNCHB(ctx, n * 2 * sizeof(K), (k_sort_scatter<K, false, DB>), nb, ST, kin, (const uint32_t*)nullptr, kout, (uint32_t*)nullptr, n, shift, (const uint32_t*)hist, nb);
+	if (vin) LAUNCHB_NAMED(ctx, n_sv.c_str(), n * (2 * sizeof(K) + 8), (k_sort_scatter<K, true, DB>), nb, ST, kin, vin, kout, vout, n, shift, (const uint32_t*)hist, nb);
+	else LAUNCHB_NAMED(ctx, n_sk.c_str(), n * 2 * sizeof(K), (k_sort_scatter<K, false, DB>), nb, ST, kin, (const uint32_t*)nullptr, kout, (uint32_t*)nullptr, n, shift, (const uint32_t*)hist, nb);
 	HIP_TRY(ctx, hipGetLastError());
 	return CL_OK;
 }
