@@ -248,33 +248,64 @@ __global__ __launch_bounds__(256) void k_match(Arena A, Arena R, EncTable T, Tas
 		const uint32_t PR = cfg.pr; const uint32_t pr_mask = (1u << PR) - 1;
 		const uint64_t key_rev = (uint64_t)(2 * sl) << (cfg.pe + PR), key_fwd = (uint64_t)(2 * sl + 1) << (cfg.pe + PR);
 		if (threadIdx.x == 0) atomicAdd(n_pairs + 1, (unsigned long long)nq);      // probes, for the achieved-bandwidth report
-		// the words of the next step are loaded while this one is worked on (the block streams through the candidate:
-		// every step is a new line)
+		// Two steps are in flight: the reference words of step i + 2 are being loaded and the table slot of step i + 1 is being
+		// probed (first slot of its probe sequence: at load 0.5 nearly every look-up ends there) while the hits of step i walk
+		// their chains — one memory latency per step instead of three in a row (words, slot, chain).
 		const uint64_t* rw = R.packed + rwb;
-		uint64_t hi = 0, lo = 0;
-		{ const uint32_t q = wv * 64 + lane; if (q < nq) { hi = rw[q >> 5]; lo = rw[(q >> 5) + 1]; } }
-		for (uint32_t q0 = wv * 64; q0 < nq; q0 += 256)
-		{
-			const uint32_t q = q0 + lane;
-			uint64_t hi2 = 0, lo2 = 0;
-			if (q + 256 < nq) { hi2 = rw[(q + 256) >> 5]; lo2 = rw[((q + 256) >> 5) + 1]; }
-			uint32_t hf = NIL, hr = NIL, nf = NIL, nr = NIL, cnt = 0;      // chain heads and their successors (most chains have one element)
+		struct Probe { uint64_t x, key; uint2 heads; uint32_t h; bool pass, fwd_other, rev_other; };
+		auto probe = [&](uint32_t q, uint64_t hi, uint64_t lo) -> Probe
+		{	// y: the m-mer at q of the reference as stored; z: the one at nq - 1 - q of its reverse complement
+			Probe P{ 0, KEY_EMPTY, make_uint2(NIL, NIL), 0, false, false, false };
 			if (q < nq)
-			{	// y: the m-mer at q of the reference as stored; z: the one at nq - 1 - q of its reverse complement
+			{
 				const uint64_t y = mmer_of(hi, lo, q, cfg.m), z = revcomp_m(y, cfg.m), x = y < z ? y : z;
 				const uint64_t hash = hash_mm(x);
 				const uint64_t fm = filt_mask(hash);
 				if ((filt[filt_word(hash)] & fm) == fm)
 				{
-					const uint2 hd = table_heads(T, t0, tsz, x, hash);
-					hf = y != x ? hd.y : hd.x; hr = z != x ? hd.y : hd.x;
+					P.pass = true; P.x = x; P.fwd_other = y != x; P.rev_other = z != x;
+					P.h = table_slot(hash, tsz);
+					const EncSlot* sp = T.slots + t0 + P.h;
+					P.key = sp->key; P.heads = *(const uint2*)sp->head;
+				}
+			}
+			return P;
+		};
+		uint64_t hi1 = 0, lo1 = 0, hi2 = 0, lo2 = 0;
+		Probe cur;
+		{
+			const uint32_t q = wv * 64 + lane;
+			uint64_t hi = 0, lo = 0;
+			if (q < nq) { hi = rw[q >> 5]; lo = rw[(q >> 5) + 1]; }
+			if (q + 256 < nq) { hi1 = rw[(q + 256) >> 5]; lo1 = rw[((q + 256) >> 5) + 1]; }
+			cur = probe(q, hi, lo);
+		}
+		const uint32_t rmask = (tsz < REGION ? tsz : REGION) - 1;             // (probing wraps inside the region the table was built by: table_heads)
+		for (uint32_t q0 = wv * 64; q0 < nq; q0 += 256)
+		{
+			const uint32_t q = q0 + lane;
+			hi2 = 0; lo2 = 0;
+			if (q + 512 < nq) { hi2 = rw[(q + 512) >> 5]; lo2 = rw[((q + 512) >> 5) + 1]; }
+			const Probe nxt = probe(q + 256, hi1, lo1);
+			uint32_t hf = NIL, hr = NIL, nf = NIL, nr = NIL, cnt = 0;      // chain heads and their successors (most chains have one element)
+			if (cur.pass)
+			{
+				uint64_t k = cur.key; uint2 hd = cur.heads; uint32_t h = cur.h;
+				while (k != cur.x && k != KEY_EMPTY)
+				{
+					h = (h & ~rmask) | ((h + 1) & rmask);
+					k = T.slots[t0 + h].key; hd = *(const uint2*)T.slots[t0 + h].head;
+				}
+				if (k == cur.x)
+				{
+					hf = cur.fwd_other ? hd.y : hd.x; hr = cur.rev_other ? hd.y : hd.x;
 					if (hf != NIL) { nf = T.next[n0 + hf]; ++cnt; }           // (two independent loads)
 					if (hr != NIL) { nr = T.next[n0 + hr]; ++cnt; }
 					for (uint32_t p = nf; p != NIL; p = T.next[n0 + p]) ++cnt;
 					for (uint32_t p = nr; p != NIL; p = T.next[n0 + p]) ++cnt;
 				}
 			}
-			hi = hi2; lo = lo2;
+			cur = nxt; hi1 = hi2; lo1 = lo2;
 			if (!__any(cnt != 0)) continue;
 			const uint32_t incl = wave_incl_scan(cnt), tot = __shfl(incl, 63, 64);
 			const uint64_t kf = key_fwd | (uint64_t)(~q & pr_mask), kr = key_rev | (uint64_t)(~(nq - 1 - q) & pr_mask);
