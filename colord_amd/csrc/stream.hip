@@ -24,6 +24,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <chrono>
 
 namespace {
 __global__ void k_accept_flags2(const uint8_t* __restrict__ acc, const uint8_t* __restrict__ has_n, uint32_t n, uint8_t* __restrict__ out)
@@ -109,6 +110,7 @@ struct cl_compressor {
 	std::thread prep_thread; cl_ctx* prep_ctx = nullptr; size_t prep_next = 0; bool prep_on = false, prep_broken = false; uint32_t prep_types = 0, prep_read_id = 0;
 	std::thread qprep_thread; cl_ctx* qprep_ctx = nullptr; size_t qprep_next = 0; bool qprep_on = false;
 	uint32_t n_dna_ahead = 0, n_qual_ahead = 0, n_dna_prep = 0, n_qual_prep = 0;      // (statistics: COLORD_HIP_STREAM_DEBUG)
+	double w_lane_idle = 0, w_lane_work = 0, w_enc_lane = 0, w_enc_prep = 0, w_enc_qprep = 0, w_prep_idle = 0, w_prep_work = 0;   // seconds: who waited for whom
 	// chunks whose model half is done ahead of their encode call (first not yet done), and how far ahead that may go: with the
 	// reference's parts the interval coders of a chunk take 1.3 s, those of `depth` + 1 chunks run side by side
 	size_t dna_evolved_upto = 0, qual_evolved_upto = 0; uint32_t evolve_depth = 0;
@@ -126,7 +128,12 @@ struct cl_compressor {
 	~cl_compressor()
 	{
 		stop_lanes();
-		if (getenv("COLORD_HIP_STREAM_DEBUG")) fprintf(stderr, "[stream] %zu chunks: dna prepared ahead %u, evolved ahead %u; qual prepared ahead %u, evolved ahead %u; %zu lanes\n", enc_chunk, n_dna_prep, n_dna_ahead, n_qual_prep, n_qual_ahead, lane_ctx.size());
+		if (getenv("COLORD_HIP_STREAM_DEBUG"))
+		{
+			fprintf(stderr, "[stream] %zu chunks: dna prepared ahead %u, evolved ahead %u; qual prepared ahead %u, evolved ahead %u; %zu lanes\n", enc_chunk, n_dna_prep, n_dna_ahead, n_qual_prep, n_qual_ahead, lane_ctx.size());
+			fprintf(stderr, "[stream] lanes: %.2f s in stage A, %.2f s waiting for the window; dna preparation: %.2f s working, %.2f s waiting; encode calls waited %.2f s for a lane, %.2f s for the dna preparation, %.2f s for the quality preparation\n",
+				w_lane_work, w_lane_idle, w_prep_work, w_prep_idle, w_enc_lane, w_enc_prep, w_enc_qprep);
+		}
 		for (auto* r : ref_pieces) cl_reads_free(r);
 		if (refs) cl_reads_free(refs);
 		if (index) cl_index_free(index);
@@ -533,16 +540,20 @@ static void lane_main(cl_compressor* c, cl_ctx* lane)
 			std::unique_lock<std::mutex> l(c->lane_mu);
 			// the lanes run at most (lanes + 2) chunks ahead of the coders: what they finish (tuple streams, ~1.5 GB per Gbase) waits in
 			// HBM until it is coded; the slack evens out chunks whose stage A or coders happen to be slow
+			const auto tw = std::chrono::steady_clock::now();
 			c->lane_cv.wait(l, [&]() { return c->lane_stop || (!c->lane_queue.empty() && c->lane_queue.front() <= c->enc_chunk + c->lane_ctx.size() + 1); });
+			c->w_lane_idle += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
 			if (c->lane_stop) return;
 			idx = c->lane_queue.front(); c->lane_queue.pop_front();
 			job = c->prepared[idx].get();
 		}
 		lane->timing = c->ctx->timing;
+		const auto tw = std::chrono::steady_clock::now();
 		const cl_status s = stage_a(c, lane, idx, job->reads, job->packs.data(), (uint32_t)job->packs.size() - 1, *job);
 		cl_timing_collect(lane);
 		{
 			std::lock_guard<std::mutex> l(c->lane_mu);
+			c->w_lane_work += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
 			job->status = s; if (s != CL_OK) job->err = lane->err;
 			job->times.swap(lane->times); lane->times.clear();
 			job->done = true;
@@ -571,6 +582,8 @@ static void prep_main(cl_compressor* c)
 		size_t idx; cl_compressor::Prepared* job;
 		{
 			std::unique_lock<std::mutex> l(c->lane_mu);
+			const auto tw = std::chrono::steady_clock::now();
+			struct Lap { cl_compressor* c; std::chrono::steady_clock::time_point t; ~Lap() { c->w_prep_idle += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); } } lap_idle{ c, tw };
 			c->lane_cv.wait(l, [&]() {
 				if (c->lane_stop || c->prep_broken) return true;
 				if (c->prep_next < c->enc_chunk) return true;                        // (a chunk was coded without this thread: the chain of walk scalars is lost)
@@ -753,9 +766,14 @@ extern "C" cl_status cl_compressor_encode(cl_compressor* c, const cl_reads* read
 		if (it != c->prepared.end())
 		{
 			if (it->second->reads != reads) return cl_fail(ctx, CL_E_INVALID, "cl_compressor_encode: not the chunk that was announced for this position");
+			auto tw = std::chrono::steady_clock::now();
+			auto lap = [&](double& acc) { const auto t = std::chrono::steady_clock::now(); acc += std::chrono::duration<double>(t - tw).count(); tw = t; };
 			c->lane_cv.wait(l, [&]() { return it->second->done; });
+			lap(c->w_enc_lane);
 			if (c->prep_on && !c->prep_broken && c->prep_next <= idx) c->lane_cv.wait(l, [&]() { return it->second->dna_done || c->prep_broken; });
+			lap(c->w_enc_prep);
 			if (c->qprep_on && c->qprep_next <= idx) c->lane_cv.wait(l, [&]() { return it->second->q_done; });
+			lap(c->w_enc_qprep);
 			own = std::move(it->second); c->prepared.erase(it);
 			job = own.get();
 		}
