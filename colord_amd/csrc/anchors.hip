@@ -72,8 +72,17 @@ __device__ inline uint64_t ref_mmer(const Arena& R, uint32_t id, bool rev, uint3
 // itself, head[1] those where it has the other one.  One probe with a reference m-mer then serves both
 // orientations of the reference (the reference's two anchor analyses, encoder.cpp:1046-1066, probe the same hash of the
 // read with the m-mers of the reference and of its reverse complement).
-// A slot is 16 bytes — key and both chain heads in one sector, so an insertion touches two sectors (slot, next), not three.
-struct EncSlot { uint64_t key; uint32_t head[2]; };
+// While a region of the table is built (in LDS) a slot holds the full key, ONE chain head and which strands the key has been seen
+// on (the count of distinct m-mers per strand is exact).  What goes to HBM is 8 bytes per slot: a 32-bit tag of the key and the head.
+// A chain link — head or `next` entry — is a position (30 bits) with the strand of THAT position in bit 31 (0: the read has the
+// canonical form there, 1: the other one), so a walk knows both orientations' hits without reading the read again.  A tag can
+// belong to another key (2^-32 per occupied slot compared, a handful per 10^10 probes): the look-up confirms a tag match on the
+// read's own m-mer at the head's position before it believes it, and goes on probing otherwise.  (Rounds 1-3a: 16-byte slots with
+// the full key and one head per strand: 15 GB written per table build of a 0.27-Gbase batch; now half.)
+struct BuildSlot { uint64_t key; uint32_t head; uint32_t strands; };
+typedef uint2 EncSlot;                                                     // x: tag, y: head link (NIL: empty)
+constexpr uint32_t LINK_POS = 0x3fffffffu;
+__device__ inline uint32_t tag_of(uint64_t hash) { return (uint32_t)((hash * 0xD6E8FEB86659FD93ULL) >> 32); }
 // slot of a hash in a table of tsz slots: tsz is a power of two below one region, else a MULTIPLE of the region size (2 n slots
 // rounded up: powers of two meant 2.5 n .. 5 n slots, 40 - 80 bytes per base written out by every table build), so the index
 // is the high half of hash x tsz rather than a mask
@@ -105,7 +114,7 @@ constexpr uint32_t REGION = REGION_SLOTS, INS_T = 256;
 __global__ __launch_bounds__(INS_T) void k_table_insert(Arena A, uint32_t r0, uint32_t r1, uint32_t m, EncTable T, uint32_t* __restrict__ n_distinct,
                                                        uint2* __restrict__ bins /* per position: (position, slot), grouped by region */, uint32_t* __restrict__ err)
 {
-	__shared__ EncSlot reg[REGION];
+	__shared__ BuildSlot reg[REGION];
 	__shared__ uint32_t cnt[512], start[513];                             // positions per region (a read of 2^20 bases has 2^21 * 2 / 2048 = ... see below)
 	const uint32_t r = r0 + blockIdx.x;
 	if (r >= r1) return;
@@ -141,7 +150,7 @@ __global__ __launch_bounds__(INS_T) void k_table_insert(Arena A, uint32_t r0, ui
 		__threadfence_block();
 		for (uint32_t rg = 0; rg < nr; ++rg)
 		{
-			for (uint32_t i = threadIdx.x; i < rs; i += INS_T) { reg[i].key = KEY_EMPTY; reg[i].head[0] = NIL; reg[i].head[1] = NIL; }
+			for (uint32_t i = threadIdx.x; i < rs; i += INS_T) { reg[i].key = KEY_EMPTY; reg[i].head = NIL; reg[i].strands = 0; }
 			__syncthreads();
 			const uint32_t b = start[rg], e = start[rg + 1];
 			for (uint32_t i = b + threadIdx.x; i < e; i += INS_T)
@@ -157,33 +166,19 @@ __global__ __launch_bounds__(INS_T) void k_table_insert(Arena A, uint32_t r0, ui
 					off = (off + 1) & (rs - 1);
 					if (++tries > rs) { atomicOr(err, 2u); break; }                // a full region: cannot happen below load 1
 				}
-				const uint32_t prev = atomicExch(&reg[off].head[xf != x ? 1 : 0], pp);
-				T.next[n0 + pp] = prev;
-				if (prev == NIL) ++fresh;                                   // first position with this m-mer: distinct m-mers of the read
+				const uint32_t strand = xf != x ? 1u : 0u;
+				T.next[n0 + pp] = atomicExch(&reg[off].head, pp | (strand << 31));   // the link to the element before (with ITS strand), or NIL
+				if (!(atomicOr(&reg[off].strands, 1u << strand) & (1u << strand))) ++fresh;   // first position with this m-mer on this strand: distinct m-mers of the read
 			}
 			__syncthreads();
 			EncSlot* dst = T.slots + t0 + (uint64_t)(rg0 + rg) * rs;
-			for (uint32_t i = threadIdx.x; i < rs; i += INS_T) dst[i] = reg[i];
+			for (uint32_t i = threadIdx.x; i < rs; i += INS_T) dst[i] = make_uint2(reg[i].head == NIL ? 0u : tag_of(hash_mm(reg[i].key)), reg[i].head);
 			__syncthreads();
 		}
 	}
 	fresh = wave_sum(fresh);
 	if (lane == 0 && fresh) atomicAdd(&n_distinct[r - r0], fresh);       // (zeroed by the caller)
 }
-// both chain heads of canonical m-mer x (NIL, NIL when absent)
-__device__ inline uint2 table_heads(const EncTable& T, uint64_t t0, uint32_t tsz, uint64_t x, uint64_t hash)
-{
-	uint32_t h = table_slot(hash, tsz);
-	const uint32_t rmask = (tsz < REGION ? tsz : REGION) - 1;           // probing wraps inside the region the table was built by
-	for (;;)
-	{
-		const uint64_t k = T.slots[t0 + h].key;
-		if (k == x) return *(const uint2*)T.slots[t0 + h].head;
-		if (k == KEY_EMPTY) return make_uint2(NIL, NIL);
-		h = (h & ~rmask) | ((h + 1) & rmask);
-	}
-}
-
 // ---- A2 / A3: the match pairs of BOTH orientations of every candidate in one pass over the reference ----
 // task id t -> read r0 + t / (2c), slot (t / 2) % c, orientation t & 1 (0 = reverse complement, analysed first).
 // Pairs go to one array in any order (they are sorted by (task, read position, ~reference position) next): a wave
@@ -228,6 +223,7 @@ __global__ __launch_bounds__(256) void k_match(Arena A, Arena R, EncTable T, Tas
 	}
 	__syncthreads();
 	const uint64_t n0 = T.noff[rl];
+	const uint64_t ewb = A.word_off[r];                                    // (the read itself: a tag match is confirmed on its m-mer)
 	// Pairs are staged per wave in LDS and leave in runs of up to STAGE with ONE atomic add on the global counter (an add
 	// per wave step — ~15 M a pass, all on one address — serialises the whole grid in the L2).
 	uint64_t* stage = stage_all[wv]; uint32_t fill = 0;
@@ -252,10 +248,10 @@ __global__ __launch_bounds__(256) void k_match(Arena A, Arena R, EncTable T, Tas
 		// probed (first slot of its probe sequence: at load 0.5 nearly every look-up ends there) while the hits of step i walk
 		// their chains — one memory latency per step instead of three in a row (words, slot, chain).
 		const uint64_t* rw = R.packed + rwb;
-		struct Probe { uint64_t x, key; uint2 heads; uint32_t h; bool pass, fwd_other, rev_other; };
+		struct Probe { uint64_t x; uint2 slot; uint32_t h, tag; bool pass, fwd_other, rev_other; };
 		auto probe = [&](uint32_t q, uint64_t hi, uint64_t lo) -> Probe
 		{	// y: the m-mer at q of the reference as stored; z: the one at nq - 1 - q of its reverse complement
-			Probe P{ 0, KEY_EMPTY, make_uint2(NIL, NIL), 0, false, false, false };
+			Probe P{ 0, make_uint2(0u, NIL), 0, 0, false, false, false };
 			if (q < nq)
 			{
 				const uint64_t y = mmer_of(hi, lo, q, cfg.m), z = revcomp_m(y, cfg.m), x = y < z ? y : z;
@@ -264,9 +260,8 @@ __global__ __launch_bounds__(256) void k_match(Arena A, Arena R, EncTable T, Tas
 				if ((filt[filt_word(hash)] & fm) == fm)
 				{
 					P.pass = true; P.x = x; P.fwd_other = y != x; P.rev_other = z != x;
-					P.h = table_slot(hash, tsz);
-					const EncSlot* sp = T.slots + t0 + P.h;
-					P.key = sp->key; P.heads = *(const uint2*)sp->head;
+					P.h = table_slot(hash, tsz); P.tag = tag_of(hash);
+					P.slot = T.slots[t0 + P.h];
 				}
 			}
 			return P;
@@ -287,23 +282,23 @@ __global__ __launch_bounds__(256) void k_match(Arena A, Arena R, EncTable T, Tas
 			hi2 = 0; lo2 = 0;
 			if (q + 512 < nq) { hi2 = rw[(q + 512) >> 5]; lo2 = rw[((q + 512) >> 5) + 1]; }
 			const Probe nxt = probe(q + 256, hi1, lo1);
-			uint32_t hf = NIL, hr = NIL, nf = NIL, nr = NIL, cnt = 0;      // chain heads and their successors (most chains have one element)
+			// the chain of this lane's m-mer (NIL: none), and how many of its elements are hits of the forward / of the reverse analysis
+			uint32_t head = NIL, cnt = 0;
+			const uint32_t fs = cur.fwd_other ? 1u : 0u, rs_ = cur.rev_other ? 1u : 0u;   // strand of the read positions that match y / z
 			if (cur.pass)
 			{
-				uint64_t k = cur.key; uint2 hd = cur.heads; uint32_t h = cur.h;
-				while (k != cur.x && k != KEY_EMPTY)
+				uint2 sl8 = cur.slot; uint32_t h = cur.h;
+				while (sl8.y != NIL)
 				{
+					if (sl8.x == cur.tag)
+					{	// a tag is not the key: the read's own m-mer at the head's position decides
+						const uint64_t xf = mmer_at(A, ewb, sl8.y & LINK_POS, cfg.m), xr = revcomp_m(xf, cfg.m);
+						if ((xf < xr ? xf : xr) == cur.x) { head = sl8.y; break; }
+					}
 					h = (h & ~rmask) | ((h + 1) & rmask);
-					k = T.slots[t0 + h].key; hd = *(const uint2*)T.slots[t0 + h].head;
+					sl8 = T.slots[t0 + h];
 				}
-				if (k == cur.x)
-				{
-					hf = cur.fwd_other ? hd.y : hd.x; hr = cur.rev_other ? hd.y : hd.x;
-					if (hf != NIL) { nf = T.next[n0 + hf]; ++cnt; }           // (two independent loads)
-					if (hr != NIL) { nr = T.next[n0 + hr]; ++cnt; }
-					for (uint32_t p = nf; p != NIL; p = T.next[n0 + p]) ++cnt;
-					for (uint32_t p = nr; p != NIL; p = T.next[n0 + p]) ++cnt;
-				}
+				for (uint32_t p = head; p != NIL; p = T.next[n0 + (p & LINK_POS)]) cnt += (uint32_t)((p >> 31) == fs) + (uint32_t)((p >> 31) == rs_);
 			}
 			cur = nxt; hi1 = hi2; lo1 = lo2;
 			if (!__any(cnt != 0)) continue;
@@ -313,10 +308,12 @@ __global__ __launch_bounds__(256) void k_match(Arena A, Arena R, EncTable T, Tas
 			if (tot <= STAGE)
 			{
 				uint32_t o = fill + incl - cnt;
-				if (hf != NIL) stage[o++] = kf | ((uint64_t)hf << PR);
-				for (uint32_t p = nf; p != NIL; p = T.next[n0 + p]) stage[o++] = kf | ((uint64_t)p << PR);
-				if (hr != NIL) stage[o++] = kr | ((uint64_t)hr << PR);
-				for (uint32_t p = nr; p != NIL; p = T.next[n0 + p]) stage[o++] = kr | ((uint64_t)p << PR);
+				for (uint32_t p = head; p != NIL; p = T.next[n0 + (p & LINK_POS)])
+				{
+					const uint64_t pos = (uint64_t)(p & LINK_POS) << PR;
+					if ((p >> 31) == fs) stage[o++] = kf | pos;
+					if ((p >> 31) == rs_) stage[o++] = kr | pos;
+				}
 				fill += tot;
 				continue;
 			}
@@ -326,10 +323,12 @@ __global__ __launch_bounds__(256) void k_match(Arena A, Arena R, EncTable T, Tas
 			base = ((unsigned long long)__shfl((int)(base >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)base, 0, 64);
 			if (base + tot > cap) continue;
 			uint64_t o = base + incl - cnt;
-			if (hf != NIL) pairs[o++] = kf | ((uint64_t)hf << PR);
-			for (uint32_t p = nf; p != NIL; p = T.next[n0 + p]) pairs[o++] = kf | ((uint64_t)p << PR);
-			if (hr != NIL) pairs[o++] = kr | ((uint64_t)hr << PR);
-			for (uint32_t p = nr; p != NIL; p = T.next[n0 + p]) pairs[o++] = kr | ((uint64_t)p << PR);
+			for (uint32_t p = head; p != NIL; p = T.next[n0 + (p & LINK_POS)])
+			{
+				const uint64_t pos = (uint64_t)(p & LINK_POS) << PR;
+				if ((p >> 31) == fs) pairs[o++] = kf | pos;
+				if ((p >> 31) == rs_) pairs[o++] = kr | pos;
+			}
 		}
 	}
 	flush();
@@ -748,7 +747,7 @@ extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* read
 		EncTable T{ B.slots.p, B.toff.p, B.next.p, B.noff.p };
 		hipStream_t main_stream = ctx->stream;
 		ctx->stream = ctx->side;                                                  // (launch + timing events on the side stream)
-		LAUNCHB(ctx, B.nsum * (0.25 + 16.0), k_table_insert, nb, INS_T, A, r0, r1, m, T, B.n_distinct.p, B.bins.p, B.err.p);
+		LAUNCHB(ctx, B.nsum * (0.25 + 16.0) /* 2 bits in, two 8-byte slots out per m-mer */, k_table_insert, nb, INS_T, A, r0, r1, m, T, B.n_distinct.p, B.bins.p, B.err.p);
 		ctx->stream = main_stream;
 		HIP_TRY(ctx, hipGetLastError());
 		return CL_OK;
