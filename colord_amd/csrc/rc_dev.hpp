@@ -7,6 +7,7 @@
 // every step of the wavefront is one coalesced 512-byte load.
 #pragma once
 #include "common.hpp"
+#include <type_traits>
 
 // A coded symbol as the interval coder needs it: cum << 42 | freq << 21 | tot in ONE 64-bit word (totals stay below 2^21).
 // The coder divides by tot through a multiplication with floor((2^64-1) / tot); that reciprocal used to travel with every
@@ -110,7 +111,8 @@ static __global__ __launch_bounds__(64) void k_range_code(const triple_t* __rest
 #pragma unroll
 	for (uint32_t u = 0; u < U; ++u) iA[u] = inv_tab[A[u] & 0x1fffff];
 	// one round: fetch `far` (two rounds ahead), look up the reciprocals of `nxt`, code `cur` with `icur`
-	auto round = [&](uint32_t pos, const triple_t (&cur)[U], const uint64_t (&icur)[U], const triple_t (&nxt)[U], uint64_t (&inxt)[U], triple_t (&far)[U])
+	// (all_active: every lane of the wave still has symbols in this round — no neutral symbols to select; decided per round, wave-uniform)
+	auto round = [&](auto all_active, uint32_t pos, const triple_t (&cur)[U], const uint64_t (&icur)[U], const triple_t (&nxt)[U], uint64_t (&inxt)[U], triple_t (&far)[U])
 	{
 #pragma unroll
 		for (uint32_t u = 0; u < U; ++u) { uint32_t q = pos + 2 * U + u; far[u] = src[(uint64_t)(q < last ? q : last) * 64]; }   // prefetch (index clamped, never a pointer select)
@@ -119,7 +121,7 @@ static __global__ __launch_bounds__(64) void k_range_code(const triple_t* __rest
 #pragma unroll
 		for (uint32_t u = 0; u < U; ++u)
 		{
-			const bool act = pos + u < len;
+			const bool act = decltype(all_active)::value || pos + u < len;
 			const uint64_t tx = act ? cur[u] : NEUTRAL_X, inv = act ? icur[u] : NEUTRAL_Y;
 			const uint32_t tot = (uint32_t)(tx & 0x1fffff), freq = (uint32_t)((tx >> 21) & 0x1fffff), cum = (uint32_t)(tx >> 42);
 			// range / tot.  With inv = floor((2^64-1) / tot) = (2^64 - 1 - rho) / tot, 0 <= rho < tot:
@@ -160,13 +162,24 @@ static __global__ __launch_bounds__(64) void k_range_code(const triple_t* __rest
 			n_out += nb;
 		}
 	};
-	for (uint32_t pos = 0; pos < lmax; pos += 3 * U)
+	uint32_t lmin = live ? len : 0u;
+#pragma unroll
+	for (int d = 32; d > 0; d >>= 1) { uint32_t t = __shfl_xor(lmin, d, 64); lmin = t < lmin ? t : lmin; }
+	const std::true_type ALL{}; const std::false_type SOME{};
+	uint32_t pos = 0;
+	for (; pos + 3 * U <= lmin; pos += 3 * U)                                  // every lane active for three whole rounds
 	{
-		round(pos, A, iA, B, iB, C);
+		round(ALL, pos, A, iA, B, iB, C);
+		round(ALL, pos + U, B, iB, C, iC, A);
+		round(ALL, pos + 2 * U, C, iC, A, iA, B);
+	}
+	for (; pos < lmax; pos += 3 * U)
+	{
+		round(SOME, pos, A, iA, B, iB, C);
 		if (pos + U >= lmax) break;
-		round(pos + U, B, iB, C, iC, A);
+		round(SOME, pos + U, B, iB, C, iC, A);
 		if (pos + 2 * U >= lmax) break;
-		round(pos + 2 * U, C, iC, A, iA, B);
+		round(SOME, pos + 2 * U, C, iC, A, iA, B);
 	}
 	if (!live) return;
 	if ((uint32_t)(range >> 32) < 0x00010000u) overflow = true;                      // (an empty range: corrupt triples)
