@@ -60,15 +60,6 @@ __device__ inline uint32_t trip_index(const TripLayoutDev& L, uint32_t part, uin
 	return (uint32_t)(L.group_base[pl >> 6] + (stream_pos - L.part_sym_start[part]) * 64 + (pl & 63));
 }
 
-// floor(x / d) given inv = floor((2^64-1) / d): the high product is at most 2 below the quotient.
-__device__ inline uint64_t div_by_inv(uint64_t x, uint32_t d, uint64_t inv)
-{
-	uint64_t q = __umul64hi(x, inv);
-	uint64_t r = x - q * d;
-	while (r >= d) { ++q; r -= d; }
-	return q;
-}
-
 // Output bytes of one part.  The coder emits the top byte of `low` on every renormalisation step and only shifts `low` in
 // between, so the n bytes of one symbol are simply the top n bytes of `low` as it was before the first shift: the whole
 // big-endian word is stored (unaligned) at the part's write position and the position advances by n — the bytes behind
@@ -86,7 +77,7 @@ static __global__ __launch_bounds__(64) void k_range_code(const triple_t* __rest
 	__builtin_amdgcn_s_setprio(3);                                          // a launch of this kernel lasts as long as its slowest chain: its waves go first on their SIMDs
 	const uint32_t p = blockIdx.x * 64 + threadIdx.x;
 	const bool live = p < n_parts;
-	const uint64_t TOP = 0x00ffffffffffffULL /* 2^48 - 1 */, MASK = 0xff00000000000000ULL;
+	const uint64_t MASK = 0xff00000000000000ULL;                            // (TOP = 0x00ffffffffffff = 2^48 - 1 appears below as its 32-bit halves)
 	uint64_t low = 0, range = MASK;
 	uint8_t* outp = live ? out + part_out_off[p] : nullptr;
 	const uint64_t cap = live ? part_out_off[p + 1] - part_out_off[p] : 0;
