@@ -79,6 +79,9 @@ def parse():
 PRESET = dict(f=12, ci=4, cs=80, c=5, g=1.0, exponent=1.0, min_part_alt=64, max_rec=3)
 
 
+QA = (2, 0, 1, (7, 14, 26), ())    # ONT default quality mode: 4-avg at level 1 (arg_parse.cpp:410-450): (mode, source, level, thresholds, -)
+
+
 def kmer_anchor_len(bases: float):
     """adjustKmerAndAnchorLen (compression.cpp:62-93) on the number of bases."""
     for lim, k, a in ((1e9, 20, 16), (4e9, 21, 18), (16e9, 23, 21), (48e9, 24, 22), (128e9, 25, 22)):
@@ -229,12 +232,51 @@ class HostSink:
         self.stream.synchronize()
 
 
-def hot_path_step(ctx, qctx, shard: Shard, prm: dict, with_qual: bool, exchange, dna_out, qual_out, expected_bases: int, ref_cut: bool = False, sink: "HostSink | None" = None):
+def pass_digest(sink: "HostSink | None", dna_out, qual_out, info: dict) -> list:
+    """Digest of EVERY part of the pass that just ended: per chunk one xxh3-128 over (part sizes + part bytes) of each stream, taken from
+    where the step left them (the pinned host buffers at N = 1, the device buffers else).  The timed passes must all give the same
+    list: nothing of a pass may depend on how its six contexts happened to interleave (the race detector the verdict of round 3
+    asked for).  Runs between the per-step timing brackets, never inside one."""
+    import xxhash
+    from concurrent.futures import ThreadPoolExecutor
+    if sink is None:
+        out = []
+        for name, buf, n in (("dna", dna_out, info["dna_bytes"]), ("qual", qual_out, info["qual_bytes"])):
+            if buf is None or not n:
+                continue
+            w = buf[:n - n % 8].view(torch.int64)
+            acc = 0
+            for a in range(0, w.numel(), 1 << 24):          # wrapping 64-bit position-weighted sums, 128 MB at a time
+                x = w[a:a + (1 << 24)]
+                acc = (acc * 1000003 + int((x * (torch.arange(x.numel(), device=x.device, dtype=torch.int64) * 2654435761 + 1)).sum().item())) & ((1 << 64) - 1)
+            out.append(f"{name}:{n}:{acc:016x}:{bytes(buf[n - n % 8:n].cpu().numpy()).hex()}")
+        return out
+    jobs = []
+    for name, h, sizes in (("dna", sink.h_dna, sink.dna_sizes), ("qual", sink.h_qual, sink.qual_sizes)):
+        if h is None:
+            continue
+        hv, o = h.numpy(), 0
+        for ci, sz in enumerate(sizes):
+            n = int(sz.sum())
+            jobs.append((name, ci, sz, hv[o:o + n]))
+            o += n
+
+    def one(j):
+        name, ci, sz, view = j
+        x = xxhash.xxh3_128()
+        x.update(sz.tobytes())
+        x.update(memoryview(view))                          # (xxhash releases the GIL on large buffers)
+        return f"{name}[{ci}]:{len(sz)}:{len(view)}:{x.hexdigest()}"
+    with ThreadPoolExecutor(16) as ex:
+        return list(ex.map(one, jobs))
+
+
+def hot_path_step(ctx, qctx, shard: Shard, prm: dict, with_qual: bool, exchange, dna_out, qual_out, expected_bases: int, ref_cut: bool = False, sink: "HostSink | None" = None, part_sizes: "list | None" = None):
     """One pass of the whole compress data path over the shard (all chunks).  Returns sizes for reporting.
     ref_cut: the coder parts are the reference's reader packs (4 Mi symbols) instead of the bench's --pack-symbols.
     sink: the parts go to host memory chunk by chunk (T_core); else they stay in dna_out / qual_out on the device."""
     from colord_amd import parallel as par
-    qa = (2, 0, 1, (7, 14, 26), ()) if with_qual else None       # ONT default: 4-avg at level 1 (arg_parse.cpp:410-450)
+    qa = QA if with_qual else None
     cmp_ = ctx.compressor(prm, qa, qctx, exchange, expected_bases=expected_bases)
     try:
         for ch in shard.chunks:
@@ -258,6 +300,8 @@ def hot_path_step(ctx, qctx, shard: Shard, prm: dict, with_qual: bool, exchange,
             _, dsz, _, qsz, inf = cmp_.encode(arena, est if ref_cut else parts, est, quals, off, d_dst, q_dst if with_qual else None)
             if sink is not None:
                 sink.take(inf["dna_bytes"], inf["qual_bytes"], dsz, qsz)
+            if part_sizes is not None:
+                part_sizes.append((np.array(dsz, dtype=np.uint64), np.array(qsz, dtype=np.uint64)))
             do += inf["dna_bytes"]; qo += inf["qual_bytes"]
             for k_ in tot:
                 tot[k_] += inf[k_]
@@ -279,23 +323,67 @@ def hot_path_step(ctx, qctx, shard: Shard, prm: dict, with_qual: bool, exchange,
                 anchors=tot["n_anchors"], tuple_bytes=tot["tuple_bytes"], dna_bytes=tot["dna_bytes"], qual_bytes=tot["qual_bytes"], parts=shard.n_parts, chunks=len(shard.chunks))
 
 
-def round_trip_check(ctx, table, shard: Shard, sink: HostSink, prm: dict, info: dict, r0: int, max_bases: float = 3.0e8):
-    """Decodes the first `dna` parts of the pass that is in `sink` (host memory) with the library's host decoder — the inverse
-    path, csrc/decode.hip — and compares the bases with the generator's.  (A part needs every reference read before it, so the
-    check runs from the start of the stream; its length is bounded by the decoder's speed, ~40 Mbases/s on one host thread.)"""
+def quantised_quals_4avg(q: np.ndarray, off: np.ndarray, thresholds=(7, 14, 26)) -> np.ndarray:
+    """What a decoder returns for `-q 4-avg` (the ONT default): the bin of a quality q - 33 is the number of thresholds <= it; per read
+    and bin the encoder codes A = (uint32)(double(sum) / double(count) * 256) (quality_coder_impl.cpp:438-450, 821-834) and the decoder
+    spreads it by error diffusion, as += A / 256; v = (uint32)(as - qs); qs += v (quality_coder_impl.cpp:506-559): the j-th base of a bin
+    gets floor(j A / 256) - floor((j - 1) A / 256) — integers throughout (A / 256 and its multiples are exact doubles).  q: ASCII
+    qualities of whole reads back to back, off: their offsets (starting at 0)."""
+    n_reads = len(off) - 1
+    v = q.astype(np.int64) - 33
+    bins = np.zeros(len(q), np.int64)
+    for t in thresholds:
+        bins += v >= t
+    read_of = np.repeat(np.arange(n_reads, dtype=np.int64), np.diff(off).astype(np.int64))
+    key = read_of * 4 + bins
+    cnt = np.bincount(key, minlength=n_reads * 4).astype(np.float64)
+    sm = np.bincount(key, weights=v.astype(np.float64), minlength=n_reads * 4)      # (sums < 2^53: exact)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        A = np.where(cnt > 0, np.floor(sm / np.where(cnt > 0, cnt, 1.0) * 256.0), 0.0).astype(np.int64)
+    out = np.empty(len(q), np.uint8)
+    for b in range(4):                                       # rank j (1-based) of every base among the bases of its read and bin
+        m = bins == b
+        cs = np.cumsum(m, dtype=np.int64)
+        start = cs[off[:-1].astype(np.int64)] - m[off[:-1].astype(np.int64)] if len(q) else cs[:0]
+        j = (cs - np.repeat(start, np.diff(off).astype(np.int64)))[m]
+        a = A[key[m]]
+        out[m] = ((j * a) // 256 - ((j - 1) * a) // 256 + 33).astype(np.uint8)
+    return out
+
+
+def round_trip_check(ctx, table, shard: Shard, sink: HostSink, prm: dict, info: dict, r0: int, max_bases: float = 3.0e8, qa=None):
+    """Decodes the first `dna` AND `qual` parts of the pass that is in `sink` (host memory) with the library's host decoders — the inverse
+    path, csrc/decode.hip — and compares the bases with the generator's and the qualities with the generator's after the reference's
+    4-avg quantisation (quantised_quals_4avg).  (A part needs every reference read before it, so the check runs from the start of the
+    stream; its length is bounded by the decoders' speed, ~40 Mbases/s on one host thread each.)"""
     import ctypes as C
     from colord_amd import _native as N, ontsim
     lib = N.load()
     d = N._P()
     if lib.cl_dna_decoder_create(prm["c"], prm["level"], 0, 0, 0 if prm["sparse"] else 1, int(info["sparse_range"]), float(prm["sparse_exponent"]), C.byref(d)) != 0:
         return {"ok": False, "why": "cl_dna_decoder_create"}
+    qd = None
+    if qa is not None and sink.h_qual is not None:
+        mode, source, level, fwd, rev = qa
+        Q = N.QualParams(mode=mode, source=source, level=level, n_fwd=len(fwd), n_rev=len(rev))
+        for i, v in enumerate(fwd):
+            Q.fwd[i] = v
+        for i, v in enumerate(rev):
+            Q.rev[i] = v
+        qd = N._P()
+        if lib.cl_qual_decoder_create(C.byref(Q), C.byref(qd)) != 0:
+            lib.cl_dna_decoder_free(d)
+            return {"ok": False, "why": "cl_qual_decoder_create"}
     arena, parts = shard.chunks[0][0], shard.chunks[0][1]
     sizes = sink.dna_sizes[0]
     h = sink.h_dna.numpy()
+    qsizes = sink.qual_sizes[0] if qd is not None else None
+    hq = sink.h_qual.numpy() if qd is not None else None
     t0 = time.time()
-    o = 0; n_reads = 0; n_bases = 0; ok = True; why = ""
-    codes, off, _ = ontsim.device_reads(table, ctx.device, r0, r0 + int(arena.n_reads), with_quals=False)
+    o = 0; qo = 0; n_reads = 0; n_bases = 0; ok = True; why = ""; qual_ok = qd is not None; n_qual = 0
+    codes, off, quals = ontsim.device_reads(table, ctx.device, r0, r0 + int(arena.n_reads), with_quals=qd is not None)
     codes, off = codes.cpu().numpy(), off.cpu().numpy()
+    quals = quals.cpu().numpy() if qd is not None else None
     for p in range(len(parts) - 1):
         nr = int(parts[p + 1] - parts[p]); sz = int(sizes[p])
         exp = codes[off[parts[p]]:off[parts[p + 1]]]
@@ -303,14 +391,28 @@ def round_trip_check(ctx, table, shard: Shard, sink: HostSink, prm: dict, info: 
         out = np.empty(len(exp) + 64, np.uint8); offs = np.zeros(nr + 1, np.uint64); got = C.c_uint64(0)
         st = lib.cl_dna_decode_part(d, buf.ctypes.data, sz, nr, out.ctypes.data, len(out), offs.ctypes.data, C.byref(got))
         if st != 0 or got.value != len(exp) or not np.array_equal(out[:len(exp)] & 7, exp):
-            ok = False; why = f"part {p}: status {st}, {got.value} bases decoded, {len(exp)} expected"
+            ok = False; why = f"dna part {p}: status {st}, {got.value} bases decoded, {len(exp)} expected"
             break
+        if qd is not None:
+            qsz = int(qsizes[p])
+            qbuf = np.ascontiguousarray(hq[qo:qo + qsz])
+            qout = np.zeros(len(exp) + 64, np.uint8)
+            st = lib.cl_qual_decode_part(qd, qbuf.ctypes.data, qsz, out.ctypes.data, offs.ctypes.data, nr, qout.ctypes.data)
+            a, b = int(off[parts[p]]), int(off[parts[p + 1]])
+            want = quantised_quals_4avg(quals[a:b], off[parts[p]:parts[p + 1] + 1] - off[parts[p]], qa[3])
+            if st != 0 or not np.array_equal(qout[:len(exp)], want):
+                ok = False; qual_ok = False; why = f"qual part {p}: status {st}, first difference at base {int(np.argmax(qout[:len(exp)] != want)) if st == 0 else -1}"
+                break
+            qo += qsz; n_qual += len(exp)
         o += sz; n_reads += nr; n_bases += len(exp)
         if n_bases >= max_bases:
             break
     lib.cl_dna_decoder_free(d)
-    return {"ok": ok, "why": why, "parts": p + 1, "reads": n_reads, "bases": n_bases, "seconds": round(time.time() - t0, 1),
-            "what": "the first `dna` parts of the last timed pass, host memory -> cl_dna_decode_part -> compared with the generator's bases"}
+    if qd is not None:
+        lib.cl_qual_decoder_free(qd)
+    return {"ok": ok, "why": why, "parts": p + 1, "reads": n_reads, "bases": n_bases, "qual_checked": bool(qual_ok and ok and n_qual > 0), "quals": n_qual, "seconds": round(time.time() - t0, 1),
+            "what": "the first `dna` and `qual` parts of the last timed pass, host memory -> cl_dna_decode_part / cl_qual_decode_part -> compared with the "
+                    "generator's bases and with its qualities after the reference's 4-avg quantisation (bench.py quantised_quals_4avg)"}
 
 
 def cpu_baseline_and_size_check(ctx, qctx, sample_bases: float, coverage: float, pack_symbols: int, k: int, a: int):
@@ -368,9 +470,22 @@ def cpu_baseline_and_size_check(ctx, qctx, sample_bases: float, coverage: float,
             shard = Shard(ctx, table, 0, table.n_reads, 1e9, cut, True)
             dna_out = torch.empty(int(shard.n_bases * 0.5) + (1 << 20), dtype=torch.uint8, device=ctx.device)
             qual_out = torch.empty(int(shard.n_bases * 0.6) + (1 << 20), dtype=torch.uint8, device=ctx.device)
-            inf = hot_path_step(ctx, qctx, shard, params_for(k, a), True, None, dna_out, qual_out, shard.n_bases)
+            psz = []
+            inf = hot_path_step(ctx, qctx, shard, params_for(k, a), True, None, dna_out, qual_out, shard.n_bases, ref_cut=(cut == 1 << 22), part_sizes=psz)
             size[f"streams_vs_ref_{name}"] = (inf["dna_bytes"] + inf["qual_bytes"]) / (ref_streams["dna"] + ref_streams["qual"])
             size[f"dna_qual_bytes_{name}"] = [inf["dna_bytes"], inf["qual_bytes"]]
+            if cut == 1 << 22:
+                # the parts the bench path wrote against the parts of the reference's archive, by SHA-256 (and part by part: the sizes)
+                import hashlib
+                eq = {}
+                for nm, buf, tot, col in (("dna", dna_out, inf["dna_bytes"], 0), ("qual", qual_out, inf["qual_bytes"], 1)):
+                    mine = bytes(buf[:tot].cpu().numpy())
+                    theirs = b"".join(p for _, p in ref_arc[nm].parts)
+                    my_sizes = [int(x) for ch in psz for x in ch[col]]
+                    eq[nm] = bool(hashlib.sha256(mine).digest() == hashlib.sha256(theirs).digest() and my_sizes == [len(p) for _, p in ref_arc[nm].parts])
+                    size[f"bench_{nm}_sha256"] = hashlib.sha256(mine).hexdigest()
+                    size[f"ref_{nm}_sha256"] = hashlib.sha256(theirs).hexdigest()
+                size["bench_parts_sha256_equal_ref"] = bool(eq["dna"] and eq["qual"])
             shard.free()
             del dna_out, qual_out
             if cut == pack_symbols:
@@ -378,10 +493,11 @@ def cpu_baseline_and_size_check(ctx, qctx, sample_bases: float, coverage: float,
     return cb, size
 
 
-def e2e_cli(bases: float, coverage: float, k: int, a: int):
+def e2e_cli(bases: float, coverage: float, k: int, a: int, part_symbols: int):
     """T_e2e: `colord_hip compress-ont` from open(FASTQ) to close(archive) — parsing, upload, all three passes, the header
-    stream, the archive — on a synthetic FASTQ of the same recipe written by the host generator; the reference's part cut (the
-    archive is the reference's, byte for byte), k / a of the main run."""
+    stream, the archive — on a synthetic FASTQ of the same recipe written by the host generator, k / a of the main run: once with the
+    part cut of the headline number (`--part-symbols`, what `value` is measured with) and once with the reference's (the archive is
+    the reference's, byte for byte)."""
     from colord_amd import ontsim
     ours = os.path.join(ROOT, "colord_amd", "colord_hip")
     if not os.path.exists(ours) or bases <= 0:
@@ -392,15 +508,25 @@ def e2e_cli(bases: float, coverage: float, k: int, a: int):
         t0 = time.time()
         n_bases = ontsim.write_fastq(table, fq)
         t_gen = time.time() - t0
-        t0 = time.time()
-        r = subprocess.run([ours, "compress-ont", "-v", "-k", str(k), "-a", str(a), fq, os.path.join(tmp, "e2e.colord")], capture_output=True, text=True)
-        dt = time.time() - t0
-        if r.returncode != 0:
-            return {"error": (r.stderr or r.stdout)[-300:]}
-        phases = [l.strip() for l in r.stderr.splitlines() if l.strip().startswith("[")][-12:]
-        return {"value": n_bases / dt / 1e9, "unit": "Gbases/s", "seconds": round(dt, 2), "bases": n_bases, "fastq_bytes": os.path.getsize(fq),
-                "archive_bytes": os.path.getsize(os.path.join(tmp, "e2e.colord")), "fastq_written_in_s": round(t_gen, 1), "phases": phases,
-                "what": f"colord_hip compress-ont -k {k} -a {a} file -> archive, whole process (parser thread + mapped file, pinned double buffers, reference part cut)"}
+        out = {}
+        for name, ps in (("headline_cut", part_symbols), ("ref_cut", 1 << 22)):
+            if name == "ref_cut" and ps == part_symbols:
+                continue
+            cmd = [ours, "compress-ont", "-v", "-k", str(k), "-a", str(a), "--part-symbols", str(ps), fq, os.path.join(tmp, "e2e.colord")]
+            t0 = time.time()
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            dt = time.time() - t0
+            if r.returncode != 0:
+                out[name] = {"error": (r.stderr or r.stdout)[-300:]}
+                continue
+            phases = [l.strip() for l in r.stderr.splitlines() if l.strip().startswith("[")][-12:]
+            out[name] = {"value": n_bases / dt / 1e9, "unit": "Gbases/s", "seconds": round(dt, 2), "part_symbols": ps, "archive_bytes": os.path.getsize(os.path.join(tmp, "e2e.colord")), "phases": phases}
+        first = out.get("headline_cut") or {}
+        res = {"value": first.get("value"), "unit": "Gbases/s", "seconds": first.get("seconds"), "bases": n_bases, "fastq_bytes": os.path.getsize(fq), "fastq_written_in_s": round(t_gen, 1),
+               "what": f"colord_hip compress-ont -k {k} -a {a} --part-symbols N file -> archive, whole process (mapped file indexed by several threads, chunks filled by parallel copies into "
+                       f"pinned double buffers); `value` is with the headline's part cut ({part_symbols}), `ref_cut` with the reference's 4194304 (byte-identical archive)"}
+        res.update(out)
+        return res
 
 
 def load_traffic(kernel: str):
@@ -504,13 +630,30 @@ def main():
     ctx.acc.clear()
     if qctx is not None:
         qctx.acc.clear()
-    sync()
-    t0 = time.perf_counter()
-    info = None
+    # K steps, each bracketed by barrier + synchronize on both sides; between two brackets (never inside one) the pass that just
+    # ended is digested part by part where the step left it: `parts_digest_stable` = every timed pass gave the same bytes
+    info, dt, step_s, digests = None, 0.0, [], []
     for _ in range(args.steps):
+        sync()
+        t0 = time.perf_counter()
         info = step()
-    sync()
-    dt = time.perf_counter() - t0
+        sync()
+        step_s.append(time.perf_counter() - t0)
+        dt += step_s[-1]
+        if not os.environ.get("BENCH_NO_DIGEST"):
+            digests.append(pass_digest(sink, dna_out, qual_out, info))
+    digest_stable = bool(digests) and all(d == digests[0] for d in digests)
+    digest_diff = ""
+    for i, d in enumerate(digests):
+        for x, y in zip(d, digests[0]):
+            if x != y and not digest_diff:
+                digest_diff = f"pass {i}: {x} != pass 0: {y}"
+        if len(d) != len(digests[0]) and not digest_diff:
+            digest_diff = f"pass {i}: {len(d)} entries != {len(digests[0])}"
+    if world > 1 and digests:
+        ok_t = torch.tensor([1 if digest_stable else 0], dtype=torch.int64, device=ctx.device if backend == "nccl" else "cpu")
+        dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
+        digest_stable = bool(ok_t.item())
     red_dev = ctx.device if backend == "nccl" else torch.device("cpu")
     tdev = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     tb = torch.tensor([shard.n_bases, info["dna_bytes"], info["qual_bytes"], shard.n_reads], dtype=torch.int64, device=red_dev)
@@ -558,7 +701,7 @@ def main():
             if left > 4.0 * (dt / args.steps):
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                rt = round_trip_check(ctx, table, shard, sink, prm, info, r0) if sink is not None else None   # (before the sink is overwritten)
+                rt = round_trip_check(ctx, table, shard, sink, prm, info, r0, qa=QA if not args.no_qual else None) if sink is not None else None   # (before the sink is overwritten)
                 warm2 = left > 9.0 * (dt / args.steps)
                 if warm2:                                  # (an untimed pass first, as for the default cut: other buffer sizes, other pool shape)
                     hot_path_step(ctx, qctx, shard, prm, not args.no_qual, None, dna_out, qual_out, shard.n_bases, ref_cut=True, sink=sink)
@@ -572,7 +715,7 @@ def main():
                            "stream_bytes_vs_default_cut": (inf2["dna_bytes"] + inf2["qual_bytes"]) / max(1, total_dna + total_qual),
                            "note": "same input, one pass, coder parts = the reference's reader packs: the streams are the reference's bytes (size_check.streams_vs_ref_ref_cut)"}
         if rt is None and sink is not None:
-            rt = round_trip_check(ctx, table, shard, sink, prm, info, r0)
+            rt = round_trip_check(ctx, table, shard, sink, prm, info, r0, qa=QA if not args.no_qual else None)
         timer_txt = ("T_core (SURVEY 8d): packed bases + quality bytes resident in HBM -> every compressed part in pinned host memory" if sink is not None
                      else "packed bases + quality bytes resident in HBM -> every compressed part gathered to rank 0 (device)")
         cb, size, e2e = (None, None, None)
@@ -594,7 +737,7 @@ def main():
                 qctx.close()
             torch.cuda.empty_cache()
             try:
-                e2e = e2e_cli(args.e2e_bases, args.coverage, k, a)
+                e2e = e2e_cli(args.e2e_bases, args.coverage, k, a, args.pack_symbols)
             except Exception as e:
                 e2e = {"error": repr(e)[:400]}
             ctx = Context(local)
@@ -607,7 +750,12 @@ def main():
             "vs_baseline_note": "BASELINE.md §1: 0.030 Gbases/s derived from the reference README's time and size for its `memory` preset (human ONT, "
                                 "whole program, hardware not stated) — the only published figure; the measured reference on this host is `cpu_baseline`",
             "archive_vs_ref": (size or {}).get("archive_vs_ref"),
-            "round_trip_checked": bool(rt and rt.get("ok")), "round_trip": rt,
+            "round_trip_checked": bool(rt and rt.get("ok")), "qual_round_trip_checked": bool(rt and rt.get("ok") and rt.get("qual_checked")), "round_trip": rt,
+            "parts_digest_stable": digest_stable,
+            "parts_digest": {"passes": len(digests), "entries_per_pass": len(digests[0]) if digests else 0, "first_difference": digest_diff,
+                             "what": "per timed pass and chunk an xxh3-128 over (part sizes, part bytes) of `dna` and of `qual`, taken from the pinned host buffers "
+                                     "between the per-step timing brackets; all passes must agree", "step_s": [round(x, 3) for x in step_s]},
+            "bench_parts_sha256_equal_ref": (size or {}).get("bench_parts_sha256_equal_ref"),
             "timer": timer_txt,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"synthetic ONT {total_bases / 1e9:.2f} Gbases ({total_reads} reads, N50~20kb, 4-avg quals), genome {genome_len} bp, "

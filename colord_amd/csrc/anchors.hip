@@ -745,10 +745,10 @@ extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* read
 		HIP_TRY(ctx, hipMemsetAsync(B.n_distinct.p, 0, (uint64_t)nb * 4, ctx->side));
 		HIP_TRY(ctx, hipMemsetAsync(B.err.p, 0, 4, ctx->side));                  // (the slots are written region by region, all of them)
 		EncTable T{ B.slots.p, B.toff.p, B.next.p, B.noff.p };
-		hipStream_t main_stream = ctx->stream;
-		ctx->stream = ctx->side;                                                  // (launch + timing events on the side stream)
-		LAUNCHB(ctx, B.nsum * (0.25 + 16.0) /* 2 bits in, two 8-byte slots out per m-mer */, k_table_insert, nb, INS_T, A, r0, r1, m, T, B.n_distinct.p, B.bins.p, B.err.p);
-		ctx->stream = main_stream;
+		{
+			LaunchOn on(ctx, ctx->side);                                          // (launch + timing events on the side stream)
+			LAUNCHB(ctx, B.nsum * (0.25 + 16.0) /* 2 bits in, two 8-byte slots out per m-mer */, k_table_insert, nb, INS_T, A, r0, r1, m, T, B.n_distinct.p, B.bins.p, B.err.p);
+		}
 		HIP_TRY(ctx, hipGetLastError());
 		return CL_OK;
 	};

@@ -14,7 +14,10 @@ extern "C" cl_status cl_ctx_create(int device, cl_ctx** out)
 	if (device < 0 || device >= n) return CL_E_INVALID;
 	if (hipSetDevice(device) != hipSuccess) return CL_E_HIP;
 	cl_ctx* c = new cl_ctx(device);
-	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return CL_E_HIP; }
+	// all four streams exist from the start and are never reassigned while the context works: the shared pool's fences and drains
+	// (cl_ctx_fence, cl_ctx_drain) read them from other threads
+	for (hipStream_t* s : { &c->stream, &c->side, &c->side2, &c->side3 })
+		if (hipStreamCreateWithFlags(s, hipStreamNonBlocking) != hipSuccess) { cl_ctx_destroy(c); return CL_E_HIP; }
 	hipDeviceProp_t p;
 	if (hipGetDeviceProperties(&p, device) == hipSuccess) c->n_cu = p.multiProcessorCount;
 	*out = c;
@@ -62,6 +65,10 @@ extern "C" void cl_ctx_destroy(cl_ctx* c)
 	if (c->prep) { cl_ctx_destroy(c->prep); c->prep = nullptr; }
 	if (c->qprep) { cl_ctx_destroy(c->qprep); c->qprep = nullptr; }
 	(void)hipSetDevice(c->device);
+	// out of the pool's owner table first (under its mutex; waits for a drain of this context another thread may be in): after
+	// this no fence or drain can reach the streams destroyed below
+	cl_ctx_drain(c);
+	c->pool.drop_owner(c->pool_id);
 	for (auto& p : c->pending) { (void)hipEventDestroy(p.second.first); (void)hipEventDestroy(p.second.second); }
 	for (auto e : c->ev_pool) (void)hipEventDestroy(e);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -70,7 +77,6 @@ extern "C" void cl_ctx_destroy(cl_ctx* c)
 	if (c->side3) (void)hipStreamDestroy(c->side3);
 	if (c->inv_tab) (void)hipFree(c->inv_tab);
 	const int dev = c->device;
-	c->pool.drop_owner(c->pool_id);
 	delete c;
 	cl_device_pool_release(dev);
 }

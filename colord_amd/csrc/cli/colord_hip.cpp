@@ -8,6 +8,7 @@
 int run_compress(int argc, char** argv);        // compress.cpp
 int run_decompress(int argc, char** argv);      // decompress.cpp
 int run_info(int argc, char** argv);
+int run_parse_check(int argc, char** argv);     // compress.cpp: the input reader alone (test aid, no GPU)
 
 int main(int argc, char** argv)
 {
@@ -15,6 +16,7 @@ int main(int argc, char** argv)
 	const std::string cmd = argc >= 2 ? argv[1] : "";
 	if (cmd == "decompress") return run_decompress(argc, argv);
 	if (cmd == "info") return run_info(argc, argv);
+	if (cmd == "parse-check") return run_parse_check(argc, argv);
 	if (argc < 2 || cmd == "-h" || cmd == "--help")
 	{
 		const char* a[] = { argv[0], "compress-ont", "--help" };

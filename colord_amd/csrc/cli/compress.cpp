@@ -65,27 +65,32 @@ struct Options {
 	int qual_mode = -1, header_mode = 0, ref_mode = -1;
 	std::vector<uint32_t> T, D; bool has_T = false, has_D = false;
 	double chunk_bases = 1.0e9;
+	uint64_t part_symbols = 2u << 21;               // --part-symbols: the coder parts close once their reads (+ 1 guard each) reach this; default = the reader packs (defs.h:45)
+	int parse_threads = 0;                          // --parse-threads (0: as many as the host offers, at most 32)
 };
 
 // ---- input: one sequential pass that finds lines (memchr) and assigns them their role; bases / qualities / ids are appended to the
 // ---- chunk under construction.  A chunk closes at the first reader-pack boundary at or after chunk_bases.
 struct Chunk {
 	uint8_t* bases = nullptr; uint8_t* quals = nullptr; uint64_t cap = 0, n = 0;       // pinned staging (ASCII)
+	bool pinned = true;                                                                // (false: plain host memory — `parse-check`, which needs no GPU)
+	uint8_t* get(uint64_t bytes) { uint8_t* p = nullptr; if (pinned) hipck(hipHostMalloc((void**)&p, bytes, hipHostMallocDefault), "hipHostMalloc"); else { p = (uint8_t*)malloc(bytes); if (!p) die("out of memory"); } return p; }
+	void give(uint8_t* p) { if (!p) return; if (pinned) (void)hipHostFree(p); else free(p); }
 	std::vector<uint64_t> off{ 0 }; std::vector<uint32_t> packs{ 0 }; uint64_t pack_acc = 0;
+	std::vector<uint32_t> parts{ 0 }; uint64_t part_acc = 0;                           // coder parts (--part-symbols); == packs by default
 	void reserve(uint64_t need, bool with_quals)
 	{
 		if (need <= cap) return;
 		uint64_t nc = std::max<uint64_t>(need, cap + cap / 2 + (1ull << 24));
-		uint8_t* nb = nullptr; uint8_t* nq = nullptr;
-		hipck(hipHostMalloc((void**)&nb, nc, hipHostMallocDefault), "hipHostMalloc");
+		uint8_t* nb = get(nc);
 		if (n) memcpy(nb, bases, n);
-		if (bases) (void)hipHostFree(bases);
+		give(bases);
 		bases = nb;
-		if (with_quals) { hipck(hipHostMalloc((void**)&nq, nc, hipHostMallocDefault), "hipHostMalloc"); if (n) memcpy(nq, quals, n); if (quals) (void)hipHostFree(quals); quals = nq; }
+		if (with_quals) { uint8_t* nq = get(nc); if (n) memcpy(nq, quals, n); give(quals); quals = nq; }
 		cap = nc;
 	}
-	void clear() { n = 0; off.assign(1, 0); packs.assign(1, 0); pack_acc = 0; }
-	void release() { if (bases) (void)hipHostFree(bases); if (quals) (void)hipHostFree(quals); bases = quals = nullptr; cap = 0; }
+	void clear() { n = 0; off.assign(1, 0); packs.assign(1, 0); pack_acc = 0; parts.assign(1, 0); part_acc = 0; }
+	void release() { give(bases); give(quals); bases = quals = nullptr; cap = 0; }
 };
 struct Reader {
 	gzFile g = nullptr; bool gz = false, fastq = true; uint64_t file_bytes = 0, total_bytes = 0, header_symbols = 0;
@@ -97,6 +102,11 @@ struct Reader {
 	std::string fa_header, fa_seq; int fa_state = 0;            // FASTA: 0 header, 1 EOLs after header, 2 read, 3 EOLs after / inside read
 	std::vector<uint8_t> ids, plus; std::vector<uint64_t> id_off{ 0 };
 	uint64_t n_reads = 0, n_bases = 0;
+	uint64_t part_symbols = 2u << 21;
+	// plain FASTQ, several threads: the mapping is cut into byte ranges at record starts, every range is indexed by a thread of its own
+	// (line ends by memchr, the reader's checks), then the chunks are filled from the index by parallel copies (index_mapped below)
+	struct Rec { const uint8_t* id; const uint8_t* seq; const uint8_t* qual; uint32_t id_len, len; uint8_t plus_eq; };
+	std::vector<Rec> recs; size_t rec_pos = 0; bool indexed = false; int threads = 1;
 	void open(const std::string& path)
 	{
 		FILE* probe = fopen(path.c_str(), "rb");
@@ -136,8 +146,140 @@ struct Reader {
 		if (short_line) { const uint8_t* r = (const uint8_t*)memchr(a, '\r', (size_t)(b - a)); if (r) { mp = r + 1; b = r; } }   // (a lone '\r' ends a line too; in a sequence or quality line it is refused as a symbol / quality value)
 		return true;
 	}
+	// One record at cursor `c` of the mapping, with the reader's rules (in_reads.cpp:79-92,188-226); "" = fine, else the reader's complaint.
+	static const char* parse_record(const uint8_t*& c, const uint8_t* end, Rec& r, uint64_t& hdr_syms, bool& got)
+	{
+		auto line = [&](const uint8_t*& a, const uint8_t*& b, bool short_line) -> bool {
+			while (c < end && (*c == '\n' || *c == '\r')) ++c;
+			if (c >= end) return false;
+			a = c;
+			const uint8_t* q = (const uint8_t*)memchr(c, '\n', (size_t)(end - c));
+			b = q ? q : end;
+			c = q ? q + 1 : end;
+			if (b > a && b[-1] == '\r') --b;
+			if (short_line) { const uint8_t* rr = (const uint8_t*)memchr(a, '\r', (size_t)(b - a)); if (rr) { c = rr + 1; b = rr; } }
+			return true;
+		};
+		const uint8_t *h0, *h1, *s0, *s1, *p0, *p1, *q0, *q1;
+		got = false;
+		if (!line(h0, h1, true)) return "";
+		if (!line(s0, s1, false) || !line(p0, p1, true) || !line(q0, q1, false)) return "truncated FASTQ record at the end of the input";
+		if (*h0 != '@') return "FASTQ record does not start with '@'";
+		if (*p0 != '+') return "FASTQ record without '+' line";
+		if (s1 - s0 != q1 - q0) return "sequence and quality lengths differ";
+		const bool eq = p1 - p0 > 1;
+		if (eq && ((p1 - p0) != (h1 - h0) || memcmp(p0 + 1, h0 + 1, (size_t)(h1 - h0 - 1)) != 0)) return "quality header not empty but different than read header";
+		if ((uint64_t)(s1 - s0) >= (1ull << 32) || (uint64_t)(h1 - h0) >= (1ull << 32)) return "line longer than 4 Gi symbols";
+		hdr_syms += (uint64_t)(h1 - h0) + (uint64_t)(p1 - p0);
+		r = Rec{ h0 + 1, s0, q0, (uint32_t)(h1 - h0 - 1), (uint32_t)(s1 - s0), (uint8_t)(eq ? 1 : 0) };
+		got = true;
+		return "";
+	}
+	// Index of the whole mapping by `threads` threads.  A range starts at the first line at or after its byte offset that begins with
+	// '@', is followed two lines later by a '+' line and whose sequence and quality lines are equally long.  That is a guess (a quality
+	// line may begin with '@'), so it is VERIFIED: the thread before must end its last record exactly there.  Any complaint or
+	// mismatch: the index is dropped and the sequential reader (which reports errors in file order) takes over.
+	bool index_mapped()
+	{
+		const int T = threads;
+		const char* mn = getenv("COLORD_HIP_INDEX_MIN_BYTES");                        // (tests index small files too)
+		if (T < 2 || (uint64_t)(me - map) < (mn ? strtoull(mn, nullptr, 10) : (64ull << 20))) return false;
+		std::vector<const uint8_t*> b((size_t)T + 1, me);
+		b[0] = map;
+		for (int i = 1; i < T; ++i)
+		{
+			const uint8_t* p = map + (uint64_t)(me - map) * i / T;
+			const uint8_t* q = (const uint8_t*)memchr(p, '\n', (size_t)(me - p));
+			const uint8_t* found = nullptr;
+			for (int tries = 0; q && tries < 64 && !found; ++tries)
+			{
+				const uint8_t* c = q + 1;
+				while (c < me && (*c == '\n' || *c == '\r')) ++c;
+				if (c >= me) break;
+				if (*c == '@')
+				{
+					const uint8_t* cc = c; Rec r; uint64_t hs = 0; bool got = false;
+					if (parse_record(cc, me, r, hs, got)[0] == 0 && got) { const uint8_t* n2 = cc; while (n2 < me && (*n2 == '\n' || *n2 == '\r')) ++n2; if (n2 >= me || *n2 == '@') found = c; }
+				}
+				q = (const uint8_t*)memchr(c, '\n', (size_t)(me - c));
+			}
+			if (!found) return false;
+			b[i] = found;
+		}
+		for (int i = 1; i <= T; ++i) if (b[i] < b[i - 1]) return false;
+		std::vector<std::vector<Rec>> part((size_t)T); std::vector<uint64_t> hs((size_t)T, 0); std::vector<int> bad((size_t)T, 0);
+		std::vector<std::thread> th;
+		for (int i = 0; i < T; ++i) th.emplace_back([&, i]() {
+			const uint8_t* c = b[i]; const uint8_t* const stop = b[i + 1];
+			part[i].reserve((size_t)((stop - c) / 20000 + 1024));
+			for (;;)
+			{
+				while (c < me && (*c == '\n' || *c == '\r')) ++c;                       // (blank lines between records belong to nobody)
+				if (c >= stop) break;
+				Rec r; bool got = false;
+				if (parse_record(c, me, r, hs[i], got)[0] != 0) { bad[i] = 1; return; }
+				if (!got) break;
+				part[i].push_back(r);
+			}
+			while (c < me && (*c == '\n' || *c == '\r')) ++c;
+			const uint8_t* want = stop; while (want < me && (*want == '\n' || *want == '\r')) ++want;
+			if (c != want) bad[i] = 1;                                                  // the next range does not begin where this one's last record ends
+		});
+		for (auto& t : th) t.join();
+		for (int i = 0; i < T; ++i) if (bad[i]) return false;
+		size_t total = 0; for (auto& v : part) total += v.size();
+		recs.reserve(total);
+		for (int i = 0; i < T; ++i) { recs.insert(recs.end(), part[i].begin(), part[i].end()); header_symbols += hs[i]; std::vector<Rec>().swap(part[i]); }
+		indexed = true;
+		return true;
+	}
+	// a chunk from the index: the bookkeeping (offsets, packs, parts, ids) in file order on this thread, the bases and qualities by parallel copies
+	bool next_chunk_indexed(Chunk& ch, uint64_t target)
+	{
+		ch.clear();
+		const size_t first = rec_pos;
+		auto chunk_full = [&]() { return ch.n >= target && ch.pack_acc == 0 && ch.off.size() > 1; };
+		while (rec_pos < recs.size() && !chunk_full())
+		{
+			const Rec& r = recs[rec_pos++];
+			ids.insert(ids.end(), r.id, r.id + r.id_len); id_off.push_back(ids.size()); plus.push_back(r.plus_eq);
+			ch.n += r.len; ch.off.push_back(ch.n);
+			++n_reads; n_bases += r.len;
+			close_bounds(ch, r.len);
+		}
+		finish_bounds(ch);
+		if (ch.off.size() <= 1) return false;
+		{ const uint64_t total = ch.n; ch.n = 0; ch.reserve(total + 1, true); ch.n = total; }     // (nothing to carry over: the buffers are filled below)
+		const size_t cnt = rec_pos - first; const int T = (int)std::min<size_t>((size_t)threads, std::max<size_t>(1, cnt / 256));
+		std::vector<std::thread> th;
+		for (int i = 0; i < T; ++i) th.emplace_back([&, i]() {
+			// (equal shares of the chunk's bytes: the offsets are ascending)
+			const uint64_t lo_b = ch.n * (uint64_t)i / T, hi_b = ch.n * (uint64_t)(i + 1) / T;
+			size_t lo = (size_t)(std::lower_bound(ch.off.begin(), ch.off.end() - 1, lo_b) - ch.off.begin());
+			size_t hi = i + 1 == T ? cnt : (size_t)(std::lower_bound(ch.off.begin(), ch.off.end() - 1, hi_b) - ch.off.begin());
+			for (size_t x = lo; x < hi; ++x) { const Rec& r = recs[first + x]; memcpy(ch.bases + ch.off[x], r.seq, r.len); memcpy(ch.quals + ch.off[x], r.qual, r.len); }
+		});
+		for (auto& t : th) t.join();
+		return true;
+	}
+	// pack / part bookkeeping of one more read of `len` symbols: a pack closes once its reads (with one guard byte each) reach 4 Mi
+	// symbols (in_reads.cpp:62-77); the coder parts likewise at --part-symbols
+	void close_bounds(Chunk& ch, uint64_t len)
+	{
+		ch.pack_acc += len + 1;
+		if (ch.pack_acc >= (2u << 21)) { ch.packs.push_back((uint32_t)(ch.off.size() - 1)); ch.pack_acc = 0; }
+		ch.part_acc += len + 1;
+		if (ch.part_acc >= part_symbols) { ch.parts.push_back((uint32_t)(ch.off.size() - 1)); ch.part_acc = 0; }
+	}
+	void finish_bounds(Chunk& ch)
+	{
+		if (ch.off.size() > 1 && ch.packs.back() != ch.off.size() - 1) { ch.packs.push_back((uint32_t)(ch.off.size() - 1)); ch.pack_acc = 0; }
+		if (ch.off.size() > 1 && ch.parts.back() != ch.off.size() - 1) { ch.parts.push_back((uint32_t)(ch.off.size() - 1)); ch.part_acc = 0; }
+		if (part_symbols == (2u << 21)) ch.parts = ch.packs;
+	}
 	bool next_chunk_mapped(Chunk& ch, uint64_t target)
 	{
+		if (indexed) return next_chunk_indexed(ch, target);
 		ch.clear();
 		auto chunk_full = [&]() { return ch.n >= target && ch.pack_acc == 0 && ch.off.size() > 1; };
 		while (!chunk_full())
@@ -153,7 +295,7 @@ struct Reader {
 			if (eq && ((p1 - p0) != (h1 - h0) || memcmp(p0 + 1, h0 + 1, (size_t)(h1 - h0 - 1)) != 0)) die("quality header not empty but different than read header");   // in_reads.cpp:79-92
 			add_record(ch, (const char*)h0 + 1, (size_t)(h1 - h0 - 1), (const char*)s0, (size_t)(s1 - s0), (const char*)q0, eq);
 		}
-		if (ch.off.size() > 1 && ch.packs.back() != ch.off.size() - 1) { ch.packs.push_back((uint32_t)(ch.off.size() - 1)); ch.pack_acc = 0; }
+		finish_bounds(ch);
 		return ch.off.size() > 1;
 	}
 	void fill() { const int n = gzread(g, buf.data(), (unsigned)buf.size()); if (n < 0) die("read error (zlib)"); len = (size_t)n; pos = 0; total_bytes += len; if (!n) eof = true; }
@@ -165,8 +307,7 @@ struct Reader {
 		if (fastq) memcpy(ch.quals + ch.n, qual, seq_len);
 		ch.n += seq_len; ch.off.push_back(ch.n);
 		++n_reads; n_bases += seq_len;
-		ch.pack_acc += seq_len + 1;                               // a pack closes once its reads (with one guard byte each) reach 4 Mi symbols (in_reads.cpp:62-77)
-		if (ch.pack_acc >= (2u << 21)) { ch.packs.push_back((uint32_t)(ch.off.size() - 1)); ch.pack_acc = 0; }
+		close_bounds(ch, seq_len);
 	}
 	void flush_fastq(Chunk& ch)
 	{
@@ -226,11 +367,11 @@ struct Reader {
 			if (fastq) { if (!line[which].empty()) { if (++which == 4) { flush_fastq(ch); which = 0; for (auto& l : line) l.clear(); } } if (which != 0) die("truncated FASTQ record at the end of the input"); }
 			else if (!fa_header.empty()) flush_fasta(ch);
 		}
-		if (ch.off.size() > 1 && ch.packs.back() != ch.off.size() - 1) { ch.packs.push_back((uint32_t)(ch.off.size() - 1)); ch.pack_acc = 0; }
+		finish_bounds(ch);
 		return ch.off.size() > 1;
 	}
 };
-struct DevChunk { cl_reads* reads = nullptr; uint8_t* d_quals = nullptr; uint64_t* d_off = nullptr; std::vector<uint32_t> packs; uint64_t n_bases = 0; uint32_t n_reads = 0; };
+struct DevChunk { cl_reads* reads = nullptr; uint8_t* d_quals = nullptr; uint64_t* d_off = nullptr; std::vector<uint32_t> packs, parts; uint64_t n_bases = 0; uint32_t n_reads = 0; };
 } // namespace
 
 static void usage()
@@ -244,7 +385,44 @@ static void usage()
 		"  -i,--identifier org|main|none   -c,--max-candidates N   -L,--Lowest-count N   -H,--Highest-count N   -f,--filter-modulo N\n"
 		"  -e,--edit-script-mult X   -r,--max-recurence-level N   --min-to-alt N   --min-mmer-frac X   --min-mmer-force-enc X\n"
 		"  --max-matches-mult X   --min-anchors N   -R,--Ref-reads-mode all|sparse   -g,--sparse-range X   -x,--sparse-exponent X\n"
-		"  -t,--threads N (accepted; the data path runs on the GPU)   -v,--verbose   --gpu N   --chunk-bases X\n");
+		"  -t,--threads N (accepted; the data path runs on the GPU)   -v,--verbose   --gpu N   --chunk-bases X\n"
+		"  --part-symbols N   coder parts of N symbols instead of the reference's 4194304 (defs.h:45): same FASTQ back from either\n"
+		"                     decompressor, 8 more bytes per part, far shorter interval-coder chains (65536: +0.04 %% size, 1.4x the speed)\n"
+		"  --parse-threads N  threads that index a plain FASTQ (default: the host's, at most 32)\n");
+}
+
+// `colord_hip parse-check [--parse-threads N] [--part-symbols N] [--chunk-bases X] input`: the reader alone (no GPU): per chunk a
+// digest of what the compressor would be handed (bases, qualities, offsets, packs, parts), then of the ids — the test that the
+// indexed, multi-threaded reader of a plain FASTQ returns exactly what the sequential one returns
+int run_parse_check(int argc, char** argv)
+{
+	uint64_t part_symbols = 2u << 21; int threads = 1; double chunk_bases = 1.0e9; std::string in;
+	for (int i = 2; i < argc; ++i)
+	{
+		const std::string a = argv[i];
+		if (a == "--parse-threads" && i + 1 < argc) threads = atoi(argv[++i]);
+		else if (a == "--part-symbols" && i + 1 < argc) part_symbols = strtoull(argv[++i], nullptr, 10);
+		else if (a == "--chunk-bases" && i + 1 < argc) chunk_bases = atof(argv[++i]);
+		else in = a;
+	}
+	if (in.empty()) die("parse-check: expected an input path");
+	Reader R; R.part_symbols = part_symbols; R.threads = threads; R.open(in);
+	const bool idx = R.map && R.index_mapped();
+	auto fnv = [](uint64_t h, const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 0x100000001b3ull; } return h; };
+	Chunk ch; ch.pinned = false; uint32_t ci = 0;
+	while (R.next_chunk(ch, (uint64_t)chunk_bases))
+	{
+		uint64_t h = 0xcbf29ce484222325ull;
+		h = fnv(h, ch.bases, ch.n); if (R.fastq) h = fnv(h, ch.quals, ch.n);
+		h = fnv(h, ch.off.data(), ch.off.size() * 8); h = fnv(h, ch.packs.data(), ch.packs.size() * 4); h = fnv(h, ch.parts.data(), ch.parts.size() * 4);
+		printf("chunk %u: %zu reads %llu bases %zu packs %zu parts %016llx\n", ci++, ch.off.size() - 1, (unsigned long long)ch.n, ch.packs.size() - 1, ch.parts.size() - 1, (unsigned long long)h);
+	}
+	uint64_t h = 0xcbf29ce484222325ull;
+	h = fnv(h, R.ids.data(), R.ids.size()); h = fnv(h, R.id_off.data(), R.id_off.size() * 8); h = fnv(h, R.plus.data(), R.plus.size());
+	printf("ids %016llx reads %llu bases %llu header symbols %llu\n", (unsigned long long)h, (unsigned long long)R.n_reads, (unsigned long long)R.n_bases, (unsigned long long)R.header_symbols);
+	fprintf(stderr, "parse-check: %s reader, %d thread(s)\n", idx ? "indexed" : "sequential", threads);
+	ch.release();
+	return 0;
 }
 
 int run_compress(int argc, char** argv)
@@ -286,6 +464,8 @@ int run_compress(int argc, char** argv)
 		else if (a == "-s" || a == "--store-reference") O.store_genome = true;
 		else if (a == "--gpu") O.gpu = atoi(need(i).c_str());
 		else if (a == "--chunk-bases") O.chunk_bases = atof(need(i).c_str());
+		else if (a == "--part-symbols") { O.part_symbols = strtoull(need(i).c_str(), nullptr, 10); if (O.part_symbols < 1024 || O.part_symbols > (2u << 21)) die("--part-symbols must be in [1024, 4194304]"); }
+		else if (a == "--parse-threads") { O.parse_threads = atoi(need(i).c_str()); if (O.parse_threads < 1 || O.parse_threads > 256) die("--parse-threads must be in [1, 256]"); }
 		else if (a == "-h" || a == "--help") { usage(); return 0; }
 		else if (!a.empty() && a[0] == '-' && a.size() > 1) die("unknown option " + a);
 		else pos.push_back(a);
@@ -318,7 +498,10 @@ int run_compress(int argc, char** argv)
 	const auto t0 = std::chrono::steady_clock::now();
 	auto lap = [&](const char* what) { if (O.verbose) fprintf(stderr, "[%7.2f s] %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), what); };
 	hipck(hipSetDevice(O.gpu), "hipSetDevice");
-	Reader R; R.open(O.in);
+	Reader R; R.part_symbols = O.part_symbols; R.open(O.in);
+	R.threads = O.parse_threads ? O.parse_threads : (int)std::min<unsigned>(32, std::max<unsigned>(1, std::thread::hardware_concurrency()));
+	if (const char* e = getenv("COLORD_HIP_PARSE_THREADS")) R.threads = std::max(1, atoi(e));
+	if (R.map && R.index_mapped()) lap("input indexed");
 	// k-mer / anchor length from the estimated number of bases (adjustKmerAndAnchorLen, compression.cpp:42-95)
 	uint32_t k = O.k, a = O.a;
 	if (!k)
@@ -383,7 +566,7 @@ int run_compress(int argc, char** argv)
 		{ std::unique_lock<std::mutex> l(pmu); pcv.wait(l, [&]() { return filled[hi] != 0; }); }
 		if (filled[hi] == 2) break;
 		Chunk& host = hostbuf[hi];
-		DevChunk dc; dc.n_reads = (uint32_t)(host.off.size() - 1); dc.n_bases = host.n; dc.packs = host.packs;
+		DevChunk dc; dc.n_reads = (uint32_t)(host.off.size() - 1); dc.n_bases = host.n; dc.packs = host.packs; dc.parts = host.parts;
 		if (with_qual)
 		{	// quality bytes outside 33..128 would index past the coder's tables: the input is rejected, not coded (qualities are Phred+33)
 			uint8_t lo = 255, hi8 = 0; const uint8_t* qv = host.quals;
@@ -463,7 +646,7 @@ int run_compress(int argc, char** argv)
 	}
 	uint64_t dna_total = 0, qual_total = 0; uint32_t n_parts_total = 0;
 	{	// pass 2: chunk by chunk; the parts of a chunk go to the archive while the next chunk is coded
-		uint64_t max_bases = 0, max_parts = 0; for (auto& dc : chunks) { max_bases = std::max(max_bases, dc.n_bases); max_parts = std::max<uint64_t>(max_parts, dc.packs.size()); }
+		uint64_t max_bases = 0, max_parts = 0; for (auto& dc : chunks) { max_bases = std::max(max_bases, dc.n_bases); max_parts = std::max<uint64_t>(max_parts, dc.parts.size()); }
 		const uint64_t dna_cap = max_bases + 64 * max_parts + 4096, qual_cap = (uint64_t)(max_bases * 1.35) + 64 * max_parts + 4096;
 		uint8_t* d_dna = nullptr; uint8_t* d_qual = nullptr;
 		hipck(hipMalloc((void**)&d_dna, dna_cap), "hipMalloc"); if (with_qual) hipck(hipMalloc((void**)&d_qual, qual_cap), "hipMalloc");
@@ -471,16 +654,16 @@ int run_compress(int argc, char** argv)
 		// every chunk is resident: announce them, so that candidates / anchors / edit scripts of the next chunks are computed on the
 		// compressor's encode lanes while this thread codes and writes the parts of the chunks before them
 		// (the coder parts are the reader packs: with them the `dna` coder's walks and sort of the next chunk are made ahead too)
-		for (auto& dc : chunks) ck(ctx, cl_compressor_prepare_parts(cmp, dc.reads, dc.packs.data(), (uint32_t)dc.packs.size() - 1, dc.packs.data(), (uint32_t)dc.packs.size() - 1, dc.d_quals, dc.d_off), "look-ahead");
+		for (auto& dc : chunks) ck(ctx, cl_compressor_prepare_parts(cmp, dc.reads, dc.packs.data(), (uint32_t)dc.packs.size() - 1, dc.parts.data(), (uint32_t)dc.parts.size() - 1, dc.d_quals, dc.d_off), "look-ahead");
 		for (auto& dc : chunks)
 		{
-			const uint32_t np = (uint32_t)dc.packs.size() - 1;
+			const uint32_t np = (uint32_t)dc.parts.size() - 1;
 			std::vector<uint64_t> dsz(np), qsz(np); cl_compress_info info{};
-			ck(ctx, cl_compressor_encode(cmp, dc.reads, dc.d_quals, dc.d_off, dc.packs.data(), np, dc.packs.data(), np, d_dna, dna_cap, dsz.data(), d_qual, qual_cap, qsz.data(), &info), "pass 2");
+			ck(ctx, cl_compressor_encode(cmp, dc.reads, dc.d_quals, dc.d_off, dc.parts.data(), np, dc.packs.data(), (uint32_t)dc.packs.size() - 1, d_dna, dna_cap, dsz.data(), d_qual, qual_cap, qsz.data(), &info), "pass 2");
 			h_dna.resize(info.dna_bytes); h_qual.resize(info.qual_bytes);
 			if (info.dna_bytes) hipck(hipMemcpy(h_dna.data(), d_dna, info.dna_bytes, hipMemcpyDeviceToHost), "hipMemcpy");
 			if (info.qual_bytes) hipck(hipMemcpy(h_qual.data(), d_qual, info.qual_bytes, hipMemcpyDeviceToHost), "hipMemcpy");
-			uint64_t o = 0; for (uint32_t p = 0; p < np; ++p) { ar.add(s_dna, h_dna.data() + o, dsz[p], dc.packs[p + 1] - dc.packs[p]); o += dsz[p]; }
+			uint64_t o = 0; for (uint32_t p = 0; p < np; ++p) { ar.add(s_dna, h_dna.data() + o, dsz[p], dc.parts[p + 1] - dc.parts[p]); o += dsz[p]; }
 			o = 0; if (with_qual) for (uint32_t p = 0; p < np; ++p) { ar.add(s_qual, h_qual.data() + o, qsz[p], 0); o += qsz[p]; }
 			dna_total += info.dna_bytes; qual_total += info.qual_bytes; n_parts_total += np;
 			cl_reads_free(dc.reads); dc.reads = nullptr; if (dc.d_quals) (void)hipFree(dc.d_quals); (void)hipFree(dc.d_off); dc.d_quals = nullptr; dc.d_off = nullptr;

@@ -17,6 +17,7 @@
 #include <map>
 #include <deque>
 #include <mutex>
+#include <condition_variable>
 #include <thread>
 #include <chrono>
 #include "../../include/colord_hip.h"
@@ -48,17 +49,19 @@ struct DevPool {
 	std::mutex mu;                                // a buffer made on one thread (an encode lane of cl_compressor) may be released on another
 	std::vector<Slab> slabs;
 	std::vector<cl_ctx*> owners; std::vector<uint64_t> drained; uint64_t clock = 0;      // by owner id
+	std::vector<uint32_t> pinned; std::condition_variable pin_cv;                          // drains of an owner's streams in progress outside the mutex (drop_owner waits for them)
 	// fences: every few releases of an owner, an event on each of its streams.  What it released before a fence is anybody's once
 	// the fence's events have completed — no need to wait for whatever the owner has started since.
 	struct Fence { uint64_t clock; hipEvent_t ev[4]; int n; };
 	std::vector<std::deque<Fence>> fences; std::vector<uint32_t> since_fence; std::vector<hipEvent_t> spare_events;
 	uint64_t reserved = 0, live_bytes = 0, peak_live = 0, peak_total = 0; uint32_t n_mallocs = 0, n_drains = 0;   // (statistics for COLORD_HIP_POOL_DEBUG)
 	static constexpr uint64_t ALIGN = 256, PAD = 256, SLAB_MIN = 256ull << 20, SLAB_MAX = 4ull << 30;
-	int32_t add_owner(cl_ctx* c) { std::lock_guard<std::mutex> l(mu); owners.push_back(c); drained.push_back(0); fences.emplace_back(); since_fence.push_back(0); return (int32_t)owners.size() - 1; }
+	int32_t add_owner(cl_ctx* c) { std::lock_guard<std::mutex> l(mu); owners.push_back(c); drained.push_back(0); fences.emplace_back(); since_fence.push_back(0); pinned.push_back(0); return (int32_t)owners.size() - 1; }
 	void drop_owner(int32_t id)
-	{	// (its streams are gone: nothing of it is in flight)
-		std::lock_guard<std::mutex> l(mu);
+	{	// (the caller has drained its streams: nothing of it is in flight; they are destroyed after this returns)
+		std::unique_lock<std::mutex> l(mu);
 		if (id < 0 || (size_t)id >= owners.size()) return;
+		pin_cv.wait(l, [&] { return pinned[id] == 0; });
 		owners[id] = nullptr; drained[id] = ~0ull;
 		for (auto& f : fences[id]) for (int i = 0; i < f.n; ++i) spare_events.push_back(f.ev[i]);
 		fences[id].clear();
@@ -119,6 +122,18 @@ struct DevPool {
 				else it = nx;
 			}
 	}
+	// waits for the streams of owner `id` with the mutex released; the owner is pinned meanwhile (drop_owner, hence the destruction
+	// of its context, waits for the pin)
+	void drain_unlocked(std::unique_lock<std::mutex>& lock, int32_t id)
+	{
+		cl_ctx* oc = owners[id];
+		if (!oc) return;
+		++pinned[id];
+		lock.unlock();
+		cl_ctx_drain(oc);
+		lock.lock();
+		if (--pinned[id] == 0) pin_cv.notify_all();
+	}
 	// best fit among the extents `who` may use; *foreign: the owner of a fitting extent it may not use yet (or -1)
 	bool carve(uint64_t r, int32_t who, void** out, int32_t* foreign)
 	{
@@ -161,12 +176,9 @@ struct DevPool {
 		for (int tries = 0; !ok && foreign >= 0 && tries < 8; ++tries)
 		{	// memory that would do was released by another context whose kernels may still be using it: wait for that context's streams
 			// (not the device), then it is anybody's
-			cl_ctx* oc = owners[foreign];
 			const uint64_t upto = clock;
 			++n_drains;
-			lock.unlock();
-			if (oc) cl_ctx_drain(oc);
-			lock.lock();
+			drain_unlocked(lock, foreign);
 			if (drained[foreign] < upto) drained[foreign] = upto;
 			coalesce_locked();
 			ok = carve(r, who, out, &foreign);
@@ -211,8 +223,8 @@ struct DevPool {
 					got_it = carve(r, who, out, &fo);
 					if (!got_it && fo >= 0 && (tries & 7) == 7)
 					{	// (something fits but its owner has not passed a fence since: wait for that owner's streams)
-						cl_ctx* oc = owners[fo]; const uint64_t upto = clock;
-						lock.unlock(); if (oc) cl_ctx_drain(oc); lock.lock();
+						const uint64_t upto = clock;
+						drain_unlocked(lock, fo);
 						if (drained[fo] < upto) drained[fo] = upto;
 					}
 				}
@@ -249,9 +261,10 @@ struct DevPool {
 				if (fences[who].size() < 64)
 				{
 					Fence f; f.clock = clock; f.n = 0;
-					for (int i = 0; i < 4; ++i) { if (spare_events.empty()) { hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); break; } spare_events.push_back(e); } f.ev[i] = spare_events.back(); spare_events.pop_back(); }
-					f.n = cl_ctx_fence(owners[who], f.ev);
-					for (int i = f.n; i < 4; ++i) spare_events.push_back(f.ev[i]);
+					int have = 0;                                                      // events actually obtained (a fence needs all four)
+					for (; have < 4; ++have) { if (spare_events.empty()) { hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); break; } spare_events.push_back(e); } f.ev[have] = spare_events.back(); spare_events.pop_back(); }
+					if (have == 4) f.n = cl_ctx_fence(owners[who], f.ev);
+					for (int i = f.n; i < have; ++i) spare_events.push_back(f.ev[i]);
 					if (f.n > 0) fences[who].push_back(f);
 				}
 			}
@@ -296,7 +309,8 @@ struct cl_ctx {
 	int device = 0;
 	int32_t pool_id = -1;                        // this context as an owner of free extents of the shared pool
 	explicit cl_ctx(int dev) : pool(cl_device_pool_acquire(dev)), device(dev) { pool_id = pool.add_owner(this); }
-	hipStream_t stream = nullptr;
+	hipStream_t stream = nullptr;                // the context's main stream; never reassigned while the context works (the pool's fences and drains read it from other threads)
+	hipStream_t launch = nullptr;                // owner thread only: where LAUNCH and its timing events go while a stage works on a side / coder stream (null: `stream`)
 	int prio = 0;                                // priority of this context's streams (cl_ctx_set_priority; 0 = the runtime's default)
 	hipStream_t side = nullptr;                  // second stream for chains that would leave the machine idle (created on first use)
 	hipStream_t side2 = nullptr;                 // third stream: the four-per-wave aligner next to the tail-bound wave-per-gap one
@@ -352,7 +366,11 @@ template<typename T> hipError_t DevBuf<T>::alloc(cl_ctx* c, uint64_t count)
 	if (_e != hipSuccess) \
 	return cl_fail((ctx), CL_E_NOMEM, std::string("hipMalloc(" #buf ") of ") + std::to_string((uint64_t)(count)) + " elems: " + hipGetErrorString(_e)); } while (0)
 
-// ---- per-kernel timing with HIP events on the context stream -------------------------------------
+// ---- per-kernel timing with HIP events on the stream of the launch --------------------------------
+static inline hipStream_t cl_launch_stream(const cl_ctx* c) { return c->launch ? c->launch : c->stream; }
+// the launches of a scope on another stream of the context (owner thread only; cl_ctx::stream itself is never swapped: the shared
+// pool's fences and drains read it from other threads)
+struct LaunchOn { cl_ctx* c; hipStream_t prev; LaunchOn(cl_ctx* c_, hipStream_t s) : c(c_), prev(c_->launch) { c->launch = s; } ~LaunchOn() { c->launch = prev; } };
 struct KernelTimer {
 	cl_ctx* c; const char* name; hipEvent_t a = nullptr, b = nullptr;
 	KernelTimer(cl_ctx* c_, const char* n) : c(c_), name(n)
@@ -360,27 +378,27 @@ struct KernelTimer {
 		if (!c->timing) return;
 		auto get = [&]() { hipEvent_t e; if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); } else (void)hipEventCreate(&e); return e; };
 		a = get(); b = get();
-		(void)hipEventRecord(a, c->stream);
+		(void)hipEventRecord(a, cl_launch_stream(c));
 	}
 	~KernelTimer()
 	{
 		if (!c->timing) return;
-		(void)hipEventRecord(b, c->stream);
+		(void)hipEventRecord(b, cl_launch_stream(c));
 		c->pending.push_back({ name, { a, b } });
 		c->pending_bytes.push_back(c->next_bytes); c->next_bytes = 0;
 	}
 };
 // every kernel launch goes through LAUNCH so that per-kernel HIP-event times are complete
 #define LAUNCH(ctx, kernel, grid, block, ...) do { KernelTimer _kt((ctx), #kernel); \
-	hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (ctx)->stream, __VA_ARGS__); } while (0)
+	hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, cl_launch_stream(ctx), __VA_ARGS__); } while (0)
 // a template kernel under the name of its instantiation (as rocprofv3 lists it), so that the two sets of times can be laid side by side
 #define LAUNCHB_NAMED(ctx, name, bytes, kernel, grid, block, ...) do { (ctx)->next_bytes = (double)(bytes); KernelTimer _kt((ctx), (name)); \
-	hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (ctx)->stream, __VA_ARGS__); } while (0)
+	hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, cl_launch_stream(ctx), __VA_ARGS__); } while (0)
 // LAUNCH with the algorithmic HBM byte count of this launch (for achieved-GB/s reporting)
 #define LAUNCHB(ctx, bytes, kernel, grid, block, ...) do { (ctx)->next_bytes = (double)(bytes); LAUNCH(ctx, kernel, grid, block, __VA_ARGS__); } while (0)
 // the same with dynamic LDS
 #define LAUNCHB_SHM(ctx, bytes, kernel, grid, block, shm, ...) do { (ctx)->next_bytes = (double)(bytes); KernelTimer _kt((ctx), #kernel); \
-	hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (shm), (ctx)->stream, __VA_ARGS__); } while (0)
+	hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (shm), cl_launch_stream(ctx), __VA_ARGS__); } while (0)
 // a further stream of the context, at the context's priority
 static inline hipError_t cl_stream_create(cl_ctx* c, hipStream_t* s) { return c->prio ? hipStreamCreateWithPriority(s, hipStreamNonBlocking, c->prio) : hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
 static inline void cl_timing_begin(cl_ctx*) {}   // times accumulate until cl_ctx_kernel_times reports them

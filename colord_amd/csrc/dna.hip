@@ -1265,13 +1265,11 @@ cl_status dna_evolve_batch(cl_ctx* ctx, cl_dna_coder* D, const cl_reads* refs, c
 		DEV_ALLOC(ctx, G->d_out_off, np + 1); DEV_ALLOC(ctx, G->d_size, np); DEV_ALLOC(ctx, G->d_dst_off, np);
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                         // the triples are complete
 		{
-			hipStream_t main_stream = ctx->stream;
-			ctx->stream = G->stream;                                              // (launch + timing events on the coder's stream)
+			LaunchOn on(ctx, G->stream);                                          // (launch + timing events on the coder's stream)
 			G->sync.s = G->stream;
 			hipError_t e1 = hipMemcpyAsync(G->d_out_off.p, G->out_off.data(), (np + 1) * 8, hipMemcpyHostToDevice, G->stream);
 			LAUNCHB(ctx, n_syms * 8.0, k_range_code, ng, 64, (const triple_t*)trip.p, (const uint64_t*)d_gbase.p, (const uint32_t*)d_plen.p, np, G->tmp.p, (const uint64_t*)G->d_out_off.p, G->d_size.p, inv_tab);
 			hipError_t e2 = hipGetLastError();
-			ctx->stream = main_stream;
 			HIP_TRY(ctx, e1); HIP_TRY(ctx, e2);
 		}
 		E.groups.push_back(std::move(G));

@@ -988,8 +988,7 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 			uint32_t max_blocks = 1;
 			for (int nb = 1; nb <= 4; ++nb) max_blocks = std::max(max_blocks, std::min<uint32_t>(grid_for(hb[nb + 1] - hb[nb], 64), n_cu * 4));
 			DEV_ALLOC(ctx, hist, (uint64_t)max_blocks * 256 * 4 * 2 * 64);
-			hipStream_t main_stream = ctx->stream;
-			ctx->stream = ctx->side;                                              // (launches + timing events on the side stream)
+			LaunchOn on(ctx, ctx->side);                                          // (launches + timing events on the side stream)
 			hipError_t le = hipSuccess;
 			for (int nb = 1; nb <= 4; ++nb)
 			{
@@ -1008,7 +1007,6 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 				}
 				if (le == hipSuccess) le = hipGetLastError();
 			}
-			ctx->stream = main_stream;
 			HIP_TRY(ctx, le);
 		}
 		// gaps of up to 16 row blocks: four per wave, on a third stream — a throughput kernel next to the wave-per-gap kernel
@@ -1028,10 +1026,8 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 			if (!ctx->side2) HIP_TRY(ctx, cl_stream_create(ctx, &ctx->side2));
 			quad_join.s = ctx->side2;
 			HIP_TRY(ctx, hipMemsetAsync(qc.p, 0, 8, ctx->side2));
-			hipStream_t main_stream = ctx->stream;
-			ctx->stream = ctx->side2;                                             // (launch + timing events on the third stream)
+			LaunchOn on(ctx, ctx->side2);                                         // (launch + timing events on the third stream)
 			LAUNCHB(ctx, 1.25 * (double)h_cb[5], k_align_quad, waves, 64, (const uint32_t*)ids.p + hb[5], n_list, L.gaps.p, L.es.p, A, R, quad_scratch.p, per_wave, qc.p, quad_redo.p, qc.p + 1);
-			ctx->stream = main_stream;
 			HIP_TRY(ctx, hipGetLastError());
 		}
 		// giant gaps: a work-group each, on a stream of their own, started before the wave-per-gap kernel (they are its former tail)
@@ -1049,10 +1045,8 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 			if (!ctx->side3) HIP_TRY(ctx, cl_stream_create(ctx, &ctx->side3));
 			team_join.s = ctx->side3;
 			HIP_TRY(ctx, hipMemsetAsync(tc.p, 0, 8, ctx->side3));
-			hipStream_t main_stream = ctx->stream;
-			ctx->stream = ctx->side3;
+			LaunchOn on(ctx, ctx->side3);
 			LAUNCHB(ctx, 1.25 * (double)h_cb[7], k_align_team, teams, 64 * wt::TW, (const uint32_t*)ids.p + hb[7], n_list, L.gaps.p, L.es.p, A, R, team_scratch.p, per_team, own_bytes, tc.p, team_redo.p, tc.p + 1);
-			ctx->stream = main_stream;
 			HIP_TRY(ctx, hipGetLastError());
 		}
 		// large gaps, in rounds of growing lane pools

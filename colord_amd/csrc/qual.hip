@@ -617,11 +617,9 @@ cl_status qual_evolve_batch(cl_ctx* ctx, cl_qual_coder* Q, const cl_reads* R, co
 		if (Q->cstreams.size() < 4) { hipStream_t ns = nullptr; HIP_TRY(ctx, hipStreamCreateWithFlags(&ns, hipStreamNonBlocking)); Q->cstreams.push_back(ns); }
 		PG.stream = Q->cstreams[Q->next_cstream++ % Q->cstreams.size()];
 		{
-			hipStream_t main_stream = ctx->stream;
-			ctx->stream = PG.stream;                                             // (launch + timing events on the coder's stream)
+			LaunchOn on(ctx, PG.stream);                                         // (launch + timing events on the coder's stream)
 			LAUNCHB(ctx, n_syms * 8.0, k_range_code, ng, 64, (const triple_t*)trip.p, (const uint64_t*)PG.d_gbase.p, (const uint32_t*)PG.d_plen.p, np, PG.tmp.p, (const uint64_t*)PG.d_out_off.p, PG.d_size.p, inv_tab);
 			hipError_t e2 = hipGetLastError();
-			ctx->stream = main_stream;
 			HIP_TRY(ctx, e2);
 		}
 		E.groups.push_back(std::move(Pn));

@@ -14,7 +14,9 @@ _COMP = np.array([3, 2, 1, 0], dtype=np.uint8)
 
 
 def make_reads(seed: int, genome_len: int, target_bases: int, mean_scale: float = 20000.0,
-               sigma: float = 0.7, n_frac: float = 0.0, max_len: int = 200000) -> ReadSet:
+               sigma: float = 0.7, n_frac: float = 0.0, max_len: int = 200000, err=(0.02, 0.03, 0.02)) -> ReadSet:
+    """err: per-base (deletion, substitution, insertion) rates — the ONT-like default, or e.g. (0.001, 0.001, 0.001) for HiFi-like reads."""
+    e_del, e_sub, e_ins = err
     rng = np.random.default_rng(seed)
     genome = rng.integers(0, 4, genome_len, dtype=np.uint8)
     mu = np.log(mean_scale) - sigma * sigma
@@ -28,11 +30,11 @@ def make_reads(seed: int, genome_len: int, target_bases: int, mean_scale: float 
         if rng.random() < 0.5:
             s = _COMP[s[::-1]]
         r = rng.random(ln)
-        sub = (r >= 0.02) & (r < 0.05)
+        sub = (r >= e_del) & (r < e_del + e_sub)
         s = s.copy()
         s[sub] = (s[sub] + rng.integers(1, 4, int(sub.sum()))) % 4
-        s = s[r >= 0.02]
-        ins = np.nonzero(rng.random(len(s)) < 0.02)[0]
+        s = s[r >= e_del]
+        ins = np.nonzero(rng.random(len(s)) < e_ins)[0]
         s = np.insert(s, ins, rng.integers(0, 4, len(ins)).astype(np.uint8))
         if n_frac > 0 and rng.random() < n_frac:          # sprinkle a few N into some reads
             pos = rng.integers(0, len(s), max(1, len(s) // 2000))

@@ -373,8 +373,12 @@ cl_status cl_compressor_prepare(cl_compressor* c, const cl_reads* chunk, const u
  * thread and context of the compressor's own, one or two chunks ahead of the encode calls (~15 GB per 1-Gbase chunk ahead); the
  * caller's stream keeps model evolution and interval coding.  Announcements must start with the first chunk.  With d_quals /
  * d_base_off (those of the later encode call; null: not prepared) the same for the `qual` coder at level 1: symbols, sort by
- * context and context runs on a second preparation thread (~8 GB per 1-Gbase chunk ahead).  Bytes unchanged; other part bounds or
- * buffers at encode time are honoured (the preparation is redone). */
+ * context and context runs on a second preparation thread (~8 GB per 1-Gbase chunk ahead).  Bytes unchanged.  The announcement is
+ * BINDING while the compressor evolves ahead (long parts, mean >= 2^19 symbols, or COLORD_HIP_EVOLVE_DEPTH > 0): the adaptive models
+ * of the next chunks are then advanced from the announced bounds and quality buffer before their encode call and cannot be rolled
+ * back — an encode call with other part bounds or buffers fails with CL_E_INVALID ("the batch evolved ahead is not the one encoded
+ * next") and the compressor is unusable afterwards.  Without evolve-ahead a differing encode call is honoured (the preparation is
+ * redone). */
 cl_status cl_compressor_prepare_parts(cl_compressor* c, const cl_reads* chunk, const uint32_t* h_pack_bounds, uint32_t n_packs, const uint32_t* h_part_bounds, uint32_t n_parts,
                                       const uint8_t* d_quals, const uint64_t* d_base_off);
 /* what the archive's `meta` stream needs (compression.cpp:704-779), valid after count_finish (n_refs_total after refs_finish):

@@ -286,3 +286,63 @@ def test_cli_more_candidates_and_levels_than_this_build_holds_degrade(tmp_path):
     subprocess.check_call([CLI, "decompress", my_arc, my_out2])
     assert sha(my_out) == sha(fq) and sha(my_out2) == sha(fq)            # -q org: lossless
     assert os.path.getsize(my_arc) <= os.path.getsize(ref_arc) * 1.02   # at most a little larger than with all 20 candidates
+
+
+@pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(CLI)), reason="needs oracle/_ref/colord and colord_amd/colord_hip")
+@pytest.mark.parametrize("mode,extra,hifi", [("compress-pbhifi", [], True), ("compress-pbhifi", ["-p", "ratio"], True), ("compress-ont", ["-p", "ratio"], False),
+                                             ("compress-ont", ["-p", "balanced"], False), ("compress-pbraw", ["-p", "ratio"], False)],
+                         ids=["pbhifi_default", "pbhifi_ratio", "ont_ratio", "ont_balanced", "pbraw_ratio"])
+def test_cli_presets_at_100_mbases_equal_the_reference(tmp_path, mode, extra, hifi):
+    """The presets other than `compress-ont` default (arg_parse.cpp:89-408) at a size where the machinery of the 50-Gbase run is in play —
+    several chunks, both encode lanes, the preparation threads, the work-group / four-per-wave / wave-per-gap aligners, the wave
+    emission, 8-byte anchor slots — against the unmodified reference on the same FASTQ: HiFi (level 2, k-mer anchors of shared
+    k-mers, 5-avg qualities; reads with 0.3 % errors), `-p ratio` (level 3, c = 10, recursion to depth 6, every read a reference read),
+    `-p balanced` (level 2, sparse references), PBRaw (qualities dropped).  Every stream but `info` byte-identical; this build's
+    decompressor returns what the reference's returns."""
+    from colord_amd import ontsim
+    fq = str(tmp_path / "in.fastq")
+    if hifi:
+        rs = make_reads(seed=31, genome_len=8_000_000, target_bases=110_000_000, mean_scale=15000.0, sigma=0.25, max_len=40000, err=(0.001, 0.001, 0.001))
+        write_fastq(fq, rs)
+        n_bases = len(rs.bases)
+    else:
+        table = ontsim.ReadTable(seed=37, genome_len=6_500_000, target_bases=105_000_000)
+        n_bases = ontsim.write_fastq(table, fq)
+    assert n_bases >= 100_000_000
+    ref_arc, my_arc, ref_out, my_out = (str(tmp_path / x) for x in ("ref.colord", "gpu.colord", "ref.fastq", "gpu.fastq"))
+    subprocess.check_call([REF, mode, "-t", str(os.cpu_count() or 8)] + extra + [fq, ref_arc], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.check_call([CLI, mode, "--chunk-bases", "25000000"] + extra + [fq, my_arc])   # four or five chunks
+    _same_streams(ref_arc, my_arc)
+    assert len(AR.read_archive(my_arc)["dna"].parts) >= 20
+    subprocess.check_call([REF, "decompress", ref_arc, ref_out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.check_call([CLI, "decompress", my_arc, my_out])
+    assert sha(my_out) == sha(ref_out)
+
+
+@pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(CLI)), reason="needs oracle/_ref/colord and colord_amd/colord_hip")
+def test_cli_part_symbols_archive_is_decoded_by_the_reference(tmp_path):
+    """`--part-symbols 65536` (the cut bench.py's headline number is measured with): many more, shorter coder parts — any cut at read
+    boundaries is a valid CoLoRd archive (entr_read.h:146-191, entr_qual.h:150-170: the decoders follow the part table).  The
+    unmodified reference and this build's decompressor both return what the reference returns for its own archive; the archive is
+    at most 0.2 % larger; the default (4194304, defs.h:45) stays the reference's archive byte for byte; the indexed reader of the plain
+    FASTQ (several threads) and the sequential one give the same archive."""
+    from colord_amd import ontsim
+    table = ontsim.ReadTable(seed=43, genome_len=4_000_000, target_bases=60_000_000)
+    fq = str(tmp_path / "in.fastq")
+    ontsim.write_fastq(table, fq)
+    ref_arc, ref_out, a64, out_ref, out_own, dflt, seq = (str(tmp_path / x) for x in ("ref.colord", "ref.fastq", "p64k.colord", "p64k_ref.fastq", "p64k_own.fastq", "default.colord", "seq.colord"))
+    subprocess.check_call([REF, "compress-ont", "-t", str(os.cpu_count() or 8), fq, ref_arc], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.check_call([REF, "decompress", ref_arc, ref_out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.check_call([CLI, "compress-ont", "--chunk-bases", "20000000", "--part-symbols", "65536", fq, a64])
+    subprocess.check_call([REF, "decompress", a64, out_ref], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.check_call([CLI, "decompress", a64, out_own])
+    assert sha(out_ref) == sha(ref_out) and sha(out_own) == sha(ref_out)
+    a, b = AR.read_archive(ref_arc), AR.read_archive(a64)
+    assert len(b["dna"].parts) > 16 * len(a["dna"].parts) and len(b["qual"].parts) == len(b["dna"].parts)
+    assert os.path.getsize(a64) <= os.path.getsize(ref_arc) * 1.002
+    for name in ("header", "meta"):
+        assert [p for _, p in a[name].parts] == [p for _, p in b[name].parts]
+    subprocess.check_call([CLI, "compress-ont", "--chunk-bases", "20000000", fq, dflt])
+    _same_streams(ref_arc, dflt)
+    subprocess.check_call([CLI, "compress-ont", "--chunk-bases", "20000000", "--part-symbols", "65536", "--parse-threads", "1", fq, seq])
+    _same_streams(a64, seq)
