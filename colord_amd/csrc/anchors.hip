@@ -714,7 +714,7 @@ extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* read
 		DevBuf<uint32_t> n_distinct, next, err; DevBuf<uint64_t> toff, noff; DevBuf<EncSlot> slots; DevBuf<uint2> bins;
 		struct SideSync { hipStream_t s = nullptr; ~SideSync() { if (s) (void)hipStreamSynchronize(s); } } sync;   // destroyed first
 	};
-	if (!ctx->side) HIP_TRY(ctx, cl_stream_create(ctx, &ctx->side));
+	HIP_TRY(ctx, cl_side_stream(ctx, ctx->side));
 	auto prepare = [&](uint32_t r0, std::unique_ptr<TableBatch>& out) -> cl_status {
 		out = std::make_unique<TableBatch>();
 		TableBatch& B = *out;

@@ -14,10 +14,7 @@ extern "C" cl_status cl_ctx_create(int device, cl_ctx** out)
 	if (device < 0 || device >= n) return CL_E_INVALID;
 	if (hipSetDevice(device) != hipSuccess) return CL_E_HIP;
 	cl_ctx* c = new cl_ctx(device);
-	// all four streams exist from the start and are never reassigned while the context works: the shared pool's fences and drains
-	// (cl_ctx_fence, cl_ctx_drain) read them from other threads
-	for (hipStream_t* s : { &c->stream, &c->side, &c->side2, &c->side3 })
-		if (hipStreamCreateWithFlags(s, hipStreamNonBlocking) != hipSuccess) { cl_ctx_destroy(c); return CL_E_HIP; }
+	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { cl_ctx_destroy(c); return CL_E_HIP; }   // (never reassigned while the context works)
 	hipDeviceProp_t p;
 	if (hipGetDeviceProperties(&p, device) == hipSuccess) c->n_cu = p.multiProcessorCount;
 	*out = c;
@@ -35,12 +32,18 @@ void cl_ctx_set_priority(cl_ctx* c, int level)
 	const int prio = level > 0 ? greatest : level < 0 ? least : 0;
 	if (prio == c->prio) return;
 	c->prio = prio;
-	hipStream_t* all[4] = { &c->stream, &c->side, &c->side2, &c->side3 };
-	for (hipStream_t* s : all)
-		if (*s)
+	if (c->stream)
+	{
+		(void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); c->stream = nullptr;
+		if (cl_stream_create(c, &c->stream) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); }
+	}
+	for (std::atomic<hipStream_t>* s : { &c->side, &c->side2, &c->side3 })
+		if (hipStream_t old = s->load())
 		{
-			(void)hipStreamSynchronize(*s); (void)hipStreamDestroy(*s); *s = nullptr;
-			if (cl_stream_create(c, s) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
+			(void)hipStreamSynchronize(old); (void)hipStreamDestroy(old);
+			hipStream_t ns = nullptr;
+			if (cl_stream_create(c, &ns) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamCreateWithFlags(&ns, hipStreamNonBlocking); }
+			s->store(ns);
 		}
 }
 // every stream of the context (the shared pool calls this before it hands memory the context released to another one)
@@ -48,13 +51,13 @@ void cl_ctx_drain(cl_ctx* c)
 {
 	if (!c) return;
 	(void)hipSetDevice(c->device);
-	for (hipStream_t s : { c->stream, c->side, c->side2, c->side3 }) if (s) (void)hipStreamSynchronize(s);
+	for (hipStream_t s : { c->stream, c->side.load(std::memory_order_acquire), c->side2.load(std::memory_order_acquire), c->side3.load(std::memory_order_acquire) }) if (s) (void)hipStreamSynchronize(s);
 }
 int cl_ctx_fence(cl_ctx* c, hipEvent_t* ev)
 {
 	if (!c) return 0;
 	int n = 0;
-	for (hipStream_t s : { c->stream, c->side, c->side2, c->side3 }) if (s && n < 4) { if (hipEventRecord(ev[n], s) == hipSuccess) ++n; else (void)hipGetLastError(); }
+	for (hipStream_t s : { c->stream, c->side.load(std::memory_order_acquire), c->side2.load(std::memory_order_acquire), c->side3.load(std::memory_order_acquire) }) if (s && n < 4) { if (hipEventRecord(ev[n], s) == hipSuccess) ++n; else (void)hipGetLastError(); }
 	return n;
 }
 extern "C" void cl_ctx_destroy(cl_ctx* c)
@@ -72,9 +75,7 @@ extern "C" void cl_ctx_destroy(cl_ctx* c)
 	for (auto& p : c->pending) { (void)hipEventDestroy(p.second.first); (void)hipEventDestroy(p.second.second); }
 	for (auto e : c->ev_pool) (void)hipEventDestroy(e);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
-	if (c->side) (void)hipStreamDestroy(c->side);
-	if (c->side2) (void)hipStreamDestroy(c->side2);
-	if (c->side3) (void)hipStreamDestroy(c->side3);
+	for (std::atomic<hipStream_t>* s : { &c->side, &c->side2, &c->side3 }) if (hipStream_t x = s->load()) (void)hipStreamDestroy(x);
 	if (c->inv_tab) (void)hipFree(c->inv_tab);
 	const int dev = c->device;
 	delete c;

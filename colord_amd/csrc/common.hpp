@@ -17,6 +17,7 @@
 #include <map>
 #include <deque>
 #include <mutex>
+#include <atomic>
 #include <condition_variable>
 #include <thread>
 #include <chrono>
@@ -312,9 +313,12 @@ struct cl_ctx {
 	hipStream_t stream = nullptr;                // the context's main stream; never reassigned while the context works (the pool's fences and drains read it from other threads)
 	hipStream_t launch = nullptr;                // owner thread only: where LAUNCH and its timing events go while a stage works on a side / coder stream (null: `stream`)
 	int prio = 0;                                // priority of this context's streams (cl_ctx_set_priority; 0 = the runtime's default)
-	hipStream_t side = nullptr;                  // second stream for chains that would leave the machine idle (created on first use)
-	hipStream_t side2 = nullptr;                 // third stream: the four-per-wave aligner next to the tail-bound wave-per-gap one
-	hipStream_t side3 = nullptr;                 // fourth stream: the work-group-per-gap aligner of the giant gaps
+	// further streams, created by the owner thread at first use (a stream that exists takes its turn on the runtime's hardware queues
+	// whether it is used or not: created eagerly for every context they cost the 50-Gbase pass 25 %) and read by the shared pool's
+	// fences and drains from other threads: atomic pointers, set once
+	std::atomic<hipStream_t> side{ nullptr };     // second stream for chains that would leave the machine idle
+	std::atomic<hipStream_t> side2{ nullptr };    // third stream: the four-per-wave aligner next to the tail-bound wave-per-gap one
+	std::atomic<hipStream_t> side3{ nullptr };    // fourth stream: the giant gaps
 	std::string err;
 	bool timing = false;
 	std::map<std::string, KernelTime> times;     // per-kernel accumulated HIP-event time of the last API call
@@ -401,6 +405,15 @@ struct KernelTimer {
 	hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (shm), cl_launch_stream(ctx), __VA_ARGS__); } while (0)
 // a further stream of the context, at the context's priority
 static inline hipError_t cl_stream_create(cl_ctx* c, hipStream_t* s) { return c->prio ? hipStreamCreateWithPriority(s, hipStreamNonBlocking, c->prio) : hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
+// ... one of the context's side streams, created at first use (owner thread)
+static inline hipError_t cl_side_stream(cl_ctx* c, std::atomic<hipStream_t>& slot)
+{
+	if (slot.load(std::memory_order_acquire)) return hipSuccess;
+	hipStream_t s = nullptr;
+	const hipError_t e = cl_stream_create(c, &s);
+	if (e == hipSuccess) slot.store(s, std::memory_order_release);
+	return e;
+}
 static inline void cl_timing_begin(cl_ctx*) {}   // times accumulate until cl_ctx_kernel_times reports them
 // Adds what has COMPLETED to the kernel times (wait = true: everything; cl_ctx_kernel_times).  Never a wait by default: the events
 // of an interval coder that is still running for the next batch (cl_dna_evolve_ahead) stay pending — waiting for them here, at

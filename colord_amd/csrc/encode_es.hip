@@ -10,7 +10,7 @@
 #include "objects.hpp"
 #include "encode_core.hpp"
 #include "align_wave.hpp"
-#include "align_team.hpp"
+#include "align_giant.hpp"
 #include "emit_wave.hpp"
 #include <algorithm>
 #include <memory>
@@ -84,10 +84,13 @@ __global__ void k_gap_offsets(GapRec* __restrict__ gaps, const uint64_t* __restr
 	const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
 	if (gi < n) gaps[gi].es_off = es_off[gi];
 }
-__global__ void k_class_bounds(const uint32_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ bounds /* N_CLASSES + 1 */)
+// bounds[N_CLASSES + 1], [N_CLASSES + 2]: over the giant gaps (class 7) the sum of their script capacities (reference + read symbols)
+// in units of 256 and the largest one — what the host sizes their heap and the number of their phases by (zeroed by the caller)
+__global__ void k_class_bounds(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ ids, const uint32_t* __restrict__ cap, uint32_t n, uint32_t* __restrict__ bounds /* N_CLASSES + 3 */)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i > n) return;
+	if (i < n && (keys[i] >> 17) == 7) { const uint32_t c = cap[ids[i]]; atomicAdd(&bounds[N_CLASSES + 1], (c + 255) / 256); atomicMax(&bounds[N_CLASSES + 2], c); }
 	const uint32_t a = i == 0 ? 0u : (keys[i - 1] >> 17) + 1, b = i == n ? N_CLASSES + 1 : (keys[i] >> 17) + 1;   // classes [a, b) start at i
 	for (uint32_t c = a; c < b && c <= N_CLASSES; ++c) bounds[c] = i;
 }
@@ -437,92 +440,182 @@ __global__ __launch_bounds__(64) void k_align_wave(const uint32_t* __restrict__ 
 	pool.beat(9);
 }
 
-// giant gaps: one WORK-GROUP per gap (align_team.hpp): the tiles of a sweep as a pipeline over the waves, the sub-problems of a
-// Hirschberg level side by side.  Same steps as align_wave_gap; what fails here (pool, more than 64 tiles) goes to `redo`.
-__device__ inline bool align_team_gap(wt::Team& T, GapRec& g, const ArenaV& A, const ArenaV& R, char* dst)
+// giant gaps: MANY waves per gap (align_giant.hpp): phases of tile jobs over all giants of the level — score sweeps, then Hirschberg
+// level by level —, then the leaves' tracebacks, then operations -> canonical script per gap.  What fails (capacities, heap, a
+// hand-over that never came) goes to `redo` and the wave-per-gap kernel.
+__global__ __launch_bounds__(256) void k_giant_stage(gt::View V, const uint32_t* __restrict__ list, const GapRec* __restrict__ gaps, ArenaV A, ArenaV R)
 {
-	const uint32_t lane = threadIdx.x & 63, tid = threadIdx.x;
-	g.es_len = 0; g.d_before = 0;
-	WaveGap W;
-	wv::WavePool& pool = T.shared;
-	const uint32_t ref_id = g.ref_rev & 0x7fffffffu; const bool rev = g.ref_rev >> 31;
-	const uint64_t rwb = R.word_off[ref_id], ewb = A.word_off[g.read]; const uint32_t rlen = R.lens[ref_id];
+	__shared__ gt::Giant sg;
+	const uint32_t gidx = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+	const GapRec g = gaps[list[V.n_giants - 1 - gidx]];                       // ascending by work: largest first
 	const bool left = g.left != 0;
-	W.left = left;
-	W.rbuf = (uint8_t*)pool.alloc(g.use + 64ull); W.ebuf = (uint8_t*)pool.alloc(g.ne + 64ull);
-	W.r2 = (uint8_t*)pool.alloc(g.use + 64ull); W.e2 = (uint8_t*)pool.alloc(g.ne + 64ull);
-	W.opsbuf = (uint8_t*)pool.alloc((uint64_t)g.use + g.ne + 64);
-	uint8_t* sparse = (uint8_t*)pool.alloc((uint64_t)g.use + g.ne + 64);
-	if (pool.overflow) return false;
-	const uint32_t lo = left ? g.nr - g.use : 0;
-	for (uint32_t i = tid; i < g.use; i += 64 * wt::TW) { const uint8_t v = (uint8_t)ref_sym(R, rwb, rlen, rev, g.cur_ref + lo + i); W.rbuf[i] = v; W.r2[left ? g.use - 1 - i : i] = v; }
-	for (uint32_t i = tid; i < g.ne; i += 64 * wt::TW) { const uint8_t v = (uint8_t)arena_base_at(A, ewb, g.enc_start + i); W.ebuf[i] = v; W.e2[left ? g.ne - 1 - i : i] = v; }
-	if (g.kind == GK_INNER) { W.Q = W.rbuf; W.n = g.nr; W.T = W.ebuf; W.m = g.ne; W.rows_ref = true; W.shw = false; }
-	else if (g.kind == GK_FLANK_TINY) { W.Q = W.r2; W.n = g.use; W.T = W.e2; W.m = g.ne; W.rows_ref = true; W.shw = false; }
-	else { W.Q = W.e2; W.n = g.ne; W.T = W.r2; W.m = g.use; W.rows_ref = false; W.shw = true; }
-	T.barrier();
-	// score (and, for a flank, where the alignment ends in the reference) by the whole team
-	const uint32_t n = W.n, mc = W.m;
-	const uint32_t ne = wv::sat_rows(W.Q, 1, n, W.T, 1, mc);
-	uint32_t score = n - mc, best = n - mc; int32_t end = (int32_t)mc - 1;
-	if (ne == n)
+	if (w == 0)
 	{
-		const uint32_t tiles = ((ne + 63) / 64 + 63) / 64;
-		const uint64_t mk = pool.mark();
-		int8_t* hb = (int8_t*)pool.alloc((uint64_t)tiles * (mc + 64));
-		if (pool.overflow || tiles > wt::MAX_TILES) return false;
-		for (uint32_t x = tid; x < 2 * wt::MAX_TILES; x += 64 * wt::TW) T.lds->prog[x] = 0;
-		T.barrier();
-		wt::team_sweep(T, 0, wt::TW, W.Q, 1, n, ne, W.T, 1, mc, W.shw, nullptr, nullptr, hb, T.lds->prog, true);
-		T.barrier();
-		score = T.lds->res[0]; best = T.lds->res[1]; end = (int32_t)T.lds->res[2];
-		T.barrier();
-		pool.release(mk);
+		uint8_t* rbuf = gt::galloc(V, g.use + 64ull); uint8_t* ebuf = gt::galloc(V, g.ne + 64ull);
+		uint8_t* r2 = gt::galloc(V, g.use + 64ull); uint8_t* e2 = gt::galloc(V, g.ne + 64ull);
+		uint8_t* opsbuf = gt::galloc(V, (uint64_t)g.use + g.ne + 64); uint8_t* sparse = gt::galloc(V, (uint64_t)g.use + g.ne + 64);
+		if (lane == 0)
+		{
+			gt::Giant G; memset(&G, 0, sizeof(G));
+			G.gi = list[V.n_giants - 1 - gidx]; G.kind = g.kind; G.left = left ? 1u : 0u;
+			G.fail = (rbuf && ebuf && r2 && e2 && opsbuf && sparse) ? 0u : 12u;
+			G.rbuf = rbuf; G.ebuf = ebuf; G.r2 = r2; G.e2 = e2; G.opsbuf = opsbuf; G.sparse = sparse;
+			if (g.kind == GK_INNER) { G.Q = rbuf; G.n = g.nr; G.T = ebuf; G.m = g.ne; G.rows_ref = 1; G.shw = 0; }
+			else if (g.kind == GK_FLANK_TINY) { G.Q = r2; G.n = g.use; G.T = e2; G.m = g.ne; G.rows_ref = 1; G.shw = 0; G.ref_end_nw = g.use - 1; }
+			else { G.Q = e2; G.n = g.ne; G.T = r2; G.m = g.use; G.rows_ref = 0; G.shw = 1; }
+			sg = G;
+		}
 	}
-	wv::Ops ops{ W.opsbuf, 0 };
-	uint32_t ref_end = 0;
-	bool ok;
-	if (!W.shw) { if (g.kind == GK_FLANK_TINY) ref_end = g.use - 1; ok = wt::team_path(T, W.Q, n, W.T, mc, score, sparse, ops); }
-	else { ref_end = (uint32_t)end; ok = wt::team_path(T, W.Q, n, W.T, (uint32_t)(end + 1), best, sparse, ops); }
-	if (!ok) return false;
-	if (T.w == 0)
+	__syncthreads();
+	if (sg.fail) { if (tid == 0) V.giants[gidx] = sg; return; }
 	{
-		T.own.top = 0; T.own.overflow = false;
-		const bool fin = wave_gap_finish(T.own, g, W, ops, ref_end, dst, 0);
-		if (lane == 0) T.lds->fail = fin ? 0u : 5u;
+		const uint32_t ref_id = g.ref_rev & 0x7fffffffu; const bool rev = g.ref_rev >> 31;
+		const uint64_t rwb = R.word_off[ref_id], ewb = A.word_off[g.read]; const uint32_t rlen = R.lens[ref_id];
+		const uint32_t lo = left ? g.nr - g.use : 0;
+		for (uint32_t i = tid; i < g.use; i += 256) { const uint8_t v = (uint8_t)ref_sym(R, rwb, rlen, rev, g.cur_ref + lo + i); sg.rbuf[i] = v; sg.r2[left ? g.use - 1 - i : i] = v; }
+		for (uint32_t i = tid; i < g.ne; i += 256) { const uint8_t v = (uint8_t)arena_base_at(A, ewb, g.enc_start + i); sg.ebuf[i] = v; sg.e2[left ? g.ne - 1 - i : i] = v; }
+		for (uint64_t x = tid; x < (uint64_t)g.use + g.ne; x += 256) sg.sparse[x] = 0xff;
 	}
-	T.barrier();
-	const bool done = T.lds->fail == 0;
-	T.barrier();
-	return done;
+	__syncthreads();
+	if (w != 0) return;
+	if (lane == 0) V.giants[gidx] = sg;
+	__builtin_amdgcn_s_waitcnt(0);
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	// the score (and, for a flank, where the alignment ends in the reference): a sweep of phase 0 — or closed form when the rows saturate
+	const uint32_t n = sg.n, mc = sg.m;
+	const uint32_t ne = wv::sat_rows(sg.Q, 1, n, sg.T, 1, mc);
+	if (ne < n)
+	{
+		const uint32_t mp = mc, ref_end = sg.shw ? mc - 1 : sg.ref_end_nw;        // D[n][j] = n - j falls strictly: the first minimum is the last column
+		if (lane == 0) { V.giants[gidx].mp = mp; V.giants[gidx].ref_end = ref_end; }
+		gt::emit_sub(V, gidx, 0, n, 0, mp, n - mc, 1);
+		return;
+	}
+	const uint32_t tiles = ((ne + 63) / 64 + 63) / 64, chunks = (mc + 63) / 64;
+	unsigned long long* hand = tiles > 1 ? (unsigned long long*)gt::galloc(V, (uint64_t)(tiles - 1) * chunks * 16) : nullptr;
+	const uint32_t f0 = gt::take(&V.ctl->n_flags, tiles - 1);
+	const uint32_t ni = gt::take(&V.ctl->n_nodes[0], 1), si = gt::take(&V.ctl->n_sweeps[0], 1), ji = gt::take(&V.ctl->n_jobs[0], tiles);
+	if ((tiles > 1 && !hand) || f0 + tiles - 1 > gt::FLAG_CAP || ni >= gt::NODE_CAP || si >= 2 * gt::NODE_CAP || ji + tiles > gt::JOB_CAP)
+	{
+		for (uint32_t x = lane; x < tiles; x += 64) if (ji + x < gt::JOB_CAP) V.jobs[0][ji + x] = gt::Job{ 0xffffffffu, 0 };
+		gt::giant_fail(V, gidx, 13);
+		return;
+	}
+	if (lane == 0)
+	{
+		V.nodes[0][ni] = gt::Node{ gidx, 0, n, 0, mc, 0, 0, 0, 0, 0, nullptr, nullptr, tiles, si };
+		V.sweeps[0][si] = gt::Sweep{ sg.Q, sg.T, 1, 1, n, ne, mc, sg.shw, nullptr, hand, V.flags + f0, tiles, ni, 0, 0, 0, 0 };
+	}
+	for (uint32_t x = lane; x < tiles; x += 64) V.jobs[0][ji + x] = gt::Job{ si, x };
 }
-__global__ __launch_bounds__(64 * wt::TW) void k_align_team(const uint32_t* __restrict__ list, uint32_t n_list, GapRec* __restrict__ gaps, char* __restrict__ es_pool, ArenaV A, ArenaV R,
-                                                           uint8_t* __restrict__ scratch, uint64_t per_team, uint64_t own_bytes, unsigned int* __restrict__ next, uint32_t* __restrict__ redo, unsigned int* __restrict__ n_redo)
+__global__ __launch_bounds__(64) void k_giant_level(gt::View V, uint32_t ph)
 {
 	__builtin_amdgcn_s_setprio(3);
-	__shared__ wt::TeamLds lds;
-	wt::Team T;
-	T.w = threadIdx.x >> 6; T.lds = &lds;
-	uint8_t* base = scratch + (uint64_t)blockIdx.x * per_team;
-	T.own = wv::WavePool{ base + (uint64_t)T.w * own_bytes, own_bytes, 0, false, nullptr };
-	T.shared = wv::WavePool{ base + (uint64_t)wt::TW * own_bytes, per_team - (uint64_t)wt::TW * own_bytes, 0, false, nullptr };
+	const uint32_t lane = threadIdx.x;
+	const uint32_t n_jobs = V.ctl->n_jobs[ph] < gt::JOB_CAP ? V.ctl->n_jobs[ph] : gt::JOB_CAP;
 	for (;;)
 	{
-		if (threadIdx.x == 0) lds.gap = atomicAdd(next, 1u);
-		__syncthreads();
-		const uint32_t slot = lds.gap;
-		__syncthreads();
-		if (slot >= n_list) break;
-		const uint32_t gi = list[n_list - 1 - slot];                            // ascending by work: largest first
-		T.shared.top = 0; T.shared.overflow = false; T.own.top = 0; T.own.overflow = false;
-		GapRec g = gaps[gi];
-		const bool ok = align_team_gap(T, g, A, R, es_pool + g.es_off);
-		if (threadIdx.x == 0)
+		const uint32_t ticket = gt::take(&V.ctl->ticket[ph], 1);
+		if (ticket >= n_jobs) break;
+		const gt::Job jb = V.jobs[ph & 1][ticket];
+		if (jb.sweep == 0xffffffffu) continue;
+		gt::Sweep* S = &V.sweeps[ph & 1][jb.sweep];
+		gt::Node* N = &V.nodes[ph & 1][S->node];
+		const uint32_t giant = N->giant;
+		if (!gt::giant_tile(S, jb.tile)) gt::giant_fail(V, giant, 14);
+		// the node's last tile splits it: what the other tiles wrote (their parts of the last columns, the sweep's result) is released
+		// before the count-down and acquired after it
+		__threadfence();
+		uint32_t left = 1;
+		if (lane == 0) left = atomicSub(&N->pending, 1u) - 1;
+		left = wv::bcast_first(left);
+		if (left) continue;
+		__threadfence();
+		if (V.giants[giant].fail) continue;
+		if (ph == 0)
 		{
-			if (ok) { gaps[gi].es_len = g.es_len; gaps[gi].d_before = g.d_before; }
-			else redo[atomicAdd(n_redo, 1u)] = gi;
+			const gt::Giant& G = V.giants[giant];
+			const uint32_t score = wv::bcast_first(S->score), best = wv::bcast_first(S->best); const int32_t end = (int32_t)wv::bcast_first((uint32_t)S->end);
+			const uint32_t mp = G.shw ? (uint32_t)(end + 1) : G.m, ref_end = G.shw ? (uint32_t)end : G.ref_end_nw;
+			if (lane == 0) { V.giants[giant].mp = mp; V.giants[giant].ref_end = ref_end; }
+			gt::emit_sub(V, giant, 0, G.n, 0, mp, G.shw ? best : score, 1);
 		}
-		__syncthreads();
+		else
+		{
+			const gt::Node nd = *N;
+			uint32_t ls = 0, rs = 0;
+			const int64_t found = wv::hirschberg_split(nd.left, nd.neL, nd.L, nd.right, nd.neR, nd.R, nd.n, nd.best, ls, rs);
+			if (found < 0) { gt::giant_fail(V, giant, 15); continue; }
+			gt::emit_sub(V, giant, nd.qo, (uint32_t)found, nd.to, nd.L, ls, ph + 1);
+			gt::emit_sub(V, giant, nd.qo + (uint32_t)found, nd.n - (uint32_t)found, nd.to + nd.L, nd.R, rs, ph + 1);
+		}
+	}
+}
+__global__ __launch_bounds__(64) void k_giant_leaves(gt::View V, uint8_t* __restrict__ scratch, uint64_t per_wave)
+{
+	__builtin_amdgcn_s_setprio(3);
+	wv::WavePool pool{ scratch + (uint64_t)blockIdx.x * per_wave, per_wave, 0, false, nullptr };
+	const uint32_t lane = threadIdx.x;
+	const uint32_t n_leaves = V.ctl->n_leaves < gt::LEAF_CAP ? V.ctl->n_leaves : gt::LEAF_CAP;
+	for (;;)
+	{
+		const uint32_t ticket = gt::take(&V.ctl->leaf_ticket, 1);
+		if (ticket >= n_leaves) break;
+		const gt::Leaf lf = V.leaves[ticket];
+		const gt::Giant& G = V.giants[lf.giant];
+		if (G.fail) continue;
+		uint8_t* dst = G.sparse + lf.qo + lf.to;                                // sub-problems tile the alignment in this order; n x m symbols give at most n + m operations
+		if (lf.n == 0 || lf.m == 0)
+		{
+			const uint8_t op = lf.n == 0 ? 2 : 1;
+			for (uint64_t x = lane; x < (uint64_t)lf.n + lf.m; x += 64) dst[x] = op;
+			continue;
+		}
+		pool.top = 0; pool.overflow = false;
+		wv::Ops o{ dst, 0 };
+		wv::wave_traceback(pool, G.Q + lf.qo, lf.n, G.T + lf.to, lf.m, o);
+		if (pool.overflow) gt::giant_fail(V, lf.giant, 16);
+	}
+}
+__global__ __launch_bounds__(64) void k_giant_finish(gt::View V, GapRec* __restrict__ gaps, char* __restrict__ es_pool, uint8_t* __restrict__ scratch, uint64_t per_wave,
+                                                    unsigned int* __restrict__ next, uint32_t* __restrict__ redo, unsigned int* __restrict__ n_redo)
+{
+	__builtin_amdgcn_s_setprio(3);
+	wv::WavePool pool{ scratch + (uint64_t)blockIdx.x * per_wave, per_wave, 0, false, nullptr };
+	const uint32_t lane = threadIdx.x;
+	for (;;)
+	{
+		const uint32_t gidx = gt::take(next, 1);
+		if (gidx >= V.n_giants) break;
+		const gt::Giant G = V.giants[gidx];
+		bool done = false;
+		GapRec g = gaps[G.gi];
+		if (!G.fail)
+		{	// the sparse buffer -> the operations, in order (a chunk of 64 at a time, the offset carried along)
+			const uint64_t span = (uint64_t)G.n + G.mp;
+			uint64_t off = 0;
+			for (uint64_t x0 = 0; x0 < span; x0 += 64)
+			{
+				const uint64_t x = x0 + lane;
+				const uint8_t v = x < span ? G.sparse[x] : (uint8_t)0xff;
+				const uint64_t bal = __ballot(v != 0xff);
+				if (v != 0xff) G.opsbuf[off + (uint32_t)__popcll(bal & ((1ull << lane) - 1))] = v;
+				off += (uint32_t)__popcll(bal);
+			}
+			__builtin_amdgcn_s_waitcnt(0);
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+			WaveGap W; W.rbuf = G.rbuf; W.ebuf = G.ebuf; W.r2 = G.r2; W.e2 = G.e2; W.opsbuf = G.opsbuf; W.Q = G.Q; W.T = G.T; W.n = G.n; W.m = G.m;
+			W.rows_ref = G.rows_ref != 0; W.shw = G.shw != 0; W.left = G.left != 0;
+			wv::Ops ops{ G.opsbuf, off };
+			pool.top = 0; pool.overflow = false;
+			g.es_len = 0; g.d_before = 0;
+			done = wave_gap_finish(pool, g, W, ops, G.ref_end, es_pool + g.es_off, 0);
+		}
+		if (lane == 0)
+		{
+			if (done) { gaps[G.gi].es_len = g.es_len; gaps[G.gi].d_before = g.d_before; }
+			else redo[atomicAdd(n_redo, 1u)] = G.gi;
+		}
 	}
 }
 
@@ -965,11 +1058,12 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 		V = L.view();
 		// size classes
 		CL_TRY(dev_sort_keys32_pairs(ctx, keys.p, ids.p, ng, 0, KEY_BITS));
-		DevBuf<uint32_t> bounds; DEV_ALLOC(ctx, bounds, N_CLASSES + 1);
-		LAUNCH(ctx, k_class_bounds, grid_for(ng + 1, 256), 256, (const uint32_t*)keys.p, L.n_gaps, bounds.p);
-		uint32_t hb[N_CLASSES + 1];
+		DevBuf<uint32_t> bounds; DEV_ALLOC(ctx, bounds, N_CLASSES + 3);
+		HIP_TRY(ctx, hipMemsetAsync(bounds.p + N_CLASSES + 1, 0, 8, st));
+		LAUNCH(ctx, k_class_bounds, grid_for(ng + 1, 256), 256, (const uint32_t*)keys.p, (const uint32_t*)ids.p, (const uint32_t*)capw.p, L.n_gaps, bounds.p);
+		uint32_t hb[N_CLASSES + 3];
 		unsigned long long h_cb[N_CLASSES] = { 0 };
-		HIP_TRY(ctx, hipMemcpyAsync(hb, bounds.p, 4 * (N_CLASSES + 1), hipMemcpyDeviceToHost, st));
+		HIP_TRY(ctx, hipMemcpyAsync(hb, bounds.p, 4 * (N_CLASSES + 3), hipMemcpyDeviceToHost, st));
 		if (ctx->timing)
 		{
 			DevBuf<unsigned long long> cb; DEV_ALLOC(ctx, cb, N_CLASSES);
@@ -980,7 +1074,7 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 		HIP_TRY(ctx, hipStreamSynchronize(st));
 		// small gaps: on the side stream, next to the large ones on the main stream (one wave per SIMD with its state in
 		// LDS here, five waves per SIMD on a bump pool in HBM there: they share the machine well)
-		if (!ctx->side) HIP_TRY(ctx, cl_stream_create(ctx, &ctx->side));
+		HIP_TRY(ctx, cl_side_stream(ctx, ctx->side));
 		struct SideJoin { hipStream_t s; ~SideJoin() { (void)hipStreamSynchronize(s); } };
 		DevBuf<uint64_t> hist;
 		SideJoin side_join{ ctx->side };                                         // (after hist in destruction order: joins first)
@@ -1023,30 +1117,48 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 			DEV_ALLOC(ctx, quad_scratch, per_wave * waves);
 			DEV_ALLOC(ctx, qc, 2);
 			DEV_ALLOC(ctx, quad_redo, (uint64_t)n_list + 1);
-			if (!ctx->side2) HIP_TRY(ctx, cl_stream_create(ctx, &ctx->side2));
+			HIP_TRY(ctx, cl_side_stream(ctx, ctx->side2));
 			quad_join.s = ctx->side2;
 			HIP_TRY(ctx, hipMemsetAsync(qc.p, 0, 8, ctx->side2));
 			LaunchOn on(ctx, ctx->side2);                                         // (launch + timing events on the third stream)
 			LAUNCHB(ctx, 1.25 * (double)h_cb[5], k_align_quad, waves, 64, (const uint32_t*)ids.p + hb[5], n_list, L.gaps.p, L.es.p, A, R, quad_scratch.p, per_wave, qc.p, quad_redo.p, qc.p + 1);
 			HIP_TRY(ctx, hipGetLastError());
 		}
-		// giant gaps: a work-group each, on a stream of their own, started before the wave-per-gap kernel (they are its former tail)
+		// giant gaps: many waves each (align_giant.hpp), on a stream of their own from the start of the level, next to everything else
 		DevBuf<uint32_t> team_redo; uint32_t n_team_redo = 0;
-		DevBuf<uint8_t> team_scratch; DevBuf<unsigned int> tc;
+		DevBuf<uint8_t> giant_mem, giant_heap, giant_scratch; DevBuf<unsigned int> tc;
 		Side2Join team_join;
 		if (hb[8] > hb[7] && !getenv("COLORD_HIP_NO_TEAM_ALIGN"))
 		{
 			const uint32_t n_list = hb[8] - hb[7];
-			const uint64_t own_bytes = 3ull << 20, per_team = wt::TW * own_bytes + (40ull << 20);
-			const uint32_t teams = std::min<uint32_t>(n_list, 32);
-			DEV_ALLOC(ctx, team_scratch, per_team * teams);
+			const uint64_t sum_cap = (uint64_t)hb[N_CLASSES + 1] * 256, max_cap = hb[N_CLASSES + 2];
+			// sequences (4 copies), operations, sparse operations: 6 x (reference + read symbols) per gap; the last columns of a Hirschberg
+			// level: 8 bytes per row and level, the hand-over pairs 2 bits per column and tile
+			const uint64_t heap_bytes = std::min<uint64_t>(6ull << 30, (64ull << 20) + 100 * sum_cap + (uint64_t)n_list * 4096);
+			uint32_t phases = 2; for (uint64_t c = max_cap; c > 8 && phases < gt::MAX_PHASES; c >>= 1) ++phases;     // the columns halve per level; below ~16 everything is a leaf
+			auto al = [](uint64_t x) { return (x + 255) & ~255ull; };
+			const uint64_t o_ctl = 0, o_flags = al(sizeof(gt::Ctl)), o_nodes = o_flags + al(4ull * gt::FLAG_CAP), o_sweeps = o_nodes + 2 * al(sizeof(gt::Node) * gt::NODE_CAP),
+				o_jobs = o_sweeps + 2 * al(sizeof(gt::Sweep) * 2 * gt::NODE_CAP), o_leaves = o_jobs + 2 * al(sizeof(gt::Job) * gt::JOB_CAP), o_giants = o_leaves + al(sizeof(gt::Leaf) * gt::LEAF_CAP),
+				o_end = o_giants + al(sizeof(gt::Giant) * n_list);
+			DEV_ALLOC(ctx, giant_mem, o_end); DEV_ALLOC(ctx, giant_heap, heap_bytes);
+			const uint32_t leaf_waves = 256; const uint64_t per_wave = 3ull << 20;     // a leaf's history is < 1 MiB twice over, + the reversed operations
+			const uint32_t fin_waves = std::min<uint32_t>(n_list, 64); const uint64_t fin_per_wave = (per_wave * leaf_waves) / 64;   // 12 MB: the canonicalisation's 9 bytes per script symbol
+			DEV_ALLOC(ctx, giant_scratch, per_wave * leaf_waves);
 			DEV_ALLOC(ctx, tc, 2);
 			DEV_ALLOC(ctx, team_redo, (uint64_t)n_list + 1);
-			if (!ctx->side3) HIP_TRY(ctx, cl_stream_create(ctx, &ctx->side3));
+			HIP_TRY(ctx, cl_side_stream(ctx, ctx->side3));
 			team_join.s = ctx->side3;
 			HIP_TRY(ctx, hipMemsetAsync(tc.p, 0, 8, ctx->side3));
+			HIP_TRY(ctx, hipMemsetAsync(giant_mem.p, 0, o_nodes, ctx->side3));       // the control block and the progress words
+			gt::View V; V.ctl = (gt::Ctl*)(giant_mem.p + o_ctl); V.heap = giant_heap.p; V.heap_bytes = heap_bytes; V.flags = (uint32_t*)(giant_mem.p + o_flags);
+			for (int i = 0; i < 2; ++i) { V.nodes[i] = (gt::Node*)(giant_mem.p + o_nodes + i * al(sizeof(gt::Node) * gt::NODE_CAP)); V.sweeps[i] = (gt::Sweep*)(giant_mem.p + o_sweeps + i * al(sizeof(gt::Sweep) * 2 * gt::NODE_CAP));
+				V.jobs[i] = (gt::Job*)(giant_mem.p + o_jobs + i * al(sizeof(gt::Job) * gt::JOB_CAP)); }
+			V.leaves = (gt::Leaf*)(giant_mem.p + o_leaves); V.giants = (gt::Giant*)(giant_mem.p + o_giants); V.n_giants = n_list;
 			LaunchOn on(ctx, ctx->side3);
-			LAUNCHB(ctx, 1.25 * (double)h_cb[7], k_align_team, teams, 64 * wt::TW, (const uint32_t*)ids.p + hb[7], n_list, L.gaps.p, L.es.p, A, R, team_scratch.p, per_team, own_bytes, tc.p, team_redo.p, tc.p + 1);
+			LAUNCHB(ctx, 1.25 * (double)h_cb[7], k_giant_stage, n_list, 256, V, (const uint32_t*)ids.p + hb[7], (const GapRec*)L.gaps.p, A, R);
+			for (uint32_t ph = 0; ph < phases; ++ph) LAUNCH(ctx, k_giant_level, 1024, 64, V, ph);
+			LAUNCH(ctx, k_giant_leaves, leaf_waves, 64, V, giant_scratch.p, per_wave);
+			LAUNCH(ctx, k_giant_finish, fin_waves, 64, V, L.gaps.p, L.es.p, giant_scratch.p, fin_per_wave, tc.p, team_redo.p, tc.p + 1);
 			HIP_TRY(ctx, hipGetLastError());
 		}
 		// large gaps, in rounds of growing lane pools
@@ -1146,7 +1258,7 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 			HIP_TRY(ctx, hipStreamSynchronize(ctx->side3));
 			team_join.s = nullptr;
 			n_team_redo = hc[1];
-			if (getenv("COLORD_HIP_GAP_DEBUG")) fprintf(stderr, "[gaps] level %u: %u giant gaps by teams, %u back to the wave kernel\n", lv, hb[8] - hb[7], n_team_redo);
+			if (getenv("COLORD_HIP_GAP_DEBUG")) fprintf(stderr, "[gaps] level %u: %u giant gaps by tile jobs (largest script %u symbols), %u back to the wave kernel\n", lv, hb[8] - hb[7], hb[N_CLASSES + 2], n_team_redo);
 		}
 		else if (hb[8] > hb[7]) CL_TRY(run_large(ids.p + hb[7], hb[8] - hb[7], 1.25 * (double)h_cb[7]));   // (COLORD_HIP_NO_TEAM_ALIGN)
 		if (n_team_redo) CL_TRY(run_large(team_redo.p, n_team_redo, 0.0));

@@ -48,3 +48,46 @@ def make_reads(seed: int, genome_len: int, target_bases: int, mean_scale: float 
     lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=len(seqs))
     offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     return ReadSet(np.concatenate(seqs), offsets, np.concatenate(quals), headers, [False] * n, True)
+
+
+def make_giant_gap_reads(seed: int, n_backbones: int = 6, backbone_len: int = 120_000, coverage: int = 22, n_chimeras: int = 24,
+                         junk=(30_000, 60_000), err=(0.02, 0.03, 0.02)) -> ReadSet:
+    """Reads that make the edit-script encoder align GIANT gaps (tens of thousands of symbols on both sides), which random sampling
+    of a genome yields only a few times per Gbase: `n_backbones` regions of a random genome, each covered `coverage` times by reads of
+    nearly the whole region (so their k-mers pass the count filter and the early ones become reference reads with long tails), then
+    CHIMERAS — 15-25 kb of a region, a stretch of unrelated sequence as long as `junk`, and for every other one 15 kb from further
+    right in the region: an inner gap (unrelated x the reference's own stretch) or a flank (unrelated x the reference's tail)."""
+    rng = np.random.default_rng(seed)
+    e_del, e_sub, e_ins = err
+    genome = rng.integers(0, 4, n_backbones * (backbone_len + 50_000), dtype=np.uint8)
+
+    def noisy(s):
+        r = rng.random(len(s))
+        s = s.copy()
+        sub = (r >= e_del) & (r < e_del + e_sub)
+        s[sub] = (s[sub] + rng.integers(1, 4, int(sub.sum()))) % 4
+        s = s[r >= e_del]
+        ins = np.nonzero(rng.random(len(s)) < e_ins)[0]
+        return np.insert(s, ins, rng.integers(0, 4, len(ins)).astype(np.uint8))
+
+    seqs = []
+    for b in range(n_backbones):
+        base = b * (backbone_len + 50_000)
+        for c in range(coverage):
+            st = base + int(rng.integers(0, 20_000)); ln = backbone_len - int(rng.integers(0, 30_000))
+            s = noisy(genome[st:st + ln])
+            seqs.append(_COMP[s[::-1]] if rng.random() < 0.5 else s)
+    for c in range(n_chimeras):
+        b = c % n_backbones
+        base = b * (backbone_len + 50_000) + int(rng.integers(0, 15_000))
+        l1 = int(rng.integers(15_000, 25_000)); j = int(rng.integers(junk[0], junk[1]))
+        parts = [noisy(genome[base:base + l1]), rng.integers(0, 4, j, dtype=np.uint8)]
+        if c % 2:
+            parts.append(noisy(genome[base + l1 + j:base + l1 + j + 15_000]))
+        s = np.concatenate(parts)
+        seqs.append(_COMP[s[::-1]] if c % 3 == 0 else s)
+    quals = [_QV[rng.choice(4, len(s), p=[0.1, 0.2, 0.4, 0.3])] for s in seqs]
+    headers = [b"read_%d ch=%d start_time=2020-01-01T00:00:%02dZ" % (i, i % 512, i % 60) for i in range(len(seqs))]
+    lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=len(seqs))
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    return ReadSet(np.concatenate(seqs), offsets, np.concatenate(quals), headers, [False] * len(seqs), True)

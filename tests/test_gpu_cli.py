@@ -346,3 +346,29 @@ def test_cli_part_symbols_archive_is_decoded_by_the_reference(tmp_path):
     _same_streams(ref_arc, dflt)
     subprocess.check_call([CLI, "compress-ont", "--chunk-bases", "20000000", "--part-symbols", "65536", "--parse-threads", "1", fq, seq])
     _same_streams(a64, seq)
+
+
+@pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(CLI)), reason="needs oracle/_ref/colord and colord_amd/colord_hip")
+@pytest.mark.parametrize("extra", [[], ["-p", "ratio"]], ids=["default", "ratio"])
+def test_cli_giant_gaps_equal_the_reference(tmp_path, extra):
+    """Giant gaps — tens of thousands of symbols on both sides, inner gaps and flanks, at several recursion levels — go through the
+    tile-job aligner (csrc/align_giant.hpp: the tiles of a sweep as a pipeline of waves anywhere on the device, Hirschberg level by
+    level over all giants, edlib.cpp:1164-1400).  Random reads yield a few such gaps per Gbase; this input (synth.make_giant_gap_reads)
+    is made of them.  Every stream but `info` equals the unmodified reference's, all giants are finished by the tile jobs (none falls
+    back to the wave-per-gap kernel), and both decompressors return the reference's output."""
+    from colord_amd.synth import make_giant_gap_reads
+    rs = make_giant_gap_reads(seed=53)
+    fq = str(tmp_path / "in.fastq")
+    write_fastq(fq, rs)
+    ref_arc, my_arc, ref_out, my_out = (str(tmp_path / x) for x in ("ref.colord", "gpu.colord", "ref.fastq", "gpu.fastq"))
+    subprocess.check_call([REF, "compress-ont", "-t", str(os.cpu_count() or 8)] + extra + [fq, ref_arc], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    r = subprocess.run([CLI, "compress-ont", "--chunk-bases", "6000000"] + extra + [fq, my_arc], capture_output=True, text=True, env=dict(os.environ, COLORD_HIP_GAP_DEBUG="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    giants = [l for l in r.stderr.splitlines() if "giant gaps by tile jobs" in l]
+    n_giants = sum(int(l.split(":")[1].split()[0]) for l in giants)
+    n_back = sum(int(l.split(",")[-1].split()[0]) for l in giants)
+    assert n_giants >= 10 and n_back == 0, giants
+    _same_streams(ref_arc, my_arc)
+    subprocess.check_call([REF, "decompress", ref_arc, ref_out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.check_call([CLI, "decompress", my_arc, my_out])
+    assert sha(my_out) == sha(ref_out)
