@@ -23,15 +23,17 @@ extern "C" cl_status cl_ctx_create(int device, cl_ctx** out)
 // Internal (stream.hip): the context's streams at a priority of the device's range: +1 = highest, -1 = lowest, 0 = default.  Queues of
 // higher priority are served first when waves compete for the machine: the compressor raises its encode lanes (the chain that bounds a
 // pass) above the coders and lowers the preparation threads (which have slack).  Call before the context has done any work.
-void cl_ctx_set_priority(cl_ctx* c, int level)
+void cl_ctx_set_priority(cl_ctx* c, int level, int role)
 {
 	if (!c) return;
 	(void)hipSetDevice(c->device);
 	int least = 0, greatest = 0;
-	if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest) { (void)hipGetLastError(); return; }
+	if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = 0; }
 	const int prio = level > 0 ? greatest : level < 0 ? least : 0;
-	if (prio == c->prio) return;
-	c->prio = prio;
+	const bool role_changes = role >= 0 && role < CL_N_ROLES && cl_cu_mask_cfg().on[role] && (role != c->role || !c->masked);
+	if (role >= 0) c->role = role;
+	if (prio == c->prio && !role_changes) return;
+	c->prio = prio; c->masked = c->role < CL_N_ROLES && cl_cu_mask_cfg().on[c->role];
 	if (c->stream)
 	{
 		(void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); c->stream = nullptr;

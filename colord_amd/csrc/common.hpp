@@ -39,7 +39,7 @@ struct KernelTime { double ms = 0; uint32_t launches = 0; double bytes = 0; };  
 // the SUM of what is live.  When the device runs short all the same, slabs that are entirely free are given back.
 struct cl_ctx;
 void cl_ctx_drain(cl_ctx* c);                  // capi.hip: waits for every stream of the context
-void cl_ctx_set_priority(cl_ctx* c, int level); // capi.hip: +1 highest, -1 lowest, 0 default stream priority of the context
+void cl_ctx_set_priority(cl_ctx* c, int level, int role = -1); // capi.hip: +1 highest, -1 lowest, 0 default stream priority of the context; role: CL_ROLE_* (-1: unchanged)
 int cl_ctx_fence(cl_ctx* c, hipEvent_t* ev);   // capi.hip: records an event on every stream of the context; returns their number (<= 4)
 struct DevPool {
 	// A free extent remembers who released it and when (pool clock).  Its owner may have it back at once — a context's own reuse
@@ -313,6 +313,8 @@ struct cl_ctx {
 	hipStream_t stream = nullptr;                // the context's main stream; never reassigned while the context works (the pool's fences and drains read it from other threads)
 	hipStream_t launch = nullptr;                // owner thread only: where LAUNCH and its timing events go while a stage works on a side / coder stream (null: `stream`)
 	int prio = 0;                                // priority of this context's streams (cl_ctx_set_priority; 0 = the runtime's default)
+	bool masked = false;                         // its streams were made on the role's CUs
+	int role = 0;                                // what the context does in the compressor (CL_ROLE_*): selects its CU mask, if any (COLORD_HIP_CU_MASK)
 	// further streams, created by the owner thread at first use (a stream that exists takes its turn on the runtime's hardware queues
 	// whether it is used or not: created eagerly for every context they cost the 50-Gbase pass 25 %) and read by the shared pool's
 	// fences and drains from other threads: atomic pointers, set once
@@ -403,8 +405,49 @@ struct KernelTimer {
 // the same with dynamic LDS
 #define LAUNCHB_SHM(ctx, bytes, kernel, grid, block, shm, ...) do { (ctx)->next_bytes = (double)(bytes); KernelTimer _kt((ctx), #kernel); \
 	hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (shm), cl_launch_stream(ctx), __VA_ARGS__); } while (0)
-// a further stream of the context, at the context's priority
-static inline hipError_t cl_stream_create(cl_ctx* c, hipStream_t* s) { return c->prio ? hipStreamCreateWithPriority(s, hipStreamNonBlocking, c->prio) : hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
+// CU partitioning (measured in DESIGN.md 5b; off unless COLORD_HIP_CU_MASK is set): streams of a role run on a range of the device's
+// CUs only, e.g. COLORD_HIP_CU_MASK="coder:0-31,lane:32-255,main:32-255,qual:32-255,prep:32-255" keeps the interval coders'
+// dependent chains (k_range_code on the coders' own streams) on 32 CUs nobody else may fill.  Bits are the runtime's CU numbering
+// (hipExtStreamCreateWithCUMask); a masked stream has the default priority (the API takes no priority).
+enum { CL_ROLE_MAIN = 0, CL_ROLE_QUAL = 1, CL_ROLE_LANE = 2, CL_ROLE_PREP = 3, CL_ROLE_CODER = 4, CL_N_ROLES = 5 };
+struct CuMaskCfg { bool any = false; bool on[CL_N_ROLES] = { false, false, false, false, false }; uint32_t lo[CL_N_ROLES] = { 0, 0, 0, 0, 0 }, hi[CL_N_ROLES] = { 0, 0, 0, 0, 0 }; };
+inline const CuMaskCfg& cl_cu_mask_cfg()
+{
+	static const CuMaskCfg cfg = []() {
+		CuMaskCfg c;
+		const char* e = getenv("COLORD_HIP_CU_MASK");
+		if (!e) return c;
+		static const char* names[CL_N_ROLES] = { "main", "qual", "lane", "prep", "coder" };
+		std::string s(e); size_t p = 0;
+		while (p < s.size())
+		{
+			size_t q = s.find(',', p); if (q == std::string::npos) q = s.size();
+			const std::string item = s.substr(p, q - p); p = q + 1;
+			const size_t colon = item.find(':'), dash = item.find('-');
+			if (colon == std::string::npos || dash == std::string::npos || dash < colon) continue;
+			for (int r = 0; r < CL_N_ROLES; ++r) if (item.substr(0, colon) == names[r])
+			{
+				c.lo[r] = (uint32_t)atoi(item.substr(colon + 1, dash - colon - 1).c_str()); c.hi[r] = (uint32_t)atoi(item.substr(dash + 1).c_str());
+				if (c.hi[r] >= c.lo[r] && c.hi[r] < 1024) { c.on[r] = true; c.any = true; }
+			}
+		}
+		return c;
+	}();
+	return cfg;
+}
+static inline hipError_t cl_stream_create_role(int role, int prio, hipStream_t* s)
+{
+	const CuMaskCfg& m = cl_cu_mask_cfg();
+	if (role >= 0 && role < CL_N_ROLES && m.on[role])
+	{
+		uint32_t bits[32] = { 0 };
+		for (uint32_t b = m.lo[role]; b <= m.hi[role]; ++b) bits[b >> 5] |= 1u << (b & 31);
+		return hipExtStreamCreateWithCUMask(s, (m.hi[role] >> 5) + 1, bits);
+	}
+	return prio ? hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio) : hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+// a further stream of the context, at the context's priority (or on its role's CUs)
+static inline hipError_t cl_stream_create(cl_ctx* c, hipStream_t* s) { return cl_stream_create_role(c->role, c->prio, s); }
 // ... one of the context's side streams, created at first use (owner thread)
 static inline hipError_t cl_side_stream(cl_ctx* c, std::atomic<hipStream_t>& slot)
 {

@@ -1032,7 +1032,7 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 		HIP_TRY(ctx, hipStreamSynchronize(st));
 		levels.push_back(std::move(L));
 	}
-	const uint32_t n_cu = 256;
+	const uint32_t n_cu = (uint32_t)std::max(1, ctx->n_cu);                  // (cl_ctx_create: the device's multiProcessorCount)
 	for (uint32_t lv = 0; lv < levels.size(); ++lv)
 	{
 		LevelBufs& L = *levels[lv];

@@ -154,6 +154,11 @@ extern "C" cl_status cl_compressor_create(cl_ctx* ctx, cl_ctx* qual_ctx, const c
 	c->ctx = ctx; c->qctx = qual_ctx ? qual_ctx : ctx; c->P = *params; c->expected_bases = expected_bases;
 	if (qparams) { c->has_qual = true; c->Q = *qparams; }
 	if (exchange && exchange->world > 1) { c->X = *exchange; c->rank = exchange->rank; c->world = exchange->world; }
+	if (cl_cu_mask_cfg().any)
+	{	// CU partitioning (COLORD_HIP_CU_MASK): the caller's two contexts take their roles' CUs (their streams are made anew, idle as they are)
+		cl_ctx_set_priority(ctx, 0, CL_ROLE_MAIN);
+		if (qual_ctx && qual_ctx != ctx) cl_ctx_set_priority(qual_ctx, 0, CL_ROLE_QUAL);
+	}
 	*out = c;
 	return CL_OK;
 }
@@ -691,7 +696,7 @@ extern "C" cl_status cl_compressor_prepare_parts(cl_compressor* c, const cl_read
 			cl_ctx* x = nullptr;
 			const cl_status s = cl_ctx_create(ctx->device, &x);
 			if (s != CL_OK) return cl_fail(ctx, s, "cl_compressor_prepare: no context for an encode lane");
-			if (!getenv("COLORD_HIP_NO_STREAM_PRIO")) cl_ctx_set_priority(x, +1);      // the lanes bound a pass: their queues are served first
+			cl_ctx_set_priority(x, getenv("COLORD_HIP_NO_STREAM_PRIO") ? 0 : +1, CL_ROLE_LANE);      // the lanes bound a pass: their queues are served first
 			ctx->lanes.push_back(x);
 		}
 		c->lane_ctx.assign(ctx->lanes.begin(), ctx->lanes.begin() + lanes);
@@ -704,7 +709,7 @@ extern "C" cl_status cl_compressor_prepare_parts(cl_compressor* c, const cl_read
 				cl_ctx* x = nullptr;
 				const cl_status s = cl_ctx_create(ctx->device, &x);
 				if (s != CL_OK) return cl_fail(ctx, s, "cl_compressor_prepare: no context for the DNA preparation thread");
-				if (!getenv("COLORD_HIP_NO_STREAM_PRIO")) cl_ctx_set_priority(x, -1);  // (works ahead: takes what the lanes and coders leave)
+				cl_ctx_set_priority(x, getenv("COLORD_HIP_NO_STREAM_PRIO") ? 0 : -1, CL_ROLE_PREP);  // (works ahead: takes what the lanes and coders leave)
 				ctx->prep = x;
 			}
 			c->prep_ctx = ctx->prep; c->prep_next = 0; c->prep_on = true;
@@ -719,7 +724,7 @@ extern "C" cl_status cl_compressor_prepare_parts(cl_compressor* c, const cl_read
 				cl_ctx* x = nullptr;
 				const cl_status s = cl_ctx_create(ctx->device, &x);
 				if (s != CL_OK) return cl_fail(ctx, s, "cl_compressor_prepare: no context for the quality preparation thread");
-				if (!getenv("COLORD_HIP_NO_STREAM_PRIO")) cl_ctx_set_priority(x, -1);
+				cl_ctx_set_priority(x, getenv("COLORD_HIP_NO_STREAM_PRIO") ? 0 : -1, CL_ROLE_PREP);
 				ctx->qprep = x;
 			}
 			c->qprep_ctx = ctx->qprep; c->qprep_next = idx; c->qprep_on = true;
