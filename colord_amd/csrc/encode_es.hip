@@ -107,19 +107,29 @@ __global__ void k_class_bytes(const uint32_t* __restrict__ keys, const uint32_t*
 	if (threadIdx.x < N_CLASSES && s_b[threadIdx.x]) atomicAdd(&bytes[threadIdx.x], s_b[threadIdx.x]);
 }
 
-// lane-private staging memory in LDS (word w of a lane at lds[w * 64 + lane]) + column history in HBM (lane-interleaved)
+// lane-private staging memory in LDS (word w of a lane at lds[w * 64 + lane]) + column history in HBM (lane-interleaved).
+// PACKED: the sequences at 2 bits per symbol, the script at 4 bits per symbol (its nine letters M D A C G T X Y Z as 0..8) — 60 to 96
+// words per lane (15 - 25 KB per wave) instead of 160 - 256 (40 - 64 KB with a byte per symbol, rounds 1-3: four such waves took a
+// CU's whole LDS, and every other kernel that needs LDS — the sorts, the table build, the match pass — waited for them).
 template<int NB>
 struct LdsMem {
-	static constexpr uint32_t QW = 16 * NB, TW = 64;                          // words: rows, columns; then the script (16*NB + 64)
-	uint8_t* base; uint64_t* hist; uint32_t lane;
-	__device__ inline uint32_t addr(uint32_t w0, uint32_t b) const { return ((w0 + (b >> 2)) * 64 + lane) * 4 + (b & 3); }
-	__device__ inline uint32_t q(uint32_t i) const { return base[addr(0, i)]; }
-	__device__ inline uint32_t t(uint32_t j) const { return base[addr(QW, j)]; }
-	__device__ inline void q_set(uint32_t i, uint32_t v) { base[addr(0, i)] = (uint8_t)v; }
-	__device__ inline void t_set(uint32_t j, uint32_t v) { base[addr(QW, j)] = (uint8_t)v; }
-	__device__ inline char es_get(uint32_t k) const { return (char)base[addr(QW + TW, k)]; }
-	__device__ inline void es_set(uint32_t k, char c) { base[addr(QW + TW, k)] = (uint8_t)c; }
-	__device__ inline uint32_t es_word(uint32_t w) const { return ((const uint32_t*)base)[(QW + TW + w) * 64 + lane]; }
+	static constexpr uint32_t QW = 4 * NB, TW = 16, EW = 8 * NB + 32;         // words: rows (64 NB symbols), columns (256), script (64 NB + 256 symbols)
+	uint32_t* base; uint64_t* hist; uint32_t lane;
+	__device__ inline uint32_t& word(uint32_t w) const { return base[w * 64 + lane]; }
+	__device__ inline uint32_t q(uint32_t i) const { return (word(i >> 4) >> (2 * (i & 15))) & 3u; }
+	__device__ inline uint32_t t(uint32_t j) const { return (word(QW + (j >> 4)) >> (2 * (j & 15))) & 3u; }
+	__device__ inline void q_set(uint32_t i, uint32_t v) { uint32_t& w = word(i >> 4); const uint32_t sh = 2 * (i & 15); w = (w & ~(3u << sh)) | ((v & 3u) << sh); }
+	__device__ inline void t_set(uint32_t j, uint32_t v) { uint32_t& w = word(QW + (j >> 4)); const uint32_t sh = 2 * (j & 15); w = (w & ~(3u << sh)) | ((v & 3u) << sh); }
+	static __device__ inline uint32_t code_of(char c) { return c == 'M' ? 0u : c == 'D' ? 1u : c == 'A' ? 2u : c == 'C' ? 3u : c == 'G' ? 4u : c == 'T' ? 5u : (uint32_t)(c - 'X') + 6u; }
+	static __device__ inline char char_of(uint32_t v) { return v == 0 ? 'M' : v == 1 ? 'D' : v == 2 ? 'A' : v == 3 ? 'C' : v == 4 ? 'G' : v == 5 ? 'T' : (char)('X' + (v - 6)); }
+	__device__ inline char es_get(uint32_t k) const { return char_of((word(QW + TW + (k >> 3)) >> (4 * (k & 7))) & 15u); }
+	__device__ inline void es_set(uint32_t k, char c) { uint32_t& w = word(QW + TW + (k >> 3)); const uint32_t sh = 4 * (k & 7); w = (w & ~(15u << sh)) | (code_of(c) << sh); }
+	// script symbols 4 w .. 4 w + 3 as the four bytes of an output word
+	__device__ inline uint32_t es_word(uint32_t w) const
+	{
+		const uint32_t x = (word(QW + TW + (w >> 1)) >> (16 * (w & 1))) & 0xffffu;
+		return (uint32_t)(uint8_t)char_of(x & 15u) | ((uint32_t)(uint8_t)char_of((x >> 4) & 15u) << 8) | ((uint32_t)(uint8_t)char_of((x >> 8) & 15u) << 16) | ((uint32_t)(uint8_t)char_of(x >> 12) << 24);
+	}
 	__device__ inline void lap(uint32_t) {}
 	__device__ inline void hist_put(uint32_t j, uint32_t b, uint64_t P, uint64_t Ph) { uint64_t* h = hist + ((uint64_t)(j * NB + b) * 2) * 64 + lane; h[0] = P; h[64] = Ph; }
 	__device__ inline void hist_get(uint32_t j, uint32_t b, uint64_t& P, uint64_t& Ph) const { const uint64_t* h = hist + ((uint64_t)(j * NB + b) * 2) * 64 + lane; P = h[0]; Ph = h[64]; }
@@ -130,7 +140,7 @@ __global__ __launch_bounds__(64) void k_align_small(const uint32_t* __restrict__
                                                    ArenaV A, ArenaV R, uint64_t* __restrict__ hist_all)
 {
 	extern __shared__ uint32_t lds_raw[];
-	LdsMem<NB> mem{ (uint8_t*)lds_raw, hist_all + (uint64_t)blockIdx.x * (256ull * NB * 2 * 64), threadIdx.x };
+	LdsMem<NB> mem{ lds_raw, hist_all + (uint64_t)blockIdx.x * (256ull * NB * 2 * 64), threadIdx.x };
 	for (uint32_t chunk = blockIdx.x; (uint64_t)chunk * 64 < n_list; chunk += gridDim.x)
 	{
 		const uint32_t idx = chunk * 64 + threadIdx.x;
@@ -1089,7 +1099,7 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 				const uint32_t n_list = hb[nb + 1] - hb[nb];
 				if (!n_list) continue;
 				const uint32_t blocks = std::min<uint32_t>(grid_for(n_list, 64), n_cu * 4);
-				const uint32_t lds = (16 * nb + 64 + 16 * nb + 64) * 64 * 4;
+				const uint32_t lds = (12 * nb + 48) * 64 * 4;                       // LdsMem<nb>: QW + TW + EW words per lane
 				const double bytes = 1.25 * (double)h_cb[nb];
 				const uint32_t* list = ids.p + hb[nb];
 				switch (nb)

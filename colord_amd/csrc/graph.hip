@@ -236,7 +236,8 @@ extern "C" cl_status cl_index_build_pairs(cl_ctx* ctx, const cl_kmer_set* S, uin
 	else DEV_ALLOC(ctx, X->refs, 0);
 	X->n_entries = n_keep;
 	DEV_ALLOC(ctx, X->off, S->n + 1);
-	CL_TRY(dev_exclusive_scan_u64(ctx, id_counts.p, X->off.p, S->n, nullptr));
+	uint64_t n_off = 0;
+	CL_TRY(dev_exclusive_scan_u64(ctx, id_counts.p, X->off.p, S->n, &n_off));        // (with the total: the call returns with the offsets complete — other contexts read the index)
 	cl_timing_collect(ctx);
 	*out = guard.release();
 	return CL_OK;

@@ -53,6 +53,80 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_tile_scan(const TIn* in, uint6
 	for (uint32_t i = 0; i < SCAN_ITEMS; ++i) { if (base + i < n) out[base + i] = pre; pre += v[i]; }
 }
 
+// ---- one pass: decoupled look-back --------------------------------------------------------------------------------------------
+// A tile publishes its sum (AGGREGATE), looks back over the tiles before it until it meets one whose inclusive PREFIX is known,
+// publishes its own PREFIX and writes its elements: one read and one write of the array, ONE launch (the three-level reduce / scan
+// above: two reads, one write, five launches and more for large arrays — 11 000 of the 45 000 dispatches of a 50-Gbase pass).  Tiles are
+// handed out by a ticket, so every tile a tile waits for has been started.  The status words carry their value WITH their flag
+// (8-byte agent-scope relaxed atomics on both sides: MI355X_MICROARCH.md, "valid forms", data-is-the-flag granules).
+constexpr uint32_t LB_ITEMS = 16, LB_TILE = SCAN_THREADS * LB_ITEMS;
+constexpr unsigned long long LB_AGG = 1ull << 62, LB_PREFIX = 2ull << 62, LB_VAL = (1ull << 62) - 1;
+// ctl[0]: ticket, ctl[1..]: status of tile 0, 1, ... (zeroed before the launch).  total_out (optional): receives the sum of all.
+template<typename TIn, typename TOut>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_lookback(const TIn* in, uint64_t n, TOut* out, unsigned long long* __restrict__ ctl, TOut* total_out)
+{
+	__shared__ TOut sh[4];
+	__shared__ unsigned long long s_excl;
+	__shared__ uint32_t s_tile;
+	if (threadIdx.x == 0) s_tile = (uint32_t)atomicAdd(ctl, 1ull);
+	__syncthreads();
+	const uint32_t tile = s_tile, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	unsigned long long* status = ctl + 1;
+	const uint64_t base = (uint64_t)tile * LB_TILE + (uint64_t)threadIdx.x * LB_ITEMS;
+	TOut v[LB_ITEMS]; TOut s = 0;
+#pragma unroll
+	for (uint32_t i = 0; i < LB_ITEMS; ++i) { v[i] = (base + i < n) ? (TOut)in[base + i] : (TOut)0; s += v[i]; }
+	const TOut incl = wave_incl_scan_t<TOut>(s);
+	if (lane == 63) sh[w] = incl;
+	__syncthreads();
+	TOut pre = incl - s, total = 0;
+	for (uint32_t i = 0; i < 4; ++i) { if (i < w) pre += sh[i]; total += sh[i]; }
+	if (w == 0)
+	{
+		unsigned long long excl = 0;
+		if (tile == 0) { if (lane == 0) __hip_atomic_store(status, LB_PREFIX | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+		else
+		{
+			if (lane == 0) __hip_atomic_store(status + tile, LB_AGG | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			// lanes look at tiles hi - 1 - lane; the nearest PREFIX ends the walk, everything nearer is an AGGREGATE (or not there yet: read again)
+			for (int64_t hi = tile; hi > 0; )
+			{
+				const int64_t j = hi - 1 - (int64_t)lane;
+				unsigned long long x = j >= 0 ? __hip_atomic_load(status + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : LB_PREFIX;   // (before tile 0: an empty prefix)
+				const uint64_t pref = __ballot((x >> 62) == 2);
+				const uint32_t stop = pref ? (uint32_t)__builtin_ctzll(pref) : 64u;        // the nearest lane that holds a PREFIX
+				const uint64_t need = stop >= 63 ? ~0ull : ((2ull << stop) - 1);
+				const uint64_t ready = __ballot((x >> 62) != 0);
+				if ((ready & need) != need) { __builtin_amdgcn_s_sleep(2); continue; }
+				unsigned long long part = lane <= stop ? (x & LB_VAL) : 0ull;
+				for (int o = 32; o; o >>= 1) part += __shfl_xor(part, o);
+				excl += part;
+				if (pref) break;
+				hi -= 64;
+			}
+			if (lane == 0) __hip_atomic_store(status + tile, LB_PREFIX | (excl + (unsigned long long)total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		if (lane == 0) s_excl = excl;
+	}
+	__syncthreads();
+	pre += (TOut)s_excl;
+#pragma unroll
+	for (uint32_t i = 0; i < LB_ITEMS; ++i) { if (base + i < n) out[base + i] = pre; pre += v[i]; }
+	if (total_out && (uint64_t)(tile + 1) * LB_TILE >= n && threadIdx.x == SCAN_THREADS - 1) *total_out = pre;    // (the last thread of the last tile has walked to the end)
+}
+
+template<typename TIn, typename TOut>
+cl_status scan_lookback(cl_ctx* ctx, const TIn* d_in, TOut* d_out, uint64_t n, TOut* d_total)
+{
+	const uint32_t tiles = grid_for(n, LB_TILE);
+	DevBuf<unsigned long long> ctl; DEV_ALLOC(ctx, ctl, (uint64_t)tiles + 1);
+	hipStream_t st = cl_launch_stream(ctx);
+	HIP_TRY(ctx, hipMemsetAsync(ctl.p, 0, ((uint64_t)tiles + 1) * 8, st));
+	LAUNCH(ctx, (k_scan_lookback<TIn, TOut>), tiles, SCAN_THREADS, d_in, n, d_out, ctl.p, d_total);
+	HIP_TRY(ctx, hipGetLastError());
+	return CL_OK;                                                                // (ctl goes back to the pool: the context's own stream order protects it)
+}
+
 template<typename T> __global__ void k_write_total(const T* last_in_scanned, T last_value, T* dst) { *dst = *last_in_scanned + last_value; }
 
 template<typename TIn, typename TOut>
@@ -80,14 +154,30 @@ cl_status scan_impl(cl_ctx* ctx, const TIn* d_in, TOut* d_out, uint64_t n)
 // In-place exclusive scan of n uint32 (sums must fit 32 bits); *h_total (optional) = sum of all.
 cl_status dev_exclusive_scan_u32(cl_ctx* ctx, uint32_t* d_data, uint64_t n, uint64_t* h_total)
 {
-	uint32_t last = 0, last_scanned = 0;
-	if (h_total && n) HIP_TRY(ctx, hipMemcpyAsync(&last, d_data + n - 1, 4, hipMemcpyDeviceToHost, ctx->stream));
-	CL_TRY((scan_impl<uint32_t, uint32_t>(ctx, d_data, d_data, n)));
+	if (h_total) *h_total = 0;
+	if (!n) return CL_OK;
+	hipStream_t st = cl_launch_stream(ctx);
+	if (getenv("COLORD_HIP_OLD_SCAN"))
+	{
+		uint32_t last = 0, last_scanned = 0;
+		if (h_total) HIP_TRY(ctx, hipMemcpyAsync(&last, d_data + n - 1, 4, hipMemcpyDeviceToHost, st));
+		CL_TRY((scan_impl<uint32_t, uint32_t>(ctx, d_data, d_data, n)));
+		if (h_total)
+		{
+			HIP_TRY(ctx, hipMemcpyAsync(&last_scanned, d_data + n - 1, 4, hipMemcpyDeviceToHost, st));
+			HIP_TRY(ctx, hipStreamSynchronize(st));
+			*h_total = (uint64_t)last + last_scanned;
+		}
+		return CL_OK;
+	}
+	DevBuf<uint32_t> tot; if (h_total) DEV_ALLOC(ctx, tot, 1);
+	CL_TRY((scan_lookback<uint32_t, uint32_t>(ctx, d_data, d_data, n, h_total ? tot.p : nullptr)));
 	if (h_total)
 	{
-		if (n) HIP_TRY(ctx, hipMemcpyAsync(&last_scanned, d_data + n - 1, 4, hipMemcpyDeviceToHost, ctx->stream));
-		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-		*h_total = (uint64_t)last + last_scanned;
+		uint32_t t = 0;
+		HIP_TRY(ctx, hipMemcpyAsync(&t, tot.p, 4, hipMemcpyDeviceToHost, st));
+		HIP_TRY(ctx, hipStreamSynchronize(st));
+		*h_total = t;
 	}
 	return CL_OK;
 }
@@ -95,18 +185,27 @@ cl_status dev_exclusive_scan_u32(cl_ctx* ctx, uint32_t* d_data, uint64_t n, uint
 // d_out[0..n] = exclusive scan of d_in[0..n) widened to 64 bits, d_out[n] = total.
 cl_status dev_exclusive_scan_u64(cl_ctx* ctx, const uint32_t* d_in, uint64_t* d_out, uint64_t n, uint64_t* h_total)
 {
+	hipStream_t st = cl_launch_stream(ctx);
 	uint64_t total = 0;
-	if (n)
+	if (n && getenv("COLORD_HIP_OLD_SCAN"))
 	{
 		CL_TRY((scan_impl<uint32_t, uint64_t>(ctx, d_in, d_out, n)));
 		uint32_t last = 0; uint64_t last_scanned = 0;
-		HIP_TRY(ctx, hipMemcpyAsync(&last, d_in + n - 1, 4, hipMemcpyDeviceToHost, ctx->stream));
-		HIP_TRY(ctx, hipMemcpyAsync(&last_scanned, d_out + n - 1, 8, hipMemcpyDeviceToHost, ctx->stream));
-		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		HIP_TRY(ctx, hipMemcpyAsync(&last, d_in + n - 1, 4, hipMemcpyDeviceToHost, st));
+		HIP_TRY(ctx, hipMemcpyAsync(&last_scanned, d_out + n - 1, 8, hipMemcpyDeviceToHost, st));
+		HIP_TRY(ctx, hipStreamSynchronize(st));
 		total = last_scanned + last;
+		HIP_TRY(ctx, hipMemcpyAsync(d_out + n, &total, 8, hipMemcpyHostToDevice, st));
+		HIP_TRY(ctx, hipStreamSynchronize(st));
+		if (h_total) *h_total = total;
+		return CL_OK;
 	}
-	HIP_TRY(ctx, hipMemcpyAsync(d_out + n, &total, 8, hipMemcpyHostToDevice, ctx->stream));
-	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	if (n)
+	{
+		CL_TRY((scan_lookback<uint32_t, uint64_t>(ctx, d_in, d_out, n, d_out + n)));       // (the total lands in d_out[n])
+		if (h_total) { HIP_TRY(ctx, hipMemcpyAsync(&total, d_out + n, 8, hipMemcpyDeviceToHost, st)); HIP_TRY(ctx, hipStreamSynchronize(st)); }
+	}
+	else { HIP_TRY(ctx, hipMemsetAsync(d_out, 0, 8, st)); }
 	if (h_total) *h_total = total;
 	return CL_OK;
 }
