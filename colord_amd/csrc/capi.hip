@@ -79,6 +79,7 @@ extern "C" void cl_ctx_destroy(cl_ctx* c)
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	for (std::atomic<hipStream_t>* s : { &c->side, &c->side2, &c->side3 }) if (hipStream_t x = s->load()) (void)hipStreamDestroy(x);
 	if (c->inv_tab) (void)hipFree(c->inv_tab);
+	if (c->slots_h) (void)hipHostFree(c->slots_h);
 	const int dev = c->device;
 	delete c;
 	cl_device_pool_release(dev);

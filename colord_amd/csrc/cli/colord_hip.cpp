@@ -9,6 +9,7 @@ int run_compress(int argc, char** argv);        // compress.cpp
 int run_decompress(int argc, char** argv);      // decompress.cpp
 int run_info(int argc, char** argv);
 int run_parse_check(int argc, char** argv);     // compress.cpp: the input reader alone (test aid, no GPU)
+int run_rccl_selftest(int argc, char** argv);   // compress.cpp: the collectives of the multi-GPU host over RCCL
 
 int main(int argc, char** argv)
 {
@@ -17,6 +18,7 @@ int main(int argc, char** argv)
 	if (cmd == "decompress") return run_decompress(argc, argv);
 	if (cmd == "info") return run_info(argc, argv);
 	if (cmd == "parse-check") return run_parse_check(argc, argv);
+	if (cmd == "rccl-selftest") return run_rccl_selftest(argc, argv);
 	if (argc < 2 || cmd == "-h" || cmd == "--help")
 	{
 		const char* a[] = { argv[0], "compress-ont", "--help" };

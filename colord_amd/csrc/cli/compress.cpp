@@ -9,6 +9,7 @@
 #include "colord_hip.h"
 #include "archive.hpp"
 #include "genome_io.hpp"
+#include "transport.hpp"
 #include <hip/hip_runtime_api.h>
 #include <zlib.h>
 #include <algorithm>
@@ -67,6 +68,7 @@ struct Options {
 	double chunk_bases = 1.0e9;
 	uint64_t part_symbols = 2u << 21;               // --part-symbols: the coder parts close once their reads (+ 1 guard each) reach this; default = the reader packs (defs.h:45)
 	int parse_threads = 0;                          // --parse-threads (0: as many as the host offers, at most 32)
+	int gpus = 1; std::vector<int> gpu_list; std::string transport = "rccl";   // --gpus N [--gpu-list a,b,..] [--transport rccl|host]: reads sharded over N GPUs (run_compress_multi)
 };
 
 // ---- input: one sequential pass that finds lines (memchr) and assigns them their role; bases / qualities / ids are appended to the
@@ -371,6 +373,59 @@ struct Reader {
 		return ch.off.size() > 1;
 	}
 };
+// the `meta` stream (compression.cpp:704-779) and the `info` stream (utils.cpp:326-342): one packing for the single- and the multi-GPU host
+struct MetaIn { uint32_t n_reads, n_pseudo, tot_ref, c; int level, source; uint64_t mean_read_len; bool with_qual; int qual_mode; std::vector<uint32_t> qual_rev; int header_mode; bool sparse; uint32_t sparse_range; double exponent;
+                bool with_genome, store_genome; uint32_t genome_read_len, genome_overlap; const uint8_t* genome_md5; };
+std::vector<uint8_t> pack_meta(const MetaIn& M)
+{
+	std::vector<uint8_t> meta;
+	le<uint32_t>(meta, M.tot_ref); le<uint32_t>(meta, M.c); le<int32_t>(meta, M.level); meta.push_back((uint8_t)M.source);
+	le<uint64_t>(meta, (uint64_t)M.n_reads * M.mean_read_len);
+	if (M.with_qual)
+	{
+		meta.push_back((uint8_t)M.qual_mode);
+		if (M.qual_mode == 8 || (M.qual_mode >= 4 && M.qual_mode <= 6)) for (uint32_t v : M.qual_rev) le<uint32_t>(meta, v);
+	}
+	meta.push_back((uint8_t)M.header_mode);
+	meta.push_back(M.sparse ? 1 : 0);                                    // ReferenceReadsMode: All = 0, Sparse = 1
+	if (M.sparse) { le<uint32_t>(meta, M.sparse_range); le_double(meta, M.exponent); }
+	meta.push_back(M.with_genome ? 1 : 0);                               // compression.cpp:764-777
+	if (M.with_genome)
+	{
+		meta.push_back(M.store_genome ? 1 : 0);
+		le<uint32_t>(meta, M.genome_read_len); le<uint32_t>(meta, M.genome_overlap); le<uint32_t>(meta, M.n_pseudo);
+		if (!M.store_genome) meta.insert(meta.end(), M.genome_md5, M.genome_md5 + 16);       // the decompressor will ask for the same genome (md5 of its packed sequences)
+	}
+	return meta;
+}
+std::vector<uint8_t> pack_info(uint64_t file_bytes, uint64_t total_bases, uint32_t n_reads, int argc, char** argv)
+{
+	std::vector<uint8_t> inf;
+	le<uint32_t>(inf, 1); le<uint32_t>(inf, 2); le<uint32_t>(inf, 1);                        // archive format of CoLoRd 1.2.1 (defs.h:24-26)
+	le<uint64_t>(inf, file_bytes); le<uint64_t>(inf, total_bases); le<uint32_t>(inf, n_reads); le<uint64_t>(inf, (uint64_t)time(nullptr));
+	std::string cmd; for (int i = 0; i < argc; ++i) { if (i) cmd += ' '; cmd += argv[i]; }
+	le<uint32_t>(inf, (uint32_t)cmd.size()); inf.insert(inf.end(), cmd.begin(), cmd.end());
+	return inf;
+}
+// the `header` stream of ids [0, n) of a reader (CEntrComprHeaders, entr_header.cpp:23-45): packs of >= 4 Mi id bytes (in_reads.cpp:50-56,93-101)
+void code_headers(const Reader& R, uint32_t n, int header_mode, std::vector<std::vector<uint8_t>>& parts, std::vector<uint32_t>& counts, std::string& err)
+{
+	cl_id_coder* idc = nullptr;
+	if (cl_id_coder_create(header_mode, &idc) != CL_OK) { err = "cl_id_coder_create"; return; }
+	uint32_t i = 0;
+	while (i < n)
+	{
+		uint32_t j = i; uint64_t acc = 0;
+		while (j < n) { acc += R.id_off[j + 1] - R.id_off[j]; ++j; if (acc >= (2u << 21)) break; }
+		std::vector<uint64_t> off(j - i + 1);
+		for (uint32_t t = i; t <= j; ++t) off[t - i] = R.id_off[t] - R.id_off[i];
+		std::vector<uint8_t> out(2 * (size_t)off.back() + 64); uint64_t got = 0;
+		if (cl_id_encode_part(idc, R.ids.data() + R.id_off[i], off.data(), R.plus.data() + i, j - i, out.data(), out.size(), &got) != CL_OK) { err = cl_id_coder_error(idc); break; }
+		out.resize(got); parts.push_back(std::move(out)); counts.push_back(j - i);
+		i = j;
+	}
+	cl_id_coder_free(idc);
+}
 struct DevChunk { cl_reads* reads = nullptr; uint8_t* d_quals = nullptr; uint64_t* d_off = nullptr; std::vector<uint32_t> packs, parts; uint64_t n_bases = 0; uint32_t n_reads = 0; };
 } // namespace
 
@@ -388,7 +443,9 @@ static void usage()
 		"  -t,--threads N (accepted; the data path runs on the GPU)   -v,--verbose   --gpu N   --chunk-bases X\n"
 		"  --part-symbols N   coder parts of N symbols instead of the reference's 4194304 (defs.h:45): same FASTQ back from either\n"
 		"                     decompressor, 8 more bytes per part, far shorter interval-coder chains (65536: +0.04 %% size, 1.4x the speed)\n"
-		"  --parse-threads N  threads that index a plain FASTQ (default: the host's, at most 32)\n");
+		"  --parse-threads N  threads that index a plain FASTQ (default: the host's, at most 32)\n"
+		"  --gpus N [--gpu-list a,b,..] [--transport rccl|host]   reads sharded over N GPUs, one host thread and one model domain per GPU;\n"
+		"                     the k-mer set, reference reads and index are replicated through RCCL (or host staging: several ranks per GPU)\n");
 }
 
 // `colord_hip parse-check [--parse-threads N] [--part-symbols N] [--chunk-bases X] input`: the reader alone (no GPU): per chunk a
@@ -422,6 +479,302 @@ int run_parse_check(int argc, char** argv)
 	printf("ids %016llx reads %llu bases %llu header symbols %llu\n", (unsigned long long)h, (unsigned long long)R.n_reads, (unsigned long long)R.n_bases, (unsigned long long)R.header_symbols);
 	fprintf(stderr, "parse-check: %s reader, %d thread(s)\n", idx ? "indexed" : "sequential", threads);
 	ch.release();
+	return 0;
+}
+
+// ---- reads sharded over several GPUs: one host thread per GPU (the reference's orchestrator is one process of threads too,
+// ---- compression.cpp:547-689).  The input is read ONCE by the process (gzip and FASTA included): rank r takes the r-th contiguous range
+// ---- of the reads (equal shares of the bases), cuts its own reader packs and chunks, and drives its own cl_compressor; the two exchanges
+// ---- of the *_finish steps run through the Transport (RCCL, or host staging) bound to cl_exchange; every rank is one model domain of the
+// ---- coders.  Each rank writes ITS parts into the archive file at the offsets an all-gather of the byte counts gives it (pwrite; no
+// ---- part travels to another rank); rank 0's thread adds `meta`, `header`, `hipdomains`, `info` and the footer.
+namespace {
+struct Source {                                    // the whole input as records: slices of the mapping (indexed reader) or of one host chunk
+	const Reader* R = nullptr; const Chunk* whole = nullptr; uint64_t n = 0;
+	uint32_t len(uint64_t i) const { return R->indexed ? R->recs[i].len : (uint32_t)(whole->off[i + 1] - whole->off[i]); }
+	const uint8_t* seq(uint64_t i) const { return R->indexed ? R->recs[i].seq : whole->bases + whole->off[i]; }
+	const uint8_t* qual(uint64_t i) const { return R->indexed ? R->recs[i].qual : whole->quals + whole->off[i]; }
+};
+struct RankOut {
+	std::vector<uint8_t> dna, qual; std::vector<uint64_t> dsz, qsz; std::vector<uint32_t> counts;      // this rank's parts, in order
+	uint64_t n_reads = 0, n_bases = 0, mean_read_len = 0; uint32_t sparse_range = 0, n_refs = 0; cl_kmer_stats ks{}; size_t n_chunks = 0;
+	uint64_t dna_base = 0, qual_base = 0;          // where its framed `dna` / `qual` parts start in the file
+	uint64_t moved = 0;
+};
+uint32_t varint_len(uint64_t x) { uint32_t n = 1; for (; x; x >>= 8) ++n; return n; }
+}
+
+static int run_compress_multi(const Options& O, const Preset& P, const QDef& qd, int argc, char** argv)
+{
+	const auto t0 = std::chrono::steady_clock::now();
+	auto lap = [&](const char* what) { if (O.verbose) fprintf(stderr, "[%7.2f s] %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), what); };
+	const uint32_t world = (uint32_t)O.gpus;
+	std::vector<int> devs = O.gpu_list;
+	if (devs.empty()) for (int i = 0; i < O.gpus; ++i) devs.push_back(i);
+	if (devs.size() != world) die("--gpu-list must name --gpus devices");
+	int n_dev = 0; hipck(hipGetDeviceCount(&n_dev), "hipGetDeviceCount");
+	for (int d : devs) if (d < 0 || d >= n_dev) die("--gpus / --gpu-list: no such device");
+	if (!O.genome.empty()) die("-G,--reference-genome with --gpus > 1: use `python -m colord_amd.mgpu` (the C++ multi-GPU host has no reference-genome mode yet)");
+	const bool use_rccl = O.transport == "rccl";
+	if (use_rccl) { std::vector<int> u = devs; std::sort(u.begin(), u.end()); if (std::adjacent_find(u.begin(), u.end()) != u.end()) die("--transport rccl needs distinct devices (several ranks on one GPU: --transport host)"); }
+
+	// the input, once
+	Reader R; R.part_symbols = O.part_symbols; R.open(O.in);
+	R.threads = O.parse_threads ? O.parse_threads : (int)std::min<unsigned>(32, std::max<unsigned>(1, std::thread::hardware_concurrency()));
+	Chunk whole; whole.pinned = false;
+	Source S; S.R = &R;
+	if (R.map && R.index_mapped())
+	{
+		S.n = R.recs.size();
+		for (const auto& r : R.recs) { R.ids.insert(R.ids.end(), r.id, r.id + r.id_len); R.id_off.push_back(R.ids.size()); R.plus.push_back(r.plus_eq); R.n_bases += r.len; }
+		R.n_reads = S.n;
+	}
+	else
+	{
+		R.indexed = false;
+		if (!R.next_chunk(whole, ~0ull >> 1)) die("no reads in " + O.in);
+		S.whole = &whole; S.n = whole.off.size() - 1;
+	}
+	lap("input read");
+	const uint64_t n = S.n, total = R.n_bases;
+	if (!n) die("no reads in " + O.in);
+	if (n >= (1ull << 32)) die("more than 2^32 reads");
+	const bool with_qual = R.fastq;
+	uint32_t k = O.k, a = O.a;
+	if (!k)
+	{	// adjustKmerAndAnchorLen (compression.cpp:42-95) on the estimate from the file size
+		const double fac = R.gz ? (R.fastq ? 2.08 : 3.98) : (R.fastq ? 0.49 : 0.98);
+		const uint64_t est = (uint64_t)(fac * (double)R.file_bytes);
+		if (est < 1000000000ull) { k = 20; a = 16; } else if (est < 4000000000ull) { k = 21; a = 18; } else if (est < 16000000000ull) { k = 23; a = 21; }
+		else if (est < 48000000000ull) { k = 24; a = 22; } else if (est < 128000000000ull) { k = 25; a = 22; } else { k = 26; a = 23; }
+	}
+	cl_compress_params cp{};
+	cp.k = k; cp.f = P.f; cp.ci = P.ci; cp.cs = P.cs; cp.c = P.c; cp.anchor_len = a; cp.min_part_alt = P.min_part_alt; cp.max_rec = P.max_rec; cp.min_anchors = (uint32_t)O.min_anchors;
+	cp.level = P.level; cp.source = O.source; cp.sparse = P.sparse; cp.sparse_g = P.g; cp.sparse_exponent = O.exponent;
+	cp.cost_mult = O.cost_mult; cp.frac_always = O.frac_always; cp.frac_min = O.frac_min; cp.max_matches_mult = O.max_matches_mult;
+	cl_qual_params qp{}; qp.mode = P.qual_mode; qp.source = O.source; qp.level = P.level;
+	qp.n_fwd = (uint32_t)qd.fwd.size(); std::copy(qd.fwd.begin(), qd.fwd.end(), qp.fwd);
+	qp.n_rev = (uint32_t)qd.rev.size(); std::copy(qd.rev.begin(), qd.rev.end(), qp.rev);
+
+	// shares: rank r starts at the first read whose cumulative base count reaches total * r / world (as colord_amd/mgpu.py)
+	std::vector<uint64_t> first(world + 1, n);
+	{
+		first[0] = 0; uint64_t acc = 0; uint32_t r = 1;
+		for (uint64_t i = 0; i < n && r < world; ++i)
+		{
+			acc += S.len(i);
+			while (r < world && (double)acc >= (double)total * r / world) first[r++] = i;
+		}
+	}
+	// the header stream on a host thread of its own, next to everything else
+	std::vector<std::vector<uint8_t>> hdr_parts; std::vector<uint32_t> hdr_counts; std::string hdr_err;
+	std::thread hdr([&]() { code_headers(R, (uint32_t)n, O.header_mode, hdr_parts, hdr_counts, hdr_err); });
+
+	// transports
+	std::vector<std::unique_ptr<Transport>> tp(world);
+	std::vector<ncclComm_t> comms(world, nullptr);
+	std::unique_ptr<HostHub> hub;
+	if (use_rccl)
+	{
+		const ncclResult_t e = ncclCommInitAll(comms.data(), (int)world, devs.data());
+		if (e != ncclSuccess) die(std::string("ncclCommInitAll: ") + ncclGetErrorString(e));
+		for (uint32_t r = 0; r < world; ++r) { auto t = std::make_unique<RcclTransport>(); if (t->init(comms[r], devs[r], r, world) != CL_OK) die(t->err); tp[r] = std::move(t); }
+	}
+	else
+	{
+		hub = std::make_unique<HostHub>(world);
+		for (uint32_t r = 0; r < world; ++r) { auto t = std::make_unique<HostTransport>(); t->init(hub.get(), devs[r], r); tp[r] = std::move(t); }
+	}
+	const int fd = ::open(O.out.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+	if (fd < 0) die("cannot open file: " + O.out);
+	std::vector<RankOut> out(world);
+	auto rank_main = [&](uint32_t rank) {
+		Transport& T = *tp[rank]; RankOut& RO = out[rank];
+		hipck(hipSetDevice(devs[rank]), "hipSetDevice");
+		cl_ctx* ctx = nullptr; cl_ctx* qctx = nullptr;
+		ck(nullptr, cl_ctx_create(devs[rank], &ctx), "cl_ctx_create"); ck(nullptr, cl_ctx_create(devs[rank], &qctx), "cl_ctx_create");
+		const uint64_t r0 = first[rank], r1 = first[rank + 1];
+		uint64_t my_bases = 0; for (uint64_t i = r0; i < r1; ++i) my_bases += S.len(i);
+		cl_exchange X = T.exchange();
+		cl_compressor* cmp = nullptr;
+		ck(ctx, cl_compressor_create(ctx, qctx, &cp, with_qual ? &qp : nullptr, &X, my_bases, &cmp), "cl_compressor_create");
+		// chunks of whole reader packs (the packs are cut from this rank's first read on: in_reads.cpp:62-77)
+		std::vector<DevChunk> chunks; Chunk host;
+		Reader B; B.part_symbols = O.part_symbols;                            // (its pack / part bookkeeping only)
+		for (uint64_t i = r0; i < r1; )
+		{
+			host.clear();
+			auto full = [&]() { return host.n >= (uint64_t)O.chunk_bases && host.pack_acc == 0 && host.off.size() > 1; };
+			const uint64_t c0 = i;
+			while (i < r1 && !full()) { const uint32_t L = S.len(i); host.n += L; host.off.push_back(host.n); B.close_bounds(host, L); ++i; }
+			B.finish_bounds(host);
+			{ const uint64_t tot = host.n; host.n = 0; host.reserve(tot + 1, with_qual); host.n = tot; }
+			for (uint64_t x = c0; x < i; ++x) { memcpy(host.bases + host.off[x - c0], S.seq(x), S.len(x)); if (with_qual) memcpy(host.quals + host.off[x - c0], S.qual(x), S.len(x)); }
+			DevChunk dc; dc.n_reads = (uint32_t)(host.off.size() - 1); dc.n_bases = host.n; dc.packs = host.packs; dc.parts = host.parts;
+			if (with_qual)
+			{
+				uint8_t lo = 255, hi8 = 0; for (uint64_t x = 0; x < host.n; ++x) { lo = host.quals[x] < lo ? host.quals[x] : lo; hi8 = host.quals[x] > hi8 ? host.quals[x] : hi8; }
+				if (host.n && (lo < 33 || hi8 > 33 + 95)) die("quality values outside '!'..'~'+1 (Phred+33, 0..95) are not supported");
+			}
+			uint8_t* d_bases = nullptr;
+			hipck(hipMalloc((void**)&d_bases, host.n + 1), "hipMalloc"); hipck(hipMalloc((void**)&dc.d_off, host.off.size() * 8), "hipMalloc");
+			hipck(hipMemcpy(d_bases, host.bases, host.n, hipMemcpyHostToDevice), "hipMemcpy");
+			hipck(hipMemcpy(dc.d_off, host.off.data(), host.off.size() * 8, hipMemcpyHostToDevice), "hipMemcpy");
+			if (with_qual) { hipck(hipMalloc((void**)&dc.d_quals, host.n + 1), "hipMalloc (the input does not fit this GPU's memory)"); hipck(hipMemcpy(dc.d_quals, host.quals, host.n, hipMemcpyHostToDevice), "hipMemcpy"); }
+			ck(ctx, cl_reads_pack(ctx, d_bases, dc.d_off, dc.n_reads, 1, &dc.reads), "input");
+			hipck(hipFree(d_bases), "hipFree");
+			ck(ctx, cl_compressor_count_add(cmp, dc.reads), "pass 1");
+			chunks.push_back(std::move(dc));
+		}
+		host.release();
+		ck(ctx, cl_compressor_count_finish(cmp, &RO.ks), "k-mer counting (exchange 1)");
+		for (auto& dc : chunks) ck(ctx, cl_compressor_refs_add(cmp, dc.reads), "reference reads");
+		ck(ctx, cl_compressor_refs_finish(cmp), "reference index (exchange 2)");
+		ck(ctx, cl_compressor_info(cmp, nullptr, nullptr, nullptr, &RO.mean_read_len, &RO.sparse_range, &RO.n_refs), "cl_compressor_info");
+		uint64_t max_bases = 0, max_parts = 0; for (auto& dc : chunks) { max_bases = std::max(max_bases, dc.n_bases); max_parts = std::max<uint64_t>(max_parts, dc.parts.size()); }
+		const uint64_t dna_cap = max_bases + 64 * max_parts + 4096, qual_cap = (uint64_t)(max_bases * 1.35) + 64 * max_parts + 4096;
+		uint8_t* d_dna = nullptr; uint8_t* d_qual = nullptr;
+		hipck(hipMalloc((void**)&d_dna, dna_cap), "hipMalloc"); if (with_qual) hipck(hipMalloc((void**)&d_qual, qual_cap), "hipMalloc");
+		for (auto& dc : chunks) ck(ctx, cl_compressor_prepare_parts(cmp, dc.reads, dc.packs.data(), (uint32_t)dc.packs.size() - 1, dc.parts.data(), (uint32_t)dc.parts.size() - 1, dc.d_quals, dc.d_off), "look-ahead");
+		for (auto& dc : chunks)
+		{
+			const uint32_t np = (uint32_t)dc.parts.size() - 1;
+			std::vector<uint64_t> dsz(np), qsz(np); cl_compress_info info{};
+			ck(ctx, cl_compressor_encode(cmp, dc.reads, dc.d_quals, dc.d_off, dc.parts.data(), np, dc.packs.data(), (uint32_t)dc.packs.size() - 1, d_dna, dna_cap, dsz.data(), d_qual, qual_cap, qsz.data(), &info), "pass 2");
+			const size_t od = RO.dna.size(), oq = RO.qual.size();
+			RO.dna.resize(od + info.dna_bytes); RO.qual.resize(oq + info.qual_bytes);
+			if (info.dna_bytes) hipck(hipMemcpy(RO.dna.data() + od, d_dna, info.dna_bytes, hipMemcpyDeviceToHost), "hipMemcpy");
+			if (info.qual_bytes) hipck(hipMemcpy(RO.qual.data() + oq, d_qual, info.qual_bytes, hipMemcpyDeviceToHost), "hipMemcpy");
+			RO.dsz.insert(RO.dsz.end(), dsz.begin(), dsz.end()); if (with_qual) RO.qsz.insert(RO.qsz.end(), qsz.begin(), qsz.end());
+			for (uint32_t p = 0; p < np; ++p) RO.counts.push_back(dc.parts[p + 1] - dc.parts[p]);
+			RO.n_reads += dc.n_reads; RO.n_bases += dc.n_bases;
+			cl_reads_free(dc.reads); dc.reads = nullptr; if (dc.d_quals) (void)hipFree(dc.d_quals); (void)hipFree(dc.d_off);
+		}
+		RO.n_chunks = chunks.size();
+		(void)hipFree(d_dna); if (d_qual) (void)hipFree(d_qual);
+		// where this rank's parts go: an all-gather of the framed byte counts, an exclusive sum, pwrite — `dna` of all ranks first, then `qual`
+		uint64_t mine[2] = { 0, 0 };
+		for (size_t p = 0; p < RO.dsz.size(); ++p) mine[0] += varint_len(RO.counts[p]) + RO.dsz[p];
+		for (size_t p = 0; p < RO.qsz.size(); ++p) mine[1] += varint_len(0) + RO.qsz[p];
+		std::vector<uint64_t> all(2 * (size_t)world);
+		ck(ctx, T.all_gather_host(mine, 2, all.data()), "all-gather of the stream sizes");
+		uint64_t dna_all = 0; for (uint32_t r = 0; r < world; ++r) { if (r == rank) RO.dna_base = dna_all; dna_all += all[2 * r]; }
+		uint64_t q = dna_all; for (uint32_t r = 0; r < world; ++r) { if (r == rank) RO.qual_base = q; q += all[2 * r + 1]; }
+		auto write_parts = [&](uint64_t at, const std::vector<uint8_t>& data, const std::vector<uint64_t>& sz, bool counted) {
+			std::vector<uint8_t> buf; uint64_t o = 0;
+			for (size_t p = 0; p < sz.size(); ++p)
+			{	// (parts are framed in memory in runs of ~64 MB, one pwrite per run)
+				ArchiveWriter::varint(buf, counted ? RO.counts[p] : 0);
+				buf.insert(buf.end(), data.begin() + o, data.begin() + o + sz[p]); o += sz[p];
+				if (buf.size() >= (64u << 20) || p + 1 == sz.size())
+				{
+					size_t done = 0;
+					while (done < buf.size()) { const ssize_t w = pwrite(fd, buf.data() + done, buf.size() - done, (off_t)(at + done)); if (w <= 0) die("cannot write the archive (disk full?)"); done += (size_t)w; }
+					at += buf.size(); buf.clear();
+				}
+			}
+		};
+		write_parts(RO.dna_base, RO.dna, RO.dsz, true);
+		if (with_qual) write_parts(RO.qual_base, RO.qual, RO.qsz, false);
+		RO.moved = T.bytes_moved;
+		cl_compressor_free(cmp);
+		cl_ctx_destroy(qctx); cl_ctx_destroy(ctx);
+	};
+	std::vector<std::thread> th;
+	for (uint32_t r = 0; r < world; ++r) th.emplace_back(rank_main, r);
+	for (auto& t : th) t.join();
+	lap("all ranks through (parts written)");
+	hdr.join();
+	if (!hdr_err.empty()) die("header stream: " + hdr_err);
+	// the rest of the archive behind the parts: meta, header, hipdomains, info, footer — by this thread
+	uint64_t end = 0;
+	for (auto& RO : out) { for (size_t p = 0; p < RO.dsz.size(); ++p) end += varint_len(RO.counts[p]) + RO.dsz[p]; for (size_t p = 0; p < RO.qsz.size(); ++p) end += 1 + RO.qsz[p]; }
+	ArchiveWriter ar;
+	ar.f = fdopen(fd, "r+b"); if (!ar.f) die("cannot open file: " + O.out);
+	if (fseeko(ar.f, (off_t)end, SEEK_SET) != 0) die("cannot seek in the archive");
+	ar.off = end;
+	const int s_meta = ar.reg("meta"), s_header = ar.reg("header"), s_dna = ar.reg("dna"), s_qual = with_qual ? ar.reg("qual") : -1, s_dom = ar.reg("hipdomains");
+	uint32_t tot_ref = (uint32_t)n;
+	const RankOut& R0 = out[0];
+	if (P.sparse) { std::vector<uint8_t> acc((size_t)n); ck(nullptr, cl_ref_accept((uint32_t)n, 0, R0.sparse_range, O.exponent, acc.data()), "cl_ref_accept"); tot_ref = 0; for (uint8_t x : acc) tot_ref += x; }
+	const std::vector<uint8_t> meta = pack_meta(MetaIn{ (uint32_t)n, 0, tot_ref, P.c, P.level, O.source, R0.mean_read_len, with_qual, P.qual_mode, qd.rev, O.header_mode, P.sparse != 0, R0.sparse_range, O.exponent, false, false, 0, 0, nullptr });
+	ar.add(s_meta, meta.data(), meta.size(), 0);
+	for (size_t p = 0; p < hdr_parts.size(); ++p) ar.add(s_header, hdr_parts[p].data(), hdr_parts[p].size(), hdr_counts[p]);
+	// part tables of the streams the ranks wrote, and the model domains (first read, first `dna` part of every rank)
+	std::vector<uint8_t> dom; le<uint32_t>(dom, world);
+	uint64_t first_read = 0, dna_total = 0, qual_total = 0;
+	for (uint32_t r = 0; r < world; ++r)
+	{
+		const RankOut& RO = out[r];
+		le<uint64_t>(dom, first_read); le<uint64_t>(dom, (uint64_t)ar.streams[s_dna].parts.size());
+		uint64_t at = RO.dna_base;
+		for (size_t p = 0; p < RO.dsz.size(); ++p) { ar.streams[s_dna].parts.push_back(ArchiveWriter::Part{ at, RO.dsz[p] }); at += varint_len(RO.counts[p]) + RO.dsz[p]; dna_total += RO.dsz[p]; }
+		at = RO.qual_base;
+		if (with_qual) for (size_t p = 0; p < RO.qsz.size(); ++p) { ar.streams[s_qual].parts.push_back(ArchiveWriter::Part{ at, RO.qsz[p] }); at += 1 + RO.qsz[p]; qual_total += RO.qsz[p]; }
+		first_read += RO.n_reads;
+	}
+	if (first_read != n) die("internal: the ranks' reads do not add up");
+	ar.add(s_dom, dom.data(), dom.size(), 0);
+	const int s_info = ar.reg("info");
+	const std::vector<uint8_t> inf = pack_info(R.total_bytes, total, (uint32_t)n, argc, argv);
+	ar.add(s_info, inf.data(), inf.size(), 0);
+	ar.close();
+	if (use_rccl) for (ncclComm_t c : comms) if (c) (void)ncclCommDestroy(c);
+	tp.clear();
+	whole.release();
+	if (R.g) gzclose(R.g);
+	const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	fprintf(stderr, "colord_hip: %llu reads, %llu bases on %u GPU(s) [%s], k=%u a=%u; dna %llu B, qual %llu B, header %zu parts; %u reference reads; %llu B exchanged by rank 0; %.2f s\n", (unsigned long long)n, (unsigned long long)total,
+		world, use_rccl ? "RCCL" : "host-staged", k, a, (unsigned long long)dna_total, (unsigned long long)qual_total, hdr_parts.size(), R0.n_refs, (unsigned long long)R0.moved, sec);
+	return 0;
+}
+
+// `colord_hip rccl-selftest [--gpus N]`: the three collectives of RcclTransport on N devices (default 1: a communicator of one rank still runs
+// the RCCL code path) with uneven and empty shares, checked against what they must deliver
+int run_rccl_selftest(int argc, char** argv)
+{
+	int world = 1; for (int i = 2; i + 1 < argc; ++i) if (std::string(argv[i]) == "--gpus") world = atoi(argv[i + 1]);
+	std::vector<int> devs; for (int i = 0; i < world; ++i) devs.push_back(i);
+	std::vector<ncclComm_t> comms((size_t)world, nullptr);
+	const ncclResult_t e = ncclCommInitAll(comms.data(), world, devs.data());
+	if (e != ncclSuccess) die(std::string("ncclCommInitAll: ") + ncclGetErrorString(e));
+	std::vector<std::string> errs((size_t)world);
+	auto run = [&](int r) {
+		RcclTransport T; if (T.init(comms[r], devs[r], (uint32_t)r, (uint32_t)world) != CL_OK) { errs[r] = T.err; return; }
+		auto fillv = [&](uint32_t from, uint32_t to, uint64_t i) { return (uint8_t)(from * 31 + to * 7 + i * 13 + 5); };
+		// all_gather_host
+		uint64_t v[3] = { (uint64_t)r * 10 + 1, (uint64_t)r * 10 + 2, ~0ull - (uint64_t)r }; std::vector<uint64_t> o(3 * (size_t)world);
+		if (T.all_gather_host(v, 3, o.data()) != CL_OK) { errs[r] = T.err; return; }
+		for (int p = 0; p < world; ++p) if (o[3 * p] != (uint64_t)p * 10 + 1 || o[3 * p + 2] != ~0ull - (uint64_t)p) { errs[r] = "all_gather_host: wrong values"; return; }
+		// all_to_all_v: rank a sends ((a + b) % 3 == 0 ? 0 : 1000 + 17 a + 5 b) bytes to rank b
+		auto cnt = [&](int a_, int b_) -> uint64_t { return (a_ + b_) % 3 == 0 && a_ != b_ ? 0ull : 1000ull + 17 * a_ + 5 * b_; };
+		std::vector<uint64_t> sb((size_t)world), rb((size_t)world); uint64_t st = 0, rt = 0;
+		for (int p = 0; p < world; ++p) { sb[p] = cnt(r, p); rb[p] = cnt(p, r); st += sb[p]; rt += rb[p]; }
+		std::vector<uint8_t> hs(st + 1), hr(rt + 1);
+		{ uint64_t o2 = 0; for (int p = 0; p < world; ++p) for (uint64_t i = 0; i < sb[p]; ++i) hs[o2++] = fillv((uint32_t)r, (uint32_t)p, i); }
+		uint8_t* ds = nullptr; uint8_t* dr = nullptr;
+		if (hipMalloc((void**)&ds, st + 1) != hipSuccess || hipMalloc((void**)&dr, rt + 1) != hipSuccess) { errs[r] = "hipMalloc"; return; }
+		(void)hipMemcpy(ds, hs.data(), st, hipMemcpyHostToDevice);
+		if (T.all_to_all_v(ds, sb.data(), dr, rb.data()) != CL_OK) { errs[r] = T.err; return; }
+		(void)hipMemcpy(hr.data(), dr, rt, hipMemcpyDeviceToHost);
+		{ uint64_t o2 = 0; for (int p = 0; p < world; ++p) for (uint64_t i = 0; i < rb[p]; ++i) if (hr[o2++] != fillv((uint32_t)p, (uint32_t)r, i)) { errs[r] = "all_to_all_v: wrong bytes"; return; } }
+		// all_gather_v: rank a contributes (a % 2 ? 0 : 777 + 3 a) bytes
+		auto gc = [&](int a_) -> uint64_t { return a_ % 2 ? 0ull : 777ull + 3 * a_; };
+		std::vector<uint64_t> gb((size_t)world); uint64_t gt = 0; for (int p = 0; p < world; ++p) { gb[p] = gc(p); gt += gb[p]; }
+		std::vector<uint8_t> gs(gc(r) + 1), gr(gt + 1); for (uint64_t i = 0; i < gc(r); ++i) gs[i] = fillv((uint32_t)r, 99, i);
+		uint8_t* dgs = nullptr; uint8_t* dgr = nullptr;
+		if (hipMalloc((void**)&dgs, gc(r) + 1) != hipSuccess || hipMalloc((void**)&dgr, gt + 1) != hipSuccess) { errs[r] = "hipMalloc"; return; }
+		(void)hipMemcpy(dgs, gs.data(), gc(r), hipMemcpyHostToDevice);
+		if (T.all_gather_v(dgs, gc(r), dgr, gb.data()) != CL_OK) { errs[r] = T.err; return; }
+		(void)hipMemcpy(gr.data(), dgr, gt, hipMemcpyDeviceToHost);
+		{ uint64_t o2 = 0; for (int p = 0; p < world; ++p) for (uint64_t i = 0; i < gb[p]; ++i) if (gr[o2++] != fillv((uint32_t)p, 99, i)) { errs[r] = "all_gather_v: wrong bytes"; return; } }
+		(void)hipFree(ds); (void)hipFree(dr); (void)hipFree(dgs); (void)hipFree(dgr);
+	};
+	std::vector<std::thread> th; for (int r = 0; r < world; ++r) th.emplace_back(run, r);
+	for (auto& t : th) t.join();
+	for (ncclComm_t c : comms) if (c) (void)ncclCommDestroy(c);
+	for (int r = 0; r < world; ++r) if (!errs[r].empty()) die("rccl-selftest, rank " + std::to_string(r) + ": " + errs[r]);
+	printf("rccl-selftest: all_gather_host, all_to_all_v, all_gather_v ok on %d rank(s)\n", world);
 	return 0;
 }
 
@@ -463,6 +816,9 @@ int run_compress(int argc, char** argv)
 		else if (a == "-G" || a == "--reference-genome") O.genome = need(i);
 		else if (a == "-s" || a == "--store-reference") O.store_genome = true;
 		else if (a == "--gpu") O.gpu = atoi(need(i).c_str());
+		else if (a == "--gpus") { O.gpus = atoi(need(i).c_str()); if (O.gpus < 1 || O.gpus > 64) die("--gpus must be in [1, 64]"); }
+		else if (a == "--gpu-list") { for (uint32_t v : list_u32(need(i))) O.gpu_list.push_back((int)v); }
+		else if (a == "--transport") { O.transport = need(i); if (O.transport != "rccl" && O.transport != "host") die("--transport must be rccl or host"); }
 		else if (a == "--chunk-bases") O.chunk_bases = atof(need(i).c_str());
 		else if (a == "--part-symbols") { O.part_symbols = strtoull(need(i).c_str(), nullptr, 10); if (O.part_symbols < 1024 || O.part_symbols > (2u << 21)) die("--part-symbols must be in [1024, 4194304]"); }
 		else if (a == "--parse-threads") { O.parse_threads = atoi(need(i).c_str()); if (O.parse_threads < 1 || O.parse_threads > 256) die("--parse-threads must be in [1, 256]"); }
@@ -494,6 +850,8 @@ int run_compress(int argc, char** argv)
 	if (O.has_T) { if (qd.fwd.empty()) die(std::string("-T,--qual-thresholds is not allowed for '") + qnames[P.qual_mode] + "' quality mode"); if (O.T.size() != qd.fwd.size()) die(std::string("for '") + qnames[P.qual_mode] + "' quality compression mode expected number of quality thresholds is " + std::to_string(qd.fwd.size()) + ", but " + std::to_string(O.T.size()) + " given."); qd.fwd = O.T; }
 	if (O.has_D) { if (qd.rev.empty()) die(std::string("-D,--qual-values is not allowed for '") + qnames[P.qual_mode] + "' quality mode"); if (O.D.size() != qd.rev.size()) die(std::string("for '") + qnames[P.qual_mode] + "' quality compression mode expected number of quality values is " + std::to_string(qd.rev.size()) + ", but " + std::to_string(O.D.size()) + " given."); qd.rev = O.D; }
 	for (size_t i = 0; i < qd.fwd.size(); ++i) if (qd.fwd[i] > 95 || (i && qd.fwd[i] < qd.fwd[i - 1])) die("quality thresholds must be ascending values in [0, 95]");
+	if (!O.gpu_list.empty() && O.gpus == 1) O.gpus = (int)O.gpu_list.size();
+	if (O.gpus > 1) return run_compress_multi(O, P, qd, argc, argv);
 
 	const auto t0 = std::chrono::steady_clock::now();
 	auto lap = [&](const char* what) { if (O.verbose) fprintf(stderr, "[%7.2f s] %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), what); };
@@ -592,23 +950,7 @@ int run_compress(int argc, char** argv)
 	if (!n) die("no reads in " + O.in);
 	// the header stream on a host thread, next to the GPU path (CEntrComprHeaders, entr_header.cpp:23-45)
 	std::vector<std::vector<uint8_t>> hdr_parts; std::vector<uint32_t> hdr_counts; std::string hdr_err;
-	std::thread hdr([&]() {
-		cl_id_coder* idc = nullptr;
-		if (cl_id_coder_create(O.header_mode, &idc) != CL_OK) { hdr_err = "cl_id_coder_create"; return; }
-		uint32_t i = 0;
-		while (i < n)
-		{
-			uint32_t j = i; uint64_t acc = 0;
-			while (j < n) { acc += R.id_off[j + 1] - R.id_off[j]; ++j; if (acc >= (2u << 21)) break; }       // in_reads.cpp:50-56,93-101
-			std::vector<uint64_t> off(j - i + 1);
-			for (uint32_t t = i; t <= j; ++t) off[t - i] = R.id_off[t] - R.id_off[i];
-			std::vector<uint8_t> out(2 * (size_t)off.back() + 64); uint64_t got = 0;
-			if (cl_id_encode_part(idc, R.ids.data() + R.id_off[i], off.data(), R.plus.data() + i, j - i, out.data(), out.size(), &got) != CL_OK) { hdr_err = cl_id_coder_error(idc); break; }
-			out.resize(got); hdr_parts.push_back(std::move(out)); hdr_counts.push_back(j - i);
-			i = j;
-		}
-		cl_id_coder_free(idc);
-	});
+	std::thread hdr([&]() { code_headers(R, n, O.header_mode, hdr_parts, hdr_counts, hdr_err); });
 	cl_kmer_stats ks{};
 	ck(ctx, cl_compressor_count_finish(cmp, &ks), "k-mer counting");
 	lap("k-mers counted");
@@ -679,36 +1021,13 @@ int run_compress(int argc, char** argv)
 	// meta (compression.cpp:704-779), info (utils.cpp:326-342)
 	uint32_t tot_ref = n + n_pseudo;
 	if (P.sparse) { std::vector<uint8_t> acc((size_t)n + n_pseudo); ck(ctx, cl_ref_accept(n, n_pseudo, sparse_range, O.exponent, acc.data()), "cl_ref_accept"); tot_ref = 0; for (uint8_t x : acc) tot_ref += x; }
-	std::vector<uint8_t> meta;
-	le<uint32_t>(meta, tot_ref); le<uint32_t>(meta, P.c); le<int32_t>(meta, P.level); meta.push_back((uint8_t)O.source);
-	le<uint64_t>(meta, (uint64_t)n * mean_read_len);
-	if (with_qual)
-	{
-		meta.push_back((uint8_t)P.qual_mode);
-		if (P.qual_mode == 8 || (P.qual_mode >= 4 && P.qual_mode <= 6)) for (uint32_t v : qd.rev) le<uint32_t>(meta, v);
-	}
-	meta.push_back((uint8_t)O.header_mode);
-	meta.push_back(P.sparse ? 1 : 0);                                    // ReferenceReadsMode: All = 0, Sparse = 1
-	if (P.sparse) { le<uint32_t>(meta, sparse_range); le_double(meta, O.exponent); }
-	meta.push_back(with_genome ? 1 : 0);                                 // compression.cpp:764-777
-	if (with_genome)
-	{
-		meta.push_back(O.store_genome ? 1 : 0);
-		le<uint32_t>(meta, genome_read_len); le<uint32_t>(meta, genome_overlap); le<uint32_t>(meta, n_pseudo);
-		if (!O.store_genome)
-		{	// the decompressor will ask for the same genome (md5 of its packed sequences)
-			uint8_t md[16];
-			if (cl_genome_md5(G.codes.data(), G.off.data(), (uint32_t)(G.off.size() - 1), md) != CL_OK) die("cannot checksum the reference genome");
-			meta.insert(meta.end(), md, md + 16);
-		}
-	}
+	uint8_t md[16] = { 0 };
+	if (with_genome && !O.store_genome && cl_genome_md5(G.codes.data(), G.off.data(), (uint32_t)(G.off.size() - 1), md) != CL_OK) die("cannot checksum the reference genome");
+	const std::vector<uint8_t> meta = pack_meta(MetaIn{ n, n_pseudo, tot_ref, P.c, P.level, O.source, mean_read_len, with_qual, P.qual_mode, qd.rev, O.header_mode, P.sparse != 0, sparse_range, O.exponent,
+	                                                    with_genome, O.store_genome, genome_read_len, genome_overlap, md });
 	ar.add(s_meta, meta.data(), meta.size(), 0);
 	const int s_info = ar.reg("info");
-	std::vector<uint8_t> inf;
-	le<uint32_t>(inf, 1); le<uint32_t>(inf, 2); le<uint32_t>(inf, 1);                        // archive format of CoLoRd 1.2.1 (defs.h:24-26)
-	le<uint64_t>(inf, R.total_bytes); le<uint64_t>(inf, total); le<uint32_t>(inf, n); le<uint64_t>(inf, (uint64_t)time(nullptr));
-	std::string cmd; for (int i = 0; i < argc; ++i) { if (i) cmd += ' '; cmd += argv[i]; }
-	le<uint32_t>(inf, (uint32_t)cmd.size()); inf.insert(inf.end(), cmd.begin(), cmd.end());
+	const std::vector<uint8_t> inf = pack_info(R.total_bytes, total, n, argc, argv);
 	ar.add(s_info, inf.data(), inf.size(), 0);
 	ar.close();
 	gzclose(R.g);

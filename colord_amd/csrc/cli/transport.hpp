@@ -1,0 +1,165 @@
+// transport.hpp — the collectives behind cl_exchange (include/colord_hip.h) for the multi-GPU host of the command-line compressor:
+// one host THREAD per GPU in one process (the reference's orchestrator is one C++ process too, compression.cpp:547-689).
+//   RcclTransport  RCCL directly (librccl: ncclCommInitAll, one communicator and one stream per rank thread): the v-collectives as ONE
+//                  group of point-to-point sends / receives per call (xGMI is point to point: a grouped send / recv pattern is what its
+//                  rings carry anyway), no padding to the largest shard, one stream synchronisation per call;
+//   HostTransport  the same three calls through pinned host staging buffers and a barrier of the rank threads: any rank -> device map,
+//                  several ranks on ONE GPU included (RCCL refuses that) — what the tests on a one-GPU box drive, and a fallback where
+//                  peer access is not to be had.
+// The library says WHAT is exchanged (csrc/stream.hip); these classes only move bytes.
+#pragma once
+#include "colord_hip.h"
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+struct Transport {
+	uint32_t rank = 0, world = 1; std::string err; uint64_t bytes_moved = 0;
+	virtual ~Transport() {}
+	virtual cl_status all_gather_host(const uint64_t* h_vals, uint32_t n, uint64_t* h_out) = 0;
+	virtual cl_status all_to_all_v(const void* d_send, const uint64_t* h_send_bytes, void* d_recv, const uint64_t* h_recv_bytes) = 0;
+	virtual cl_status all_gather_v(const void* d_send, uint64_t send_bytes, void* d_recv, const uint64_t* h_recv_bytes) = 0;
+	cl_status fail(const std::string& m) { err = m; return CL_E_HIP; }
+	// the three callbacks of cl_exchange over `this`
+	static cl_status cb_gather_host(void* u, const uint64_t* v, uint32_t n, uint64_t* o) { return ((Transport*)u)->all_gather_host(v, n, o); }
+	static cl_status cb_all_to_all_v(void* u, const void* s, const uint64_t* sb, void* r, const uint64_t* rb) { return ((Transport*)u)->all_to_all_v(s, sb, r, rb); }
+	static cl_status cb_all_gather_v(void* u, const void* s, uint64_t sb, void* r, const uint64_t* rb) { return ((Transport*)u)->all_gather_v(s, sb, r, rb); }
+	cl_exchange exchange() { cl_exchange x; memset(&x, 0, sizeof(x)); x.user = this; x.rank = rank; x.world = world; x.all_gather_host = cb_gather_host; x.all_to_all_v = cb_all_to_all_v; x.all_gather_v = cb_all_gather_v; return x; }
+};
+
+// ---- RCCL ---------------------------------------------------------------------------------------------------------------------
+struct RcclTransport : Transport {
+	ncclComm_t comm = nullptr; hipStream_t stream = nullptr; int device = 0;
+	uint64_t* d_small = nullptr; uint64_t small_cap = 0;                       // staging of all_gather_host
+	cl_status init(ncclComm_t c, int dev, uint32_t r, uint32_t w)
+	{
+		comm = c; device = dev; rank = r; world = w;
+		if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return fail("RCCL transport: no stream");
+		return CL_OK;
+	}
+	~RcclTransport() override { if (d_small) (void)hipFree(d_small); if (stream) (void)hipStreamDestroy(stream); }
+	cl_status nc(ncclResult_t r, const char* what) { if (r == ncclSuccess) return CL_OK; return fail(std::string(what) + ": " + ncclGetErrorString(r)); }
+	cl_status all_gather_host(const uint64_t* h_vals, uint32_t n, uint64_t* h_out) override
+	{
+		(void)hipSetDevice(device);
+		const uint64_t need = (uint64_t)n * (world + 1);
+		if (need > small_cap) { if (d_small) (void)hipFree(d_small); small_cap = need + 1024; if (hipMalloc((void**)&d_small, small_cap * 8) != hipSuccess) return fail("RCCL transport: hipMalloc"); }
+		if (n && hipMemcpyAsync(d_small, h_vals, (uint64_t)n * 8, hipMemcpyHostToDevice, stream) != hipSuccess) return fail("RCCL transport: copy in");
+		if (n) { const cl_status s = nc(ncclAllGather(d_small, d_small + n, (size_t)n * 8, ncclChar, comm, stream), "ncclAllGather"); if (s != CL_OK) return s; }
+		if (n && hipMemcpyAsync(h_out, d_small + n, (uint64_t)n * 8 * world, hipMemcpyDeviceToHost, stream) != hipSuccess) return fail("RCCL transport: copy out");
+		if (hipStreamSynchronize(stream) != hipSuccess) return fail("RCCL transport: synchronise");
+		return CL_OK;
+	}
+	cl_status all_to_all_v(const void* d_send, const uint64_t* sb, void* d_recv, const uint64_t* rb) override
+	{
+		(void)hipSetDevice(device);
+		cl_status s = nc(ncclGroupStart(), "ncclGroupStart");
+		uint64_t so = 0, ro = 0;
+		for (uint32_t p = 0; p < world && s == CL_OK; ++p)
+		{	// (the share for itself travels as a send / recv pair too: one code path, RCCL makes it a local copy)
+			if (sb[p]) s = nc(ncclSend((const char*)d_send + so, (size_t)sb[p], ncclChar, (int)p, comm, stream), "ncclSend");
+			if (s == CL_OK && rb[p]) s = nc(ncclRecv((char*)d_recv + ro, (size_t)rb[p], ncclChar, (int)p, comm, stream), "ncclRecv");
+			so += sb[p]; ro += rb[p]; bytes_moved += p == rank ? 0 : sb[p];
+		}
+		const cl_status e = nc(ncclGroupEnd(), "ncclGroupEnd");
+		if (s == CL_OK) s = e;
+		if (s == CL_OK && hipStreamSynchronize(stream) != hipSuccess) s = fail("RCCL transport: synchronise");
+		return s;
+	}
+	cl_status all_gather_v(const void* d_send, uint64_t send_bytes, void* d_recv, const uint64_t* rb) override
+	{
+		(void)hipSetDevice(device);
+		if (rb[rank] != send_bytes) return fail("all_gather_v: send_bytes != h_recv_bytes[rank]");
+		cl_status s = nc(ncclGroupStart(), "ncclGroupStart");
+		uint64_t ro = 0;
+		for (uint32_t p = 0; p < world && s == CL_OK; ++p)
+		{
+			if (send_bytes) s = nc(ncclSend(d_send, (size_t)send_bytes, ncclChar, (int)p, comm, stream), "ncclSend");
+			if (s == CL_OK && rb[p]) s = nc(ncclRecv((char*)d_recv + ro, (size_t)rb[p], ncclChar, (int)p, comm, stream), "ncclRecv");
+			ro += rb[p]; bytes_moved += p == rank ? 0 : send_bytes;
+		}
+		const cl_status e = nc(ncclGroupEnd(), "ncclGroupEnd");
+		if (s == CL_OK) s = e;
+		if (s == CL_OK && hipStreamSynchronize(stream) != hipSuccess) s = fail("RCCL transport: synchronise");
+		return s;
+	}
+};
+
+// ---- host staging ----------------------------------------------------------------------------------------------------------------
+struct HostHub {
+	uint32_t world; std::mutex mu; std::condition_variable cv; uint32_t arrived = 0; uint64_t epoch = 0;
+	std::vector<std::vector<uint64_t>> small;                                  // per rank: what it contributes to all_gather_host
+	std::vector<uint8_t*> stage; std::vector<uint64_t> stage_cap; std::vector<std::vector<uint64_t>> counts;   // per rank: pinned copy of its send buffer, bytes per destination
+	explicit HostHub(uint32_t w) : world(w), small(w), stage(w, nullptr), stage_cap(w, 0), counts(w) {}
+	~HostHub() { for (uint8_t* p : stage) if (p) (void)hipHostFree(p); }
+	void barrier()
+	{
+		std::unique_lock<std::mutex> l(mu);
+		const uint64_t e = epoch;
+		if (++arrived == world) { arrived = 0; ++epoch; cv.notify_all(); }
+		else cv.wait(l, [&] { return epoch != e; });
+	}
+};
+struct HostTransport : Transport {
+	HostHub* hub = nullptr; int device = 0;
+	void init(HostHub* h, int dev, uint32_t r) { hub = h; device = dev; rank = r; world = h->world; }
+	cl_status publish(const void* d_send, uint64_t bytes)
+	{
+		(void)hipSetDevice(device);
+		if (bytes > hub->stage_cap[rank])
+		{
+			if (hub->stage[rank]) (void)hipHostFree(hub->stage[rank]);
+			hub->stage[rank] = nullptr; hub->stage_cap[rank] = 0;
+			void* p = nullptr;
+			if (hipHostMalloc(&p, bytes + bytes / 4 + 4096, hipHostMallocPortable) != hipSuccess) return fail("host transport: hipHostMalloc");
+			hub->stage[rank] = (uint8_t*)p; hub->stage_cap[rank] = bytes + bytes / 4 + 4096;
+		}
+		if (bytes && hipMemcpy(hub->stage[rank], d_send, bytes, hipMemcpyDeviceToHost) != hipSuccess) return fail("host transport: copy to host");
+		return CL_OK;
+	}
+	cl_status all_gather_host(const uint64_t* h_vals, uint32_t n, uint64_t* h_out) override
+	{
+		hub->small[rank].assign(h_vals, h_vals + n);
+		hub->barrier();
+		for (uint32_t p = 0; p < world; ++p) { if (hub->small[p].size() != n) return fail("all_gather_host: ranks disagree on n"); memcpy(h_out + (uint64_t)p * n, hub->small[p].data(), (uint64_t)n * 8); }
+		hub->barrier();                                                         // (nobody overwrites its contribution before everybody has read it)
+		return CL_OK;
+	}
+	cl_status all_to_all_v(const void* d_send, const uint64_t* sb, void* d_recv, const uint64_t* rb) override
+	{
+		uint64_t tot = 0; for (uint32_t p = 0; p < world; ++p) tot += sb[p];
+		cl_status s = publish(d_send, tot);
+		hub->counts[rank].assign(sb, sb + world);
+		hub->barrier();
+		(void)hipSetDevice(device);
+		uint64_t ro = 0;
+		for (uint32_t p = 0; p < world && s == CL_OK; ++p)
+		{	// what rank p holds for this rank: behind its shares for the ranks before this one
+			uint64_t so = 0; for (uint32_t q = 0; q < rank; ++q) so += hub->counts[p][q];
+			if (hub->counts[p][rank] != rb[p]) { s = fail("all_to_all_v: ranks disagree on a share's size"); break; }
+			if (rb[p] && hipMemcpy((char*)d_recv + ro, hub->stage[p] + so, rb[p], hipMemcpyHostToDevice) != hipSuccess) s = fail("host transport: copy to device");
+			ro += rb[p]; bytes_moved += p == rank ? 0 : rb[p];
+		}
+		hub->barrier();
+		return s;
+	}
+	cl_status all_gather_v(const void* d_send, uint64_t send_bytes, void* d_recv, const uint64_t* rb) override
+	{
+		if (rb[rank] != send_bytes) return fail("all_gather_v: send_bytes != h_recv_bytes[rank]");
+		cl_status s = publish(d_send, send_bytes);
+		hub->barrier();
+		(void)hipSetDevice(device);
+		uint64_t ro = 0;
+		for (uint32_t p = 0; p < world && s == CL_OK; ++p)
+		{
+			if (rb[p] && hipMemcpy((char*)d_recv + ro, hub->stage[p], rb[p], hipMemcpyHostToDevice) != hipSuccess) s = fail("host transport: copy to device");
+			ro += rb[p]; bytes_moved += p == rank ? 0 : rb[p];
+		}
+		hub->barrier();
+		return s;
+	}
+};

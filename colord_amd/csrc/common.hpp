@@ -330,6 +330,7 @@ struct cl_ctx {
 	std::vector<hipEvent_t> ev_pool;
 	int n_cu = 256;
 	uint64_t* inv_tab = nullptr;                 // floor((2^64-1) / t) for t < 2^21: the interval coder's division table (rc_dev.hpp), made at first use
+	uint64_t* slots_h = nullptr; uint64_t* slots_d = nullptr; uint32_t slot_next = 0;   // pinned, device-mapped words that kernels write results the host waits for into (cl_slot)
 	std::vector<cl_ctx*> lanes;                  // encode lanes of cl_compressor (contexts of their own; kept for the next compressor, freed with this context)
 	cl_ctx* prep = nullptr;                      // context of cl_compressor's DNA preparation thread (same life cycle)
 	cl_ctx* qprep = nullptr;                     // ... and of its quality preparation thread
@@ -371,6 +372,31 @@ template<typename T> hipError_t DevBuf<T>::alloc(cl_ctx* c, uint64_t count)
 	if ((buf).bytes >= (1ull << 30) && cl_pool_debug()) fprintf(stderr, "[pool] %s:%d %s %.2f GB (live %.1f GB)\n", &__FILE__[sizeof(__FILE__) > 24 ? sizeof(__FILE__) - 24 : 0], __LINE__, #buf, (buf).bytes / 1e9, (ctx)->pool.live_bytes / 1e9); \
 	if (_e != hipSuccess) \
 	return cl_fail((ctx), CL_E_NOMEM, std::string("hipMalloc(" #buf ") of ") + std::to_string((uint64_t)(count)) + " elems: " + hipGetErrorString(_e)); } while (0)
+
+// Small results the host waits for (a scan's total, a level's class bounds, a counter): kernels write them straight into pinned host
+// memory that is mapped into the device's address space, and the host reads them after synchronising the stream — no copy command
+// (a D2H copy into pageable memory is a dispatch of its own plus a staged transfer: ~1 ms each with six threads in the runtime, 1 700
+// of them per encode lane and pass in round 3).  Slots go round a ring of 4096 words; a user synchronises before it reads, long
+// before the ring comes round.  Owner thread only.
+static inline hipError_t cl_slot(cl_ctx* c, uint32_t n_words, uint64_t** h, uint64_t** d)
+{
+	constexpr uint32_t RING = 4096;
+	if (!c->slots_h)
+	{
+		void* p = nullptr; void* dp = nullptr;
+		hipError_t e = hipHostMalloc(&p, RING * 8, hipHostMallocMapped);
+		if (e != hipSuccess) return e;
+		e = hipHostGetDevicePointer(&dp, p, 0);
+		if (e != hipSuccess) { (void)hipHostFree(p); return e; }
+		memset(p, 0, RING * 8);
+		c->slots_h = (uint64_t*)p; c->slots_d = (uint64_t*)dp;
+	}
+	if (n_words > RING) return hipErrorInvalidValue;
+	if (c->slot_next + n_words > RING) c->slot_next = 0;
+	*h = c->slots_h + c->slot_next; *d = c->slots_d + c->slot_next;
+	c->slot_next += n_words;
+	return hipSuccess;
+}
 
 // ---- per-kernel timing with HIP events on the stream of the launch --------------------------------
 static inline hipStream_t cl_launch_stream(const cl_ctx* c) { return c->launch ? c->launch : c->stream; }

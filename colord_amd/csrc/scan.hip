@@ -63,7 +63,7 @@ constexpr uint32_t LB_ITEMS = 16, LB_TILE = SCAN_THREADS * LB_ITEMS;
 constexpr unsigned long long LB_AGG = 1ull << 62, LB_PREFIX = 2ull << 62, LB_VAL = (1ull << 62) - 1;
 // ctl[0]: ticket, ctl[1..]: status of tile 0, 1, ... (zeroed before the launch).  total_out (optional): receives the sum of all.
 template<typename TIn, typename TOut>
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_lookback(const TIn* in, uint64_t n, TOut* out, unsigned long long* __restrict__ ctl, TOut* total_out)
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_lookback(const TIn* in, uint64_t n, TOut* out, unsigned long long* __restrict__ ctl, TOut* total_out, TOut* total_out2)
 {
 	__shared__ TOut sh[4];
 	__shared__ unsigned long long s_excl;
@@ -112,17 +112,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_lookback(const TIn* in, u
 	pre += (TOut)s_excl;
 #pragma unroll
 	for (uint32_t i = 0; i < LB_ITEMS; ++i) { if (base + i < n) out[base + i] = pre; pre += v[i]; }
-	if (total_out && (uint64_t)(tile + 1) * LB_TILE >= n && threadIdx.x == SCAN_THREADS - 1) *total_out = pre;    // (the last thread of the last tile has walked to the end)
+	if ((uint64_t)(tile + 1) * LB_TILE >= n && threadIdx.x == SCAN_THREADS - 1) { if (total_out) *total_out = pre; if (total_out2) *total_out2 = pre; }    // (the last thread of the last tile has walked to the end)
 }
 
 template<typename TIn, typename TOut>
-cl_status scan_lookback(cl_ctx* ctx, const TIn* d_in, TOut* d_out, uint64_t n, TOut* d_total)
+cl_status scan_lookback(cl_ctx* ctx, const TIn* d_in, TOut* d_out, uint64_t n, TOut* d_total, TOut* d_total2 = nullptr)
 {
 	const uint32_t tiles = grid_for(n, LB_TILE);
 	DevBuf<unsigned long long> ctl; DEV_ALLOC(ctx, ctl, (uint64_t)tiles + 1);
 	hipStream_t st = cl_launch_stream(ctx);
 	HIP_TRY(ctx, hipMemsetAsync(ctl.p, 0, ((uint64_t)tiles + 1) * 8, st));
-	LAUNCH(ctx, (k_scan_lookback<TIn, TOut>), tiles, SCAN_THREADS, d_in, n, d_out, ctl.p, d_total);
+	LAUNCH(ctx, (k_scan_lookback<TIn, TOut>), tiles, SCAN_THREADS, d_in, n, d_out, ctl.p, d_total, d_total2);
 	HIP_TRY(ctx, hipGetLastError());
 	return CL_OK;                                                                // (ctl goes back to the pool: the context's own stream order protects it)
 }
@@ -170,14 +170,13 @@ cl_status dev_exclusive_scan_u32(cl_ctx* ctx, uint32_t* d_data, uint64_t n, uint
 		}
 		return CL_OK;
 	}
-	DevBuf<uint32_t> tot; if (h_total) DEV_ALLOC(ctx, tot, 1);
-	CL_TRY((scan_lookback<uint32_t, uint32_t>(ctx, d_data, d_data, n, h_total ? tot.p : nullptr)));
+	uint64_t* hs = nullptr; uint64_t* ds = nullptr;
+	if (h_total) HIP_TRY(ctx, cl_slot(ctx, 1, &hs, &ds));                      // (the total goes straight to mapped host memory)
+	CL_TRY((scan_lookback<uint32_t, uint32_t>(ctx, d_data, d_data, n, (uint32_t*)ds)));
 	if (h_total)
 	{
-		uint32_t t = 0;
-		HIP_TRY(ctx, hipMemcpyAsync(&t, tot.p, 4, hipMemcpyDeviceToHost, st));
 		HIP_TRY(ctx, hipStreamSynchronize(st));
-		*h_total = t;
+		*h_total = *(volatile uint32_t*)hs;
 	}
 	return CL_OK;
 }
@@ -202,8 +201,10 @@ cl_status dev_exclusive_scan_u64(cl_ctx* ctx, const uint32_t* d_in, uint64_t* d_
 	}
 	if (n)
 	{
-		CL_TRY((scan_lookback<uint32_t, uint64_t>(ctx, d_in, d_out, n, d_out + n)));       // (the total lands in d_out[n])
-		if (h_total) { HIP_TRY(ctx, hipMemcpyAsync(&total, d_out + n, 8, hipMemcpyDeviceToHost, st)); HIP_TRY(ctx, hipStreamSynchronize(st)); }
+		uint64_t* hs = nullptr; uint64_t* ds = nullptr;
+		if (h_total) HIP_TRY(ctx, cl_slot(ctx, 1, &hs, &ds));
+		CL_TRY((scan_lookback<uint32_t, uint64_t>(ctx, d_in, d_out, n, d_out + n, ds)));   // (the total lands in d_out[n] — and in mapped host memory)
+		if (h_total) { HIP_TRY(ctx, hipStreamSynchronize(st)); total = *(volatile uint64_t*)hs; }
 	}
 	else { HIP_TRY(ctx, hipMemsetAsync(d_out, 0, 8, st)); }
 	if (h_total) *h_total = total;

@@ -163,3 +163,44 @@ def test_reference_genome_mode_with_sharded_reads(tmp_path, stored):
     assert a["meta"].parts[0][1] == b["meta"].parts[0][1]                # pseudo-read geometry, reference count, checksum
     one = sum(len(p) for _, p in a["dna"].parts)
     assert sum(len(p) for _, p in b["dna"].parts) < one * 1.5           # a genome-less second rank would lose far more than a model restart
+
+
+# ---- the C++ multi-GPU host: `colord_hip compress-* --gpus N` (csrc/cli/compress.cpp run_compress_multi, cli/transport.hpp) ------------
+def test_cpp_rccl_transport_selftest():
+    """The three collectives behind cl_exchange over RCCL directly (ncclCommInitAll, grouped send / recv): a communicator of ONE rank
+    on this box's one GPU still runs the RCCL code path — uneven and empty shares, every byte checked."""
+    r = subprocess.run([CLI, "rccl-selftest"], capture_output=True, text=True, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), timeout=600)
+    assert r.returncode == 0 and "ok on 1 rank" in r.stdout, r.stderr[-2000:] + r.stdout[-500:]
+
+
+@pytest.mark.parametrize("n_ranks", [2, 3])
+def test_cpp_host_ranks_write_the_archive_of_the_python_driver(tmp_path, n_ranks):
+    """`colord_hip --gpus N --gpu-list 0,0[,0] --transport host` (N rank threads sharing this box's GPU, collectives through pinned host
+    staging) against `python -m colord_amd.mgpu` with N gloo ranks on the same gzip FASTQ: same shares, same exchanges, same model
+    domains -> every stream but `info` byte-identical, `hipdomains` included (each rank pwrites its own parts; the part tables must
+    agree all the same); this build's decompressor returns the reference's output."""
+    import gzip
+    spec = json.load(open(os.path.join(ROOT, "tests", "golden", "s6m_ont", "streams.json")))
+    fq, gz, py_arc, cpp_arc, out = (str(tmp_path / x) for x in ("in.fastq", "in.fastq.gz", "py.colord", "cpp.colord", "cpp.fastq"))
+    write_fastq(fq, make_reads(**spec["synth"]))
+    with open(fq, "rb") as f, gzip.open(gz, "wb", compresslevel=1) as g:
+        g.write(f.read())
+    run_ranks(n_ranks, ["compress-ont", "--chunk-bases", "1.5e6", gz, py_arc], 29640 + n_ranks)
+    r = subprocess.run([CLI, "compress-ont", "--gpus", str(n_ranks), "--gpu-list", ",".join(["0"] * n_ranks), "--transport", "host", "--chunk-bases", "1.5e6", gz, cpp_arc], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    a, b = AR.read_archive(py_arc), AR.read_archive(cpp_arc)
+    assert set(a) == set(b) and "hipdomains" in b
+    for name in a:
+        if name != "info":
+            assert [(m, hashlib.sha256(p).hexdigest()) for m, p in a[name].parts] == [(m, hashlib.sha256(p).hexdigest()) for m, p in b[name].parts], name
+    subprocess.check_call([CLI, "decompress", cpp_arc, out])
+    assert sha(out) == spec["decompressed_sha256"]
+    # the same reads from the plain file through the indexed (multi-threaded) reader: the same archive
+    cpp2 = str(tmp_path / "cpp_plain.colord")
+    r = subprocess.run([CLI, "compress-ont", "-k", "20", "-a", "16", "--gpus", str(n_ranks), "--gpu-list", ",".join(["0"] * n_ranks), "--transport", "host", "--chunk-bases", "1.5e6", fq, cpp2],
+                       capture_output=True, text=True, timeout=1500, env=dict(os.environ, COLORD_HIP_INDEX_MIN_BYTES="1000"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    c = AR.read_archive(cpp2)
+    for name in b:
+        if name != "info":
+            assert [(m, hashlib.sha256(p).hexdigest()) for m, p in b[name].parts] == [(m, hashlib.sha256(p).hexdigest()) for m, p in c[name].parts], name
