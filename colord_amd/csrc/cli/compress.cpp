@@ -585,7 +585,7 @@ static int run_compress_multi(const Options& O, const Preset& P, const QDef& qd,
 		hub = std::make_unique<HostHub>(world);
 		for (uint32_t r = 0; r < world; ++r) { auto t = std::make_unique<HostTransport>(); t->init(hub.get(), devs[r], r); tp[r] = std::move(t); }
 	}
-	const int fd = ::open(O.out.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+	const int fd = ::open(O.out.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
 	if (fd < 0) die("cannot open file: " + O.out);
 	std::vector<RankOut> out(world);
 	auto rank_main = [&](uint32_t rank) {
