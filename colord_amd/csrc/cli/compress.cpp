@@ -68,6 +68,7 @@ struct Options {
 	double chunk_bases = 1.0e9;
 	uint64_t part_symbols = 2u << 21;               // --part-symbols: the coder parts close once their reads (+ 1 guard each) reach this; default = the reader packs (defs.h:45)
 	int parse_threads = 0;                          // --parse-threads (0: as many as the host offers, at most 32)
+	int domains = 1;                                // --domains K: K INDEPENDENT model domains on one GPU (own k-mer set, references, index, models each): decoded side by side
 	int gpus = 1; std::vector<int> gpu_list; std::string transport = "rccl";   // --gpus N [--gpu-list a,b,..] [--transport rccl|host]: reads sharded over N GPUs (run_compress_multi)
 };
 
@@ -444,6 +445,8 @@ static void usage()
 		"  --part-symbols N   coder parts of N symbols instead of the reference's 4194304 (defs.h:45): same FASTQ back from either\n"
 		"                     decompressor, 8 more bytes per part, far shorter interval-coder chains (65536: +0.04 %% size, 1.4x the speed)\n"
 		"  --parse-threads N  threads that index a plain FASTQ (default: the host's, at most 32)\n"
+		"  --domains K        K independent model domains (equal shares of the reads, each compressed on its own): `colord_hip decompress`\n"
+		"                     decodes them side by side; costs archive size (own k-mer statistics and reference reads per domain)\n"
 		"  --gpus N [--gpu-list a,b,..] [--transport rccl|host]   reads sharded over N GPUs, one host thread and one model domain per GPU;\n"
 		"                     the k-mer set, reference reads and index are replicated through RCCL (or host staging: several ranks per GPU)\n");
 }
@@ -498,7 +501,7 @@ struct Source {                                    // the whole input as records
 struct RankOut {
 	std::vector<uint8_t> dna, qual; std::vector<uint64_t> dsz, qsz; std::vector<uint32_t> counts;      // this rank's parts, in order
 	uint64_t n_reads = 0, n_bases = 0, mean_read_len = 0; uint32_t sparse_range = 0, n_refs = 0; cl_kmer_stats ks{}; size_t n_chunks = 0;
-	uint64_t dna_base = 0, qual_base = 0;          // where its framed `dna` / `qual` parts start in the file
+	uint64_t dna_base = 0, qual_base = 0, qual_framed = 0;     // where its framed `dna` / `qual` parts start in the file; bytes of the latter
 	uint64_t moved = 0;
 };
 uint32_t varint_len(uint64_t x) { uint32_t n = 1; for (; x; x >>= 8) ++n; return n; }
@@ -508,14 +511,16 @@ static int run_compress_multi(const Options& O, const Preset& P, const QDef& qd,
 {
 	const auto t0 = std::chrono::steady_clock::now();
 	auto lap = [&](const char* what) { if (O.verbose) fprintf(stderr, "[%7.2f s] %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), what); };
-	const uint32_t world = (uint32_t)O.gpus;
+	const bool independent = O.domains > 1;             // --domains K: the shares are compressed one after the other on one GPU, nothing is exchanged
+	const uint32_t world = independent ? (uint32_t)O.domains : (uint32_t)O.gpus;
 	std::vector<int> devs = O.gpu_list;
+	if (independent) devs.assign(world, O.gpu);
 	if (devs.empty()) for (int i = 0; i < O.gpus; ++i) devs.push_back(i);
 	if (devs.size() != world) die("--gpu-list must name --gpus devices");
 	int n_dev = 0; hipck(hipGetDeviceCount(&n_dev), "hipGetDeviceCount");
 	for (int d : devs) if (d < 0 || d >= n_dev) die("--gpus / --gpu-list: no such device");
 	if (!O.genome.empty()) die("-G,--reference-genome with --gpus > 1: use `python -m colord_amd.mgpu` (the C++ multi-GPU host has no reference-genome mode yet)");
-	const bool use_rccl = O.transport == "rccl";
+	const bool use_rccl = !independent && O.transport == "rccl";
 	if (use_rccl) { std::vector<int> u = devs; std::sort(u.begin(), u.end()); if (std::adjacent_find(u.begin(), u.end()) != u.end()) die("--transport rccl needs distinct devices (several ranks on one GPU: --transport host)"); }
 
 	// the input, once
@@ -574,7 +579,8 @@ static int run_compress_multi(const Options& O, const Preset& P, const QDef& qd,
 	std::vector<std::unique_ptr<Transport>> tp(world);
 	std::vector<ncclComm_t> comms(world, nullptr);
 	std::unique_ptr<HostHub> hub;
-	if (use_rccl)
+	if (independent) {}
+	else if (use_rccl)
 	{
 		const ncclResult_t e = ncclCommInitAll(comms.data(), (int)world, devs.data());
 		if (e != ncclSuccess) die(std::string("ncclCommInitAll: ") + ncclGetErrorString(e));
@@ -589,15 +595,15 @@ static int run_compress_multi(const Options& O, const Preset& P, const QDef& qd,
 	if (fd < 0) die("cannot open file: " + O.out);
 	std::vector<RankOut> out(world);
 	auto rank_main = [&](uint32_t rank) {
-		Transport& T = *tp[rank]; RankOut& RO = out[rank];
+		Transport* const T = tp[rank].get(); RankOut& RO = out[rank];
 		hipck(hipSetDevice(devs[rank]), "hipSetDevice");
 		cl_ctx* ctx = nullptr; cl_ctx* qctx = nullptr;
 		ck(nullptr, cl_ctx_create(devs[rank], &ctx), "cl_ctx_create"); ck(nullptr, cl_ctx_create(devs[rank], &qctx), "cl_ctx_create");
 		const uint64_t r0 = first[rank], r1 = first[rank + 1];
 		uint64_t my_bases = 0; for (uint64_t i = r0; i < r1; ++i) my_bases += S.len(i);
-		cl_exchange X = T.exchange();
+		cl_exchange X; if (T) X = T->exchange();
 		cl_compressor* cmp = nullptr;
-		ck(ctx, cl_compressor_create(ctx, qctx, &cp, with_qual ? &qp : nullptr, &X, my_bases, &cmp), "cl_compressor_create");
+		ck(ctx, cl_compressor_create(ctx, qctx, &cp, with_qual ? &qp : nullptr, T ? &X : nullptr, my_bases, &cmp), "cl_compressor_create");
 		// chunks of whole reader packs (the packs are cut from this rank's first read on: in_reads.cpp:62-77)
 		std::vector<DevChunk> chunks; Chunk host;
 		Reader B; B.part_symbols = O.part_symbols;                            // (its pack / part bookkeeping only)
@@ -656,10 +662,19 @@ static int run_compress_multi(const Options& O, const Preset& P, const QDef& qd,
 		uint64_t mine[2] = { 0, 0 };
 		for (size_t p = 0; p < RO.dsz.size(); ++p) mine[0] += varint_len(RO.counts[p]) + RO.dsz[p];
 		for (size_t p = 0; p < RO.qsz.size(); ++p) mine[1] += varint_len(0) + RO.qsz[p];
-		std::vector<uint64_t> all(2 * (size_t)world);
-		ck(ctx, T.all_gather_host(mine, 2, all.data()), "all-gather of the stream sizes");
-		uint64_t dna_all = 0; for (uint32_t r = 0; r < world; ++r) { if (r == rank) RO.dna_base = dna_all; dna_all += all[2 * r]; }
-		uint64_t q = dna_all; for (uint32_t r = 0; r < world; ++r) { if (r == rank) RO.qual_base = q; q += all[2 * r + 1]; }
+		if (T)
+		{
+			std::vector<uint64_t> all(2 * (size_t)world);
+			ck(ctx, T->all_gather_host(mine, 2, all.data()), "all-gather of the stream sizes");
+			uint64_t dna_all = 0; for (uint32_t r = 0; r < world; ++r) { if (r == rank) RO.dna_base = dna_all; dna_all += all[2 * r]; }
+			uint64_t q = dna_all; for (uint32_t r = 0; r < world; ++r) { if (r == rank) RO.qual_base = q; q += all[2 * r + 1]; }
+		}
+		else
+		{	// independent domains run one after the other: a domain's parts follow those of the domains before it
+			uint64_t at = 0; for (uint32_t r = 0; r < rank; ++r) at = out[r].qual_base + out[r].qual_framed;
+			RO.dna_base = at; RO.qual_base = at + mine[0];
+		}
+		RO.qual_framed = mine[1];
 		auto write_parts = [&](uint64_t at, const std::vector<uint8_t>& data, const std::vector<uint64_t>& sz, bool counted) {
 			std::vector<uint8_t> buf; uint64_t o = 0;
 			for (size_t p = 0; p < sz.size(); ++p)
@@ -676,13 +691,17 @@ static int run_compress_multi(const Options& O, const Preset& P, const QDef& qd,
 		};
 		write_parts(RO.dna_base, RO.dna, RO.dsz, true);
 		if (with_qual) write_parts(RO.qual_base, RO.qual, RO.qsz, false);
-		RO.moved = T.bytes_moved;
+		RO.moved = T ? T->bytes_moved : 0;
 		cl_compressor_free(cmp);
 		cl_ctx_destroy(qctx); cl_ctx_destroy(ctx);
 	};
-	std::vector<std::thread> th;
-	for (uint32_t r = 0; r < world; ++r) th.emplace_back(rank_main, r);
-	for (auto& t : th) t.join();
+	if (independent) for (uint32_t r = 0; r < world; ++r) rank_main(r);
+	else
+	{
+		std::vector<std::thread> th;
+		for (uint32_t r = 0; r < world; ++r) th.emplace_back(rank_main, r);
+		for (auto& t : th) t.join();
+	}
 	lap("all ranks through (parts written)");
 	hdr.join();
 	if (!hdr_err.empty()) die("header stream: " + hdr_err);
@@ -701,7 +720,9 @@ static int run_compress_multi(const Options& O, const Preset& P, const QDef& qd,
 	ar.add(s_meta, meta.data(), meta.size(), 0);
 	for (size_t p = 0; p < hdr_parts.size(); ++p) ar.add(s_header, hdr_parts[p].data(), hdr_parts[p].size(), hdr_counts[p]);
 	// part tables of the streams the ranks wrote, and the model domains (first read, first `dna` part of every rank)
-	std::vector<uint8_t> dom; le<uint32_t>(dom, world);
+	// (bit 31 of the count: INDEPENDENT domains — each has its own reference reads, so each decodes with a decoder of its own and its
+	// own sparse range, appended below; cli/reader.hpp)
+	std::vector<uint8_t> dom; le<uint32_t>(dom, world | (independent ? 0x80000000u : 0u));
 	uint64_t first_read = 0, dna_total = 0, qual_total = 0;
 	for (uint32_t r = 0; r < world; ++r)
 	{
@@ -714,6 +735,7 @@ static int run_compress_multi(const Options& O, const Preset& P, const QDef& qd,
 		first_read += RO.n_reads;
 	}
 	if (first_read != n) die("internal: the ranks' reads do not add up");
+	if (independent) for (uint32_t r = 0; r < world; ++r) le<uint32_t>(dom, out[r].sparse_range);
 	ar.add(s_dom, dom.data(), dom.size(), 0);
 	const int s_info = ar.reg("info");
 	const std::vector<uint8_t> inf = pack_info(R.total_bytes, total, (uint32_t)n, argc, argv);
@@ -817,6 +839,7 @@ int run_compress(int argc, char** argv)
 		else if (a == "-s" || a == "--store-reference") O.store_genome = true;
 		else if (a == "--gpu") O.gpu = atoi(need(i).c_str());
 		else if (a == "--gpus") { O.gpus = atoi(need(i).c_str()); if (O.gpus < 1 || O.gpus > 64) die("--gpus must be in [1, 64]"); }
+		else if (a == "--domains") { O.domains = atoi(need(i).c_str()); if (O.domains < 1 || O.domains > 1024) die("--domains must be in [1, 1024]"); }
 		else if (a == "--gpu-list") { for (uint32_t v : list_u32(need(i))) O.gpu_list.push_back((int)v); }
 		else if (a == "--transport") { O.transport = need(i); if (O.transport != "rccl" && O.transport != "host") die("--transport must be rccl or host"); }
 		else if (a == "--chunk-bases") O.chunk_bases = atof(need(i).c_str());
@@ -851,7 +874,8 @@ int run_compress(int argc, char** argv)
 	if (O.has_D) { if (qd.rev.empty()) die(std::string("-D,--qual-values is not allowed for '") + qnames[P.qual_mode] + "' quality mode"); if (O.D.size() != qd.rev.size()) die(std::string("for '") + qnames[P.qual_mode] + "' quality compression mode expected number of quality values is " + std::to_string(qd.rev.size()) + ", but " + std::to_string(O.D.size()) + " given."); qd.rev = O.D; }
 	for (size_t i = 0; i < qd.fwd.size(); ++i) if (qd.fwd[i] > 95 || (i && qd.fwd[i] < qd.fwd[i - 1])) die("quality thresholds must be ascending values in [0, 95]");
 	if (!O.gpu_list.empty() && O.gpus == 1) O.gpus = (int)O.gpu_list.size();
-	if (O.gpus > 1) return run_compress_multi(O, P, qd, argc, argv);
+	if (O.domains > 1 && O.gpus > 1) die("--domains and --gpus exclude each other (every GPU is a model domain already)");
+	if (O.gpus > 1 || O.domains > 1) return run_compress_multi(O, P, qd, argc, argv);
 
 	const auto t0 = std::chrono::steady_clock::now();
 	auto lap = [&](const char* what) { if (O.verbose) fprintf(stderr, "[%7.2f s] %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), what); };

@@ -71,10 +71,49 @@ inline ArchiveInfo parse_info(const std::vector<uint8_t>& b)
 
 struct Record { const uint8_t* header; size_t header_len; const uint8_t* bases; size_t n_bases; const uint8_t* quals; bool plus_is_header; };   // views, valid until the next call
 
+// every id of an archive, decoded once: what the domain-parallel decompressor's workers share (the `header` stream is one coder over
+// the whole file, entr_header.cpp:46-80)
+struct HeaderCache {
+	std::vector<uint8_t> ids; std::vector<uint64_t> off{ 0 }; std::vector<uint8_t> plus; std::string err;
+	void decode_all(const std::string& path)
+	{
+		ArchiveReader ar; if (!ar.open(path)) { err = "cannot open archive: " + path; return; }
+		const int s_hdr = ar.id("header"), s_meta = ar.id("meta");
+		std::vector<uint8_t> mb, in; uint64_t mm = 0, n = 0;
+		cl_id_decoder* c = nullptr;
+		try
+		{
+			if (s_hdr < 0 || s_meta < 0 || !ar.part(s_meta, 0, mb, mm)) throw std::runtime_error("header / meta stream missing");
+			const Meta M = parse_meta(mb, ar.id("qual") >= 0);
+			if (cl_id_decoder_create(M.header_mode, &c) != CL_OK) throw std::runtime_error("cl_id_decoder_create");
+			for (size_t p = 0; p < ar.n_parts(s_hdr); ++p)
+			{
+				if (!ar.part(s_hdr, p, in, n) || n > 0xffffffffull) throw std::runtime_error("cannot read a `header` part");
+				std::vector<uint64_t> o(n + 1); std::vector<uint8_t> pl(n), buf(std::max<uint64_t>(in.size() * 64, 1 << 20)); uint64_t got = 0;
+				cl_status st = cl_id_decode_part(c, in.data(), in.size(), (uint32_t)n, buf.data(), buf.size(), o.data(), pl.data(), &got);
+				if (st == CL_E_CAPACITY) { buf.resize(got); st = cl_id_decode_part(c, in.data(), in.size(), (uint32_t)n, buf.data(), got, o.data(), pl.data(), &got); }
+				if (st != CL_OK) throw std::runtime_error("corrupt `header` part");
+				const uint64_t base = ids.size();
+				ids.insert(ids.end(), buf.begin(), buf.begin() + got); plus.insert(plus.end(), pl.begin(), pl.end());
+				for (uint64_t i = 1; i <= n; ++i) off.push_back(base + o[i]);
+			}
+		}
+		catch (const std::exception& e) { err = e.what(); }
+		if (c) cl_id_decoder_free(c);
+		ar.close();
+	}
+};
+
 class RecordStream {
 	ArchiveReader ar; Meta M; ArchiveInfo I; bool fastq = false, started = false, finished = false;
 	int s_dna = -1, s_qual = -1, s_hdr = -1;
 	std::vector<uint64_t> domain_first_part;                              // first `dna` part of every model domain after the first
+	// INDEPENDENT domains (`colord_hip compress-* --domains K`: bit 31 of the count in `hipdomains`): a domain has its own reference reads,
+	// so it is decoded by a DNA decoder of its own (with its own sparse range) — and K of them side by side (cli/decompress.cpp)
+	bool independent = false; std::vector<uint64_t> dom_part{ 0 }, dom_read{ 0 }; std::vector<uint32_t> dom_sparse;
+	int only_domain = -1; const HeaderCache* ext_hdr = nullptr; uint64_t read_index = 0;
+	size_t part_begin() const { return only_domain >= 0 ? (size_t)dom_part[only_domain] : 0; }
+	size_t part_end() const { return only_domain >= 0 && (size_t)only_domain + 1 < dom_part.size() ? (size_t)dom_part[only_domain + 1] : ar.n_parts(s_dna); }
 	genome_io::Sequences pseudo;                                          // reference-genome mode: the pseudo reads that precede the first read
 	Queue<ReadPart> q_bases_for_qual, q_reads, q_quals; Queue<HeaderPart> q_hdr;
 	std::string err_dna, err_qual, err_hdr;
@@ -87,7 +126,11 @@ class RecordStream {
 	void start();
 	void join() { if (t_dna.joinable()) t_dna.join(); if (t_qual.joinable()) t_qual.join(); if (t_hdr.joinable()) t_hdr.join(); }
 public:
-	explicit RecordStream(const std::string& path, const std::string& genome_path = "");
+	// only_domain >= 0 (archives with independent domains): the records of that domain only, their ids from `headers` (all ids of the archive)
+	explicit RecordStream(const std::string& path, const std::string& genome_path = "", int only_domain = -1, const HeaderCache* headers = nullptr);
+	bool independent_domains() const { return independent; }
+	size_t n_domains() const { return dom_part.size(); }
+	void prefetch() { if (!started) start(); }                           // starts the decoder threads before the first next()
 	~RecordStream() { q_bases_for_qual.abort(); q_reads.abort(); q_quals.abort(); q_hdr.abort(); join(); ar.close(); }
 	RecordStream(const RecordStream&) = delete; RecordStream& operator=(const RecordStream&) = delete;
 	bool is_fastq() const { return fastq; }
@@ -96,8 +139,9 @@ public:
 	bool next(Record& r);                                                 // false at the end; throws on a corrupt archive
 };
 
-inline RecordStream::RecordStream(const std::string& path, const std::string& genome_path)
+inline RecordStream::RecordStream(const std::string& path, const std::string& genome_path, int only_domain_, const HeaderCache* headers)
 {
+	only_domain = only_domain_; ext_hdr = headers;
 	if (!ar.open(path)) throw std::runtime_error("cannot open archive: " + path);
 	s_dna = ar.id("dna"); s_qual = ar.id("qual"); s_hdr = ar.id("header");
 	const int s_meta = ar.id("meta"), s_dom = ar.id("hipdomains"), s_info = ar.id("info");
@@ -140,29 +184,49 @@ inline RecordStream::RecordStream(const std::string& path, const std::string& ge
 		std::vector<uint8_t> db; uint64_t dm = 0;
 		if (!ar.part(s_dom, 0, db, dm)) throw std::runtime_error("cannot read the `hipdomains` stream");
 		const uint8_t* p = db.data(); const uint8_t* e = p + db.size();
-		const uint32_t n = rd<uint32_t>(p, e);
-		for (uint32_t i = 0; i < n; ++i) { (void)rd<uint64_t>(p, e); const uint64_t fp = rd<uint64_t>(p, e); if (i) domain_first_part.push_back(fp); }
+		const uint32_t nf = rd<uint32_t>(p, e), n = nf & 0x7fffffffu;
+		independent = (nf >> 31) != 0;
+		if (n > db.size() / 16) throw std::runtime_error("corrupt `hipdomains` stream");
+		for (uint32_t i = 0; i < n; ++i)
+		{
+			const uint64_t fr = rd<uint64_t>(p, e), fp = rd<uint64_t>(p, e);
+			if (fp > ar.n_parts(s_dna) || (i && fp < dom_part.back())) throw std::runtime_error("corrupt `hipdomains` stream");
+			if (i) { domain_first_part.push_back(fp); dom_part.push_back(fp); dom_read.push_back(fr); }
+		}
+		if (independent) for (uint32_t i = 0; i < n; ++i) dom_sparse.push_back(rd<uint32_t>(p, e));
 	}
+	if (only_domain >= 0 && (!independent || (size_t)only_domain >= dom_part.size() || !ext_hdr)) throw std::runtime_error("a single domain can be read from an archive with independent domains only");
+	if (only_domain >= 0) read_index = dom_read[only_domain];
 	if (fastq && ar.n_parts(s_qual) != ar.n_parts(s_dna)) throw std::runtime_error("`dna` and `qual` streams have different numbers of parts");
 }
 
 inline void RecordStream::start()
 {
 	started = true;
-	const size_t n_parts = ar.n_parts(s_dna);
-	t_dna = std::thread([this, n_parts]() {
+	const size_t n_parts = part_end(), p_first = part_begin();
+	t_dna = std::thread([this, n_parts, p_first]() {
 		cl_dna_decoder* d = nullptr;
 		try {
-		if (cl_dna_decoder_create(M.max_candidates, M.level, M.n_pseudo, M.n_pseudo, M.ref_mode == 0, M.sparse_range, M.sparse_exp, &d) != CL_OK) { err_dna = "cl_dna_decoder_create"; }
+		const uint32_t sr0 = independent && !dom_sparse.empty() ? dom_sparse[only_domain >= 0 ? only_domain : 0] : M.sparse_range;
+		if (cl_dna_decoder_create(M.max_candidates, M.level, M.n_pseudo, M.n_pseudo, M.ref_mode == 0, sr0, M.sparse_exp, &d) != CL_OK) { err_dna = "cl_dna_decoder_create"; }
 		for (size_t i = 0; d && i + 1 < pseudo.off.size(); ++i)                    // decompression_common.cpp:287-292
 			if (cl_dna_decoder_add_ref(d, pseudo.codes.data() + pseudo.off[i], (uint32_t)(pseudo.off[i + 1] - pseudo.off[i])) != CL_OK) { err_dna = "cl_dna_decoder_add_ref"; break; }
 		if (!err_dna.empty() && d) { cl_dna_decoder_free(d); d = nullptr; }
 		std::vector<uint8_t> in; uint64_t n_reads = 0;
-		for (size_t p = 0; d && p < n_parts; ++p)
+		for (size_t p = p_first; d && p < n_parts; ++p)
 		{
 			if (!ar.part(s_dna, p, in, n_reads)) { err_dna = "cannot read a `dna` part"; break; }
 			if (!count_ok(n_reads)) { err_dna = "a `dna` part claims more reads than the archive holds"; break; }
-			if (is_domain_start(p)) cl_dna_decoder_new_domain(d);
+			if (p > p_first && is_domain_start(p))
+			{
+				if (!independent) cl_dna_decoder_new_domain(d);
+				else
+				{	// an independent domain: nothing of the domains before it is a reference read here
+					size_t di = 0; while (di + 1 < dom_part.size() && dom_part[di + 1] <= p) ++di;
+					cl_dna_decoder_free(d); d = nullptr;
+					if (cl_dna_decoder_create(M.max_candidates, M.level, 0, 0, M.ref_mode == 0, di < dom_sparse.size() ? dom_sparse[di] : M.sparse_range, M.sparse_exp, &d) != CL_OK) { err_dna = "cl_dna_decoder_create"; break; }
+				}
+			}
 			ReadPart x; x.off.resize(n_reads + 1);
 			uint64_t cap = std::max<uint64_t>(in.size() * 8, 1 << 20), got = 0;
 			x.bases.resize(cap);
@@ -183,12 +247,12 @@ inline void RecordStream::start()
 		for (size_t i = 0; i < M.rev.size(); ++i) qpar.rev[i] = M.rev[i];
 		cl_qual_decoder* q = nullptr;
 		if (cl_qual_decoder_create(&qpar, &q) != CL_OK) { err_qual = "cl_qual_decoder_create"; }
-		ReadPart x; std::vector<uint8_t> in; uint64_t meta = 0; size_t p = 0;
+		ReadPart x; std::vector<uint8_t> in; uint64_t meta = 0; size_t p = part_begin(); const size_t p_first = p;
 		try {
 		while (q && q_bases_for_qual.pop(x))
 		{
 			if (!ar.part(s_qual, p, in, meta)) { err_qual = "cannot read a `qual` part"; break; }
-			if (is_domain_start(p)) cl_qual_decoder_new_domain(q);
+			if (p > p_first && is_domain_start(p)) cl_qual_decoder_new_domain(q);
 			x.quals.resize(x.bases.size());
 			if (cl_qual_decode_part(q, in.data(), in.size(), x.bases.data(), x.off.data(), (uint32_t)(x.off.size() - 1), x.quals.data()) != CL_OK) { err_qual = "corrupt `qual` part"; break; }
 			x.bases.clear(); x.bases.shrink_to_fit();
@@ -200,6 +264,7 @@ inline void RecordStream::start()
 		if (q) cl_qual_decoder_free(q);
 		q_quals.finish();
 	});
+	if (ext_hdr) { q_hdr.finish(); return; }
 	t_hdr = std::thread([this]() {
 		cl_id_decoder* c = nullptr;
 		if (cl_id_decoder_create(M.header_mode, &c) != CL_OK) { err_hdr = "cl_id_decoder_create"; }
@@ -229,8 +294,8 @@ inline bool RecordStream::next(Record& r)
 	if (finished) return false;
 	if (!started) start();
 	auto next_read = [&]() { while (!have_r || ri + 1 >= rp.off.size()) { if (!q_reads.pop(rp)) return false; if (fastq && !q_quals.pop(qp)) return false; ri = 0; have_r = true; } return true; };
-	auto next_hdr = [&]() { while (!have_h || hi + 1 >= hp.off.size()) { if (!q_hdr.pop(hp)) return false; hi = 0; have_h = true; } return true; };
-	const bool a = next_read(), b = next_hdr();
+	auto next_hdr = [&]() { if (ext_hdr) return read_index + 1 < ext_hdr->off.size(); while (!have_h || hi + 1 >= hp.off.size()) { if (!q_hdr.pop(hp)) return false; hi = 0; have_h = true; } return true; };
+	const bool a = next_read(), b = ext_hdr ? (a ? next_hdr() : false) : next_hdr();
 	if (!a || !b)
 	{	// the end, or an error: let the producers run out, then report
 		finished = true;
@@ -242,7 +307,18 @@ inline bool RecordStream::next(Record& r)
 		if (a != b) throw std::runtime_error("the streams hold different numbers of records");
 		return false;
 	}
-	const uint64_t b0 = rp.off[ri], b1 = rp.off[ri + 1], h0 = hp.off[hi], h1 = hp.off[hi + 1];
+	const uint64_t b0 = rp.off[ri], b1 = rp.off[ri + 1];
+	if (ext_hdr)
+	{
+		const uint64_t h0 = ext_hdr->off[read_index], h1 = ext_hdr->off[read_index + 1];
+		r.header = ext_hdr->ids.data() + h0; r.header_len = (size_t)(h1 - h0);
+		r.bases = rp.bases.data() + b0; r.n_bases = (size_t)(b1 - b0);
+		r.quals = fastq ? qp.quals.data() + b0 : nullptr;
+		r.plus_is_header = fastq && ext_hdr->plus[read_index] != 0;
+		++ri; ++read_index;
+		return true;
+	}
+	const uint64_t h0 = hp.off[hi], h1 = hp.off[hi + 1];
 	r.header = hp.ids.data() + h0; r.header_len = (size_t)(h1 - h0);
 	r.bases = rp.bases.data() + b0; r.n_bases = (size_t)(b1 - b0);
 	r.quals = fastq ? qp.quals.data() + b0 : nullptr;

@@ -372,3 +372,39 @@ def test_cli_giant_gaps_equal_the_reference(tmp_path, extra):
     subprocess.check_call([REF, "decompress", ref_arc, ref_out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     subprocess.check_call([CLI, "decompress", my_arc, my_out])
     assert sha(my_out) == sha(ref_out)
+
+
+@pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(CLI)), reason="needs oracle/_ref/colord and colord_amd/colord_hip")
+def test_cli_independent_domains_decode_side_by_side(tmp_path):
+    """`--domains K`: K independent model domains (own k-mer statistics, reference reads, index and models each; `hipdomains` with bit 31
+    of its count set and a sparse range per domain).  `colord_hip decompress` decodes them with K workers into files of their own and
+    joins them; one worker at a time and the sequential record stream behind the C++ API (tests/tools/api_dump) give the same bytes —
+    what the reference returns for its own archive of the same FASTQ (4-avg qualities are quantised per read)."""
+    from colord_amd import ontsim
+    table = ontsim.ReadTable(seed=47, genome_len=4_000_000, target_bases=80_000_000)
+    fq = str(tmp_path / "in.fastq")
+    ontsim.write_fastq(table, fq)
+    ref_arc, ref_out, one, dom, out_par, out_seq = (str(tmp_path / x) for x in ("ref.colord", "ref.fastq", "one.colord", "dom.colord", "par.fastq", "seq.fastq"))
+    subprocess.check_call([REF, "compress-ont", "-t", str(os.cpu_count() or 8), fq, ref_arc], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.check_call([REF, "decompress", ref_arc, ref_out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.check_call([CLI, "compress-ont", fq, one])
+    subprocess.check_call([CLI, "compress-ont", "--domains", "4", "--chunk-bases", "10000000", fq, dom])
+    a = AR.read_archive(dom)
+    hd = a["hipdomains"].parts[0][1]
+    assert int.from_bytes(hd[:4], "little") == (4 | 0x80000000) and len(hd) == 4 + 4 * 16 + 4 * 4
+    r = subprocess.run([CLI, "decompress", dom, out_par], capture_output=True, text=True)
+    assert r.returncode == 0 and "4 independent domains" in r.stderr, r.stderr
+    assert sha(out_par) == sha(ref_out)
+    subprocess.check_call([CLI, "decompress", "-t", "1", dom, out_seq])
+    assert sha(out_seq) == sha(ref_out)
+    # the price: every domain has a quarter of the coverage to find reference reads in (here 5x per domain instead of 20x: `dna` grows by
+    # three quarters; `qual`, whose models only start anew, by 0.5 %) — independent domains are for inputs whose coverage can afford them
+    b1 = AR.read_archive(one)
+    assert sum(len(p) for _, p in a["qual"].parts) <= sum(len(p) for _, p in b1["qual"].parts) * 1.02
+    assert os.path.getsize(dom) <= os.path.getsize(one) * 1.5
+    # the sequential reader of the public API (include/colord_api.h) walks the domains one after the other
+    from tests.test_api_cpu import build
+    dump = build(os.path.join(ROOT, "tests", "tools", "api_dump.cpp"), str(tmp_path / "api_dump"))
+    r = subprocess.run([dump, dom], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert hashlib.sha256(r.stdout).hexdigest() == sha(ref_out)
