@@ -93,7 +93,7 @@ def kmer_anchor_len(bases: float):
 class StepTimes:
     """Per-kernel HIP-event times (context streams) accumulated by colord_amd.device.Context."""
     def __init__(self, *ctxs):
-        self.ms, self.launches, self.bytes = {}, {}, {}
+        self.ms, self.launches, self.bytes, self.cells = {}, {}, {}, {}
         for ctx in ctxs:
             if ctx is None:
                 continue
@@ -101,6 +101,7 @@ class StepTimes:
                 self.ms[n] = self.ms.get(n, 0.0) + v[0]
                 self.launches[n] = self.launches.get(n, 0) + v[1]
                 self.bytes[n] = self.bytes.get(n, 0.0) + v[2]
+                self.cells[n] = self.cells.get(n, 0.0) + (v[3] if len(v) > 3 else 0.0)
 
 
 def reference_part_bounds(lengths: np.ndarray, pack_symbols: int) -> np.ndarray:
@@ -690,6 +691,14 @@ def main():
         order = sorted(times.ms, key=times.ms.get, reverse=True)
         roof["kernel_ms_per_step"] = {n: round(times.ms[n] / args.steps, 3) for n in order[:40]}
         roof["kernel_achieved_GBps"] = {n: round(times.bytes[n] / (times.ms[n] * 1e-3) / 1e9, 1) for n in order if times.bytes.get(n, 0) > 0 and times.ms[n] > 0}
+        # the aligners as what they are — dynamic-programming kernels: cell updates per second (rows x columns of every gap once; a
+        # large gap's second and third sweep, Hirschberg, are not counted) over the summed HIP-event time of the class
+        al = [n for n in times.ms if n.startswith(("k_align_", "k_giant_"))]
+        al_cells, al_ms = sum(times.cells.get(n, 0.0) for n in al), sum(times.ms[n] for n in al)
+        roof["aligners_gcups"] = {"value": al_cells / (al_ms * 1e-3) / 1e9 if al_ms > 0 else None, "cells_per_step": al_cells / args.steps, "kernel_ms_per_step": al_ms / args.steps,
+                                  "by_kernel": {n: round(times.cells.get(n, 0.0) / (times.ms[n] * 1e-3) / 1e9, 1) for n in al if times.ms[n] > 0 and times.cells.get(n, 0.0) > 0},
+                                  "what": "DP cells (rows x columns of every aligned gap, once) / summed HIP-event time of k_align_small<1..4>, k_align_quad, k_align_wave and the k_giant_* launches; "
+                                          "kernels share the machine, so this is a rate inside the pipeline, not a peak"}
         # compulsory floor of the whole path (3.2 B/base) against the step time
         roof["whole_path_floor_frac"] = 3.2 * total_bases * args.steps / dt / 1e9 / (HBM_PEAK_GBS * world)
         # the same input once more in the byte-identical mode: coder parts = the reference's reader packs (4 Mi symbols; each part is

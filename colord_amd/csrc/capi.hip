@@ -102,7 +102,7 @@ extern "C" cl_status cl_ctx_kernel_times(cl_ctx* c, char* buf, uint64_t cap, uin
 	if (!c) return CL_E_INVALID;
 	cl_timing_collect(c);                                                      // (what has completed: never a wait — callers ask after every stage, and a coder of the next chunk may be running)
 	std::string out;
-	for (auto& kv : c->times) out += kv.first + "\t" + std::to_string(kv.second.ms) + "\t" + std::to_string(kv.second.launches) + "\t" + std::to_string(kv.second.bytes) + "\n";
+	for (auto& kv : c->times) out += kv.first + "\t" + std::to_string(kv.second.ms) + "\t" + std::to_string(kv.second.launches) + "\t" + std::to_string(kv.second.bytes) + "\t" + std::to_string(kv.second.cells) + "\n";
 	if (needed) *needed = out.size() + 1;
 	if (!buf || cap < out.size() + 1) return CL_E_CAPACITY;
 	memcpy(buf, out.c_str(), out.size() + 1);

@@ -25,7 +25,7 @@
 
 #define CL_WAVE 64
 
-struct KernelTime { double ms = 0; uint32_t launches = 0; double bytes = 0; };   // bytes = algorithmic HBM bytes of the timed launches
+struct KernelTime { double ms = 0; uint32_t launches = 0; double bytes = 0, cells = 0; };   // bytes = algorithmic HBM bytes of the timed launches; cells = DP cell updates (aligners: rows x columns of their gaps)
 
 // Device memory of a context: a sub-allocator over a few large slabs.  hipMalloc / hipFree cost 0.1-1 ms each (a second
 // for tens of GB) and synchronise the device, and a cache of whole hipMalloc blocks keyed by size wastes HBM exactly where
@@ -325,8 +325,8 @@ struct cl_ctx {
 	bool timing = false;
 	std::map<std::string, KernelTime> times;     // per-kernel accumulated HIP-event time of the last API call
 	std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
-	std::vector<double> pending_bytes;
-	double next_bytes = 0;                       // algorithmic bytes of the next LAUNCH (set by LAUNCHB)
+	std::vector<double> pending_bytes, pending_cells;
+	double next_bytes = 0, next_cells = 0;       // algorithmic bytes (LAUNCHB) / DP cells (aligners) of the next LAUNCH
 	std::vector<hipEvent_t> ev_pool;
 	int n_cu = 256;
 	uint64_t* inv_tab = nullptr;                 // floor((2^64-1) / t) for t < 2^21: the interval coder's division table (rc_dev.hpp), made at first use
@@ -418,6 +418,7 @@ struct KernelTimer {
 		(void)hipEventRecord(b, cl_launch_stream(c));
 		c->pending.push_back({ name, { a, b } });
 		c->pending_bytes.push_back(c->next_bytes); c->next_bytes = 0;
+		c->pending_cells.push_back(c->next_cells); c->next_cells = 0;
 	}
 };
 // every kernel launch goes through LAUNCH so that per-kernel HIP-event times are complete
@@ -499,17 +500,17 @@ static inline void cl_timing_collect(cl_ctx* c, bool wait = false)
 		else if (hipEventQuery(p.second.second) != hipSuccess) { (void)hipGetLastError(); done = false; }
 		if (!done)
 		{
-			if (keep != i) { c->pending[keep] = std::move(p); c->pending_bytes[keep] = c->pending_bytes[i]; }
+			if (keep != i) { c->pending[keep] = std::move(p); c->pending_bytes[keep] = c->pending_bytes[i]; c->pending_cells[keep] = c->pending_cells[i]; }
 			++keep;
 			continue;
 		}
 		float ms = 0; (void)hipEventElapsedTime(&ms, p.second.first, p.second.second);
 		std::string nm = p.first;
 		if (!nm.empty() && nm.front() == '(' && nm.back() == ')') nm = nm.substr(1, nm.size() - 2);
-		auto& t = c->times[nm]; t.ms += ms; t.launches += 1; t.bytes += c->pending_bytes[i];
+		auto& t = c->times[nm]; t.ms += ms; t.launches += 1; t.bytes += c->pending_bytes[i]; t.cells += c->pending_cells[i];
 		c->ev_pool.push_back(p.second.first); c->ev_pool.push_back(p.second.second);
 	}
-	c->pending.resize(keep); c->pending_bytes.resize(keep);
+	c->pending.resize(keep); c->pending_bytes.resize(keep); c->pending_cells.resize(keep);
 }
 
 // ---- device primitives ---------------------------------------------------------------------------

@@ -95,16 +95,22 @@ __global__ void k_class_bounds(const uint32_t* __restrict__ keys, const uint32_t
 	for (uint32_t c = a; c < b && c <= N_CLASSES; ++c) bounds[c] = i;
 }
 
-// algorithmic bytes of each size class: 2-bit symbols in, one script byte per symbol out (for the roofline report)
-__global__ void k_class_bytes(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ ids, const uint32_t* __restrict__ cap, uint32_t n, unsigned long long* __restrict__ bytes /* N_CLASSES */)
+// algorithmic bytes of each size class: 2-bit symbols in, one script byte per symbol out — and its DP cells, rows x columns of every
+// gap (what edlib's recurrence has to fill once; Hirschberg's second and third sweep over a large gap are not counted) — for the report
+__global__ void k_class_bytes(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ ids, const uint32_t* __restrict__ cap, const GapRec* __restrict__ gaps, uint32_t n, unsigned long long* __restrict__ bytes /* 2 x N_CLASSES */)
 {
-	__shared__ unsigned long long s_b[N_CLASSES];
-	if (threadIdx.x < N_CLASSES) s_b[threadIdx.x] = 0;
+	__shared__ unsigned long long s_b[2 * N_CLASSES];
+	if (threadIdx.x < 2 * N_CLASSES) s_b[threadIdx.x] = 0;
 	__syncthreads();
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n) atomicAdd(&s_b[keys[i] >> 17], (unsigned long long)cap[ids[i]]);
+	if (i < n)
+	{
+		uint32_t rows, cols; const uint32_t cls = gap_class(gaps[ids[i]], rows, cols);
+		atomicAdd(&s_b[cls], (unsigned long long)cap[ids[i]]);
+		atomicAdd(&s_b[N_CLASSES + cls], (unsigned long long)rows * cols);
+	}
 	__syncthreads();
-	if (threadIdx.x < N_CLASSES && s_b[threadIdx.x]) atomicAdd(&bytes[threadIdx.x], s_b[threadIdx.x]);
+	if (threadIdx.x < 2 * N_CLASSES && s_b[threadIdx.x]) atomicAdd(&bytes[threadIdx.x], s_b[threadIdx.x]);
 }
 
 // lane-private staging memory in LDS (word w of a lane at lds[w * 64 + lane]) + column history in HBM (lane-interleaved).
@@ -1072,14 +1078,14 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 		HIP_TRY(ctx, hipMemsetAsync(bounds.p + N_CLASSES + 1, 0, 8, st));
 		LAUNCH(ctx, k_class_bounds, grid_for(ng + 1, 256), 256, (const uint32_t*)keys.p, (const uint32_t*)ids.p, (const uint32_t*)capw.p, L.n_gaps, bounds.p);
 		uint32_t hb[N_CLASSES + 3];
-		unsigned long long h_cb[N_CLASSES] = { 0 };
+		unsigned long long h_cb[2 * N_CLASSES] = { 0 };                           // bytes, then DP cells, per class (timing runs only)
 		HIP_TRY(ctx, hipMemcpyAsync(hb, bounds.p, 4 * (N_CLASSES + 3), hipMemcpyDeviceToHost, st));
 		if (ctx->timing)
 		{
-			DevBuf<unsigned long long> cb; DEV_ALLOC(ctx, cb, N_CLASSES);
-			HIP_TRY(ctx, hipMemsetAsync(cb.p, 0, 8 * N_CLASSES, st));
-			LAUNCH(ctx, k_class_bytes, grid_for(ng, 256), 256, (const uint32_t*)keys.p, (const uint32_t*)ids.p, (const uint32_t*)capw.p, L.n_gaps, cb.p);
-			HIP_TRY(ctx, hipMemcpyAsync(h_cb, cb.p, 8 * N_CLASSES, hipMemcpyDeviceToHost, st));
+			DevBuf<unsigned long long> cb; DEV_ALLOC(ctx, cb, 2 * N_CLASSES);
+			HIP_TRY(ctx, hipMemsetAsync(cb.p, 0, 16 * N_CLASSES, st));
+			LAUNCH(ctx, k_class_bytes, grid_for(ng, 256), 256, (const uint32_t*)keys.p, (const uint32_t*)ids.p, (const uint32_t*)capw.p, (const GapRec*)L.gaps.p, L.n_gaps, cb.p);
+			HIP_TRY(ctx, hipMemcpyAsync(h_cb, cb.p, 16 * N_CLASSES, hipMemcpyDeviceToHost, st));
 		}
 		HIP_TRY(ctx, hipStreamSynchronize(st));
 		// small gaps: on the side stream, next to the large ones on the main stream (one wave per SIMD with its state in
@@ -1101,6 +1107,7 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 				const uint32_t blocks = std::min<uint32_t>(grid_for(n_list, 64), n_cu * 4);
 				const uint32_t lds = (12 * nb + 48) * 64 * 4;                       // LdsMem<nb>: QW + TW + EW words per lane
 				const double bytes = 1.25 * (double)h_cb[nb];
+				ctx->next_cells = (double)h_cb[N_CLASSES + nb];
 				const uint32_t* list = ids.p + hb[nb];
 				switch (nb)
 				{
@@ -1131,6 +1138,7 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 			quad_join.s = ctx->side2;
 			HIP_TRY(ctx, hipMemsetAsync(qc.p, 0, 8, ctx->side2));
 			LaunchOn on(ctx, ctx->side2);                                         // (launch + timing events on the third stream)
+			ctx->next_cells = (double)h_cb[N_CLASSES + 5];
 			LAUNCHB(ctx, 1.25 * (double)h_cb[5], k_align_quad, waves, 64, (const uint32_t*)ids.p + hb[5], n_list, L.gaps.p, L.es.p, A, R, quad_scratch.p, per_wave, qc.p, quad_redo.p, qc.p + 1);
 			HIP_TRY(ctx, hipGetLastError());
 		}
@@ -1165,6 +1173,7 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 				V.jobs[i] = (gt::Job*)(giant_mem.p + o_jobs + i * al(sizeof(gt::Job) * gt::JOB_CAP)); }
 			V.leaves = (gt::Leaf*)(giant_mem.p + o_leaves); V.giants = (gt::Giant*)(giant_mem.p + o_giants); V.n_giants = n_list;
 			LaunchOn on(ctx, ctx->side3);
+			ctx->next_cells = (double)h_cb[N_CLASSES + 7];                         // (booked on the staging launch: the class as a whole is what the report adds up)
 			LAUNCHB(ctx, 1.25 * (double)h_cb[7], k_giant_stage, n_list, 256, V, (const uint32_t*)ids.p + hb[7], (const GapRec*)L.gaps.p, A, R);
 			for (uint32_t ph = 0; ph < phases; ++ph) LAUNCH(ctx, k_giant_level, 1024, 64, V, ph);
 			LAUNCH(ctx, k_giant_leaves, leaf_waves, 64, V, giant_scratch.p, per_wave);
@@ -1251,6 +1260,7 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 			}
 			return CL_OK;
 		};
+		ctx->next_cells = (double)h_cb[N_CLASSES + 6];
 		CL_TRY(run_large(ids.p + hb[6], hb[7] - hb[6], 1.25 * (double)h_cb[6]));
 		if (quad_join.s)
 		{

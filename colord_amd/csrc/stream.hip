@@ -819,7 +819,7 @@ extern "C" cl_status cl_compressor_encode(cl_compressor* c, const cl_reads* read
 	if (job)
 	{
 		if (job->status != CL_OK) return cl_fail(ctx, job->status, "encode lane: " + job->err);
-		for (auto& kv : job->times) { auto& t = ctx->times[kv.first]; t.ms += kv.second.ms; t.launches += kv.second.launches; t.bytes += kv.second.bytes; }
+		for (auto& kv : job->times) { auto& t = ctx->times[kv.first]; t.ms += kv.second.ms; t.launches += kv.second.launches; t.bytes += kv.second.bytes; t.cells += kv.second.cells; }
 		for (auto& kv : job->dna_times) { auto& t = ctx->times[kv.first]; t.ms += kv.second.ms; t.launches += kv.second.launches; t.bytes += kv.second.bytes; }
 		if (job->walked) { cl_dna_set_ahead(c->dna, job->walked); job->walked = nullptr; ++c->n_dna_prep; }
 	}

@@ -9,11 +9,12 @@ from . import _native as N
 
 def _check(ctx, st):
     if ctx is not None and getattr(ctx, "timing", False):
-        for n, (ms, k, b) in ctx.kernel_times().items():
-            a = ctx.acc.setdefault(n, [0.0, 0, 0.0])
+        for n, (ms, k, b, cells) in ctx.kernel_times().items():
+            a = ctx.acc.setdefault(n, [0.0, 0, 0.0, 0.0])
             a[0] += ms
             a[1] += k
             a[2] += b
+            a[3] += cells
     if st != N.CL_OK:
         msg = N.load().cl_last_error(ctx.h).decode() if ctx is not None and ctx.h else ""
         raise N.ColordHipError(st, msg)
@@ -75,8 +76,8 @@ class Context:
             return {}
         out = {}
         for line in buf.value.decode().splitlines():
-            n, ms, k, b = line.split("\t")
-            out[n] = (float(ms), int(k), float(b))
+            f = line.split("\t")
+            out[f[0]] = (float(f[1]), int(f[2]), float(f[3]), float(f[4]) if len(f) > 4 else 0.0)
         return out
 
     # ---- arena ----

@@ -166,16 +166,27 @@ def _record_start(f, pos: int, size: int) -> int:
         return 0
     if pos >= size:
         return size
-    f.seek(pos - 1)
-    buf = f.read(1 << 22)                          # (reads are at most a few hundred kb: four lines fit many times over)
-    i = buf.find(b"\n") + 1                        # first line start at or after pos
-    starts = []
-    while i < len(buf) and len(starts) < 12:
-        starts.append(i)
-        j = buf.find(b"\n", i)
-        if j < 0:
+    # the window grows until it holds the first line end and twelve line starts behind it (or the file ends): records of ultra-long
+    # reads are megabytes — a window without a line end must not make a mid-line byte a line start, and one with fewer than four
+    # lines must not end the share at the end of the file
+    want = 1 << 22
+    while True:
+        f.seek(pos - 1)
+        buf = f.read(want)
+        eof = pos - 1 + len(buf) >= size
+        first = buf.find(b"\n")
+        starts = []
+        if first >= 0:
+            i = first + 1                          # first line start at or after pos
+            while i < len(buf) and len(starts) < 12:
+                starts.append(i)
+                j = buf.find(b"\n", i)
+                if j < 0:
+                    break
+                i = j + 1
+        if len(starts) >= 12 or eof:
             break
-        i = j + 1
+        want *= 4
     for a in range(len(starts) - 3):
         l0, l2 = buf[starts[a]:starts[a] + 1], buf[starts[a + 2]:starts[a + 2] + 1]
         l1 = buf[starts[a + 1]:starts[a + 1] + 1]

@@ -357,10 +357,17 @@ def main(argv=None):
     # every rank reads ITS byte range of a plain 4-line FASTQ (no rank parses or holds the whole file); other inputs (gzip, FASTA,
     # multi-line records) are read whole by every rank, which keeps its share
     rank_ = int(os.environ.get("RANK", "0"))
-    shard = read_fastx_range(pos[0], rank_, world) if world > 1 else None
+    shard, shard_err = None, None
+    if world > 1:
+        try:                                              # (a rank whose share is malformed votes 0 below instead of leaving the others in the collective)
+            shard = read_fastx_range(pos[0], rank_, world)
+        except ValueError as e:
+            shard_err = e
     ok = torch.tensor([1 if (shard is not None or world == 1) else 0], dtype=torch.int64, device=torch.device("cuda", torch.cuda.current_device()) if (world > 1 and dist.get_backend() == "nccl") else "cpu")
     if world > 1:
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)            # (all ranks take the same path)
+    if shard_err is not None and world > 1 and int(ok.item()) == 0:
+        print(f"colord_amd.mgpu: rank {rank_}: {shard_err}", file=sys.stderr)
     if world > 1 and int(ok.item()) == 1:
         rs = shard[0]
         est = size * 0.49
