@@ -638,8 +638,9 @@ __global__ __launch_bounds__(64) void k_giant_finish(gt::View V, GapRec* __restr
 // gaps of up to 16 row blocks whose history fits a wave's pool: FOUR per wave (wv::quad_sweep), largest first; what does not
 // fit a wave's pool goes to `redo` (k_align_wave takes it)
 __global__ __launch_bounds__(64) void k_align_quad(const uint32_t* __restrict__ list, uint32_t n_list, GapRec* __restrict__ gaps, char* __restrict__ es_pool, ArenaV A, ArenaV R,
-                                                  uint8_t* __restrict__ scratch, uint64_t per_wave, unsigned int* __restrict__ next, uint32_t* __restrict__ redo, unsigned int* __restrict__ n_redo)
+                                                  uint8_t* __restrict__ scratch, uint64_t per_wave, unsigned int* __restrict__ next, uint32_t* __restrict__ redo, unsigned int* __restrict__ n_redo, uint32_t dbg)
 {
+	__shared__ uint64_t s_win[4 * wv::QWC * 16 * 2];                         // the four rows' traceback windows (wv::quad_walk): 32 KB
 	wv::WavePool pool{ scratch + (uint64_t)blockIdx.x * per_wave, per_wave, 0, false, nullptr };
 	const uint32_t lane = threadIdx.x, gq = lane >> 4;
 	const uint32_t n_quads = (n_list + 3) / 4;
@@ -651,11 +652,11 @@ __global__ __launch_bounds__(64) void k_align_quad(const uint32_t* __restrict__ 
 		if (slot >= n_quads) break;
 		pool.top = 0; pool.overflow = false;
 		const uint32_t hi = n_list - slot * 4, cnt = hi < 4 ? hi : 4;        // gaps list[hi - 1], list[hi - 2], ... (ascending list, taken from its end)
-		GapRec g[4]; WaveGap W[4]; uint64_t* P[4]; uint64_t* H[4]; uint8_t* rev[4]; uint32_t gi[4]; bool ok[4];
+		GapRec g[4]; WaveGap W[4]; uint64_t* CK[4]; uint8_t* rev[4]; uint32_t gi[4]; bool ok[4];
 #pragma unroll
 		for (uint32_t j = 0; j < 4; ++j)
 		{
-			ok[j] = false; gi[j] = 0; P[j] = H[j] = nullptr; rev[j] = nullptr;
+			ok[j] = false; gi[j] = 0; CK[j] = nullptr; rev[j] = nullptr;
 			if (j >= cnt) continue;
 			gi[j] = list[hi - 1 - j];
 			g[j] = gaps[gi[j]];
@@ -663,27 +664,48 @@ __global__ __launch_bounds__(64) void k_align_quad(const uint32_t* __restrict__ 
 			if (pool.overflow) continue;
 			if (!wave_gap_stage(pool, g[j], A, R, W[j])) continue;
 			if (W[j].n == 0 || W[j].m == 0 || W[j].n > 1024) continue;        // (not of this class: the wave kernel handles every shape)
-			const uint64_t words = ((uint64_t)W[j].m + 64) * ((W[j].n + 63) / 64);
-			P[j] = (uint64_t*)pool.alloc(words * 8); H[j] = (uint64_t*)pool.alloc(words * 8); rev[j] = (uint8_t*)pool.alloc((uint64_t)W[j].n + W[j].m + 64);
+			CK[j] = (uint64_t*)pool.alloc(wv::quad_ck_words(W[j].n, W[j].m) * 8 + 64); rev[j] = (uint8_t*)pool.alloc((uint64_t)W[j].n + W[j].m + 64);
 			ok[j] = !pool.overflow;
 		}
 		pool.overflow = false;
-		const uint8_t* q = nullptr; const uint8_t* t = nullptr; uint32_t n = 0, m = 0; bool shw = false; uint64_t* hp = nullptr; uint64_t* hh = nullptr;
+		const uint8_t* q = nullptr; const uint8_t* t = nullptr; uint32_t n = 0, m = 0; bool shw = false; uint64_t* ckp = nullptr; uint8_t* revp = nullptr;
 #pragma unroll
-		for (uint32_t j = 0; j < 4; ++j) if (gq == j && ok[j]) { q = W[j].Q; n = W[j].n; t = W[j].T; m = W[j].m; shw = W[j].shw; hp = P[j]; hh = H[j]; }
-		const wv::Sweep sw = wv::quad_sweep(q, n, t, m, shw, hp, hh);
+		for (uint32_t j = 0; j < 4; ++j) if (gq == j && ok[j]) { q = W[j].Q; n = W[j].n; t = W[j].T; m = W[j].m; shw = W[j].shw; ckp = CK[j]; revp = rev[j]; }
+		// the sweep: score / end position and a checkpoint every QWC columns; then the traceback of all four in lock step
+		uint64_t e0, e1, e2, e3;
+		wv::quad_masks(q, n, e0, e1, e2, e3);
+		uint32_t i_e, j_e, k_e; int32_t end;
+		{
+			uint64_t Pv = ~0ull, Mv = 0; uint32_t sc = n, best = 0xffffffffu; end = (int32_t)m - 1;
+			if (shw && (n & 63)) { best = n; end = -1; }
+			wv::quad_cols<false>(t, n, m, 0, n ? m : 0, shw, e0, e1, e2, e3, Pv, Mv, nullptr, ckp, sc, best, end);
+			const uint32_t nb = (n + 63) / 64;
+			end = __shfl(end, (int)((lane & 48) + (nb ? nb - 1 : 0)));
+			__builtin_amdgcn_s_waitcnt(0);
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+			if (dbg == 1) { i_e = n; j_e = 0; k_e = 0; }
+			else wv::quad_walk(q, t, n, m, shw ? (uint32_t)(end + 1) : m, ckp, revp, e0, e1, e2, e3, s_win, i_e, j_e, k_e);
+			__builtin_amdgcn_s_waitcnt(0);
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		}
 #pragma unroll
 		for (uint32_t j = 0; j < 4; ++j)
 		{
 			if (j >= cnt) continue;
 			bool done = false;
-			if (ok[j])
-			{
-				const int32_t end = wv::bcast(sw.end, 16u * j);
-				wv::Ops ops{ W[j].opsbuf, 0 };
-				const wv::Hist h{ P[j], H[j], (W[j].n + 63) / 64, W[j].m, W[j].n };
-				wv::wave_walk(pool, h, W[j].Q, W[j].n, W[j].T, W[j].shw ? (uint32_t)(end + 1) : W[j].m, rev[j], ops);
-				const uint32_t ref_end = W[j].shw ? (uint32_t)end : g[j].kind == GK_FLANK_TINY ? g[j].use - 1 : 0u;
+			if (ok[j] && dbg) done = true;
+			else if (ok[j])
+			{	// the operations in forward order: what is left of the prefix first (the walk ended with i == 0 or j == 0), then the walk's, reversed
+				const uint32_t wi = wv::bcast(i_e, 16u * j), wj = wv::bcast(j_e, 16u * j), wk = wv::bcast(k_e, 16u * j);
+				const int32_t gend = wv::bcast(end, 16u * j);
+				uint8_t* dst = W[j].opsbuf; const uint8_t* rv = rev[j];
+				const uint32_t pre = wi + wj; const uint8_t pre_op = wi ? 1 : 2;
+				for (uint32_t x = lane; x < pre; x += 64) dst[x] = pre_op;
+				for (uint32_t x = lane; x < wk; x += 64) dst[pre + x] = rv[wk - 1 - x];
+				__builtin_amdgcn_s_waitcnt(0);
+				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+				wv::Ops ops{ W[j].opsbuf, (uint64_t)pre + wk };
+				const uint32_t ref_end = W[j].shw ? (uint32_t)gend : g[j].kind == GK_FLANK_TINY ? g[j].use - 1 : 0u;
 				const uint64_t mk = pool.mark();
 				done = wave_gap_finish(pool, g[j], W[j], ops, ref_end, es_pool + g[j].es_off, 0);
 				pool.release(mk); pool.overflow = false;
@@ -1129,8 +1151,8 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 		if (hb[6] > hb[5])
 		{
 			const uint32_t n_list = hb[6] - hb[5];
-			const uint64_t per_wave = 9ull << 18;                                 // 2.25 MB: four histories of at most 512 KB + the sequences and scripts of four gaps
-			const uint32_t waves = std::min<uint32_t>((n_list + 3) / 4, 2048);      // (4.7 GB; 4096 waves were no faster beside the other streams)
+			const uint64_t per_wave = 1ull << 20;                                 // 1 MB: the sequences, operations, checkpoints and scripts of four gaps (no history: round 4)
+			const uint32_t waves = std::min<uint32_t>((n_list + 3) / 4, n_cu * 10);   // (16 KB of LDS each: ten per CU)
 			DEV_ALLOC(ctx, quad_scratch, per_wave * waves);
 			DEV_ALLOC(ctx, qc, 2);
 			DEV_ALLOC(ctx, quad_redo, (uint64_t)n_list + 1);
@@ -1139,7 +1161,7 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 			HIP_TRY(ctx, hipMemsetAsync(qc.p, 0, 8, ctx->side2));
 			LaunchOn on(ctx, ctx->side2);                                         // (launch + timing events on the third stream)
 			ctx->next_cells = (double)h_cb[N_CLASSES + 5];
-			LAUNCHB(ctx, 1.25 * (double)h_cb[5], k_align_quad, waves, 64, (const uint32_t*)ids.p + hb[5], n_list, L.gaps.p, L.es.p, A, R, quad_scratch.p, per_wave, qc.p, quad_redo.p, qc.p + 1);
+			LAUNCHB(ctx, 1.25 * (double)h_cb[5], k_align_quad, waves, 64, (const uint32_t*)ids.p + hb[5], n_list, L.gaps.p, L.es.p, A, R, quad_scratch.p, per_wave, qc.p, quad_redo.p, qc.p + 1, (uint32_t)(getenv("COLORD_HIP_QUAD_DBG") ? atoi(getenv("COLORD_HIP_QUAD_DBG")) : 0));
 			HIP_TRY(ctx, hipGetLastError());
 		}
 		// giant gaps: many waves each (align_giant.hpp), on a stream of their own from the start of the level, next to everything else
