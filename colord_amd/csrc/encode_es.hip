@@ -635,8 +635,74 @@ __global__ __launch_bounds__(64) void k_giant_finish(gt::View V, GapRec* __restr
 	}
 }
 
-// gaps of up to 16 row blocks whose history fits a wave's pool: FOUR per wave (wv::quad_sweep), largest first; what does not
-// fit a wave's pool goes to `redo` (k_align_wave takes it)
+// gaps of up to 16 row blocks: FOUR per wave (one per 16-lane row), largest first; what does not fit a wave's pool goes to `redo`
+// (k_align_wave takes it).  Two forms of the same sweep and the same walk:
+//   k_align_quad_hist  (default) the whole history of the sweep — two words per block and column — goes to the wave's pool in HBM and the four
+//                      tracebacks read it back one after the other with the whole wave (wv::wave_walk): 15.6 GB per level-0 launch for 0.14 GB
+//                      of sequences and scripts;
+//   k_align_quad       (COLORD_HIP_QUAD_NOHIST) no history: a checkpoint every 16 columns, the tracebacks recompute their windows into LDS and
+//                      run in lock step (wv::quad_walk): 1 / 16 of the bytes, 1.25 x the kernel time (the recomputation is a second sweep,
+//                      and HBM bandwidth is not what this pipeline is short of: DESIGN.md 5d) — measured, not the default.
+__global__ __launch_bounds__(64) void k_align_quad_hist(const uint32_t* __restrict__ list, uint32_t n_list, GapRec* __restrict__ gaps, char* __restrict__ es_pool, ArenaV A, ArenaV R,
+                                                  uint8_t* __restrict__ scratch, uint64_t per_wave, unsigned int* __restrict__ next, uint32_t* __restrict__ redo, unsigned int* __restrict__ n_redo)
+{
+	wv::WavePool pool{ scratch + (uint64_t)blockIdx.x * per_wave, per_wave, 0, false, nullptr };
+	const uint32_t lane = threadIdx.x, gq = lane >> 4;
+	const uint32_t n_quads = (n_list + 3) / 4;
+	for (;;)
+	{
+		uint32_t slot = 0;
+		if (lane == 0) slot = atomicAdd(next, 1u);
+		slot = wv::bcast_first(slot);
+		if (slot >= n_quads) break;
+		pool.top = 0; pool.overflow = false;
+		const uint32_t hi = n_list - slot * 4, cnt = hi < 4 ? hi : 4;        // gaps list[hi - 1], list[hi - 2], ... (ascending list, taken from its end)
+		GapRec g[4]; WaveGap W[4]; uint64_t* P[4]; uint64_t* H[4]; uint8_t* rev[4]; uint32_t gi[4]; bool ok[4];
+#pragma unroll
+		for (uint32_t j = 0; j < 4; ++j)
+		{
+			ok[j] = false; gi[j] = 0; P[j] = H[j] = nullptr; rev[j] = nullptr;
+			if (j >= cnt) continue;
+			gi[j] = list[hi - 1 - j];
+			g[j] = gaps[gi[j]];
+			g[j].es_len = 0; g[j].d_before = 0;
+			if (pool.overflow) continue;
+			if (!wave_gap_stage(pool, g[j], A, R, W[j])) continue;
+			if (W[j].n == 0 || W[j].m == 0 || W[j].n > 1024) continue;        // (not of this class: the wave kernel handles every shape)
+			const uint64_t words = ((uint64_t)W[j].m + 64) * ((W[j].n + 63) / 64);
+			P[j] = (uint64_t*)pool.alloc(words * 8); H[j] = (uint64_t*)pool.alloc(words * 8); rev[j] = (uint8_t*)pool.alloc((uint64_t)W[j].n + W[j].m + 64);
+			ok[j] = !pool.overflow;
+		}
+		pool.overflow = false;
+		const uint8_t* q = nullptr; const uint8_t* t = nullptr; uint32_t n = 0, m = 0; bool shw = false; uint64_t* hp = nullptr; uint64_t* hh = nullptr;
+#pragma unroll
+		for (uint32_t j = 0; j < 4; ++j) if (gq == j && ok[j]) { q = W[j].Q; n = W[j].n; t = W[j].T; m = W[j].m; shw = W[j].shw; hp = P[j]; hh = H[j]; }
+		const wv::Sweep sw = wv::quad_sweep(q, n, t, m, shw, hp, hh);
+#pragma unroll
+		for (uint32_t j = 0; j < 4; ++j)
+		{
+			if (j >= cnt) continue;
+			bool done = false;
+			if (ok[j])
+			{
+				const int32_t end = wv::bcast(sw.end, 16u * j);
+				wv::Ops ops{ W[j].opsbuf, 0 };
+				const wv::Hist h{ P[j], H[j], (W[j].n + 63) / 64, W[j].m, W[j].n };
+				wv::wave_walk(pool, h, W[j].Q, W[j].n, W[j].T, W[j].shw ? (uint32_t)(end + 1) : W[j].m, rev[j], ops);
+				const uint32_t ref_end = W[j].shw ? (uint32_t)end : g[j].kind == GK_FLANK_TINY ? g[j].use - 1 : 0u;
+				const uint64_t mk = pool.mark();
+				done = wave_gap_finish(pool, g[j], W[j], ops, ref_end, es_pool + g[j].es_off, 0);
+				pool.release(mk); pool.overflow = false;
+			}
+			if (lane == 0)
+			{
+				if (done) { gaps[gi[j]].es_len = g[j].es_len; gaps[gi[j]].d_before = g[j].d_before; }
+				else redo[atomicAdd(n_redo, 1u)] = gi[j];
+			}
+		}
+	}
+}
+
 __global__ __launch_bounds__(64) void k_align_quad(const uint32_t* __restrict__ list, uint32_t n_list, GapRec* __restrict__ gaps, char* __restrict__ es_pool, ArenaV A, ArenaV R,
                                                   uint8_t* __restrict__ scratch, uint64_t per_wave, unsigned int* __restrict__ next, uint32_t* __restrict__ redo, unsigned int* __restrict__ n_redo, uint32_t dbg)
 {
@@ -1151,8 +1217,11 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 		if (hb[6] > hb[5])
 		{
 			const uint32_t n_list = hb[6] - hb[5];
-			const uint64_t per_wave = 1ull << 20;                                 // 1 MB: the sequences, operations, checkpoints and scripts of four gaps (no history: round 4)
-			const uint32_t waves = std::min<uint32_t>((n_list + 3) / 4, n_cu * 10);   // (16 KB of LDS each: ten per CU)
+			static const bool nohist = getenv("COLORD_HIP_QUAD_NOHIST") != nullptr;
+			// with the history: 2.25 MB a wave (four histories of at most 512 KB + the sequences and scripts of four gaps), 2048 waves (4096 were
+			// no faster beside the other streams); without: 1 MB, ten waves per CU (16 KB of LDS each)
+			const uint64_t per_wave = nohist ? 1ull << 20 : 9ull << 18;
+			const uint32_t waves = std::min<uint32_t>((n_list + 3) / 4, nohist ? n_cu * 10 : 2048u);
 			DEV_ALLOC(ctx, quad_scratch, per_wave * waves);
 			DEV_ALLOC(ctx, qc, 2);
 			DEV_ALLOC(ctx, quad_redo, (uint64_t)n_list + 1);
@@ -1161,7 +1230,8 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 			HIP_TRY(ctx, hipMemsetAsync(qc.p, 0, 8, ctx->side2));
 			LaunchOn on(ctx, ctx->side2);                                         // (launch + timing events on the third stream)
 			ctx->next_cells = (double)h_cb[N_CLASSES + 5];
-			LAUNCHB(ctx, 1.25 * (double)h_cb[5], k_align_quad, waves, 64, (const uint32_t*)ids.p + hb[5], n_list, L.gaps.p, L.es.p, A, R, quad_scratch.p, per_wave, qc.p, quad_redo.p, qc.p + 1, (uint32_t)(getenv("COLORD_HIP_QUAD_DBG") ? atoi(getenv("COLORD_HIP_QUAD_DBG")) : 0));
+			if (nohist) LAUNCHB(ctx, 1.25 * (double)h_cb[5], k_align_quad, waves, 64, (const uint32_t*)ids.p + hb[5], n_list, L.gaps.p, L.es.p, A, R, quad_scratch.p, per_wave, qc.p, quad_redo.p, qc.p + 1, (uint32_t)(getenv("COLORD_HIP_QUAD_DBG") ? atoi(getenv("COLORD_HIP_QUAD_DBG")) : 0));
+			else LAUNCHB(ctx, 1.25 * (double)h_cb[5], k_align_quad_hist, waves, 64, (const uint32_t*)ids.p + hb[5], n_list, L.gaps.p, L.es.p, A, R, quad_scratch.p, per_wave, qc.p, quad_redo.p, qc.p + 1);
 			HIP_TRY(ctx, hipGetLastError());
 		}
 		// giant gaps: many waves each (align_giant.hpp), on a stream of their own from the start of the level, next to everything else
