@@ -372,7 +372,7 @@ __device__ inline int lis_search(const int* __restrict__ tf, int size, int value
 __global__ __launch_bounds__(64) void k_lis_anchors(Arena A, Arena R, TaskCfg cfg, const uint32_t* __restrict__ cand_refs, uint32_t n_tasks,
                                                    const uint64_t* __restrict__ pair_off, const uint32_t* __restrict__ pair_cnt, const uint64_t* __restrict__ pairs,
                                                    int* __restrict__ tf, int* __restrict__ ts, int* __restrict__ pred,
-                                                   uint32_t* __restrict__ anch, uint32_t* __restrict__ t_nanch, uint32_t* __restrict__ t_tot)
+                                                   uint32_t* __restrict__ anch, uint32_t* __restrict__ t_nanch, uint32_t* __restrict__ t_tot, uint32_t dbg)
 {
 	__builtin_amdgcn_s_setprio(3);                                          // a launch of this kernel lasts as long as its slowest chain: its waves go first on their SIMDs
 	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -404,9 +404,11 @@ __global__ __launch_bounds__(64) void k_lis_anchors(Arena A, Arena R, TaskCfg cf
 			PR[i] = pos > 0 ? S[pos - 1] : -1;
 			if (pos == out_len - 1) { last_f = x; last_s = i; }
 		}
+		if (dbg == 1) { t_nanch[t] = 0; t_tot[t] = 0; return; }
 		// chain in increasing order: walk the predecessor links backwards, storing the pair indices in S (reused)
 		int cur = S[out_len - 1];
 		for (int i = out_len - 1; i >= 0; --i) { F[i] = cur; cur = PR[cur]; }       // F[i] = pair index of chain element i
+		if (dbg == 2) { t_nanch[t] = 0; t_tot[t] = 0; return; }
 		// map-back + merge.  The reference re-derives the enc position by scanning the distinct enc positions forward for
 		// the next one that carries the chain element's m-mer.
 		const uint32_t rl = t / (2 * cfg.c), slot = (t / 2) % cfg.c; const bool rev = (t & 1) == 0;
@@ -416,17 +418,49 @@ __global__ __launch_bounds__(64) void k_lis_anchors(Arena A, Arena R, TaskCfg cf
 		const uint32_t rlen = R.lens[id]; const uint64_t rwb = R.word_off[id];
 		uint32_t* out = anch + 3 * a;
 		uint32_t ep = 0;                                   // index into the pairs, positioned on the first pair of a distinct enc position
+		uint32_t pe_at_ep = enc_pos(0);                    // ... and that position (kept from the advance below: no load of its own)
+		uint32_t pe_ahead = n > 1 ? enc_pos(1) : 0xffffffffu;   // ... and the one of pair ep + 1, fetched an advance ahead
 		uint32_t run = 0, start_e = 0, start_r = 0, prev_e = 0, prev_r = 0;
+		// This loop was 70 % of the kernel: per chain element a chain of four dependent loads (its pair, the reference words of its m-mer, the
+		// pair under the scan, the read's words there), 2 us each on the longest list of a launch.  Everything of element i + 1 that does not
+		// depend on the scan — its pair, its reference m-mer, the read's m-mer at ITS OWN position (where the scan nearly always hits) — is
+		// fetched while element i is worked on; the scan's own pair comes from the advance of the step before.
+		// THREE stages, one load level each, so that no load is waited for in the iteration that issues it: element i + 3's pair index,
+		// element i + 2's pair, element i + 1's four sequence words (raw: the m-mers are cut out of them an iteration later).
+		auto m_from = [&](uint64_t hi, uint64_t lo, uint32_t p) -> uint64_t {
+			const uint32_t j = p & 31, sft = 128 - 2 * (j + cfg.m);
+			const uint64_t v = (sft >= 64) ? (hi >> (sft - 64)) : ((hi << (64 - sft)) | (lo >> sft));
+			return v & ((1ULL << (2 * cfg.m)) - 1);
+		};
+		auto idx_of = [&](int x) -> int { return x < out_len ? F[x] : F[out_len - 1]; };
+		struct Raw { uint32_t pr, e, rp; uint64_t r0, r1, a0, a1; };
+		auto words_of = [&](uint64_t pw) -> Raw {
+			Raw w; w.pr = ~(uint32_t)pw & pr_mask; w.e = (uint32_t)(pw >> cfg.pr) & pe_mask;
+			w.rp = rev ? rlen - cfg.m - w.pr : w.pr;
+			const uint64_t* rw = R.packed + rwb + (w.rp >> 5); const uint64_t* aw = A.packed + ewb + (w.e >> 5);
+			w.r0 = rw[0]; w.r1 = rw[1]; w.a0 = aw[0]; w.a1 = aw[1];
+			return w;
+		};
+		int idx3 = idx_of(2);                                             // (filled to the pipeline's depth before the first element)
+		uint64_t pw2 = P[idx_of(1)];
+		Raw w1 = words_of(P[idx_of(0)]);
 		for (int i = 0; i < out_len; ++i)
 		{
-			const uint32_t pr = (uint32_t)ref_pos((uint32_t)F[i]);
-			const uint64_t mm = rev ? revcomp_m(mmer_at(R, rwb, rlen - cfg.m - pr, cfg.m), cfg.m) : mmer_at(R, rwb, pr, cfg.m);
+			// this element: cut its m-mers out of the words fetched an iteration ago
+			const uint32_t pr = w1.pr, e_own = w1.e;
+			const uint64_t mraw = m_from(w1.r0, w1.r1, w1.rp), mm = rev ? revcomp_m(mraw, cfg.m) : mraw, am = m_from(w1.a0, w1.a1, w1.e);
+			// the stages move up: words of element i + 1 from its pair, the pair of element i + 2 from its index, the index of element i + 3
+			w1 = words_of(pw2);
+			pw2 = P[idx3];
+			idx3 = idx_of(i + 3);
 			uint32_t pe;
 			for (;;)
 			{
-				pe = enc_pos(ep);
-				const bool hit = mmer_at(A, ewb, pe, cfg.m) == mm;
-				do { ++ep; } while (ep < n && enc_pos(ep) == pe);      // advance to the next distinct enc position
+				pe = pe_at_ep;
+				const bool hit = (pe == e_own ? am : mmer_at(A, ewb, pe, cfg.m)) == mm;
+				uint32_t nxt = pe;
+				do { ++ep; nxt = pe_ahead; pe_ahead = ep + 1 < n ? enc_pos(ep + 1) : 0xffffffffu; } while (ep < n && nxt == pe);      // advance to the next distinct enc position
+				pe_at_ep = nxt;
 				if (hit || ep >= n) break;                              // (the scan always hits before the end; the bound only guards against a hang)
 			}
 			if (run && prev_e == pe - 1 && prev_r == pr - 1) ++run;
@@ -800,7 +834,7 @@ extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* read
 		}
 		LAUNCH(ctx, k_task_pairs, grid_for((uint64_t)n_tasks + 1, 256), 256, (const uint64_t*)pairs.p, n_pairs, A, cfg, (const uint32_t*)n_distinct.p, n_tasks, pair_off.p, pair_cnt.p);
 		LAUNCHB(ctx, n_pairs * 32.0, k_lis_anchors, grid_for(n_tasks, 64), 64, A, R, cfg, d_cand_refs, n_tasks, (const uint64_t*)pair_off.p, (const uint32_t*)pair_cnt.p, (const uint64_t*)pairs.p,
-			tf.p, ts.p, pred.p, anch.p, t_nanch.p, t_tot.p);
+			tf.p, ts.p, pred.p, anch.p, t_nanch.p, t_tot.p, (uint32_t)(getenv("COLORD_HIP_LIS_DBG") ? atoi(getenv("COLORD_HIP_LIS_DBG")) : 0));
 		HIP_TRY(ctx, hipGetLastError());
 		const uint64_t n_slots = (uint64_t)nb * c;
 		// HiFi: k-mer anchors from the shared k-mers of every (read, candidate)
