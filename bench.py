@@ -532,7 +532,9 @@ def e2e_cli(bases: float, coverage: float, k: int, a: int, part_symbols: int):
 
 def load_traffic(kernel: str):
     """HBM bytes per launch of `kernel` from the committed PMC passes (tools/pmc_traffic.py -> profiles/r03_traffic.json)."""
-    path = os.path.join(ROOT, "profiles", "r03_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r04_traffic.json")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r03_traffic.json")
     if not os.path.exists(path):
         return None, None
     t = json.load(open(path))
