@@ -577,6 +577,7 @@ __device__ static inline uint32_t block_excl_scan_256(uint32_t v, uint32_t* sh, 
 cl_status dev_exclusive_scan_u32(cl_ctx* ctx, uint32_t* d_data, uint64_t n, uint64_t* h_total);   // in place
 cl_status dev_exclusive_scan_u64(cl_ctx* ctx, const uint32_t* d_in, uint64_t* d_out, uint64_t n, uint64_t* h_total); // d_out has n+1
 cl_status dev_sort_pairs(cl_ctx* ctx, uint64_t* d_keys, uint32_t* d_vals, uint64_t n, uint32_t begin_bit, uint32_t end_bit);
+cl_status dev_sort_pairs_swap(cl_ctx* ctx, DevBuf<uint64_t>& keys, DevBuf<uint32_t>& vals, uint64_t n, uint32_t begin_bit, uint32_t end_bit);   // buffers of exactly n elements may come back swapped with the sort's temporaries (no copy back)
 cl_status dev_sort_keys32_pairs(cl_ctx* ctx, uint32_t* d_keys, uint32_t* d_vals, uint64_t n, uint32_t begin_bit, uint32_t end_bit);
 
 static inline uint32_t grid_for(uint64_t n, uint32_t per_block) { return (uint32_t)((n + per_block - 1) / per_block); }

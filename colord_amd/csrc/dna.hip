@@ -1102,9 +1102,10 @@ cl_status dna_group_prepare(cl_ctx* ctx, cl_dna_coder* D, DnaWalked& W, uint32_t
 		LAUNCHB(ctx, n_syms * 4.0, k_fill_sidx, grid_for(nr, 4), 256, (const uint64_t*)W.sym_off.p, s0, r0, r1, lay, G.sidx.p);
 		HIP_TRY(ctx, hipGetLastError());
 		uint32_t cbits = 1; while ((1ull << cbits) < f.ctx_base[N_FAM]) ++cbits;
-		CL_TRY(dev_sort_pairs(ctx, gkey, G.sidx.p, n_syms, 16, 16 + cbits));
+		if (s0 == 0 && W.key.n == n_syms) CL_TRY(dev_sort_pairs_swap(ctx, W.key, G.sidx, n_syms, 16, 16 + cbits));   // (one group = the whole batch: the usual case)
+		else CL_TRY(dev_sort_pairs(ctx, gkey, G.sidx.p, n_syms, 16, 16 + cbits));
 		DevBuf<uint32_t> hf; DEV_ALLOC(ctx, hf, n_syms);
-		LAUNCH(ctx, k_ctx_heads, grid_for(n_syms, 256), 256, (const uint64_t*)gkey, n_syms, hf.p);
+		LAUNCH(ctx, k_ctx_heads, grid_for(n_syms, 256), 256, (const uint64_t*)(W.key.p + s0), n_syms, hf.p);
 		CL_TRY(dev_exclusive_scan_u32(ctx, hf.p, n_syms, &G.n_seg));
 		DEV_ALLOC(ctx, G.seg, G.n_seg + 1);
 		LAUNCH(ctx, k_seg_starts, grid_for(n_syms, 256), 256, (const uint32_t*)hf.p, n_syms, G.n_seg, G.seg.p);

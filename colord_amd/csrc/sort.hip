@@ -149,8 +149,11 @@ cl_status sort_pass(cl_ctx* ctx, const K* kin, const uint32_t* vin, K* kout, uin
 	return CL_OK;
 }
 
+// swap_k / swap_v (optional): the caller's arrays as buffers of exactly n elements — when an odd number of passes leaves the result in
+// the temporaries, the buffers are SWAPPED with them instead of copying n elements back (the DNA coder's sort: 14 GB per 1-Gbase chunk
+// read and written again for nothing, the largest share of the 3.5 s of copy kernels per pass)
 template<typename K>
-cl_status sort_impl(cl_ctx* ctx, K* d_keys, uint32_t* d_vals, uint64_t n, uint32_t begin_bit, uint32_t end_bit)
+cl_status sort_impl(cl_ctx* ctx, K* d_keys, uint32_t* d_vals, uint64_t n, uint32_t begin_bit, uint32_t end_bit, DevBuf<K>* swap_k = nullptr, DevBuf<uint32_t>* swap_v = nullptr)
 {
 	if (n <= 1 || end_bit <= begin_bit) return CL_OK;
 	if (n >= (1ULL << 32)) return cl_fail(ctx, CL_E_UNSUPPORTED, "radix sort: n must be < 2^32 per call");
@@ -185,7 +188,12 @@ cl_status sort_impl(cl_ctx* ctx, K* d_keys, uint32_t* d_vals, uint64_t n, uint32
 		shift += use;
 		kin = kout; vin = vout;
 	}
-	if (kin != d_keys)
+	if (kin != d_keys && swap_k && kin == ktmp.p && (!d_vals || (swap_v && vin == vtmp.p)))
+	{
+		std::swap(*swap_k, ktmp);                                               // (same sizes: both were made for n elements)
+		if (d_vals) std::swap(*swap_v, vtmp);
+	}
+	else if (kin != d_keys)
 	{
 		HIP_TRY(ctx, hipMemcpyAsync(d_keys, kin, n * sizeof(K), hipMemcpyDeviceToDevice, ctx->stream));
 		if (d_vals) HIP_TRY(ctx, hipMemcpyAsync(d_vals, vin, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
@@ -198,6 +206,11 @@ cl_status sort_impl(cl_ctx* ctx, K* d_keys, uint32_t* d_vals, uint64_t n, uint32
 cl_status dev_sort_pairs(cl_ctx* ctx, uint64_t* d_keys, uint32_t* d_vals, uint64_t n, uint32_t begin_bit, uint32_t end_bit)
 {
 	return sort_impl<uint64_t>(ctx, d_keys, d_vals, n, begin_bit, end_bit);
+}
+cl_status dev_sort_pairs_swap(cl_ctx* ctx, DevBuf<uint64_t>& keys, DevBuf<uint32_t>& vals, uint64_t n, uint32_t begin_bit, uint32_t end_bit)
+{
+	if (keys.n != n || vals.n != n) return sort_impl<uint64_t>(ctx, keys.p, vals.p, n, begin_bit, end_bit);
+	return sort_impl<uint64_t>(ctx, keys.p, vals.p, n, begin_bit, end_bit, &keys, &vals);
 }
 cl_status dev_sort_keys32_pairs(cl_ctx* ctx, uint32_t* d_keys, uint32_t* d_vals, uint64_t n, uint32_t begin_bit, uint32_t end_bit)
 {

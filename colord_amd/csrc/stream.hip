@@ -18,6 +18,7 @@
 // RCCL in colord_amd/parallel.py); this file only says what is exchanged.  Host code; all data work is in the stages.
 #include "common.hpp"
 #include "objects.hpp"
+#include <set>
 #include <algorithm>
 #include <condition_variable>
 #include <deque>
@@ -94,15 +95,19 @@ struct cl_compressor {
 		cl_status status = CL_OK; std::string err;
 		std::map<std::string, KernelTime> times;      // kernel times of the lane for this chunk (merged into the caller's context)
 		bool done = false;
+		cl_anchors* anc = nullptr; uint32_t cc = 0;    // stage-split lanes (COLORD_HIP_LANE_SPLIT): the anchors between the two halves of stage A
 		// the model-independent half of the DNA coder for this chunk (tuple walks, and with part bounds the sort by context), made by
 		// the compressor's preparation thread beside the coding of the chunk before (cl_dna_prepare_batch)
 		std::vector<uint32_t> parts; DnaWalked* walked = nullptr; bool dna_done = false; std::map<std::string, KernelTime> dna_times;
 		// ... and of the quality coder (symbols, sort by context), which needs the input only (level 1: no flags from the edit scripts)
 		const uint8_t* d_quals = nullptr; const uint64_t* d_base_off = nullptr; QualPrepared* qprep = nullptr; bool q_done = false; std::map<std::string, KernelTime> q_times;
-		~Prepared() { if (walked) cl_dna_walked_free(walked); if (qprep) cl_qual_prepared_free(qprep); }
+		~Prepared() { if (walked) cl_dna_walked_free(walked); if (qprep) cl_qual_prepared_free(qprep); if (anc) cl_anchors_free(anc); }
 	};
 	std::mutex lane_mu; std::condition_variable lane_cv;
 	std::deque<size_t> lane_queue;                   // announced chunk indices not yet started, ascending
+	std::deque<size_t> a2_queue;                     // stage-split lanes: chunks whose anchors are made, waiting for the edit-script half
+	std::set<size_t> a1_finished; size_t a1_next = 0;    // stage-split lanes: chunks whose anchors are done but not yet queued (kept in order)
+	uint32_t n_a1_lanes = 0;                         // stage-split lanes: the first n_a1_lanes lane threads make anchors only, the others edit scripts only (0: every lane does both)
 	std::map<size_t, std::unique_ptr<Prepared>> prepared;
 	std::vector<std::thread> lane_threads; std::vector<cl_ctx*> lane_ctx;
 	size_t n_announced = 0; bool lane_stop = false;
@@ -495,8 +500,20 @@ extern "C" cl_status cl_compressor_refs_finish(cl_compressor* c)
 // Stage A of a chunk on context `ctx` (the caller's, or an encode lane's): a4 accepted k-mers, a5 candidates among the
 // EARLIER reference reads (d_bounds), a8/a9 anchors, a10-a12 edit scripts -> tuple streams.  Reads only state that pass 2a
 // completed (set, index, reference reads), so chunks are independent here.
-static cl_status stage_a(cl_compressor* c, cl_ctx* ctx, size_t chunk_idx, const cl_reads* reads, const uint32_t* h_pack_bounds, uint32_t n_packs, cl_compressor::Prepared& out)
-{
+static cl_status stage_a(cl_compressor* c, cl_ctx* ctx, size_t chunk_idx, const cl_reads* reads, const uint32_t* h_pack_bounds, uint32_t n_packs, cl_compressor::Prepared& out, int half = 0)
+{	// half: 0 = all of stage A; 1 = up to the anchors (kept in out.anc); 2 = from the anchors on
+	if (half == 2)
+	{
+		HIP_TRY(ctx, hipSetDevice(ctx->device));
+		const cl_compress_params* P2 = &c->P;
+		const uint32_t n2 = reads->n_reads, max_rec2 = std::min<uint32_t>(P2->max_rec, 8);
+		std::unique_ptr<cl_anchors, void (*)(cl_anchors*)> ag2(out.anc, cl_anchors_free);
+		out.anc = nullptr;
+		const uint64_t es_cap2 = reads->total_bases + 16ull * n2 + 4096;
+		DEV_ALLOC(ctx, out.es, es_cap2); DEV_ALLOC(ctx, out.es_off, (uint64_t)n2 + 1); DEV_ALLOC(ctx, out.es_nt, n2);
+		CL_TRY(cl_encode_reads(ctx, reads, c->refs, ag2.get(), out.cc, P2->anchor_len, P2->min_part_alt, max_rec2, P2->cost_mult, h_pack_bounds, n_packs, out.es.p, es_cap2, out.es_off.p, out.es_nt.p, &out.es_bytes));
+		return CL_OK;
+	}
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	const cl_compress_params* P = &c->P;
 	const uint32_t n = reads->n_reads;
@@ -530,17 +547,44 @@ static cl_status stage_a(cl_compressor* c, cl_ctx* ctx, size_t chunk_idx, const 
 	std::unique_ptr<cl_anchors, void (*)(cl_anchors*)> ag(anc, cl_anchors_free);
 	out.n_anchors = cl_anchors_total(anc);
 	crefs.release(); cnt.release(); common_off.release(); common.release();
+	if (half == 1) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); out.anc = ag.release(); out.cc = cc; return CL_OK; }
 	const uint64_t es_cap = reads->total_bases + 16ull * n + 4096;
 	DEV_ALLOC(ctx, out.es, es_cap); DEV_ALLOC(ctx, out.es_off, (uint64_t)n + 1); DEV_ALLOC(ctx, out.es_nt, n);
 	CL_TRY(cl_encode_reads(ctx, reads, c->refs, anc, cc, P->anchor_len, P->min_part_alt, max_rec, P->cost_mult, h_pack_bounds, n_packs, out.es.p, es_cap, out.es_off.p, out.es_nt.p, &out.es_bytes));
 	return CL_OK;
 }
 
-static void lane_main(cl_compressor* c, cl_ctx* lane)
+static void lane_main(cl_compressor* c, cl_ctx* lane, int half)
 {
 	for (;;)
 	{
 		size_t idx; cl_compressor::Prepared* job;
+		if (half == 2)
+		{	// stage-split lanes: this thread turns anchors into edit scripts, chunk after chunk
+			{
+				std::unique_lock<std::mutex> l(c->lane_mu);
+				const auto tw = std::chrono::steady_clock::now();
+				c->lane_cv.wait(l, [&]() { return c->lane_stop || !c->a2_queue.empty(); });
+				c->w_lane_idle += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
+				if (c->lane_stop) return;
+				idx = c->a2_queue.front(); c->a2_queue.pop_front();
+				job = c->prepared[idx].get();
+			}
+			lane->timing = c->ctx->timing;
+			const auto tw = std::chrono::steady_clock::now();
+			const cl_status s = job->status == CL_OK ? stage_a(c, lane, idx, job->reads, job->packs.data(), (uint32_t)job->packs.size() - 1, *job, 2) : job->status;
+			cl_timing_collect(lane);
+			{
+				std::lock_guard<std::mutex> l(c->lane_mu);
+				c->w_lane_work += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
+				if (job->status == CL_OK) { job->status = s; if (s != CL_OK) job->err = lane->err; }
+				for (auto& kv : lane->times) { auto& t = job->times[kv.first]; t.ms += kv.second.ms; t.launches += kv.second.launches; t.bytes += kv.second.bytes; t.cells += kv.second.cells; }
+				lane->times.clear();
+				job->done = true;
+			}
+			c->lane_cv.notify_all();
+			continue;
+		}
 		{
 			std::unique_lock<std::mutex> l(c->lane_mu);
 			// the lanes run at most (lanes + 2) chunks ahead of the coders: what they finish (tuple streams, ~1.5 GB per Gbase) waits in
@@ -554,14 +598,19 @@ static void lane_main(cl_compressor* c, cl_ctx* lane)
 		}
 		lane->timing = c->ctx->timing;
 		const auto tw = std::chrono::steady_clock::now();
-		const cl_status s = stage_a(c, lane, idx, job->reads, job->packs.data(), (uint32_t)job->packs.size() - 1, *job);
+		const cl_status s = stage_a(c, lane, idx, job->reads, job->packs.data(), (uint32_t)job->packs.size() - 1, *job, half);
 		cl_timing_collect(lane);
 		{
 			std::lock_guard<std::mutex> l(c->lane_mu);
 			c->w_lane_work += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
 			job->status = s; if (s != CL_OK) job->err = lane->err;
 			job->times.swap(lane->times); lane->times.clear();
-			job->done = true;
+			if (half == 1)
+			{	// the anchors are made: the chunks go on to the edit-script lanes IN ORDER (several anchor lanes may finish out of order)
+				job->cc = job->cc ? job->cc : 1; c->a1_finished.insert(idx);
+				while (!c->a1_finished.empty() && *c->a1_finished.begin() == c->a1_next) { c->a2_queue.push_back(c->a1_next); c->a1_finished.erase(c->a1_finished.begin()); ++c->a1_next; }
+			}
+			else job->done = true;
 		}
 		c->lane_cv.notify_all();
 	}
@@ -690,6 +739,10 @@ extern "C" cl_status cl_compressor_prepare_parts(cl_compressor* c, const cl_read
 		c->evolve_depth = long_parts ? 2 : 0;
 		if (long_parts) lanes = 2;
 		if (const char* e = getenv("COLORD_HIP_ENCODE_LANES")) lanes = (uint32_t)std::min(4, std::max(1, atoi(e)));
+		// stage-split lanes: "a,b" = a lanes that make anchors only + b lanes that turn anchors into edit scripts only (a pipeline of the two
+		// halves of stage A instead of whole chunks side by side: then no kernel runs beside a copy of itself)
+		c->n_a1_lanes = 0;
+		if (const char* e = getenv("COLORD_HIP_LANE_SPLIT")) { int a1 = 0, a2 = 0; if (sscanf(e, "%d,%d", &a1, &a2) == 2 && a1 >= 1 && a2 >= 1 && a1 + a2 <= 4) { c->n_a1_lanes = (uint32_t)a1; lanes = (uint32_t)(a1 + a2); } }
 		if (const char* e = getenv("COLORD_HIP_EVOLVE_DEPTH")) c->evolve_depth = (uint32_t)std::min(3, std::max(0, atoi(e)));
 		while (ctx->lanes.size() < lanes)
 		{
@@ -700,7 +753,8 @@ extern "C" cl_status cl_compressor_prepare_parts(cl_compressor* c, const cl_read
 			ctx->lanes.push_back(x);
 		}
 		c->lane_ctx.assign(ctx->lanes.begin(), ctx->lanes.begin() + lanes);
-		for (cl_ctx* x : c->lane_ctx) c->lane_threads.emplace_back(lane_main, c, x);
+		c->a1_next = idx;
+		for (size_t li = 0; li < c->lane_ctx.size(); ++li) c->lane_threads.emplace_back(lane_main, c, c->lane_ctx[li], c->n_a1_lanes ? (li < c->n_a1_lanes ? 1 : 2) : 0);
 		// the DNA preparation thread: only from the first chunk on (its walk scalars chain from chunk to chunk)
 		if (idx == 0 && c->enc_chunk == 0 && !getenv("COLORD_HIP_NO_DNA_PREP"))
 		{
