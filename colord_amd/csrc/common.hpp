@@ -403,6 +403,7 @@ static inline hipStream_t cl_launch_stream(const cl_ctx* c) { return c->launch ?
 // the launches of a scope on another stream of the context (owner thread only; cl_ctx::stream itself is never swapped: the shared
 // pool's fences and drains read it from other threads)
 struct LaunchOn { cl_ctx* c; hipStream_t prev; LaunchOn(cl_ctx* c_, hipStream_t s) : c(c_), prev(c_->launch) { c->launch = s; } ~LaunchOn() { c->launch = prev; } };
+static inline bool cl_sync_debug() { static const bool d = getenv("COLORD_HIP_SYNC_DEBUG") != nullptr; return d; }
 struct KernelTimer {
 	cl_ctx* c; const char* name; hipEvent_t a = nullptr, b = nullptr;
 	KernelTimer(cl_ctx* c_, const char* n) : c(c_), name(n)
@@ -414,6 +415,12 @@ struct KernelTimer {
 	}
 	~KernelTimer()
 	{
+		if (cl_sync_debug())
+		{	// COLORD_HIP_SYNC_DEBUG: wait for every launch and name the kernel that was running when the device reported an error
+			fprintf(stderr, "[sync] > %s\n", name);
+			const hipError_t e = hipStreamSynchronize(cl_launch_stream(c));
+			fprintf(stderr, "[sync] < %s%s%s\n", name, e == hipSuccess ? "" : ": ", e == hipSuccess ? "" : hipGetErrorString(e));
+		}
 		if (!c->timing) return;
 		(void)hipEventRecord(b, cl_launch_stream(c));
 		c->pending.push_back({ name, { a, b } });

@@ -68,8 +68,22 @@ __device__ inline uint32_t trip_index(const TripLayoutDev& L, uint32_t part, uin
 struct __attribute__((packed)) unaligned_u64 { uint64_t v; };
 __device__ inline void store_be64(uint8_t* p, uint64_t v) { ((unaligned_u64*)p)->v = __builtin_bswap64(v); }
 
+// The bytes on their way out.  A lane that stores its own bytes issues one 8-byte write request per symbol, 64 scattered requests per
+// step of the wave; alone that costs nothing, but next to kernels that fill the memory system's write queues with scattered writes
+// (radix scatters, table inserts) the coder waits for its own stores — tools/rc_interference.py: 13 ms alone, 172 ms beside a random
+// 8-byte scatter, 77 ms in the pipeline.  STAGED: every lane owns a 256-byte ring in LDS (RING_STRIDE apart: an odd
+// number of words, so that the lanes' stores spread over the banks), written with the same whole-word trick, and whenever a lane has
+// 128 bytes ready half a wave writes them out as ONE contiguous 128-byte store: two orders of magnitude fewer write requests.
+// [8 bytes before | 256-byte ring | 8 bytes behind]: a word that runs over the ring's end is stored a second time 256 bytes lower.
+constexpr uint32_t RING = 256, RING_UNIT = 128, RING_STRIDE = 8 + RING + 8 + 4;
+typedef uint64_t __attribute__((may_alias, aligned(1))) u64_any;          // (the ring is written as words at any byte and read as words and bytes)
+typedef uint32_t __attribute__((may_alias, aligned(1))) u32_any;
+__device__ inline void lds_store_be64(uint8_t* p, uint64_t v) { *(u64_any*)p = __builtin_bswap64(v); }
+// (COLORD_HIP_RC_DIRECT=1: the lanes store their bytes themselves, as before — for A/B)
+static inline int cl_rc_direct() { static const int d = [] { const char* e = getenv("COLORD_HIP_RC_DIRECT"); return e ? atoi(e) : 0; }(); return d; }
+
 // one lane per part, one wave per group of 64 parts (sub_rc.h:72-100,203-210)
-static __global__ __launch_bounds__(64) void k_range_code(const triple_t* __restrict__ trip, const uint64_t* __restrict__ group_base,
+template<bool STAGED> static __global__ __launch_bounds__(64) void k_range_code(const triple_t* __restrict__ trip, const uint64_t* __restrict__ group_base,
                                                          const uint32_t* __restrict__ part_len, uint32_t n_parts,
                                                          uint8_t* __restrict__ out, const uint64_t* __restrict__ part_out_off, uint64_t* __restrict__ part_size,
                                                          const uint64_t* __restrict__ inv_tab)
@@ -79,10 +93,34 @@ static __global__ __launch_bounds__(64) void k_range_code(const triple_t* __rest
 	const bool live = p < n_parts;
 	const uint64_t MASK = 0xff00000000000000ULL;                            // (TOP = 0x00ffffffffffff = 2^48 - 1 appears below as its 32-bit halves)
 	uint64_t low = 0, range = MASK;
-	uint8_t* outp = live ? out + part_out_off[p] : nullptr;
+	const uint64_t out_off = live ? part_out_off[p] : 0;
+	uint8_t* outp = out + out_off;
 	const uint64_t cap = live ? part_out_off[p + 1] - part_out_off[p] : 0;
 	const uint32_t cap8 = cap < 8 ? 0u : cap - 8 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)(cap - 8);    // last position an 8-byte store may start at
 	uint32_t n_out = 0; bool overflow = cap < 8 || cap > 0xfffffff0ull;
+	__shared__ __attribute__((aligned(16))) uint8_t s_ring[STAGED ? 64 * RING_STRIDE : 16];
+	uint8_t* const ring = s_ring + (STAGED ? threadIdx.x * RING_STRIDE + 8 : 0);
+	const uint32_t room = overflow ? 0u : (uint32_t)cap;                      // bytes this lane may write
+	uint32_t flushed = 0;                                                    // bytes of the ring already written out (a multiple of RING_UNIT)
+	// write out every lane's complete 128-byte units (called once per round: a round adds at most 8 U = 64 bytes per lane, so a ring
+	// holds at most 127 + 64 bytes and the 8-byte stores never reach back into bytes not yet written out)
+	auto drain = [&]()
+	{
+		static_assert(RING_UNIT - 1 + 8 * 8 + 8 <= RING, "a round's bytes must fit behind an incomplete unit");
+		uint64_t m;
+		while ((m = __ballot(n_out - flushed >= RING_UNIT)) != 0)
+		{
+			const int L = __builtin_ctzll(m);
+			const uint32_t fl = __builtin_amdgcn_readlane(flushed, L), rm = __builtin_amdgcn_readlane(room, L);
+			const uint64_t o = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(out_off >> 32), L) << 32) | (uint32_t)__builtin_amdgcn_readlane((uint32_t)out_off, L);   // (readlane returns int)
+			if (fl + RING_UNIT <= rm && threadIdx.x < RING_UNIT / 4)
+			{
+				const uint32_t w = *(const u32_any*)(s_ring + L * RING_STRIDE + 8 + (fl & (RING - 1)) + threadIdx.x * 4);
+				*(u32_any*)(out + o + fl + threadIdx.x * 4) = w;
+			}
+			if ((int)threadIdx.x == L) flushed += RING_UNIT;                      // (a unit that does not fit is dropped: the part is reported as overflowing at the end)
+		}
+	};
 	const uint32_t len = live ? part_len[p] : 0;
 	uint32_t lmax = len;
 #pragma unroll
@@ -149,9 +187,14 @@ static __global__ __launch_bounds__(64) void k_range_code(const triple_t* __rest
 			}
 			range = ((uint64_t)rh << 32) | rl; low = ((uint64_t)lh << 32) | ll;
 			// the bytes: the whole word at the write position (held inside the part's room; a part that outgrows it is seen at the end)
-			if (nb) store_be64(outp + (n_out < cap8 ? n_out : cap8), low0);
+			if constexpr (STAGED)
+			{
+				if (nb) { const uint32_t rp = n_out & (RING - 1); lds_store_be64(ring + rp, low0); if (rp > RING - 8) lds_store_be64(ring + rp - RING, low0); }
+			}
+			else if (nb) store_be64(outp + (n_out < cap8 ? n_out : cap8), low0);
 			n_out += nb;
 		}
+		if constexpr (STAGED) drain();
 	};
 	uint32_t lmin = live ? len : 0u;
 #pragma unroll
@@ -171,6 +214,24 @@ static __global__ __launch_bounds__(64) void k_range_code(const triple_t* __rest
 		round(SOME, pos + U, B, iB, C, iC, A);
 		if (pos + 2 * U >= lmax) break;
 		round(SOME, pos + 2 * U, C, iC, A, iA, B);
+	}
+	if constexpr (STAGED)
+	{
+		// End(): 8 bytes of low (sub_rc.h:203-210) go through the ring as well; then every lane's remainder, byte by byte, by the whole wave
+		{ const uint32_t rp = n_out & (RING - 1); lds_store_be64(ring + rp, low); if (rp > RING - 8) lds_store_be64(ring + rp - RING, low); }
+		n_out += 8;
+		if (!live || n_out > room || (uint32_t)(range >> 32) < 0x00010000u) overflow = true;   // (an empty range: corrupt triples)
+		drain();
+		const uint32_t rem = overflow ? 0u : n_out - flushed;
+		for (int L = 0; L < 64; ++L)
+		{
+			const uint32_t n = __builtin_amdgcn_readlane(rem, L), fl = __builtin_amdgcn_readlane(flushed, L);
+			if (n == 0) continue;
+			const uint64_t o = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(out_off >> 32), L) << 32) | (uint32_t)__builtin_amdgcn_readlane((uint32_t)out_off, L);   // (readlane returns int)
+			for (uint32_t b = threadIdx.x; b < n; b += 64) out[o + fl + b] = s_ring[L * RING_STRIDE + 8 + ((fl + b) & (RING - 1))];
+		}
+		if (live) part_size[p] = overflow ? ~0ULL : n_out;
+		return;
 	}
 	if (!live) return;
 	if ((uint32_t)(range >> 32) < 0x00010000u) overflow = true;                      // (an empty range: corrupt triples)
