@@ -1269,7 +1269,8 @@ cl_status dna_evolve_batch(cl_ctx* ctx, cl_dna_coder* D, const cl_reads* refs, c
 			LaunchOn on(ctx, G->stream);                                          // (launch + timing events on the coder's stream)
 			G->sync.s = G->stream;
 			hipError_t e1 = hipMemcpyAsync(G->d_out_off.p, G->out_off.data(), (np + 1) * 8, hipMemcpyHostToDevice, G->stream);
-			if (cl_rc_direct() == 1 || cl_rc_direct() == 2) { LAUNCHB_NAMED(ctx, "k_range_code", n_syms * 8.0, k_range_code<false>, ng, 64, (const triple_t*)trip.p, (const uint64_t*)d_gbase.p, (const uint32_t*)d_plen.p, np, G->tmp.p, (const uint64_t*)G->d_out_off.p, G->d_size.p, inv_tab); } else { LAUNCHB_NAMED(ctx, "k_range_code", n_syms * 8.0, k_range_code<true>, ng, 64, (const triple_t*)trip.p, (const uint64_t*)d_gbase.p, (const uint32_t*)d_plen.p, np, G->tmp.p, (const uint64_t*)G->d_out_off.p, G->d_size.p, inv_tab); }
+			const bool cl_rc_direct_here = cl_rc_direct() == 1 || cl_rc_direct() == 2;
+			LAUNCH_RANGE_CODE(ctx, n_syms * 8.0, ng, (const triple_t*)trip.p, (const uint64_t*)d_gbase.p, (const uint32_t*)d_plen.p, np, G->tmp.p, (const uint64_t*)G->d_out_off.p, G->d_size.p, inv_tab);
 			hipError_t e2 = hipGetLastError();
 			HIP_TRY(ctx, e1); HIP_TRY(ctx, e2);
 		}

@@ -26,7 +26,7 @@ qc = ctx.qual_coder(mode=2, source=0, level=1, fwd=(7, 14, 26))
 for it in range(2):
     payload, sizes = qc.encode(reads, q, off, pb)
     torch.cuda.synchronize()
-    ms, k, byt = ctx.acc.pop("k_range_code", (0.0, 0, 0.0))
+    ms, k, byt = ctx.acc.pop("k_range_code", (0.0, 0, 0.0))[:3]
     ctx.acc.clear()
     longest = int(np.diff(pb).max()) * rlen
     print(f"pass {it}: {len(pb) - 1} parts of <= {longest} symbols; k_range_code {ms:.1f} ms in {k} launches -> {ms * 1e6 / max(k, 1) / longest:.1f} ns per symbol of the chain; "
