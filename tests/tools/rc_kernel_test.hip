@@ -46,7 +46,8 @@ int main()
 		plen[p] = n;
 	}
 	const uint32_t ng = (np + 63) / 64;
-	std::vector<uint64_t> gbase(ng), out_off(np + 1, 0);
+	const uint64_t BIG = (1ull << 31) + 4096;                    // the parts' room begins beyond 2 GB: offsets whose low half has its top bit set
+	std::vector<uint64_t> gbase(ng), out_off(np + 1, BIG);
 	uint64_t total = 0;
 	for (uint32_t g = 0; g < ng; ++g) { gbase[g] = total; uint32_t m = 0; for (uint32_t p = g * 64; p < np && p < g * 64 + 64; ++p) m = std::max(m, plen[p]); total += (uint64_t)m * 64; }
 	std::vector<triple_t> trip(total + 64, 0xdeadbeefdeadbeefULL);
@@ -57,21 +58,28 @@ int main()
 	hipMalloc((void**)&d_inv, (uint64_t)INV_TABLE_SIZE * 8); hipMalloc((void**)&d_plen, np * 4); hipMalloc((void**)&d_out, out_off[np]);
 	hipMemcpy(d_trip, trip.data(), trip.size() * 8, hipMemcpyHostToDevice); hipMemcpy(d_gbase, gbase.data(), ng * 8, hipMemcpyHostToDevice);
 	hipMemcpy(d_off, out_off.data(), (np + 1) * 8, hipMemcpyHostToDevice); hipMemcpy(d_plen, plen.data(), np * 4, hipMemcpyHostToDevice);
-	hipMemset(d_out, 0xAA, out_off[np]);
 	hipLaunchKernelGGL(k_fill_inv_table, dim3(INV_TABLE_SIZE / 256), dim3(256), 0, 0, d_inv);
-	hipLaunchKernelGGL(k_range_code, dim3(ng), dim3(64), 0, 0, (const triple_t*)d_trip, (const uint64_t*)d_gbase, (const uint32_t*)d_plen, np, d_out, (const uint64_t*)d_off, d_size, (const uint64_t*)d_inv);
-	if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); return 2; }
-	std::vector<uint64_t> size(np); std::vector<uint8_t> out(out_off[np]);
-	hipMemcpy(size.data(), d_size, np * 8, hipMemcpyDeviceToHost); hipMemcpy(out.data(), d_out, out.size(), hipMemcpyDeviceToHost);
 	int bad = 0;
-	if (getenv("RC_DEBUG")) host_code(parts[1], true);
-	for (uint32_t p = 0; p < np; ++p)
+	// the kernel's three forms: bytes staged in LDS rings + reciprocal table (default), staged + computed reciprocals, lane-by-lane stores + table
+	for (int form = 0; form < 3; ++form)
 	{
-		const std::vector<uint8_t> e = host_code(parts[p]);
-		if (size[p] != e.size()) { if (bad++ < 10) printf("part %u (%u symbols): size %llu, expected %zu\n", p, plen[p], (unsigned long long)size[p], e.size()); continue; }
-		for (size_t i = 0; i < e.size(); ++i) if (out[out_off[p] + i] != e[i]) { if (bad++ < 10) printf("part %u: byte %zu of %zu differs (%02x, expected %02x)\n", p, i, e.size(), out[out_off[p] + i], e[i]); break; }
-		for (uint64_t i = out_off[p] + e.size(); i < out_off[p + 1]; ++i) if (out[i] != 0xAA) { if (bad++ < 10) printf("part %u: wrote beyond its size (offset %llu of size %zu)\n", p, (unsigned long long)(i - out_off[p]), e.size()); break; }
+		hipMemset(d_out + BIG, 0xAA, out_off[np] - BIG); hipMemset(d_size, 0, np * 8);
+		if (form == 0) hipLaunchKernelGGL((k_range_code<true, true>), dim3(ng), dim3(64), 0, 0, (const triple_t*)d_trip, (const uint64_t*)d_gbase, (const uint32_t*)d_plen, np, d_out, (const uint64_t*)d_off, d_size, (const uint64_t*)d_inv);
+		else if (form == 1) hipLaunchKernelGGL((k_range_code<true, false>), dim3(ng), dim3(64), 0, 0, (const triple_t*)d_trip, (const uint64_t*)d_gbase, (const uint32_t*)d_plen, np, d_out, (const uint64_t*)d_off, d_size, (const uint64_t*)d_inv);
+		else hipLaunchKernelGGL((k_range_code<false, true>), dim3(ng), dim3(64), 0, 0, (const triple_t*)d_trip, (const uint64_t*)d_gbase, (const uint32_t*)d_plen, np, d_out, (const uint64_t*)d_off, d_size, (const uint64_t*)d_inv);
+		if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed (form %d)\n", form); return 2; }
+		std::vector<uint64_t> size(np); std::vector<uint8_t> out_v(out_off[np] - BIG);
+		hipMemcpy(size.data(), d_size, np * 8, hipMemcpyDeviceToHost); hipMemcpy(out_v.data(), d_out + BIG, out_v.size(), hipMemcpyDeviceToHost);
+		const uint8_t* out = out_v.data() - BIG;
+		if (form == 0 && getenv("RC_DEBUG")) host_code(parts[1], true);
+		for (uint32_t p = 0; p < np; ++p)
+		{
+			const std::vector<uint8_t> e = host_code(parts[p]);
+			if (size[p] != e.size()) { if (bad++ < 10) printf("form %d part %u (%u symbols): size %llu, expected %zu\n", form, p, plen[p], (unsigned long long)size[p], e.size()); continue; }
+			for (size_t i = 0; i < e.size(); ++i) if (out[out_off[p] + i] != e[i]) { if (bad++ < 10) printf("form %d part %u: byte %zu of %zu differs (%02x, expected %02x)\n", form, p, i, e.size(), out[out_off[p] + i], e[i]); break; }
+			for (uint64_t i = out_off[p] + e.size(); i < out_off[p + 1]; ++i) if (out[i] != 0xAA) { if (bad++ < 10) printf("form %d part %u: wrote beyond its size (offset %llu of size %zu)\n", form, p, (unsigned long long)(i - out_off[p]), e.size()); break; }
+		}
 	}
-	printf(bad ? "FAILED: %d parts\n" : "ok: %u parts equal the host coder, nothing written beyond a part's size\n", bad ? bad : np);
+	printf(bad ? "FAILED: %d parts\n" : "ok: %u parts equal the host coder in all three forms of the kernel, nothing written beyond a part's size\n", bad ? bad : np);
 	return bad ? 1 : 0;
 }
