@@ -20,6 +20,7 @@
 #include <fcntl.h>
 #include <unistd.h>
 #include <condition_variable>
+#include <functional>
 #include <mutex>
 
 namespace {
@@ -68,6 +69,7 @@ struct Options {
 	double chunk_bases = 1.0e9;
 	uint64_t part_symbols = 2u << 21;               // --part-symbols: the coder parts close once their reads (+ 1 guard each) reach this; default = the reader packs (defs.h:45)
 	int parse_threads = 0;                          // --parse-threads (0: as many as the host offers, at most 32)
+	bool stream_input = false;                      // --stream-input: the input is read three times (k-mers, reference reads, coding) and only a window of chunks is resident in HBM
 	int domains = 1;                                // --domains K: K INDEPENDENT model domains on one GPU (own k-mer set, references, index, models each): decoded side by side
 	int gpus = 1; std::vector<int> gpu_list; std::string transport = "rccl";   // --gpus N [--gpu-list a,b,..] [--transport rccl|host]: reads sharded over N GPUs (run_compress_multi)
 };
@@ -106,6 +108,17 @@ struct Reader {
 	std::vector<uint8_t> ids, plus; std::vector<uint64_t> id_off{ 0 };
 	uint64_t n_reads = 0, n_bases = 0;
 	uint64_t part_symbols = 2u << 21;
+	bool replay = false;                                         // a later pass over the same input (--stream-input): ids, counters and checks are those of the first
+	// back to the first record: the chunks come again exactly as in the first pass (the reference reads its input twice as well,
+	// compression.cpp:432,547-561)
+	void rewind()
+	{
+		replay = true;
+		if (map) { mp = map; rec_pos = 0; return; }
+		if (gzrewind(g) != 0) die("cannot rewind the input");
+		pos = len = 0; eof = false; which = 0; for (auto& l : line) l.clear();
+		fa_header.clear(); fa_seq.clear(); fa_state = 0;
+	}
 	// plain FASTQ, several threads: the mapping is cut into byte ranges at record starts, every range is indexed by a thread of its own
 	// (line ends by memchr, the reader's checks), then the chunks are filled from the index by parallel copies (index_mapped below)
 	struct Rec { const uint8_t* id; const uint8_t* seq; const uint8_t* qual; uint32_t id_len, len; uint8_t plus_eq; };
@@ -245,9 +258,8 @@ struct Reader {
 		while (rec_pos < recs.size() && !chunk_full())
 		{
 			const Rec& r = recs[rec_pos++];
-			ids.insert(ids.end(), r.id, r.id + r.id_len); id_off.push_back(ids.size()); plus.push_back(r.plus_eq);
+			if (!replay) { ids.insert(ids.end(), r.id, r.id + r.id_len); id_off.push_back(ids.size()); plus.push_back(r.plus_eq); ++n_reads; n_bases += r.len; }
 			ch.n += r.len; ch.off.push_back(ch.n);
-			++n_reads; n_bases += r.len;
 			close_bounds(ch, r.len);
 		}
 		finish_bounds(ch);
@@ -293,7 +305,7 @@ struct Reader {
 			if (*h0 != '@') die("FASTQ record does not start with '@'");
 			if (*p0 != '+') die("FASTQ record without '+' line");
 			if (s1 - s0 != q1 - q0) die("sequence and quality lengths differ");
-			header_symbols += (uint64_t)(h1 - h0) + (uint64_t)(p1 - p0);
+			if (!replay) header_symbols += (uint64_t)(h1 - h0) + (uint64_t)(p1 - p0);
 			const bool eq = p1 - p0 > 1;
 			if (eq && ((p1 - p0) != (h1 - h0) || memcmp(p0 + 1, h0 + 1, (size_t)(h1 - h0 - 1)) != 0)) die("quality header not empty but different than read header");   // in_reads.cpp:79-92
 			add_record(ch, (const char*)h0 + 1, (size_t)(h1 - h0 - 1), (const char*)s0, (size_t)(s1 - s0), (const char*)q0, eq);
@@ -301,15 +313,14 @@ struct Reader {
 		finish_bounds(ch);
 		return ch.off.size() > 1;
 	}
-	void fill() { const int n = gzread(g, buf.data(), (unsigned)buf.size()); if (n < 0) die("read error (zlib)"); len = (size_t)n; pos = 0; total_bytes += len; if (!n) eof = true; }
+	void fill() { const int n = gzread(g, buf.data(), (unsigned)buf.size()); if (n < 0) die("read error (zlib)"); len = (size_t)n; pos = 0; if (!replay) total_bytes += len; if (!n) eof = true; }
 	void add_record(Chunk& ch, const char* id, size_t id_len, const char* seq, size_t seq_len, const char* qual, bool plus_eq)
 	{
-		ids.insert(ids.end(), id, id + id_len); id_off.push_back(ids.size()); plus.push_back(plus_eq ? 1 : 0);
+		if (!replay) { ids.insert(ids.end(), id, id + id_len); id_off.push_back(ids.size()); plus.push_back(plus_eq ? 1 : 0); ++n_reads; n_bases += seq_len; }
 		ch.reserve(ch.n + seq_len + 1, fastq);
 		memcpy(ch.bases + ch.n, seq, seq_len);
 		if (fastq) memcpy(ch.quals + ch.n, qual, seq_len);
 		ch.n += seq_len; ch.off.push_back(ch.n);
-		++n_reads; n_bases += seq_len;
 		close_bounds(ch, seq_len);
 	}
 	void flush_fastq(Chunk& ch)
@@ -317,14 +328,14 @@ struct Reader {
 		if (line[0].empty() || line[0][0] != '@') die("FASTQ record does not start with '@'");
 		if (line[2].empty() || line[2][0] != '+') die("FASTQ record without '+' line");
 		if (line[1].size() != line[3].size()) die("sequence and quality lengths differ");
-		header_symbols += line[0].size() + line[2].size();
+		if (!replay) header_symbols += line[0].size() + line[2].size();
 		const bool eq = line[2].size() > 1;
 		if (eq && line[2].compare(1, std::string::npos, line[0], 1, std::string::npos) != 0) die("quality header not empty but different than read header");   // in_reads.cpp:79-92
 		add_record(ch, line[0].data() + 1, line[0].size() - 1, line[1].data(), line[1].size(), line[3].data(), eq);
 	}
 	void flush_fasta(Chunk& ch)
 	{
-		header_symbols += fa_header.size();
+		if (!replay) header_symbols += fa_header.size();
 		add_record(ch, fa_header.data() + 1, fa_header.size() - 1, fa_seq.data(), fa_seq.size(), nullptr, false);
 		fa_header.clear(); fa_seq.clear();
 	}
@@ -445,6 +456,8 @@ static void usage()
 		"  --part-symbols N   coder parts of N symbols instead of the reference's 4194304 (defs.h:45): same FASTQ back from either\n"
 		"                     decompressor, 8 more bytes per part, far shorter interval-coder chains (65536: +0.04 %% size, 1.4x the speed)\n"
 		"  --parse-threads N  threads that index a plain FASTQ (default: the host's, at most 32)\n"
+		"  --stream-input     bounded device memory: the input is read three times (k-mers, reference reads, coding) and only a window of\n"
+		"                     four chunks is resident at a time instead of the whole input (same archive)\n"
 		"  --domains K        K independent model domains (equal shares of the reads, each compressed on its own): `colord_hip decompress`\n"
 		"                     decodes them side by side; costs archive size (own k-mer statistics and reference reads per domain)\n"
 		"  --gpus N [--gpu-list a,b,..] [--transport rccl|host]   reads sharded over N GPUs, one host thread and one model domain per GPU;\n"
@@ -844,6 +857,7 @@ int run_compress(int argc, char** argv)
 		else if (a == "--transport") { O.transport = need(i); if (O.transport != "rccl" && O.transport != "host") die("--transport must be rccl or host"); }
 		else if (a == "--chunk-bases") O.chunk_bases = atof(need(i).c_str());
 		else if (a == "--part-symbols") { O.part_symbols = strtoull(need(i).c_str(), nullptr, 10); if (O.part_symbols < 1024 || O.part_symbols > (2u << 21)) die("--part-symbols must be in [1024, 4194304]"); }
+		else if (a == "--stream-input") O.stream_input = true;
 		else if (a == "--parse-threads") { O.parse_threads = atoi(need(i).c_str()); if (O.parse_threads < 1 || O.parse_threads > 256) die("--parse-threads must be in [1, 256]"); }
 		else if (a == "-h" || a == "--help") { usage(); return 0; }
 		else if (!a.empty() && a[0] == '-' && a.size() > 1) die("unknown option " + a);
@@ -875,6 +889,7 @@ int run_compress(int argc, char** argv)
 	for (size_t i = 0; i < qd.fwd.size(); ++i) if (qd.fwd[i] > 95 || (i && qd.fwd[i] < qd.fwd[i - 1])) die("quality thresholds must be ascending values in [0, 95]");
 	if (!O.gpu_list.empty() && O.gpus == 1) O.gpus = (int)O.gpu_list.size();
 	if (O.domains > 1 && O.gpus > 1) die("--domains and --gpus exclude each other (every GPU is a model domain already)");
+	if (O.stream_input && (O.gpus > 1 || O.domains > 1)) die("--stream-input is not available with --gpus / --domains");
 	if (O.gpus > 1 || O.domains > 1) return run_compress_multi(O, P, qd, argc, argv);
 
 	const auto t0 = std::chrono::steady_clock::now();
@@ -930,24 +945,54 @@ int run_compress(int argc, char** argv)
 	}
 
 	// pass 1 while parsing: every chunk goes to HBM (2-bit arena + quality bytes) and stays there for the three passes
-	// (the parser fills one pinned buffer on a thread of its own while this thread uploads and scans the other)
+	// (the parser fills one pinned buffer on a thread of its own while this thread uploads and scans the other).
+	// --stream-input: a chunk leaves HBM again after each pass and the input is read three times (k-mers; reference reads; coding,
+	// where a loader thread keeps a window of chunks resident ahead of the coders) — the reference reads its file twice for the same
+	// reason (compression.cpp:432,547-561).
 	std::vector<DevChunk> chunks; Chunk hostbuf[2];
-	std::mutex pmu; std::condition_variable pcv; int filled[2] = { 0, 0 };      // 0 free, 1 full, 2 end of input
-	std::thread parser([&]() {
-		for (int i = 0;; i ^= 1)
+	auto for_each_chunk = [&](const std::function<void(Chunk&)>& fn) {
+		std::mutex pmu; std::condition_variable pcv; int filled[2] = { 0, 0 };      // 0 free, 1 full, 2 end of input
+		std::thread parser([&]() {
+			for (int i = 0;; i ^= 1)
+			{
+				{ std::unique_lock<std::mutex> l(pmu); pcv.wait(l, [&]() { return filled[i] == 0; }); }
+				const bool ok = R.next_chunk(hostbuf[i], (uint64_t)O.chunk_bases);
+				{ std::lock_guard<std::mutex> l(pmu); filled[i] = ok ? 1 : 2; }
+				pcv.notify_all();
+				if (!ok) break;
+			}
+		});
+		for (int hi = 0;; hi ^= 1)
 		{
-			{ std::unique_lock<std::mutex> l(pmu); pcv.wait(l, [&]() { return filled[i] == 0; }); }
-			const bool ok = R.next_chunk(hostbuf[i], (uint64_t)O.chunk_bases);
-			{ std::lock_guard<std::mutex> l(pmu); filled[i] = ok ? 1 : 2; }
+			{ std::unique_lock<std::mutex> l(pmu); pcv.wait(l, [&]() { return filled[hi] != 0; }); }
+			if (filled[hi] == 2) break;
+			fn(hostbuf[hi]);
+			{ std::lock_guard<std::mutex> l(pmu); filled[hi] = 0; }
 			pcv.notify_all();
-			if (!ok) break;
 		}
-	});
-	for (int hi = 0;; hi ^= 1)
-	{
-		{ std::unique_lock<std::mutex> l(pmu); pcv.wait(l, [&]() { return filled[hi] != 0; }); }
-		if (filled[hi] == 2) break;
-		Chunk& host = hostbuf[hi];
+		parser.join();
+	};
+	auto upload_chunk = [&](cl_ctx* uc, const Chunk& host, DevChunk& dc) {
+		uint8_t* d_bases = nullptr;
+		hipck(hipMalloc((void**)&d_bases, host.n + 1), "hipMalloc"); hipck(hipMalloc((void**)&dc.d_off, host.off.size() * 8), "hipMalloc");
+		hipck(hipMemcpy(d_bases, host.bases, host.n, hipMemcpyHostToDevice), "hipMemcpy");
+		hipck(hipMemcpy(dc.d_off, host.off.data(), host.off.size() * 8, hipMemcpyHostToDevice), "hipMemcpy");
+		if (with_qual) { hipck(hipMalloc((void**)&dc.d_quals, host.n + 1), "hipMalloc (the input does not fit this GPU's memory: --stream-input keeps only a window of it resident)"); hipck(hipMemcpy(dc.d_quals, host.quals, host.n, hipMemcpyHostToDevice), "hipMemcpy"); }
+		ck(uc, cl_reads_pack(uc, d_bases, dc.d_off, dc.n_reads, 1, &dc.reads), "input");        // "Only ACGTN symbols supported inside a read"
+		hipck(hipFree(d_bases), "hipFree");
+	};
+	auto free_chunk = [&](DevChunk& dc) {
+		if (dc.reads) cl_reads_free(dc.reads);
+		if (dc.d_quals) (void)hipFree(dc.d_quals);
+		if (dc.d_off) (void)hipFree(dc.d_off);
+		dc.reads = nullptr; dc.d_quals = nullptr; dc.d_off = nullptr;
+	};
+	// a later pass must see the chunks of the first
+	auto same_chunk = [&](const Chunk& host, size_t ci) {
+		if (ci >= chunks.size() || chunks[ci].n_reads != host.off.size() - 1 || chunks[ci].n_bases != host.n || chunks[ci].packs != host.packs || chunks[ci].parts != host.parts)
+			die("the input changed between two passes over it (--stream-input)");
+	};
+	for_each_chunk([&](Chunk& host) {
 		DevChunk dc; dc.n_reads = (uint32_t)(host.off.size() - 1); dc.n_bases = host.n; dc.packs = host.packs; dc.parts = host.parts;
 		if (with_qual)
 		{	// quality bytes outside 33..128 would index past the coder's tables: the input is rejected, not coded (qualities are Phred+33)
@@ -955,20 +1000,12 @@ int run_compress(int argc, char** argv)
 			for (uint64_t i = 0; i < host.n; ++i) { lo = qv[i] < lo ? qv[i] : lo; hi8 = qv[i] > hi8 ? qv[i] : hi8; }
 			if (host.n && (lo < 33 || hi8 > 33 + 95)) die("quality values outside '!'..'~'+1 (Phred+33, 0..95) are not supported");
 		}
-		uint8_t* d_bases = nullptr;
-		hipck(hipMalloc((void**)&d_bases, host.n + 1), "hipMalloc"); hipck(hipMalloc((void**)&dc.d_off, host.off.size() * 8), "hipMalloc");
-		hipck(hipMemcpy(d_bases, host.bases, host.n, hipMemcpyHostToDevice), "hipMemcpy");
-		hipck(hipMemcpy(dc.d_off, host.off.data(), host.off.size() * 8, hipMemcpyHostToDevice), "hipMemcpy");
-		if (with_qual) { hipck(hipMalloc((void**)&dc.d_quals, host.n + 1), "hipMalloc (the input does not fit this GPU's memory)"); hipck(hipMemcpy(dc.d_quals, host.quals, host.n, hipMemcpyHostToDevice), "hipMemcpy"); }
-		ck(ctx, cl_reads_pack(ctx, d_bases, dc.d_off, dc.n_reads, 1, &dc.reads), "input");        // "Only ACGTN symbols supported inside a read"
-		hipck(hipFree(d_bases), "hipFree");
+		upload_chunk(ctx, host, dc);
 		ck(ctx, cl_compressor_count_add(cmp, dc.reads), "pass 1");
+		if (O.stream_input) free_chunk(dc);
 		chunks.push_back(std::move(dc));
-		{ std::lock_guard<std::mutex> l(pmu); filled[hi] = 0; }
-		pcv.notify_all();
-	}
-	parser.join();
-	hostbuf[0].release(); hostbuf[1].release();
+	});
+	if (!O.stream_input) { hostbuf[0].release(); hostbuf[1].release(); }
 	lap("input parsed, uploaded and scanned (pass 1)");
 	const uint32_t n = (uint32_t)R.n_reads; const uint64_t total = R.n_bases;
 	if (!n) die("no reads in " + O.in);
@@ -993,7 +1030,21 @@ int run_compress(int argc, char** argv)
 		cl_reads_free(pr);
 		if (O.verbose) fprintf(stderr, "# ref genome pseudo reads: %u (length %u, overlap %u)\n", n_pseudo, genome_read_len, genome_overlap);
 	}
-	for (auto& dc : chunks) ck(ctx, cl_compressor_refs_add(cmp, dc.reads), "reference reads");
+	if (!O.stream_input) for (auto& dc : chunks) ck(ctx, cl_compressor_refs_add(cmp, dc.reads), "reference reads");
+	else
+	{
+		R.rewind();
+		size_t ci = 0;
+		for_each_chunk([&](Chunk& host) {
+			same_chunk(host, ci);
+			DevChunk dc; dc.n_reads = chunks[ci].n_reads;
+			upload_chunk(ctx, host, dc);
+			ck(ctx, cl_compressor_refs_add(cmp, dc.reads), "reference reads");
+			free_chunk(dc);
+			++ci;
+		});
+		if (ci != chunks.size()) die("the input changed between two passes over it (--stream-input)");
+	}
 	ck(ctx, cl_compressor_refs_finish(cmp), "reference index");
 	lap("reference reads and index");
 	uint64_t mean_read_len = 0; uint32_t sparse_range = 0, n_refs = 0;
@@ -1020,9 +1071,49 @@ int run_compress(int argc, char** argv)
 		// every chunk is resident: announce them, so that candidates / anchors / edit scripts of the next chunks are computed on the
 		// compressor's encode lanes while this thread codes and writes the parts of the chunks before them
 		// (the coder parts are the reader packs: with them the `dna` coder's walks and sort of the next chunk are made ahead too)
-		for (auto& dc : chunks) ck(ctx, cl_compressor_prepare_parts(cmp, dc.reads, dc.packs.data(), (uint32_t)dc.packs.size() - 1, dc.parts.data(), (uint32_t)dc.parts.size() - 1, dc.d_quals, dc.d_off), "look-ahead");
-		for (auto& dc : chunks)
+		// --stream-input: a loader thread (a context of its own) parses and uploads the chunks again, at most WINDOW + 1 resident: the one
+		// being coded and WINDOW announced ahead of it for the encode lanes and the preparation threads; it also frees what has been coded
+		constexpr size_t WINDOW = 3;
+		std::mutex lmu; std::condition_variable lcv; size_t n_loaded = 0, done_upto = 0; std::thread loader; cl_ctx* lctx = nullptr;
+		if (O.stream_input)
 		{
+			ck(nullptr, cl_ctx_create(O.gpu, &lctx), "cl_ctx_create");
+			R.rewind();
+			loader = std::thread([&]() {
+				hipck(hipSetDevice(O.gpu), "hipSetDevice");
+				size_t freed = 0;
+				auto free_done = [&](size_t upto) { for (; freed < upto; ++freed) free_chunk(chunks[freed]); };
+				size_t ci = 0;
+				for_each_chunk([&](Chunk& host) {
+					same_chunk(host, ci);
+					size_t upto;
+					{ std::unique_lock<std::mutex> l(lmu); lcv.wait(l, [&]() { return ci - done_upto < WINDOW + 1; }); upto = done_upto; }
+					free_done(upto);
+					upload_chunk(lctx, host, chunks[ci]);
+					++ci;
+					{ std::lock_guard<std::mutex> l(lmu); n_loaded = ci; }
+					lcv.notify_all();
+				});
+				if (ci != chunks.size()) die("the input changed between two passes over it (--stream-input)");
+				{ std::unique_lock<std::mutex> l(lmu); lcv.wait(l, [&]() { return done_upto == chunks.size(); }); }
+				free_done(chunks.size());
+			});
+		}
+		else for (auto& dc : chunks) ck(ctx, cl_compressor_prepare_parts(cmp, dc.reads, dc.packs.data(), (uint32_t)dc.packs.size() - 1, dc.parts.data(), (uint32_t)dc.parts.size() - 1, dc.d_quals, dc.d_off), "look-ahead");
+		size_t announced = 0;
+		for (size_t ci = 0; ci < chunks.size(); ++ci)
+		{
+			DevChunk& dc = chunks[ci];
+			if (O.stream_input)
+			{
+				size_t have;
+				{ std::unique_lock<std::mutex> l(lmu); lcv.wait(l, [&]() { return n_loaded > ci; }); have = n_loaded; }
+				for (; announced < have; ++announced)
+				{
+					DevChunk& x = chunks[announced];
+					ck(ctx, cl_compressor_prepare_parts(cmp, x.reads, x.packs.data(), (uint32_t)x.packs.size() - 1, x.parts.data(), (uint32_t)x.parts.size() - 1, x.d_quals, x.d_off), "look-ahead");
+				}
+			}
 			const uint32_t np = (uint32_t)dc.parts.size() - 1;
 			std::vector<uint64_t> dsz(np), qsz(np); cl_compress_info info{};
 			ck(ctx, cl_compressor_encode(cmp, dc.reads, dc.d_quals, dc.d_off, dc.parts.data(), np, dc.packs.data(), (uint32_t)dc.packs.size() - 1, d_dna, dna_cap, dsz.data(), d_qual, qual_cap, qsz.data(), &info), "pass 2");
@@ -1032,8 +1123,10 @@ int run_compress(int argc, char** argv)
 			uint64_t o = 0; for (uint32_t p = 0; p < np; ++p) { ar.add(s_dna, h_dna.data() + o, dsz[p], dc.parts[p + 1] - dc.parts[p]); o += dsz[p]; }
 			o = 0; if (with_qual) for (uint32_t p = 0; p < np; ++p) { ar.add(s_qual, h_qual.data() + o, qsz[p], 0); o += qsz[p]; }
 			dna_total += info.dna_bytes; qual_total += info.qual_bytes; n_parts_total += np;
-			cl_reads_free(dc.reads); dc.reads = nullptr; if (dc.d_quals) (void)hipFree(dc.d_quals); (void)hipFree(dc.d_off); dc.d_quals = nullptr; dc.d_off = nullptr;
+			if (!O.stream_input) free_chunk(dc);
+			else { { std::lock_guard<std::mutex> l(lmu); done_upto = ci + 1; } lcv.notify_all(); }     // (the loader frees it)
 		}
+		if (O.stream_input) { loader.join(); cl_ctx_destroy(lctx); hostbuf[0].release(); hostbuf[1].release(); }
 		(void)hipFree(d_dna); if (d_qual) (void)hipFree(d_qual);
 	}
 	lap("pass 2 (dna + qual parts written)");

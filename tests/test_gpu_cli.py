@@ -426,3 +426,36 @@ def test_cli_quad_aligner_without_history_writes_the_same_archive(tmp_path):
     subprocess.check_call([CLI, "compress-pbhifi", "-p", "ratio", fq, a])
     subprocess.check_call([CLI, "compress-pbhifi", "-p", "ratio", fq, b], env=dict(os.environ, COLORD_HIP_QUAD_NOHIST="1"))
     _same_streams(a, b)
+
+
+@pytest.mark.skipif(not os.path.exists(CLI), reason="needs colord_amd/colord_hip")
+def test_cli_stream_input_writes_the_same_archive(tmp_path):
+    """`--stream-input`: bounded device memory — the input is read three times (k-mers; reference reads; coding) and a chunk leaves HBM after
+    every pass; in the coding pass a loader thread keeps a window of four chunks resident ahead of the coders (the reference reads its
+    file twice for the same reason, compression.cpp:432,547-561).  Six / twelve chunks here.  Same archive (every stream but `info`, which
+    holds the command line) from the indexed reader of a plain FASTQ, from the sequential one, and from a gzip file re-read through zlib."""
+    import gzip, shutil
+    from colord_amd import ontsim
+    table = ontsim.ReadTable(seed=47, genome_len=4_000_000, target_bases=60_000_000)
+    fq = str(tmp_path / "in.fastq")
+    ontsim.write_fastq(table, fq)
+    base, st_idx, st_seq, st_gz, st_small = (str(tmp_path / x) for x in ("base.colord", "st_idx.colord", "st_seq.colord", "st_gz.colord", "st_small.colord"))
+    common = ["compress-ont", "--chunk-bases", "10000000", "--part-symbols", "65536"]
+    subprocess.check_call([CLI] + common + [fq, base])
+    subprocess.check_call([CLI] + common + ["--stream-input", fq, st_idx])
+    _same_streams(base, st_idx)
+    subprocess.check_call([CLI] + common + ["--stream-input", "--parse-threads", "1", fq, st_seq])
+    _same_streams(base, st_seq)
+    gz = fq + ".gz"
+    with open(fq, "rb") as f, gzip.open(gz, "wb", compresslevel=1) as g:
+        shutil.copyfileobj(f, g)
+    subprocess.check_call([CLI] + common + ["--stream-input", gz, st_gz])
+    _same_streams(base, st_gz)
+    # more chunks than the window several times over, reference cut
+    base5, st5 = str(tmp_path / "base5.colord"), str(tmp_path / "st5.colord")
+    subprocess.check_call([CLI, "compress-ont", "--chunk-bases", "5000000", fq, base5])
+    subprocess.check_call([CLI, "compress-ont", "--chunk-bases", "5000000", "--stream-input", fq, st5])
+    _same_streams(base5, st5)
+    out = str(tmp_path / "out.fastq")
+    subprocess.check_call([CLI, "decompress", st5, out])
+    assert sha(out) == sha(fq)
