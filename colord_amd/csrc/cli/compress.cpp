@@ -469,26 +469,32 @@ static void usage()
 // indexed, multi-threaded reader of a plain FASTQ returns exactly what the sequential one returns
 int run_parse_check(int argc, char** argv)
 {
-	uint64_t part_symbols = 2u << 21; int threads = 1; double chunk_bases = 1.0e9; std::string in;
+	uint64_t part_symbols = 2u << 21; int threads = 1, passes = 1; double chunk_bases = 1.0e9; std::string in;
 	for (int i = 2; i < argc; ++i)
 	{
 		const std::string a = argv[i];
 		if (a == "--parse-threads" && i + 1 < argc) threads = atoi(argv[++i]);
 		else if (a == "--part-symbols" && i + 1 < argc) part_symbols = strtoull(argv[++i], nullptr, 10);
 		else if (a == "--chunk-bases" && i + 1 < argc) chunk_bases = atof(argv[++i]);
+		else if (a == "--passes" && i + 1 < argc) passes = atoi(argv[++i]);          // the input again after Reader::rewind (--stream-input): same lines, same totals
 		else in = a;
 	}
 	if (in.empty()) die("parse-check: expected an input path");
 	Reader R; R.part_symbols = part_symbols; R.threads = threads; R.open(in);
 	const bool idx = R.map && R.index_mapped();
 	auto fnv = [](uint64_t h, const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 0x100000001b3ull; } return h; };
-	Chunk ch; ch.pinned = false; uint32_t ci = 0;
-	while (R.next_chunk(ch, (uint64_t)chunk_bases))
+	Chunk ch; ch.pinned = false;
+	for (int pass = 0; pass < passes; ++pass)
 	{
-		uint64_t h = 0xcbf29ce484222325ull;
-		h = fnv(h, ch.bases, ch.n); if (R.fastq) h = fnv(h, ch.quals, ch.n);
-		h = fnv(h, ch.off.data(), ch.off.size() * 8); h = fnv(h, ch.packs.data(), ch.packs.size() * 4); h = fnv(h, ch.parts.data(), ch.parts.size() * 4);
-		printf("chunk %u: %zu reads %llu bases %zu packs %zu parts %016llx\n", ci++, ch.off.size() - 1, (unsigned long long)ch.n, ch.packs.size() - 1, ch.parts.size() - 1, (unsigned long long)h);
+		if (pass) { R.rewind(); printf("pass %d\n", pass + 1); }
+		uint32_t ci = 0;
+		while (R.next_chunk(ch, (uint64_t)chunk_bases))
+		{
+			uint64_t h = 0xcbf29ce484222325ull;
+			h = fnv(h, ch.bases, ch.n); if (R.fastq) h = fnv(h, ch.quals, ch.n);
+			h = fnv(h, ch.off.data(), ch.off.size() * 8); h = fnv(h, ch.packs.data(), ch.packs.size() * 4); h = fnv(h, ch.parts.data(), ch.parts.size() * 4);
+			printf("chunk %u: %zu reads %llu bases %zu packs %zu parts %016llx\n", ci++, ch.off.size() - 1, (unsigned long long)ch.n, ch.packs.size() - 1, ch.parts.size() - 1, (unsigned long long)h);
+		}
 	}
 	uint64_t h = 0xcbf29ce484222325ull;
 	h = fnv(h, R.ids.data(), R.ids.size()); h = fnv(h, R.id_off.data(), R.id_off.size() * 8); h = fnv(h, R.plus.data(), R.plus.size());

@@ -78,3 +78,32 @@ def test_4avg_quantisation_of_bench_equals_the_decoder(tmp_path):
     n = len(dec.offsets) - 1
     want = quantised_quals_4avg(src.quals[:src.offsets[n]], src.offsets[:n + 1].astype(np.int64))
     assert np.array_equal(want, dec.quals)
+
+
+@pytest.mark.parametrize("form", ["indexed", "sequential", "gz", "fasta"])
+def test_a_second_and_third_pass_over_the_input_cut_the_same_chunks(tmp_path, form):
+    """`--stream-input` reads its input three times (Reader::rewind: the mapping's cursor, the record index, or gzrewind): every pass must
+    return the chunks of the first — bytes, offsets, packs, parts — and the ids and totals must be those of ONE pass."""
+    import gzip
+    fq = str(tmp_path / "in.fastq")
+    make_fastq(fq, 4000, seed=21, crlf=form == "sequential", blank=True)
+    path, threads = fq, 4 if form == "indexed" else 1
+    if form == "gz":
+        path = fq + ".gz"
+        with open(fq, "rb") as f, gzip.open(path, "wb") as g:
+            g.write(f.read())
+    if form == "fasta":
+        path = str(tmp_path / "in.fasta")
+        lines = open(fq).read().split("\n")
+        recs = [l for l in lines if l]                                         # (blank lines dropped: four lines per record)
+        with open(path, "w") as f:
+            for i in range(0, len(recs) - 3, 4):
+                f.write(">" + recs[i][1:] + "\n" + recs[i + 1].replace("N", "A") + "\n")
+    one = parse_check(path, threads)
+    three = parse_check(path, threads, ["--passes", "3"])
+    assert one.returncode == 0 and three.returncode == 0, one.stderr + three.stderr
+    a, b = one.stdout.splitlines(), three.stdout.splitlines()
+    chunks = [l for l in a if l.startswith("chunk")]
+    assert len(chunks) >= 2 and a[-1].startswith("ids ")
+    assert b == chunks + ["pass 2"] + chunks + ["pass 3"] + chunks + [a[-1]]
+    assert ("indexed" in one.stderr) == (form == "indexed")
