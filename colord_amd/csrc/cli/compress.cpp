@@ -1105,15 +1105,17 @@ int run_compress(int argc, char** argv)
 				free_done(chunks.size());
 			});
 		}
-		else for (auto& dc : chunks) ck(ctx, cl_compressor_prepare_parts(cmp, dc.reads, dc.packs.data(), (uint32_t)dc.packs.size() - 1, dc.parts.data(), (uint32_t)dc.parts.size() - 1, dc.d_quals, dc.d_off), "look-ahead");
+		// resident input: the chunks are announced a window ahead as well (COLORD_HIP_ANNOUNCE_WINDOW, 0 = all at once): lanes that run far
+		// ahead of the coders only pile up edit scripts the pool has to grow for
+		size_t ann_window = 4;
+		if (const char* e = getenv("COLORD_HIP_ANNOUNCE_WINDOW")) ann_window = (size_t)std::max(0, atoi(e));
 		size_t announced = 0;
 		for (size_t ci = 0; ci < chunks.size(); ++ci)
 		{
 			DevChunk& dc = chunks[ci];
-			if (O.stream_input)
 			{
-				size_t have;
-				{ std::unique_lock<std::mutex> l(lmu); lcv.wait(l, [&]() { return n_loaded > ci; }); have = n_loaded; }
+				size_t have = ann_window ? std::min(chunks.size(), ci + 1 + ann_window) : chunks.size();
+				if (O.stream_input) { std::unique_lock<std::mutex> l(lmu); lcv.wait(l, [&]() { return n_loaded > ci; }); have = n_loaded; }
 				for (; announced < have; ++announced)
 				{
 					DevChunk& x = chunks[announced];

@@ -18,15 +18,15 @@ with tempfile.TemporaryDirectory() as tmp:
     fq = os.path.join(tmp, "in.fastq")
     t0 = time.time(); n = ontsim.write_fastq(table, fq); print(f"{n} bases, {os.path.getsize(fq)} bytes written in {time.time() - t0:.1f} s", flush=True)
     digests = {}
-    for name, extra in [("resident", []), ("stream-input", ["--stream-input"]), ("resident", []), ("stream-input", ["--stream-input"])]:
-        arc = os.path.join(tmp, name + ".colord")
+    for name, extra, env in [("resident, all announced", [], {"COLORD_HIP_ANNOUNCE_WINDOW": "0"}), ("resident", [], {}), ("stream-input", ["--stream-input"], {})] * 2:
+        arc = os.path.join(tmp, name.split(",")[0] + ".colord")
         peak = [0]; stop = [False]
         def watch():
             while not stop[0]:
                 peak[0] = max(peak[0], vram_used()); time.sleep(0.2)
         th = threading.Thread(target=watch); th.start()
         t0 = time.time()
-        r = subprocess.run([CLI, "compress-ont", "-v", "-k", "25", "-a", "22", "--part-symbols", "65536", "--chunk-bases", chunk] + extra + [fq, arc], capture_output=True, text=True)
+        r = subprocess.run([CLI, "compress-ont", "-v", "-k", "25", "-a", "22", "--part-symbols", "65536", "--chunk-bases", chunk] + extra + [fq, arc], capture_output=True, text=True, env=dict(os.environ, **env))
         dt = time.time() - t0
         stop[0] = True; th.join()
         if r.returncode != 0: print(name, "FAILED", r.stderr[-800:]); continue
@@ -34,5 +34,5 @@ with tempfile.TemporaryDirectory() as tmp:
         from colord_amd import archive as AR
         a = AR.read_archive(arc)
         digests[name] = {s: hashlib.sha256(b"".join(p for _, p in a[s].parts)).hexdigest()[:12] for s in a if s != "info"}
-        print(f"{name:13s}: {dt:6.2f} s = {n / dt / 1e9:.3f} Gbases/s; peak device memory {peak[0] / 1e9:6.1f} GB; archive {os.path.getsize(arc)} B; {phases}", flush=True)
+        print(f"{name:24s}: {dt:6.2f} s = {n / dt / 1e9:.3f} Gbases/s; peak device memory {peak[0] / 1e9:6.1f} GB; archive {os.path.getsize(arc)} B; {phases}", flush=True)
     print("streams equal:", digests.get("resident") == digests.get("stream-input"), digests.get("stream-input"))
