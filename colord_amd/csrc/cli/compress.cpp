@@ -538,7 +538,18 @@ static int run_compress_multi(const Options& O, const Preset& P, const QDef& qd,
 	if (devs.size() != world) die("--gpu-list must name --gpus devices");
 	int n_dev = 0; hipck(hipGetDeviceCount(&n_dev), "hipGetDeviceCount");
 	for (int d : devs) if (d < 0 || d >= n_dev) die("--gpus / --gpu-list: no such device");
-	if (!O.genome.empty()) die("-G,--reference-genome with --gpus > 1: use `python -m colord_amd.mgpu` (the C++ multi-GPU host has no reference-genome mode yet)");
+	// reference-genome mode (compression.cpp:405-447) with sharded reads: every rank is handed the genome and the pseudo reads, the library
+	// lets rank 0 count the genome's k-mers and contribute the pseudo reads (reference reads 0 .. n_pseudo - 1 of the replicated store)
+	const bool with_genome = !O.genome.empty();
+	if (with_genome && independent) die("-G,--reference-genome is not available with --domains");
+	genome_io::Sequences G, PR; std::mutex pr_mu; bool pr_made = false;
+	uint32_t genome_read_len = 0, n_pseudo = 0;
+	if (with_genome)
+	{
+		try { G = genome_io::read_fasta(O.genome); } catch (const std::exception& e) { die(e.what()); }
+		if (G.off.size() - 1 >= (1ull << 32)) die("reference genome: too many sequences");
+		if (O.verbose) fprintf(stderr, "total sequences in reference genome file: %zu (%zu bases)\n", G.off.size() - 1, G.codes.size());
+	}
 	const bool use_rccl = !independent && O.transport == "rccl";
 	if (use_rccl) { std::vector<int> u = devs; std::sort(u.begin(), u.end()); if (std::adjacent_find(u.begin(), u.end()) != u.end()) die("--transport rccl needs distinct devices (several ranks on one GPU: --transport host)"); }
 
@@ -623,6 +634,16 @@ static int run_compress_multi(const Options& O, const Preset& P, const QDef& qd,
 		cl_exchange X; if (T) X = T->exchange();
 		cl_compressor* cmp = nullptr;
 		ck(ctx, cl_compressor_create(ctx, qctx, &cp, with_qual ? &qp : nullptr, T ? &X : nullptr, my_bases, &cmp), "cl_compressor_create");
+		auto upload = [&](const genome_io::Sequences& Q) -> cl_reads* {
+			uint8_t* d_codes = nullptr; uint64_t* d_off = nullptr; cl_reads* r = nullptr;
+			hipck(hipMalloc((void**)&d_codes, Q.codes.size() + 1), "hipMalloc"); hipck(hipMalloc((void**)&d_off, Q.off.size() * 8), "hipMalloc");
+			hipck(hipMemcpy(d_codes, Q.codes.data(), Q.codes.size(), hipMemcpyHostToDevice), "hipMemcpy");
+			hipck(hipMemcpy(d_off, Q.off.data(), Q.off.size() * 8, hipMemcpyHostToDevice), "hipMemcpy");
+			ck(ctx, cl_reads_pack(ctx, d_codes, d_off, (uint32_t)(Q.off.size() - 1), 0, &r), "reference genome");
+			hipck(hipFree(d_codes), "hipFree"); hipck(hipFree(d_off), "hipFree");
+			return r;
+		};
+		if (with_genome) { cl_reads* gr = upload(G); ck(ctx, cl_compressor_genome_add(cmp, gr), "reference genome k-mers"); cl_reads_free(gr); }
 		// chunks of whole reader packs (the packs are cut from this rank's first read on: in_reads.cpp:62-77)
 		std::vector<DevChunk> chunks; Chunk host;
 		Reader B; B.part_symbols = O.part_symbols;                            // (its pack / part bookkeeping only)
@@ -653,6 +674,26 @@ static int run_compress_multi(const Options& O, const Preset& P, const QDef& qd,
 		}
 		host.release();
 		ck(ctx, cl_compressor_count_finish(cmp, &RO.ks), "k-mer counting (exchange 1)");
+		if (with_genome)
+		{	// pseudo reads of 20 x the mean read length (of ALL reads: the same on every rank), made once
+			uint64_t mrl = 0;
+			ck(ctx, cl_compressor_info(cmp, nullptr, nullptr, nullptr, &mrl, nullptr, nullptr), "cl_compressor_info");
+			{
+				std::lock_guard<std::mutex> l(pr_mu);
+				if (!pr_made)
+				{
+					if (20 * mrl >= (1ull << 32)) die("reference genome: pseudo reads too long");
+					genome_read_len = (uint32_t)(20 * mrl);
+					try { PR = genome_io::pseudo_reads(G, genome_read_len, (k - 1) * 10); } catch (const std::exception& e) { die(e.what()); }
+					n_pseudo = (uint32_t)(PR.off.size() - 1);
+					pr_made = true;
+				}
+				else if (genome_read_len != (uint32_t)(20 * mrl)) die("internal: the ranks disagree about the mean read length");
+			}
+			cl_reads* pr = upload(PR);
+			ck(ctx, cl_compressor_pseudo_reads(cmp, pr), "reference genome pseudo reads");
+			cl_reads_free(pr);
+		}
 		for (auto& dc : chunks) ck(ctx, cl_compressor_refs_add(cmp, dc.reads), "reference reads");
 		ck(ctx, cl_compressor_refs_finish(cmp), "reference index (exchange 2)");
 		ck(ctx, cl_compressor_info(cmp, nullptr, nullptr, nullptr, &RO.mean_read_len, &RO.sparse_range, &RO.n_refs), "cl_compressor_info");
@@ -731,12 +772,23 @@ static int run_compress_multi(const Options& O, const Preset& P, const QDef& qd,
 	ar.f = fdopen(fd, "r+b"); if (!ar.f) die("cannot open file: " + O.out);
 	if (fseeko(ar.f, (off_t)end, SEEK_SET) != 0) die("cannot seek in the archive");
 	ar.off = end;
-	const int s_meta = ar.reg("meta"), s_header = ar.reg("header"), s_dna = ar.reg("dna"), s_qual = with_qual ? ar.reg("qual") : -1, s_dom = ar.reg("hipdomains");
-	uint32_t tot_ref = (uint32_t)n;
+	const int s_meta = ar.reg("meta"), s_genome = (with_genome && O.store_genome) ? ar.reg("ref-genome") : -1, s_header = ar.reg("header"), s_dna = ar.reg("dna"), s_qual = with_qual ? ar.reg("qual") : -1, s_dom = ar.reg("hipdomains");
+	uint32_t tot_ref = (uint32_t)n + n_pseudo;
 	const RankOut& R0 = out[0];
-	if (P.sparse) { std::vector<uint8_t> acc((size_t)n); ck(nullptr, cl_ref_accept((uint32_t)n, 0, R0.sparse_range, O.exponent, acc.data()), "cl_ref_accept"); tot_ref = 0; for (uint8_t x : acc) tot_ref += x; }
-	const std::vector<uint8_t> meta = pack_meta(MetaIn{ (uint32_t)n, 0, tot_ref, P.c, P.level, O.source, R0.mean_read_len, with_qual, P.qual_mode, qd.rev, O.header_mode, P.sparse != 0, R0.sparse_range, O.exponent, false, false, 0, 0, nullptr });
+	if (P.sparse) { std::vector<uint8_t> acc((size_t)n + n_pseudo); ck(nullptr, cl_ref_accept((uint32_t)n, n_pseudo, R0.sparse_range, O.exponent, acc.data()), "cl_ref_accept"); tot_ref = 0; for (uint8_t x : acc) tot_ref += x; }
+	uint8_t md[16] = { 0 };
+	if (with_genome && !O.store_genome && cl_genome_md5(G.codes.data(), G.off.data(), (uint32_t)(G.off.size() - 1), md) != CL_OK) die("cannot checksum the reference genome");
+	const std::vector<uint8_t> meta = pack_meta(MetaIn{ (uint32_t)n, n_pseudo, tot_ref, P.c, P.level, O.source, R0.mean_read_len, with_qual, P.qual_mode, qd.rev, O.header_mode, P.sparse != 0, R0.sparse_range, O.exponent,
+	                                                    with_genome, O.store_genome, genome_read_len, (k - 1) * 10, md });
 	ar.add(s_meta, meta.data(), meta.size(), 0);
+	if (s_genome >= 0)
+	{	// CReferenceGenome::Store(archive) (reference_genome.cpp:325-370): one part, metadata = number of sequences
+		std::vector<uint8_t> gs(G.codes.size() / 3 + 4096); uint64_t got = 0;
+		cl_status st = cl_genome_encode(G.codes.data(), G.off.data(), (uint32_t)(G.off.size() - 1), gs.data(), gs.size(), &got);
+		if (st == CL_E_CAPACITY) { gs.resize(got); st = cl_genome_encode(G.codes.data(), G.off.data(), (uint32_t)(G.off.size() - 1), gs.data(), gs.size(), &got); }
+		if (st != CL_OK) die("cannot code the reference genome");
+		ar.add(s_genome, gs.data(), got, G.off.size() - 1);
+	}
 	for (size_t p = 0; p < hdr_parts.size(); ++p) ar.add(s_header, hdr_parts[p].data(), hdr_parts[p].size(), hdr_counts[p]);
 	// part tables of the streams the ranks wrote, and the model domains (first read, first `dna` part of every rank)
 	// (bit 31 of the count: INDEPENDENT domains — each has its own reference reads, so each decodes with a decoder of its own and its

@@ -204,3 +204,30 @@ def test_cpp_host_ranks_write_the_archive_of_the_python_driver(tmp_path, n_ranks
     for name in b:
         if name != "info":
             assert [(m, hashlib.sha256(p).hexdigest()) for m, p in b[name].parts] == [(m, hashlib.sha256(p).hexdigest()) for m, p in c[name].parts], name
+
+
+@pytest.mark.parametrize("stored", [True, False])
+def test_cpp_host_reference_genome_mode_with_sharded_reads(tmp_path, stored):
+    """`colord_hip compress-ont -G genome [-s] --gpus 2` (two rank threads on this box's GPU, host-staged collectives): every rank is handed
+    the genome and the pseudo reads, the library lets rank 0 count the genome's k-mers and contribute the pseudo reads — the archive of
+    `python -m colord_amd.mgpu` with two gloo ranks, every stream but `info` (`ref-genome` and the genome fields of `meta` included), and
+    the reference's output back from the decompressor."""
+    name = "c4_ont_genome_stored" if stored else "c4_ont_genome_external"
+    exp = json.load(open(os.path.join(ROOT, "tests", "golden", "archives", "expected.json")))[name]
+    import gzip
+    fq0, gen = _m_bovis(tmp_path)
+    fq = fq0 + ".gz"                                                     # (gzip: both drivers parse the whole file and share the reads by bases)
+    with open(fq0, "rb") as f, gzip.open(fq, "wb", compresslevel=1) as g:
+        g.write(f.read())
+    py_arc, cpp_arc, out = str(tmp_path / "py.colord"), str(tmp_path / "cpp.colord"), str(tmp_path / "o.fastq")
+    opts = ["compress-ont", "-G", gen] + (["-s"] if stored else []) + ["--chunk-bases", "3e6"]
+    run_ranks(2, opts + [fq, py_arc], 29660 + int(stored))
+    r = subprocess.run([CLI] + opts + ["--gpus", "2", "--gpu-list", "0,0", "--transport", "host", fq, cpp_arc], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    a, b = AR.read_archive(py_arc), AR.read_archive(cpp_arc)
+    assert set(a) == set(b) and ("ref-genome" in b) == stored
+    for s in a:
+        if s != "info":
+            assert [(m, hashlib.sha256(p).hexdigest()) for m, p in a[s].parts] == [(m, hashlib.sha256(p).hexdigest()) for m, p in b[s].parts], s
+    subprocess.check_call([CLI, "decompress"] + ([] if stored else ["-G", gen]) + [cpp_arc, out])
+    assert sha(out) == exp["decompressed_sha256"]
