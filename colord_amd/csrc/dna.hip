@@ -68,13 +68,43 @@ struct RefCur {
 __device__ inline uint32_t ilog2_(uint64_t x) { return x ? 64u - (uint32_t)__clzll((long long)x) : 0u; }     // bit length (basic_coder.h:39-47)
 __device__ inline uint32_t no_bytes_(uint64_t x) { uint32_t r = 1; x >>= 8; for (; x; ++r) x >>= 8; return r; }
 
+// The write pass's keys on their way out.  A lane emits its symbols one at a time, 8 bytes each to consecutive places, between long
+// stretches of reading: stored one by one, the eight stores that fill a 64-byte sector arrive so far apart that the L2 writes the sector
+// back in between (PMC: 37 GB written per launch for 8.8 GB of keys) — and every one of them is one more small scattered write for the
+// memory system.  STAGED: the lane keeps the sector it is filling in LDS (slot = place & 7) and writes it as four
+// 16-byte stores back to back when it is full; the first and the last sector of its range, shared with the neighbouring chunks' lanes
+// (and, for plain reads, with k_dna_plain), go out key by key.
 struct Emitter {
 	bool write; uint64_t* key; uint64_t off; uint32_t count; const FamTab* ft;
+	uint64_t* stage = nullptr; uint64_t first = 0; bool any = false;        // the lane's 8 slots in LDS (nullptr: direct stores); first place written
+	__device__ inline void put(uint64_t k)
+	{
+		const uint64_t g = off + count;
+		if (!stage) { key[g] = k; return; }
+		if (!any) { first = g; any = true; }
+		stage[g & 7] = k;
+		if ((g & 7) != 7) return;
+		const uint64_t base = g & ~7ull;
+		if (first <= base)
+		{
+			uint4* dst = (uint4*)(key + base);
+#pragma unroll
+			for (int q = 0; q < 4; ++q) { const uint64_t a = stage[2 * q], b = stage[2 * q + 1]; dst[q] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)); }
+		}
+		else for (uint64_t x = first; x <= g; ++x) key[x] = stage[x & 7];
+	}
+	// the keys of the sector the lane was filling when it stopped
+	__device__ inline void finish()
+	{
+		if (!stage || !any) return;
+		const uint64_t g = off + count, base = g & ~7ull;
+		for (uint64_t x = first > base ? first : base; x < g; ++x) key[x] = stage[x & 7];
+	}
 	__device__ inline void operator()(int fam, uint32_t ctx, uint32_t sym, int e1 = 15, int e2 = 15)
 	{
 		if (write)
 		{
-			key[off + count] = ((uint64_t)(ft->ctx_base[fam] + ctx) << 16) | ((uint64_t)(e1 & 15) << 12) | ((uint64_t)(e2 & 15) << 8) | sym;
+			put(((uint64_t)(ft->ctx_base[fam] + ctx) << 16) | ((uint64_t)(e1 & 15) << 12) | ((uint64_t)(e2 & 15) << 8) | sym);
 			// the triple index of symbol i, trip_index(lay, part, i), is a function of i alone within a read: k_fill_sidx writes
 			// them coalesced instead of one scattered 4-byte store per symbol here
 		}
@@ -194,10 +224,11 @@ __global__ __launch_bounds__(64) void k_dna_walk(const FamTab* __restrict__ ftp,
                                                 const uint32_t* __restrict__ es_ntup, const uint8_t* __restrict__ read_flag,
                                                 uint32_t n_reads, uint32_t prev_types, uint32_t cur_read_id0, const uint64_t* __restrict__ chunk_off, WalkCk* __restrict__ cks, uint32_t n_chunks,
                                                 uint32_t* __restrict__ counts, uint32_t* __restrict__ hdr_counts, const uint64_t* __restrict__ sym_off,
-                                                uint64_t* __restrict__ key, uint32_t* __restrict__ err)
+                                                uint64_t* __restrict__ key, uint32_t* __restrict__ err, uint32_t staged)
 {
 	__builtin_amdgcn_s_setprio(3);                                          // a launch of this kernel lasts as long as its slowest chain: its waves go first on their SIMDs
 	__shared__ FamTab ft;
+	__shared__ uint64_t s_stage[WRITE ? 64 * 9 : 1];                             // (a lane's 8 slots, 9 words apart: the lanes' stores spread over the banks)
 	for (uint32_t i = threadIdx.x; i < sizeof(FamTab) / 4; i += blockDim.x) ((uint32_t*)&ft)[i] = ((const uint32_t*)ftp)[i];
 	__syncthreads();
 	const uint32_t CH = ft.walk_chunk, WARM = ft.walk_warm;
@@ -219,6 +250,7 @@ __global__ __launch_bounds__(64) void k_dna_walk(const FamTab* __restrict__ ftp,
 	bool track_all = WRITE;                                                      // symbol history kept throughout
 restart:
 	Emitter em{ WRITE, key, WRITE ? sym_off[r] : 0, 0, &ft };
+	if (WRITE && staged) em.stage = s_stage + threadIdx.x * 9;
 	EsReader rd{ es + es_off[r], es + es_off[r + 1] };
 	uint32_t type = T_NONE, v1 = 0, v2 = 0;
 	rd.next(type, v1, v2);
@@ -255,6 +287,7 @@ restart:
 		if (type == T_START_PLAIN || type == T_START_PLAIN_N)
 		{
 			if (!WRITE) { hdr_counts[r] = em.count; counts[r] = em.count + (ntup - 1); }
+			em.finish();
 			return;
 		}
 		emit_read_id(em, ref_id, cur_read_id);
@@ -356,7 +389,7 @@ restart:
 				const int32_t short_id = slot;
 				if (slot < 0)
 				{
-					if (n_alt >= MAX_ALT) { if (err) atomicOr(err, 1u); return; }
+					if (n_alt >= MAX_ALT) { if (err) atomicOr(err, 1u); em.finish(); return; }
 					slot = (int32_t)n_alt; alt_ids[n_alt] = (int32_t)v1; alt_pos_of[n_alt] = 0; ++n_alt; is_new = true;
 				}
 				em(F_SEEN, seen, short_id >= 0 ? 1u : 0u);
@@ -443,6 +476,7 @@ restart:
 		}
 		last_type = type;
 	}
+	em.finish();
 	if (!WRITE)
 	{
 		hdr_counts[r] = em.count; counts[r] = em.count;
@@ -1023,7 +1057,7 @@ cl_status dna_walk(cl_ctx* ctx, cl_dna_coder* D, const cl_reads* refs, const uin
 			DEV_ALLOC(ctx, cks, n_chunks);
 			LAUNCHB(ctx, (double)(h_eb[1] - h_eb[0]) + 8.0 * n_reads + (double)n_chunks * sizeof(WalkCk), (k_dna_walk<false>), grid_for(n_reads, WALK_LPW), 64, /* tuple bytes in, one count and the chunk states out */
 				(const FamTab*)D->d_ft.p, R, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, n_reads,
-				prev_types, cur_read_id, (const uint64_t*)chunk_off.p, cks.p, (uint32_t)n_chunks, counts.p, hdr.p, (const uint64_t*)nullptr, (uint64_t*)nullptr, err.p);
+				prev_types, cur_read_id, (const uint64_t*)chunk_off.p, cks.p, (uint32_t)n_chunks, counts.p, hdr.p, (const uint64_t*)nullptr, (uint64_t*)nullptr, err.p, 0u);
 			HIP_TRY(ctx, hipGetLastError());
 			CL_TRY(dev_exclusive_scan_u64(ctx, counts.p, sym_off.p, n_reads, &total_syms));
 		}
@@ -1035,7 +1069,7 @@ cl_status dna_walk(cl_ctx* ctx, cl_dna_coder* D, const cl_reads* refs, const uin
 		DEV_ALLOC(ctx, key, total_syms);
 		LAUNCHB(ctx, total_syms * 9.0, (k_dna_walk<true>), grid_for(n_chunks, WALK_LPW), 64, /* tuple bytes in (<= 1 per symbol), 8 bytes per symbol out */
 			(const FamTab*)D->d_ft.p, R, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, n_reads,
-			prev_types, cur_read_id, (const uint64_t*)chunk_off.p, cks.p, (uint32_t)n_chunks, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint64_t*)sym_off.p, key.p, err.p);
+			prev_types, cur_read_id, (const uint64_t*)chunk_off.p, cks.p, (uint32_t)n_chunks, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint64_t*)sym_off.p, key.p, err.p, (uint32_t)(getenv("COLORD_HIP_WALK_DIRECT") ? 0 : 1));
 		LAUNCH(ctx, k_dna_plain, grid_for(n_reads, 4), 256, (const FamTab*)D->d_ft.p, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, (const uint32_t*)hdr.p,
 			(const uint64_t*)sym_off.p, 0u, n_reads, key.p);
 		HIP_TRY(ctx, hipGetLastError());
