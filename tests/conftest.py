@@ -18,3 +18,16 @@ def ctx():
     c = Context(0)
     yield c
     c.close()
+
+
+def pytest_runtest_logreport(report):
+    """Every failure's full text goes to gpurun_out/test_failures.txt as well (a summary line on a terminal is cut at the first 80 columns;
+    a rare failure on the GPU box must leave its message behind)."""
+    if report.failed:
+        try:
+            d = os.path.join(ROOT, "gpurun_out")
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, "test_failures.txt"), "a") as f:
+                f.write(f"==== {report.nodeid} [{report.when}]\n{report.longreprtext}\n")
+        except OSError:
+            pass
