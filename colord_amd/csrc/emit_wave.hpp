@@ -93,10 +93,19 @@ __device__ inline RunEl run_of_script_wave(const char* es, uint32_t k)
 {
 	const uint32_t lane = threadIdx.x & 63;
 	RunEl acc = run_empty();
-	for (uint32_t x0 = 0; x0 < k; x0 += 64)
+	// eight symbols per lane (one 8-byte load, combined in the lane) and one wave scan per 512 symbols: the scan — six rounds of seven
+	// shuffles and a combine — was paid per 64 symbols, one byte load each
+	for (uint32_t x0 = 0; x0 < k; x0 += 512)
 	{
-		const uint32_t x = x0 + lane;
-		const RunEl e = x < k ? run_single((uint32_t)(uint8_t)es[x], 1) : run_empty();
+		const uint32_t x = x0 + lane * 8;
+		RunEl e = run_empty();
+		if (x + 8 <= k)
+		{
+			uint64_t w; __builtin_memcpy(&w, es + x, 8);
+#pragma unroll
+			for (int j = 0; j < 8; ++j) e = run_combine(e, run_single((uint32_t)(w >> (8 * j)) & 0xffu, 1));
+		}
+		else for (uint32_t y = x; y < k; ++y) e = run_combine(e, run_single((uint32_t)(uint8_t)es[y], 1));
 		RunEl pre, total;
 		run_wave_scan(e, acc, pre, total);
 		acc = total;

@@ -857,17 +857,32 @@ __global__ __launch_bounds__(256) void k_gap_stats_long(LevelV L, ArenaV A, EncC
 		nd = i0 + 64 < g.es_len ? i0 + 64 : g.es_len;
 	}
 	uint32_t h[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, hd[4] = { 0, 0, 0, 0 };
-	for (uint32_t i = lane; i < g.es_len; i += 64)
+	// the script eight symbols per lane and load, the read's bases a packed word (32 bases) per lane and load, counted by popcounts: a byte
+	// and a base per lane were es_len / 64 + ne / 64 load latencies in a row for every gap
+	for (uint32_t i = lane * 8; i < g.es_len; i += 512)
 	{
-		const uint32_t c = es_class(es[i]);
+		uint64_t w = 0; uint32_t nb = 8;
+		if (i + 8 <= g.es_len) __builtin_memcpy(&w, es + i, 8);
+		else { nb = g.es_len - i; for (uint32_t y = 0; y < nb; ++y) w |= (uint64_t)(uint8_t)es[i + y] << (8 * y); }
+		for (uint32_t y = 0; y < nb; ++y)
+		{
+			const uint32_t c = es_class((char)((w >> (8 * y)) & 0xffu));
 #pragma unroll
-		for (int k = 0; k < 9; ++k) h[k] += c == (uint32_t)k;
+			for (int k = 0; k < 9; ++k) h[k] += c == (uint32_t)k;
+		}
 	}
-	for (uint32_t i = lane; i < g.ne; i += 64)
+	if (g.ne)
 	{
-		const uint32_t c = arena_base_at(A, ewb, g.enc_start + i);
-#pragma unroll
-		for (int k = 0; k < 4; ++k) hd[k] += c == (uint32_t)k;
+		const uint32_t s = g.enc_start, last = g.enc_start + g.ne - 1, w0 = s >> 5, w1 = last >> 5;
+		for (uint32_t wi2 = w0 + lane; wi2 <= w1; wi2 += 64)
+		{
+			const uint64_t w = A.packed[ewb + wi2];
+			const uint32_t ja = wi2 == w0 ? (s & 31) : 0u, jb = wi2 == w1 ? (last & 31) : 31u;    // fields (bases) ja .. jb of the word count; base j sits at bits 63 - 2 j, 62 - 2 j
+			const uint64_t from = ja == 0 ? ~0ull : ((1ull << (64 - 2 * ja)) - 1), upto = ~((1ull << (62 - 2 * jb)) - 1);
+			const uint64_t v = from & upto & 0x5555555555555555ull, lo = w & 0x5555555555555555ull, hi = (w >> 1) & 0x5555555555555555ull;
+			const uint32_t c3 = (uint32_t)__popcll(lo & hi & v), c2 = (uint32_t)__popcll(hi & ~lo & v), c1 = (uint32_t)__popcll(lo & ~hi & v);
+			hd[3] += c3; hd[2] += c2; hd[1] += c1; hd[0] += (uint32_t)__popcll(v) - c1 - c2 - c3;
+		}
 	}
 #pragma unroll
 	for (int k = 0; k < 9; ++k) for (int o = 32; o; o >>= 1) h[k] += __shfl_xor(h[k], o);
