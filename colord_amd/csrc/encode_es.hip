@@ -181,8 +181,32 @@ __device__ inline bool wave_gap_stage(wv::WavePool& pool, const GapRec& g, const
 	W.opsbuf = (uint8_t*)pool.alloc((uint64_t)g.use + g.ne + 64);
 	if (pool.overflow) return false;
 	const uint32_t lo = left ? g.nr - g.use : 0;
-	for (uint32_t i = lane; i < g.use; i += 64) { const uint8_t v = (uint8_t)ref_sym(R, rwb, rlen, rev, g.cur_ref + lo + i); W.rbuf[i] = v; W.r2[left ? g.use - 1 - i : i] = v; }
-	for (uint32_t i = lane; i < g.ne; i += 64) { const uint8_t v = (uint8_t)arena_base_at(A, ewb, g.enc_start + i); W.ebuf[i] = v; W.e2[left ? g.ne - 1 - i : i] = v; }
+	// eight symbols per lane and step: two packed words in, one 8-byte store per buffer out (a symbol per lane was use / 64 + ne / 64 load
+	// latencies in a row and four byte stores per symbol pair).  A reverse-complemented reference is read backwards: eight ascending places
+	// of the stored read, bytes swapped, complemented.
+	auto sym8 = [](const ArenaV& X, uint64_t wb, uint32_t fp) -> uint64_t {      // bases fp .. fp + 7 of a stored read, one per byte
+		const uint64_t wa = X.packed[wb + (fp >> 5)], wz = X.packed[wb + ((fp + 7) >> 5)];
+		uint64_t out = 0;
+#pragma unroll
+		for (uint32_t j = 0; j < 8; ++j) { const uint32_t p = fp + j; const uint64_t w = (p >> 5) == (fp >> 5) ? wa : wz; out |= ((w >> (62 - 2 * (p & 31))) & 3ull) << (8 * j); }
+		return out;
+	};
+	auto put8 = [&](uint8_t* fwd, uint8_t* other, uint32_t total, uint32_t i, uint64_t v) {     // places i .. i + 7 of fwd; `other` is fwd or its mirror image
+		__builtin_memcpy(fwd + i, &v, 8);
+		if (!left) __builtin_memcpy(other + i, &v, 8);
+		else { const uint64_t m = __builtin_bswap64(v); __builtin_memcpy(other + (total - 8 - i), &m, 8); }
+	};
+	for (uint32_t i = lane * 8; i < g.use; i += 512)
+	{
+		const uint32_t pos0 = g.cur_ref + lo + i;
+		if (i + 8 <= g.use) put8(W.rbuf, W.r2, g.use, i, rev ? 0x0303030303030303ull - __builtin_bswap64(sym8(R, rwb, rlen - 1 - (pos0 + 7))) : sym8(R, rwb, pos0));
+		else for (uint32_t y = i; y < g.use; ++y) { const uint8_t v = (uint8_t)ref_sym(R, rwb, rlen, rev, g.cur_ref + lo + y); W.rbuf[y] = v; W.r2[left ? g.use - 1 - y : y] = v; }
+	}
+	for (uint32_t i = lane * 8; i < g.ne; i += 512)
+	{
+		if (i + 8 <= g.ne) put8(W.ebuf, W.e2, g.ne, i, sym8(A, ewb, g.enc_start + i));
+		else for (uint32_t y = i; y < g.ne; ++y) { const uint8_t v = (uint8_t)arena_base_at(A, ewb, g.enc_start + y); W.ebuf[y] = v; W.e2[left ? g.ne - 1 - y : y] = v; }
+	}
 	if (g.kind == GK_INNER) { W.Q = W.rbuf; W.n = g.nr; W.T = W.ebuf; W.m = g.ne; W.rows_ref = true; W.shw = false; }
 	else if (g.kind == GK_FLANK_TINY) { W.Q = W.r2; W.n = g.use; W.T = W.e2; W.m = g.ne; W.rows_ref = true; W.shw = false; }
 	else { W.Q = W.e2; W.n = g.ne; W.T = W.r2; W.m = g.use; W.rows_ref = false; W.shw = true; }
