@@ -915,7 +915,28 @@ __global__ __launch_bounds__(256) void k_gap_stats_long(LevelV L, ArenaV A, EncC
 	uint32_t n = g.es_len, extra = g.d_before;
 	if (nd + g.d_before >= 10) { h[2] -= nd; n -= nd; extra = 0; }                 // the script is scored without its leading deletions
 	h[2] += extra;
-	const bool accept = entropy_hist(h, 9) * (double)(n + extra) * cfg.cost_mult < entropy_hist(hd, 4) * (double)g.ne;
+	// the two entropies (entropy_hist, encode_core.hpp): their thirteen p log2 p terms one per lane in ONE evaluation of the logarithm (lanes
+	// 0 .. 8 the script's classes, 16 .. 19 the bases) instead of thirteen in a row on every lane; the sums run over the terms in the
+	// sequential order, so the doubles are the sequential ones
+	double sum_h = 0, sum_d = 0;
+#pragma unroll
+	for (int i = 0; i < 9; ++i) sum_h += h[i];
+#pragma unroll
+	for (int i = 0; i < 4; ++i) sum_d += hd[i];
+	const double rec_h = 1.0 / sum_h, rec_d = 1.0 / sum_d;
+	uint32_t mine = 0;
+#pragma unroll
+	for (int i = 0; i < 9; ++i) if (lane == (uint32_t)i) mine = h[i];
+#pragma unroll
+	for (int i = 0; i < 4; ++i) if (lane == 16u + (uint32_t)i) mine = hd[i];
+	double term = 0;
+	if (mine) { const double p = (double)mine * (lane < 16 ? rec_h : rec_d); term = glibc_log2::log2(p) * p; }
+	double e_h = 0, e_d = 0;
+#pragma unroll
+	for (int i = 0; i < 9; ++i) { const double t = __shfl(term, i, 64); if (h[i]) e_h += t; }
+#pragma unroll
+	for (int i = 0; i < 4; ++i) { const double t = __shfl(term, 16 + i, 64); if (hd[i]) e_d += t; }
+	const bool accept = -e_h * (double)(n + extra) * cfg.cost_mult < -e_d * (double)g.ne;
 	g.state = accept ? GS_ES : GS_REJECTED;
 	if (lane == 0) { L.gaps[gi] = g; spawn_flag[gi] = accept ? 0u : 1u; }
 }
