@@ -17,6 +17,15 @@
 #include <stdexcept>
 #include <thread>
 
+#include <ctime>
+// COLORD_HIP_DECODE_DEBUG: CPU seconds of a decoder thread on stderr when it ends
+static inline void thread_report(const char* what)
+{
+	if (!getenv("COLORD_HIP_DECODE_DEBUG")) return;
+	timespec t; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t);
+	fprintf(stderr, "[decode] %s thread: %.2f s of CPU\n", what, (double)t.tv_sec + 1e-9 * (double)t.tv_nsec);
+}
+
 namespace colord_hip_reader {
 template<class T> struct Queue {                                       // bounded hand-over between the stream threads
 	std::mutex m; std::condition_variable cv; std::deque<T> q; bool done = false; size_t cap = 4;
@@ -239,6 +248,7 @@ inline void RecordStream::start()
 		}
 		} catch (const std::exception& e) { err_dna = std::string("corrupt `dna` part (") + e.what() + ")"; }
 		if (d) cl_dna_decoder_free(d);
+		thread_report("dna");
 		q_bases_for_qual.finish(); q_reads.finish();
 	});
 	t_qual = std::thread([this]() {
@@ -262,6 +272,7 @@ inline void RecordStream::start()
 		} catch (const std::exception& e) { err_qual = std::string("corrupt `qual` part (") + e.what() + ")"; }
 		while (q_bases_for_qual.pop(x)) {}                                    // drain after an error so that the producer can finish
 		if (q) cl_qual_decoder_free(q);
+		thread_report("qual");
 		q_quals.finish();
 	});
 	if (ext_hdr) { q_hdr.finish(); return; }
@@ -285,6 +296,7 @@ inline void RecordStream::start()
 		}
 		} catch (const std::exception& e) { err_hdr = std::string("corrupt `header` part (") + e.what() + ")"; }
 		if (c) cl_id_decoder_free(c);
+		thread_report("header");
 		q_hdr.finish();
 	});
 }
