@@ -553,9 +553,23 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print("bench.py: launch with torch.distributed.run for --gpus > 1", file=sys.stderr)
-            sys.exit(2)
+        if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+            # `python bench.py --gpus N` launches itself: the same command shape as N = 1.  One rank per GPU over RCCL; on a box with fewer
+            # GPUs than ranks the ranks share the GPUs and the collectives go over gloo (a functional run of the N-rank path, not a measurement)
+            import socket
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0))
+                port = s_.getsockname()[1]
+            env = dict(os.environ)
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            if torch.cuda.device_count() < args.gpus:
+                env.setdefault("BENCH_BACKEND", "gloo")
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                   os.path.abspath(__file__)] + sys.argv[1:]
+            sys.stdout.flush(); sys.stderr.flush()
+            os.execvpe(cmd[0], cmd, env)
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
     backend = os.environ.get("BENCH_BACKEND", "nccl")      # "gloo": functional check of the multi-rank path with ranks sharing GPUs
     if backend != "nccl":
         local = local % torch.cuda.device_count()

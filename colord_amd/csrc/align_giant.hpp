@@ -53,6 +53,7 @@ struct Ctl {
 struct View {
 	Ctl* ctl; uint8_t* heap; unsigned long long heap_bytes; uint32_t* flags;
 	Node* nodes[2]; Sweep* sweeps[2]; Job* jobs[2]; Leaf* leaves; Giant* giants; uint32_t n_giants;
+	uint32_t n_phases = MAX_PHASES;             // the phases the host launches (k_giant_level 0 .. n_phases - 1): a node of a later phase would never run
 };
 
 // ---- wave-uniform helpers (every lane calls; lane 0 does the atomic) --------------------------------------------------------
@@ -86,7 +87,7 @@ __device__ inline void emit_sub(const View& V, uint32_t giant, uint32_t qo, uint
 		if (lane == 0) V.leaves[li] = Leaf{ giant, qo, n, to, m };
 		return;
 	}
-	if (ph > MAX_PHASES) { giant_fail(V, giant, 11); return; }
+	if (ph >= V.n_phases || ph > MAX_PHASES) { giant_fail(V, giant, 11); return; }   // (few columns but too many rows for a leaf at the last launched phase: the wave kernel takes the gap)
 	const uint32_t L = m / 2, R = m - L;
 	const uint8_t* ql = G.Q + qo; const uint8_t* tl = G.T + to;
 	const uint8_t* qr = G.Q + qo + n - 1; const uint8_t* tr = G.T + to + m - 1;

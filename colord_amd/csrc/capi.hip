@@ -73,6 +73,8 @@ extern "C" void cl_ctx_destroy(cl_ctx* c)
 	// out of the pool's owner table first (under its mutex; waits for a drain of this context another thread may be in): after
 	// this no fence or drain can reach the streams destroyed below
 	cl_ctx_drain(c);
+	for (auto& kv : c->scan_ctl) if (kv.second.p) c->pool.put(kv.second.p, kv.second.got, c->pool_id);
+	c->scan_ctl.clear();
 	c->pool.drop_owner(c->pool_id);
 	for (auto& p : c->pending) { (void)hipEventDestroy(p.second.first); (void)hipEventDestroy(p.second.second); }
 	for (auto e : c->ev_pool) (void)hipEventDestroy(e);

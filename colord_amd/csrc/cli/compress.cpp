@@ -607,14 +607,14 @@ static int run_compress_multi(const Options& O, const Preset& P, const QDef& qd,
 
 	// transports
 	std::vector<std::unique_ptr<Transport>> tp(world);
-	std::vector<ncclComm_t> comms(world, nullptr);
+	RcclGroup rccl; rccl.comms.assign(world, nullptr);
 	std::unique_ptr<HostHub> hub;
 	if (independent) {}
 	else if (use_rccl)
 	{
-		const ncclResult_t e = ncclCommInitAll(comms.data(), (int)world, devs.data());
+		const ncclResult_t e = ncclCommInitAll(rccl.comms.data(), (int)world, devs.data());
 		if (e != ncclSuccess) die(std::string("ncclCommInitAll: ") + ncclGetErrorString(e));
-		for (uint32_t r = 0; r < world; ++r) { auto t = std::make_unique<RcclTransport>(); if (t->init(comms[r], devs[r], r, world) != CL_OK) die(t->err); tp[r] = std::move(t); }
+		for (uint32_t r = 0; r < world; ++r) { auto t = std::make_unique<RcclTransport>(); if (t->init(rccl.comms[r], devs[r], r, world, &rccl) != CL_OK) die(t->err); tp[r] = std::move(t); }
 	}
 	else
 	{
@@ -812,7 +812,7 @@ static int run_compress_multi(const Options& O, const Preset& P, const QDef& qd,
 	const std::vector<uint8_t> inf = pack_info(R.total_bytes, total, (uint32_t)n, argc, argv);
 	ar.add(s_info, inf.data(), inf.size(), 0);
 	ar.close();
-	if (use_rccl) for (ncclComm_t c : comms) if (c) (void)ncclCommDestroy(c);
+	if (use_rccl) rccl.destroy_all();
 	tp.clear();
 	whole.release();
 	if (R.g) gzclose(R.g);

@@ -11,6 +11,7 @@
 #include "colord_hip.h"
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
+#include <atomic>
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
@@ -32,27 +33,52 @@ struct Transport {
 };
 
 // ---- RCCL ---------------------------------------------------------------------------------------------------------------------
-struct RcclTransport : Transport {
-	ncclComm_t comm = nullptr; hipStream_t stream = nullptr; int device = 0;
-	uint64_t* d_small = nullptr; uint64_t small_cap = 0;                       // staging of all_gather_host
-	cl_status init(ncclComm_t c, int dev, uint32_t r, uint32_t w)
+// The communicators of all rank threads of the process.  A rank that fails inside a collective (a send / recv refused, a copy, a
+// synchronisation) must not leave its peers waiting in theirs for a partner that will never come: it ABORTS every communicator of the
+// group (ncclCommAbort, from the failing thread) — the peers' pending operations end with an error, every rank returns its failure
+// to the library and the process stops.  After an abort the communicators are gone (no ncclCommDestroy).
+struct RcclGroup {
+	std::vector<ncclComm_t> comms; std::mutex mu; bool aborted = false;
+	void abort_all()
 	{
-		comm = c; device = dev; rank = r; world = w;
+		std::lock_guard<std::mutex> l(mu);
+		if (aborted) return;
+		aborted = true;
+		for (ncclComm_t& c : comms) if (c) { (void)ncclCommAbort(c); c = nullptr; }
+	}
+	void destroy_all() { std::lock_guard<std::mutex> l(mu); if (!aborted) for (ncclComm_t& c : comms) if (c) { (void)ncclCommDestroy(c); c = nullptr; } }
+};
+struct RcclTransport : Transport {
+	ncclComm_t comm = nullptr; hipStream_t stream = nullptr; int device = 0; RcclGroup* group = nullptr;
+	uint64_t* d_small = nullptr; uint64_t small_cap = 0;                       // staging of all_gather_host
+	cl_status init(ncclComm_t c, int dev, uint32_t r, uint32_t w, RcclGroup* g = nullptr)
+	{
+		comm = c; device = dev; rank = r; world = w; group = g;
 		if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return fail("RCCL transport: no stream");
 		return CL_OK;
 	}
 	~RcclTransport() override { if (d_small) (void)hipFree(d_small); if (stream) (void)hipStreamDestroy(stream); }
-	cl_status nc(ncclResult_t r, const char* what) { if (r == ncclSuccess) return CL_OK; return fail(std::string(what) + ": " + ncclGetErrorString(r)); }
+	// a failure inside a collective takes the peers down with it
+	cl_status fail_all(const std::string& m) { const cl_status s = fail(m); if (group) group->abort_all(); return s; }
+	cl_status nc(ncclResult_t r, const char* what) { if (r == ncclSuccess) return CL_OK; return fail_all(std::string(what) + ": " + ncclGetErrorString(r)); }
+	// waits for the stream; an asynchronous error of the communicator (a peer aborted, a link went down) is an error of this call
+	cl_status finish(const char* what)
+	{
+		if (hipStreamSynchronize(stream) != hipSuccess) { (void)hipGetLastError(); return fail_all(std::string(what) + ": synchronise"); }
+		if (group && group->aborted) return fail(std::string(what) + ": the communicators were aborted by a rank that failed");
+		ncclResult_t ar = ncclSuccess;
+		if (ncclCommGetAsyncError(comm, &ar) != ncclSuccess || ar != ncclSuccess) return fail_all(std::string(what) + ": " + ncclGetErrorString(ar));
+		return CL_OK;
+	}
 	cl_status all_gather_host(const uint64_t* h_vals, uint32_t n, uint64_t* h_out) override
 	{
 		(void)hipSetDevice(device);
 		const uint64_t need = (uint64_t)n * (world + 1);
-		if (need > small_cap) { if (d_small) (void)hipFree(d_small); small_cap = need + 1024; if (hipMalloc((void**)&d_small, small_cap * 8) != hipSuccess) return fail("RCCL transport: hipMalloc"); }
-		if (n && hipMemcpyAsync(d_small, h_vals, (uint64_t)n * 8, hipMemcpyHostToDevice, stream) != hipSuccess) return fail("RCCL transport: copy in");
+		if (need > small_cap) { if (d_small) (void)hipFree(d_small); small_cap = need + 1024; if (hipMalloc((void**)&d_small, small_cap * 8) != hipSuccess) return fail_all("RCCL transport: hipMalloc"); }
+		if (n && hipMemcpyAsync(d_small, h_vals, (uint64_t)n * 8, hipMemcpyHostToDevice, stream) != hipSuccess) return fail_all("RCCL transport: copy in");
 		if (n) { const cl_status s = nc(ncclAllGather(d_small, d_small + n, (size_t)n * 8, ncclChar, comm, stream), "ncclAllGather"); if (s != CL_OK) return s; }
-		if (n && hipMemcpyAsync(h_out, d_small + n, (uint64_t)n * 8 * world, hipMemcpyDeviceToHost, stream) != hipSuccess) return fail("RCCL transport: copy out");
-		if (hipStreamSynchronize(stream) != hipSuccess) return fail("RCCL transport: synchronise");
-		return CL_OK;
+		if (n && hipMemcpyAsync(h_out, d_small + n, (uint64_t)n * 8 * world, hipMemcpyDeviceToHost, stream) != hipSuccess) return fail_all("RCCL transport: copy out");
+		return finish("all_gather_host");
 	}
 	cl_status all_to_all_v(const void* d_send, const uint64_t* sb, void* d_recv, const uint64_t* rb) override
 	{
@@ -65,15 +91,15 @@ struct RcclTransport : Transport {
 			if (s == CL_OK && rb[p]) s = nc(ncclRecv((char*)d_recv + ro, (size_t)rb[p], ncclChar, (int)p, comm, stream), "ncclRecv");
 			so += sb[p]; ro += rb[p]; bytes_moved += p == rank ? 0 : sb[p];
 		}
-		const cl_status e = nc(ncclGroupEnd(), "ncclGroupEnd");
+		const cl_status e = nc(ncclGroupEnd(), "ncclGroupEnd");                 // (always closed: a group left open would swallow the next call)
 		if (s == CL_OK) s = e;
-		if (s == CL_OK && hipStreamSynchronize(stream) != hipSuccess) s = fail("RCCL transport: synchronise");
+		if (s == CL_OK) s = finish("all_to_all_v");
 		return s;
 	}
 	cl_status all_gather_v(const void* d_send, uint64_t send_bytes, void* d_recv, const uint64_t* rb) override
 	{
 		(void)hipSetDevice(device);
-		if (rb[rank] != send_bytes) return fail("all_gather_v: send_bytes != h_recv_bytes[rank]");
+		if (rb[rank] != send_bytes) return fail_all("all_gather_v: send_bytes != h_recv_bytes[rank]");
 		cl_status s = nc(ncclGroupStart(), "ncclGroupStart");
 		uint64_t ro = 0;
 		for (uint32_t p = 0; p < world && s == CL_OK; ++p)
@@ -84,14 +110,17 @@ struct RcclTransport : Transport {
 		}
 		const cl_status e = nc(ncclGroupEnd(), "ncclGroupEnd");
 		if (s == CL_OK) s = e;
-		if (s == CL_OK && hipStreamSynchronize(stream) != hipSuccess) s = fail("RCCL transport: synchronise");
+		if (s == CL_OK) s = finish("all_gather_v");
 		return s;
 	}
 };
 
 // ---- host staging ----------------------------------------------------------------------------------------------------------------
+// Every call passes BOTH of its barriers whatever happens to it (a rank that returned early would leave the others in the second one
+// for ever); a failure is recorded in the hub, the peers see it after the first barrier, skip their copies and fail too.
 struct HostHub {
 	uint32_t world; std::mutex mu; std::condition_variable cv; uint32_t arrived = 0; uint64_t epoch = 0;
+	std::atomic<bool> failed{ false };
 	std::vector<std::vector<uint64_t>> small;                                  // per rank: what it contributes to all_gather_host
 	std::vector<uint8_t*> stage; std::vector<uint64_t> stage_cap; std::vector<std::vector<uint64_t>> counts;   // per rank: pinned copy of its send buffer, bytes per destination
 	explicit HostHub(uint32_t w) : world(w), small(w), stage(w, nullptr), stage_cap(w, 0), counts(w) {}
@@ -107,6 +136,8 @@ struct HostHub {
 struct HostTransport : Transport {
 	HostHub* hub = nullptr; int device = 0;
 	void init(HostHub* h, int dev, uint32_t r) { hub = h; device = dev; rank = r; world = h->world; }
+	cl_status fail_all(const std::string& m) { hub->failed.store(true); return fail(m); }
+	cl_status peer_failed(const char* what) { return fail(std::string(what) + ": another rank failed"); }
 	cl_status publish(const void* d_send, uint64_t bytes)
 	{
 		(void)hipSetDevice(device);
@@ -115,19 +146,25 @@ struct HostTransport : Transport {
 			if (hub->stage[rank]) (void)hipHostFree(hub->stage[rank]);
 			hub->stage[rank] = nullptr; hub->stage_cap[rank] = 0;
 			void* p = nullptr;
-			if (hipHostMalloc(&p, bytes + bytes / 4 + 4096, hipHostMallocPortable) != hipSuccess) return fail("host transport: hipHostMalloc");
+			if (hipHostMalloc(&p, bytes + bytes / 4 + 4096, hipHostMallocPortable) != hipSuccess) return fail_all("host transport: hipHostMalloc");
 			hub->stage[rank] = (uint8_t*)p; hub->stage_cap[rank] = bytes + bytes / 4 + 4096;
 		}
-		if (bytes && hipMemcpy(hub->stage[rank], d_send, bytes, hipMemcpyDeviceToHost) != hipSuccess) return fail("host transport: copy to host");
+		if (bytes && hipMemcpy(hub->stage[rank], d_send, bytes, hipMemcpyDeviceToHost) != hipSuccess) return fail_all("host transport: copy to host");
 		return CL_OK;
 	}
 	cl_status all_gather_host(const uint64_t* h_vals, uint32_t n, uint64_t* h_out) override
 	{
 		hub->small[rank].assign(h_vals, h_vals + n);
 		hub->barrier();
-		for (uint32_t p = 0; p < world; ++p) { if (hub->small[p].size() != n) return fail("all_gather_host: ranks disagree on n"); memcpy(h_out + (uint64_t)p * n, hub->small[p].data(), (uint64_t)n * 8); }
+		cl_status s = CL_OK;
+		for (uint32_t p = 0; p < world && s == CL_OK; ++p)
+		{
+			if (hub->small[p].size() != n) s = fail_all("all_gather_host: ranks disagree on n");
+			else memcpy(h_out + (uint64_t)p * n, hub->small[p].data(), (uint64_t)n * 8);
+		}
 		hub->barrier();                                                         // (nobody overwrites its contribution before everybody has read it)
-		return CL_OK;
+		if (s == CL_OK && hub->failed.load()) s = peer_failed("all_gather_host");
+		return s;
 	}
 	cl_status all_to_all_v(const void* d_send, const uint64_t* sb, void* d_recv, const uint64_t* rb) override
 	{
@@ -136,30 +173,33 @@ struct HostTransport : Transport {
 		hub->counts[rank].assign(sb, sb + world);
 		hub->barrier();
 		(void)hipSetDevice(device);
+		if (s == CL_OK && hub->failed.load()) s = peer_failed("all_to_all_v");  // (a rank whose publish failed has no staging buffer to read from)
 		uint64_t ro = 0;
 		for (uint32_t p = 0; p < world && s == CL_OK; ++p)
 		{	// what rank p holds for this rank: behind its shares for the ranks before this one
 			uint64_t so = 0; for (uint32_t q = 0; q < rank; ++q) so += hub->counts[p][q];
-			if (hub->counts[p][rank] != rb[p]) { s = fail("all_to_all_v: ranks disagree on a share's size"); break; }
-			if (rb[p] && hipMemcpy((char*)d_recv + ro, hub->stage[p] + so, rb[p], hipMemcpyHostToDevice) != hipSuccess) s = fail("host transport: copy to device");
+			if (hub->counts[p][rank] != rb[p]) { s = fail_all("all_to_all_v: ranks disagree on a share's size"); break; }
+			if (rb[p] && hipMemcpy((char*)d_recv + ro, hub->stage[p] + so, rb[p], hipMemcpyHostToDevice) != hipSuccess) s = fail_all("host transport: copy to device");
 			ro += rb[p]; bytes_moved += p == rank ? 0 : rb[p];
 		}
 		hub->barrier();
+		if (s == CL_OK && hub->failed.load()) s = peer_failed("all_to_all_v");
 		return s;
 	}
 	cl_status all_gather_v(const void* d_send, uint64_t send_bytes, void* d_recv, const uint64_t* rb) override
 	{
-		if (rb[rank] != send_bytes) return fail("all_gather_v: send_bytes != h_recv_bytes[rank]");
-		cl_status s = publish(d_send, send_bytes);
+		cl_status s = rb[rank] != send_bytes ? fail_all("all_gather_v: send_bytes != h_recv_bytes[rank]") : publish(d_send, send_bytes);
 		hub->barrier();
 		(void)hipSetDevice(device);
+		if (s == CL_OK && hub->failed.load()) s = peer_failed("all_gather_v");
 		uint64_t ro = 0;
 		for (uint32_t p = 0; p < world && s == CL_OK; ++p)
 		{
-			if (rb[p] && hipMemcpy((char*)d_recv + ro, hub->stage[p], rb[p], hipMemcpyHostToDevice) != hipSuccess) s = fail("host transport: copy to device");
+			if (rb[p] && hipMemcpy((char*)d_recv + ro, hub->stage[p], rb[p], hipMemcpyHostToDevice) != hipSuccess) s = fail_all("host transport: copy to device");
 			ro += rb[p]; bytes_moved += p == rank ? 0 : rb[p];
 		}
 		hub->barrier();
+		if (s == CL_OK && hub->failed.load()) s = peer_failed("all_gather_v");
 		return s;
 	}
 };

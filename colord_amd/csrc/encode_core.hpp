@@ -959,7 +959,7 @@ CL_DEV inline uint32_t gap_es_capacity(const GapRec& g) { return ((g.kind == GK_
 // 512 KB (four of them share a wave, k_align_quad; edlib keeps the whole history of such a gap: 20 B * blocks * columns + 8 B *
 // columns stays under its 1 MiB), 6 large (a wave each), 7 giant (a work-group each, align_team.hpp): more rows than one tile of 64
 // blocks, at least 2^19 block-columns, and not so many more rows than columns that the sweeps saturate (wv::sat_rows)
-constexpr uint32_t QUAD_ROWS = 1024, QUAD_CELLS = 32768;
+constexpr uint32_t QUAD_ROWS = 1024, QUAD_CELLS = 32768, QUAD_SEQ = 2048;   // (QUAD_SEQ: what a 16-lane row keeps in LDS, align_rows.hpp)
 constexpr uint32_t GIANT_ROWS = 4096, GIANT_MAX_ROWS = 64 * 4096, GIANT_WORK = 1u << 19;
 // sort key = class << 17 | row blocks (9 bits) << 8 | columns / 16 (8 bits): lanes of a wave get gaps of like shape
 constexpr uint32_t N_CLASSES = 8, KEY_BITS = 20;
@@ -968,7 +968,7 @@ CL_DEV inline uint32_t gap_class(const GapRec& g, uint32_t& rows, uint32_t& cols
 	if (g.kind == GK_TRIVIAL) { rows = cols = 0; return 0; }
 	if (g.kind == GK_FLANK) { rows = g.ne; cols = g.use; } else { rows = g.use; cols = g.ne; }
 	if (rows <= 256 && cols <= 256) return (rows + 63) / 64;
-	if (rows <= QUAD_ROWS && (uint64_t)((rows + 63) / 64) * (cols + 16) <= QUAD_CELLS) return 5;
+	if (rows <= QUAD_ROWS && rows + cols <= QUAD_SEQ && (uint64_t)((rows + 63) / 64) * (cols + 16) <= QUAD_CELLS) return 5;
 	if (rows > GIANT_ROWS && rows <= GIANT_MAX_ROWS && (uint64_t)((rows + 63) / 64) * cols >= GIANT_WORK && rows / 8 < cols) return 7;
 	return 6;
 }

@@ -10,6 +10,7 @@
 #include "objects.hpp"
 #include "encode_core.hpp"
 #include "align_wave.hpp"
+#include "align_rows.hpp"
 #include "align_giant.hpp"
 #include "emit_wave.hpp"
 #include <algorithm>
@@ -809,6 +810,84 @@ __global__ __launch_bounds__(64) void k_align_quad(const uint32_t* __restrict__ 
 	}
 }
 
+// the same class, every phase of a gap in its 16-lane row (align_rows.hpp; round 5): sequences, operations and script in LDS, the history
+// in the wave's pool.  What does not fit (pool, LDS) goes to `redo`.
+__global__ __launch_bounds__(64) void k_align_quad_rows(const uint32_t* __restrict__ list, uint32_t n_list, GapRec* __restrict__ gaps, char* __restrict__ es_pool, ArenaV A, ArenaV R,
+                                                  uint8_t* __restrict__ scratch, uint64_t per_wave, unsigned int* __restrict__ next, uint32_t* __restrict__ redo, unsigned int* __restrict__ n_redo)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t s_rows[4 * qr::ROW_BYTES];
+	const uint32_t lane = threadIdx.x, gq = lane >> 4, bl = lane & 15;
+	ulonglong2* const pool = (ulonglong2*)(scratch + (uint64_t)blockIdx.x * per_wave);
+	const uint64_t pool_pairs = per_wave / 16;
+	const uint32_t n_quads = (n_list + 3) / 4;
+	uint8_t* const mem = s_rows + gq * qr::ROW_BYTES;
+	for (;;)
+	{
+		uint32_t slot = 0;
+		if (lane == 0) slot = atomicAdd(next, 1u);
+		slot = wv::bcast_first(slot);
+		if (slot >= n_quads) break;
+		const uint32_t hi = n_list - slot * 4, cnt = hi < 4 ? hi : 4;            // gaps list[hi - 1], list[hi - 2], ... (ascending list, taken from its end)
+		const bool have = gq < cnt;
+		const uint32_t gi = have ? list[hi - 1 - gq] : 0u;
+		GapRec g; memset(&g, 0, sizeof(g));
+		if (have) g = gaps[gi];
+		qr::Row r;
+		r.seq = (uint32_t*)mem; r.ops = mem + qr::SEQ_WORDS * 4; r.es = r.ops + qr::SEQ_MAX;
+		r.use = g.use; r.ne = g.ne; r.e_off = (g.use + 15) / 16;
+		r.left = g.left != 0; r.rev_seq = r.left && g.kind != GK_INNER;
+		if (g.kind == GK_INNER) { r.n = g.nr; r.m = g.ne; r.rows_ref = true; r.shw = false; }
+		else if (g.kind == GK_FLANK_TINY) { r.n = g.use; r.m = g.ne; r.rows_ref = true; r.shw = false; }
+		else { r.n = g.ne; r.m = g.use; r.rows_ref = false; r.shw = true; }
+		const uint32_t nb = (r.n + 63) / 64;
+		const uint64_t pairs = ((uint64_t)r.m + 16) * nb;
+		bool ok = have && r.n && r.m && r.n <= 1024 && (g.kind != GK_INNER || g.nr == g.use) && g.use + g.ne <= qr::SEQ_MAX;
+		// the rows' shares of the pool (a row that does not fit takes none)
+		uint64_t off = 0;
+		{
+			const uint64_t mine = ok ? pairs : 0;
+			const uint64_t p0 = wv::bcast(mine, 0u), p1 = wv::bcast(mine, 16u), p2 = wv::bcast(mine, 32u);
+			off = gq == 0 ? 0 : gq == 1 ? p0 : gq == 2 ? p0 + p1 : p0 + p1 + p2;
+			if (off + mine > pool_pairs) ok = false;
+		}
+		if (!ok) { r.n = 0; r.m = 0; }
+		ulonglong2* const hist = pool + off;
+		qr::row_stage(r, ok, g, A, R);
+		qr::lds_fence();
+		const wv::Sweep sw = qr::row_sweep(r, hist);
+		__builtin_amdgcn_s_waitcnt(0);
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		uint32_t wi, wj, wk;
+		qr::row_walk(r, hist, r.shw ? (uint32_t)(sw.end + 1) : r.m, wi, wj, wk);
+		qr::lds_fence();
+		const uint32_t pre = wi + wj, K = pre + wk;
+		qr::row_convert(r, pre, (uint8_t)(wi ? 1 : 2), wk);
+		qr::lds_fence();
+		// canonical indel placement: pass 1 along the reference symbols the script consumes, pass 2 along the read's
+		const uint32_t ref_end = r.shw ? (uint32_t)sw.end : g.kind == GK_FLANK_TINY ? g.use - 1 : 0u;
+		uint32_t d_before = 0, seq_off = 0;
+		if (r.left && g.kind != GK_INNER)
+		{
+			const uint32_t ref_offset = (g.nr - 1) - ref_end;                    // uint32 wrap for end = -1, as in the reference
+			seq_off = ref_offset - (g.nr - g.use);
+			d_before = ref_offset;
+		}
+		qr::row_refactor_pass(r, K, seq_off, 1);
+		qr::row_refactor_pass(r, K, 0, 2);
+		if (ok)
+		{
+			uint32_t* dst = (uint32_t*)(es_pool + g.es_off); const uint32_t* src = (const uint32_t*)r.es;
+			for (uint32_t w = bl; w * 4 < K; w += 16) dst[w] = src[w];
+		}
+		if (have && bl == 0)
+		{
+			if (ok) { gaps[gi].es_len = K; gaps[gi].d_before = d_before; }
+			else redo[atomicAdd(n_redo, 1u)] = gi;
+		}
+		qr::lds_fence();
+	}
+}
+
 // the rest: one lane per gap, lane pool in HBM; gaps whose lane ran out of pool are redone with larger pools
 __global__ __launch_bounds__(64) void k_align_large(const uint32_t* __restrict__ list, uint32_t n_list, GapRec* __restrict__ gaps, char* __restrict__ es_pool, ArenaV A, ArenaV R,
                                                    uint8_t* __restrict__ scratch, uint64_t per_lane, unsigned int* __restrict__ next, uint32_t* __restrict__ redo, unsigned int* __restrict__ n_redo)
@@ -1290,7 +1369,9 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 			HIP_TRY(ctx, hipMemsetAsync(qc.p, 0, 8, ctx->side2));
 			LaunchOn on(ctx, ctx->side2);                                         // (launch + timing events on the third stream)
 			ctx->next_cells = (double)h_cb[N_CLASSES + 5];
-			if (nohist) LAUNCHB(ctx, 1.25 * (double)h_cb[5], k_align_quad, waves, 64, (const uint32_t*)ids.p + hb[5], n_list, L.gaps.p, L.es.p, A, R, quad_scratch.p, per_wave, qc.p, quad_redo.p, qc.p + 1, (uint32_t)(getenv("COLORD_HIP_QUAD_DBG") ? atoi(getenv("COLORD_HIP_QUAD_DBG")) : 0));
+			static const bool old_quad = getenv("COLORD_HIP_QUAD_OLD") != nullptr;
+			if (!nohist && !old_quad) LAUNCHB(ctx, 1.25 * (double)h_cb[5], k_align_quad_rows, waves, 64, (const uint32_t*)ids.p + hb[5], n_list, L.gaps.p, L.es.p, A, R, quad_scratch.p, per_wave, qc.p, quad_redo.p, qc.p + 1);
+			else if (nohist) LAUNCHB(ctx, 1.25 * (double)h_cb[5], k_align_quad, waves, 64, (const uint32_t*)ids.p + hb[5], n_list, L.gaps.p, L.es.p, A, R, quad_scratch.p, per_wave, qc.p, quad_redo.p, qc.p + 1, (uint32_t)(getenv("COLORD_HIP_QUAD_DBG") ? atoi(getenv("COLORD_HIP_QUAD_DBG")) : 0));
 			else LAUNCHB(ctx, 1.25 * (double)h_cb[5], k_align_quad_hist, waves, 64, (const uint32_t*)ids.p + hb[5], n_list, L.gaps.p, L.es.p, A, R, quad_scratch.p, per_wave, qc.p, quad_redo.p, qc.p + 1);
 			HIP_TRY(ctx, hipGetLastError());
 		}
@@ -1323,7 +1404,7 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 			gt::View V; V.ctl = (gt::Ctl*)(giant_mem.p + o_ctl); V.heap = giant_heap.p; V.heap_bytes = heap_bytes; V.flags = (uint32_t*)(giant_mem.p + o_flags);
 			for (int i = 0; i < 2; ++i) { V.nodes[i] = (gt::Node*)(giant_mem.p + o_nodes + i * al(sizeof(gt::Node) * gt::NODE_CAP)); V.sweeps[i] = (gt::Sweep*)(giant_mem.p + o_sweeps + i * al(sizeof(gt::Sweep) * 2 * gt::NODE_CAP));
 				V.jobs[i] = (gt::Job*)(giant_mem.p + o_jobs + i * al(sizeof(gt::Job) * gt::JOB_CAP)); }
-			V.leaves = (gt::Leaf*)(giant_mem.p + o_leaves); V.giants = (gt::Giant*)(giant_mem.p + o_giants); V.n_giants = n_list;
+			V.leaves = (gt::Leaf*)(giant_mem.p + o_leaves); V.giants = (gt::Giant*)(giant_mem.p + o_giants); V.n_giants = n_list; V.n_phases = phases;
 			LaunchOn on(ctx, ctx->side3);
 			ctx->next_cells = (double)h_cb[N_CLASSES + 7];                         // (booked on the staging launch: the class as a whole is what the report adds up)
 			LAUNCHB(ctx, 1.25 * (double)h_cb[7], k_giant_stage, n_list, 256, V, (const uint32_t*)ids.p + hb[7], (const GapRec*)L.gaps.p, A, R);
@@ -1435,6 +1516,44 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 		else if (hb[8] > hb[7]) CL_TRY(run_large(ids.p + hb[7], hb[8] - hb[7], 1.25 * (double)h_cb[7]));   // (COLORD_HIP_NO_TEAM_ALIGN)
 		if (n_team_redo) CL_TRY(run_large(team_redo.p, n_team_redo, 0.0));
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->side));                           // the small gaps are through
+		if (getenv("COLORD_HIP_GAP_SHAPES"))
+		{	// diagnostic: shapes and edit distances of the aligned gaps by class — what a band (edlib.cpp:192-212) would save, what fits LDS
+			HIP_TRY(ctx, hipDeviceSynchronize());
+			std::vector<GapRec> all(L.n_gaps); std::vector<char> hes(es_total + 16);
+			HIP_TRY(ctx, hipMemcpy(all.data(), L.gaps.p, (uint64_t)L.n_gaps * sizeof(GapRec), hipMemcpyDeviceToHost));
+			HIP_TRY(ctx, hipMemcpy(hes.data(), L.es.p, es_total, hipMemcpyDeviceToHost));
+			struct Acc { uint64_t n = 0; double cells = 0, band = 0, band_ideal = 0; std::vector<uint32_t> nm, dpm; uint64_t ratio[11] = { 0 }; } acc[N_CLASSES + 1];
+			for (const GapRec& g : all)
+			{
+				if (g.kind == GK_TRIVIAL) continue;
+				const uint32_t rows = g.kind == GK_FLANK ? g.ne : g.use, cols = g.kind == GK_FLANK ? g.use : g.ne;      // (gap_class, restated for the host)
+				const uint32_t cls = (rows <= 256 && cols <= 256) ? (rows + 63) / 64 : (rows <= QUAD_ROWS && rows + cols <= QUAD_SEQ && (uint64_t)((rows + 63) / 64) * (cols + 16) <= QUAD_CELLS) ? 5u
+					: (rows > GIANT_ROWS && rows <= GIANT_MAX_ROWS && (uint64_t)((rows + 63) / 64) * cols >= GIANT_WORK && rows / 8 < cols) ? 7u : 6u;
+				if (!cls || !rows || !cols) continue;
+				uint32_t d = 0; for (uint32_t x = 0; x < g.es_len; ++x) d += hes[g.es_off + x] != 'M';
+				Acc& a = acc[cls]; ++a.n;
+				const double nb = (rows + 63) / 64; a.cells += nb * cols;
+				// edlib's k-doubling (edlib.cpp:192-212: k = 64, 128, ... until the score fits) with Ukkonen's band of 2 k + |rows - cols| + 1 rows
+				const double diff = rows > cols ? rows - cols : cols - rows;
+				auto bandw = [&](double k) { return std::min(nb, std::ceil((2 * k + diff + 1) / 64.0) + 1); };
+				double k = 64, cost = 0; while (k < d) { cost += bandw(k) * cols * 0.5; k *= 2; }   // (a failed round stops about half way)
+				a.band += cost + bandw(k) * cols; a.band_ideal += bandw(d) * cols;
+				a.nm.push_back(rows + cols); a.dpm.push_back((uint32_t)(1000.0 * d / std::max(rows, cols)));
+				a.ratio[std::min<uint32_t>(10, (uint32_t)(20.0 * d / std::max(rows, cols)))]++;
+			}
+			for (uint32_t cls = 1; cls <= N_CLASSES; ++cls)
+			{
+				Acc& a = acc[cls]; if (!a.n) continue;
+				std::sort(a.nm.begin(), a.nm.end()); std::sort(a.dpm.begin(), a.dpm.end());
+				auto pc = [&](std::vector<uint32_t>& v, double p) { return v[std::min<size_t>(v.size() - 1, (size_t)(p * v.size()))]; };
+				auto le = [&](uint32_t x) { return (double)(std::upper_bound(a.nm.begin(), a.nm.end(), x) - a.nm.begin()) / a.n; };
+				fprintf(stderr, "[shapes] level %u class %u: %llu gaps, block-columns %.4g, k-doubling band %.4g (%.2f), band of the true distance %.4g (%.2f); rows+cols p50 %u p90 %u p99 %u p99.9 %u max %u; <=1536 %.4f <=2048 %.4f <=2730 %.4f <=4096 %.4f; d/len permille p10 %u p50 %u p90 %u p99 %u; by d/len in steps of 5%%:",
+					lv, cls, (unsigned long long)a.n, a.cells, a.band, a.band / a.cells, a.band_ideal, a.band_ideal / a.cells, pc(a.nm, 0.5), pc(a.nm, 0.9), pc(a.nm, 0.99), pc(a.nm, 0.999), a.nm.back(),
+					le(1536), le(2048), le(2730), le(4096), pc(a.dpm, 0.1), pc(a.dpm, 0.5), pc(a.dpm, 0.9), pc(a.dpm, 0.99));
+				for (int i = 0; i < 11; ++i) fprintf(stderr, " %llu", (unsigned long long)a.ratio[i]);
+				fprintf(stderr, "\n");
+			}
+		}
 		// statistics / decisions, children
 		DevBuf<uint32_t> sflag, sncand; DEV_ALLOC(ctx, sflag, ng + 1); DEV_ALLOC(ctx, sncand, ng + 1);
 		const uint32_t n_long = (uint32_t)(ng - n_pend);

@@ -63,7 +63,7 @@ constexpr uint32_t LB_ITEMS = 16, LB_TILE = SCAN_THREADS * LB_ITEMS;
 constexpr unsigned long long LB_AGG = 1ull << 62, LB_PREFIX = 2ull << 62, LB_VAL = (1ull << 62) - 1;
 // ctl[0]: ticket, ctl[1..]: status of tile 0, 1, ... (zeroed before the launch).  total_out (optional): receives the sum of all.
 template<typename TIn, typename TOut>
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_lookback(const TIn* in, uint64_t n, TOut* out, unsigned long long* __restrict__ ctl, TOut* total_out, TOut* total_out2)
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_lookback(const TIn* in, uint64_t n, TOut* out, unsigned long long* __restrict__ ctl, TOut* total_out, unsigned long long* total64)
 {
 	__shared__ TOut sh[4];
 	__shared__ unsigned long long s_excl;
@@ -112,19 +112,34 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_lookback(const TIn* in, u
 	pre += (TOut)s_excl;
 #pragma unroll
 	for (uint32_t i = 0; i < LB_ITEMS; ++i) { if (base + i < n) out[base + i] = pre; pre += v[i]; }
-	if ((uint64_t)(tile + 1) * LB_TILE >= n && threadIdx.x == SCAN_THREADS - 1) { if (total_out) *total_out = pre; if (total_out2) *total_out2 = pre; }    // (the last thread of the last tile has walked to the end)
+	// (the last thread of the last tile has walked to the end; the 64-bit total comes from the look-back's own 62-bit sums, so a sum that
+	// does not fit TOut is seen by the host instead of wrapping silently)
+	if ((uint64_t)(tile + 1) * LB_TILE >= n && threadIdx.x == SCAN_THREADS - 1) { if (total_out) *total_out = pre; if (total64) *total64 = s_excl + (unsigned long long)total; }
 }
 
 template<typename TIn, typename TOut>
-cl_status scan_lookback(cl_ctx* ctx, const TIn* d_in, TOut* d_out, uint64_t n, TOut* d_total, TOut* d_total2 = nullptr)
+cl_status scan_lookback(cl_ctx* ctx, const TIn* d_in, TOut* d_out, uint64_t n, TOut* d_total, unsigned long long* d_total64 = nullptr)
 {
 	const uint32_t tiles = grid_for(n, LB_TILE);
-	DevBuf<unsigned long long> ctl; DEV_ALLOC(ctx, ctl, (uint64_t)tiles + 1);
+	// The status words live in a buffer the context keeps PER STREAM (round 5).  Rounds 3-4 took them from the pool and gave them back on
+	// return, with memset and kernel still queued: the pool hands a context its own blocks back at once, so the next allocation of the same
+	// context — made for work on ANOTHER of its streams (a side stream, a LaunchOn scope) — could overwrite the flags under a running scan:
+	// a wrong prefix or a look-back that never ends.  Scans on one stream are ordered, so one buffer per stream is safe; it grows rarely, and
+	// only after the stream has drained.
 	hipStream_t st = cl_launch_stream(ctx);
-	HIP_TRY(ctx, hipMemsetAsync(ctl.p, 0, ((uint64_t)tiles + 1) * 8, st));
-	LAUNCH(ctx, (k_scan_lookback<TIn, TOut>), tiles, SCAN_THREADS, d_in, n, d_out, ctl.p, d_total, d_total2);
+	cl_ctx::ScanCtl& C = ctx->scan_ctl[(void*)st];
+	if (C.words < (uint64_t)tiles + 1)
+	{
+		if (C.p) { HIP_TRY(ctx, hipStreamSynchronize(st)); ctx->pool.put(C.p, C.got, ctx->pool_id); C.p = nullptr; C.words = 0; }
+		const uint64_t want = std::max<uint64_t>((uint64_t)tiles + 1, 1u << 16);
+		void* q = nullptr;
+		if (ctx->pool.get(want * 8, &q, &C.got, ctx->pool_id) != hipSuccess) return cl_fail(ctx, CL_E_NOMEM, "scan_lookback: no memory for the status words");
+		C.p = (unsigned long long*)q; C.words = want;
+	}
+	HIP_TRY(ctx, hipMemsetAsync(C.p, 0, ((uint64_t)tiles + 1) * 8, st));
+	LAUNCH(ctx, (k_scan_lookback<TIn, TOut>), tiles, SCAN_THREADS, d_in, n, d_out, C.p, d_total, d_total64);
 	HIP_TRY(ctx, hipGetLastError());
-	return CL_OK;                                                                // (ctl goes back to the pool: the context's own stream order protects it)
+	return CL_OK;
 }
 
 template<typename T> __global__ void k_write_total(const T* last_in_scanned, T last_value, T* dst) { *dst = *last_in_scanned + last_value; }
@@ -146,7 +161,7 @@ cl_status scan_impl(cl_ctx* ctx, const TIn* d_in, TOut* d_out, uint64_t n)
 	CL_TRY((scan_impl<TOut, TOut>(ctx, sums.p, sums.p, tiles)));
 	LAUNCH(ctx, (k_tile_scan<TIn, TOut>), tiles, SCAN_THREADS, d_in, n, (const TOut*)sums.p, d_out);
 	HIP_TRY(ctx, hipGetLastError());
-	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // sums is freed on return
+	HIP_TRY(ctx, hipStreamSynchronize(cl_launch_stream(ctx)));   // sums is freed on return
 	return CL_OK;
 }
 } // namespace
@@ -172,11 +187,12 @@ cl_status dev_exclusive_scan_u32(cl_ctx* ctx, uint32_t* d_data, uint64_t n, uint
 	}
 	uint64_t* hs = nullptr; uint64_t* ds = nullptr;
 	if (h_total) HIP_TRY(ctx, cl_slot(ctx, 1, &hs, &ds));                      // (the total goes straight to mapped host memory)
-	CL_TRY((scan_lookback<uint32_t, uint32_t>(ctx, d_data, d_data, n, (uint32_t*)ds)));
+	CL_TRY((scan_lookback<uint32_t, uint32_t>(ctx, d_data, d_data, n, (uint32_t*)nullptr, (unsigned long long*)ds)));
 	if (h_total)
 	{
 		HIP_TRY(ctx, hipStreamSynchronize(st));
-		*h_total = *(volatile uint32_t*)hs;
+		*h_total = *(volatile uint64_t*)hs;
+		if (*h_total >= (1ull << 32)) return cl_fail(ctx, CL_E_UNSUPPORTED, "dev_exclusive_scan_u32: the sum " + std::to_string(*h_total) + " does not fit 32 bits");
 	}
 	return CL_OK;
 }
@@ -203,7 +219,7 @@ cl_status dev_exclusive_scan_u64(cl_ctx* ctx, const uint32_t* d_in, uint64_t* d_
 	{
 		uint64_t* hs = nullptr; uint64_t* ds = nullptr;
 		if (h_total) HIP_TRY(ctx, cl_slot(ctx, 1, &hs, &ds));
-		CL_TRY((scan_lookback<uint32_t, uint64_t>(ctx, d_in, d_out, n, d_out + n, ds)));   // (the total lands in d_out[n] — and in mapped host memory)
+		CL_TRY((scan_lookback<uint32_t, uint64_t>(ctx, d_in, d_out, n, d_out + n, (unsigned long long*)ds)));   // (the total lands in d_out[n] — and in mapped host memory)
 		if (h_total) { HIP_TRY(ctx, hipStreamSynchronize(st)); total = *(volatile uint64_t*)hs; }
 	}
 	else { HIP_TRY(ctx, hipMemsetAsync(d_out, 0, 8, st)); }

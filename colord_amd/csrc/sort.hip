@@ -195,10 +195,10 @@ cl_status sort_impl(cl_ctx* ctx, K* d_keys, uint32_t* d_vals, uint64_t n, uint32
 	}
 	else if (kin != d_keys)
 	{
-		HIP_TRY(ctx, hipMemcpyAsync(d_keys, kin, n * sizeof(K), hipMemcpyDeviceToDevice, ctx->stream));
-		if (d_vals) HIP_TRY(ctx, hipMemcpyAsync(d_vals, vin, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+		HIP_TRY(ctx, hipMemcpyAsync(d_keys, kin, n * sizeof(K), hipMemcpyDeviceToDevice, cl_launch_stream(ctx)));
+		if (d_vals) HIP_TRY(ctx, hipMemcpyAsync(d_vals, vin, n * 4, hipMemcpyDeviceToDevice, cl_launch_stream(ctx)));
 	}
-	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(cl_launch_stream(ctx)));                  // (the stream the passes ran on: the temporaries go back to the pool on return)
 	return CL_OK;
 }
 } // namespace
