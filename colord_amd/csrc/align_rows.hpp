@@ -68,8 +68,21 @@ __device__ inline void row_stage(const Row& r, bool act, const enc::GapRec& g, c
 }
 
 // ---- the sweep (as wv::quad_sweep; sequences from LDS, the history as 16-byte pairs) -------------------------------------------------------
-// cell of block b, column j (0-based): pair (j + b) * nb + b = { vertical +1 bits after the column, horizontal +1 bits of the column }
-__device__ inline wv::Sweep row_sweep(const Row& r, ulonglong2* __restrict__ hist)
+// The history is what this kernel moves: one pair { vertical +1 bits after the column, horizontal +1 bits of the column } per row block and
+// column — measured (round 5) at 4 TB/s of writes with 2048 waves sweeping, i.e. the sweep ran at the speed of its stores, and the
+// traceback's 16-byte reads with a stride of nb pairs fetched a whole sector each.  So:
+//   * BLOCK-MAJOR: cell of block b, column j (0-based) = pair b * stride + j — the 16 columns of a traceback window are 256 contiguous bytes;
+//   * a BAND: every cell (i, j) of an optimal path has D[i][j] <= d (the final distance) and D[i][j] >= |i - j|, so a block is stored for
+//     column j only if it holds a row within `band` of j.  `band` is an assumption (a quarter of the gap's length: 99.3 % of the class, the
+//     rest are unrelated sequences at d > len / 2); the caller checks d <= band after the sweep and hands the gap to the wave kernel
+//     otherwise — the sweep itself is exact either way, only what it keeps is limited.
+__device__ inline uint64_t sel64(uint32_t mask, uint64_t a, uint64_t b)       // mask all ones: a, zero: b
+{
+	const uint32_t lo = ((uint32_t)a & mask) | ((uint32_t)b & ~mask), hi = ((uint32_t)(a >> 32) & mask) | ((uint32_t)(b >> 32) & ~mask);
+	return ((uint64_t)hi << 32) | lo;
+}
+__device__ inline uint32_t hist_stride(uint32_t m) { return (m + 15) & ~15u; }
+__device__ inline wv::Sweep row_sweep(const Row& r, ulonglong2* __restrict__ hist, uint32_t band)
 {
 	const uint32_t lane = wv::lane_id(), bl = lane & 15, row0 = lane & 48;
 	const uint32_t n = r.n, m = r.m, nb = (n + 63) / 64;
@@ -84,44 +97,49 @@ __device__ inline wv::Sweep row_sweep(const Row& r, ulonglong2* __restrict__ his
 			e0 |= s == 0 ? bit : 0; e1 |= s == 1 ? bit : 0; e2 |= s == 2 ? bit : 0; e3 |= s == 3 ? bit : 0;
 		}
 	}
+	// The step is one straight line (round 5: hipcc turned the four-way choice of the match mask and the owner's score update into
+	// branches — 110 instructions and six exec-mask switches per step): the mask is chosen by bit selects, the horizontal delta travels
+	// as two bits (1: +1, 2: -1), the score is read through a mask that is zero outside the lane that owns the last row.
 	uint64_t Pv = ~0ull, Mv = 0;
-	const bool owner = act && bl == nb - 1;
-	const uint32_t lastbit = (n - 1) & 63;
+	const uint64_t lastmask = (act && bl == nb - 1) ? 1ull << ((n - 1) & 63) : 0ull;
 	uint32_t sc = n, best = 0xffffffffu; int32_t end = (int32_t)m - 1;
 	if (r.shw && (n & 63)) { best = n; end = -1; }
+	const bool shw = r.shw;
 	const uint32_t steps = nb ? m + nb - 1 : 0;
 	const uint32_t steps_max = max4(steps);
-	uint32_t c = 0, tchunk = 0; int hout = 0;
+	ulonglong2* const hrow = hist + (uint64_t)bl * hist_stride(m) - bl;        // (+ s: column s - bl of block bl)
+	// 1-based columns [keep_lo, keep_hi] of this block are kept: steps s with s - s_lo <= s_span
+	const uint32_t keep_lo = 64 * bl + 1 > band ? 64 * bl + 1 - band : 1, keep_hi = 64 * bl + 64 + band;
+	const uint32_t s_lo = keep_lo - 1 + bl, s_span = keep_hi - keep_lo;
+	const uint32_t m_act = act ? m : 0;
+	uint32_t c = 0, tchunk = 0, hout = 0;
 	for (uint32_t s = 0; s < steps_max; ++s)
 	{
 		if ((s & 15) == 0) { const uint32_t j0 = s + bl; tchunk = (nb && j0 < m) ? Ts(r, j0) : 0u; }
 		else tchunk = wv::row_rol1(tchunk);
-		const uint32_t c_up = wv::row_shr1(c); const int h_up = wv::row_shr1(hout);
+		const uint32_t c_up = wv::row_shr1(c), h_up = wv::row_shr1(hout);
 		c = bl == 0 ? tchunk : c_up;
-		const int hin = bl == 0 ? 1 : h_up;
-		const bool valid = act && s >= bl && s - bl < m;
+		const uint32_t hin = bl == 0 ? 1u : h_up;
 		hout = 0;
-		if (valid)
+		if (s - bl < m_act)
 		{
-			uint64_t Eq = c == 0 ? e0 : c == 1 ? e1 : c == 2 ? e2 : e3;
-			const uint64_t hneg = hin < 0 ? 1ull : 0ull;
+			const uint32_t M0 = 0u - (c & 1), M1 = 0u - (c >> 1);               // (32-bit masks on both halves: v_bfi_b32)
+			uint64_t Eq = sel64(M1, sel64(M0, e3, e2), sel64(M0, e1, e0));
+			const uint64_t hneg = hin >> 1, hpos = hin & 1;
 			const uint64_t Xv = Eq | Mv;
 			Eq |= hneg;
 			const uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
 			uint64_t Ph = Mv | ~(Xh | Pv);
 			uint64_t Mh = Pv & Xh;
 			const uint64_t ph_rows = Ph;
-			if (owner)
-			{
-				sc += (uint32_t)((Ph >> lastbit) & 1) - (uint32_t)((Mh >> lastbit) & 1);
-				if (r.shw && sc < best) { best = sc; end = (int32_t)(s - bl); }
-			}
-			hout = (int)(Ph >> 63) - (int)(Mh >> 63);
-			Ph <<= 1; Mh <<= 1;
-			Mh |= hneg; Ph |= hin > 0 ? 1ull : 0ull;
+			sc += (uint32_t)((Ph & lastmask) != 0) - (uint32_t)((Mh & lastmask) != 0);
+			const bool better = shw && sc < best;                                // (lanes that do not own the last row: sc stays n, never below best)
+			best = better ? sc : best; end = better ? (int32_t)(s - bl) : end;
+			hout = (uint32_t)(Ph >> 63) | ((uint32_t)(Mh >> 63) << 1);
+			Ph = (Ph << 1) | hpos; Mh = (Mh << 1) | hneg;
 			Pv = Mh | ~(Xv | Ph);
 			Mv = Ph & Xv;
-			hist[(uint64_t)s * nb + bl] = make_ulonglong2(Pv, ph_rows);
+			if (s - s_lo <= s_span) hrow[s] = make_ulonglong2(Pv, ph_rows);
 		}
 	}
 	wv::Sweep out;
@@ -132,74 +150,76 @@ __device__ inline wv::Sweep row_sweep(const Row& r, ulonglong2* __restrict__ his
 
 // ---- the traceback of the four gaps in lock step (decisions of edlib.cpp:1021-1147: up if the vertical delta is +1, else left if the
 // horizontal delta is +1, else diagonal) -----------------------------------------------------------------------------------------------------
-// A WINDOW = the pairs of 16 consecutive columns (lane d of the row: column wj0 - d, 1-based) for two row blocks, wb and wb - 1.  When a
-// window is installed the one the path will most likely need next — 16 columns further left, the blocks around the row a diagonal path
-// reaches there — is requested; it is taken if it fits when the walk leaves the current one (an exact test), else the window is fetched
-// on demand.  The operations go to r.ops, LAST operation first; the walk ends in cell (i_out, j_out), one of them 0.
-struct Win { uint64_t P0, H0, P1, H1; uint32_t j0, b0; bool ok; };
-__device__ inline void win_load(Win& w, const ulonglong2* __restrict__ hist, uint32_t nb, uint32_t d, bool want)
-{
-	if (!want) return;
-	w.P0 = w.H0 = w.P1 = w.H1 = 0;
-	if (w.j0 > d)
-	{
-		const uint32_t jj = w.j0 - d - 1;
-		const ulonglong2 a = hist[(uint64_t)(jj + w.b0) * nb + w.b0];
-		w.P0 = a.x; w.H0 = a.y;
-		if (w.b0) { const ulonglong2 b = hist[(uint64_t)(jj + w.b0 - 1) * nb + w.b0 - 1]; w.P1 = b.x; w.H1 = b.y; }
-	}
-}
-__device__ inline void row_walk(const Row& r, const ulonglong2* __restrict__ hist, uint32_t j_start, uint32_t& i_out, uint32_t& j_out, uint32_t& k_out)
+// A WINDOW = the pairs of 64 consecutive columns (sub-window x of lane d: column j0 - 16 x - d, 1-based) for two row blocks, b0 and b0 - 1:
+// 16 registers a lane.  A fetch from HBM is a microsecond and hipcc waits for every load it has issued before the next use of any of
+// them (measured: a queue of four 16-column windows requested ahead changed nothing — `s_waitcnt vmcnt(0)` every iteration), so what counts
+// is the NUMBER of fetches the wave waits for: whenever one row leaves its window ALL rows take a new one at their current cell (one wait
+// for the four of them; ~20 per quad instead of 62 with 16 columns and a fetch per row).  The 16 lanes of a row look at the 16 columns
+// j, j - 1, ... j - 15 wherever they fall in the window, so a run is never cut at a sub-window's edge.
+// The operations go to r.ops, LAST operation first; the walk ends in cell (i_out, j_out), one of them 0.
+struct WalkStats { uint32_t iters = 0, miss = 0, hit = 0; };                  // (per wave: iterations, iterations that waited for new windows; `hit` unused)
+__device__ inline void row_walk(const Row& r, const ulonglong2* __restrict__ hist, uint32_t j_start, uint32_t& i_out, uint32_t& j_out, uint32_t& k_out, WalkStats* ws = nullptr)
 {
 	const uint32_t lane = wv::lane_id(), d = lane & 15, row0 = lane & 48;
-	const uint32_t n = r.n, nb = (n + 63) / 64;
+	const uint32_t n = r.n, stride = hist_stride(r.m);
 	uint32_t i = n, j = n ? j_start : 0, k = 0;
-	Win cur{ 0, 0, 0, 0, 0, 0, false }, nxt{ 0, 0, 0, 0, 0, 0, false };
+	uint64_t P0[4], H0[4], P1[4], H1[4];                                        // [x]: sub-window x; 0: block b0, 1: block b0 - 1
+#pragma unroll
+	for (int x = 0; x < 4; ++x) P0[x] = H0[x] = P1[x] = H1[x] = 0;
+	uint32_t j0 = 0, b0 = 0; bool have = false;
 	for (;;)
 	{
 		const bool go = i > 0 && j > 0;
 		if (!__ballot(go)) break;
 		const uint32_t rr = i - 1, b = rr >> 6, rb = rr & 63;
-		auto fits = [&](const Win& w) { return w.ok && (b == w.b0 || b + 1 == w.b0) && j <= w.j0 && w.j0 - j < 16; };
-		const bool need = go && !fits(cur);
+		const bool need = go && !(have && (b == b0 || b + 1 == b0) && j <= j0 && j0 - j < 64);
+		if (ws) ++ws->iters;
 		if (__ballot(need))
 		{
-			const bool hit = need && fits(nxt);
-			const bool miss = need && !hit;
-			if (hit) cur = nxt;
-			if (__ballot(miss))
+			if (ws) ++ws->miss;
+			if (go)
 			{
-				if (miss) { cur.j0 = j; cur.b0 = b; cur.ok = true; }
-				win_load(cur, hist, nb, d, miss);
+				j0 = j; b0 = b; have = true;
+#pragma unroll
+				for (int x = 0; x < 4; ++x)
+				{
+					P0[x] = H0[x] = P1[x] = H1[x] = 0;
+					if (j0 > 16 * x + d)
+					{
+						const uint32_t jj = j0 - 16 * x - d - 1;
+						const ulonglong2 a = hist[(uint64_t)b0 * stride + jj];
+						P0[x] = a.x; H0[x] = a.y;
+						if (b0) { const ulonglong2 c = hist[(uint64_t)(b0 - 1) * stride + jj]; P1[x] = c.x; H1[x] = c.y; }
+					}
+				}
 			}
-			// the next window: a diagonal path leaves the current one at column cur.j0 - 16 in row rr - (j - (cur.j0 - 16)); blocks around it
-			const bool pre = need && cur.j0 > 16 && rr + cur.j0 >= j + 16;
-			if (need)
-			{
-				nxt.ok = pre;
-				if (pre) { const uint32_t r2 = rr + cur.j0 - 16 - j; nxt.j0 = cur.j0 - 16; nxt.b0 = (r2 + 16) >> 6; if (nxt.b0 >= nb) nxt.b0 = nb - 1; }
-			}
-			if (__ballot(pre)) win_load(nxt, hist, nb, d, pre);
 		}
-		const uint32_t src = go ? cur.j0 - j : 0u;                              // the lane of the row that holds column j
-		const int dd = (int)d - (int)src;                                       // this lane's column is j - dd
-		const bool col_ok = go && dd >= 0 && d < cur.j0;
-		const bool lower = b == cur.b0;
-		const uint64_t Pb = lower ? cur.P0 : cur.P1, Hb = lower ? cur.H0 : cur.H1;
+		const uint32_t o = go ? j0 - j : 0u, sub = o >> 4, src = o & 15;           // column j sits in sub-window `sub`, lane `src`
+		const uint32_t dd = (d - src) & 15;                                     // this lane's column is j - dd ...
+		const uint32_t x = sub + (d < src ? 1u : 0u);                           // ... in sub-window x
+		const bool col_ok = go && dd < j && x < 4;
+		const bool lower = b == b0;
+		uint64_t Pb, Hb;
+		{
+			const uint64_t pa = lower ? P0[0] : P1[0], pb = lower ? P0[1] : P1[1], pc = lower ? P0[2] : P1[2], pd = lower ? P0[3] : P1[3];
+			const uint64_t ha = lower ? H0[0] : H1[0], hb = lower ? H0[1] : H1[1], hc = lower ? H0[2] : H1[2], hd = lower ? H0[3] : H1[3];
+			Pb = x == 0 ? pa : x == 1 ? pb : x == 2 ? pc : pd;
+			Hb = x == 0 ? ha : x == 1 ? hb : x == 2 ? hc : hd;
+		}
 		const uint32_t pr = (uint32_t)(Pb >> rb) & 1, hr = (uint32_t)(Hb >> rb) & 1;
-		const uint32_t pm16 = rb16(col_ok && pr, row0), hm16 = rb16(col_ok && hr, row0);
-		const uint32_t p0 = (pm16 >> src) & 1, h0 = (hm16 >> src) & 1;
+		auto rot = [&](uint32_t m16) { return ((m16 >> src) | (m16 << (16 - src))) & 0xffffu; };   // bit of lane d -> bit dd
+		const uint32_t pm = rot(rb16(col_ok && pr, row0)), hm = rot(rb16(col_ok && hr, row0));
+		const uint32_t p0 = pm & 1, h0 = hm & 1;
 		// up: while the vertical +1 bits of column j continue (inside this block) — every lane for its own column, the row takes lane src's
 		uint32_t myrun;
-		{ const uint64_t x = ~Pb << (63 - rb); myrun = x ? (uint32_t)__builtin_clzll(x) : 64u; if (myrun > rb + 1) myrun = rb + 1; }
-		const uint32_t uprun = (uint32_t)__shfl((int)myrun, (int)(row0 + (src & 15)));
-		const uint32_t left16 = rb16(col_ok && !pr && hr, row0);
-		const uint32_t bp = (rb - (uint32_t)dd) & 63;
-		const bool dg = col_ok && (uint32_t)dd <= rb && !((Pb >> bp) & 1) && !((Hb >> bp) & 1);
-		const uint32_t diag16 = rb16(dg, row0);
+		{ const uint64_t y = ~Pb << (63 - rb); myrun = y ? (uint32_t)__builtin_clzll(y) : 64u; if (myrun > rb + 1) myrun = rb + 1; }
+		const uint32_t uprun = (uint32_t)__shfl((int)myrun, (int)(row0 + src));
+		const uint32_t left16 = rot(rb16(col_ok && !pr && hr, row0));
+		const uint32_t bp = (rb - dd) & 63;
+		const bool dg = col_ok && dd <= rb && !((Pb >> bp) & 1) && !((Hb >> bp) & 1);
+		const uint32_t diag16 = rot(rb16(dg, row0));
 		if (go)
 		{
-			const uint32_t from_src = (0xffffu << src) & 0xffffu;
 			uint32_t run;
 			if (p0)
 			{
@@ -209,16 +229,16 @@ __device__ inline void row_walk(const Row& r, const ulonglong2* __restrict__ his
 			}
 			else if (h0)
 			{	// left while row rr has no vertical +1 and a horizontal +1
-				const uint32_t stop = ~left16 & from_src;
-				run = (stop ? (uint32_t)__builtin_ctz(stop) : 16u) - src;
-				if (dd >= 0 && (uint32_t)dd < run) r.ops[k + (uint32_t)dd] = 2;
+				const uint32_t stop = ~left16 & 0xffffu;
+				run = stop ? (uint32_t)__builtin_ctz(stop) : 16u;
+				if (dd < run) r.ops[k + dd] = 2;
 				j -= run;
 			}
 			else
 			{	// diagonal while neither bit is set at (rr - dd, j - dd); the symbols decide match / mismatch
-				const uint32_t stop = ~diag16 & from_src;
-				run = (stop ? (uint32_t)__builtin_ctz(stop) : 16u) - src;
-				if (dd >= 0 && (uint32_t)dd < run) r.ops[k + (uint32_t)dd] = Qs(r, rr - (uint32_t)dd) == Ts(r, j - 1 - (uint32_t)dd) ? 0 : 3;
+				const uint32_t stop = ~diag16 & 0xffffu;
+				run = stop ? (uint32_t)__builtin_ctz(stop) : 16u;
+				if (dd < run) r.ops[k + dd] = Qs(r, rr - dd) == Ts(r, j - 1 - dd) ? 0 : 3;
 				i -= run; j -= run;
 			}
 			k += run;

@@ -812,9 +812,14 @@ __global__ __launch_bounds__(64) void k_align_quad(const uint32_t* __restrict__ 
 
 // the same class, every phase of a gap in its 16-lane row (align_rows.hpp; round 5): sequences, operations and script in LDS, the history
 // in the wave's pool.  What does not fit (pool, LDS) goes to `redo`.
+// PROF (COLORD_HIP_QUAD_PROFILE): 100-MHz clocks per phase and the traceback's window statistics, summed over the waves into prof[0..10]
+template<bool PROF>
 __global__ __launch_bounds__(64) void k_align_quad_rows(const uint32_t* __restrict__ list, uint32_t n_list, GapRec* __restrict__ gaps, char* __restrict__ es_pool, ArenaV A, ArenaV R,
-                                                  uint8_t* __restrict__ scratch, uint64_t per_wave, unsigned int* __restrict__ next, uint32_t* __restrict__ redo, unsigned int* __restrict__ n_redo)
+                                                  uint8_t* __restrict__ scratch, uint64_t per_wave, unsigned int* __restrict__ next, uint32_t* __restrict__ redo, unsigned int* __restrict__ n_redo, unsigned long long* __restrict__ prof)
 {
+	uint64_t t_last = PROF ? wall_clock64() : 0;
+	auto lap = [&](uint32_t phase) { if (PROF) { const uint64_t now = wall_clock64(); if (threadIdx.x == 0) atomicAdd(prof + phase, (unsigned long long)(now - t_last)); t_last = now; } };
+	qr::WalkStats wstat;
 	__shared__ __attribute__((aligned(16))) uint8_t s_rows[4 * qr::ROW_BYTES];
 	const uint32_t lane = threadIdx.x, gq = lane >> 4, bl = lane & 15;
 	ulonglong2* const pool = (ulonglong2*)(scratch + (uint64_t)blockIdx.x * per_wave);
@@ -840,7 +845,9 @@ __global__ __launch_bounds__(64) void k_align_quad_rows(const uint32_t* __restri
 		else if (g.kind == GK_FLANK_TINY) { r.n = g.use; r.m = g.ne; r.rows_ref = true; r.shw = false; }
 		else { r.n = g.ne; r.m = g.use; r.rows_ref = false; r.shw = true; }
 		const uint32_t nb = (r.n + 63) / 64;
-		const uint64_t pairs = ((uint64_t)r.m + 16) * nb;
+		const uint64_t pairs = (uint64_t)qr::hist_stride(r.m) * nb;
+		// what the sweep keeps of its history: the blocks within `band` rows of a column (align_rows.hpp); a distance beyond it: not of this kernel
+		const uint32_t band = (r.shw ? r.n : (r.n > r.m ? r.n : r.m)) / 4 + 16;
 		bool ok = have && r.n && r.m && r.n <= 1024 && (g.kind != GK_INNER || g.nr == g.use) && g.use + g.ne <= qr::SEQ_MAX;
 		// the rows' shares of the pool (a row that does not fit takes none)
 		uint64_t off = 0;
@@ -852,17 +859,23 @@ __global__ __launch_bounds__(64) void k_align_quad_rows(const uint32_t* __restri
 		}
 		if (!ok) { r.n = 0; r.m = 0; }
 		ulonglong2* const hist = pool + off;
+		lap(5);
 		qr::row_stage(r, ok, g, A, R);
 		qr::lds_fence();
-		const wv::Sweep sw = qr::row_sweep(r, hist);
+		lap(0);
+		const wv::Sweep sw = qr::row_sweep(r, hist, band);
 		__builtin_amdgcn_s_waitcnt(0);
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		if (ok && (r.shw ? sw.best : sw.score) > band) { ok = false; r.n = 0; r.m = 0; }
+		lap(1);
 		uint32_t wi, wj, wk;
-		qr::row_walk(r, hist, r.shw ? (uint32_t)(sw.end + 1) : r.m, wi, wj, wk);
+		qr::row_walk(r, hist, r.shw ? (uint32_t)(sw.end + 1) : r.m, wi, wj, wk, PROF ? &wstat : nullptr);
 		qr::lds_fence();
+		lap(2);
 		const uint32_t pre = wi + wj, K = pre + wk;
 		qr::row_convert(r, pre, (uint8_t)(wi ? 1 : 2), wk);
 		qr::lds_fence();
+		lap(3);
 		// canonical indel placement: pass 1 along the reference symbols the script consumes, pass 2 along the read's
 		const uint32_t ref_end = r.shw ? (uint32_t)sw.end : g.kind == GK_FLANK_TINY ? g.use - 1 : 0u;
 		uint32_t d_before = 0, seq_off = 0;
@@ -874,6 +887,7 @@ __global__ __launch_bounds__(64) void k_align_quad_rows(const uint32_t* __restri
 		}
 		qr::row_refactor_pass(r, K, seq_off, 1);
 		qr::row_refactor_pass(r, K, 0, 2);
+		lap(4);
 		if (ok)
 		{
 			uint32_t* dst = (uint32_t*)(es_pool + g.es_off); const uint32_t* src = (const uint32_t*)r.es;
@@ -885,7 +899,9 @@ __global__ __launch_bounds__(64) void k_align_quad_rows(const uint32_t* __restri
 			else redo[atomicAdd(n_redo, 1u)] = gi;
 		}
 		qr::lds_fence();
+		if (PROF) { const uint32_t smax = qr::max4(r.n ? r.m + nb - 1 : 0); if (lane == 0) { atomicAdd(prof + 9, 1ull); atomicAdd(prof + 10, (unsigned long long)smax); } }
 	}
+	if (PROF && lane == 0) { atomicAdd(prof + 6, (unsigned long long)wstat.iters); atomicAdd(prof + 7, (unsigned long long)wstat.miss); atomicAdd(prof + 8, (unsigned long long)wstat.hit); }
 }
 
 // the rest: one lane per gap, lane pool in HBM; gaps whose lane ran out of pool are redone with larger pools
@@ -1370,7 +1386,20 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 			LaunchOn on(ctx, ctx->side2);                                         // (launch + timing events on the third stream)
 			ctx->next_cells = (double)h_cb[N_CLASSES + 5];
 			static const bool old_quad = getenv("COLORD_HIP_QUAD_OLD") != nullptr;
-			if (!nohist && !old_quad) LAUNCHB(ctx, 1.25 * (double)h_cb[5], k_align_quad_rows, waves, 64, (const uint32_t*)ids.p + hb[5], n_list, L.gaps.p, L.es.p, A, R, quad_scratch.p, per_wave, qc.p, quad_redo.p, qc.p + 1);
+			static const bool quad_prof = getenv("COLORD_HIP_QUAD_PROFILE") != nullptr;
+			if (!nohist && !old_quad && quad_prof)
+			{	// diagnostic: the phases of the row kernel (waits for the launch)
+				DevBuf<unsigned long long> qp; DEV_ALLOC(ctx, qp, 16);
+				HIP_TRY(ctx, hipMemsetAsync(qp.p, 0, 128, ctx->side2));
+				LAUNCHB(ctx, 1.25 * (double)h_cb[5], k_align_quad_rows<true>, waves, 64, (const uint32_t*)ids.p + hb[5], n_list, L.gaps.p, L.es.p, A, R, quad_scratch.p, per_wave, qc.p, quad_redo.p, qc.p + 1, qp.p);
+				unsigned long long hp[16];
+				HIP_TRY(ctx, hipStreamSynchronize(ctx->side2));
+				HIP_TRY(ctx, hipMemcpy(hp, qp.p, 128, hipMemcpyDeviceToHost));
+				const double q = (double)std::max<unsigned long long>(hp[9], 1);
+				fprintf(stderr, "[quad rows, level %u] %u gaps in %llu quads on %u waves; us per quad: stage %.1f sweep %.1f walk %.1f convert %.1f refactor %.1f fetch+write %.1f; sweep steps per quad %.0f; walk iterations per quad %.0f, of which waited for a window on demand %.1f, took a queued one %.1f\n",
+					lv, n_list, hp[9], waves, hp[0] / q / 100.0, hp[1] / q / 100.0, hp[2] / q / 100.0, hp[3] / q / 100.0, hp[4] / q / 100.0, hp[5] / q / 100.0, hp[10] / q, hp[6] / q, hp[7] / q, hp[8] / q);
+			}
+			else if (!nohist && !old_quad) LAUNCHB(ctx, 1.25 * (double)h_cb[5], k_align_quad_rows<false>, waves, 64, (const uint32_t*)ids.p + hb[5], n_list, L.gaps.p, L.es.p, A, R, quad_scratch.p, per_wave, qc.p, quad_redo.p, qc.p + 1, (unsigned long long*)nullptr);
 			else if (nohist) LAUNCHB(ctx, 1.25 * (double)h_cb[5], k_align_quad, waves, 64, (const uint32_t*)ids.p + hb[5], n_list, L.gaps.p, L.es.p, A, R, quad_scratch.p, per_wave, qc.p, quad_redo.p, qc.p + 1, (uint32_t)(getenv("COLORD_HIP_QUAD_DBG") ? atoi(getenv("COLORD_HIP_QUAD_DBG")) : 0));
 			else LAUNCHB(ctx, 1.25 * (double)h_cb[5], k_align_quad_hist, waves, 64, (const uint32_t*)ids.p + hb[5], n_list, L.gaps.p, L.es.p, A, R, quad_scratch.p, per_wave, qc.p, quad_redo.p, qc.p + 1);
 			HIP_TRY(ctx, hipGetLastError());
