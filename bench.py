@@ -453,6 +453,19 @@ def cpu_baseline_and_size_check(ctx, qctx, sample_bases: float, coverage: float,
               "sample": f"oracle/_ref/colord compress-ont -t {cores} -k {k} -a {a} on {n_bases} synthetic ONT bases ({table.n_reads} reads, same recipe, genome {table.genome_len} bp), "
                         f"whole compressor (parsing, header stream and archive included); {dt:.2f} s wall, archive {ref_size} B = {ref_size / n_bases:.4f} B/base"
                         + (f"; run {tries} of the command (the earlier ones crashed inside the reference)" if tries > 1 else "")}
+        # SURVEY 8d asks for the reference at `-t 8` beside `-t <all cores>`: on a fifth of the sample (a prefix of the same reads), so that
+        # the leg stays within half a minute; both runs are whole compressors, parsing and archive included
+        try:
+            t8 = ontsim.ReadTable(seed=101, genome_len=max(1_000_000, int(sample_bases / coverage)), target_bases=int(sample_bases / 5))
+            fq8 = os.path.join(tmp, "sample_t8.fastq")
+            nb8 = ontsim.write_fastq(t8, fq8)
+            t0 = time.time()
+            rc8 = subprocess.call([ref, "compress-ont", "-t", "8"] + ka + [fq8, os.path.join(tmp, "ref8.colord")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            dt8 = time.time() - t0
+            cb["t8"] = {"value": nb8 / dt8 / 1e9 if rc8 == 0 else None, "unit": "Gbases/s", "cores": 8, "sample": f"the same command with -t 8 on {nb8} bases of the same recipe; {dt8:.2f} s wall" + ("" if rc8 == 0 else f" (exit status {rc8})")}
+            os.remove(fq8)
+        except Exception as e:
+            cb["t8"] = {"value": None, "error": repr(e)[:200]}
         size = {"sample_bases": n_bases, "k": k, "a": a, "ref_archive_bytes": ref_size, "ref_dna_bytes": ref_streams.get("dna"), "ref_qual_bytes": ref_streams.get("qual")}
         # (1) the command-line compressor of this build on the same file: whole archive, reference part cut
         if os.path.exists(ours):
@@ -494,7 +507,7 @@ def cpu_baseline_and_size_check(ctx, qctx, sample_bases: float, coverage: float,
     return cb, size
 
 
-def e2e_cli(bases: float, coverage: float, k: int, a: int, part_symbols: int):
+def e2e_cli(bases: float, coverage: float, k: int, a: int, part_symbols: int, gpus: int = 1, gpu_list=None, timeout_s: float = 900.0):
     """T_e2e: `colord_hip compress-ont` from open(FASTQ) to close(archive) — parsing, upload, all three passes, the header
     stream, the archive — on a synthetic FASTQ of the same recipe written by the host generator, k / a of the main run: once with the
     part cut of the headline number (`--part-symbols`, what `value` is measured with) and once with the reference's (the archive is
@@ -513,9 +526,19 @@ def e2e_cli(bases: float, coverage: float, k: int, a: int, part_symbols: int):
         for name, ps in (("headline_cut", part_symbols), ("ref_cut", 1 << 22)):
             if name == "ref_cut" and ps == part_symbols:
                 continue
-            cmd = [ours, "compress-ont", "-v", "-k", str(k), "-a", str(a), "--part-symbols", str(ps), fq, os.path.join(tmp, "e2e.colord")]
+            multi = []
+            if gpus > 1:                                    # the product's multi-GPU host: one rank thread per GPU, RCCL (host-staged where ranks share a GPU)
+                gl = gpu_list or list(range(gpus))
+                multi = ["--gpus", str(gpus), "--gpu-list", ",".join(str(x) for x in gl), "--transport", "rccl" if len(set(gl)) == len(gl) else "host"]
+                if name == "ref_cut":
+                    continue
+            cmd = [ours, "compress-ont", "-v", "-k", str(k), "-a", str(a), "--part-symbols", str(ps)] + multi + [fq, os.path.join(tmp, "e2e.colord")]
             t0 = time.time()
-            r = subprocess.run(cmd, capture_output=True, text=True)
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                out[name] = {"error": f"no archive after {timeout_s:.0f} s: {' '.join(cmd[:-2])}"}
+                continue
             dt = time.time() - t0
             if r.returncode != 0:
                 out[name] = {"error": (r.stderr or r.stdout)[-300:]}
@@ -524,10 +547,35 @@ def e2e_cli(bases: float, coverage: float, k: int, a: int, part_symbols: int):
             out[name] = {"value": n_bases / dt / 1e9, "unit": "Gbases/s", "seconds": round(dt, 2), "part_symbols": ps, "archive_bytes": os.path.getsize(os.path.join(tmp, "e2e.colord")), "phases": phases}
         first = out.get("headline_cut") or {}
         res = {"value": first.get("value"), "unit": "Gbases/s", "seconds": first.get("seconds"), "bases": n_bases, "fastq_bytes": os.path.getsize(fq), "fastq_written_in_s": round(t_gen, 1),
-               "what": f"colord_hip compress-ont -k {k} -a {a} --part-symbols N file -> archive, whole process (mapped file indexed by several threads, chunks filled by parallel copies into "
-                       f"pinned double buffers); `value` is with the headline's part cut ({part_symbols}), `ref_cut` with the reference's 4194304 (byte-identical archive)"}
+               "what": f"colord_hip compress-ont -k {k} -a {a} --part-symbols N" + (f" --gpus {gpus}" if gpus > 1 else "") + " file -> archive, whole process (mapped file indexed by several threads, chunks filled by parallel copies into "
+                       f"pinned double buffers); `value` is with the headline's part cut ({part_symbols}), `ref_cut` with the reference's 4194304 (byte-identical archive)"
+                       + ("; the C++ host: one rank thread per GPU, exchanges over RCCL (or host-staged), each rank writes its own parts" if gpus > 1 else "")}
         res.update(out)
         return res
+
+
+def multi_gpu_cli_leg(rank: int, world: int, args, k: int, a: int):
+    """Every rank calls this after it has released its GPU memory.  Rank 0 waits until all have (a key per rank in the process group's
+    store: host-side waits, no collective spinning on the GPUs the leg is about to use), runs `colord_hip --gpus N` on a FASTQ of
+    --e2e-bases x N bases (at most 20 Gbases) and releases the others."""
+    from datetime import timedelta
+    from torch.distributed import distributed_c10d as c10d
+    st = c10d._get_default_store()
+    st.set(f"bench_freed_{rank}", b"1")
+    if rank != 0:
+        try:
+            st.wait(["bench_e2e_done"], timedelta(seconds=1500))
+        except Exception:
+            pass
+        return None
+    res = None
+    try:
+        st.wait([f"bench_freed_{r}" for r in range(world)], timedelta(seconds=180))
+        n_dev = torch.cuda.device_count()
+        res = e2e_cli(min(args.e2e_bases * world, 2.0e10), args.coverage, k, a, args.pack_symbols, gpus=world, gpu_list=[r % n_dev for r in range(world)], timeout_s=900.0)
+    finally:
+        st.set("bench_e2e_done", b"1")
+    return res
 
 
 def load_traffic(kernel: str):
@@ -744,6 +792,22 @@ def main():
         timer_txt = ("T_core (SURVEY 8d): packed bases + quality bytes resident in HBM -> every compressed part in pinned host memory" if sink is not None
                      else "packed bases + quality bytes resident in HBM -> every compressed part gathered to rank 0 (device)")
         cb, size, e2e = (None, None, None)
+        if world > 1 and args.e2e_bases > 0 and not args.no_cpu_baseline:
+            # N > 1, second leg: the PRODUCT's multi-GPU host (`colord_hip --gpus N`: C++, one rank thread per GPU, RCCL) file -> archive on
+            # the same GPUs.  Every rank gives its memory back first (the ranks of this process group stay alive, idle, until the leg is through).
+            shard.free()
+            del dna_out, qual_out
+            dna_out = qual_out = None
+            ctx.close()
+            if qctx is not None:
+                qctx.close()
+            torch.cuda.empty_cache()
+            try:
+                e2e = multi_gpu_cli_leg(rank, world, args, k, a)
+            except Exception as e:
+                e2e = {"error": repr(e)[:400]}
+            ctx = Context(local)
+            qctx = Context(local) if qctx is not None else None
         if not args.no_cpu_baseline and world == 1:
             shard.free()                                    # the sample runs (and the command-line compressor) need the memory:
             del dna_out, qual_out, sink                     # give everything back, pools included, and start from fresh contexts
@@ -798,6 +862,15 @@ def main():
         print(json.dumps(line))
     else:
         shard.free()
+        if world > 1 and args.e2e_bases > 0 and not args.no_cpu_baseline:
+            del dna_out, qual_out
+            ctx.close()
+            if qctx is not None:
+                qctx.close()
+            torch.cuda.empty_cache()
+            multi_gpu_cli_leg(rank, world, args, k, a)
+            ctx = Context(local)
+            qctx = Context(local) if qctx is not None else None
     ctx.close()
     if qctx is not None:
         qctx.close()

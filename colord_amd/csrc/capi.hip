@@ -48,6 +48,30 @@ void cl_ctx_set_priority(cl_ctx* c, int level, int role)
 			s->store(ns);
 		}
 }
+// COLORD_HIP_POOL_POISON (common.hpp)
+namespace { __global__ void k_poison_check(const uint32_t* __restrict__ p, uint64_t n, unsigned long long* __restrict__ bad)
+{
+	uint64_t mine = 0;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) mine += p[i] != 0xCDCDCDCDu;
+	if (mine) atomicAdd(bad, (unsigned long long)mine);
+} }
+void cl_ctx_poison(cl_ctx* c, void* p, uint64_t bytes)
+{
+	if (!c || !c->stream) return;
+	(void)hipSetDevice(c->device);
+	if (hipMemsetAsync(p, 0xCD, bytes, c->stream) != hipSuccess) (void)hipGetLastError();
+}
+uint64_t cl_pool_poison_check(void* p, uint64_t bytes)
+{
+	static unsigned long long* d_bad = nullptr;
+	if (!d_bad && hipMalloc((void**)&d_bad, 8) != hipSuccess) { (void)hipGetLastError(); return 0; }
+	(void)hipDeviceSynchronize();                                               // (the pattern's memset may still be queued on its owner's stream)
+	(void)hipMemset(d_bad, 0, 8);
+	hipLaunchKernelGGL(k_poison_check, dim3(1024), dim3(256), 0, nullptr, (const uint32_t*)p, bytes / 4, d_bad);
+	unsigned long long h = 0;
+	(void)hipMemcpy(&h, d_bad, 8, hipMemcpyDeviceToHost);
+	return h;
+}
 // every stream of the context (the shared pool calls this before it hands memory the context released to another one)
 void cl_ctx_drain(cl_ctx* c)
 {

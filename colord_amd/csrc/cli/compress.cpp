@@ -66,7 +66,7 @@ struct Options {
 	double cost_mult = 1.0, frac_min = 0.5, frac_always = 0.9, max_matches_mult = 10.0, g = -1, exponent = 1.0;
 	int qual_mode = -1, header_mode = 0, ref_mode = -1;
 	std::vector<uint32_t> T, D; bool has_T = false, has_D = false;
-	double chunk_bases = 1.0e9;
+	double chunk_bases = 1.0e9; bool chunk_bases_set = false;
 	uint64_t part_symbols = 2u << 21;               // --part-symbols: the coder parts close once their reads (+ 1 guard each) reach this; default = the reader packs (defs.h:45)
 	int parse_threads = 0;                          // --parse-threads (0: as many as the host offers, at most 32)
 	bool stream_input = false;                      // --stream-input: the input is read three times (k-mers, reference reads, coding) and only a window of chunks is resident in HBM
@@ -644,35 +644,58 @@ static int run_compress_multi(const Options& O, const Preset& P, const QDef& qd,
 			return r;
 		};
 		if (with_genome) { cl_reads* gr = upload(G); ck(ctx, cl_compressor_genome_add(cmp, gr), "reference genome k-mers"); cl_reads_free(gr); }
-		// chunks of whole reader packs (the packs are cut from this rank's first read on: in_reads.cpp:62-77)
-		std::vector<DevChunk> chunks; Chunk host;
+		// chunks of whole reader packs (the packs are cut from this rank's first read on: in_reads.cpp:62-77).  The chunk size follows the
+		// rank's share unless --chunk-bases says otherwise: at least 12 chunks a rank, so that the look-ahead pipeline of the compressor (encode
+		// lanes, preparation threads: three to five chunks deep) fills — 8 ranks on 5 Gbases would otherwise get one chunk each.
+		const uint64_t rank_chunk = O.chunk_bases_set ? (uint64_t)O.chunk_bases : std::min<uint64_t>((uint64_t)O.chunk_bases, std::max<uint64_t>(my_bases / 12, 32ull << 20));
+		std::vector<DevChunk> chunks; std::vector<uint64_t> cut;                 // cut[ci] .. cut[ci + 1]: the reads of chunk ci
+		Chunk host;
 		Reader B; B.part_symbols = O.part_symbols;                            // (its pack / part bookkeeping only)
+		// the reads [c0, c1) into the host buffer (offsets, bases, qualities)
+		auto fill = [&](uint64_t c0, uint64_t c1) {
+			if (host.off.size() != c1 - c0 + 1) { host.clear(); for (uint64_t x = c0; x < c1; ++x) { host.n += S.len(x); host.off.push_back(host.n); } }
+			{ const uint64_t tot = host.n; host.n = 0; host.reserve(tot + 1, with_qual); host.n = tot; }
+			for (uint64_t x = c0; x < c1; ++x) { memcpy(host.bases + host.off[x - c0], S.seq(x), S.len(x)); if (with_qual) memcpy(host.quals + host.off[x - c0], S.qual(x), S.len(x)); }
+		};
+		auto upload_chunk = [&](DevChunk& dc) {
+			uint8_t* d_bases = nullptr;
+			hipck(hipMalloc((void**)&d_bases, host.n + 1), "hipMalloc"); hipck(hipMalloc((void**)&dc.d_off, host.off.size() * 8), "hipMalloc");
+			hipck(hipMemcpy(d_bases, host.bases, host.n, hipMemcpyHostToDevice), "hipMemcpy");
+			hipck(hipMemcpy(dc.d_off, host.off.data(), host.off.size() * 8, hipMemcpyHostToDevice), "hipMemcpy");
+			if (with_qual) { hipck(hipMalloc((void**)&dc.d_quals, host.n + 1), "hipMalloc (the input does not fit this GPU's memory: --stream-input keeps only a window of it resident)"); hipck(hipMemcpy(dc.d_quals, host.quals, host.n, hipMemcpyHostToDevice), "hipMemcpy"); }
+			ck(ctx, cl_reads_pack(ctx, d_bases, dc.d_off, dc.n_reads, 1, &dc.reads), "input");
+			hipck(hipFree(d_bases), "hipFree");
+		};
+		auto free_chunk = [&](DevChunk& dc) {
+			if (dc.reads) cl_reads_free(dc.reads);
+			if (dc.d_quals) (void)hipFree(dc.d_quals);
+			if (dc.d_off) (void)hipFree(dc.d_off);
+			dc.reads = nullptr; dc.d_quals = nullptr; dc.d_off = nullptr;
+		};
 		for (uint64_t i = r0; i < r1; )
 		{
 			host.clear();
-			auto full = [&]() { return host.n >= (uint64_t)O.chunk_bases && host.pack_acc == 0 && host.off.size() > 1; };
+			auto full = [&]() { return host.n >= rank_chunk && host.pack_acc == 0 && host.off.size() > 1; };
 			const uint64_t c0 = i;
 			while (i < r1 && !full()) { const uint32_t L = S.len(i); host.n += L; host.off.push_back(host.n); B.close_bounds(host, L); ++i; }
 			B.finish_bounds(host);
-			{ const uint64_t tot = host.n; host.n = 0; host.reserve(tot + 1, with_qual); host.n = tot; }
-			for (uint64_t x = c0; x < i; ++x) { memcpy(host.bases + host.off[x - c0], S.seq(x), S.len(x)); if (with_qual) memcpy(host.quals + host.off[x - c0], S.qual(x), S.len(x)); }
+			fill(c0, i);
 			DevChunk dc; dc.n_reads = (uint32_t)(host.off.size() - 1); dc.n_bases = host.n; dc.packs = host.packs; dc.parts = host.parts;
 			if (with_qual)
 			{
 				uint8_t lo = 255, hi8 = 0; for (uint64_t x = 0; x < host.n; ++x) { lo = host.quals[x] < lo ? host.quals[x] : lo; hi8 = host.quals[x] > hi8 ? host.quals[x] : hi8; }
 				if (host.n && (lo < 33 || hi8 > 33 + 95)) die("quality values outside '!'..'~'+1 (Phred+33, 0..95) are not supported");
 			}
-			uint8_t* d_bases = nullptr;
-			hipck(hipMalloc((void**)&d_bases, host.n + 1), "hipMalloc"); hipck(hipMalloc((void**)&dc.d_off, host.off.size() * 8), "hipMalloc");
-			hipck(hipMemcpy(d_bases, host.bases, host.n, hipMemcpyHostToDevice), "hipMemcpy");
-			hipck(hipMemcpy(dc.d_off, host.off.data(), host.off.size() * 8, hipMemcpyHostToDevice), "hipMemcpy");
-			if (with_qual) { hipck(hipMalloc((void**)&dc.d_quals, host.n + 1), "hipMalloc (the input does not fit this GPU's memory)"); hipck(hipMemcpy(dc.d_quals, host.quals, host.n, hipMemcpyHostToDevice), "hipMemcpy"); }
-			ck(ctx, cl_reads_pack(ctx, d_bases, dc.d_off, dc.n_reads, 1, &dc.reads), "input");
-			hipck(hipFree(d_bases), "hipFree");
+			upload_chunk(dc);
 			ck(ctx, cl_compressor_count_add(cmp, dc.reads), "pass 1");
+			if (O.stream_input) free_chunk(dc);                                 // (--stream-input: a chunk leaves HBM after each pass, as in the single-GPU path)
+			cut.push_back(c0);
 			chunks.push_back(std::move(dc));
 		}
-		host.release();
+		cut.push_back(r1);
+		// a chunk of an earlier pass again (--stream-input): the same reads, from the source this process holds
+		auto reload = [&](size_t ci) { host.clear(); fill(cut[ci], cut[ci + 1]); upload_chunk(chunks[ci]); };
+		if (!O.stream_input) host.release();
 		ck(ctx, cl_compressor_count_finish(cmp, &RO.ks), "k-mer counting (exchange 1)");
 		if (with_genome)
 		{	// pseudo reads of 20 x the mean read length (of ALL reads: the same on every rank), made once
@@ -694,16 +717,34 @@ static int run_compress_multi(const Options& O, const Preset& P, const QDef& qd,
 			ck(ctx, cl_compressor_pseudo_reads(cmp, pr), "reference genome pseudo reads");
 			cl_reads_free(pr);
 		}
-		for (auto& dc : chunks) ck(ctx, cl_compressor_refs_add(cmp, dc.reads), "reference reads");
+		for (size_t ci = 0; ci < chunks.size(); ++ci)
+		{
+			if (O.stream_input) reload(ci);
+			ck(ctx, cl_compressor_refs_add(cmp, chunks[ci].reads), "reference reads");
+			if (O.stream_input) free_chunk(chunks[ci]);
+		}
 		ck(ctx, cl_compressor_refs_finish(cmp), "reference index (exchange 2)");
 		ck(ctx, cl_compressor_info(cmp, nullptr, nullptr, nullptr, &RO.mean_read_len, &RO.sparse_range, &RO.n_refs), "cl_compressor_info");
 		uint64_t max_bases = 0, max_parts = 0; for (auto& dc : chunks) { max_bases = std::max(max_bases, dc.n_bases); max_parts = std::max<uint64_t>(max_parts, dc.parts.size()); }
 		const uint64_t dna_cap = max_bases + 64 * max_parts + 4096, qual_cap = (uint64_t)(max_bases * 1.35) + 64 * max_parts + 4096;
 		uint8_t* d_dna = nullptr; uint8_t* d_qual = nullptr;
 		hipck(hipMalloc((void**)&d_dna, dna_cap), "hipMalloc"); if (with_qual) hipck(hipMalloc((void**)&d_qual, qual_cap), "hipMalloc");
-		for (auto& dc : chunks) ck(ctx, cl_compressor_prepare_parts(cmp, dc.reads, dc.packs.data(), (uint32_t)dc.packs.size() - 1, dc.parts.data(), (uint32_t)dc.parts.size() - 1, dc.d_quals, dc.d_off), "look-ahead");
-		for (auto& dc : chunks)
+		// the chunks are announced a window ahead of the one being coded (look-ahead of the compressor: encode lanes, preparation threads);
+		// --stream-input: they are uploaded again as they are announced and freed as they are coded, so at most window + 1 are resident
+		size_t ann_window = 4;
+		if (const char* e = getenv("COLORD_HIP_ANNOUNCE_WINDOW")) ann_window = (size_t)std::max(0, atoi(e));
+		if (O.stream_input && !ann_window) ann_window = 4;
+		size_t announced = 0;
+		for (size_t ci = 0; ci < chunks.size(); ++ci)
 		{
+			DevChunk& dc = chunks[ci];
+			const size_t have = ann_window ? std::min(chunks.size(), ci + 1 + ann_window) : chunks.size();
+			for (; announced < have; ++announced)
+			{
+				DevChunk& x = chunks[announced];
+				if (O.stream_input) reload(announced);
+				ck(ctx, cl_compressor_prepare_parts(cmp, x.reads, x.packs.data(), (uint32_t)x.packs.size() - 1, x.parts.data(), (uint32_t)x.parts.size() - 1, x.d_quals, x.d_off), "look-ahead");
+			}
 			const uint32_t np = (uint32_t)dc.parts.size() - 1;
 			std::vector<uint64_t> dsz(np), qsz(np); cl_compress_info info{};
 			ck(ctx, cl_compressor_encode(cmp, dc.reads, dc.d_quals, dc.d_off, dc.parts.data(), np, dc.packs.data(), (uint32_t)dc.packs.size() - 1, d_dna, dna_cap, dsz.data(), d_qual, qual_cap, qsz.data(), &info), "pass 2");
@@ -714,8 +755,9 @@ static int run_compress_multi(const Options& O, const Preset& P, const QDef& qd,
 			RO.dsz.insert(RO.dsz.end(), dsz.begin(), dsz.end()); if (with_qual) RO.qsz.insert(RO.qsz.end(), qsz.begin(), qsz.end());
 			for (uint32_t p = 0; p < np; ++p) RO.counts.push_back(dc.parts[p + 1] - dc.parts[p]);
 			RO.n_reads += dc.n_reads; RO.n_bases += dc.n_bases;
-			cl_reads_free(dc.reads); dc.reads = nullptr; if (dc.d_quals) (void)hipFree(dc.d_quals); (void)hipFree(dc.d_off);
+			free_chunk(dc);
 		}
+		host.release();
 		RO.n_chunks = chunks.size();
 		(void)hipFree(d_dna); if (d_qual) (void)hipFree(d_qual);
 		// where this rank's parts go: an all-gather of the framed byte counts, an exclusive sum, pwrite — `dna` of all ranks first, then `qual`
@@ -913,7 +955,7 @@ int run_compress(int argc, char** argv)
 		else if (a == "--domains") { O.domains = atoi(need(i).c_str()); if (O.domains < 1 || O.domains > 1024) die("--domains must be in [1, 1024]"); }
 		else if (a == "--gpu-list") { for (uint32_t v : list_u32(need(i))) O.gpu_list.push_back((int)v); }
 		else if (a == "--transport") { O.transport = need(i); if (O.transport != "rccl" && O.transport != "host") die("--transport must be rccl or host"); }
-		else if (a == "--chunk-bases") O.chunk_bases = atof(need(i).c_str());
+		else if (a == "--chunk-bases") { O.chunk_bases = atof(need(i).c_str()); O.chunk_bases_set = true; }
 		else if (a == "--part-symbols") { O.part_symbols = strtoull(need(i).c_str(), nullptr, 10); if (O.part_symbols < 1024 || O.part_symbols > (2u << 21)) die("--part-symbols must be in [1024, 4194304]"); }
 		else if (a == "--stream-input") O.stream_input = true;
 		else if (a == "--parse-threads") { O.parse_threads = atoi(need(i).c_str()); if (O.parse_threads < 1 || O.parse_threads > 256) die("--parse-threads must be in [1, 256]"); }
@@ -947,7 +989,7 @@ int run_compress(int argc, char** argv)
 	for (size_t i = 0; i < qd.fwd.size(); ++i) if (qd.fwd[i] > 95 || (i && qd.fwd[i] < qd.fwd[i - 1])) die("quality thresholds must be ascending values in [0, 95]");
 	if (!O.gpu_list.empty() && O.gpus == 1) O.gpus = (int)O.gpu_list.size();
 	if (O.domains > 1 && O.gpus > 1) die("--domains and --gpus exclude each other (every GPU is a model domain already)");
-	if (O.stream_input && (O.gpus > 1 || O.domains > 1)) die("--stream-input is not available with --gpus / --domains");
+	if (O.stream_input && O.domains > 1) die("--stream-input is not available with --domains");
 	if (O.gpus > 1 || O.domains > 1) return run_compress_multi(O, P, qd, argc, argv);
 
 	const auto t0 = std::chrono::steady_clock::now();

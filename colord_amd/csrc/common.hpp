@@ -41,11 +41,18 @@ struct cl_ctx;
 void cl_ctx_drain(cl_ctx* c);                  // capi.hip: waits for every stream of the context
 void cl_ctx_set_priority(cl_ctx* c, int level, int role = -1); // capi.hip: +1 highest, -1 lowest, 0 default stream priority of the context; role: CL_ROLE_* (-1: unchanged)
 int cl_ctx_fence(cl_ctx* c, hipEvent_t* ev);   // capi.hip: records an event on every stream of the context; returns their number (<= 4)
+// COLORD_HIP_POOL_POISON=1 (debugging the hand-over of memory between contexts): every block is filled with a pattern on the releasing
+// context's main stream when it goes back to the pool, and checked when it is carved for ANOTHER context (after the owner's fence says
+// so): a broken pattern = somebody wrote into the block after its release.  The other direction shows by itself: whoever still READS a
+// block it released (a side stream that was not joined) now reads the pattern, and the byte comparisons of the suite fail.
+void cl_ctx_poison(cl_ctx* c, void* p, uint64_t bytes);       // capi.hip: hipMemsetAsync on the context's main stream
+uint64_t cl_pool_poison_check(void* p, uint64_t bytes);      // capi.hip: waits for the device, returns the number of 4-byte words that lost the pattern
+static inline bool cl_pool_poison() { static const bool on = getenv("COLORD_HIP_POOL_POISON") != nullptr; return on; }
 struct DevPool {
 	// A free extent remembers who released it and when (pool clock).  Its owner may have it back at once — a context's own reuse
 	// is ordered by its streams, as with a pool per context; anybody else only once the owner's streams have drained since
 	// (`drained`): kernels of the owner may still be reading a block it released early.
-	struct Ext { uint64_t len; int32_t owner; uint64_t clock; };
+	struct Ext { uint64_t len; int32_t owner; uint64_t clock; bool poisoned = false; };   // poisoned: the whole extent holds the pattern (COLORD_HIP_POOL_POISON)
 	struct Slab { char* base = nullptr; uint64_t size = 0, free_bytes = 0; std::map<uint64_t, Ext> ext; };   // ext: offset -> free extent
 	std::mutex mu;                                // a buffer made on one thread (an encode lane of cl_compressor) may be released on another
 	std::vector<Slab> slabs;
@@ -56,6 +63,7 @@ struct DevPool {
 	struct Fence { uint64_t clock; hipEvent_t ev[4]; int n; };
 	std::vector<std::deque<Fence>> fences; std::vector<uint32_t> since_fence; std::vector<hipEvent_t> spare_events;
 	uint64_t reserved = 0, live_bytes = 0, peak_live = 0, peak_total = 0; uint32_t n_mallocs = 0, n_drains = 0;   // (statistics for COLORD_HIP_POOL_DEBUG)
+	uint64_t n_poison_checks = 0, n_poison_bad = 0;                                                                  // (COLORD_HIP_POOL_POISON)
 	static constexpr uint64_t ALIGN = 256, PAD = 256, SLAB_MIN = 256ull << 20, SLAB_MAX = 4ull << 30;
 	int32_t add_owner(cl_ctx* c) { std::lock_guard<std::mutex> l(mu); owners.push_back(c); drained.push_back(0); fences.emplace_back(); since_fence.push_back(0); pinned.push_back(0); return (int32_t)owners.size() - 1; }
 	void drop_owner(int32_t id)
@@ -118,6 +126,7 @@ struct DevPool {
 				if (it->first + it->second.len == nx->first && (it->second.owner == nx->second.owner || (clean(it->second) && clean(nx->second))))
 				{
 					if (it->second.owner != nx->second.owner) { it->second.owner = -1; it->second.clock = 0; } else it->second.clock = std::max(it->second.clock, nx->second.clock);
+					it->second.poisoned = it->second.poisoned && nx->second.poisoned;
 					it->second.len += nx->second.len; S.ext.erase(nx);
 				}
 				else it = nx;
@@ -155,9 +164,15 @@ struct DevPool {
 		Slab& S = slabs[bs];
 		const Ext old = S.ext[boff];
 		S.ext.erase(boff);
-		if (blen > r) S.ext.emplace(boff + r, Ext{ blen - r, old.owner, old.clock });
+		if (blen > r) S.ext.emplace(boff + r, Ext{ blen - r, old.owner, old.clock, old.poisoned });
 		S.free_bytes -= r;
 		*out = S.base + boff;
+		if (old.poisoned && old.owner != who && cl_pool_poison())
+		{	// handed to another context: the pattern must have survived since the release
+			const uint64_t bad = cl_pool_poison_check(*out, r);
+			++n_poison_checks;
+			if (bad) { ++n_poison_bad; fprintf(stderr, "colord_hip: POOL POISON: a block of %llu bytes released by context %d (clock %llu) was written to after its release: %llu words differ; now handed to context %d\n", (unsigned long long)r, old.owner, (unsigned long long)old.clock, (unsigned long long)bad, who); }
+		}
 		return true;
 	}
 	hipError_t get(uint64_t bytes, void** out, uint64_t* got, int32_t who)
@@ -250,9 +265,10 @@ struct DevPool {
 			if ((char*)p < S.base || (char*)p >= S.base + S.size) continue;
 			uint64_t off = (uint64_t)((char*)p - S.base);
 			Ext me{ r, who, ++clock };
+			if (cl_pool_poison() && who >= 0 && owners[who]) { cl_ctx_poison(owners[who], p, r); me.poisoned = true; }
 			auto nx = S.ext.lower_bound(off);
-			if (nx != S.ext.begin()) { auto pv = std::prev(nx); if (pv->first + pv->second.len == off && pv->second.owner == who) { off = pv->first; me.len += pv->second.len; S.ext.erase(pv); } }
-			if (nx != S.ext.end() && off + me.len == nx->first && nx->second.owner == who) { me.len += nx->second.len; S.ext.erase(nx); }
+			if (nx != S.ext.begin()) { auto pv = std::prev(nx); if (pv->first + pv->second.len == off && pv->second.owner == who) { off = pv->first; me.len += pv->second.len; me.poisoned = me.poisoned && pv->second.poisoned; S.ext.erase(pv); } }
+			if (nx != S.ext.end() && off + me.len == nx->first && nx->second.owner == who) { me.len += nx->second.len; me.poisoned = me.poisoned && nx->second.poisoned; S.ext.erase(nx); }
 			S.ext.emplace(off, me);
 			S.free_bytes += r; live_bytes -= r;
 			if (who >= 0 && owners[who] && (++since_fence[who] >= 8 || r >= (64ull << 20)))
@@ -276,6 +292,7 @@ struct DevPool {
 	void trim()
 	{
 		std::lock_guard<std::mutex> lock(mu);
+		if (cl_pool_poison()) fprintf(stderr, "[pool poison] %llu blocks checked at their hand-over to another context, %llu had lost the pattern\n", (unsigned long long)n_poison_checks, (unsigned long long)n_poison_bad);
 		if (getenv("COLORD_HIP_POOL_DEBUG")) fprintf(stderr, "[pool] at trim: peak live %.1f GB, peak reserved %.1f GB, reserved %.1f GB in %zu slabs, %u hipMalloc calls, %u waits for another context's streams, still live %.3f GB\n", peak_live / 1e9, peak_total / 1e9, reserved / 1e9, slabs.size(), n_mallocs, n_drains, live_bytes / 1e9);
 		for (auto& S : slabs) (void)hipFree(S.base);
 		slabs.clear(); reserved = 0;

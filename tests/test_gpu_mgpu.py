@@ -231,3 +231,52 @@ def test_cpp_host_reference_genome_mode_with_sharded_reads(tmp_path, stored):
             assert [(m, hashlib.sha256(p).hexdigest()) for m, p in a[s].parts] == [(m, hashlib.sha256(p).hexdigest()) for m, p in b[s].parts], s
     subprocess.check_call([CLI, "decompress"] + ([] if stored else ["-G", gen]) + [cpp_arc, out])
     assert sha(out) == exp["decompressed_sha256"]
+
+
+REF = os.path.join(ROOT, "oracle", "_ref", "colord")
+
+
+@pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(CLI)), reason="needs oracle/_ref/colord and colord_amd/colord_hip")
+def test_cpp_host_eight_ranks_400_mbases(tmp_path):
+    """BASELINE.json's configuration 5 is an EIGHT-way split: `colord_hip --gpus 8 --gpu-list 0,0,0,0,0,0,0,0 --transport host` (eight rank
+    threads on this box's one GPU, each a compressor with lanes and preparation threads of its own over the one shared pool) on 400 Mbases
+    of the bench's recipe.  The archive has eight model domains, decodes to what the unmodified reference returns for its own archive of
+    the same file (4-avg qualities are quantised per read), and stays within 1 % of the one-rank archive — the metric's size budget.
+    Then the same with --stream-input (bounded device memory under --gpus N: chunks are uploaded again for each pass): the same archive."""
+    t = ontsim.ReadTable(seed=13, genome_len=24_000_000, target_bases=400_000_000)
+    fq, ref_arc, ref_out, one, eight, out, eight_s = (str(tmp_path / x) for x in ("in.fastq", "ref.colord", "ref.fastq", "one.colord", "eight.colord", "eight.fastq", "eight_stream.colord"))
+    ontsim.write_fastq(t, fq)
+    subprocess.check_call([REF, "compress-ont", "-t", str(min(64, os.cpu_count() or 8)), fq, ref_arc], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.check_call([REF, "decompress", ref_arc, ref_out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.check_call([CLI, "compress-ont", fq, one])
+    many = ["--gpus", "8", "--gpu-list", ",".join(["0"] * 8), "--transport", "host"]
+    r = subprocess.run([CLI, "compress-ont"] + many + [fq, eight], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    a = AR.read_archive(eight)
+    dom = a["hipdomains"].parts[0][1]
+    assert int.from_bytes(dom[:4], "little") == 8 and len(dom) == 4 + 8 * 16
+    subprocess.check_call([CLI, "decompress", eight, out])
+    assert sha(out) == sha(ref_out)
+    s1, s8 = os.path.getsize(one), os.path.getsize(eight)
+    print(f"one rank {s1} B, eight ranks {s8} B: {100.0 * (s8 / s1 - 1):+.3f} %; {r.stderr.strip().splitlines()[-1]}")
+    assert s8 <= s1 * 1.01
+    assert sum(m for m, _ in a["dna"].parts) == t.n_reads
+    r = subprocess.run([CLI, "compress-ont", "--stream-input"] + many + [fq, eight_s], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    b = AR.read_archive(eight_s)
+    assert set(a) == set(b)
+    for s in a:
+        if s != "info":
+            assert [(m, hashlib.sha256(p).hexdigest()) for m, p in a[s].parts] == [(m, hashlib.sha256(p).hexdigest()) for m, p in b[s].parts], s
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` from a plain python command (the shape of the driver's N = 1 command): bench.py starts its ranks itself —
+    here two ranks sharing this box's GPU over gloo — and rank 0 prints the one JSON line with n_gpus = 2."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BENCH_BACKEND="gloo", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--bases", "2e8", "--chunk-bases", "5e7", "--e2e-bases", "1e8"],
+                       capture_output=True, text=True, env=env, cwd=str(tmp_path), timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["parts_digest_stable"]
+    assert line["config"]["parallelism"].startswith("reads sharded x2")
