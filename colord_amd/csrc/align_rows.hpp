@@ -76,11 +76,7 @@ __device__ inline void row_stage(const Row& r, bool act, const enc::GapRec& g, c
 //     column j only if it holds a row within `band` of j.  `band` is an assumption (a quarter of the gap's length: 99.3 % of the class, the
 //     rest are unrelated sequences at d > len / 2); the caller checks d <= band after the sweep and hands the gap to the wave kernel
 //     otherwise — the sweep itself is exact either way, only what it keeps is limited.
-__device__ inline uint64_t sel64(uint32_t mask, uint64_t a, uint64_t b)       // mask all ones: a, zero: b
-{
-	const uint32_t lo = ((uint32_t)a & mask) | ((uint32_t)b & ~mask), hi = ((uint32_t)(a >> 32) & mask) | ((uint32_t)(b >> 32) & ~mask);
-	return ((uint64_t)hi << 32) | lo;
-}
+using enc::sel64;
 __device__ inline uint32_t hist_stride(uint32_t m) { return (m + 15) & ~15u; }
 __device__ inline wv::Sweep row_sweep(const Row& r, ulonglong2* __restrict__ hist, uint32_t band)
 {

@@ -144,6 +144,11 @@ CL_DEV inline bool gap_geometry(const FrameRec& F, const CandEnt& M, const uint3
 
 CL_DEV inline char mismatch_sym(uint32_t ref, uint32_t nw) { return (char)('X' + (nw - (nw > ref ? 1u : 0u))); }    // utils.h:341-352
 CL_DEV inline bool is_mismatch(char c) { return c == 'X' || c == 'Y' || c == 'Z'; }
+CL_DEV inline uint64_t sel64(uint32_t mask, uint64_t a, uint64_t b)           // mask all ones: a, zero: b (v_bfi_b32 on both halves)
+{
+	const uint32_t lo = ((uint32_t)a & mask) | ((uint32_t)b & ~mask), hi = ((uint32_t)(a >> 32) & mask) | ((uint32_t)(b >> 32) & ~mask);
+	return ((uint64_t)hi << 32) | lo;
+}
 CL_DEV inline char base_letter(uint32_t b) { return b == 0 ? 'A' : b == 1 ? 'C' : b == 2 ? 'G' : 'T'; }
 
 // refactor_edit_script (edit_script.h:416-446,591-671) over accessors: es(k) read, es_set(k, c), ref(x), enc(x)
@@ -246,31 +251,34 @@ CL_DEV inline uint32_t align_small(MEM& mem, uint32_t n, uint32_t m, uint32_t ki
 	const uint32_t lastbit = (n - 1) & 63;
 	uint32_t score = n, best = 0xffffffffu; int32_t end = (int32_t)m - 1;
 	if (shw && (n & 63)) { best = n; end = -1; }
+	// (the column step as one straight line — round 5: the four-way choice of the match mask by bit selects, the horizontal delta as two
+	// bits (1: +1, 2: -1); hipcc made branches of both, four times per column)
+	const uint64_t lastmask = 1ull << lastbit;
 	for (uint32_t j = 0; j < m; ++j)
 	{
 		const uint32_t c = mem.t(j);
-		int hin = 1;
+		const uint32_t M0 = 0u - (c & 1), M1 = 0u - (c >> 1);
+		uint32_t hin = 1;
 #pragma unroll
 		for (int b = 0; b < NB; ++b)
 		{
-			uint64_t Eq = c == 0 ? peq[0][b] : c == 1 ? peq[1][b] : c == 2 ? peq[2][b] : peq[3][b];
-			const uint64_t hneg = hin < 0 ? 1ull : 0ull;
+			uint64_t Eq = sel64(M1, sel64(M0, peq[3][b], peq[2][b]), sel64(M0, peq[1][b], peq[0][b]));
+			const uint64_t hneg = hin >> 1, hpos = hin & 1;
 			const uint64_t Xv = Eq | Mv[b];
 			Eq |= hneg;
 			const uint64_t Xh = (((Eq & Pv[b]) + Pv[b]) ^ Pv[b]) | Eq;
 			uint64_t Ph = Mv[b] | ~(Xh | Pv[b]);
 			uint64_t Mh = Pv[b] & Xh;
-			if (b == NB - 1) score += (uint32_t)((Ph >> lastbit) & 1) - (uint32_t)((Mh >> lastbit) & 1);
+			if (b == NB - 1) score += (uint32_t)((Ph & lastmask) != 0) - (uint32_t)((Mh & lastmask) != 0);
 			const uint64_t ph_rows = Ph;
-			const int hout = (int)(Ph >> 63) - (int)(Mh >> 63);
-			Ph <<= 1; Mh <<= 1;
-			Mh |= hneg; Ph |= hin > 0 ? 1ull : 0ull;
+			hin = (uint32_t)(Ph >> 63) | ((uint32_t)(Mh >> 63) << 1);
+			Ph = (Ph << 1) | hpos; Mh = (Mh << 1) | hneg;
 			Pv[b] = Mh | ~(Xv | Ph);
 			Mv[b] = Ph & Xv;
 			mem.hist_put(j, b, Pv[b], ph_rows);
-			hin = hout;
 		}
-		if (shw && score < best) { best = score; end = (int32_t)j; }
+		const bool better = shw && score < best;
+		best = better ? score : best; end = better ? (int32_t)j : end;
 	}
 	// traceback from (n, jend)
 	uint32_t i = n, j = shw ? (uint32_t)(end + 1) : m, k = 0;

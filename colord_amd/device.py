@@ -43,6 +43,34 @@ def _hip():
     return _HIP
 
 
+class _OrderedLib:
+    """The C ABI as this binding calls it: every entry point first waits for torch's current stream on the device.  The library works
+    on streams of its own (non-blocking: nothing orders them after torch's), so a tensor torch is still computing — offsets rebased by a
+    subtraction, a slice made contiguous — could be read by the library before it was written.  That was the one unexplained failure of
+    round 4 (`cl_reads_pack: offsets not monotone` once in seven runs of test_chunked_equals_one_call_200_mbases; reproduced at will under
+    COLORD_HIP_SYNC_DEBUG, which shifts the timing): a race of the HARNESS, not of the library's pool.  Waiting on an idle stream costs
+    microseconds; a host that embeds the library orders its own streams."""
+    _HOST_ONLY = ("cl_last_error", "cl_ctx_kernel_times", "cl_ctx_last_kernel_ms", "cl_ctx_set_timing", "cl_ref_accept")
+
+    def __init__(self, lib, device):
+        self._lib, self._device, self._cache = lib, device, {}
+
+    def __getattr__(self, name):
+        f = self._cache.get(name)
+        if f is None:
+            raw = getattr(self._lib, name)
+            if not name.startswith("cl_") or name in self._HOST_ONLY or name.endswith("_free") or name.endswith("_destroy"):
+                f = raw
+            else:
+                dev = self._device
+
+                def f(*a, _raw=raw, _dev=dev):
+                    torch.cuda.current_stream(_dev).synchronize()
+                    return _raw(*a)
+            self._cache[name] = f
+        return f
+
+
 class Context:
     def __init__(self, device: int = 0, timing: bool = False):
         self.lib = N.load()
@@ -53,6 +81,7 @@ class Context:
         if st != N.CL_OK:
             raise N.ColordHipError(st, "cl_ctx_create failed")
         self.device = torch.device("cuda", device)
+        self.lib = _OrderedLib(self.lib, self.device)
         self.timing = timing
         self.acc = {}                  # {kernel: [ms, launches]} accumulated over API calls while timing is on
         if timing:
