@@ -288,238 +288,12 @@ __device__ inline void wave_walk(WavePool& pool, const Hist& h, const uint8_t* q
 	__builtin_amdgcn_s_waitcnt(0);
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 }
-// ---- four gaps per wave ---------------------------------------------------------------------------------------------
-// 90 % of the gaps of this class have 4 - 16 row blocks: in wave_sweep they keep 4 - 16 of the 64 lanes busy, and the class
-// is bound by instruction issue.  quad_sweep runs FOUR such gaps at once, one per 16-lane row of the wave: every argument is
-// uniform within a row and may differ between rows (n = 0: the row has no gap).  Same recurrence, same history layout as
-// wave_sweep with one tile (cell of block b, column j at (j + b) * nb + b), so wave_walk reads it unchanged.  The column
-// symbol and the horizontal delta move down a row with DPP row shifts; the symbols of the next 16 columns sit one per lane
-// and rotate towards lane 0 of the row.  n <= 1024 (16 blocks), history always kept (the caller made sure it fits).
+// ---- 16-lane rows (align_rows.hpp: four gaps per wave, one per row) ----------------------------------------------------------------------
+// DPP moves inside a row: lane l of a row receives lane l - 1's value (row_shr:1; the row's lane 0 keeps 0), or the value of the next lane
+// round the row (row_ror:15).
 __device__ inline uint32_t row_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); }
 __device__ inline int row_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false); }
 __device__ inline uint32_t row_rol1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x12f, 0xf, 0xf, false); }     // row_ror:15
-__device__ inline Sweep quad_sweep(const uint8_t* q, uint32_t n, const uint8_t* t, uint32_t m, bool shw, uint64_t* histP, uint64_t* histH)
-{
-	const uint32_t lane = lane_id(), bl = lane & 15, row0 = lane & 48;
-	const uint32_t nb = (n + 63) / 64;
-	const bool act = bl < nb;
-	uint64_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
-	if (act)
-	{
-		const uint32_t lo = bl * 64, hi = n < lo + 64 ? n : lo + 64;
-		for (uint32_t i = lo; i < hi; ++i)
-		{
-			const uint32_t s = q[i] & 3; const uint64_t bit = 1ull << (i - lo);
-			e0 |= s == 0 ? bit : 0; e1 |= s == 1 ? bit : 0; e2 |= s == 2 ? bit : 0; e3 |= s == 3 ? bit : 0;
-		}
-	}
-	uint64_t Pv = ~0ull, Mv = 0;
-	const bool owner = act && bl == nb - 1;
-	const uint32_t lastbit = (n - 1) & 63;
-	uint32_t sc = n, best = 0xffffffffu; int32_t end = (int32_t)m - 1;
-	if (shw && (n & 63)) { best = n; end = -1; }
-	const uint32_t steps = nb ? m + nb - 1 : 0;
-	uint32_t steps_max = bcast(steps, 0u);
-	{ const uint32_t a = bcast(steps, 16u), b = bcast(steps, 32u), c3 = bcast(steps, 48u); steps_max = steps_max > a ? steps_max : a; steps_max = steps_max > b ? steps_max : b; steps_max = steps_max > c3 ? steps_max : c3; }
-	uint32_t c = 0, tchunk = 0; int hout = 0;
-	for (uint32_t s = 0; s < steps_max; ++s)
-	{
-		if ((s & 15) == 0) { const uint32_t j0 = s + bl; tchunk = (nb && j0 < m) ? (uint32_t)(t[j0] & 3) : 0u; }
-		else tchunk = row_rol1(tchunk);
-		const uint32_t c_up = row_shr1(c); const int h_up = row_shr1(hout);
-		c = bl == 0 ? tchunk : c_up;
-		const int hin = bl == 0 ? 1 : h_up;
-		const bool valid = act && s >= bl && s - bl < m;
-		hout = 0;
-		if (valid)
-		{
-			uint64_t Eq = c == 0 ? e0 : c == 1 ? e1 : c == 2 ? e2 : e3;
-			const uint64_t hneg = hin < 0 ? 1ull : 0ull;
-			const uint64_t Xv = Eq | Mv;
-			Eq |= hneg;
-			const uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
-			uint64_t Ph = Mv | ~(Xh | Pv);
-			uint64_t Mh = Pv & Xh;
-			const uint64_t ph_rows = Ph;
-			if (owner)
-			{
-				sc += (uint32_t)((Ph >> lastbit) & 1) - (uint32_t)((Mh >> lastbit) & 1);
-				if (shw && sc < best) { best = sc; end = (int32_t)(s - bl); }
-			}
-			hout = (int)(Ph >> 63) - (int)(Mh >> 63);
-			Ph <<= 1; Mh <<= 1;
-			Mh |= hneg; Ph |= hin > 0 ? 1ull : 0ull;
-			Pv = Mh | ~(Xv | Ph);
-			Mv = Ph & Xv;
-			const uint64_t idx = (uint64_t)s * nb + bl;
-			histP[idx] = Pv; histH[idx] = ph_rows;
-		}
-	}
-	Sweep out;
-	const int own = (int)(row0 + (nb ? nb - 1 : 0));
-	out.score = (uint32_t)__shfl((int)sc, own); out.best = (uint32_t)__shfl((int)best, own); out.end = __shfl(end, own);
-	__builtin_amdgcn_s_waitcnt(0);
-	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-	return out;
-}
-
-// ---- four gaps per wave WITHOUT a history in memory (round 4) ------------------------------------------------------------------------
-// quad_sweep wrote two words per block and column to HBM and the traceback read them back: 15.6 GB per launch for 0.14 GB of sequences and
-// scripts (109 x), one gap walked at a time through dependent global round trips.  Here the sweep keeps a CHECKPOINT (the vertical deltas
-// Pv, Mv of every block) every QWC columns — 1 / QWC of the history — and the traceback RECOMPUTES the window of QWC columns it stands in
-// into LDS, right to left, all four gaps of the quad in lock step: every 16-lane row sweeps its own gap's window (same recurrence, same
-// words as the history held) and then walks it, a RUN of cells per iteration as wave_walk does — 16 columns at a time, the three cases
-// (up, left, diagonal: edlib.cpp:1021-1147) predicated, row ballots.  Same history, same decisions, same operations.
-constexpr uint32_t QWC = 16;                                                  // columns per window (16 KB of LDS per wave: ten waves per CU)
-struct QuadCk { uint64_t* ck; };                                              // per gap: [m / QWC][nb][2] = (Pv, Mv) after column (c + 1) * QWC - 1
-__device__ inline uint64_t quad_ck_words(uint32_t n, uint32_t m) { return (uint64_t)(m / QWC) * ((n + 63) / 64) * 2; }
-__device__ inline uint32_t row_first(uint32_t v, uint32_t row0) { return (uint32_t)__shfl((int)v, (int)row0); }
-__device__ inline uint64_t row_first(uint64_t v, uint32_t row0) { return ((uint64_t)(uint32_t)__shfl((int)(v >> 32), (int)row0) << 32) | (uint32_t)__shfl((int)(uint32_t)v, (int)row0); }
-// the match masks of this lane's block (q[bl * 64 ...]) — kept in registers for the sweep and every window
-__device__ inline void quad_masks(const uint8_t* q, uint32_t n, uint64_t& e0, uint64_t& e1, uint64_t& e2, uint64_t& e3)
-{
-	const uint32_t bl = lane_id() & 15, nb = (n + 63) / 64;
-	e0 = e1 = e2 = e3 = 0;
-	if (bl < nb)
-	{
-		const uint32_t lo = bl * 64, hi = n < lo + 64 ? n : lo + 64;
-		for (uint32_t i = lo; i < hi; ++i)
-		{
-			const uint32_t s = q[i] & 3; const uint64_t bit = 1ull << (i - lo);
-			e0 |= s == 0 ? bit : 0; e1 |= s == 1 ? bit : 0; e2 |= s == 2 ? bit : 0; e3 |= s == 3 ? bit : 0;
-		}
-	}
-}
-// Columns [c0, c0 + len) of every row's gap from the state (Pv, Mv) before column c0 (len, c0, n, m differ between the rows; len = 0:
-// nothing to do).  WIN: the (vertical +1, horizontal +1) words of every cell go to win[(local column * 16 + block) * 2 ..] (LDS);
-// else a checkpoint is stored after every QWC-th column and the score / end position of the last row are tracked.
-// nb_use (WIN): the blocks a window needs — those down to the row the walk stands in; the path only goes up and left from there.
-template<bool WIN>
-__device__ inline void quad_cols(const uint8_t* t, uint32_t n, uint32_t m, uint32_t c0, uint32_t len, bool shw, uint64_t e0, uint64_t e1, uint64_t e2, uint64_t e3,
-                                 uint64_t& Pv, uint64_t& Mv, uint64_t* win, uint64_t* ck, uint32_t& sc, uint32_t& best, int32_t& end, uint32_t nb_use = 16)
-{
-	const uint32_t lane = lane_id(), bl = lane & 15;
-	const uint32_t nb_all = (n + 63) / 64, nb = WIN ? (nb_all < nb_use ? nb_all : nb_use) : nb_all;
-	const bool act = bl < nb && len > 0;
-	const bool owner = act && bl == nb - 1;
-	const uint32_t lastbit = (n - 1) & 63;
-	const uint32_t steps = (nb && len) ? len + nb - 1 : 0;
-	uint32_t steps_max = bcast(steps, 0u);
-	{ const uint32_t a = bcast(steps, 16u), b = bcast(steps, 32u), c3 = bcast(steps, 48u); steps_max = steps_max > a ? steps_max : a; steps_max = steps_max > b ? steps_max : b; steps_max = steps_max > c3 ? steps_max : c3; }
-	uint32_t c = 0, tchunk = 0; int hout = 0;
-	for (uint32_t s = 0; s < steps_max; ++s)
-	{
-		if ((s & 15) == 0) { const uint32_t j0 = s + bl; tchunk = (nb && j0 < len) ? (uint32_t)(t[c0 + j0] & 3) : 0u; }
-		else tchunk = row_rol1(tchunk);
-		const uint32_t c_up = row_shr1(c); const int h_up = row_shr1(hout);
-		c = bl == 0 ? tchunk : c_up;
-		const int hin = bl == 0 ? 1 : h_up;
-		const bool valid = act && s >= bl && s - bl < len;
-		hout = 0;
-		if (valid)
-		{
-			uint64_t Eq = c == 0 ? e0 : c == 1 ? e1 : c == 2 ? e2 : e3;
-			const uint64_t hneg = hin < 0 ? 1ull : 0ull;
-			const uint64_t Xv = Eq | Mv;
-			Eq |= hneg;
-			const uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
-			uint64_t Ph = Mv | ~(Xh | Pv);
-			uint64_t Mh = Pv & Xh;
-			const uint64_t ph_rows = Ph;
-			const uint32_t lc = s - bl;
-			if (!WIN && owner)
-			{
-				sc += (uint32_t)((Ph >> lastbit) & 1) - (uint32_t)((Mh >> lastbit) & 1);
-				if (shw && sc < best) { best = sc; end = (int32_t)(c0 + lc); }
-			}
-			hout = (int)(Ph >> 63) - (int)(Mh >> 63);
-			Ph <<= 1; Mh <<= 1;
-			Mh |= hneg; Ph |= hin > 0 ? 1ull : 0ull;
-			Pv = Mh | ~(Xv | Ph);
-			Mv = Ph & Xv;
-			if (WIN) { uint64_t* w = win + ((uint64_t)lc * 16 + bl) * 2; w[0] = Pv; w[1] = ph_rows; }
-			else if (((c0 + lc + 1) % QWC) == 0) { uint64_t* k = ck + ((uint64_t)((c0 + lc + 1) / QWC - 1) * nb_all + bl) * 2; k[0] = Pv; k[1] = Mv; }
-		}
-	}
-}
-// The traceback of the four gaps in lock step.  Per row: q / t (bytes), n x m, the walk starts at cell (n, j_start); ck: its
-// checkpoints; rev: where its operations go, LAST operation first (as wave_walk's `rev`); win: QWC * 16 * 2 words of LDS per row.
-// Returns through i_out / j_out / k_out the cell the walk ended in (one of them 0) and the number of operations written.
-__device__ inline void quad_walk(const uint8_t* q, const uint8_t* t, uint32_t n, uint32_t m, uint32_t j_start, const uint64_t* ck, uint8_t* rev,
-                                 uint64_t e0, uint64_t e1, uint64_t e2, uint64_t e3, uint64_t* win_all, uint32_t& i_out, uint32_t& j_out, uint32_t& k_out)
-{
-	const uint32_t lane = lane_id(), d = lane & 15, row0 = lane & 48;
-	uint64_t* const win = win_all + (uint64_t)(row0 >> 4) * (QWC * 16 * 2);
-	const uint32_t nb = (n + 63) / 64;
-	uint32_t i = n, j = n ? j_start : 0, k = 0;
-	uint32_t w0 = 0xffffffffu;                                               // first column of the window in LDS (none yet)
-	for (;;)
-	{
-		// ---- windows: every row whose walk stands left of its window (or has none yet) sweeps the next one
-		const bool act = i > 0 && j > 0;
-		const bool need = act && (w0 == 0xffffffffu || j - 1 < w0);
-		if (!__ballot(act)) break;
-		if (__ballot(need))
-		{
-			const uint32_t nw0 = need ? ((j - 1) / QWC) * QWC : 0, len = need ? (m - nw0 < QWC ? m - nw0 : QWC) : 0;
-			uint64_t Pv = ~0ull, Mv = 0;
-			if (need && nw0 && d < nb) { const uint64_t* c = ck + ((uint64_t)(nw0 / QWC - 1) * nb + d) * 2; Pv = c[0]; Mv = c[1]; }
-			uint32_t sc = 0, best = 0; int32_t end = 0;
-			__builtin_amdgcn_wave_barrier();
-			quad_cols<true>(t, need ? n : 0, m, nw0, len, false, e0, e1, e2, e3, Pv, Mv, win, nullptr, sc, best, end, ((i - 1) >> 6) + 1);
-			__builtin_amdgcn_s_waitcnt(0);
-			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-			if (need) w0 = nw0;
-		}
-		// ---- walk inside the windows until every row is through or at its window's left edge
-		for (;;)
-		{
-			const bool go = i > 0 && j > 0 && j - 1 >= w0;
-			if (!__ballot(go)) break;
-			const uint32_t r = i - 1, b = r >> 6, rb = r & 63;
-			const int32_t jl = (int32_t)j - 1 - (int32_t)d;                         // this lane's column (0-based)
-			const bool col_ok = go && jl >= (int32_t)w0;
-			uint64_t P = 0, H = 0;
-			if (col_ok) { const uint64_t* w = win + ((uint64_t)((uint32_t)jl - w0) * 16 + b) * 2; P = w[0]; H = w[1]; }
-			const uint32_t pr = (uint32_t)(P >> rb) & 1, hr = (uint32_t)(H >> rb) & 1;
-			const uint64_t P0 = row_first(P, row0);
-			const uint32_t p0 = (uint32_t)(P0 >> rb) & 1, h0 = row_first(hr, row0);
-			// (the three cases, each for the rows it applies to)
-			const uint32_t left16 = (uint32_t)((__ballot(col_ok && !pr && hr) >> row0) & 0xffffu);
-			const uint32_t bp = (rb - d) & 63;
-			const bool dg = col_ok && d <= rb && !((P >> bp) & 1) && !((H >> bp) & 1);
-			const uint32_t diag16 = (uint32_t)((__ballot(dg) >> row0) & 0xffffu);
-			uint32_t run = 0; uint8_t op = 0; bool wr = false;
-			if (go)
-			{
-				if (p0)
-				{	// up while the vertical +1 bits of column j continue (inside this block)
-					const uint64_t x = ~P0 << (63 - rb);
-					run = x ? (uint32_t)__builtin_clzll(x) : 64u;
-					if (run > rb + 1) run = rb + 1;
-					for (uint32_t y = d; y < run; y += 16) rev[k + y] = 1;
-					i -= run;
-				}
-				else if (h0)
-				{	// left while row r has no vertical +1 and a horizontal +1
-					run = (uint32_t)__builtin_ctz(~left16 | 0x10000u);
-					op = 2; wr = d < run;
-					j -= run;
-				}
-				else
-				{	// diagonal while neither bit is set at (r - d, j - d); the symbols decide match / mismatch
-					run = (uint32_t)__builtin_ctz(~diag16 | 0x10000u);
-					wr = d < run;
-					if (wr) op = q[r - d] == t[jl] ? 0 : 3;
-					i -= run; j -= run;
-				}
-				if (wr) rev[k + d] = op;
-				k += run;
-			}
-		}
-	}
-	i_out = i; j_out = j; k_out = k;
-}
 
 // edlib keeps the whole history when it fits 1 MiB (edlib.cpp:1176-1183), else it divides (Hirschberg)
 __device__ inline bool wave_direct_fits(uint32_t n, uint32_t m)

@@ -764,7 +764,7 @@ extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* read
 		B.r0 = r0; B.r1 = r1; B.acc = acc; B.pe = bits_for(mx);
 		if (B.pe + pr_bits + bits_for((r1 - r0) * 2 * c) > 64) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_anchor_candidates: a read and its candidates are too long for 64-bit match keys");
 		const uint32_t nb = r1 - r0;
-		static const uint32_t table_x4 = [] { const char* e = getenv("COLORD_HIP_TABLE_X4"); const int v = e ? atoi(e) : 8; return (uint32_t)(v < 5 ? 5 : v > 16 ? 16 : v); }();   // table slots per m-mer, in quarters (8 = load 0.5)
+		const uint32_t table_x4 = 8;                                          // table slots per m-mer, in quarters (8 = load 0.5; denser tables were slower: longer probe chains)
 		DevBuf<uint32_t> tsize, nsize, err; DEV_ALLOC(ctx, tsize, nb); DEV_ALLOC(ctx, nsize, nb); DEV_ALLOC(ctx, err, 1); DEV_ALLOC(ctx, B.n_distinct, nb);
 		HIP_TRY(ctx, hipMemsetAsync(err.p, 0, 4, ctx->stream));
 		LAUNCH(ctx, k_table_sizes, grid_for(nb, 256), 256, (const uint32_t*)reads->lens.p, (const uint8_t*)reads->has_n.p, d_cand_n, r0, r1, m, table_x4, tsize.p, nsize.p, err.p);

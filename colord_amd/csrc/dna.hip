@@ -1069,7 +1069,7 @@ cl_status dna_walk(cl_ctx* ctx, cl_dna_coder* D, const cl_reads* refs, const uin
 		DEV_ALLOC(ctx, key, total_syms);
 		LAUNCHB(ctx, total_syms * 9.0, (k_dna_walk<true>), grid_for(n_chunks, WALK_LPW), 64, /* tuple bytes in (<= 1 per symbol), 8 bytes per symbol out */
 			(const FamTab*)D->d_ft.p, R, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, n_reads,
-			prev_types, cur_read_id, (const uint64_t*)chunk_off.p, cks.p, (uint32_t)n_chunks, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint64_t*)sym_off.p, key.p, err.p, (uint32_t)(getenv("COLORD_HIP_WALK_DIRECT") ? 0 : 1));
+			prev_types, cur_read_id, (const uint64_t*)chunk_off.p, cks.p, (uint32_t)n_chunks, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint64_t*)sym_off.p, key.p, err.p, 1u);
 		LAUNCH(ctx, k_dna_plain, grid_for(n_reads, 4), 256, (const FamTab*)D->d_ft.p, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, (const uint32_t*)hdr.p,
 			(const uint64_t*)sym_off.p, 0u, n_reads, key.p);
 		HIP_TRY(ctx, hipGetLastError());
@@ -1174,6 +1174,20 @@ cl_status cl_dna_prepare_batch(cl_ctx* ctx, cl_dna_coder* D, const cl_reads* ref
 	}
 	if (prev_types_out) *prev_types_out = W->prev_types_out;
 	*out = W.release();
+	return CL_OK;
+}
+// What dna_walk's k_last_types computes, without the walk: the flags of the last four reads come from their first tuples (k_read_flags).
+cl_status cl_dna_batch_types(cl_ctx* ctx, const uint8_t* d_es, const uint64_t* d_es_off, uint32_t n_reads, uint32_t prev_types, uint32_t* out)
+{
+	if (!ctx || !d_es || !d_es_off || !out) return CL_E_INVALID;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	uint32_t v = prev_types;
+	const uint32_t start = n_reads > 4 ? n_reads - 4 : 0, k = n_reads - start;
+	uint64_t off[4] = { 0, 0, 0, 0 }; uint8_t first[4] = { 0, 0, 0, 0 };
+	if (k) HIP_TRY(ctx, hipMemcpy(off, d_es_off + start, (size_t)k * 8, hipMemcpyDeviceToHost));
+	for (uint32_t i = 0; i < k; ++i) HIP_TRY(ctx, hipMemcpy(&first[i], d_es + off[i], 1, hipMemcpyDeviceToHost));
+	for (uint32_t i = 0; i < k; ++i) { const uint32_t t = first[i] >> 4; v = ((v << 2) + (t == T_START_PLAIN ? 0u : t == T_START_PLAIN_N ? 1u : 2u)) & 0xff; }
+	*out = v;
 	return CL_OK;
 }
 void cl_dna_walked_free(DnaWalked* W) { delete W; }
@@ -1303,7 +1317,6 @@ cl_status dna_evolve_batch(cl_ctx* ctx, cl_dna_coder* D, const cl_reads* refs, c
 			LaunchOn on(ctx, G->stream);                                          // (launch + timing events on the coder's stream)
 			G->sync.s = G->stream;
 			hipError_t e1 = hipMemcpyAsync(G->d_out_off.p, G->out_off.data(), (np + 1) * 8, hipMemcpyHostToDevice, G->stream);
-			const bool cl_rc_direct_here = cl_rc_direct() == 1 || cl_rc_direct() == 2;
 			LAUNCH_RANGE_CODE(ctx, n_syms * 8.0, ng, (const triple_t*)trip.p, (const uint64_t*)d_gbase.p, (const uint32_t*)d_plen.p, np, G->tmp.p, (const uint64_t*)G->d_out_off.p, G->d_size.p, inv_tab);
 			hipError_t e2 = hipGetLastError();
 			HIP_TRY(ctx, e1); HIP_TRY(ctx, e2);

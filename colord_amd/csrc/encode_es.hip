@@ -164,8 +164,7 @@ __global__ __launch_bounds__(64) void k_align_small(const uint32_t* __restrict__
 	}
 }
 
-// large gaps: one WAVE per gap (align_wave.hpp), largest first.  Three steps, so that k_align_quad can run the middle one
-// for four gaps at once: the sequences into byte buffers (stage), sweep + path -> operations, operations -> canonical script.
+// large gaps: one WAVE per gap (align_wave.hpp), largest first.  Three steps: the sequences into byte buffers (stage), sweep + path -> operations, operations -> canonical script.
 struct WaveGap {
 	uint8_t* rbuf; uint8_t* ebuf; uint8_t* r2; uint8_t* e2; uint8_t* opsbuf;
 	const uint8_t* Q; const uint8_t* T; uint32_t n, m; bool rows_ref, shw, left;     // m: columns offered to the sweep (g.use for a flank)
@@ -660,158 +659,10 @@ __global__ __launch_bounds__(64) void k_giant_finish(gt::View V, GapRec* __restr
 	}
 }
 
-// gaps of up to 16 row blocks: FOUR per wave (one per 16-lane row), largest first; what does not fit a wave's pool goes to `redo`
-// (k_align_wave takes it).  Two forms of the same sweep and the same walk:
-//   k_align_quad_hist  (default) the whole history of the sweep — two words per block and column — goes to the wave's pool in HBM and the four
-//                      tracebacks read it back one after the other with the whole wave (wv::wave_walk): 15.6 GB per level-0 launch for 0.14 GB
-//                      of sequences and scripts;
-//   k_align_quad       (COLORD_HIP_QUAD_NOHIST) no history: a checkpoint every 16 columns, the tracebacks recompute their windows into LDS and
-//                      run in lock step (wv::quad_walk): 1 / 16 of the bytes, 1.25 x the kernel time (the recomputation is a second sweep,
-//                      and HBM bandwidth is not what this pipeline is short of: DESIGN.md 5d) — measured, not the default.
-__global__ __launch_bounds__(64) void k_align_quad_hist(const uint32_t* __restrict__ list, uint32_t n_list, GapRec* __restrict__ gaps, char* __restrict__ es_pool, ArenaV A, ArenaV R,
-                                                  uint8_t* __restrict__ scratch, uint64_t per_wave, unsigned int* __restrict__ next, uint32_t* __restrict__ redo, unsigned int* __restrict__ n_redo)
-{
-	wv::WavePool pool{ scratch + (uint64_t)blockIdx.x * per_wave, per_wave, 0, false, nullptr };
-	const uint32_t lane = threadIdx.x, gq = lane >> 4;
-	const uint32_t n_quads = (n_list + 3) / 4;
-	for (;;)
-	{
-		uint32_t slot = 0;
-		if (lane == 0) slot = atomicAdd(next, 1u);
-		slot = wv::bcast_first(slot);
-		if (slot >= n_quads) break;
-		pool.top = 0; pool.overflow = false;
-		const uint32_t hi = n_list - slot * 4, cnt = hi < 4 ? hi : 4;        // gaps list[hi - 1], list[hi - 2], ... (ascending list, taken from its end)
-		GapRec g[4]; WaveGap W[4]; uint64_t* P[4]; uint64_t* H[4]; uint8_t* rev[4]; uint32_t gi[4]; bool ok[4];
-#pragma unroll
-		for (uint32_t j = 0; j < 4; ++j)
-		{
-			ok[j] = false; gi[j] = 0; P[j] = H[j] = nullptr; rev[j] = nullptr;
-			if (j >= cnt) continue;
-			gi[j] = list[hi - 1 - j];
-			g[j] = gaps[gi[j]];
-			g[j].es_len = 0; g[j].d_before = 0;
-			if (pool.overflow) continue;
-			if (!wave_gap_stage(pool, g[j], A, R, W[j])) continue;
-			if (W[j].n == 0 || W[j].m == 0 || W[j].n > 1024) continue;        // (not of this class: the wave kernel handles every shape)
-			const uint64_t words = ((uint64_t)W[j].m + 64) * ((W[j].n + 63) / 64);
-			P[j] = (uint64_t*)pool.alloc(words * 8); H[j] = (uint64_t*)pool.alloc(words * 8); rev[j] = (uint8_t*)pool.alloc((uint64_t)W[j].n + W[j].m + 64);
-			ok[j] = !pool.overflow;
-		}
-		pool.overflow = false;
-		const uint8_t* q = nullptr; const uint8_t* t = nullptr; uint32_t n = 0, m = 0; bool shw = false; uint64_t* hp = nullptr; uint64_t* hh = nullptr;
-#pragma unroll
-		for (uint32_t j = 0; j < 4; ++j) if (gq == j && ok[j]) { q = W[j].Q; n = W[j].n; t = W[j].T; m = W[j].m; shw = W[j].shw; hp = P[j]; hh = H[j]; }
-		const wv::Sweep sw = wv::quad_sweep(q, n, t, m, shw, hp, hh);
-#pragma unroll
-		for (uint32_t j = 0; j < 4; ++j)
-		{
-			if (j >= cnt) continue;
-			bool done = false;
-			if (ok[j])
-			{
-				const int32_t end = wv::bcast(sw.end, 16u * j);
-				wv::Ops ops{ W[j].opsbuf, 0 };
-				const wv::Hist h{ P[j], H[j], (W[j].n + 63) / 64, W[j].m, W[j].n };
-				wv::wave_walk(pool, h, W[j].Q, W[j].n, W[j].T, W[j].shw ? (uint32_t)(end + 1) : W[j].m, rev[j], ops);
-				const uint32_t ref_end = W[j].shw ? (uint32_t)end : g[j].kind == GK_FLANK_TINY ? g[j].use - 1 : 0u;
-				const uint64_t mk = pool.mark();
-				done = wave_gap_finish(pool, g[j], W[j], ops, ref_end, es_pool + g[j].es_off, 0);
-				pool.release(mk); pool.overflow = false;
-			}
-			if (lane == 0)
-			{
-				if (done) { gaps[gi[j]].es_len = g[j].es_len; gaps[gi[j]].d_before = g[j].d_before; }
-				else redo[atomicAdd(n_redo, 1u)] = gi[j];
-			}
-		}
-	}
-}
-
-__global__ __launch_bounds__(64) void k_align_quad(const uint32_t* __restrict__ list, uint32_t n_list, GapRec* __restrict__ gaps, char* __restrict__ es_pool, ArenaV A, ArenaV R,
-                                                  uint8_t* __restrict__ scratch, uint64_t per_wave, unsigned int* __restrict__ next, uint32_t* __restrict__ redo, unsigned int* __restrict__ n_redo, uint32_t dbg)
-{
-	__shared__ uint64_t s_win[4 * wv::QWC * 16 * 2];                         // the four rows' traceback windows (wv::quad_walk): 32 KB
-	wv::WavePool pool{ scratch + (uint64_t)blockIdx.x * per_wave, per_wave, 0, false, nullptr };
-	const uint32_t lane = threadIdx.x, gq = lane >> 4;
-	const uint32_t n_quads = (n_list + 3) / 4;
-	for (;;)
-	{
-		uint32_t slot = 0;
-		if (lane == 0) slot = atomicAdd(next, 1u);
-		slot = wv::bcast_first(slot);
-		if (slot >= n_quads) break;
-		pool.top = 0; pool.overflow = false;
-		const uint32_t hi = n_list - slot * 4, cnt = hi < 4 ? hi : 4;        // gaps list[hi - 1], list[hi - 2], ... (ascending list, taken from its end)
-		GapRec g[4]; WaveGap W[4]; uint64_t* CK[4]; uint8_t* rev[4]; uint32_t gi[4]; bool ok[4];
-#pragma unroll
-		for (uint32_t j = 0; j < 4; ++j)
-		{
-			ok[j] = false; gi[j] = 0; CK[j] = nullptr; rev[j] = nullptr;
-			if (j >= cnt) continue;
-			gi[j] = list[hi - 1 - j];
-			g[j] = gaps[gi[j]];
-			g[j].es_len = 0; g[j].d_before = 0;
-			if (pool.overflow) continue;
-			if (!wave_gap_stage(pool, g[j], A, R, W[j])) continue;
-			if (W[j].n == 0 || W[j].m == 0 || W[j].n > 1024) continue;        // (not of this class: the wave kernel handles every shape)
-			CK[j] = (uint64_t*)pool.alloc(wv::quad_ck_words(W[j].n, W[j].m) * 8 + 64); rev[j] = (uint8_t*)pool.alloc((uint64_t)W[j].n + W[j].m + 64);
-			ok[j] = !pool.overflow;
-		}
-		pool.overflow = false;
-		const uint8_t* q = nullptr; const uint8_t* t = nullptr; uint32_t n = 0, m = 0; bool shw = false; uint64_t* ckp = nullptr; uint8_t* revp = nullptr;
-#pragma unroll
-		for (uint32_t j = 0; j < 4; ++j) if (gq == j && ok[j]) { q = W[j].Q; n = W[j].n; t = W[j].T; m = W[j].m; shw = W[j].shw; ckp = CK[j]; revp = rev[j]; }
-		// the sweep: score / end position and a checkpoint every QWC columns; then the traceback of all four in lock step
-		uint64_t e0, e1, e2, e3;
-		wv::quad_masks(q, n, e0, e1, e2, e3);
-		uint32_t i_e, j_e, k_e; int32_t end;
-		{
-			uint64_t Pv = ~0ull, Mv = 0; uint32_t sc = n, best = 0xffffffffu; end = (int32_t)m - 1;
-			if (shw && (n & 63)) { best = n; end = -1; }
-			wv::quad_cols<false>(t, n, m, 0, n ? m : 0, shw, e0, e1, e2, e3, Pv, Mv, nullptr, ckp, sc, best, end);
-			const uint32_t nb = (n + 63) / 64;
-			end = __shfl(end, (int)((lane & 48) + (nb ? nb - 1 : 0)));
-			__builtin_amdgcn_s_waitcnt(0);
-			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-			if (dbg == 1) { i_e = n; j_e = 0; k_e = 0; }
-			else wv::quad_walk(q, t, n, m, shw ? (uint32_t)(end + 1) : m, ckp, revp, e0, e1, e2, e3, s_win, i_e, j_e, k_e);
-			__builtin_amdgcn_s_waitcnt(0);
-			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-		}
-#pragma unroll
-		for (uint32_t j = 0; j < 4; ++j)
-		{
-			if (j >= cnt) continue;
-			bool done = false;
-			if (ok[j] && dbg) done = true;
-			else if (ok[j])
-			{	// the operations in forward order: what is left of the prefix first (the walk ended with i == 0 or j == 0), then the walk's, reversed
-				const uint32_t wi = wv::bcast(i_e, 16u * j), wj = wv::bcast(j_e, 16u * j), wk = wv::bcast(k_e, 16u * j);
-				const int32_t gend = wv::bcast(end, 16u * j);
-				uint8_t* dst = W[j].opsbuf; const uint8_t* rv = rev[j];
-				const uint32_t pre = wi + wj; const uint8_t pre_op = wi ? 1 : 2;
-				for (uint32_t x = lane; x < pre; x += 64) dst[x] = pre_op;
-				for (uint32_t x = lane; x < wk; x += 64) dst[pre + x] = rv[wk - 1 - x];
-				__builtin_amdgcn_s_waitcnt(0);
-				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-				wv::Ops ops{ W[j].opsbuf, (uint64_t)pre + wk };
-				const uint32_t ref_end = W[j].shw ? (uint32_t)gend : g[j].kind == GK_FLANK_TINY ? g[j].use - 1 : 0u;
-				const uint64_t mk = pool.mark();
-				done = wave_gap_finish(pool, g[j], W[j], ops, ref_end, es_pool + g[j].es_off, 0);
-				pool.release(mk); pool.overflow = false;
-			}
-			if (lane == 0)
-			{
-				if (done) { gaps[gi[j]].es_len = g[j].es_len; gaps[gi[j]].d_before = g[j].d_before; }
-				else redo[atomicAdd(n_redo, 1u)] = gi[j];
-			}
-		}
-	}
-}
-
-// the same class, every phase of a gap in its 16-lane row (align_rows.hpp; round 5): sequences, operations and script in LDS, the history
-// in the wave's pool.  What does not fit (pool, LDS) goes to `redo`.
+// gaps of up to 16 row blocks (rows <= 1024, rows + columns <= 2048): FOUR per wave, every phase of a gap in its 16-lane row (align_rows.hpp;
+// round 5): sequences, operations and script in LDS, the banded history in the wave's pool.  What does not fit (pool, LDS, a distance beyond the
+// band) goes to `redo` (k_align_wave takes it).  Rounds 2-4 ran only the sweep four gaps at a time (k_align_quad_hist: 495 us per quad against
+// 233 here; a form without history in HBM — checkpoints, windows recomputed into LDS — was 1.25 x slower still: numbers in DESIGN.md).
 // PROF (COLORD_HIP_QUAD_PROFILE): 100-MHz clocks per phase and the traceback's window statistics, summed over the waves into prof[0..10]
 template<bool PROF>
 __global__ __launch_bounds__(64) void k_align_quad_rows(const uint32_t* __restrict__ list, uint32_t n_list, GapRec* __restrict__ gaps, char* __restrict__ es_pool, ArenaV A, ArenaV R,
@@ -1183,40 +1034,10 @@ __global__ __launch_bounds__(64) void k_estimator(TreeV T, const uint32_t* __res
 		}
 	}
 }
-// Tuple emission.  A read's tuples come out of one sequential walk over its frame tree (runs of equal symbols merge
-// across anchors and gaps), and one lane takes ~0.2 s for a 170 k-tuple read however idle the machine is.  So:
-//   k_emit_count  one lane per READ: sizes and tuple counts, and every EMIT_CHUNK output bytes the state of the walk;
-//   k_emit_write  one lane per saved STATE: resumes there and writes the bytes up to the next saved state;
-//   k_emit_plain  reads stored plain: one wave per read, one lane per base.
-constexpr uint32_t EMIT_LPW = 16, EMIT_WPW = 64, EMIT_CHUNK = 2048;
-__global__ void k_emit_slots(const uint32_t* __restrict__ lens, const uint32_t* __restrict__ frame_of_read, uint32_t n, uint32_t* __restrict__ out)
-{	// slots for saved states: a guess of the output size; a read with more output just gets longer last chunks
-	const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-	if (r < n) out[r] = frame_of_read[r] == 0xffffffffu ? 0u : lens[r] / EMIT_CHUNK + 2;
-}
-__global__ __launch_bounds__(64) void k_emit_count(ArenaV A, const uint32_t* __restrict__ inv, const uint8_t* __restrict__ has_n, TreeV T, uint32_t n_reads, const uint32_t* __restrict__ data,
-                                                  const uint64_t* __restrict__ slot_off, EmitCk* __restrict__ cks, uint32_t* __restrict__ sizes, uint32_t* __restrict__ ntuples)
-{
-	__builtin_amdgcn_s_setprio(3);                                          // a launch of this kernel lasts as long as its slowest chain: its waves go first on their SIMDs	// EMIT_LPW reads per wave: the walk is divergent (every lane is somewhere else in its frame tree), and the machine has
-	// far more wave slots than a 64-reads-per-wave launch would use
-	if (threadIdx.x >= EMIT_LPW) return;
-	const uint32_t r = blockIdx.x * EMIT_LPW + threadIdx.x;
-	if (r >= n_reads) return;
-	if (T.frame_of_read[r] == 0xffffffffu) { sizes[r] = A.lens[r] + 1; ntuples[r] = A.lens[r] + 1; return; }   // a start tuple and one tuple per base
-	const uint64_t base = slot_off[r];
-	emit_read<false>(A, inv, has_n, T, r, data, sizes, ntuples, nullptr, nullptr, cks + base, (uint32_t)(slot_off[r + 1] - base), EMIT_CHUNK, nullptr);
-}
-__global__ __launch_bounds__(64) void k_emit_write(ArenaV A, const uint32_t* __restrict__ inv, const uint8_t* __restrict__ has_n, TreeV T, const uint32_t* __restrict__ data,
-                                                  const EmitCk* __restrict__ cks, uint64_t n_slots, const uint64_t* __restrict__ es_off, uint8_t* __restrict__ out)
-{
-	if (threadIdx.x >= EMIT_WPW) return;
-	const uint64_t s = (uint64_t)blockIdx.x * EMIT_WPW + threadIdx.x;
-	if (s >= n_slots) return;
-	const EmitCk* k = cks + s;
-	if (!k->used) return;
-	emit_read<true>(A, inv, has_n, T, k->read, data, nullptr, nullptr, es_off, out, nullptr, 0, EMIT_CHUNK, k);
-}
-// the same two passes by one WAVE per read (emit_wave.hpp): the lanes take 64 fragments of a frame at a time
+// Tuple emission: one wave per read over the run-length monoid of its fragments (emit_wave.hpp; k_emit_count_wave sizes and tuple counts,
+// k_emit_write_wave the bytes), k_emit_plain for reads stored plain (one wave per read, one lane per base).  Rounds 1-2 walked a read's frame
+// tree with one lane (emit_read, encode_core.hpp: 12.6 s per pass against 2.1; it stays as the sequential statement the host debugging
+// build replays, tests/tools/encode_host.hip).
 __global__ __launch_bounds__(256) void k_emit_count_wave(ArenaV A, TreeV T, uint32_t n_reads, const uint32_t* __restrict__ data, uint32_t* __restrict__ sizes, uint32_t* __restrict__ ntuples)
 {
 	const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1339,7 +1160,8 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 		SideJoin side_join{ ctx->side };                                         // (after hist in destruction order: joins first)
 		{
 			uint32_t max_blocks = 1;
-			for (int nb = 1; nb <= 4; ++nb) max_blocks = std::max(max_blocks, std::min<uint32_t>(grid_for(hb[nb + 1] - hb[nb], 64), n_cu * 4));
+			static const uint32_t small_per_cu = getenv("COLORD_HIP_SMALL_PER_CU") ? (uint32_t)std::max(1, atoi(getenv("COLORD_HIP_SMALL_PER_CU"))) : 4u;   // (tuning knob: blocks of 15 - 25 KB of LDS each)
+			for (int nb = 1; nb <= 4; ++nb) max_blocks = std::max(max_blocks, std::min<uint32_t>(grid_for(hb[nb + 1] - hb[nb], 64), n_cu * small_per_cu));
 			DEV_ALLOC(ctx, hist, (uint64_t)max_blocks * 256 * 4 * 2 * 64);
 			LaunchOn on(ctx, ctx->side);                                          // (launches + timing events on the side stream)
 			hipError_t le = hipSuccess;
@@ -1347,7 +1169,7 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 			{
 				const uint32_t n_list = hb[nb + 1] - hb[nb];
 				if (!n_list) continue;
-				const uint32_t blocks = std::min<uint32_t>(grid_for(n_list, 64), n_cu * 4);
+				const uint32_t blocks = std::min<uint32_t>(grid_for(n_list, 64), n_cu * small_per_cu);
 				const uint32_t lds = (12 * nb + 48) * 64 * 4;                       // LdsMem<nb>: QW + TW + EW words per lane
 				const double bytes = 1.25 * (double)h_cb[nb];
 				ctx->next_cells = (double)h_cb[N_CLASSES + nb];
@@ -1372,11 +1194,10 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 		if (hb[6] > hb[5])
 		{
 			const uint32_t n_list = hb[6] - hb[5];
-			static const bool nohist = getenv("COLORD_HIP_QUAD_NOHIST") != nullptr;
-			// with the history: 2.25 MB a wave (four histories of at most 512 KB + the sequences and scripts of four gaps), 2048 waves (4096 were
-			// no faster beside the other streams); without: 1 MB, ten waves per CU (16 KB of LDS each)
-			const uint64_t per_wave = nohist ? 1ull << 20 : 9ull << 18;
-			const uint32_t waves = std::min<uint32_t>((n_list + 3) / 4, nohist ? n_cu * 10 : 2048u);
+			// 2.25 MB a wave: four banded histories of at most 512 KB; 2048 waves (4096 were no faster beside the other streams)
+			const uint64_t per_wave = 9ull << 18;
+			static const uint32_t quad_waves = getenv("COLORD_HIP_QUAD_WAVES") ? (uint32_t)std::max(64, atoi(getenv("COLORD_HIP_QUAD_WAVES"))) : 2048u;   // (tuning knob: waves of 18.5 KB of LDS each)
+			const uint32_t waves = std::min<uint32_t>((n_list + 3) / 4, quad_waves);
 			DEV_ALLOC(ctx, quad_scratch, per_wave * waves);
 			DEV_ALLOC(ctx, qc, 2);
 			DEV_ALLOC(ctx, quad_redo, (uint64_t)n_list + 1);
@@ -1385,9 +1206,8 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 			HIP_TRY(ctx, hipMemsetAsync(qc.p, 0, 8, ctx->side2));
 			LaunchOn on(ctx, ctx->side2);                                         // (launch + timing events on the third stream)
 			ctx->next_cells = (double)h_cb[N_CLASSES + 5];
-			static const bool old_quad = getenv("COLORD_HIP_QUAD_OLD") != nullptr;
 			static const bool quad_prof = getenv("COLORD_HIP_QUAD_PROFILE") != nullptr;
-			if (!nohist && !old_quad && quad_prof)
+			if (quad_prof)
 			{	// diagnostic: the phases of the row kernel (waits for the launch)
 				DevBuf<unsigned long long> qp; DEV_ALLOC(ctx, qp, 16);
 				HIP_TRY(ctx, hipMemsetAsync(qp.p, 0, 128, ctx->side2));
@@ -1396,12 +1216,10 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 				HIP_TRY(ctx, hipStreamSynchronize(ctx->side2));
 				HIP_TRY(ctx, hipMemcpy(hp, qp.p, 128, hipMemcpyDeviceToHost));
 				const double q = (double)std::max<unsigned long long>(hp[9], 1);
-				fprintf(stderr, "[quad rows, level %u] %u gaps in %llu quads on %u waves; us per quad: stage %.1f sweep %.1f walk %.1f convert %.1f refactor %.1f fetch+write %.1f; sweep steps per quad %.0f; walk iterations per quad %.0f, of which waited for a window on demand %.1f, took a queued one %.1f\n",
-					lv, n_list, hp[9], waves, hp[0] / q / 100.0, hp[1] / q / 100.0, hp[2] / q / 100.0, hp[3] / q / 100.0, hp[4] / q / 100.0, hp[5] / q / 100.0, hp[10] / q, hp[6] / q, hp[7] / q, hp[8] / q);
+				fprintf(stderr, "[quad rows, level %u] %u gaps in %llu quads on %u waves; us per quad: stage %.1f sweep %.1f walk %.1f convert %.1f refactor %.1f fetch+write %.1f; sweep steps per quad %.0f; walk iterations per quad %.0f, of which waited for new windows %.1f\n",
+					lv, n_list, hp[9], waves, hp[0] / q / 100.0, hp[1] / q / 100.0, hp[2] / q / 100.0, hp[3] / q / 100.0, hp[4] / q / 100.0, hp[5] / q / 100.0, hp[10] / q, hp[6] / q, hp[7] / q);
 			}
-			else if (!nohist && !old_quad) LAUNCHB(ctx, 1.25 * (double)h_cb[5], k_align_quad_rows<false>, waves, 64, (const uint32_t*)ids.p + hb[5], n_list, L.gaps.p, L.es.p, A, R, quad_scratch.p, per_wave, qc.p, quad_redo.p, qc.p + 1, (unsigned long long*)nullptr);
-			else if (nohist) LAUNCHB(ctx, 1.25 * (double)h_cb[5], k_align_quad, waves, 64, (const uint32_t*)ids.p + hb[5], n_list, L.gaps.p, L.es.p, A, R, quad_scratch.p, per_wave, qc.p, quad_redo.p, qc.p + 1, (uint32_t)(getenv("COLORD_HIP_QUAD_DBG") ? atoi(getenv("COLORD_HIP_QUAD_DBG")) : 0));
-			else LAUNCHB(ctx, 1.25 * (double)h_cb[5], k_align_quad_hist, waves, 64, (const uint32_t*)ids.p + hb[5], n_list, L.gaps.p, L.es.p, A, R, quad_scratch.p, per_wave, qc.p, quad_redo.p, qc.p + 1);
+			else LAUNCHB(ctx, 1.25 * (double)h_cb[5], k_align_quad_rows<false>, waves, 64, (const uint32_t*)ids.p + hb[5], n_list, L.gaps.p, L.es.p, A, R, quad_scratch.p, per_wave, qc.p, quad_redo.p, qc.p + 1, (unsigned long long*)nullptr);
 			HIP_TRY(ctx, hipGetLastError());
 		}
 		// giant gaps: many waves each (align_giant.hpp), on a stream of their own from the start of the level, next to everything else
@@ -1633,7 +1451,6 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 	if (n_packs) LAUNCH(ctx, k_estimator, n_packs, 64, T, (const uint32_t*)d_pb.p, n_packs, (const uint32_t*)reads->lens.p, has_n, (const uint32_t*)base_counts.p, (const uint64_t*)ev_off.p, (const uint32_t*)events.p);
 	DevBuf<uint32_t> sizes; DEV_ALLOC(ctx, sizes, nr);
 	uint64_t total = 0;
-	if (!getenv("COLORD_HIP_OLD_EMIT"))
 	{	// one wave per read, the lanes over the fragments of a frame (emit_wave.hpp)
 		LAUNCHB(ctx, reads->total_bases * 1.25, k_emit_count_wave, grid_for(nr, 4), 256, A, T, nr, AV.data, sizes.p, d_es_ntuples);
 		HIP_TRY(ctx, hipGetLastError());
@@ -1641,24 +1458,6 @@ extern "C" cl_status cl_encode_reads(cl_ctx* ctx, const cl_reads* reads, const c
 		*n_out = total;
 		if (total > cap || (total && !d_es)) return cl_fail(ctx, CL_E_CAPACITY, "cl_encode_reads: need " + std::to_string(total) + " bytes");
 		LAUNCHB(ctx, reads->total_bases * 1.25 + (double)total, k_emit_write_wave, grid_for(nr, 4), 256, A, T, nr, AV.data, (const uint64_t*)d_es_off, d_es);
-	}
-	else
-	{
-		DevBuf<uint64_t> slot_off; DEV_ALLOC(ctx, slot_off, (uint64_t)nr + 1);
-		uint64_t n_slots = 0;
-		LAUNCH(ctx, k_emit_slots, grid_for(nr, 256), 256, (const uint32_t*)reads->lens.p, (const uint32_t*)frame_of_read.p, nr, sizes.p);
-		CL_TRY(dev_exclusive_scan_u64(ctx, sizes.p, slot_off.p, nr, &n_slots));
-		DevBuf<EmitCk> cks; DEV_ALLOC(ctx, cks, n_slots + 1);
-		HIP_TRY(ctx, hipMemsetAsync(cks.p, 0, (n_slots + 1) * sizeof(EmitCk), st));
-		LAUNCHB(ctx, reads->total_bases * 1.25, k_emit_count, grid_for(nr, EMIT_LPW), 64, /* 2 bits per base + at most one script byte per base in */ A, (const uint32_t*)reads->inv.p, has_n, T, nr, AV.data, (const uint64_t*)slot_off.p, cks.p, sizes.p, d_es_ntuples);
-		HIP_TRY(ctx, hipGetLastError());
-			CL_TRY(dev_exclusive_scan_u64(ctx, sizes.p, d_es_off, nr, &total));
-		*n_out = total;
-		if (total > cap || (total && !d_es)) return cl_fail(ctx, CL_E_CAPACITY, "cl_encode_reads: need " + std::to_string(total) + " bytes");
-		if (n_slots) LAUNCHB(ctx, reads->total_bases * 1.25 + (double)total, k_emit_write, grid_for(n_slots, EMIT_WPW), 64, /* the same in + the tuple bytes out */ A, (const uint32_t*)reads->inv.p, has_n, T, AV.data, (const EmitCk*)cks.p, n_slots, (const uint64_t*)d_es_off, d_es);
-	#ifdef CL_EMIT_DEBUG
-		{ (void)hipDeviceSynchronize(); unsigned long long h[2]; (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(enc::g_emit_dbg), 16); fprintf(stderr, "[emit dbg] bytes written by chunk lanes %llu in %llu chunks; total output %llu\n", h[0], h[1], (unsigned long long)total); }
-	#endif
 	}
 	LAUNCH(ctx, k_emit_plain, grid_for(nr, 4), 256, A, (const uint32_t*)reads->inv.p, has_n, (const uint32_t*)frame_of_read.p, nr, (const uint64_t*)d_es_off, d_es);
 	HIP_TRY(ctx, hipGetLastError());

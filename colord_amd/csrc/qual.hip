@@ -618,7 +618,6 @@ cl_status qual_evolve_batch(cl_ctx* ctx, cl_qual_coder* Q, const cl_reads* R, co
 		PG.stream = Q->cstreams[Q->next_cstream++ % Q->cstreams.size()];
 		{
 			LaunchOn on(ctx, PG.stream);                                         // (launch + timing events on the coder's stream)
-			const bool cl_rc_direct_here = cl_rc_direct() == 1 || cl_rc_direct() == 3;
 			LAUNCH_RANGE_CODE(ctx, n_syms * 8.0, ng, (const triple_t*)trip.p, (const uint64_t*)PG.d_gbase.p, (const uint32_t*)PG.d_plen.p, np, PG.tmp.p, (const uint64_t*)PG.d_out_off.p, PG.d_size.p, inv_tab);
 			hipError_t e2 = hipGetLastError();
 			HIP_TRY(ctx, e2);

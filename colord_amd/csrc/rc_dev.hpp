@@ -25,36 +25,8 @@ static __global__ void k_fill_inv_table(uint64_t* __restrict__ tab)
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < INV_TABLE_SIZE) tab[i] = i ? ~0ULL / (uint64_t)i : ~0ULL;
 }
-// The same reciprocal, floor((2^64 - 1) / tot) for 1 <= tot < 2^21, from arithmetic alone (COLORD_HIP_RC_INV_COMPUTE=1) — the table costs
-// the coder one gather per symbol, up to 64 requests to L2 per step of a wave next to the 8 of its coalesced symbol fetch.  Long division
-// in two digits of 2^32 with a double-precision reciprocal: q1 = (2^32 - 1) / tot with remainder r1 < tot, then
-// q2 = (r1 2^32 + 2^32 - 1) / tot < 2^32 (the dividend is below 2^53: exact in a double).  r = 1 / tot after one Newton step is far
-// closer than the 2^-33 that keeps either estimate within one of the quotient; the remainders (exact: 32-bit wrap-around, fma) correct
-// it.  Checked against the table for every tot under COLORD_HIP_RC_INV_CHECK=1 (0 of 2 097 151 differ).  Measured: beside
-// a random scatter the coder takes 49 ms instead of 94, alone 17.5 instead of 13, in the pipeline 8.7 s per pass instead of 7.3 with the
-// pass unchanged within its noise (18.8 - 19.2 s either way: what the coder saves the memory system it takes from the CUs' issue slots,
-// the DNA sort beside it goes from 5.1 to 5.8 s) — so the table stays the default.
-__device__ inline uint64_t inv_of(uint32_t tot)
-{
-	const double d = (double)tot;
-	double r = __builtin_amdgcn_rcp(d);
-	r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
-	uint32_t q1 = (uint32_t)(4294967295.0 * r);
-	uint32_t r1 = 0xffffffffu - q1 * tot;
-	if ((int32_t)r1 < 0) { --q1; r1 += tot; } else if (r1 >= tot) { ++q1; r1 -= tot; }
-	const double n2 = __builtin_fma((double)r1, 4294967296.0, 4294967295.0);
-	double q2 = __builtin_trunc(n2 * r);
-	const double rem = __builtin_fma(-q2, d, n2);
-	q2 += rem < 0.0 ? -1.0 : rem >= d ? 1.0 : 0.0;
-	return ((uint64_t)q1 << 32) | (uint32_t)q2;
-}
-static __global__ void k_check_inv(const uint64_t* __restrict__ tab, unsigned int* __restrict__ bad)
-{
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= 1 && i < INV_TABLE_SIZE && inv_of(i) != tab[i]) atomicAdd(bad, 1u);
-}
-// how the coder gets its reciprocals: looked up (default) or computed (COLORD_HIP_RC_INV_COMPUTE=1)
-static inline bool cl_rc_inv_table() { static const bool d = [] { const char* e = getenv("COLORD_HIP_RC_INV_COMPUTE"); return !(e && atoi(e) != 0); }(); return d; }
+// (Computing the reciprocal instead — two-digit long division with a double-precision reciprocal, exact for all 2 097 151 totals — was
+// measured in round 4: the coder 7.3 -> 8.7 s per pass, the pass unchanged; DESIGN.md.  The table stays.)
 // the context's reciprocal table (made at first use)
 static inline cl_status cl_inv_table(cl_ctx* ctx, const uint64_t** out)
 {
@@ -64,18 +36,6 @@ static inline cl_status cl_inv_table(cl_ctx* ctx, const uint64_t** out)
 		hipLaunchKernelGGL(k_fill_inv_table, dim3(INV_TABLE_SIZE / 256), dim3(256), 0, ctx->stream, ctx->inv_tab);
 		HIP_TRY(ctx, hipGetLastError());
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-		if (getenv("COLORD_HIP_RC_INV_CHECK"))
-		{
-			unsigned int* bad = nullptr; unsigned int h = 0;
-			HIP_TRY(ctx, hipMalloc((void**)&bad, 4));
-			HIP_TRY(ctx, hipMemsetAsync(bad, 0, 4, ctx->stream));
-			hipLaunchKernelGGL(k_check_inv, dim3(INV_TABLE_SIZE / 256), dim3(256), 0, ctx->stream, (const uint64_t*)ctx->inv_tab, bad);
-			HIP_TRY(ctx, hipMemcpyAsync(&h, bad, 4, hipMemcpyDeviceToHost, ctx->stream));
-			HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-			(void)hipFree(bad);
-			fprintf(stderr, "[rc] computed reciprocals checked against the table: %u of %u differ\n", h, INV_TABLE_SIZE - 1);
-			if (h) return cl_fail(ctx, CL_E_HIP, "interval coder: a computed reciprocal differs from the table");
-		}
 	}
 	*out = ctx->inv_tab;
 	return CL_OK;
@@ -121,11 +81,9 @@ constexpr uint32_t RING = 256, RING_UNIT = 128, RING_STRIDE = 8 + RING + 8 + 4;
 typedef uint64_t __attribute__((may_alias, aligned(1))) u64_any;          // (the ring is written as words at any byte and read as words and bytes)
 typedef uint32_t __attribute__((may_alias, aligned(1))) u32_any;
 __device__ inline void lds_store_be64(uint8_t* p, uint64_t v) { *(u64_any*)p = __builtin_bswap64(v); }
-// (COLORD_HIP_RC_DIRECT=1: the lanes store their bytes themselves, as before — for A/B)
-static inline int cl_rc_direct() { static const int d = [] { const char* e = getenv("COLORD_HIP_RC_DIRECT"); return e ? atoi(e) : 0; }(); return d; }
 
 // one lane per part, one wave per group of 64 parts (sub_rc.h:72-100,203-210)
-template<bool STAGED, bool TABLE> static __global__ __launch_bounds__(64) void k_range_code(const triple_t* __restrict__ trip, const uint64_t* __restrict__ group_base,
+static __global__ __launch_bounds__(64) void k_range_code(const triple_t* __restrict__ trip, const uint64_t* __restrict__ group_base,
                                                          const uint32_t* __restrict__ part_len, uint32_t n_parts,
                                                          uint8_t* __restrict__ out, const uint64_t* __restrict__ part_out_off, uint64_t* __restrict__ part_size,
                                                          const uint64_t* __restrict__ inv_tab)
@@ -138,10 +96,9 @@ template<bool STAGED, bool TABLE> static __global__ __launch_bounds__(64) void k
 	const uint64_t out_off = live ? part_out_off[p] : 0;
 	uint8_t* outp = out + out_off;
 	const uint64_t cap = live ? part_out_off[p + 1] - part_out_off[p] : 0;
-	const uint32_t cap8 = cap < 8 ? 0u : cap - 8 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)(cap - 8);    // last position an 8-byte store may start at
 	uint32_t n_out = 0; bool overflow = cap < 8 || cap > 0xfffffff0ull;
-	__shared__ __attribute__((aligned(16))) uint8_t s_ring[STAGED ? 64 * RING_STRIDE : 16];
-	uint8_t* const ring = s_ring + (STAGED ? threadIdx.x * RING_STRIDE + 8 : 0);
+	__shared__ __attribute__((aligned(16))) uint8_t s_ring[64 * RING_STRIDE];
+	uint8_t* const ring = s_ring + threadIdx.x * RING_STRIDE + 8;
 	const uint32_t room = overflow ? 0u : (uint32_t)cap;                      // bytes this lane may write
 	uint32_t flushed = 0;                                                    // bytes of the ring already written out (a multiple of RING_UNIT)
 	// write out every lane's complete 128-byte units (called once per round: a round adds at most 8 U = 64 bytes per lane, so a ring
@@ -180,7 +137,7 @@ template<bool STAGED, bool TABLE> static __global__ __launch_bounds__(64) void k
 #pragma unroll
 	for (uint32_t u = 0; u < U; ++u) { A[u] = src[(uint64_t)(u < last ? u : last) * 64]; B[u] = src[(uint64_t)(U + u < last ? U + u : last) * 64]; }
 #pragma unroll
-	for (uint32_t u = 0; u < U; ++u) iA[u] = TABLE ? inv_tab[A[u] & 0x1fffff] : inv_of((uint32_t)A[u] & 0x1fffff);
+	for (uint32_t u = 0; u < U; ++u) iA[u] = inv_tab[A[u] & 0x1fffff];
 	// one round: fetch `far` (two rounds ahead), look up the reciprocals of `nxt`, code `cur` with `icur`
 	// (all_active: every lane of the wave still has symbols in this round — no neutral symbols to select; decided per round, wave-uniform)
 	auto round = [&](auto all_active, uint32_t pos, const triple_t (&cur)[U], const uint64_t (&icur)[U], const triple_t (&nxt)[U], uint64_t (&inxt)[U], triple_t (&far)[U])
@@ -188,7 +145,7 @@ template<bool STAGED, bool TABLE> static __global__ __launch_bounds__(64) void k
 #pragma unroll
 		for (uint32_t u = 0; u < U; ++u) { uint32_t q = pos + 2 * U + u; far[u] = src[(uint64_t)(q < last ? q : last) * 64]; }   // prefetch (index clamped, never a pointer select)
 #pragma unroll
-		for (uint32_t u = 0; u < U; ++u) inxt[u] = TABLE ? inv_tab[nxt[u] & 0x1fffff] : inv_of((uint32_t)nxt[u] & 0x1fffff);
+		for (uint32_t u = 0; u < U; ++u) inxt[u] = inv_tab[nxt[u] & 0x1fffff];
 #pragma unroll
 		for (uint32_t u = 0; u < U; ++u)
 		{
@@ -229,14 +186,10 @@ template<bool STAGED, bool TABLE> static __global__ __launch_bounds__(64) void k
 			}
 			range = ((uint64_t)rh << 32) | rl; low = ((uint64_t)lh << 32) | ll;
 			// the bytes: the whole word at the write position (held inside the part's room; a part that outgrows it is seen at the end)
-			if constexpr (STAGED)
-			{
-				if (nb) { const uint32_t rp = n_out & (RING - 1); lds_store_be64(ring + rp, low0); if (rp > RING - 8) lds_store_be64(ring + rp - RING, low0); }
-			}
-			else if (nb) store_be64(outp + (n_out < cap8 ? n_out : cap8), low0);
+			if (nb) { const uint32_t rp = n_out & (RING - 1); lds_store_be64(ring + rp, low0); if (rp > RING - 8) lds_store_be64(ring + rp - RING, low0); }
 			n_out += nb;
 		}
-		if constexpr (STAGED) drain();
+		drain();
 	};
 	uint32_t lmin = live ? len : 0u;
 #pragma unroll
@@ -257,7 +210,6 @@ template<bool STAGED, bool TABLE> static __global__ __launch_bounds__(64) void k
 		if (pos + 2 * U >= lmax) break;
 		round(SOME, pos + 2 * U, C, iC, A, iA, B);
 	}
-	if constexpr (STAGED)
 	{
 		// End(): 8 bytes of low (sub_rc.h:203-210) go through the ring as well; then every lane's remainder, byte by byte, by the whole wave
 		{ const uint32_t rp = n_out & (RING - 1); lds_store_be64(ring + rp, low); if (rp > RING - 8) lds_store_be64(ring + rp - RING, low); }
@@ -273,17 +225,7 @@ template<bool STAGED, bool TABLE> static __global__ __launch_bounds__(64) void k
 			for (uint32_t b = threadIdx.x; b < n; b += 64) out[o + fl + b] = s_ring[L * RING_STRIDE + 8 + ((fl + b) & (RING - 1))];
 		}
 		if (live) part_size[p] = overflow ? ~0ULL : n_out;
-		return;
 	}
-	if (!live) return;
-	if ((uint32_t)(range >> 32) < 0x00010000u) overflow = true;                      // (an empty range: corrupt triples)
-	if (n_out <= cap8 && !overflow) store_be64(outp + n_out, low); else overflow = true;       // End(): 8 bytes of low (sub_rc.h:203-210)
-	n_out += 8;
-	part_size[p] = overflow ? ~0ULL : n_out;
 }
 
-// the launch, in the form the environment asks for (default: bytes staged in LDS, reciprocals from the table)
-#define LAUNCH_RANGE_CODE(ctx, bytes, ng, ...) do { \
-	if (cl_rc_direct_here) { LAUNCHB_NAMED(ctx, "k_range_code", bytes, (k_range_code<false, true>), ng, 64, __VA_ARGS__); } \
-	else if (cl_rc_inv_table()) { LAUNCHB_NAMED(ctx, "k_range_code", bytes, (k_range_code<true, true>), ng, 64, __VA_ARGS__); } \
-	else { LAUNCHB_NAMED(ctx, "k_range_code", bytes, (k_range_code<true, false>), ng, 64, __VA_ARGS__); } } while (0)
+#define LAUNCH_RANGE_CODE(ctx, bytes, ng, ...) LAUNCHB_NAMED(ctx, "k_range_code", bytes, k_range_code, ng, 64, __VA_ARGS__)

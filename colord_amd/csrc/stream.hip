@@ -95,24 +95,24 @@ struct cl_compressor {
 		cl_status status = CL_OK; std::string err;
 		std::map<std::string, KernelTime> times;      // kernel times of the lane for this chunk (merged into the caller's context)
 		bool done = false;
-		cl_anchors* anc = nullptr; uint32_t cc = 0;    // stage-split lanes (COLORD_HIP_LANE_SPLIT): the anchors between the two halves of stage A
 		// the model-independent half of the DNA coder for this chunk (tuple walks, and with part bounds the sort by context), made by
 		// the compressor's preparation thread beside the coding of the chunk before (cl_dna_prepare_batch)
 		std::vector<uint32_t> parts; DnaWalked* walked = nullptr; bool dna_done = false; std::map<std::string, KernelTime> dna_times;
 		// ... and of the quality coder (symbols, sort by context), which needs the input only (level 1: no flags from the edit scripts)
 		const uint8_t* d_quals = nullptr; const uint64_t* d_base_off = nullptr; QualPrepared* qprep = nullptr; bool q_done = false; std::map<std::string, KernelTime> q_times;
-		~Prepared() { if (walked) cl_dna_walked_free(walked); if (qprep) cl_qual_prepared_free(qprep); if (anc) cl_anchors_free(anc); }
+		~Prepared() { if (walked) cl_dna_walked_free(walked); if (qprep) cl_qual_prepared_free(qprep); }
 	};
 	std::mutex lane_mu; std::condition_variable lane_cv;
 	std::deque<size_t> lane_queue;                   // announced chunk indices not yet started, ascending
-	std::deque<size_t> a2_queue;                     // stage-split lanes: chunks whose anchors are made, waiting for the edit-script half
-	std::set<size_t> a1_finished; size_t a1_next = 0;    // stage-split lanes: chunks whose anchors are done but not yet queued (kept in order)
-	uint32_t n_a1_lanes = 0;                         // stage-split lanes: the first n_a1_lanes lane threads make anchors only, the others edit scripts only (0: every lane does both)
 	std::map<size_t, std::unique_ptr<Prepared>> prepared;
 	std::vector<std::thread> lane_threads; std::vector<cl_ctx*> lane_ctx;
 	size_t n_announced = 0; bool lane_stop = false;
 	// DNA preparation thread: walks (and sorts) the chunks in order, one or two ahead of the coders, on a context of its own
-	std::thread prep_thread; cl_ctx* prep_ctx = nullptr; size_t prep_next = 0; bool prep_on = false, prep_broken = false; uint32_t prep_types = 0, prep_read_id = 0;
+	// DNA preparation: workers (contexts of their own) that CLAIM the chunks in order; the two scalars that chain from chunk to chunk — the
+	// types of the last four reads, the read count — are advanced at the claim (cl_dna_batch_types: a few bytes of the tuple streams), so
+	// the chunks themselves are prepared side by side
+	std::vector<std::thread> prep_threads; std::vector<cl_ctx*> prep_ctxs; std::mutex prep_claim_mu;
+	size_t prep_next = 0; bool prep_on = false, prep_broken = false; uint32_t prep_types = 0, prep_read_id = 0;
 	std::thread qprep_thread; cl_ctx* qprep_ctx = nullptr; size_t qprep_next = 0; bool qprep_on = false;
 	uint32_t n_dna_ahead = 0, n_qual_ahead = 0, n_dna_prep = 0, n_qual_prep = 0;      // (statistics: COLORD_HIP_STREAM_DEBUG)
 	double w_lane_idle = 0, w_lane_work = 0, w_enc_lane = 0, w_enc_prep = 0, w_enc_qprep = 0, w_prep_idle = 0, w_prep_work = 0;   // seconds: who waited for whom
@@ -124,7 +124,7 @@ struct cl_compressor {
 		{ std::lock_guard<std::mutex> l(lane_mu); lane_stop = true; }
 		lane_cv.notify_all();
 		for (auto& t : lane_threads) if (t.joinable()) t.join();
-		if (prep_thread.joinable()) prep_thread.join();
+		for (auto& t : prep_threads) if (t.joinable()) t.join();
 		if (qprep_thread.joinable()) qprep_thread.join();
 		lane_threads.clear();
 		prepared.clear();                                // (buffers go back to the lanes' pools)
@@ -500,20 +500,8 @@ extern "C" cl_status cl_compressor_refs_finish(cl_compressor* c)
 // Stage A of a chunk on context `ctx` (the caller's, or an encode lane's): a4 accepted k-mers, a5 candidates among the
 // EARLIER reference reads (d_bounds), a8/a9 anchors, a10-a12 edit scripts -> tuple streams.  Reads only state that pass 2a
 // completed (set, index, reference reads), so chunks are independent here.
-static cl_status stage_a(cl_compressor* c, cl_ctx* ctx, size_t chunk_idx, const cl_reads* reads, const uint32_t* h_pack_bounds, uint32_t n_packs, cl_compressor::Prepared& out, int half = 0)
-{	// half: 0 = all of stage A; 1 = up to the anchors (kept in out.anc); 2 = from the anchors on
-	if (half == 2)
-	{
-		HIP_TRY(ctx, hipSetDevice(ctx->device));
-		const cl_compress_params* P2 = &c->P;
-		const uint32_t n2 = reads->n_reads, max_rec2 = std::min<uint32_t>(P2->max_rec, 8);
-		std::unique_ptr<cl_anchors, void (*)(cl_anchors*)> ag2(out.anc, cl_anchors_free);
-		out.anc = nullptr;
-		const uint64_t es_cap2 = reads->total_bases + 16ull * n2 + 4096;
-		DEV_ALLOC(ctx, out.es, es_cap2); DEV_ALLOC(ctx, out.es_off, (uint64_t)n2 + 1); DEV_ALLOC(ctx, out.es_nt, n2);
-		CL_TRY(cl_encode_reads(ctx, reads, c->refs, ag2.get(), out.cc, P2->anchor_len, P2->min_part_alt, max_rec2, P2->cost_mult, h_pack_bounds, n_packs, out.es.p, es_cap2, out.es_off.p, out.es_nt.p, &out.es_bytes));
-		return CL_OK;
-	}
+static cl_status stage_a(cl_compressor* c, cl_ctx* ctx, size_t chunk_idx, const cl_reads* reads, const uint32_t* h_pack_bounds, uint32_t n_packs, cl_compressor::Prepared& out)
+{
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	const cl_compress_params* P = &c->P;
 	const uint32_t n = reads->n_reads;
@@ -547,44 +535,17 @@ static cl_status stage_a(cl_compressor* c, cl_ctx* ctx, size_t chunk_idx, const 
 	std::unique_ptr<cl_anchors, void (*)(cl_anchors*)> ag(anc, cl_anchors_free);
 	out.n_anchors = cl_anchors_total(anc);
 	crefs.release(); cnt.release(); common_off.release(); common.release();
-	if (half == 1) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); out.anc = ag.release(); out.cc = cc; return CL_OK; }
 	const uint64_t es_cap = reads->total_bases + 16ull * n + 4096;
 	DEV_ALLOC(ctx, out.es, es_cap); DEV_ALLOC(ctx, out.es_off, (uint64_t)n + 1); DEV_ALLOC(ctx, out.es_nt, n);
 	CL_TRY(cl_encode_reads(ctx, reads, c->refs, anc, cc, P->anchor_len, P->min_part_alt, max_rec, P->cost_mult, h_pack_bounds, n_packs, out.es.p, es_cap, out.es_off.p, out.es_nt.p, &out.es_bytes));
 	return CL_OK;
 }
 
-static void lane_main(cl_compressor* c, cl_ctx* lane, int half)
+static void lane_main(cl_compressor* c, cl_ctx* lane)
 {
 	for (;;)
 	{
 		size_t idx; cl_compressor::Prepared* job;
-		if (half == 2)
-		{	// stage-split lanes: this thread turns anchors into edit scripts, chunk after chunk
-			{
-				std::unique_lock<std::mutex> l(c->lane_mu);
-				const auto tw = std::chrono::steady_clock::now();
-				c->lane_cv.wait(l, [&]() { return c->lane_stop || !c->a2_queue.empty(); });
-				c->w_lane_idle += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
-				if (c->lane_stop) return;
-				idx = c->a2_queue.front(); c->a2_queue.pop_front();
-				job = c->prepared[idx].get();
-			}
-			lane->timing = c->ctx->timing;
-			const auto tw = std::chrono::steady_clock::now();
-			const cl_status s = job->status == CL_OK ? stage_a(c, lane, idx, job->reads, job->packs.data(), (uint32_t)job->packs.size() - 1, *job, 2) : job->status;
-			cl_timing_collect(lane);
-			{
-				std::lock_guard<std::mutex> l(c->lane_mu);
-				c->w_lane_work += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
-				if (job->status == CL_OK) { job->status = s; if (s != CL_OK) job->err = lane->err; }
-				for (auto& kv : lane->times) { auto& t = job->times[kv.first]; t.ms += kv.second.ms; t.launches += kv.second.launches; t.bytes += kv.second.bytes; t.cells += kv.second.cells; }
-				lane->times.clear();
-				job->done = true;
-			}
-			c->lane_cv.notify_all();
-			continue;
-		}
 		{
 			std::unique_lock<std::mutex> l(c->lane_mu);
 			// the lanes run at most (lanes + 2) chunks ahead of the coders: what they finish (tuple streams, ~1.5 GB per Gbase) waits in
@@ -598,19 +559,14 @@ static void lane_main(cl_compressor* c, cl_ctx* lane, int half)
 		}
 		lane->timing = c->ctx->timing;
 		const auto tw = std::chrono::steady_clock::now();
-		const cl_status s = stage_a(c, lane, idx, job->reads, job->packs.data(), (uint32_t)job->packs.size() - 1, *job, half);
+		const cl_status s = stage_a(c, lane, idx, job->reads, job->packs.data(), (uint32_t)job->packs.size() - 1, *job);
 		cl_timing_collect(lane);
 		{
 			std::lock_guard<std::mutex> l(c->lane_mu);
 			c->w_lane_work += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
 			job->status = s; if (s != CL_OK) job->err = lane->err;
 			job->times.swap(lane->times); lane->times.clear();
-			if (half == 1)
-			{	// the anchors are made: the chunks go on to the edit-script lanes IN ORDER (several anchor lanes may finish out of order)
-				job->cc = job->cc ? job->cc : 1; c->a1_finished.insert(idx);
-				while (!c->a1_finished.empty() && *c->a1_finished.begin() == c->a1_next) { c->a2_queue.push_back(c->a1_next); c->a1_finished.erase(c->a1_finished.begin()); ++c->a1_next; }
-			}
-			else job->done = true;
+			job->done = true;
 		}
 		c->lane_cv.notify_all();
 	}
@@ -628,42 +584,54 @@ static uint64_t avail_bytes(cl_ctx* ctx)
 	if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return 0; }
 	return fr + (ctx->pool.reserved - std::min(ctx->pool.reserved, ctx->pool.live_bytes));
 }
-static void prep_main(cl_compressor* c)
+static void prep_main(cl_compressor* c, cl_ctx* ctx)
 {
-	cl_ctx* ctx = c->prep_ctx;
 	for (;;)
 	{
-		size_t idx; cl_compressor::Prepared* job;
-		{
-			std::unique_lock<std::mutex> l(c->lane_mu);
-			const auto tw = std::chrono::steady_clock::now();
-			struct Lap { cl_compressor* c; std::chrono::steady_clock::time_point t; ~Lap() { c->w_prep_idle += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); } } lap_idle{ c, tw };
-			c->lane_cv.wait(l, [&]() {
-				if (c->lane_stop || c->prep_broken) return true;
-				if (c->prep_next < c->enc_chunk) return true;                        // (a chunk was coded without this thread: the chain of walk scalars is lost)
-				auto it = c->prepared.find(c->prep_next);
-				return it != c->prepared.end() && it->second->done && c->prep_next <= c->enc_chunk + 1 + c->evolve_depth;     // (far enough ahead for the chunks that may be evolved ahead)
-			});
-			if (c->lane_stop || c->prep_broken) return;
-			if (c->prep_next < c->enc_chunk) { c->prep_broken = true; c->lane_cv.notify_all(); return; }
-			idx = c->prep_next; job = c->prepared[idx].get();
+		size_t idx; cl_compressor::Prepared* job; uint32_t types_in = 0, read_id_in = 0, types_out = 0; cl_status s = CL_OK;
+		{	// one claim at a time: the scalars of chunk idx + 1 follow from those of chunk idx
+			std::lock_guard<std::mutex> claim(c->prep_claim_mu);
+			{
+				std::unique_lock<std::mutex> l(c->lane_mu);
+				const auto tw = std::chrono::steady_clock::now();
+				struct Lap { cl_compressor* c; std::chrono::steady_clock::time_point t; ~Lap() { c->w_prep_idle += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); } } lap_idle{ c, tw };
+				c->lane_cv.wait(l, [&]() {
+					if (c->lane_stop || c->prep_broken) return true;
+					if (c->prep_next < c->enc_chunk) return true;                        // (a chunk was coded without these threads: the chain of walk scalars is lost)
+					auto it = c->prepared.find(c->prep_next);
+					return it != c->prepared.end() && it->second->done && c->prep_next <= c->enc_chunk + c->prep_ctxs.size() + c->evolve_depth;     // (far enough ahead for the chunks that may be evolved ahead)
+				});
+				if (c->lane_stop || c->prep_broken) return;
+				if (c->prep_next < c->enc_chunk) { c->prep_broken = true; c->lane_cv.notify_all(); return; }
+				idx = c->prep_next; job = c->prepared[idx].get();
+				types_in = c->prep_types; read_id_in = c->prep_read_id;
+			}
+			const uint32_t n = job->reads->n_reads;
+			types_out = types_in;
+			if (job->status == CL_OK && n) s = cl_dna_batch_types(ctx, job->es.p, job->es_off.p, n, types_in, &types_out);
+			{
+				std::lock_guard<std::mutex> l(c->lane_mu);
+				if (s == CL_OK && job->status == CL_OK) { c->prep_types = types_out; c->prep_read_id += n; }
+				c->prep_next = idx + 1;
+			}
+			c->lane_cv.notify_all();
 		}
-		DnaWalked* W = nullptr; uint32_t types_out = c->prep_types; cl_status s = CL_OK;
+		DnaWalked* W = nullptr; uint32_t walked_types = types_out;
 		const uint32_t n = job->reads->n_reads;
-		if (job->status == CL_OK && n)
+		if (s == CL_OK && job->status == CL_OK && n)
 		{
 			ctx->timing = c->ctx->timing;
-			s = cl_dna_prepare_batch(ctx, c->dna, c->refs, job->es.p, job->es_off.p, job->es_nt.p, n, c->prep_types, c->prep_read_id,
-			                         job->parts.empty() ? nullptr : job->parts.data(), job->parts.empty() ? 0u : (uint32_t)job->parts.size() - 1, &W, &types_out);
+			s = cl_dna_prepare_batch(ctx, c->dna, c->refs, job->es.p, job->es_off.p, job->es_nt.p, n, types_in, read_id_in,
+			                         job->parts.empty() ? nullptr : job->parts.data(), job->parts.empty() ? 0u : (uint32_t)job->parts.size() - 1, &W, &walked_types);
 			cl_timing_collect(ctx);
+			if (s == CL_OK && walked_types != types_out) s = cl_fail(ctx, CL_E_INVALID, "dna preparation: the read types of a chunk changed between the claim and the walk");
 		}
 		{
 			std::lock_guard<std::mutex> l(c->lane_mu);
-			if (s == CL_OK && job->status == CL_OK) { job->walked = W; c->prep_types = types_out; c->prep_read_id += n; }
+			if (s == CL_OK && job->status == CL_OK) job->walked = W;
 			else { if (W) cl_dna_walked_free(W); if (job->status == CL_OK) c->prep_broken = true; }   // (the caller's thread walks this chunk itself and reports what fails)
 			job->dna_times.swap(ctx->times); ctx->times.clear();
 			job->dna_done = true;
-			c->prep_next = idx + 1;
 		}
 		c->lane_cv.notify_all();
 	}
@@ -739,10 +707,6 @@ extern "C" cl_status cl_compressor_prepare_parts(cl_compressor* c, const cl_read
 		c->evolve_depth = long_parts ? 2 : 0;
 		if (long_parts) lanes = 2;
 		if (const char* e = getenv("COLORD_HIP_ENCODE_LANES")) lanes = (uint32_t)std::min(4, std::max(1, atoi(e)));
-		// stage-split lanes: "a,b" = a lanes that make anchors only + b lanes that turn anchors into edit scripts only (a pipeline of the two
-		// halves of stage A instead of whole chunks side by side: then no kernel runs beside a copy of itself)
-		c->n_a1_lanes = 0;
-		if (const char* e = getenv("COLORD_HIP_LANE_SPLIT")) { int a1 = 0, a2 = 0; if (sscanf(e, "%d,%d", &a1, &a2) == 2 && a1 >= 1 && a2 >= 1 && a1 + a2 <= 4) { c->n_a1_lanes = (uint32_t)a1; lanes = (uint32_t)(a1 + a2); } }
 		if (const char* e = getenv("COLORD_HIP_EVOLVE_DEPTH")) c->evolve_depth = (uint32_t)std::min(3, std::max(0, atoi(e)));
 		while (ctx->lanes.size() < lanes)
 		{
@@ -753,11 +717,12 @@ extern "C" cl_status cl_compressor_prepare_parts(cl_compressor* c, const cl_read
 			ctx->lanes.push_back(x);
 		}
 		c->lane_ctx.assign(ctx->lanes.begin(), ctx->lanes.begin() + lanes);
-		c->a1_next = idx;
-		for (size_t li = 0; li < c->lane_ctx.size(); ++li) c->lane_threads.emplace_back(lane_main, c, c->lane_ctx[li], c->n_a1_lanes ? (li < c->n_a1_lanes ? 1 : 2) : 0);
+		for (size_t li = 0; li < c->lane_ctx.size(); ++li) c->lane_threads.emplace_back(lane_main, c, c->lane_ctx[li]);
 		// the DNA preparation thread: only from the first chunk on (its walk scalars chain from chunk to chunk)
 		if (idx == 0 && c->enc_chunk == 0 && !getenv("COLORD_HIP_NO_DNA_PREP"))
 		{
+			// ONE worker.  (Two, claiming alternate chunks, were measured in round 5 when this chain was the busiest queue of a pass — 87 %: each
+			// one's sort took twice as long beside the other's, 18.7 against 18.7 s per pass: the machine is the bound, not the chain.)
 			if (!ctx->prep)
 			{
 				cl_ctx* x = nullptr;
@@ -766,9 +731,10 @@ extern "C" cl_status cl_compressor_prepare_parts(cl_compressor* c, const cl_read
 				cl_ctx_set_priority(x, getenv("COLORD_HIP_NO_STREAM_PRIO") ? 0 : -1, CL_ROLE_PREP);  // (works ahead: takes what the lanes and coders leave)
 				ctx->prep = x;
 			}
-			c->prep_ctx = ctx->prep; c->prep_next = 0; c->prep_on = true;
+			c->prep_ctxs.assign(1, ctx->prep);
+			c->prep_next = 0; c->prep_on = true;
 			cl_dna_coder_state(c->dna, &c->prep_types, &c->prep_read_id);
-			c->prep_thread = std::thread(prep_main, c);
+			for (cl_ctx* pc : c->prep_ctxs) c->prep_threads.emplace_back(prep_main, c, pc);
 		}
 		// the quality preparation thread: level 1 only (above, the contexts take flags from the edit scripts), quality context of its own
 		if (c->qual && c->P.level <= 1 && c->qctx && c->qctx != ctx && !getenv("COLORD_HIP_NO_QUAL_PREP"))
@@ -829,7 +795,7 @@ extern "C" cl_status cl_compressor_encode(cl_compressor* c, const cl_reads* read
 			auto lap = [&](double& acc) { const auto t = std::chrono::steady_clock::now(); acc += std::chrono::duration<double>(t - tw).count(); tw = t; };
 			c->lane_cv.wait(l, [&]() { return it->second->done; });
 			lap(c->w_enc_lane);
-			if (c->prep_on && !c->prep_broken && c->prep_next <= idx) c->lane_cv.wait(l, [&]() { return it->second->dna_done || c->prep_broken; });
+			if (c->prep_on && !c->prep_broken) c->lane_cv.wait(l, [&]() { return it->second->dna_done || c->prep_broken; });
 			lap(c->w_enc_prep);
 			if (c->qprep_on && c->qprep_next <= idx) c->lane_cv.wait(l, [&]() { return it->second->q_done; });
 			lap(c->w_enc_qprep);

@@ -411,24 +411,6 @@ def test_cli_independent_domains_decode_side_by_side(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(CLI), reason="needs colord_amd/colord_hip")
-def test_cli_quad_aligner_without_history_writes_the_same_archive(tmp_path):
-    """`COLORD_HIP_QUAD_NOHIST`: the four-per-wave aligner keeps a checkpoint every 16 columns instead of its history in HBM and its
-    tracebacks recompute their windows into LDS, four gaps in lock step (wv::quad_walk) — 1 / 16 of the bytes, measured 1.25 x the
-    kernel time, hence not the default.  Same history, same walk: the archive's streams are the default's, byte for byte."""
-    from colord_amd import ontsim
-    table = ontsim.ReadTable(seed=59, genome_len=3_000_000, target_bases=50_000_000)
-    fq = str(tmp_path / "in.fastq")
-    ontsim.write_fastq(table, fq)
-    a, b = str(tmp_path / "hist.colord"), str(tmp_path / "nohist.colord")
-    subprocess.check_call([CLI, "compress-ont", "-k", "25", "-a", "22", "--chunk-bases", "20000000", fq, a])
-    subprocess.check_call([CLI, "compress-ont", "-k", "25", "-a", "22", "--chunk-bases", "20000000", fq, b], env=dict(os.environ, COLORD_HIP_QUAD_NOHIST="1"))
-    _same_streams(a, b)
-    subprocess.check_call([CLI, "compress-pbhifi", "-p", "ratio", fq, a])
-    subprocess.check_call([CLI, "compress-pbhifi", "-p", "ratio", fq, b], env=dict(os.environ, COLORD_HIP_QUAD_NOHIST="1"))
-    _same_streams(a, b)
-
-
-@pytest.mark.skipif(not os.path.exists(CLI), reason="needs colord_amd/colord_hip")
 def test_cli_stream_input_writes_the_same_archive(tmp_path):
     """`--stream-input`: bounded device memory — the input is read three times (k-mers; reference reads; coding) and a chunk leaves HBM after
     every pass; in the coding pass a loader thread keeps a window of four chunks resident ahead of the coders (the reference reads its
