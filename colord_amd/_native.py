@@ -11,7 +11,7 @@ import os
 # streams that share a queue serialise (bench.py has the measurement); only effective before the runtime initialises
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcolord_hip.so")
+LIB_PATH = os.environ.get("COLORD_HIP_LIBRARY") or os.path.join(_HERE, "libcolord_hip.so")    # (COLORD_HIP_LIBRARY: another build of the same library, for A/B measurements)
 
 CL_OK, CL_E_INVALID, CL_E_HIP, CL_E_CAPACITY, CL_E_NOMEM, CL_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 

@@ -503,8 +503,8 @@ __global__ __launch_bounds__(256) void k_fill_sidx(const uint64_t* __restrict__ 
 	const uint64_t a = sym_off[r] - s0, b = sym_off[r + 1] - s0;
 	if (a == b) return;
 	const uint32_t part = part_of_read(lay, r), pl = lay.rank ? lay.rank[part] : part;
-	const uint64_t tbase = lay.group_base[pl >> 6] - lay.part_sym_start[part] * 64 + (pl & 63);
-	for (uint64_t i = a + lane; i < b; i += 64) sidx[i] = (uint32_t)(tbase + i * 64);
+	const uint64_t gb = lay.group_base[pl >> 6], p0 = lay.part_sym_start[part];
+	for (uint64_t i = a + lane; i < b; i += 64) sidx[i] = (uint32_t)trip_slot(gb, pl & 63, i - p0);
 }
 // ---- D1b: bases of plain reads, one wave per read, one lane per base (dna_coder.cpp:1178-1227) ----------
 __global__ __launch_bounds__(256) void k_dna_plain(const FamTab* __restrict__ ftp, const uint8_t* __restrict__ es, const uint64_t* __restrict__ es_off,
@@ -1117,7 +1117,7 @@ cl_status dna_group_prepare(cl_ctx* ctx, cl_dna_coder* D, DnaWalked& W, uint32_t
 	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return plen[a] > plen[b]; });
 	for (uint32_t i = 0; i < np; ++i) { rank[order[i]] = i; plen_r[i] = plen[order[i]]; }
 	std::vector<uint64_t> gbase(ng + 1, 0);
-	for (uint32_t g = 0; g < ng; ++g) gbase[g + 1] = gbase[g] + (uint64_t)plen_r[g * 64] * 64;
+	for (uint32_t g = 0; g < ng; ++g) gbase[g + 1] = gbase[g] + trip_group_words(plen_r[g * 64]);
 	if (gbase[ng] >= (1ull << 32)) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_dna_encode: group too large for 32-bit triple indices");
 	G.trip_words = gbase[ng];
 	DevBuf<uint64_t> d_sym_start; DevBuf<uint32_t> d_pfirst, d_rank;

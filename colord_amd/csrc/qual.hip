@@ -427,9 +427,23 @@ extern "C" void cl_qual_coder_free(cl_qual_coder* q) { delete q; }
 // CEntrComprQuals::Compress for a batch of whole parts (entr_qual.h:100-135).  Models persist across calls.
 namespace {
 __global__ __launch_bounds__(256) void k_qual_check(const uint8_t* __restrict__ q, uint64_t n, uint32_t* __restrict__ bad)
-{
+{	// every byte in '!' .. '!' + 95; sixteen bytes per load (a byte per lane was 26 ms per Gbase: 64-byte requests)
+	const uint64_t head = n < 16 ? n : ((16 - ((uint64_t)(size_t)q & 15)) & 15);    // bytes before the first 16-byte boundary
+	const uint64_t n16 = (n - head) / 16, tail0 = head + n16 * 16;
 	bool b = false;
-	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) { const uint32_t v = q[i] - 33u; b |= v > 95u; }
+	const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x, stride = (uint64_t)gridDim.x * 256;
+	const uint4* v = (const uint4*)(q + head);
+	for (uint64_t i = t; i < n16; i += stride)
+	{
+		const uint4 w = v[i];
+		const uint32_t x[4] = { w.x, w.y, w.z, w.w };
+#pragma unroll
+		for (int k = 0; k < 4; ++k)
+#pragma unroll
+			for (int s = 0; s < 32; s += 8) b |= (((x[k] >> s) & 0xffu) - 33u) > 95u;
+	}
+	if (t < head) b |= ((uint32_t)q[t] - 33u) > 95u;
+	if (tail0 + t < n && t < 16) b |= ((uint32_t)q[tail0 + t] - 33u) > 95u;
 	if (__ballot(b) && (threadIdx.x & 63) == 0) atomicOr(bad, 1u);
 }
 } // namespace
@@ -498,7 +512,7 @@ cl_status qual_prepare(cl_ctx* ctx, cl_qual_coder* Q, const cl_reads* R, const u
 		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return plen[a] > plen[b]; });
 		for (uint32_t i = 0; i < np; ++i) { rank[order[i]] = i; plen_r[i] = plen[order[i]]; }
 		gbase[0] = 0;
-		for (uint32_t g = 0; g < ng; ++g) gbase[g + 1] = gbase[g] + (uint64_t)plen_r[g * 64] * 64;
+		for (uint32_t g = 0; g < ng; ++g) gbase[g + 1] = gbase[g] + trip_group_words(plen_r[g * 64]);
 		if (gbase[ng] >= (1ull << 32)) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_qual_encode: group too large for 32-bit triple indices");
 		G.trip_words = gbase[ng];
 		DevBuf<uint64_t> d_sym_start; DevBuf<uint32_t> d_pfirst, d_rank;

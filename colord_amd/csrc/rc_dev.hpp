@@ -3,8 +3,7 @@
 //
 // A part (= one range-coder restart, entr_qual.h:68-79 / entr_read.h:69-77) is coded by ONE lane: the
 // recurrence on (low, range) is a dependent chain.  64 consecutive parts form a group handled by one
-// wavefront; the triples of a group are stored interleaved — index = group_base + pos * 64 + lane — so that
-// every step of the wavefront is one coalesced 512-byte load.
+// wavefront; the triples of a group are stored in runs of 8 symbols per part, the 64 parts' runs side by side (trip_slot below).
 #pragma once
 #include "common.hpp"
 #include <type_traits>
@@ -41,6 +40,20 @@ static inline cl_status cl_inv_table(cl_ctx* ctx, const uint64_t** out)
 	return CL_OK;
 }
 
+// Where a part's triples live.  A group = 64 parts coded by one wave; inside a group RUNS of TRIP_RUN consecutive symbols of a part are
+// contiguous (one 64-byte sector) and the 64 parts' runs of the same positions lie side by side (4 KB):
+//     slot = group_base + (pos / TRIP_RUN) * 64 * TRIP_RUN + place * TRIP_RUN + pos % TRIP_RUN.
+// Rounds 1-4 interleaved symbol by symbol (pos * 64 + place): every step of the coder one coalesced 512-byte load, but the model kernels —
+// which write the triples in CONTEXT order, scattered over the stream — hit a different sector with every 8-byte store, whose other seven
+// slots belonged to seven other parts (PMC: 32 GB written per launch of k_evolve_small for 8.4 GB of triples).  With runs, symbols of a
+// context that sit within a few positions of each other (a stretch of equal qualities, the tuple types of consecutive tuples) share their
+// sector and leave the wave as one write; the coder fetches a lane's run with its round of TRIP_RUN symbols.
+#ifndef CL_TRIP_RUN
+#define CL_TRIP_RUN 8
+#endif
+constexpr uint32_t TRIP_RUN = CL_TRIP_RUN;                                    // (-DCL_TRIP_RUN=1 builds the symbol-by-symbol interleave of rounds 1-4 for an A/B)
+__host__ __device__ inline uint64_t trip_slot(uint64_t group_base, uint32_t place, uint64_t pos) { return group_base + (pos / TRIP_RUN) * (64ull * TRIP_RUN) + (uint64_t)place * TRIP_RUN + pos % TRIP_RUN; }
+__host__ __device__ inline uint64_t trip_group_words(uint64_t longest_part) { return (longest_part + TRIP_RUN - 1) / TRIP_RUN * TRIP_RUN * 64; }   // triples of a group whose longest part has that many symbols
 struct TripLayoutDev {
 	const uint32_t* part_first_read;   // np + 1 read indices (absolute)
 	const uint64_t* part_sym_start;    // np + 1 stream positions (relative to the call's first symbol)
@@ -59,7 +72,7 @@ __device__ inline uint32_t part_of_read(const TripLayoutDev& L, uint32_t r)
 __device__ inline uint32_t trip_index(const TripLayoutDev& L, uint32_t part, uint64_t stream_pos)
 {
 	const uint32_t pl = L.rank ? L.rank[part] : part;
-	return (uint32_t)(L.group_base[pl >> 6] + (stream_pos - L.part_sym_start[part]) * 64 + (pl & 63));
+	return (uint32_t)trip_slot(L.group_base[pl >> 6], pl & 63, stream_pos - L.part_sym_start[part]);
 }
 
 // Output bytes of one part.  The coder emits the top byte of `low` on every renormalisation step and only shifts `low` in
@@ -125,8 +138,10 @@ static __global__ __launch_bounds__(64) void k_range_code(const triple_t* __rest
 #pragma unroll
 	for (int d = 32; d > 0; d >>= 1) { uint32_t t = __shfl_xor(lmax, d, 64); lmax = t > lmax ? t : lmax; }
 	if (lmax == 0) { if (live) { if (!overflow) store_be64(outp, 0); part_size[p] = overflow ? ~0ULL : 8; } return; }
-	const triple_t* src = trip + group_base[blockIdx.x] + threadIdx.x;
+	const triple_t* src = trip + group_base[blockIdx.x] + threadIdx.x * TRIP_RUN;   // this lane's runs: symbol q at src[at(q)]
+	auto at = [](uint32_t q) -> uint64_t { return (uint64_t)(q / TRIP_RUN) * (64 * TRIP_RUN) + q % TRIP_RUN; };
 	constexpr uint32_t U = 8;
+	static_assert(U % TRIP_RUN == 0, "a round of the coder takes whole runs of a lane's triples");
 	// three stages ahead of the chain: symbols two rounds ahead, their reciprocals one round ahead (looked up from the symbols
 	// fetched the round before), the round being coded.  The three register sets trade roles from round to round (no copies).
 	triple_t A[U], B[U], C[U]; uint64_t iA[U], iB[U], iC[U];
@@ -135,15 +150,28 @@ static __global__ __launch_bounds__(64) void k_range_code(const triple_t* __rest
 	const uint64_t NEUTRAL_X = (1ULL << 21) | 1ULL, NEUTRAL_Y = ~0ULL;
 	const uint32_t last = lmax - 1;
 #pragma unroll
-	for (uint32_t u = 0; u < U; ++u) { A[u] = src[(uint64_t)(u < last ? u : last) * 64]; B[u] = src[(uint64_t)(U + u < last ? U + u : last) * 64]; }
+	for (uint32_t u = 0; u < U; ++u) { A[u] = src[at(u < last ? u : last)]; B[u] = src[at(U + u < last ? U + u : last)]; }
 #pragma unroll
 	for (uint32_t u = 0; u < U; ++u) iA[u] = inv_tab[A[u] & 0x1fffff];
 	// one round: fetch `far` (two rounds ahead), look up the reciprocals of `nxt`, code `cur` with `icur`
 	// (all_active: every lane of the wave still has symbols in this round — no neutral symbols to select; decided per round, wave-uniform)
 	auto round = [&](auto all_active, uint32_t pos, const triple_t (&cur)[U], const uint64_t (&icur)[U], const triple_t (&nxt)[U], uint64_t (&inxt)[U], triple_t (&far)[U])
 	{
+		{	// prefetch: the lane's run two rounds ahead — whole (four 16-byte loads) while it lies inside the group's longest part, else symbol by
+			// symbol with the index clamped (never a pointer select)
+			const uint32_t q0 = pos + 2 * U;                                          // (a multiple of TRIP_RUN: rounds start at multiples of U)
+			if (TRIP_RUN == U && q0 + U - 1 <= last)
+			{
+				const ulonglong2* v = (const ulonglong2*)(src + at(q0));
 #pragma unroll
-		for (uint32_t u = 0; u < U; ++u) { uint32_t q = pos + 2 * U + u; far[u] = src[(uint64_t)(q < last ? q : last) * 64]; }   // prefetch (index clamped, never a pointer select)
+				for (uint32_t u = 0; u < U; u += 2) { const ulonglong2 w = v[u / 2]; far[u] = w.x; far[u + 1] = w.y; }
+			}
+			else
+			{
+#pragma unroll
+				for (uint32_t u = 0; u < U; ++u) { const uint32_t q = q0 + u; far[u] = src[at(q < last ? q : last)]; }
+			}
+		}
 #pragma unroll
 		for (uint32_t u = 0; u < U; ++u) inxt[u] = inv_tab[nxt[u] & 0x1fffff];
 #pragma unroll
