@@ -463,6 +463,33 @@ def cpu_baseline_and_size_check(ctx, qctx, sample_bases: float, coverage: float,
             rc8 = subprocess.call([ref, "compress-ont", "-t", "8"] + ka + [fq8, os.path.join(tmp, "ref8.colord")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             dt8 = time.time() - t0
             cb["t8"] = {"value": nb8 / dt8 / 1e9 if rc8 == 0 else None, "unit": "Gbases/s", "cores": 8, "sample": f"the same command with -t 8 on {nb8} bases of the same recipe; {dt8:.2f} s wall" + ("" if rc8 == 0 else f" (exit status {rc8})")}
+            # the inverse path on the same small sample: `colord_hip decompress` (host code: one dependent chain per stream and model domain,
+            # three stream threads as the reference's decompressor) beside the reference's own decompressor on the reference's archive
+            if rc8 == 0 and os.path.exists(ours):
+                dec = {}
+                for who, exe, arc in (("colord_hip", ours, os.path.join(tmp, "ref8.colord")), ("reference", ref, os.path.join(tmp, "ref8.colord"))):
+                    t0 = time.time()
+                    rcd = subprocess.call([exe, "decompress", arc, os.path.join(tmp, "dec8.fastq")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                    dtd = time.time() - t0
+                    dec[who] = {"value": nb8 / dtd / 1e9 if rcd == 0 else None, "unit": "Gbases/s", "seconds": round(dtd, 2), "threads": 3}
+                    if rcd == 0 and who == "colord_hip":
+                        import hashlib
+                        h = hashlib.sha256()
+                        with open(os.path.join(tmp, "dec8.fastq"), "rb") as f:
+                            for blk in iter(lambda: f.read(1 << 24), b""):
+                                h.update(blk)
+                        dec["sha256_colord_hip"] = h.hexdigest()
+                    elif rcd == 0:
+                        import hashlib
+                        h = hashlib.sha256()
+                        with open(os.path.join(tmp, "dec8.fastq"), "rb") as f:
+                            for blk in iter(lambda: f.read(1 << 24), b""):
+                                h.update(blk)
+                        dec["same_output_as_reference"] = bool(h.hexdigest() == dec.get("sha256_colord_hip"))
+                    if os.path.exists(os.path.join(tmp, "dec8.fastq")):
+                        os.remove(os.path.join(tmp, "dec8.fastq"))
+                dec["sample"] = f"the reference's archive of the {nb8}-base sample above, file to FASTQ; both decoders are host code (no GPU)"
+                cb["decompress"] = dec
             os.remove(fq8)
         except Exception as e:
             cb["t8"] = {"value": None, "error": repr(e)[:200]}
@@ -579,13 +606,13 @@ def multi_gpu_cli_leg(rank: int, world: int, args, k: int, a: int):
 
 
 def load_traffic(kernel: str):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (tools/pmc_traffic.py -> profiles/r03_traffic.json)."""
-    path = os.path.join(ROOT, "profiles", "r04_traffic.json")
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "r03_traffic.json")
-    if not os.path.exists(path):
+    """HBM bytes per launch of `kernel` from the newest committed PMC passes (tools/pmc_traffic.py -> profiles/r0N_traffic.json)."""
+    path = next((p for p in (os.path.join(ROOT, "profiles", f"r0{r}_traffic.json") for r in (5, 4, 3)) if os.path.exists(p)), None)
+    if path is None:
         return None, None
     t = json.load(open(path))
+    # (the file says which commit of the kernels it was measured on: `measured_at_commit`, written when it is copied into profiles/)
+    t["source"] = f"{os.path.basename(path)} (kernels as of commit {t.get('measured_at_commit', 'unknown')}): " + str(t.get("source"))
     key = kernel.split("<")[0].strip()
     if key == "k_sort_scatter":                             # (with / without a value array: tools/pmc_traffic.py keeps them apart)
         key += "<true>" if ", true" in kernel else "<false>"
