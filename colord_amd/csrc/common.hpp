@@ -348,7 +348,7 @@ struct cl_ctx {
 	int n_cu = 256;
 	uint64_t* inv_tab = nullptr;                 // floor((2^64-1) / t) for t < 2^21: the interval coder's division table (rc_dev.hpp), made at first use
 	uint64_t* slots_h = nullptr; uint64_t* slots_d = nullptr; uint32_t slot_next = 0;   // pinned, device-mapped words that kernels write results the host waits for into (cl_slot)
-	struct ScanCtl { unsigned long long* p = nullptr; uint64_t words = 0, got = 0; };
+	struct ScanCtl { unsigned long long* p = nullptr; uint64_t words = 0, got = 0; uint32_t gen = 0; unsigned long long tickets = 0; };   // gen: generation of the last scan (0: buffer not zeroed yet); tickets: tile tickets drawn so far
 	std::map<void*, ScanCtl> scan_ctl;           // status words of the look-back scans, one buffer per stream of the context (scan.hip; owner thread only)
 	std::vector<cl_ctx*> lanes;                  // encode lanes of cl_compressor (contexts of their own; kept for the next compressor, freed with this context)
 	cl_ctx* prep = nullptr;                      // context of cl_compressor's DNA preparation thread (same life cycle)

@@ -19,15 +19,21 @@ template<typename TOut> __device__ inline TOut wave_incl_scan_t(TOut v)
 // handed out by a ticket, so every tile a tile waits for has been started.  The status words carry their value WITH their flag
 // (8-byte agent-scope relaxed atomics on both sides: MI355X_MICROARCH.md, "valid forms", data-is-the-flag granules).
 constexpr uint32_t LB_ITEMS = 16, LB_TILE = SCAN_THREADS * LB_ITEMS;
-constexpr unsigned long long LB_AGG = 1ull << 62, LB_PREFIX = 2ull << 62, LB_VAL = (1ull << 62) - 1;
+constexpr unsigned long long LB_AGG = 1ull << 62, LB_PREFIX = 2ull << 62, LB_VAL = (1ull << 44) - 1;
+// A status word = flag (2 bits) | generation of the scan that wrote it (18 bits) | value (44 bits).  The buffer of a stream is reused from
+// scan to scan WITHOUT being zeroed in between (round 5: the memset before every scan was a quarter of a pass's dispatches — 77 per chunk on
+// an encode lane's main queue): a word of another generation reads as "not there yet", the tile ticket counts on from scan to scan (the
+// launch is told where it starts).  The buffer is zeroed when the generations wrap, every 2^18 - 1 scans.
+constexpr uint32_t LB_GEN_BITS = 18, LB_GEN_SHIFT = 44;
 // ctl[0]: ticket, ctl[1..]: status of tile 0, 1, ... (zeroed before the launch).  total_out (optional): receives the sum of all.
 template<typename TIn, typename TOut>
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_lookback(const TIn* in, uint64_t n, TOut* out, unsigned long long* __restrict__ ctl, TOut* total_out, unsigned long long* total64)
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_lookback(const TIn* in, uint64_t n, TOut* out, unsigned long long* __restrict__ ctl, TOut* total_out, unsigned long long* total64, unsigned long long ticket_base, uint32_t gen)
 {
 	__shared__ TOut sh[4];
 	__shared__ unsigned long long s_excl;
 	__shared__ uint32_t s_tile;
-	if (threadIdx.x == 0) s_tile = (uint32_t)atomicAdd(ctl, 1ull);
+	if (threadIdx.x == 0) s_tile = (uint32_t)(atomicAdd(ctl, 1ull) - ticket_base);
+	const unsigned long long G = (unsigned long long)gen << LB_GEN_SHIFT;
 	__syncthreads();
 	const uint32_t tile = s_tile, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	unsigned long long* status = ctl + 1;
@@ -43,15 +49,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_lookback(const TIn* in, u
 	if (w == 0)
 	{
 		unsigned long long excl = 0;
-		if (tile == 0) { if (lane == 0) __hip_atomic_store(status, LB_PREFIX | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+		if (tile == 0) { if (lane == 0) __hip_atomic_store(status, LB_PREFIX | G | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 		else
 		{
-			if (lane == 0) __hip_atomic_store(status + tile, LB_AGG | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (lane == 0) __hip_atomic_store(status + tile, LB_AGG | G | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			// lanes look at tiles hi - 1 - lane; the nearest PREFIX ends the walk, everything nearer is an AGGREGATE (or not there yet: read again)
 			for (int64_t hi = tile; hi > 0; )
 			{
 				const int64_t j = hi - 1 - (int64_t)lane;
-				unsigned long long x = j >= 0 ? __hip_atomic_load(status + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : LB_PREFIX;   // (before tile 0: an empty prefix)
+				unsigned long long x = j >= 0 ? __hip_atomic_load(status + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (LB_PREFIX | G);   // (before tile 0: an empty prefix)
+				if (((x >> LB_GEN_SHIFT) & ((1u << LB_GEN_BITS) - 1)) != gen) x = 0;       // written by an earlier scan: not there yet
 				const uint64_t pref = __ballot((x >> 62) == 2);
 				const uint32_t stop = pref ? (uint32_t)__builtin_ctzll(pref) : 64u;        // the nearest lane that holds a PREFIX
 				const uint64_t need = stop >= 63 ? ~0ull : ((2ull << stop) - 1);
@@ -63,7 +70,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_lookback(const TIn* in, u
 				if (pref) break;
 				hi -= 64;
 			}
-			if (lane == 0) __hip_atomic_store(status + tile, LB_PREFIX | (excl + (unsigned long long)total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (lane == 0) __hip_atomic_store(status + tile, LB_PREFIX | G | ((excl + (unsigned long long)total) & LB_VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 		if (lane == 0) s_excl = excl;
 	}
@@ -93,10 +100,16 @@ cl_status scan_lookback(cl_ctx* ctx, const TIn* d_in, TOut* d_out, uint64_t n, T
 		const uint64_t want = std::max<uint64_t>((uint64_t)tiles + 1, 1u << 16);
 		void* q = nullptr;
 		if (ctx->pool.get(want * 8, &q, &C.got, ctx->pool_id) != hipSuccess) return cl_fail(ctx, CL_E_NOMEM, "scan_lookback: no memory for the status words");
-		C.p = (unsigned long long*)q; C.words = want;
+		C.p = (unsigned long long*)q; C.words = want; C.gen = 0;
 	}
-	HIP_TRY(ctx, hipMemsetAsync(C.p, 0, ((uint64_t)tiles + 1) * 8, st));
-	LAUNCH(ctx, (k_scan_lookback<TIn, TOut>), tiles, SCAN_THREADS, d_in, n, d_out, C.p, d_total, d_total64);
+	if (C.gen == 0 || C.gen + 1 >= (1u << LB_GEN_BITS))
+	{	// a new buffer, or the generations wrap: every word (and the ticket) back to zero
+		HIP_TRY(ctx, hipMemsetAsync(C.p, 0, C.words * 8, st));
+		C.gen = 0; C.tickets = 0;
+	}
+	++C.gen;
+	const unsigned long long ticket_base = C.tickets; C.tickets += tiles;
+	LAUNCH(ctx, (k_scan_lookback<TIn, TOut>), tiles, SCAN_THREADS, d_in, n, d_out, C.p, d_total, d_total64, ticket_base, C.gen);
 	HIP_TRY(ctx, hipGetLastError());
 	return CL_OK;
 }
