@@ -3,7 +3,8 @@
 //
 // A part (= one range-coder restart, entr_qual.h:68-79 / entr_read.h:69-77) is coded by ONE lane: the
 // recurrence on (low, range) is a dependent chain.  64 consecutive parts form a group handled by one
-// wavefront; the triples of a group are stored in runs of 8 symbols per part, the 64 parts' runs side by side (trip_slot below).
+// wavefront; the triples of a group are stored interleaved — index = group_base + pos * 64 + lane (trip_slot below) — so that
+// every step of the wavefront is one coalesced 512-byte load.
 #pragma once
 #include "common.hpp"
 #include <type_traits>
@@ -40,18 +41,18 @@ static inline cl_status cl_inv_table(cl_ctx* ctx, const uint64_t** out)
 	return CL_OK;
 }
 
-// Where a part's triples live.  A group = 64 parts coded by one wave; inside a group RUNS of TRIP_RUN consecutive symbols of a part are
-// contiguous (one 64-byte sector) and the 64 parts' runs of the same positions lie side by side (4 KB):
-//     slot = group_base + (pos / TRIP_RUN) * 64 * TRIP_RUN + place * TRIP_RUN + pos % TRIP_RUN.
-// Rounds 1-4 interleaved symbol by symbol (pos * 64 + place): every step of the coder one coalesced 512-byte load, but the model kernels —
-// which write the triples in CONTEXT order, scattered over the stream — hit a different sector with every 8-byte store, whose other seven
-// slots belonged to seven other parts (PMC: 32 GB written per launch of k_evolve_small for 8.4 GB of triples).  With runs, symbols of a
-// context that sit within a few positions of each other (a stretch of equal qualities, the tuple types of consecutive tuples) share their
-// sector and leave the wave as one write; the coder fetches a lane's run with its round of TRIP_RUN symbols.
+// Where a part's triples live.  A group = 64 parts coded by one wave, interleaved symbol by symbol: slot = group_base + pos * 64 + place —
+// every step of the coder is one coalesced 512-byte load.  The price is paid by the model kernels, which write the triples in CONTEXT order:
+// every 8-byte store hits a sector whose other slots belong to other parts (PMC: 32 GB written per launch of k_evolve_small for 8.4 GB of
+// triples).  TRIP_RUN > 1 keeps RUNS of that many consecutive symbols of a part together instead (a 64-byte sector for 8), the 64 parts' runs
+// side by side: slot = group_base + (pos / RUN) * 64 * RUN + place * RUN + pos % RUN.  Measured in round 5 with RUN = 8 (-DCL_TRIP_RUN=8, the
+// two builds interleaved at 50 Gbases): the model kernels write exactly as many bytes as before (PMC 41.0 / 25.4 / 11.9 GB per launch of
+// k_evolve_small / k_dna_evolve / k_long_apply: symbols of one context that are neighbours in the stream are too rare to share sectors), the
+// coder takes 7 % longer, the pass is the same — so the default stays 1.
 #ifndef CL_TRIP_RUN
-#define CL_TRIP_RUN 8
+#define CL_TRIP_RUN 1
 #endif
-constexpr uint32_t TRIP_RUN = CL_TRIP_RUN;                                    // (-DCL_TRIP_RUN=1 builds the symbol-by-symbol interleave of rounds 1-4 for an A/B)
+constexpr uint32_t TRIP_RUN = CL_TRIP_RUN;
 __host__ __device__ inline uint64_t trip_slot(uint64_t group_base, uint32_t place, uint64_t pos) { return group_base + (pos / TRIP_RUN) * (64ull * TRIP_RUN) + (uint64_t)place * TRIP_RUN + pos % TRIP_RUN; }
 __host__ __device__ inline uint64_t trip_group_words(uint64_t longest_part) { return (longest_part + TRIP_RUN - 1) / TRIP_RUN * TRIP_RUN * 64; }   // triples of a group whose longest part has that many symbols
 struct TripLayoutDev {

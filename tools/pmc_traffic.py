@@ -33,7 +33,7 @@ PATTERN = {
     "k_table_insert": ("read_b64", "write_b128"),          # regions of 16-byte slots written out whole, coalesced
     "k_match": ("gather_b64x8", "write_b64"),
     "k_align_wave": ("read_b64", "write_b64"),             # history words, lane-contiguous
-    "k_align_quad": ("read_b64", "write_b64"),
+    "k_align_quad_rows": ("read_b128", "write_b128"),  # 16-byte history pairs, block-major
     "k_align_small": ("read_b64", "write_b64"),
     "k_emit_write": ("read_b32", "write_b64"),
     "k_emit_count": ("read_b32", "write_b32"),

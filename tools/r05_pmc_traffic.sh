@@ -1,5 +1,5 @@
 #!/bin/bash
-# (round 5; SUF and extra environment from the caller, e.g. SUF=_nohist COLORD_HIP_QUAD_NOHIST=1)
+# (round 5; SUF and extra environment from the caller, e.g. SUF=_x SOME_KNOB=1)
 # Calibrated PMC traffic passes (FETCH_SIZE / WRITE_SIZE separately, MI355X_MICROARCH.md HBM section) on a 2-Gbase prefix of the
 # bench recipe at the run's k / a -> gpurun_out/r05t$SUF/r05_traffic.json (copied to profiles/ by hand).  Run from the repo root on the GPU box.
 set -x

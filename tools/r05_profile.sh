@@ -9,6 +9,7 @@ cp $KS gpurun_out/$T/kernel_stats.csv
 python tools/queue_busy.py $KT > gpurun_out/$T/queue_busy.txt 2>&1
 python tools/window_dump.py $KT 8.0 1.2 0.5 > gpurun_out/$T/window.txt 2>&1
 python tools/lane_gaps.py $KT > gpurun_out/$T/lane_gaps.txt 2>&1
+python tools/copy_top.py $KT > gpurun_out/$T/copy_top.txt 2>&1
 python - $KT > gpurun_out/$T/kernel_minmax.txt <<'PY'
 import csv, sys
 from collections import defaultdict
