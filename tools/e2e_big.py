@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""T_e2e at scale, once: a FASTQ of `bases` (default 20 G) of the bench recipe written by the host generator, then `colord_hip compress-ont
+-k 25 -a 22 --part-symbols 65536 -v` file -> archive, resident input and --stream-input (bounded device memory).  Prints the phase stamps.
+Needs 2 bytes of disk per base (checked first).  Usage: tools/e2e_big.py [bases]"""
+import os, shutil, subprocess, sys, tempfile, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from colord_amd import ontsim
+bases = float(sys.argv[1]) if len(sys.argv) > 1 else 2e10
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+cli = os.path.join(root, "colord_amd", "colord_hip")
+base_dir = os.environ.get("TMPDIR", "/tmp")
+free = shutil.disk_usage(base_dir).free
+print(f"{base_dir}: {free / 1e9:.0f} GB free; need {2.6 * bases / 1e9:.0f} GB", flush=True)
+if free < 2.6 * bases:
+    bases = max(1e9, free / 2.6 * 0.9)
+    print(f"reduced to {bases / 1e9:.1f} Gbases", flush=True)
+t = ontsim.ReadTable(seed=41, genome_len=max(1_000_000, int(bases / 16.7)), target_bases=int(bases))
+with tempfile.TemporaryDirectory(dir=base_dir) as tmp:
+    fq = os.path.join(tmp, "in.fastq")
+    t0 = time.time(); nb = ontsim.write_fastq(t, fq)
+    print(f"fastq: {nb} bases, {os.path.getsize(fq)} bytes, written in {time.time() - t0:.1f} s", flush=True)
+    for name, extra in (("resident", []), ("stream-input", ["--stream-input"])):
+        t0 = time.time()
+        r = subprocess.run([cli, "compress-ont", "-v", "-k", "25", "-a", "22", "--part-symbols", "65536"] + extra + [fq, os.path.join(tmp, "a.colord")], capture_output=True, text=True)
+        dt = time.time() - t0
+        print(f"{name}: exit {r.returncode}, {dt:.2f} s = {nb / dt / 1e9:.3f} Gbases/s, archive {os.path.getsize(os.path.join(tmp, 'a.colord')) if r.returncode == 0 else 0} bytes", flush=True)
+        print("\n".join(l for l in r.stderr.splitlines() if l.startswith("[") or l.startswith("colord_hip"))[-1500:], flush=True)
