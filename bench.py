@@ -432,6 +432,7 @@ def cpu_baseline_and_size_check(ctx, qctx, sample_bases: float, coverage: float,
     with tempfile.TemporaryDirectory() as tmp:
         fq = os.path.join(tmp, "sample.fastq")
         n_bases = ontsim.write_fastq(table, fq)
+        os.sync()                                           # (the input's own write-back is not part of what is timed: without this the timed command's output waits behind 10 GB of dirty pages)
         ka = ["-k", str(k), "-a", str(a)]
         # (the unmodified reference has been seen to die of SIGSEGV on a 256-thread host, once in several runs of the same command: it
         # is run again — then with fewer threads — before the baseline is given up; `cores` reports the threads of the run that counted)
@@ -459,6 +460,7 @@ def cpu_baseline_and_size_check(ctx, qctx, sample_bases: float, coverage: float,
             t8 = ontsim.ReadTable(seed=101, genome_len=max(1_000_000, int(sample_bases / coverage)), target_bases=int(sample_bases / 5))
             fq8 = os.path.join(tmp, "sample_t8.fastq")
             nb8 = ontsim.write_fastq(t8, fq8)
+            os.sync()
             t0 = time.time()
             rc8 = subprocess.call([ref, "compress-ont", "-t", "8"] + ka + [fq8, os.path.join(tmp, "ref8.colord")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             dt8 = time.time() - t0
@@ -548,6 +550,7 @@ def e2e_cli(bases: float, coverage: float, k: int, a: int, part_symbols: int, gp
         fq = os.path.join(tmp, "e2e.fastq")
         t0 = time.time()
         n_bases = ontsim.write_fastq(table, fq)
+        os.sync()                                           # (the input's own write-back is not part of what is timed: without this the timed command's output waits behind 10 GB of dirty pages)
         t_gen = time.time() - t0
         out = {}
         for name, ps in (("headline_cut", part_symbols), ("ref_cut", 1 << 22)):
@@ -560,7 +563,8 @@ def e2e_cli(bases: float, coverage: float, k: int, a: int, part_symbols: int, gp
                 if name == "ref_cut":
                     continue
             cmd = [ours, "compress-ont", "-v", "-k", str(k), "-a", str(a), "--part-symbols", str(ps)] + multi + [fq, os.path.join(tmp, "e2e.colord")]
-            t0 = time.time()
+            time.sleep(8.0)                                 # the driver clears what the process before gave back (this one's pools, the run before) while the next one starts:
+            t0 = time.time()                                # measured 5.2-5.3 s after a pause against 5.5-6.8 s back to back (profiles/r05_e2e_pause_5Gbases.txt)
             try:
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
             except subprocess.TimeoutExpired:

@@ -1023,7 +1023,6 @@ int run_compress(int argc, char** argv)
 	const uint64_t est_bases = (uint64_t)((R.gz ? (R.fastq ? 2.08 : 3.98) : (R.fastq ? 0.49 : 0.98)) * (double)R.file_bytes);
 	cl_compressor* cmp = nullptr;
 	ck(ctx, cl_compressor_create(ctx, qctx, &cp, with_qual ? &qp : nullptr, nullptr, est_bases, &cmp), "cl_compressor_create");
-
 	// reference-genome mode (compression.cpp:405-429): the genome's sequences are a second input of the k-mer counter
 	genome_io::Sequences G; const bool with_genome = !O.genome.empty();
 	auto upload = [&](const genome_io::Sequences& S) -> cl_reads* {
@@ -1106,8 +1105,7 @@ int run_compress(int argc, char** argv)
 		if (O.stream_input) free_chunk(dc);
 		chunks.push_back(std::move(dc));
 	});
-	if (!O.stream_input) { hostbuf[0].release(); hostbuf[1].release(); }
-	lap("input parsed, uploaded and scanned (pass 1)");
+	lap("input parsed, uploaded and scanned (pass 1)");        // (the pinned staging of a resident input is used once more: pass 2 receives its parts in it)
 	const uint32_t n = (uint32_t)R.n_reads; const uint64_t total = R.n_bases;
 	if (!n) die("no reads in " + O.in);
 	// the header stream on a host thread, next to the GPU path (CEntrComprHeaders, entr_header.cpp:23-45)
@@ -1168,16 +1166,31 @@ int run_compress(int argc, char** argv)
 		const uint64_t dna_cap = max_bases + 64 * max_parts + 4096, qual_cap = (uint64_t)(max_bases * 1.35) + 64 * max_parts + 4096;
 		// The parts of a chunk leave through TWO sets of buffers (device and pinned host) and a writer thread: while chunk i + 1 is coded, chunk
 		// i's parts are copied out on a stream of their own and added to the archive.  (Round 5: copied into pageable memory and written by the
-		// coding thread itself they cost 0.2 s of the 0.55 s a chunk took at 20 Gbases.)
+		// coding thread itself they cost 0.2 s of the 0.55 s a chunk took at 20 Gbases.)  The pinned side is pass 1's staging where the input is
+		// resident (it is free by now) and grows on demand otherwise: pinning two sets of the device side's worst-case sizes (4.7 GB at 1-Gbase
+		// chunks, for the 0.8 GB the parts of two chunks take) cost about a second a run.
 		uint8_t* d_dna2[2] = { nullptr, nullptr }; uint8_t* d_qual2[2] = { nullptr, nullptr }; uint8_t* h_dna2[2] = { nullptr, nullptr }; uint8_t* h_qual2[2] = { nullptr, nullptr };
+		uint64_t h_dna_cap[2] = { 0, 0 }, h_qual_cap[2] = { 0, 0 };
 		hipStream_t out_stream = nullptr; hipEvent_t out_ev[2] = { nullptr, nullptr };
 		hipck(hipStreamCreateWithFlags(&out_stream, hipStreamNonBlocking), "hipStreamCreate");
 		for (int b = 0; b < 2; ++b)
 		{
-			hipck(hipMalloc((void**)&d_dna2[b], dna_cap), "hipMalloc"); hipck(hipHostMalloc((void**)&h_dna2[b], dna_cap, hipHostMallocDefault), "hipHostMalloc");
-			if (with_qual) { hipck(hipMalloc((void**)&d_qual2[b], qual_cap), "hipMalloc"); hipck(hipHostMalloc((void**)&h_qual2[b], qual_cap, hipHostMallocDefault), "hipHostMalloc"); }
+			hipck(hipMalloc((void**)&d_dna2[b], dna_cap), "hipMalloc");
+			if (with_qual) hipck(hipMalloc((void**)&d_qual2[b], qual_cap), "hipMalloc");
 			hipck(hipEventCreateWithFlags(&out_ev[b], hipEventDisableTiming), "hipEventCreate");
+			if (!O.stream_input)
+			{
+				h_dna2[b] = hostbuf[b].bases; h_dna_cap[b] = hostbuf[b].bases ? hostbuf[b].cap : 0;
+				h_qual2[b] = hostbuf[b].quals; h_qual_cap[b] = hostbuf[b].quals ? hostbuf[b].cap : 0;
+				hostbuf[b].bases = hostbuf[b].quals = nullptr; hostbuf[b].cap = 0;
+			}
 		}
+		auto host_room = [&](uint8_t*& p, uint64_t& cap, uint64_t need) {
+			if (need <= cap) return;
+			if (p) (void)hipHostFree(p);
+			cap = need + need / 4 + (1ull << 20); p = nullptr;
+			hipck(hipHostMalloc((void**)&p, cap, hipHostMallocDefault), "hipHostMalloc");
+		};
 		struct OutJob { size_t ci; int b; std::vector<uint64_t> dsz, qsz; uint64_t dna_bytes, qual_bytes; };
 		std::mutex omu; std::condition_variable ocv; std::deque<OutJob> ojobs; bool odone = false; bool obusy[2] = { false, false }; std::string oerr;
 		std::thread writer([&]() {
@@ -1246,6 +1259,7 @@ int run_compress(int argc, char** argv)
 			const int b = (int)(ci & 1);
 			{ std::unique_lock<std::mutex> l(omu); ocv.wait(l, [&]() { return !obusy[b]; }); obusy[b] = true; }      // (the writer is through with this set: chunk ci - 2)
 			ck(ctx, cl_compressor_encode(cmp, dc.reads, dc.d_quals, dc.d_off, dc.parts.data(), np, dc.packs.data(), (uint32_t)dc.packs.size() - 1, d_dna2[b], dna_cap, dsz.data(), d_qual2[b], qual_cap, qsz.data(), &info), "pass 2");
+			host_room(h_dna2[b], h_dna_cap[b], info.dna_bytes); host_room(h_qual2[b], h_qual_cap[b], info.qual_bytes);       // (set b is the writer's no more: awaited above)
 			if (info.dna_bytes) hipck(hipMemcpyAsync(h_dna2[b], d_dna2[b], info.dna_bytes, hipMemcpyDeviceToHost, out_stream), "hipMemcpyAsync");
 			if (info.qual_bytes) hipck(hipMemcpyAsync(h_qual2[b], d_qual2[b], info.qual_bytes, hipMemcpyDeviceToHost, out_stream), "hipMemcpyAsync");
 			hipck(hipEventRecord(out_ev[b], out_stream), "hipEventRecord");
@@ -1260,7 +1274,7 @@ int run_compress(int argc, char** argv)
 		writer.join();
 		if (!oerr.empty()) die(oerr);
 		if (O.stream_input) { loader.join(); cl_ctx_destroy(lctx); hostbuf[0].release(); hostbuf[1].release(); }
-		for (int b = 0; b < 2; ++b) { (void)hipFree(d_dna2[b]); (void)hipHostFree(h_dna2[b]); if (d_qual2[b]) (void)hipFree(d_qual2[b]); if (h_qual2[b]) (void)hipHostFree(h_qual2[b]); (void)hipEventDestroy(out_ev[b]); }
+		for (int b = 0; b < 2; ++b) { (void)hipFree(d_dna2[b]); if (h_dna2[b]) (void)hipHostFree(h_dna2[b]); if (d_qual2[b]) (void)hipFree(d_qual2[b]); if (h_qual2[b]) (void)hipHostFree(h_qual2[b]); (void)hipEventDestroy(out_ev[b]); }
 		(void)hipStreamDestroy(out_stream);
 	}
 	lap("pass 2 (dna + qual parts written)");

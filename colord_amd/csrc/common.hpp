@@ -213,6 +213,7 @@ struct DevPool {
 			sz = (sz + g - 1) / g * g;
 			make_room(sz, dbg);
 			void* base = nullptr;
+			const auto t_slab = std::chrono::steady_clock::now();
 			hipError_t e = hipMalloc(&base, sz);
 			if (e != hipSuccess && sz > r + g)
 			{	// not even after making room: the request alone
@@ -222,7 +223,8 @@ struct DevPool {
 				e = hipMalloc(&base, sz);
 			}
 			++n_mallocs;
-			if (dbg) fprintf(stderr, "[pool] slab of %.3f GB (%s) for a block of %.3f GB; live %.3f GB, reserved %.3f GB in %zu slabs\n", sz / 1e9, e == hipSuccess ? "ok" : "failed", r / 1e9, live_bytes / 1e9, reserved / 1e9, slabs.size());
+			if (dbg) fprintf(stderr, "[pool] slab of %.3f GB (%s, %.1f ms) for a block of %.3f GB; live %.3f GB, reserved %.3f GB in %zu slabs\n", sz / 1e9, e == hipSuccess ? "ok" : "failed",
+				std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_slab).count(), r / 1e9, live_bytes / 1e9, reserved / 1e9, slabs.size());
 			if (e != hipSuccess)
 			{	// The device is full.  Other contexts of this process hold most of it for a moment only (the look-ahead stages of
 				// cl_compressor): wait for what they release — up to a few seconds — before this becomes the caller's error.

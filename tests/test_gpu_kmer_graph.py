@@ -32,6 +32,20 @@ def test_radix_sort_matches_torch(ctx):
         assert torch.equal(dk2.cpu(), ek)
 
 
+@pytest.mark.parametrize("bits", [27, 32, 40])          # digits of 9, 8 and 10 bits
+def test_radix_sort_grouped_histogram_tiles(ctx, bits):
+    """From 4096 tiles on a histogram block counts 8 or 16 consecutive tiles (sort.hip k_sort_hist<K, DB, G>); the last group is ragged."""
+    n = 4096 * 4096 + 5 * 4096 + 77
+    gen = torch.Generator().manual_seed(bits)
+    keys = torch.randint(0, 1 << bits, (n,), generator=gen, dtype=torch.int64)
+    vals = torch.arange(n, dtype=torch.int32)
+    dk, dv = keys.to(ctx.device), vals.to(ctx.device)
+    ctx.sort_u64(dk, dv, 0, bits)
+    ek, order = torch.sort(keys, stable=True)
+    assert torch.equal(dk.cpu(), ek)
+    assert torch.equal(dv.cpu(), vals[order])
+
+
 @pytest.mark.parametrize("cfg", ["c1_ont_default", "s3m_ont_n_ratio"])
 def test_arena_layout(ctx, cfg):
     rs = golden(cfg).reads

@@ -17,9 +17,10 @@ if free < 2.6 * bases:
 t = ontsim.ReadTable(seed=41, genome_len=max(1_000_000, int(bases / 16.7)), target_bases=int(bases))
 with tempfile.TemporaryDirectory(dir=base_dir) as tmp:
     fq = os.path.join(tmp, "in.fastq")
-    t0 = time.time(); nb = ontsim.write_fastq(t, fq)
+    t0 = time.time(); nb = ontsim.write_fastq(t, fq); os.sync()
     print(f"fastq: {nb} bases, {os.path.getsize(fq)} bytes, written in {time.time() - t0:.1f} s", flush=True)
     for name, extra in (("resident", []), ("stream-input", ["--stream-input"])):
+        time.sleep(8.0)
         t0 = time.time()
         r = subprocess.run([cli, "compress-ont", "-v", "-k", "25", "-a", "22", "--part-symbols", "65536"] + extra + [fq, os.path.join(tmp, "a.colord")], capture_output=True, text=True)
         dt = time.time() - t0
