@@ -66,6 +66,9 @@ __global__ __launch_bounds__(ST) void k_sort_scatter(const K* __restrict__ kin, 
 	const uint64_t tbase = (uint64_t)blockIdx.x * STILE, wbase = tbase + (uint64_t)w * (64 * SI);
 	K key[SI]; uint32_t rank[SI]; uint32_t val[HAS_V ? SI : 1];
 	const uint64_t lt = (1ULL << lane) - 1;
+	uint32_t goff[PER];                                                      // the tile's places in the output, asked for with the keys (they are one
+#pragma unroll                                                                // scattered word per digit: a round trip of their own if read where they are used)
+	for (uint32_t k = 0; k < PER; ++k) goff[k] = offs[(uint64_t)(threadIdx.x * PER + k) * nb + blockIdx.x];
 #pragma unroll
 	for (uint32_t r = 0; r < SI; ++r)
 	{
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(ST) void k_sort_scatter(const K* __restrict__ kin, 
 			const uint32_t d = threadIdx.x * PER + k;
 			lstart[d] = ls;
 			if (d == ND - 1) lstart[ND] = ls + tot[k];
-			gdelta[d] = offs[(uint64_t)d * nb + blockIdx.x] - ls;
+			gdelta[d] = goff[k] - ls;
 			wh[0][d] = ls; wh[1][d] = ls + c[k][0]; wh[2][d] = ls + c[k][0] + c[k][1]; wh[3][d] = ls + c[k][0] + c[k][1] + c[k][2];
 			ls += tot[k];
 		}
