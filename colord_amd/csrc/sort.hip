@@ -14,7 +14,7 @@ constexpr uint32_t STILE = ST * SI;     // 4096 keys per tile
 
 // DB = digit bits of the pass (8, 9 or 10): the passes of a sort share the key bits evenly, so 17 bits take two passes (9 + 8),
 // not three, and 20 bits two of 10.
-// G consecutive tiles per block: a digit's G counts are neighbours in the digit-major table and leave as one 32- or 64-byte run.  (One tile
+// G consecutive tiles per block: a digit's G counts are neighbours in the digit-major table and leave as one 16- or 64-byte run.  (One tile
 // per block wrote every count into a sector of its own: 275 MB of counts cost 1.7 GB of HBM writes per pass of the DNA coder's sort,
 // profiles/r05_pmc_write_2Gbases.txt.)  G = 1 for the small sorts, whose few tiles are wanted on as many CUs as there are tiles.
 template<typename K, uint32_t DB, uint32_t G>
@@ -22,8 +22,9 @@ __global__ __launch_bounds__(ST) void k_sort_hist(const K* __restrict__ keys, ui
                                                   uint32_t* __restrict__ hist, uint32_t nb)
 {
 	constexpr uint32_t ND = 1u << DB;
-	__shared__ uint32_t h[G * ND];                       // [digit][tile of the block]
-	for (uint32_t i = threadIdx.x; i < G * ND; i += ST) h[i] = 0;
+	constexpr uint32_t ROW = G > 1 ? ND + 1 : ND;        // (a tile's counters side by side as with one tile per block; the odd row length spreads the
+	__shared__ uint32_t h[G * ROW];                      // transposed read-out below over the banks)  [tile of the block][digit]
+	for (uint32_t i = threadIdx.x; i < G * ROW; i += ST) h[i] = 0;
 	__syncthreads();
 	const uint32_t tile0 = blockIdx.x * G;
 	for (uint32_t g = 0; g < G && tile0 + g < nb; ++g)
@@ -33,14 +34,14 @@ __global__ __launch_bounds__(ST) void k_sort_hist(const K* __restrict__ keys, ui
 		for (uint32_t i = 0; i < SI; ++i)
 		{
 			uint64_t idx = base + (uint64_t)i * ST + threadIdx.x;
-			if (idx < n) atomicAdd(&h[((uint32_t)(keys[idx] >> shift) & (ND - 1)) * G + g], 1u);
+			if (idx < n) atomicAdd(&h[g * ROW + ((uint32_t)(keys[idx] >> shift) & (ND - 1))], 1u);
 		}
 	}
 	__syncthreads();
 	for (uint32_t i = threadIdx.x; i < G * ND; i += ST)
 	{
 		const uint32_t g = i % G, d = i / G;
-		if (tile0 + g < nb) hist[(uint64_t)d * nb + tile0 + g] = h[i];
+		if (tile0 + g < nb) hist[(uint64_t)d * nb + tile0 + g] = h[g * ROW + d];
 	}
 }
 
@@ -153,7 +154,9 @@ cl_status sort_pass(cl_ctx* ctx, const K* kin, const uint32_t* vin, K* kout, uin
 {
 	// (names as rocprofv3 prints the instantiations)
 	static const std::string kt = sizeof(K) == 8 ? "unsigned long" : "unsigned int", db = std::to_string(DB) + "u";
-	constexpr uint32_t G = DB == 10 ? 8 : 16; const bool grouped = nb >= 4096;           // (16 M keys and more)
+	// (group sizes measured inside the pipeline at 10 Gbases, summed histogram time per pass with G = 1 / 4 / 16: 8-bit digits 174 / 122 / 102 ms,
+	// 9-bit 185 / 139 / 518 ms — 16 tiles of 512 counters are 32 KB of LDS and halve the blocks a CU holds)
+	constexpr uint32_t G = DB == 8 ? 16 : 4; const bool grouped = nb >= 4096;           // (16 M keys and more)
 	static const std::string n_hist1 = "k_sort_hist<" + kt + ", " + db + ", 1u>", n_histg = "k_sort_hist<" + kt + ", " + db + ", " + std::to_string(G) + "u>", n_sv = "k_sort_scatter<" + kt + ", true, " + db + ">", n_sk = "k_sort_scatter<" + kt + ", false, " + db + ">";
 	if (grouped) LAUNCHB_NAMED(ctx, n_histg.c_str(), n * sizeof(K), (k_sort_hist<K, DB, G>), (nb + G - 1) / G, ST, kin, n, shift, hist, nb);
 	else LAUNCHB_NAMED(ctx, n_hist1.c_str(), n * sizeof(K), (k_sort_hist<K, DB, 1>), nb, ST, kin, n, shift, hist, nb);
