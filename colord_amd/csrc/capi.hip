@@ -29,6 +29,7 @@ void cl_ctx_set_priority(cl_ctx* c, int level, int role)
 	(void)hipSetDevice(c->device);
 	int least = 0, greatest = 0;
 	if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = 0; }
+	level = cl_role_level(role >= 0 ? role : c->role, level);
 	const int prio = level > 0 ? greatest : level < 0 ? least : 0;
 	const bool role_changes = role >= 0 && role < CL_N_ROLES && cl_cu_mask_cfg().on[role] && (role != c->role || !c->masked);
 	if (role >= 0) c->role = role;

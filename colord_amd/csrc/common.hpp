@@ -490,6 +490,26 @@ inline const CuMaskCfg& cl_cu_mask_cfg()
 	}();
 	return cfg;
 }
+// COLORD_HIP_ROLE_PRIO="lane:-1,prep:0,main:1,qual:1,coder:1" (an experiment's knob): the level (+1 highest, -1 lowest, 0 default) the streams of
+// a role are made at, instead of the compressor's own choice (lanes +1, preparation -1, the others 0).  Returns `dflt` for a role not named.
+static inline int cl_role_level(int role, int dflt)
+{
+	static const struct Cfg { bool on[CL_N_ROLES] = {}; int level[CL_N_ROLES] = {}; Cfg() {
+		const char* e = getenv("COLORD_HIP_ROLE_PRIO"); if (!e) return;
+		static const char* names[CL_N_ROLES] = { "main", "qual", "lane", "prep", "coder" };
+		std::string t(e); size_t p = 0;
+		while (p < t.size()) { size_t q = t.find(',', p); if (q == std::string::npos) q = t.size(); const std::string item = t.substr(p, q - p); const size_t c = item.find(':');
+			if (c != std::string::npos) for (int r = 0; r < CL_N_ROLES; ++r) if (item.substr(0, c) == names[r]) { on[r] = true; level[r] = atoi(item.c_str() + c + 1); }
+			p = q + 1; }
+	} } cfg;
+	return role >= 0 && role < CL_N_ROLES && cfg.on[role] ? cfg.level[role] : dflt;
+}
+static inline int cl_level_to_prio(int level)
+{
+	int least = 0, greatest = 0;
+	if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); return 0; }
+	return level > 0 ? greatest : level < 0 ? least : 0;
+}
 static inline hipError_t cl_stream_create_role(int role, int prio, hipStream_t* s)
 {
 	const CuMaskCfg& m = cl_cu_mask_cfg();

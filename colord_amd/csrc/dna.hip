@@ -1305,7 +1305,7 @@ cl_status dna_evolve_batch(cl_ctx* ctx, cl_dna_coder* D, const cl_reads* refs, c
 		if (herr & 8) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_dna_encode: epoch table of a long context run too small");
 		if (herr) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_dna_encode: a read uses more than 64 alternative references");
 		// interval arithmetic per part: on a stream of the coder's own, beside whatever follows on this one
-		if (D->cstreams.size() < 4) { hipStream_t ns = nullptr; HIP_TRY(ctx, cl_stream_create_role(CL_ROLE_CODER, 0, &ns)); D->cstreams.push_back(ns); }
+		if (D->cstreams.size() < 4) { hipStream_t ns = nullptr; HIP_TRY(ctx, cl_stream_create_role(CL_ROLE_CODER, cl_level_to_prio(cl_role_level(CL_ROLE_CODER, 0)), &ns)); D->cstreams.push_back(ns); }
 		G->stream = D->cstreams[D->next_cstream++ % D->cstreams.size()];
 		G->out_off.resize(np + 1);
 		G->out_off[0] = 0;

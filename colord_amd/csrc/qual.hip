@@ -628,7 +628,7 @@ cl_status qual_evolve_batch(cl_ctx* ctx, cl_qual_coder* Q, const cl_reads* R, co
 		G.key.release(); G.sidx.release(); G.bkey.release(); G.bsidx.release();   // (the models are through with them)
 		// the interval arithmetic, one dependent chain per part, on a stream of the coder's own: the model half of the next batch
 		// runs beside it (cl_qual_evolve_ahead)
-		if (Q->cstreams.size() < 4) { hipStream_t ns = nullptr; HIP_TRY(ctx, cl_stream_create_role(CL_ROLE_CODER, 0, &ns)); Q->cstreams.push_back(ns); }
+		if (Q->cstreams.size() < 4) { hipStream_t ns = nullptr; HIP_TRY(ctx, cl_stream_create_role(CL_ROLE_CODER, cl_level_to_prio(cl_role_level(CL_ROLE_CODER, 0)), &ns)); Q->cstreams.push_back(ns); }
 		PG.stream = Q->cstreams[Q->next_cstream++ % Q->cstreams.size()];
 		{
 			LaunchOn on(ctx, PG.stream);                                         // (launch + timing events on the coder's stream)

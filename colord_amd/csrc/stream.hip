@@ -159,8 +159,8 @@ extern "C" cl_status cl_compressor_create(cl_ctx* ctx, cl_ctx* qual_ctx, const c
 	c->ctx = ctx; c->qctx = qual_ctx ? qual_ctx : ctx; c->P = *params; c->expected_bases = expected_bases;
 	if (qparams) { c->has_qual = true; c->Q = *qparams; }
 	if (exchange && exchange->world > 1) { c->X = *exchange; c->rank = exchange->rank; c->world = exchange->world; }
-	if (cl_cu_mask_cfg().any)
-	{	// CU partitioning (COLORD_HIP_CU_MASK): the caller's two contexts take their roles' CUs (their streams are made anew, idle as they are)
+	if (cl_cu_mask_cfg().any || getenv("COLORD_HIP_ROLE_PRIO"))
+	{	// CU partitioning (COLORD_HIP_CU_MASK) / priorities by role: the caller's two contexts take their roles' CUs (their streams are made anew, idle as they are)
 		cl_ctx_set_priority(ctx, 0, CL_ROLE_MAIN);
 		if (qual_ctx && qual_ctx != ctx) cl_ctx_set_priority(qual_ctx, 0, CL_ROLE_QUAL);
 	}

@@ -171,9 +171,11 @@ def test_prepare_rejects_wrong_order(ctx):
 
 
 def test_chunked_equals_one_call_200_mbases(ctx):
-    """A synthetic ONT set of 200 Mbases (~13 k reads, 48 reader packs of 4 Mi symbols) in 3 chunks."""
+    """A synthetic ONT set of 200 Mbases (~13 k reads, 48 reader packs of 4 Mi symbols) in 3 chunks.
+    (COLORD_TEST_CHUNKED_MBASES: another size — the run under the debugging modes below, where every hand-over waits for the device.)"""
     from colord_amd.synth_device import make_reads_device
-    codes, offsets, quals = make_reads_device(ctx.device, seed=77, genome_len=12_000_000, target_bases=200_000_000, with_quals=True)
+    mb = int(os.environ.get("COLORD_TEST_CHUNKED_MBASES", "200"))
+    codes, offsets, quals = make_reads_device(ctx.device, seed=77, genome_len=12_000_000 * mb // 200, target_bases=mb * 1_000_000, with_quals=True)
     lens = (offsets[1:] - offsets[:-1]).cpu().numpy().astype(np.uint32)
     packs = reference_part_bounds(lens, 1 << 22)
     prm = dict(k=21, f=12, ci=4, cs=80, c=5, anchor_len=18, min_part_alt=64, max_rec=3, min_anchors=1, level=1, source=0, sparse=1,
@@ -237,11 +239,12 @@ def test_pipeline_under_pool_poison_and_sync_debug(env):
     COLORD_HIP_POOL_POISON fills every block with a pattern when it goes back to the shared pool (on the releasing context's main stream)
     and checks the pattern when the block is handed to another context — a stream that still reads a released block reads the pattern and
     the byte comparisons of the two tests fail; a write after release is reported as `POOL POISON`.  COLORD_HIP_SYNC_DEBUG waits after
-    every launch (no overlap at all: what differs from the normal run is a race)."""
+    every launch (no overlap at all: what differs from the normal run is a race).  The chunked test runs at 80 Mbases here (19 reader packs in
+    3 chunks; at 200 Mbases the two modes took 250 s of the suite's 900)."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_stream.py"), "-x", "-q", "-k", "chunked_equals_one_call_200_mbases or lookahead_lanes_change_no_byte"],
-                       capture_output=True, text=True, env=dict(os.environ, **env), cwd=root, timeout=2400)
+                       capture_output=True, text=True, env=dict(os.environ, COLORD_TEST_CHUNKED_MBASES="80", **env), cwd=root, timeout=2400)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "POOL POISON" not in r.stderr and "POOL POISON" not in r.stdout
     if "COLORD_HIP_POOL_POISON" in env:
