@@ -15,8 +15,8 @@ constexpr uint32_t STILE = ST * SI;     // 4096 keys per tile
 // DB = digit bits of the pass (8, 9 or 10): the passes of a sort share the key bits evenly, so 17 bits take two passes (9 + 8),
 // not three, and 20 bits two of 10.
 // G consecutive tiles per block: a digit's G counts are neighbours in the digit-major table and leave as one 16- or 64-byte run.  (One tile
-// per block wrote every count into a sector of its own: 275 MB of counts cost 1.7 GB of HBM writes per pass of the DNA coder's sort,
-// profiles/r05_pmc_write_2Gbases.txt.)  G = 1 for the small sorts, whose few tiles are wanted on as many CUs as there are tiles.
+// per block wrote every count into a sector of its own: 275 MB of counts cost 1.7 GB of HBM writes per pass of the DNA coder's sort by the
+// round's first WRITE_SIZE pass; 0.39 -> 0.09 GB per launch on average since, profiles/r05_pmc_traffic_summary.txt.)  G = 1 for the small sorts, whose few tiles are wanted on as many CUs as there are tiles.
 template<typename K, uint32_t DB, uint32_t G>
 __global__ __launch_bounds__(ST) void k_sort_hist(const K* __restrict__ keys, uint64_t n, uint32_t shift,
                                                   uint32_t* __restrict__ hist, uint32_t nb)
