@@ -545,6 +545,12 @@ def e2e_cli(bases: float, coverage: float, k: int, a: int, part_symbols: int, gp
     ours = os.path.join(ROOT, "colord_amd", "colord_hip")
     if not os.path.exists(ours) or bases <= 0:
         return None
+    import shutil
+    free = shutil.disk_usage(tempfile.gettempdir()).free    # the FASTQ takes 2 bytes per base, the archive 0.4: a smaller sample where the disk is short
+    if free < 2.6 * bases + (4 << 30):
+        bases = max(0.0, (free - (4 << 30)) / 2.6)
+        if bases < 2.0e8:
+            return {"error": f"{free / 1e9:.0f} GB free in {tempfile.gettempdir()}: no room for the FASTQ of the command-line leg"}
     table = ontsim.ReadTable(seed=103, genome_len=max(1_000_000, int(bases / coverage)), target_bases=int(bases))
     with tempfile.TemporaryDirectory() as tmp:
         fq = os.path.join(tmp, "e2e.fastq")
