@@ -39,10 +39,13 @@ struct cl_dna_decoder {
 	std::vector<uint8_t> pending; std::vector<uint64_t> pending_off; bool has_pending = false;   // a decoded part the caller's buffer could not hold
 	void init_models()
 	{	// dna_coder.h:48-60 <symbols, MAX_TOTAL, ADDER>
-		m_rev_comp.init(2, 1u << 15, 1); m_read_type.init(3, 1u << 15, 1); m_seen.init(2, 1u << 15, 1); m_len_bits.init(32, 1u << 18, 8);
-		m_len_data.init(256, 1u << 18, 8); m_symbols.init(4, 1u << 10, 1); m_symbols_n.init(5, 1u << 10, 1); m_read_id.init(256, 1u << 13, 1);
-		m_skip_distant.init(256, 1u << 15, 1); m_tuple_type.init(8, 1u << 15, 1); m_read_id_short.init(max_alt, 1u << 13, 1);
-		m_anchor_len.init(24, 1u << 15, 1); m_skip_local.init(256, 1u << 15, 1);
+		// (last argument: the width of the family's regular contexts — indexed directly, host_coder.hpp; contexts built from the guard symbol
+		// 255 behind a reference read's last base lie above it and are hashed)
+		const uint32_t T3 = 3 * (uint32_t)no_tuples_in_mask, S2 = 2 * (uint32_t)no_symbols_in_mask;
+		m_rev_comp.init(2, 1u << 15, 1, 4); m_read_type.init(3, 1u << 15, 1, 8); m_seen.init(2, 1u << 15, 1, 7); m_len_bits.init(32, 1u << 18, 8, 1);
+		m_len_data.init(256, 1u << 18, 8, 9); m_symbols.init(4, 1u << 10, 1, level == 1 ? 22 : level == 2 ? 23 : level == 3 ? 24 : 14); m_symbols_n.init(5, 1u << 10, 1, S2 < 8 ? 8 : S2); m_read_id.init(256, 1u << 13, 1, 11);
+		m_skip_distant.init(256, 1u << 15, 1, 8); m_tuple_type.init(8, 1u << 15, 1, T3 + 9); m_read_id_short.init(max_alt, 1u << 13, 1, 7);
+		m_anchor_len.init(24, 1u << 15, 1, 8); m_skip_local.init(256, 1u << 15, 1, 8);
 		ctx_read_type = 0;
 	}
 	bool should_add(uint32_t idx)
@@ -91,18 +94,10 @@ struct cl_dna_decoder {
 		ctx += (uint64_t)ref_symbol << shift; shift += 2;
 		if (cur_ref_delta < -10) ctx += 1ULL << shift; else if (cur_ref_delta < -1) ctx += 2ULL << shift;
 		else if (cur_ref_delta > 10) ctx += 3ULL << shift; else if (cur_ref_delta > 1) ctx += 4ULL << shift;
-		int e1 = -1, e2 = -1;
-		if (!first)
-			switch (last)
-			{
-			case T_MATCH: e1 = T_ANCHOR; break;
-			case T_DEL: e1 = T_SKIP; break;
-			case T_ANCHOR: e1 = T_ANCHOR; e2 = T_MATCH; break;
-			case T_SKIP: e1 = T_DEL; e2 = T_SKIP; break;
-			case T_MAIN_REF: case T_ALT_ID: e1 = T_ALT_ID; e2 = T_MAIN_REF; break;
-			default: break;
-			}
-		const uint32_t f = m_tuple_type.decode(rc, ctx, e1, e2);
+		// what cannot follow the tuple before (dna_coder.cpp:735-757) as a table: a mask of the excluded types per previous type (no branch to mispredict)
+		static const uint8_t EXCL[16] = { /* INS */ 0, /* DEL */ 1u << T_SKIP, /* MATCH */ 1u << T_ANCHOR, /* SUBST */ 0, /* ANCHOR */ (1u << T_ANCHOR) | (1u << T_MATCH), /* SKIP */ (1u << T_DEL) | (1u << T_SKIP),
+			/* ALT_ID */ (1u << T_ALT_ID) | (1u << T_MAIN_REF), /* MAIN_REF */ (1u << T_ALT_ID) | (1u << T_MAIN_REF), 0, 0, 0, 0, 0, 0, 0, 0 };
+		const uint32_t f = m_tuple_type.decode_masked8(rc, ctx, first ? 0u : EXCL[last & 15]);
 		ctx_tuple_type = ((ctx_tuple_type << 3) + f) & mask_tuple;
 		return f;
 	}
@@ -170,12 +165,19 @@ bool cl_dna_decoder::decode_read(std::vector<uint8_t>& out)           // CDNACod
 	cur_ref_delta = 0;
 	std::vector<uint8_t> plain;                                       // read_without_flags
 	plain.reserve(std::min<uint32_t>(read_len, 1u << 24));                 // (a decoded value: a hint, never trusted with memory)
-	auto emit = [&](uint32_t b, uint8_t fl) { out.push_back((uint8_t)(b | fl)); plain.push_back((uint8_t)b); };
+	// level 1 carries no flags: the bases are collected once (`plain`) and appended to the part when the read is complete
+	const bool flagged = level > 1;
+	auto emit = [&](uint32_t b, uint8_t fl) { if (flagged) out.push_back((uint8_t)(b | fl)); plain.push_back((uint8_t)b); };
+	// the two reference reads in use as (bases, length): one indirection less per symbol than refs[id][pos] (they do not move while this
+	// read is decoded: `refs` grows only at its end)
+	const uint8_t* mp = refs[ref_id].data(); const int64_t ml = (int64_t)refs[ref_id].size();
+	const uint8_t* ap = nullptr; int64_t al = 0;
+	auto at = [](const uint8_t* p, int64_t l, int rev, int64_t pos) -> uint32_t { return pos < 0 || pos >= l ? 255u : rev ? 3u - p[l - 1 - pos] : p[pos]; };
 	for (uint32_t t_i = 0; t_i < read_len; ++t_i)
 	{
-		const uint32_t ref_symbol = is_main ? ref_at(ref_id, ref_rev, ref_pos) : ref_at(alt_id, alt_rev, alt_pos);
+		const uint32_t ref_symbol = is_main ? at(mp, ml, ref_rev, ref_pos) : at(ap, al, alt_rev, alt_pos);
 		const uint32_t t = dec_tuple_type(ref_symbol, last, t_i == 0);
-		if (bad_len || out.size() - o0 > MAX_READ_BASES) { err = "dna stream: run or read longer than the format allows"; return false; }
+		if (bad_len || plain.size() > MAX_READ_BASES) { err = "dna stream: run or read longer than the format allows"; return false; }
 		switch (t)
 		{
 		case T_ALT_ID:
@@ -192,13 +194,26 @@ bool cl_dna_decoder::decode_read(std::vector<uint8_t>& out)           // CDNACod
 			alt_id = alt_ids[slot]; alt_slot = slot;
 			if ((size_t)alt_id >= refs.size()) { err = "dna stream: alternative reference id out of range"; return false; }
 			alt_rev = dec_rev_comp(alt_id);
+			ap = refs[alt_id].data(); al = (int64_t)refs[alt_id].size();
 			alt_pos = 0; is_main = false; cur_ref_delta = 0;
 			break;
 		}
 		case T_ANCHOR:
 		{
 			const uint32_t len = dec_anchor_len();
-			for (uint32_t i = 0; i < len; ++i) emit((is_main ? ref_at(ref_id, ref_rev, ref_pos + i) : ref_at(alt_id, alt_rev, alt_pos + i)) & 0xff, f_anchor);
+			{	// the anchor's bases in one sweep (the stretch inside the reference read; what lies beyond its ends reads as the guard)
+				const uint8_t* p = is_main ? mp : ap; const int64_t l = is_main ? ml : al, pos = is_main ? ref_pos : alt_pos; const int rev = is_main ? ref_rev : alt_rev;
+				const size_t q = plain.size();
+				plain.resize(q + len);
+				uint8_t* pq = plain.data() + q;
+				if (pos >= 0 && pos + (int64_t)len <= l)
+				{
+					if (!rev) memcpy(pq, p + pos, len);
+					else { const uint8_t* src = p + (l - 1 - pos); for (uint32_t i = 0; i < len; ++i) pq[i] = (uint8_t)(3u - *(src - i)); }
+				}
+				else for (uint32_t i = 0; i < len; ++i) pq[i] = (uint8_t)(at(p, l, rev, pos + i) & 0xff);
+				if (flagged) { const size_t o = out.size(); out.resize(o + len); uint8_t* po = out.data() + o; for (uint32_t i = 0; i < len; ++i) po[i] = (uint8_t)(pq[i] | f_anchor); }
+			}
 			if (is_main) ref_pos += len; else alt_pos += len;
 			cur_ref_delta = 0;
 			for (int i = no_symbols_in_mask; i > 0; --i) ctx_symbol = (ctx_symbol << 2) + ((int64_t)plain.size() >= i ? plain[plain.size() - i] : 0);
@@ -253,6 +268,7 @@ bool cl_dna_decoder::decode_read(std::vector<uint8_t>& out)           // CDNACod
 		}
 		last = t;
 	}
+	if (!flagged) out.insert(out.end(), plain.begin(), plain.end());
 	if (accept) refs.push_back(std::move(plain));
 	++cur_read_id;
 	return true;
@@ -323,7 +339,7 @@ struct cl_qual_decoder {
 	Family sym, bytes; RangeDec rc; std::string err;
 	void init_models()
 	{
-		if (mode == 0) sym.init(96, 1u << 20, 32); else sym.init(n_sym, 1u << 18, 8);      // quality_coder.h:36-39
+		if (mode == 0) sym.init(96, 1u << 20, 32, ctx_bits + 11); else sym.init(n_sym, 1u << 18, 8, ctx_bits + 10);      // quality_coder.h:36-39 (contexts: history + bases + flags)
 		bytes.init(256, 1u << 18, 8);                                                        // :41
 	}
 	static uint64_t vs(uint8_t x) { return (uint64_t)(x & 3); }                               // valid_sym: N aliases A
@@ -506,7 +522,7 @@ extern "C" cl_status cl_id_decoder_create(int32_t header_mode, cl_id_decoder** o
 {
 	if (!out || header_mode < 0 || header_mode > 2) return CL_E_INVALID;
 	cl_id_decoder* c = new cl_id_decoder(); c->mode = header_mode;
-	c->plus_id.init(2, 1u << 15, 1); c->flags.init(2, 1u << 15, 1); c->literal.init(256, 1u << 20, 64); c->same.init(2, 1u << 15, 1); c->same_len.init(2, 1u << 15, 1); c->plain.init(128, 1u << 19, 32);
+	c->plus_id.init(2, 1u << 15, 1, 1); c->flags.init(2, 1u << 15, 1, 8); c->literal.init(256, 1u << 20, 64); c->same.init(2, 1u << 15, 1, 8); c->same_len.init(2, 1u << 15, 1, 8); c->plain.init(128, 1u << 19, 32, 12);
 	*out = c;
 	return CL_OK;
 }
