@@ -35,15 +35,23 @@ void cl_ctx_set_priority(cl_ctx* c, int level, int role)
 	if (role >= 0) c->role = role;
 	if (prio == c->prio && !role_changes) return;
 	c->prio = prio; c->masked = c->role < CL_N_ROLES && cl_cu_mask_cfg().on[c->role];
+	// the scans' status words are kept per stream (scan.hip): those of a stream that goes away go back to the pool with it — a handle the
+	// runtime hands out again must not inherit another stream's generation and ticket
+	auto drop_scan_ctl = [&](hipStream_t old) {
+		auto it = c->scan_ctl.find((void*)old);
+		if (it == c->scan_ctl.end()) return;
+		if (it->second.p) c->pool.put(it->second.p, it->second.got, c->pool_id);
+		c->scan_ctl.erase(it);
+	};
 	if (c->stream)
 	{
-		(void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); c->stream = nullptr;
+		(void)hipStreamSynchronize(c->stream); drop_scan_ctl(c->stream); (void)hipStreamDestroy(c->stream); c->stream = nullptr;
 		if (cl_stream_create(c, &c->stream) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); }
 	}
 	for (std::atomic<hipStream_t>* s : { &c->side, &c->side2, &c->side3 })
 		if (hipStream_t old = s->load())
 		{
-			(void)hipStreamSynchronize(old); (void)hipStreamDestroy(old);
+			(void)hipStreamSynchronize(old); drop_scan_ctl(old); (void)hipStreamDestroy(old);
 			hipStream_t ns = nullptr;
 			if (cl_stream_create(c, &ns) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamCreateWithFlags(&ns, hipStreamNonBlocking); }
 			s->store(ns);
@@ -60,7 +68,10 @@ void cl_ctx_poison(cl_ctx* c, void* p, uint64_t bytes)
 {
 	if (!c || !c->stream) return;
 	(void)hipSetDevice(c->device);
-	if (hipMemsetAsync(p, 0xCD, bytes, c->stream) != hipSuccess) (void)hipGetLastError();
+	if (hipMemsetAsync(p, 0xCD, bytes, c->stream) != hipSuccess) { (void)hipGetLastError(); return; }
+	// (waited for: the pool hands the owner its own extent back at once, and the next use may be on ANOTHER of its streams — a pattern still
+	// queued here would land on top of the new writes: false reports, or corrupted data, in the very mode that looks for races)
+	(void)hipStreamSynchronize(c->stream);
 }
 uint64_t cl_pool_poison_check(void* p, uint64_t bytes)
 {
@@ -70,7 +81,7 @@ uint64_t cl_pool_poison_check(void* p, uint64_t bytes)
 	(void)hipMemset(d_bad, 0, 8);
 	hipLaunchKernelGGL(k_poison_check, dim3(1024), dim3(256), 0, nullptr, (const uint32_t*)p, bytes / 4, d_bad);
 	unsigned long long h = 0;
-	(void)hipMemcpy(&h, d_bad, 8, hipMemcpyDeviceToHost);
+	if (hipGetLastError() != hipSuccess || hipMemcpy(&h, d_bad, 8, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); fprintf(stderr, "colord_hip: pool poison: the check itself failed\n"); return 0; }
 	return h;
 }
 // every stream of the context (the shared pool calls this before it hands memory the context released to another one)

@@ -439,7 +439,7 @@ void code_headers(const Reader& R, uint32_t n, int header_mode, std::vector<std:
 	}
 	cl_id_coder_free(idc);
 }
-struct DevChunk { cl_reads* reads = nullptr; uint8_t* d_quals = nullptr; uint64_t* d_off = nullptr; std::vector<uint32_t> packs, parts; uint64_t n_bases = 0; uint32_t n_reads = 0; };
+struct DevChunk { cl_reads* reads = nullptr; uint8_t* d_quals = nullptr; uint64_t* d_off = nullptr; std::vector<uint32_t> packs, parts; uint64_t n_bases = 0; uint32_t n_reads = 0; uint64_t quals_cap = 0, off_cap = 0; };
 } // namespace
 
 static void usage()
@@ -658,19 +658,41 @@ static int run_compress_multi(const Options& O, const Preset& P, const QDef& qd,
 			{ const uint64_t tot = host.n; host.n = 0; host.reserve(tot + 1, with_qual); host.n = tot; }
 			for (uint64_t x = c0; x < c1; ++x) { memcpy(host.bases + host.off[x - c0], S.seq(x), S.len(x)); if (with_qual) memcpy(host.quals + host.off[x - c0], S.qual(x), S.len(x)); }
 		};
+		// The rank's input buffers on the device.  Under --stream-input a chunk is uploaded three times (counting, reference pass, coding
+		// pass) and freed after each: its buffers come from and go back to a small per-rank cache — round 5 made a hipMalloc and a hipFree per
+		// buffer and chunk, and hipFree waits for the WHOLE device: every announce stalled the lanes and preparation threads of all ranks on
+		// the GPU.  (Resident input: every buffer is asked for once.)
+		struct DevCache {
+			std::vector<std::pair<void*, uint64_t>> idle;
+			void* get(uint64_t bytes, uint64_t& cap)
+			{
+				size_t best = idle.size();
+				for (size_t i = 0; i < idle.size(); ++i) if (idle[i].second >= bytes && (best == idle.size() || idle[i].second < idle[best].second)) best = i;
+				if (best != idle.size()) { void* p = idle[best].first; cap = idle[best].second; idle.erase(idle.begin() + (long)best); return p; }
+				void* p = nullptr; cap = bytes + bytes / 8 + 4096;                       // (a little room: the chunks of a rank are alike, not equal)
+				if (hipMalloc(&p, cap) != hipSuccess) { (void)hipGetLastError(); cap = bytes; if (hipMalloc(&p, cap) != hipSuccess) { (void)hipGetLastError(); return nullptr; } }
+				return p;
+			}
+			void put(void* p, uint64_t cap) { if (p) idle.emplace_back(p, cap); }
+			void clear() { for (auto& x : idle) (void)hipFree(x.first); idle.clear(); }
+		} dcache;
+		uint8_t* d_bases_stage = nullptr; uint64_t bases_stage_cap = 0;          // (the 1-byte-per-base form cl_reads_pack reads: needed only during the call)
 		auto upload_chunk = [&](DevChunk& dc) {
-			uint8_t* d_bases = nullptr;
-			hipck(hipMalloc((void**)&d_bases, host.n + 1), "hipMalloc"); hipck(hipMalloc((void**)&dc.d_off, host.off.size() * 8), "hipMalloc");
-			hipck(hipMemcpy(d_bases, host.bases, host.n, hipMemcpyHostToDevice), "hipMemcpy");
+			if (host.n + 1 > bases_stage_cap) { if (d_bases_stage) hipck(hipFree(d_bases_stage), "hipFree"); d_bases_stage = (uint8_t*)dcache.get(host.n + 1, bases_stage_cap); if (!d_bases_stage) die("hipMalloc"); }
+			dc.d_off = (uint64_t*)dcache.get(host.off.size() * 8, dc.off_cap); if (!dc.d_off) die("hipMalloc");
+			hipck(hipMemcpy(d_bases_stage, host.bases, host.n, hipMemcpyHostToDevice), "hipMemcpy");
 			hipck(hipMemcpy(dc.d_off, host.off.data(), host.off.size() * 8, hipMemcpyHostToDevice), "hipMemcpy");
-			if (with_qual) { hipck(hipMalloc((void**)&dc.d_quals, host.n + 1), "hipMalloc (the input does not fit this GPU's memory: --stream-input keeps only a window of it resident)"); hipck(hipMemcpy(dc.d_quals, host.quals, host.n, hipMemcpyHostToDevice), "hipMemcpy"); }
-			ck(ctx, cl_reads_pack(ctx, d_bases, dc.d_off, dc.n_reads, 1, &dc.reads), "input");
-			hipck(hipFree(d_bases), "hipFree");
+			if (with_qual)
+			{
+				dc.d_quals = (uint8_t*)dcache.get(host.n + 1, dc.quals_cap);
+				if (!dc.d_quals) die("hipMalloc (the input does not fit this GPU's memory: --stream-input keeps only a window of it resident)");
+				hipck(hipMemcpy(dc.d_quals, host.quals, host.n, hipMemcpyHostToDevice), "hipMemcpy");
+			}
+			ck(ctx, cl_reads_pack(ctx, d_bases_stage, dc.d_off, dc.n_reads, 1, &dc.reads), "input");
 		};
 		auto free_chunk = [&](DevChunk& dc) {
 			if (dc.reads) cl_reads_free(dc.reads);
-			if (dc.d_quals) (void)hipFree(dc.d_quals);
-			if (dc.d_off) (void)hipFree(dc.d_off);
+			dcache.put(dc.d_quals, dc.quals_cap); dcache.put(dc.d_off, dc.off_cap);
 			dc.reads = nullptr; dc.d_quals = nullptr; dc.d_off = nullptr;
 		};
 		for (uint64_t i = r0; i < r1; )
@@ -761,6 +783,8 @@ static int run_compress_multi(const Options& O, const Preset& P, const QDef& qd,
 		host.release();
 		RO.n_chunks = chunks.size();
 		(void)hipFree(d_dna); if (d_qual) (void)hipFree(d_qual);
+		if (d_bases_stage) (void)hipFree(d_bases_stage);
+		dcache.clear();
 		// where this rank's parts go: an all-gather of the framed byte counts, an exclusive sum, pwrite — `dna` of all ranks first, then `qual`
 		uint64_t mine[2] = { 0, 0 };
 		for (size_t p = 0; p < RO.dsz.size(); ++p) mine[0] += varint_len(RO.counts[p]) + RO.dsz[p];
@@ -1198,10 +1222,13 @@ int run_compress(int argc, char** argv)
 			{
 				OutJob j;
 				{ std::unique_lock<std::mutex> l(omu); ocv.wait(l, [&]() { return odone || !ojobs.empty(); }); if (ojobs.empty()) return; j = std::move(ojobs.front()); ojobs.pop_front(); }
-				if (hipEventSynchronize(out_ev[j.b]) != hipSuccess) oerr = "copy of the parts to the host failed";
-				const DevChunk& dc = chunks[j.ci]; const uint32_t np = (uint32_t)j.dsz.size();
-				uint64_t o = 0; for (uint32_t p = 0; p < np; ++p) { ar.add(s_dna, h_dna2[j.b] + o, j.dsz[p], dc.parts[p + 1] - dc.parts[p]); o += j.dsz[p]; }
-				o = 0; if (with_qual) for (uint32_t p = 0; p < np; ++p) { ar.add(s_qual, h_qual2[j.b] + o, j.qsz[p], 0); o += j.qsz[p]; }
+				if (oerr.empty() && hipEventSynchronize(out_ev[j.b]) != hipSuccess) { (void)hipGetLastError(); oerr = "copy of the parts to the host failed"; }
+				if (oerr.empty())
+				{	// (after a failure nothing more goes into the archive: the jobs are only taken off the queue so that the coding thread is not left waiting)
+					const DevChunk& dc = chunks[j.ci]; const uint32_t np = (uint32_t)j.dsz.size();
+					uint64_t o = 0; for (uint32_t p = 0; p < np; ++p) { ar.add(s_dna, h_dna2[j.b] + o, j.dsz[p], dc.parts[p + 1] - dc.parts[p]); o += j.dsz[p]; }
+					o = 0; if (with_qual) for (uint32_t p = 0; p < np; ++p) { ar.add(s_qual, h_qual2[j.b] + o, j.qsz[p], 0); o += j.qsz[p]; }
+				}
 				{ std::lock_guard<std::mutex> l(omu); obusy[j.b] = false; }
 				ocv.notify_all();
 			}
@@ -1272,7 +1299,7 @@ int run_compress(int argc, char** argv)
 		{ std::lock_guard<std::mutex> l(omu); odone = true; }
 		ocv.notify_all();
 		writer.join();
-		if (!oerr.empty()) die(oerr);
+		if (!oerr.empty()) { (void)remove(O.out.c_str()); die(oerr + " (no archive was written)"); }     // (what is on disk is half a file: it goes with the error)
 		if (O.stream_input) { loader.join(); cl_ctx_destroy(lctx); hostbuf[0].release(); hostbuf[1].release(); }
 		for (int b = 0; b < 2; ++b) { (void)hipFree(d_dna2[b]); if (h_dna2[b]) (void)hipHostFree(h_dna2[b]); if (d_qual2[b]) (void)hipFree(d_qual2[b]); if (h_qual2[b]) (void)hipHostFree(h_qual2[b]); (void)hipEventDestroy(out_ev[b]); }
 		(void)hipStreamDestroy(out_stream);

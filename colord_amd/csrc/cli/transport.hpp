@@ -12,6 +12,8 @@
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 #include <atomic>
+#include <chrono>
+#include <thread>
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
@@ -34,19 +36,23 @@ struct Transport {
 
 // ---- RCCL ---------------------------------------------------------------------------------------------------------------------
 // The communicators of all rank threads of the process.  A rank that fails inside a collective (a send / recv refused, a copy, a
-// synchronisation) must not leave its peers waiting in theirs for a partner that will never come: it ABORTS every communicator of the
-// group (ncclCommAbort, from the failing thread) — the peers' pending operations end with an error, every rank returns its failure
-// to the library and the process stops.  After an abort the communicators are gone (no ncclCommDestroy).
+// synchronisation) must not leave its peers waiting in theirs for a partner that will never come.  EVERY RANK ABORTS ITS OWN
+// COMMUNICATOR, and only its own (round 6; round 5 let the failing thread abort all of them — a peer that was not inside a collective at
+// that moment would later have handed RCCL a freed communicator): the failing rank raises the group's flag and aborts its communicator;
+// a peer sees the flag at the start of its next call, or while it waits for its stream (the wait polls), aborts its own communicator —
+// which ends its pending operations with an error — and returns the failure to the library.  After an abort a communicator is gone (no
+// ncclCommDestroy); `comms` is only read again by destroy_all, after the rank threads have ended.
 struct RcclGroup {
-	std::vector<ncclComm_t> comms; std::mutex mu; bool aborted = false;
-	void abort_all()
+	std::vector<ncclComm_t> comms; std::mutex mu; std::atomic<bool> aborted{ false };
+	// the owner thread of `c` gives it up (c is set to null: nobody uses it again)
+	void abort_one(ncclComm_t& c)
 	{
 		std::lock_guard<std::mutex> l(mu);
-		if (aborted) return;
-		aborted = true;
-		for (ncclComm_t& c : comms) if (c) { (void)ncclCommAbort(c); c = nullptr; }
+		if (!c) return;
+		for (ncclComm_t& x : comms) if (x == c) x = nullptr;
+		(void)ncclCommAbort(c); c = nullptr;
 	}
-	void destroy_all() { std::lock_guard<std::mutex> l(mu); if (!aborted) for (ncclComm_t& c : comms) if (c) { (void)ncclCommDestroy(c); c = nullptr; } }
+	void destroy_all() { std::lock_guard<std::mutex> l(mu); for (ncclComm_t& c : comms) if (c) { (void)ncclCommDestroy(c); c = nullptr; } }
 };
 struct RcclTransport : Transport {
 	ncclComm_t comm = nullptr; hipStream_t stream = nullptr; int device = 0; RcclGroup* group = nullptr;
@@ -58,14 +64,45 @@ struct RcclTransport : Transport {
 		return CL_OK;
 	}
 	~RcclTransport() override { if (d_small) (void)hipFree(d_small); if (stream) (void)hipStreamDestroy(stream); }
-	// a failure inside a collective takes the peers down with it
-	cl_status fail_all(const std::string& m) { const cl_status s = fail(m); if (group) group->abort_all(); return s; }
+	// this rank gives up: the flag for the peers, its own communicator aborted
+	void give_up() { if (group) { group->aborted.store(true); group->abort_one(comm); } }
+	cl_status fail_all(const std::string& m) { const cl_status s = fail(m); give_up(); return s; }
+	// before every use of `comm`: a peer has failed (or this rank has, earlier) -> no RCCL call is made any more
+	bool alive(const char* what)
+	{
+		if (comm && !(group && group->aborted.load())) return true;
+		give_up();
+		fail(std::string(what) + ": the communicators were aborted by a rank that failed");
+		return false;
+	}
 	cl_status nc(ncclResult_t r, const char* what) { if (r == ncclSuccess) return CL_OK; return fail_all(std::string(what) + ": " + ncclGetErrorString(r)); }
-	// waits for the stream; an asynchronous error of the communicator (a peer aborted, a link went down) is an error of this call
+	// inside ncclGroupStart .. ncclGroupEnd: the failure is only noted — the group is closed first, then the rank gives up (grouped())
+	cl_status ncq(ncclResult_t r, const char* what) { if (r == ncclSuccess) return CL_OK; return fail(std::string(what) + ": " + ncclGetErrorString(r)); }
+	template<class F> cl_status grouped(const char* what, F&& body)
+	{
+		cl_status s = ncq(ncclGroupStart(), "ncclGroupStart");
+		if (s != CL_OK) { give_up(); return s; }
+		s = body();
+		const std::string first = err;
+		const cl_status e = ncq(ncclGroupEnd(), "ncclGroupEnd");                // (always closed: a group left open would swallow the next call)
+		if (s != CL_OK) { err = first; give_up(); return s; }
+		if (e != CL_OK) { give_up(); return e; }
+		return finish(what);
+	}
+	// waits for the stream — polling, so that a peer's failure ends the wait; an asynchronous error of the communicator (a link went down)
+	// is an error of this call
 	cl_status finish(const char* what)
 	{
-		if (hipStreamSynchronize(stream) != hipSuccess) { (void)hipGetLastError(); return fail_all(std::string(what) + ": synchronise"); }
-		if (group && group->aborted) return fail(std::string(what) + ": the communicators were aborted by a rank that failed");
+		for (;;)
+		{
+			const hipError_t q = hipStreamQuery(stream);
+			if (q == hipSuccess) break;
+			if (q != hipErrorNotReady) { (void)hipGetLastError(); return fail_all(std::string(what) + ": synchronise"); }
+			(void)hipGetLastError();
+			if (group && group->aborted.load()) { give_up(); (void)hipStreamSynchronize(stream); (void)hipGetLastError(); return fail(std::string(what) + ": the communicators were aborted by a rank that failed"); }
+			std::this_thread::sleep_for(std::chrono::microseconds(50));
+		}
+		if (!alive(what)) return CL_E_HIP;
 		ncclResult_t ar = ncclSuccess;
 		if (ncclCommGetAsyncError(comm, &ar) != ncclSuccess || ar != ncclSuccess) return fail_all(std::string(what) + ": " + ncclGetErrorString(ar));
 		return CL_OK;
@@ -73,6 +110,7 @@ struct RcclTransport : Transport {
 	cl_status all_gather_host(const uint64_t* h_vals, uint32_t n, uint64_t* h_out) override
 	{
 		(void)hipSetDevice(device);
+		if (!alive("all_gather_host")) return CL_E_HIP;
 		const uint64_t need = (uint64_t)n * (world + 1);
 		if (need > small_cap) { if (d_small) (void)hipFree(d_small); small_cap = need + 1024; if (hipMalloc((void**)&d_small, small_cap * 8) != hipSuccess) return fail_all("RCCL transport: hipMalloc"); }
 		if (n && hipMemcpyAsync(d_small, h_vals, (uint64_t)n * 8, hipMemcpyHostToDevice, stream) != hipSuccess) return fail_all("RCCL transport: copy in");
@@ -83,35 +121,33 @@ struct RcclTransport : Transport {
 	cl_status all_to_all_v(const void* d_send, const uint64_t* sb, void* d_recv, const uint64_t* rb) override
 	{
 		(void)hipSetDevice(device);
-		cl_status s = nc(ncclGroupStart(), "ncclGroupStart");
-		uint64_t so = 0, ro = 0;
-		for (uint32_t p = 0; p < world && s == CL_OK; ++p)
-		{	// (the share for itself travels as a send / recv pair too: one code path, RCCL makes it a local copy)
-			if (sb[p]) s = nc(ncclSend((const char*)d_send + so, (size_t)sb[p], ncclChar, (int)p, comm, stream), "ncclSend");
-			if (s == CL_OK && rb[p]) s = nc(ncclRecv((char*)d_recv + ro, (size_t)rb[p], ncclChar, (int)p, comm, stream), "ncclRecv");
-			so += sb[p]; ro += rb[p]; bytes_moved += p == rank ? 0 : sb[p];
-		}
-		const cl_status e = nc(ncclGroupEnd(), "ncclGroupEnd");                 // (always closed: a group left open would swallow the next call)
-		if (s == CL_OK) s = e;
-		if (s == CL_OK) s = finish("all_to_all_v");
-		return s;
+		if (!alive("all_to_all_v")) return CL_E_HIP;
+		return grouped("all_to_all_v", [&]() -> cl_status {
+			cl_status s = CL_OK; uint64_t so = 0, ro = 0;
+			for (uint32_t p = 0; p < world && s == CL_OK; ++p)
+			{	// (the share for itself travels as a send / recv pair too: one code path, RCCL makes it a local copy)
+				if (sb[p]) s = ncq(ncclSend((const char*)d_send + so, (size_t)sb[p], ncclChar, (int)p, comm, stream), "ncclSend");
+				if (s == CL_OK && rb[p]) s = ncq(ncclRecv((char*)d_recv + ro, (size_t)rb[p], ncclChar, (int)p, comm, stream), "ncclRecv");
+				so += sb[p]; ro += rb[p]; bytes_moved += p == rank ? 0 : sb[p];
+			}
+			return s;
+		});
 	}
 	cl_status all_gather_v(const void* d_send, uint64_t send_bytes, void* d_recv, const uint64_t* rb) override
 	{
 		(void)hipSetDevice(device);
+		if (!alive("all_gather_v")) return CL_E_HIP;
 		if (rb[rank] != send_bytes) return fail_all("all_gather_v: send_bytes != h_recv_bytes[rank]");
-		cl_status s = nc(ncclGroupStart(), "ncclGroupStart");
-		uint64_t ro = 0;
-		for (uint32_t p = 0; p < world && s == CL_OK; ++p)
-		{
-			if (send_bytes) s = nc(ncclSend(d_send, (size_t)send_bytes, ncclChar, (int)p, comm, stream), "ncclSend");
-			if (s == CL_OK && rb[p]) s = nc(ncclRecv((char*)d_recv + ro, (size_t)rb[p], ncclChar, (int)p, comm, stream), "ncclRecv");
-			ro += rb[p]; bytes_moved += p == rank ? 0 : send_bytes;
-		}
-		const cl_status e = nc(ncclGroupEnd(), "ncclGroupEnd");
-		if (s == CL_OK) s = e;
-		if (s == CL_OK) s = finish("all_gather_v");
-		return s;
+		return grouped("all_gather_v", [&]() -> cl_status {
+			cl_status s = CL_OK; uint64_t ro = 0;
+			for (uint32_t p = 0; p < world && s == CL_OK; ++p)
+			{
+				if (send_bytes) s = ncq(ncclSend(d_send, (size_t)send_bytes, ncclChar, (int)p, comm, stream), "ncclSend");
+				if (s == CL_OK && rb[p]) s = ncq(ncclRecv((char*)d_recv + ro, (size_t)rb[p], ncclChar, (int)p, comm, stream), "ncclRecv");
+				ro += rb[p]; bytes_moved += p == rank ? 0 : send_bytes;
+			}
+			return s;
+		});
 	}
 };
 

@@ -455,6 +455,7 @@ struct KernelTimer {
 // a template kernel under the name of its instantiation (as rocprofv3 lists it), so that the two sets of times can be laid side by side
 #define LAUNCHB_NAMED(ctx, name, bytes, kernel, grid, block, ...) do { (ctx)->next_bytes = (double)(bytes); KernelTimer _kt((ctx), (name)); \
 	hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, cl_launch_stream(ctx), __VA_ARGS__); } while (0)
+#define LAUNCH_NAMED(ctx, name, kernel, grid, block, ...) LAUNCHB_NAMED(ctx, name, 0.0, kernel, grid, block, __VA_ARGS__)
 // LAUNCH with the algorithmic HBM byte count of this launch (for achieved-GB/s reporting)
 #define LAUNCHB(ctx, bytes, kernel, grid, block, ...) do { (ctx)->next_bytes = (double)(bytes); LAUNCH(ctx, kernel, grid, block, __VA_ARGS__); } while (0)
 // the same with dynamic LDS
@@ -624,8 +625,11 @@ __device__ static inline uint32_t block_excl_scan_256(uint32_t v, uint32_t* sh, 
 // device-wide primitives implemented in scan.hip / sort.hip
 cl_status dev_exclusive_scan_u32(cl_ctx* ctx, uint32_t* d_data, uint64_t n, uint64_t* h_total);   // in place
 cl_status dev_exclusive_scan_u64(cl_ctx* ctx, const uint32_t* d_in, uint64_t* d_out, uint64_t n, uint64_t* h_total); // d_out has n+1
+cl_status dev_run_starts_u32(cl_ctx* ctx, const uint32_t* d_keys, uint64_t n, uint32_t shift, uint32_t* d_seg, uint64_t seg_cap, uint64_t* h_n_runs);   // scan.hip: starts of the runs of equal key >> shift in sorted keys
+cl_status dev_run_starts_u64(cl_ctx* ctx, const uint64_t* d_keys, uint64_t n, uint32_t shift, uint32_t* d_seg, uint64_t seg_cap, uint64_t* h_n_runs);
 cl_status dev_sort_pairs(cl_ctx* ctx, uint64_t* d_keys, uint32_t* d_vals, uint64_t n, uint32_t begin_bit, uint32_t end_bit);
 cl_status dev_sort_pairs_swap(cl_ctx* ctx, DevBuf<uint64_t>& keys, DevBuf<uint32_t>& vals, uint64_t n, uint32_t begin_bit, uint32_t end_bit);   // buffers of exactly n elements may come back swapped with the sort's temporaries (no copy back)
 cl_status dev_sort_keys32_pairs(cl_ctx* ctx, uint32_t* d_keys, uint32_t* d_vals, uint64_t n, uint32_t begin_bit, uint32_t end_bit);
+cl_status dev_sort_keys32_pairs_swap(cl_ctx* ctx, DevBuf<uint32_t>& keys, DevBuf<uint32_t>& vals, uint64_t n, uint32_t begin_bit, uint32_t end_bit);   // as dev_sort_pairs_swap
 
 static inline uint32_t grid_for(uint64_t n, uint32_t per_block) { return (uint32_t)((n + per_block - 1) / per_block); }

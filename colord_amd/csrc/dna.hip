@@ -68,43 +68,83 @@ struct RefCur {
 __device__ inline uint32_t ilog2_(uint64_t x) { return x ? 64u - (uint32_t)__clzll((long long)x) : 0u; }     // bit length (basic_coder.h:39-47)
 __device__ inline uint32_t no_bytes_(uint64_t x) { uint32_t r = 1; x >>= 8; for (; x; ++r) x >>= 8; return r; }
 
-// The write pass's keys on their way out.  A lane emits its symbols one at a time, 8 bytes each to consecutive places, between long
-// stretches of reading: stored one by one, the eight stores that fill a 64-byte sector arrive so far apart that the L2 writes the sector
+// A coded symbol's KEY, what the stable sort by context and the model kernels work on: dense context id << 8 | payload.  The payload is
+// the symbol and, in the two families that code with exclusions (rc.h:316-341), WHICH symbols are excluded — as a small class, not as
+// two 4-bit symbols (rounds 1-5: context << 16 | e1 << 12 | e2 << 8 | symbol, 40 bits, always a 64-bit word):
+//   F_TUPLE_TYPE  x << 3 | type     x = what the tuple before forbids (dna_coder.cpp:735-757): 0 nothing, 1 after a match, 2 after a deletion,
+//                                   3 after an anchor, 4 after a skip, 5 after an alternative-reference / main-reference tuple
+//   F_SYMBOLS     x << 2 | base     x = 0, or 1 + the reference base a substitution excludes
+//   the others    symbol (up to 256 of them)
+// At level 1 the 8.7 M contexts take 24 bits: the key is ONE 32-bit word — the walk writes, the three sort passes move, and the model
+// kernels read half the bytes (levels 2 and 3: 25 / 26 bits, 64-bit keys of the same form).
+template<typename K> struct KeyFmt {
+	static __host__ __device__ inline K make(uint32_t gctx, uint32_t payload) { return ((K)gctx << 8) | (K)payload; }
+	static __host__ __device__ inline uint32_t ctx(K k) { return (uint32_t)(k >> 8); }
+	static __host__ __device__ inline uint32_t payload(K k) { return (uint32_t)k & 0xffu; }
+};
+__device__ inline uint32_t key_payload(int fam, uint32_t sym, int e1, int e2)
+{
+	if (fam == F_TUPLE_TYPE)
+	{
+		const uint32_t x = e1 == 15 ? 0u : e2 == 15 ? (e1 == T_ANCHOR ? 1u : 2u) : e1 == T_ANCHOR ? 3u : e1 == T_DEL ? 4u : 5u;
+		return (x << 3) | sym;
+	}
+	if (fam == F_SYMBOLS) return ((e1 == 15 ? 0u : (uint32_t)e1 + 1u) << 2) | sym;
+	return sym;
+}
+// symbol and exclusions (15 = none) of a payload; fam is uniform over a context run
+__device__ inline void key_decode(uint32_t fam, uint32_t p, uint32_t& sym, uint32_t& e1, uint32_t& e2)
+{
+	if (fam == F_TUPLE_TYPE)
+	{
+		const uint32_t x = p >> 3; sym = p & 7u;
+		e1 = x == 0 ? 15u : (x == 1 || x == 3) ? (uint32_t)T_ANCHOR : x == 2 ? (uint32_t)T_SKIP : x == 4 ? (uint32_t)T_DEL : (uint32_t)T_ALT_ID;
+		e2 = x == 3 ? (uint32_t)T_MATCH : x == 4 ? (uint32_t)T_SKIP : x == 5 ? (uint32_t)T_MAIN_REF : 15u;
+	}
+	else if (fam == F_SYMBOLS) { const uint32_t x = p >> 2; sym = p & 3u; e1 = x ? x - 1u : 15u; e2 = 15u; }
+	else { sym = p; e1 = e2 = 15u; }
+}
+__device__ inline uint32_t key_sym_mask(uint32_t fam) { return fam == F_TUPLE_TYPE ? 7u : fam == F_SYMBOLS ? 3u : 0xffu; }
+
+// The write pass's keys on their way out.  A lane emits its symbols one at a time to consecutive places, between long
+// stretches of reading: stored one by one, the stores that fill a 64-byte sector arrive so far apart that the L2 writes the sector
 // back in between (PMC: 37 GB written per launch for 8.8 GB of keys) — and every one of them is one more small scattered write for the
-// memory system.  STAGED: the lane keeps the sector it is filling in LDS (slot = place & 7) and writes it as four
-// 16-byte stores back to back when it is full; the first and the last sector of its range, shared with the neighbouring chunks' lanes
-// (and, for plain reads, with k_dna_plain), go out key by key.
+// memory system.  STAGED: the lane keeps the sector it is filling in LDS (slot = place mod the keys of a sector) and writes
+// it as four 16-byte stores back to back when it is full; the first and the last sector of its range, shared with the neighbouring
+// chunks' lanes (and, for plain reads, with k_dna_plain), go out key by key.
+template<typename K>
 struct Emitter {
-	bool write; uint64_t* key; uint64_t off; uint32_t count; const FamTab* ft;
-	uint64_t* stage = nullptr; uint64_t first = 0; bool any = false;        // the lane's 8 slots in LDS (nullptr: direct stores); first place written
-	__device__ inline void put(uint64_t k)
+	static constexpr uint32_t SLOTS = 64 / sizeof(K);                        // keys of a 64-byte sector
+	bool write; K* key; uint64_t off; uint32_t count; const FamTab* ft;
+	K* stage = nullptr; uint64_t first = 0; bool any = false;              // the lane's SLOTS slots in LDS (nullptr: direct stores); first place written
+	__device__ inline void put(K k)
 	{
 		const uint64_t g = off + count;
 		if (!stage) { key[g] = k; return; }
 		if (!any) { first = g; any = true; }
-		stage[g & 7] = k;
-		if ((g & 7) != 7) return;
-		const uint64_t base = g & ~7ull;
+		stage[g & (SLOTS - 1)] = k;
+		if ((g & (SLOTS - 1)) != SLOTS - 1) return;
+		const uint64_t base = g & ~(uint64_t)(SLOTS - 1);
 		if (first <= base)
 		{
-			uint4* dst = (uint4*)(key + base);
+			uint4* dst = (uint4*)(key + base); const uint32_t* sw = (const uint32_t*)stage;
 #pragma unroll
-			for (int q = 0; q < 4; ++q) { const uint64_t a = stage[2 * q], b = stage[2 * q + 1]; dst[q] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)); }
+			for (int q = 0; q < 4; ++q) dst[q] = make_uint4(sw[4 * q], sw[4 * q + 1], sw[4 * q + 2], sw[4 * q + 3]);
 		}
-		else for (uint64_t x = first; x <= g; ++x) key[x] = stage[x & 7];
+		else for (uint64_t x = first; x <= g; ++x) key[x] = stage[x & (SLOTS - 1)];
 	}
 	// the keys of the sector the lane was filling when it stopped
 	__device__ inline void finish()
 	{
 		if (!stage || !any) return;
-		const uint64_t g = off + count, base = g & ~7ull;
-		for (uint64_t x = first > base ? first : base; x < g; ++x) key[x] = stage[x & 7];
+		const uint64_t g = off + count, base = g & ~(uint64_t)(SLOTS - 1);
+		for (uint64_t x = first > base ? first : base; x < g; ++x) key[x] = stage[x & (SLOTS - 1)];
 	}
 	__device__ inline void operator()(int fam, uint32_t ctx, uint32_t sym, int e1 = 15, int e2 = 15)
 	{
 		if (write)
 		{
-			put(((uint64_t)(ft->ctx_base[fam] + ctx) << 16) | ((uint64_t)(e1 & 15) << 12) | ((uint64_t)(e2 & 15) << 8) | sym);
+			put(KeyFmt<K>::make(ft->ctx_base[fam] + ctx, key_payload(fam, sym, e1, e2)));
 			// the triple index of symbol i, trip_index(lay, part, i), is a function of i alone within a read: k_fill_sidx writes
 			// them coalesced instead of one scattered 4-byte store per symbol here
 		}
@@ -142,7 +182,7 @@ struct EsReader {
 	}
 };
 
-__device__ inline void emit_read_len(Emitter& em, uint32_t len)                  // dna_coder.cpp:1004-1056
+template<typename K> __device__ inline void emit_read_len(Emitter<K>& em, uint32_t len)                  // dna_coder.cpp:1004-1056
 {
 	int nb = (int)ilog2_(len);
 	em(F_LEN_BITS, 0, (uint32_t)nb);
@@ -157,7 +197,7 @@ __device__ inline void emit_read_len(Emitter& em, uint32_t len)                 
 	nb -= 9; ctx += 4;
 	for (; nb > 0; nb -= 8) { em(F_LEN_DATA, ctx, suffix & 0xff); suffix >>= 8; ++ctx; }
 }
-__device__ inline void emit_read_id(Emitter& em, uint32_t id, uint32_t cur_read_id)   // :535-551
+template<typename K> __device__ inline void emit_read_id(Emitter<K>& em, uint32_t id, uint32_t cur_read_id)   // :535-551
 {
 	const int n = (int)no_bytes_(cur_read_id);
 	for (int i = n - 1; i >= 0; --i)
@@ -166,7 +206,7 @@ __device__ inline void emit_read_id(Emitter& em, uint32_t id, uint32_t cur_read_
 		em(F_READ_ID, (uint32_t)i + (add << 3), (id >> (8 * i)) & 0xff);
 	}
 }
-__device__ inline void emit_anchor_len(Emitter& em, uint32_t len)                // :958-978
+template<typename K> __device__ inline void emit_anchor_len(Emitter<K>& em, uint32_t len)                // :958-978
 {
 	for (uint32_t part = 0; len; ++part)
 	{
@@ -175,7 +215,7 @@ __device__ inline void emit_anchor_len(Emitter& em, uint32_t len)               
 		len -= 22;
 	}
 }
-__device__ inline void emit_skip_len(Emitter& em, uint32_t len, bool local)      // :1109-1137
+template<typename K> __device__ inline void emit_skip_len(Emitter<K>& em, uint32_t len, bool local)      // :1109-1137
 {
 	if (local)
 	{
@@ -219,16 +259,17 @@ __global__ void k_walk_chunks(const uint32_t* __restrict__ es_ntup, const uint8_
 	const uint32_t t = es_ntup[r] ? es_ntup[r] - 1 : 0;
 	out[r] = read_flag[r] != 2 || t == 0 ? 1u : (t + chunk - 1) / chunk;
 }
-template<bool WRITE>
+template<bool WRITE, typename K>
 __global__ __launch_bounds__(64) void k_dna_walk(const FamTab* __restrict__ ftp, RefStore R, const uint8_t* __restrict__ es, const uint64_t* __restrict__ es_off,
                                                 const uint32_t* __restrict__ es_ntup, const uint8_t* __restrict__ read_flag,
                                                 uint32_t n_reads, uint32_t prev_types, uint32_t cur_read_id0, const uint64_t* __restrict__ chunk_off, WalkCk* __restrict__ cks, uint32_t n_chunks,
                                                 uint32_t* __restrict__ counts, uint32_t* __restrict__ hdr_counts, const uint64_t* __restrict__ sym_off,
-                                                uint64_t* __restrict__ key, uint32_t* __restrict__ err, uint32_t staged)
+                                                K* __restrict__ key, uint32_t* __restrict__ err, uint32_t staged)
 {
 	__builtin_amdgcn_s_setprio(3);                                          // a launch of this kernel lasts as long as its slowest chain: its waves go first on their SIMDs
 	__shared__ FamTab ft;
-	__shared__ uint64_t s_stage[WRITE ? 64 * 9 : 1];                             // (a lane's 8 slots, 9 words apart: the lanes' stores spread over the banks)
+	constexpr uint32_t STAGE_STRIDE = Emitter<K>::SLOTS + 1;                     // (a lane's slots, an odd number of keys apart: the lanes' stores spread over the banks)
+	__shared__ K s_stage[WRITE ? 64 * STAGE_STRIDE : 1];
 	for (uint32_t i = threadIdx.x; i < sizeof(FamTab) / 4; i += blockDim.x) ((uint32_t*)&ft)[i] = ((const uint32_t*)ftp)[i];
 	__syncthreads();
 	const uint32_t CH = ft.walk_chunk, WARM = ft.walk_warm;
@@ -249,8 +290,8 @@ __global__ __launch_bounds__(64) void k_dna_walk(const FamTab* __restrict__ ftp,
 	if (!WRITE) for (uint32_t x = 0; x < n_ch; ++x) cks[c + x].read = r;
 	bool track_all = WRITE;                                                      // symbol history kept throughout
 restart:
-	Emitter em{ WRITE, key, WRITE ? sym_off[r] : 0, 0, &ft };
-	if (WRITE && staged) em.stage = s_stage + threadIdx.x * 9;
+	Emitter<K> em{ WRITE, key, WRITE ? sym_off[r] : 0, 0, &ft };
+	if (WRITE && staged) em.stage = s_stage + threadIdx.x * STAGE_STRIDE;
 	EsReader rd{ es + es_off[r], es + es_off[r + 1] };
 	uint32_t type = T_NONE, v1 = 0, v2 = 0;
 	rd.next(type, v1, v2);
@@ -507,9 +548,10 @@ __global__ __launch_bounds__(256) void k_fill_sidx(const uint64_t* __restrict__ 
 	for (uint64_t i = a + lane; i < b; i += 64) sidx[i] = (uint32_t)trip_slot(gb, pl & 63, i - p0);
 }
 // ---- D1b: bases of plain reads, one wave per read, one lane per base (dna_coder.cpp:1178-1227) ----------
+template<typename K>
 __global__ __launch_bounds__(256) void k_dna_plain(const FamTab* __restrict__ ftp, const uint8_t* __restrict__ es, const uint64_t* __restrict__ es_off,
                                                   const uint32_t* __restrict__ es_ntup, const uint8_t* __restrict__ read_flag, const uint32_t* __restrict__ hdr_counts,
-                                                  const uint64_t* __restrict__ sym_off, uint32_t r0, uint32_t r1, uint64_t* __restrict__ key)
+                                                  const uint64_t* __restrict__ sym_off, uint32_t r0, uint32_t r1, K* __restrict__ key)
 {
 	const uint32_t r = r0 + blockIdx.x * 4 + (threadIdx.x >> 6);
 	if (r >= r1) return;
@@ -537,25 +579,11 @@ __global__ __launch_bounds__(256) void k_dna_plain(const FamTab* __restrict__ ft
 			const uint32_t n = i < 4 ? i : 4;
 			for (uint32_t t = n; t >= 1; --t) ctx = ((ctx << 4) + (b[i - t] & 0xfu)) & mask;
 		}
-		key[off + i] = ((uint64_t)(cbase + ctx) << 16) | (15u << 12) | (15u << 8) | (b[i] & 0xfu);
+		key[off + i] = KeyFmt<K>::make(cbase + ctx, b[i] & 0xfu);                 // (no exclusions: the payload is the symbol in both families)
 	}
 }
 
-// ---- D3: runs of equal context in the sorted keys --------------------------------------------------------
-__global__ void k_ctx_heads(const uint64_t* __restrict__ skey, uint64_t n, uint32_t* __restrict__ flags)
-{
-	uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (j < n) flags[j] = (j == 0 || (skey[j - 1] >> 16) != (skey[j] >> 16)) ? 1u : 0u;
-}
-__global__ void k_seg_starts(const uint32_t* __restrict__ scan, uint64_t n, uint64_t n_heads, uint32_t* __restrict__ seg_start)
-{
-	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n) return;
-	uint32_t s = scan[i];
-	uint32_t nx = (i + 1 < n) ? scan[i + 1] : (uint32_t)n_heads;
-	if (nx != s) seg_start[s] = (uint32_t)i;
-	if (i == 0) seg_start[n_heads] = (uint32_t)n;
-}
+// ---- D3: runs of equal context in the sorted keys: dev_run_starts (scan.hip), one pass over the keys ---------------------------------
 
 // ---- D4': LONG runs of a small-alphabet model (e.g. the tuple-type context "match after match" holds a third of all
 // symbols).  The counters of a model between two rescales are its state at the last rescale + ADDER x (occurrences
@@ -575,14 +603,15 @@ __device__ inline uint32_t find_run(const LongRun* runs, uint32_t n_runs, uint64
 	while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (runs[mid].step0 <= step) lo = mid; else hi = mid; }
 	return lo;
 }
-__global__ void k_long_find(const uint32_t* __restrict__ seg_start, uint32_t n_seg, const uint64_t* __restrict__ skey, const FamTab* __restrict__ ftp, LongRun* __restrict__ runs /* 2 lists of cap */, uint32_t cap, uint32_t* __restrict__ n_runs /* 2 */)
+template<typename K>
+__global__ void k_long_find(const uint32_t* __restrict__ seg_start, uint32_t n_seg, const K* __restrict__ skey, const FamTab* __restrict__ ftp, LongRun* __restrict__ runs /* 2 lists of cap */, uint32_t cap, uint32_t* __restrict__ n_runs /* 2 */)
 {
 	const uint32_t sg = blockIdx.x * blockDim.x + threadIdx.x;
 	if (sg >= n_seg) return;
 	const uint32_t s = seg_start[sg], e = seg_start[sg + 1];
 	const FamTab& ft = *ftp;
 	if (e - s < ft.long_run) return;
-	const uint32_t gctx = (uint32_t)(skey[s] >> 16);
+	const uint32_t gctx = KeyFmt<K>::ctx(skey[s]);
 	uint32_t fam = 0;
 	for (uint32_t f = 1; f < N_FAM; ++f) if (gctx >= ft.ctx_base[f]) fam = f;
 	if (ft.n_sym[fam] > 32) return;
@@ -591,8 +620,8 @@ __global__ void k_long_find(const uint32_t* __restrict__ seg_start, uint32_t n_s
 	if (i < cap) { LongRun r; r.s = s; r.e = e; r.fam = fam; r.gctx = gctx; r.step0 = r.group0 = r.epoch0 = 0; r.epoch_cap = 0; r.pad = 0; runs[which * cap + i] = r; }
 }
 // one wave per group of 64 steps (4096 symbols)
-template<int NS>
-__global__ __launch_bounds__(256) void k_long_hist(const LongRun* __restrict__ runs, uint32_t n_runs, uint64_t n_groups, const uint64_t* __restrict__ skey,
+template<int NS, typename K>
+__global__ __launch_bounds__(256) void k_long_hist(const LongRun* __restrict__ runs, uint32_t n_runs, uint64_t n_groups, const K* __restrict__ skey,
                                                   uint32_t* __restrict__ step_pfx, uint32_t* __restrict__ group_tot)
 {
 	const uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; const uint32_t lane = threadIdx.x & 63;
@@ -601,6 +630,7 @@ __global__ __launch_bounds__(256) void k_long_hist(const LongRun* __restrict__ r
 	while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (runs[mid].group0 <= g) lo = mid; else hi = mid; }
 	const LongRun R = runs[lo];
 	const uint64_t gl = g - R.group0;                                          // group inside the run
+	const uint32_t smask = key_sym_mask(R.fam);
 	uint32_t c[NS];
 #pragma unroll
 	for (int a = 0; a < NS; ++a) c[a] = 0;
@@ -608,7 +638,7 @@ __global__ __launch_bounds__(256) void k_long_hist(const LongRun* __restrict__ r
 	{
 		const uint64_t j = (uint64_t)R.s + (gl * 64 + k) * 64 + lane;
 		const bool valid = j < R.e;
-		const uint32_t sym = valid ? (uint32_t)(skey[j] & 0xff) : 0xffu;
+		const uint32_t sym = valid ? (uint32_t)skey[j] & smask : 0xffu;
 #pragma unroll
 		for (uint32_t a = 0; a < NS; ++a) { const uint32_t n = (uint32_t)__popcll(__ballot(sym == a)); if (lane == k) c[a] = n; }
 	}
@@ -646,16 +676,17 @@ __global__ __launch_bounds__(64) void k_long_groups(const LongRun* __restrict__ 
 	}
 }
 // occurrences of each class among the first x symbols of the run: lane a (< NS) returns class a
-template<int NS>
-__device__ inline uint32_t long_prefix(const LongRun& R, const uint64_t* skey, const uint32_t* step_pfx, const uint32_t* group_pfx, uint32_t x, uint32_t lane)
+template<int NS, typename K>
+__device__ inline uint32_t long_prefix(const LongRun& R, const K* skey, const uint32_t* step_pfx, const uint32_t* group_pfx, uint32_t x, uint32_t lane)
 {
+	const uint32_t smask = key_sym_mask(R.fam);
 	const uint64_t step = x >> 6; const uint32_t off = x & 63;
 	const uint32_t a = lane & (NS - 1);
 	uint32_t v = group_pfx[(R.group0 + (step >> 6)) * NS + a] + (step * 64 < (uint64_t)(R.e - R.s) || off ? step_pfx[(R.step0 + step) * NS + a] : 0u);
 	if (x == R.e - R.s && off == 0)
 	{	// exactly at the end on a step boundary: the last step's prefix + its own histogram = prefix of a virtual next step
 		const uint64_t last = step - 1;
-		const uint64_t j = (uint64_t)R.s + last * 64 + lane; const uint32_t sym = j < R.e ? (uint32_t)(skey[j] & 0xff) : 0xffu;
+		const uint64_t j = (uint64_t)R.s + last * 64 + lane; const uint32_t sym = j < R.e ? (uint32_t)skey[j] & smask : 0xffu;
 		uint32_t mine = 0;
 #pragma unroll
 		for (uint32_t b = 0; b < NS; ++b) { const uint32_t n = (uint32_t)__popcll(__ballot(sym == b)); if (a == b) mine = n; }
@@ -663,7 +694,7 @@ __device__ inline uint32_t long_prefix(const LongRun& R, const uint64_t* skey, c
 	}
 	if (off)
 	{
-		const uint64_t j = (uint64_t)R.s + step * 64 + lane; const uint32_t sym = j < R.e ? (uint32_t)(skey[j] & 0xff) : 0xffu;
+		const uint64_t j = (uint64_t)R.s + step * 64 + lane; const uint32_t sym = j < R.e ? (uint32_t)skey[j] & smask : 0xffu;
 		const uint64_t below = (1ULL << off) - 1;
 		uint32_t mine = 0;
 #pragma unroll
@@ -672,8 +703,8 @@ __device__ inline uint32_t long_prefix(const LongRun& R, const uint64_t* skey, c
 	}
 	return v;
 }
-template<int NS>
-__global__ __launch_bounds__(64) void k_long_epochs(const FamTab* __restrict__ ftp, const LongRun* __restrict__ runs, uint32_t n_runs, const uint64_t* __restrict__ skey,
+template<int NS, typename K>
+__global__ __launch_bounds__(64) void k_long_epochs(const FamTab* __restrict__ ftp, const LongRun* __restrict__ runs, uint32_t n_runs, const K* __restrict__ skey,
                                                    const uint32_t* __restrict__ step_pfx, const uint32_t* __restrict__ group_pfx, uint32_t* __restrict__ state,
                                                    EpochRec<NS>* __restrict__ epochs, uint32_t* __restrict__ n_epochs, uint32_t* __restrict__ group_epoch, uint32_t* __restrict__ err)
 {
@@ -696,7 +727,7 @@ __global__ __launch_bounds__(64) void k_long_epochs(const FamTab* __restrict__ f
 		const uint32_t rr = (max_total - tot + adder - 1) / adder;              // symbols until total reaches MAX_TOTAL
 		if ((uint64_t)p + rr > L) break;
 		p += rr;
-		const uint32_t c1 = long_prefix<NS>(R, skey, step_pfx, group_pfx, p, lane);
+		const uint32_t c1 = long_prefix<NS, K>(R, skey, step_pfx, group_pfx, p, lane);
 		st += adder * (c1 - cnt0); cnt0 = c1;
 		tot += adder * rr;
 		while (tot >= max_total)
@@ -709,7 +740,7 @@ __global__ __launch_bounds__(64) void k_long_epochs(const FamTab* __restrict__ f
 		if (p == L) { if (lane < NS && ne < R.epoch_cap) { E[ne].st[lane] = st; E[ne].cnt0[lane] = cnt0; } if (lane == 0 && ne < R.epoch_cap) { E[ne].start = p; E[ne].tot = tot; } ++ne; break; }
 	}
 	// final state of the model
-	const uint32_t cl = long_prefix<NS>(R, skey, step_pfx, group_pfx, L, lane);
+	const uint32_t cl = long_prefix<NS, K>(R, skey, step_pfx, group_pfx, L, lane);
 	if (p < L) { st += adder * (cl - cnt0); tot += adder * (L - p); }
 	if (lane < n_sym) sp[lane] = st;
 	if (lane == 0) { sp[n_sym] = tot; n_epochs[r] = ne; }
@@ -728,8 +759,8 @@ __global__ __launch_bounds__(64) void k_long_epochs(const FamTab* __restrict__ f
 	}
 }
 // one wave per step
-template<int NS>
-__global__ __launch_bounds__(256) void k_long_apply(const LongRun* __restrict__ runs, uint32_t n_runs, uint64_t n_steps, const uint64_t* __restrict__ skey, const uint32_t* __restrict__ sval,
+template<int NS, typename K>
+__global__ __launch_bounds__(256) void k_long_apply(const LongRun* __restrict__ runs, uint32_t n_runs, uint64_t n_steps, const K* __restrict__ skey, const uint32_t* __restrict__ sval,
                                                    const uint32_t* __restrict__ step_pfx, const uint32_t* __restrict__ group_pfx, const EpochRec<NS>* __restrict__ epochs,
                                                    const uint32_t* __restrict__ n_epochs, const uint32_t* __restrict__ group_epoch, const FamTab* __restrict__ ftp, triple_t* __restrict__ trip)
 {
@@ -741,8 +772,8 @@ __global__ __launch_bounds__(256) void k_long_apply(const LongRun* __restrict__ 
 	const uint64_t sl = step - R.step0;                                        // step inside the run
 	const uint32_t x0 = (uint32_t)(sl * 64), x = x0 + lane;
 	const uint64_t j = (uint64_t)R.s + x; const bool valid = j < R.e;
-	const uint64_t k = valid ? skey[j] : 0;
-	const uint32_t sym = valid ? (uint32_t)(k & 0xff) : 0xffu, e1 = (uint32_t)(k >> 12) & 15u, e2 = (uint32_t)(k >> 8) & 15u;
+	uint32_t sym = 0xffu, e1 = 15u, e2 = 15u;
+	if (valid) key_decode(R.fam, KeyFmt<K>::payload(skey[j]), sym, e1, e2);
 	uint64_t m[NS];
 #pragma unroll
 	for (uint32_t a = 0; a < NS; ++a) m[a] = __ballot(sym == a);
@@ -771,7 +802,8 @@ __global__ __launch_bounds__(256) void k_long_apply(const LongRun* __restrict__ 
 
 // ---- D4: model evolution, one wave per non-empty (family, context) run ---------------------------------
 // alphabets <= 8: per-class ballots (with the two optional exclusions of rc.h:316-341); larger: LDS counters.
-__global__ __launch_bounds__(256) void k_dna_evolve(const FamTab* __restrict__ ftp, const uint64_t* __restrict__ skey, const uint32_t* __restrict__ sval,
+template<typename K>
+__global__ __launch_bounds__(256) void k_dna_evolve(const FamTab* __restrict__ ftp, const K* __restrict__ skey, const uint32_t* __restrict__ sval,
                                                    const uint32_t* __restrict__ seg_start, uint32_t n_seg, uint32_t* __restrict__ state, triple_t* __restrict__ trip)
 {
 	__shared__ uint32_t s_cnt[4][256];
@@ -781,7 +813,7 @@ __global__ __launch_bounds__(256) void k_dna_evolve(const FamTab* __restrict__ f
 	if (sg >= n_seg) return;
 	const uint32_t s = seg_start[sg], e = seg_start[sg + 1];
 	const FamTab& ft = *ftp;
-	const uint32_t gctx = (uint32_t)(skey[s] >> 16);
+	const uint32_t gctx = KeyFmt<K>::ctx(skey[s]);
 	uint32_t fam = 0;
 	for (uint32_t f = 1; f < N_FAM; ++f) if (gctx >= ft.ctx_base[f]) fam = f;
 	const uint32_t n_sym = ft.n_sym[fam], max_total = ft.max_total[fam], adder = ft.adder[fam];
@@ -796,8 +828,8 @@ __global__ __launch_bounds__(256) void k_dna_evolve(const FamTab* __restrict__ f
 		for (uint32_t j0 = s; j0 < e; j0 += 64)
 		{
 			const uint32_t j = j0 + lane; const bool valid = j < e;
-			const uint64_t k = valid ? skey[j] : 0;
-			const uint32_t sym = valid ? (uint32_t)(k & 0xff) : 0xffu, e1 = (uint32_t)(k >> 12) & 15u, e2 = (uint32_t)(k >> 8) & 15u;
+			uint32_t sym = 0xffu, e1 = 15u, e2 = 15u;
+			if (valid) key_decode(fam, KeyFmt<K>::payload(skey[j]), sym, e1, e2);
 			const uint32_t dst = valid ? sval[j] : 0u;
 			uint64_t m[8];
 #pragma unroll
@@ -860,7 +892,7 @@ __global__ __launch_bounds__(256) void k_dna_evolve(const FamTab* __restrict__ f
 	for (uint32_t j0 = s; j0 < e; j0 += 64)
 	{
 		const uint32_t j = j0 + lane; const bool valid = j < e;
-		const uint32_t sym = valid ? (uint32_t)(skey[j] & 0xff) : 0u;
+		const uint32_t sym = valid ? KeyFmt<K>::payload(skey[j]) : 0u;                // (the large alphabets code without exclusions: the payload is the symbol)
 		const uint32_t dst = valid ? sval[j] : 0u;
 		const uint32_t n_here = (e - j0) < 64 ? (e - j0) : 64;
 		uint32_t start = 0;
@@ -937,7 +969,7 @@ struct DnaGroupPrep {
 struct DnaWalked {
 	const uint8_t* d_es = nullptr; uint32_t n_reads = 0;                       // identity of the batch
 	uint32_t prev_types_in = 0, cur_read_id_in = 0, prev_types_out = 0;
-	DevBuf<uint8_t> rflag; DevBuf<uint32_t> hdr; DevBuf<uint64_t> sym_off, key;
+	DevBuf<uint8_t> rflag; DevBuf<uint32_t> hdr; DevBuf<uint64_t> sym_off, key; DevBuf<uint32_t> key32; bool narrow = false;   // the keys: 32-bit words where context + payload fit (level 1), else 64-bit
 	std::vector<uint64_t> h_sym_off;
 	bool presorted = false; std::vector<uint32_t> part_bounds; std::vector<std::unique_ptr<DnaGroupPrep>> groups;   // (keys sorted group by group, in place)
 };
@@ -946,6 +978,7 @@ struct cl_dna_coder {
 	FamTab ft;
 	DevBuf<FamTab> d_ft;
 	DevBuf<uint32_t> state;
+	uint32_t ctx_bits = 0; bool narrow = false;   // bits of the dense context ids; 32-bit keys (context << 8 | payload fits)
 	uint32_t cur_read_id = 0;        // CDNACoder::cur_read_id
 	uint32_t prev_types = 0;         // ctx_read_type (types of the last four reads)
 	uint32_t next_read_id = 0, next_prev_types = 0; bool next_valid = false;   // the same after the batch being coded (known once it is walked)
@@ -994,6 +1027,8 @@ extern "C" cl_status cl_dna_coder_create(cl_ctx* ctx, uint32_t max_alt_refs, int
 	for (int i = 0; i < N_FAM; ++i) { f.ctx_base[i] = (uint32_t)cb; f.state_base[i] = sb; cb += f.n_ctx[i]; sb += (uint64_t)f.n_ctx[i] * (f.n_sym[i] + 1); }
 	f.ctx_base[N_FAM] = (uint32_t)cb; f.state_base[N_FAM] = sb;
 	if (cb >= (1ull << 32)) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_dna_coder_create: context space too large");
+	D->ctx_bits = 1; while ((1ull << D->ctx_bits) < cb) ++D->ctx_bits;
+	D->narrow = D->ctx_bits + 8 <= 32 && !getenv("COLORD_HIP_DNA_WIDE_KEYS");     // (the knob: 64-bit keys at level 1 too, for A/B runs and for the tests of that form)
 	DEV_ALLOC(ctx, D->d_ft, 1);
 	HIP_TRY(ctx, hipMemcpyAsync(D->d_ft.p, &f, sizeof(f), hipMemcpyHostToDevice, ctx->stream));
 	DEV_ALLOC(ctx, D->state, sb);
@@ -1035,7 +1070,8 @@ cl_status dna_walk(cl_ctx* ctx, cl_dna_coder* D, const cl_reads* refs, const uin
 	const FamTab& f = D->ft;
 	RefStore R{ refs->packed.p, refs->word_off.p, refs->lens.p, refs->n_reads };
 	W.d_es = d_es; W.n_reads = n_reads; W.prev_types_in = prev_types; W.cur_read_id_in = cur_read_id;
-	DevBuf<uint8_t>& rflag = W.rflag; DevBuf<uint32_t>& hdr = W.hdr; DevBuf<uint64_t>& sym_off = W.sym_off; DevBuf<uint64_t>& key = W.key; std::vector<uint64_t>& h_sym_off = W.h_sym_off;
+	DevBuf<uint8_t>& rflag = W.rflag; DevBuf<uint32_t>& hdr = W.hdr; DevBuf<uint64_t>& sym_off = W.sym_off; std::vector<uint64_t>& h_sym_off = W.h_sym_off;
+	W.narrow = D->narrow;
 	DEV_ALLOC(ctx, rflag, (uint64_t)n_reads + 1); DEV_ALLOC(ctx, hdr, (uint64_t)n_reads + 1); DEV_ALLOC(ctx, sym_off, (uint64_t)n_reads + 1);
 	DevBuf<uint32_t> err; DEV_ALLOC(ctx, err, 1);
 	HIP_TRY(ctx, hipMemsetAsync(err.p, 0, 4, ctx->stream));
@@ -1055,9 +1091,9 @@ cl_status dna_walk(cl_ctx* ctx, cl_dna_coder* D, const cl_reads* refs, const uin
 			CL_TRY(dev_exclusive_scan_u64(ctx, counts.p, chunk_off.p, n_reads, &n_chunks));
 			if (n_chunks >= (1ull << 32)) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_dna_encode: too many tuples in one call");
 			DEV_ALLOC(ctx, cks, n_chunks);
-			LAUNCHB(ctx, (double)(h_eb[1] - h_eb[0]) + 8.0 * n_reads + (double)n_chunks * sizeof(WalkCk), (k_dna_walk<false>), grid_for(n_reads, WALK_LPW), 64, /* tuple bytes in, one count and the chunk states out */
+			LAUNCHB_NAMED(ctx, "k_dna_walk<false>", (double)(h_eb[1] - h_eb[0]) + 8.0 * n_reads + (double)n_chunks * sizeof(WalkCk), (k_dna_walk<false, uint32_t>), grid_for(n_reads, WALK_LPW), 64, /* tuple bytes in, one count and the chunk states out */
 				(const FamTab*)D->d_ft.p, R, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, n_reads,
-				prev_types, cur_read_id, (const uint64_t*)chunk_off.p, cks.p, (uint32_t)n_chunks, counts.p, hdr.p, (const uint64_t*)nullptr, (uint64_t*)nullptr, err.p, 0u);
+				prev_types, cur_read_id, (const uint64_t*)chunk_off.p, cks.p, (uint32_t)n_chunks, counts.p, hdr.p, (const uint64_t*)nullptr, (uint32_t*)nullptr, err.p, 0u);
 			HIP_TRY(ctx, hipGetLastError());
 			CL_TRY(dev_exclusive_scan_u64(ctx, counts.p, sym_off.p, n_reads, &total_syms));
 		}
@@ -1066,12 +1102,25 @@ cl_status dna_walk(cl_ctx* ctx, cl_dna_coder* D, const cl_reads* refs, const uin
 		HIP_TRY(ctx, hipMemcpy(&herr0, err.p, 4, hipMemcpyDeviceToHost));
 		if (herr0 & 2) return cl_fail(ctx, CL_E_INVALID, "cl_dna_encode: the tuple count of a read does not match its stream");
 		if (herr0) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_dna_encode: a read uses more than 64 alternative references");
-		DEV_ALLOC(ctx, key, total_syms);
-		LAUNCHB(ctx, total_syms * 9.0, (k_dna_walk<true>), grid_for(n_chunks, WALK_LPW), 64, /* tuple bytes in (<= 1 per symbol), 8 bytes per symbol out */
-			(const FamTab*)D->d_ft.p, R, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, n_reads,
-			prev_types, cur_read_id, (const uint64_t*)chunk_off.p, cks.p, (uint32_t)n_chunks, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint64_t*)sym_off.p, key.p, err.p, 1u);
-		LAUNCH(ctx, k_dna_plain, grid_for(n_reads, 4), 256, (const FamTab*)D->d_ft.p, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, (const uint32_t*)hdr.p,
-			(const uint64_t*)sym_off.p, 0u, n_reads, key.p);
+		// tuple bytes in (<= 1 per symbol), one key per symbol out
+		if (W.narrow)
+		{
+			DEV_ALLOC(ctx, W.key32, total_syms);
+			LAUNCHB_NAMED(ctx, "k_dna_walk<true>", total_syms * 5.0, (k_dna_walk<true, uint32_t>), grid_for(n_chunks, WALK_LPW), 64,
+				(const FamTab*)D->d_ft.p, R, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, n_reads,
+				prev_types, cur_read_id, (const uint64_t*)chunk_off.p, cks.p, (uint32_t)n_chunks, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint64_t*)sym_off.p, W.key32.p, err.p, 1u);
+			LAUNCH_NAMED(ctx, "k_dna_plain", (k_dna_plain<uint32_t>), grid_for(n_reads, 4), 256, (const FamTab*)D->d_ft.p, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, (const uint32_t*)hdr.p,
+				(const uint64_t*)sym_off.p, 0u, n_reads, W.key32.p);
+		}
+		else
+		{
+			DEV_ALLOC(ctx, W.key, total_syms);
+			LAUNCHB_NAMED(ctx, "k_dna_walk<true>", total_syms * 9.0, (k_dna_walk<true, uint64_t>), grid_for(n_chunks, WALK_LPW), 64,
+				(const FamTab*)D->d_ft.p, R, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, n_reads,
+				prev_types, cur_read_id, (const uint64_t*)chunk_off.p, cks.p, (uint32_t)n_chunks, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint64_t*)sym_off.p, W.key.p, err.p, 1u);
+			LAUNCH_NAMED(ctx, "k_dna_plain", (k_dna_plain<uint64_t>), grid_for(n_reads, 4), 256, (const FamTab*)D->d_ft.p, d_es, d_es_off, d_es_ntuples, (const uint8_t*)rflag.p, (const uint32_t*)hdr.p,
+				(const uint64_t*)sym_off.p, 0u, n_reads, W.key.p);
+		}
 		HIP_TRY(ctx, hipGetLastError());
 	}
 	{	// the types of the last four reads: what the batch after this one starts from
@@ -1090,7 +1139,6 @@ namespace {
 // for the triples allow): layout, triple slots, stable sort of (key, slot) by (family, context), context runs.
 cl_status dna_group_prepare(cl_ctx* ctx, cl_dna_coder* D, DnaWalked& W, uint32_t p0, const uint32_t* h_part_bounds, uint32_t n_parts, DnaGroupPrep& G)
 {
-	const FamTab& f = D->ft;
 	const std::vector<uint64_t>& h_sym_off = W.h_sym_off;
 	const uint64_t GROUP_SYMS = 5ull << 28;
 	uint32_t p1 = p0; const uint32_t r0 = h_part_bounds[p0];
@@ -1131,19 +1179,26 @@ cl_status dna_group_prepare(cl_ctx* ctx, cl_dna_coder* D, DnaWalked& W, uint32_t
 	TripLayoutDev lay{ d_pfirst.p, d_sym_start.p, G.d_gbase.p, np, d_rank.p };
 	if (n_syms)
 	{
-		uint64_t* const gkey = W.key.p + s0;                                     // this group's keys (written by the walk)
 		DEV_ALLOC(ctx, G.sidx, n_syms);
 		LAUNCHB(ctx, n_syms * 4.0, k_fill_sidx, grid_for(nr, 4), 256, (const uint64_t*)W.sym_off.p, s0, r0, r1, lay, G.sidx.p);
 		HIP_TRY(ctx, hipGetLastError());
-		uint32_t cbits = 1; while ((1ull << cbits) < f.ctx_base[N_FAM]) ++cbits;
-		if (s0 == 0 && W.key.n == n_syms) CL_TRY(dev_sort_pairs_swap(ctx, W.key, G.sidx, n_syms, 16, 16 + cbits));   // (one group = the whole batch: the usual case)
-		else CL_TRY(dev_sort_pairs(ctx, gkey, G.sidx.p, n_syms, 16, 16 + cbits));
-		DevBuf<uint32_t> hf; DEV_ALLOC(ctx, hf, n_syms);
-		LAUNCH(ctx, k_ctx_heads, grid_for(n_syms, 256), 256, (const uint64_t*)(W.key.p + s0), n_syms, hf.p);
-		CL_TRY(dev_exclusive_scan_u32(ctx, hf.p, n_syms, &G.n_seg));
-		DEV_ALLOC(ctx, G.seg, G.n_seg + 1);
-		LAUNCH(ctx, k_seg_starts, grid_for(n_syms, 256), 256, (const uint32_t*)hf.p, n_syms, G.n_seg, G.seg.p);
-		HIP_TRY(ctx, hipGetLastError());
+		const uint32_t cbits = D->ctx_bits;
+		// this group's keys (written by the walk) sorted in place — one group = the whole batch is the usual case: then the buffers are swapped
+		// with the sort's —, then the starts of the context runs (at most one per context in use: the bound of the run list)
+		const uint64_t seg_cap = std::min<uint64_t>(n_syms, D->ft.ctx_base[N_FAM]) + 1;
+		DEV_ALLOC(ctx, G.seg, seg_cap);
+		if (W.narrow)
+		{
+			if (s0 == 0 && W.key32.n == n_syms) CL_TRY(dev_sort_keys32_pairs_swap(ctx, W.key32, G.sidx, n_syms, 8, 8 + cbits));
+			else CL_TRY(dev_sort_keys32_pairs(ctx, W.key32.p + s0, G.sidx.p, n_syms, 8, 8 + cbits));
+			CL_TRY(dev_run_starts_u32(ctx, W.key32.p + s0, n_syms, 8, G.seg.p, seg_cap, &G.n_seg));
+		}
+		else
+		{
+			if (s0 == 0 && W.key.n == n_syms) CL_TRY(dev_sort_pairs_swap(ctx, W.key, G.sidx, n_syms, 8, 8 + cbits));
+			else CL_TRY(dev_sort_pairs(ctx, W.key.p + s0, G.sidx.p, n_syms, 8, 8 + cbits));
+			CL_TRY(dev_run_starts_u64(ctx, W.key.p + s0, n_syms, 8, G.seg.p, seg_cap, &G.n_seg));
+		}
 	}
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                             // (the uploads above read host vectors of this frame)
 	return CL_OK;
@@ -1176,18 +1231,36 @@ cl_status cl_dna_prepare_batch(cl_ctx* ctx, cl_dna_coder* D, const cl_reads* ref
 	*out = W.release();
 	return CL_OK;
 }
-// What dna_walk's k_last_types computes, without the walk: the flags of the last four reads come from their first tuples (k_read_flags).
-cl_status cl_dna_batch_types(cl_ctx* ctx, const uint8_t* d_es, const uint64_t* d_es_off, uint32_t n_reads, uint32_t prev_types, uint32_t* out)
+// What dna_walk's k_last_types computes, without the walk: the flags of the last four reads come from their first tuples.  ONE one-lane
+// kernel on the context's own stream, its result in a mapped host word (round 5: five blocking copies on the legacy stream, four of them
+// of one byte, under the compressor's claim lock) — and it refuses offsets that do not lie inside the tuple stream or a read without a tuple.
+namespace {
+__global__ void k_batch_types(const uint8_t* __restrict__ es, const uint64_t* __restrict__ es_off, uint32_t n_reads, uint64_t es_bytes, uint32_t prev, unsigned long long* __restrict__ out)
+{
+	uint32_t v = prev; bool ok = true;
+	const uint32_t start = n_reads > 4 ? n_reads - 4 : 0;
+	for (uint32_t r = start; r < n_reads; ++r)
+	{
+		const uint64_t a = es_off[r], b = es_off[r + 1];
+		if (a >= b || b > es_bytes) { ok = false; break; }                        // a read without a tuple, or offsets outside the stream
+		const uint32_t t = es[a] >> 4;
+		v = ((v << 2) + (t == T_START_PLAIN ? 0u : t == T_START_PLAIN_N ? 1u : 2u)) & 0xff;
+	}
+	*out = ok ? (unsigned long long)v : ~0ull;
+}
+} // namespace
+cl_status cl_dna_batch_types(cl_ctx* ctx, const uint8_t* d_es, const uint64_t* d_es_off, uint32_t n_reads, uint64_t es_bytes, uint32_t prev_types, uint32_t* out)
 {
 	if (!ctx || !d_es || !d_es_off || !out) return CL_E_INVALID;
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
-	uint32_t v = prev_types;
-	const uint32_t start = n_reads > 4 ? n_reads - 4 : 0, k = n_reads - start;
-	uint64_t off[4] = { 0, 0, 0, 0 }; uint8_t first[4] = { 0, 0, 0, 0 };
-	if (k) HIP_TRY(ctx, hipMemcpy(off, d_es_off + start, (size_t)k * 8, hipMemcpyDeviceToHost));
-	for (uint32_t i = 0; i < k; ++i) HIP_TRY(ctx, hipMemcpy(&first[i], d_es + off[i], 1, hipMemcpyDeviceToHost));
-	for (uint32_t i = 0; i < k; ++i) { const uint32_t t = first[i] >> 4; v = ((v << 2) + (t == T_START_PLAIN ? 0u : t == T_START_PLAIN_N ? 1u : 2u)) & 0xff; }
-	*out = v;
+	uint64_t* hs = nullptr; uint64_t* ds = nullptr;
+	HIP_TRY(ctx, cl_slot(ctx, 1, &hs, &ds));
+	LAUNCH(ctx, k_batch_types, 1, 1, d_es, d_es_off, n_reads, es_bytes, prev_types, (unsigned long long*)ds);
+	HIP_TRY(ctx, hipGetLastError());
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	const uint64_t v = *(volatile uint64_t*)hs;
+	if (v == ~0ull) return cl_fail(ctx, CL_E_INVALID, "cl_dna_batch_types: a tuple stream offset of the last reads lies outside the stream");
+	*out = (uint32_t)v;
 	return CL_OK;
 }
 void cl_dna_walked_free(DnaWalked* W) { delete W; }
@@ -1219,7 +1292,6 @@ cl_status dna_evolve_batch(cl_ctx* ctx, cl_dna_coder* D, const cl_reads* refs, c
 	if (Wp && Wp->presorted && (Wp->part_bounds.size() != (size_t)n_parts + 1 || memcmp(Wp->part_bounds.data(), h_part_bounds, ((size_t)n_parts + 1) * 4) != 0)) Wp.reset();
 	if (!Wp) { Wp = std::make_unique<DnaWalked>(); CL_TRY(dna_walk(ctx, D, refs, d_es, d_es_off, d_es_ntuples, n_reads, prev_types, read_id, *Wp)); }
 	DnaWalked& W = *Wp;
-	DevBuf<uint64_t>& key = W.key;
 	DevBuf<uint32_t> err; DEV_ALLOC(ctx, err, 1);
 	HIP_TRY(ctx, hipMemsetAsync(err.p, 0, 4, ctx->stream));
 	E.d_es = d_es; E.n_reads = n_reads; E.prev_types_in = prev_types; E.read_id_in = read_id; E.prev_types_out = W.prev_types_out;
@@ -1240,17 +1312,19 @@ cl_status dna_evolve_batch(cl_ctx* ctx, cl_dna_coder* D, const cl_reads* refs, c
 		DEV_ALLOC(ctx, trip, GP->trip_words);
 		if (n_syms)
 		{
-			uint64_t* const gkey = key.p + s0;                                       // this group's keys, sorted
 			DevBuf<uint32_t>& sidx = GP->sidx; DevBuf<uint32_t>& seg = GP->seg; const uint64_t n_seg = GP->n_seg;
-			LAUNCHB(ctx, n_syms * 20.0, k_dna_evolve, grid_for(n_seg, 4), 256, (const FamTab*)D->d_ft.p, (const uint64_t*)gkey, (const uint32_t*)sidx.p, (const uint32_t*)seg.p,
-				(uint32_t)n_seg, D->state.p, trip.p);
-			HIP_TRY(ctx, hipGetLastError());
-			{	// long runs of the models with up to 32 symbols (k_dna_evolve skipped them)
+			// this group's keys, sorted: the model kernels for the key width of the batch
+			auto models = [&](auto* gkey) -> cl_status {
+				typedef std::remove_cv_t<std::remove_pointer_t<decltype(gkey)>> K;
+				LAUNCHB_NAMED(ctx, "k_dna_evolve", n_syms * (12.0 + sizeof(K)), (k_dna_evolve<K>), grid_for(n_seg, 4), 256, (const FamTab*)D->d_ft.p, (const K*)gkey, (const uint32_t*)sidx.p, (const uint32_t*)seg.p,
+					(uint32_t)n_seg, D->state.p, trip.p);
+				HIP_TRY(ctx, hipGetLastError());
+				// long runs of the models with up to 32 symbols (k_dna_evolve skipped them)
 				const uint32_t RUN_CAP = (uint32_t)std::max<uint64_t>(4096, n_syms / f.long_run + 2);   // (a long run holds at least long_run symbols: never more runs than this)
 				DevBuf<LongRun> runs; DEV_ALLOC(ctx, runs, 2 * RUN_CAP);
 				DevBuf<uint32_t> n_runs; DEV_ALLOC(ctx, n_runs, 2);
 				HIP_TRY(ctx, hipMemsetAsync(n_runs.p, 0, 8, ctx->stream));
-				LAUNCH(ctx, k_long_find, grid_for(n_seg, 256), 256, (const uint32_t*)seg.p, (uint32_t)n_seg, (const uint64_t*)gkey, (const FamTab*)D->d_ft.p, runs.p, RUN_CAP, n_runs.p);
+				LAUNCH_NAMED(ctx, "k_long_find", (k_long_find<K>), grid_for(n_seg, 256), 256, (const uint32_t*)seg.p, (uint32_t)n_seg, (const K*)gkey, (const FamTab*)D->d_ft.p, runs.p, RUN_CAP, n_runs.p);
 				uint32_t nlr2[2] = { 0, 0 };
 				HIP_TRY(ctx, hipMemcpyAsync(nlr2, n_runs.p, 8, hipMemcpyDeviceToHost, ctx->stream));
 				HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1278,26 +1352,28 @@ cl_status dna_evolve_batch(cl_ctx* ctx, cl_dna_coder* D, const cl_reads* refs, c
 					const LongRun* cr = d_runs;
 					if (which == 0)
 					{
-						LAUNCHB(ctx, steps * 64 * 8.0, (k_long_hist<8>), grid_for(groups * 64, 256), 256, cr, nlr, groups, (const uint64_t*)gkey, step_pfx.p, group_pfx.p);
+						LAUNCHB_NAMED(ctx, "k_long_hist<8>", steps * 64.0 * sizeof(K), (k_long_hist<8, K>), grid_for(groups * 64, 256), 256, cr, nlr, groups, (const K*)gkey, step_pfx.p, group_pfx.p);
 						LAUNCH(ctx, (k_long_groups<8>), nlr, 64, cr, nlr, group_pfx.p);
-						LAUNCH(ctx, (k_long_epochs<8>), nlr, 64, (const FamTab*)D->d_ft.p, cr, nlr, (const uint64_t*)gkey, (const uint32_t*)step_pfx.p, (const uint32_t*)group_pfx.p,
+						LAUNCH_NAMED(ctx, "k_long_epochs<8>", (k_long_epochs<8, K>), nlr, 64, (const FamTab*)D->d_ft.p, cr, nlr, (const K*)gkey, (const uint32_t*)step_pfx.p, (const uint32_t*)group_pfx.p,
 							D->state.p, (EpochRec<8>*)epochs.p, d_ne.p, group_epoch.p, err.p);
-						LAUNCHB(ctx, steps * 64 * 20.0, (k_long_apply<8>), grid_for(steps * 64, 256), 256, cr, nlr, steps, (const uint64_t*)gkey, (const uint32_t*)sidx.p,
+						LAUNCHB_NAMED(ctx, "k_long_apply<8>", steps * 64 * (12.0 + sizeof(K)), (k_long_apply<8, K>), grid_for(steps * 64, 256), 256, cr, nlr, steps, (const K*)gkey, (const uint32_t*)sidx.p,
 							(const uint32_t*)step_pfx.p, (const uint32_t*)group_pfx.p, (const EpochRec<8>*)epochs.p, (const uint32_t*)d_ne.p, (const uint32_t*)group_epoch.p, (const FamTab*)D->d_ft.p, trip.p);
 					}
 					else
 					{
-						LAUNCHB(ctx, steps * 64 * 8.0, (k_long_hist<32>), grid_for(groups * 64, 256), 256, cr, nlr, groups, (const uint64_t*)gkey, step_pfx.p, group_pfx.p);
+						LAUNCHB_NAMED(ctx, "k_long_hist<32>", steps * 64.0 * sizeof(K), (k_long_hist<32, K>), grid_for(groups * 64, 256), 256, cr, nlr, groups, (const K*)gkey, step_pfx.p, group_pfx.p);
 						LAUNCH(ctx, (k_long_groups<32>), nlr, 64, cr, nlr, group_pfx.p);
-						LAUNCH(ctx, (k_long_epochs<32>), nlr, 64, (const FamTab*)D->d_ft.p, cr, nlr, (const uint64_t*)gkey, (const uint32_t*)step_pfx.p, (const uint32_t*)group_pfx.p,
+						LAUNCH_NAMED(ctx, "k_long_epochs<32>", (k_long_epochs<32, K>), nlr, 64, (const FamTab*)D->d_ft.p, cr, nlr, (const K*)gkey, (const uint32_t*)step_pfx.p, (const uint32_t*)group_pfx.p,
 							D->state.p, (EpochRec<32>*)epochs.p, d_ne.p, group_epoch.p, err.p);
-						LAUNCHB(ctx, steps * 64 * 20.0, (k_long_apply<32>), grid_for(steps * 64, 256), 256, cr, nlr, steps, (const uint64_t*)gkey, (const uint32_t*)sidx.p,
+						LAUNCHB_NAMED(ctx, "k_long_apply<32>", steps * 64 * (12.0 + sizeof(K)), (k_long_apply<32, K>), grid_for(steps * 64, 256), 256, cr, nlr, steps, (const K*)gkey, (const uint32_t*)sidx.p,
 							(const uint32_t*)step_pfx.p, (const uint32_t*)group_pfx.p, (const EpochRec<32>*)epochs.p, (const uint32_t*)d_ne.p, (const uint32_t*)group_epoch.p, (const FamTab*)D->d_ft.p, trip.p);
 					}
 					HIP_TRY(ctx, hipGetLastError());
 					HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 				}
-			}
+				return CL_OK;
+			};
+			if (W.narrow) CL_TRY(models((const uint32_t*)(W.key32.p + s0))); else CL_TRY(models((const uint64_t*)(W.key.p + s0)));
 			HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 		}
 		uint32_t herr = 0;

@@ -63,7 +63,7 @@ void cl_dna_walked_free(DnaWalked* W);
 void cl_dna_set_ahead(cl_dna_coder* D, DnaWalked* W);               // takes W: the next cl_dna_encode uses it if it is the batch it was made for
 void cl_dna_coder_state(const cl_dna_coder* D, uint32_t* prev_types, uint32_t* read_id);
 // the read-type history a batch hands to the next one (types of its last four reads after `prev_types`): from the first tuple of those reads alone
-cl_status cl_dna_batch_types(cl_ctx* ctx, const uint8_t* d_es, const uint64_t* d_es_off, uint32_t n_reads, uint32_t prev_types, uint32_t* out);
+cl_status cl_dna_batch_types(cl_ctx* ctx, const uint8_t* d_es, const uint64_t* d_es_off, uint32_t n_reads, uint64_t es_bytes, uint32_t prev_types, uint32_t* out);
 // the same for the quality coder (qual.hip): symbols, sort by context, context runs of a batch, on any context
 struct QualPrepared;
 cl_status cl_qual_prepare_batch(cl_ctx* ctx, cl_qual_coder* Q, const cl_reads* R, const uint8_t* d_quals, const uint64_t* d_qual_off,

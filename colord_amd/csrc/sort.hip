@@ -235,3 +235,8 @@ cl_status dev_sort_keys32_pairs(cl_ctx* ctx, uint32_t* d_keys, uint32_t* d_vals,
 {
 	return sort_impl<uint32_t>(ctx, d_keys, d_vals, n, begin_bit, end_bit);
 }
+cl_status dev_sort_keys32_pairs_swap(cl_ctx* ctx, DevBuf<uint32_t>& keys, DevBuf<uint32_t>& vals, uint64_t n, uint32_t begin_bit, uint32_t end_bit)
+{
+	if (keys.n != n || vals.n != n) return sort_impl<uint32_t>(ctx, keys.p, vals.p, n, begin_bit, end_bit);
+	return sort_impl<uint32_t>(ctx, keys.p, vals.p, n, begin_bit, end_bit, &keys, &vals);
+}

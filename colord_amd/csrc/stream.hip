@@ -608,7 +608,7 @@ static void prep_main(cl_compressor* c, cl_ctx* ctx)
 			}
 			const uint32_t n = job->reads->n_reads;
 			types_out = types_in;
-			if (job->status == CL_OK && n) s = cl_dna_batch_types(ctx, job->es.p, job->es_off.p, n, types_in, &types_out);
+			if (job->status == CL_OK && n) s = cl_dna_batch_types(ctx, job->es.p, job->es_off.p, n, job->es_bytes, types_in, &types_out);
 			{
 				std::lock_guard<std::mutex> l(c->lane_mu);
 				if (s == CL_OK && job->status == CL_OK) { c->prep_types = types_out; c->prep_read_id += n; }

@@ -247,5 +247,3 @@ def test_pipeline_under_pool_poison_and_sync_debug(env):
                        capture_output=True, text=True, env=dict(os.environ, COLORD_TEST_CHUNKED_MBASES="80", **env), cwd=root, timeout=2400)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "POOL POISON" not in r.stderr and "POOL POISON" not in r.stdout
-    if "COLORD_HIP_POOL_POISON" in env:
-        assert "[pool poison]" in r.stderr + r.stdout or True      # (the summary line is printed when the last context of the process goes)
