@@ -282,10 +282,16 @@ def hot_path_step(ctx, qctx, shard: Shard, prm: dict, with_qual: bool, exchange,
     try:
         for ch in shard.chunks:
             cmp_.count_add(ch[0])
+        if exchange is not None:
+            exchange.phase = "kmers"                         # exchange 1: k-mers to their owners, kept set back to everybody
         st = cmp_.count_finish()
         for ch in shard.chunks:
             cmp_.refs_add(ch[0])
+        if exchange is not None:
+            exchange.phase = "refs"                          # exchange 2: reference reads and index entries to everybody
         cmp_.refs_finish()
+        if exchange is not None:
+            exchange.phase = ""
         do, qo = 0, 0
         tot = dict(n_anchors=0, tuple_bytes=0, dna_bytes=0, qual_bytes=0)
         if sink is not None:
@@ -317,9 +323,13 @@ def hot_path_step(ctx, qctx, shard: Shard, prm: dict, with_qual: bool, exchange,
         cmp_.free()
     if par.world() > 1:
         # SURVEY §8e "collective for results": the parts of every rank go to the rank that writes the archive
+        t_g = time.perf_counter()
         par.gather_to_root(dna_out[:do])
         if with_qual:
             par.gather_to_root(qual_out[:qo])
+        torch.cuda.synchronize()
+        if exchange is not None:
+            exchange.log.append(("parts", "gather_to_root", time.perf_counter() - t_g, 0))
     return dict(tot_kmers=int(st.tot_kmers), kept=int(st.n_unique_counted), refs=info["n_refs_total"], sparse_range=info["sparse_range"],
                 anchors=tot["n_anchors"], tuple_bytes=tot["tuple_bytes"], dna_bytes=tot["dna_bytes"], qual_bytes=tot["qual_bytes"], parts=shard.n_parts, chunks=len(shard.chunks))
 
@@ -585,7 +595,9 @@ def e2e_cli(bases: float, coverage: float, k: int, a: int, part_symbols: int, gp
         first = out.get("headline_cut") or {}
         res = {"value": first.get("value"), "unit": "Gbases/s", "seconds": first.get("seconds"), "bases": n_bases, "fastq_bytes": os.path.getsize(fq), "fastq_written_in_s": round(t_gen, 1),
                "what": f"colord_hip compress-ont -k {k} -a {a} --part-symbols N" + (f" --gpus {gpus}" if gpus > 1 else "") + " file -> archive, whole process (mapped file indexed by several threads, chunks filled by parallel copies into "
-                       f"pinned double buffers); `value` is with the headline's part cut ({part_symbols}), `ref_cut` with the reference's 4194304 (byte-identical archive)"
+                       f"pinned double buffers); `value` is with the headline's part cut ({part_symbols}), `ref_cut` with the reference's 4194304 (byte-identical archive). "
+                       f"INPUT STATE: the FASTQ was written by this process just before, `sync`ed, and is PAGE-CACHE RESIDENT when the timed command starts (a warm-file number, "
+                       f"not a cold-disk one); an 8-s pause precedes the timed command (the driver's clean-up of the memory the process before gave back is not part of it)"
                        + ("; the C++ host: one rank thread per GPU, exchanges over RCCL (or host-staged), each rank writes its own parts" if gpus > 1 else "")}
         res.update(out)
         return res
@@ -667,6 +679,23 @@ def main():
             dist.init_process_group(backend)
     from colord_amd.device import Context
     from colord_amd import ontsim, parallel as par
+
+    preflight = None
+    if world > 1:
+        # N > 1 preflight, before any context exists: the C++ host's RCCL collectives alone (`colord_hip rccl-selftest`: all-gather, all-to-all-v
+        # and all-gather-v with uneven and empty shares, every byte checked) on as many GPUs as the box has for the ranks — a broken fabric or a
+        # broken RCCL shows here in seconds, with its message in the line, instead of as a hang of the 50-Gbase passes
+        if rank == 0:
+            exe = os.path.join(ROOT, "colord_amd", "colord_hip")
+            n_self = min(world, torch.cuda.device_count())
+            t0 = time.time()
+            try:
+                r_ = subprocess.run([exe, "rccl-selftest", "--gpus", str(n_self)], capture_output=True, text=True, timeout=300)
+                preflight = {"command": f"colord_hip rccl-selftest --gpus {n_self}", "rc": r_.returncode, "seconds": round(time.time() - t0, 2), "gpus": n_self,
+                             "output": ((r_.stdout or "") + (r_.stderr or "")).strip()[-400:]}
+            except Exception as e:
+                preflight = {"command": f"colord_hip rccl-selftest --gpus {n_self}", "rc": None, "seconds": round(time.time() - t0, 2), "error": repr(e)[:300]}
+        dist.barrier()
 
     ctx = Context(local, timing=not os.environ.get("BENCH_NO_TIMING"))
     qctx = Context(local, timing=not os.environ.get("BENCH_NO_TIMING")) if not os.environ.get("BENCH_NO_OVERLAP") else None
@@ -764,6 +793,29 @@ def main():
         dist.all_reduce(tb)
     dt = float(tdev.item())
     total_bases, total_dna, total_qual, total_reads = (int(x) for x in tb.tolist())
+    multi = None
+    if world > 1:
+        # what a first run on N GPUs needs to be read: every rank's own step times, bases and stream bytes, and where its time between the
+        # GPUs went (seconds / bytes received per exchange of the timed passes), gathered to rank 0
+        mine = {"rank": rank, "device": int(local), "step_s": [round(x, 3) for x in step_s], "bases": int(shard.n_bases), "reads": int(shard.n_reads),
+                "dna_bytes": int(info["dna_bytes"]), "qual_bytes": int(info["qual_bytes"]), "input_generation_s": round(t_gen, 1),
+                "exchange": exchange.summary() if exchange is not None else None, "exchange_bytes_received": int(exchange.bytes_moved) if exchange is not None else 0}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        if rank == 0:
+            ex_tot = {}
+            for r_ in allr:
+                for k_, e in (r_["exchange"] or {}).items():
+                    t_ = ex_tot.setdefault(k_, {"max_seconds_per_step": 0.0, "bytes_received_all_ranks_per_step": 0, "calls_per_step": e["calls"] / max(1, args.steps + args.warmup)})
+                    t_["max_seconds_per_step"] = max(t_["max_seconds_per_step"], round(e["seconds"] / max(1, args.steps + args.warmup), 4))
+                    t_["bytes_received_all_ranks_per_step"] += e["bytes_received"] // max(1, args.steps + args.warmup)
+            multi = {"backend": backend, "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0, "process_group_ranks": dist.get_world_size(),
+                     "devices": sorted({r_["device"] for r_ in allr}), "ranks_share_gpus": len({r_["device"] for r_ in allr}) < world,
+                     "per_rank": allr, "exchange_s": ex_tot,
+                     "exchange_note": "per exchange (`kmers`: k-mers to their owners + kept set to all, inside cl_compressor_count_finish; `refs`: reference reads + index entries to all, "
+                                      "inside cl_compressor_refs_finish; `parts`: compressed parts to rank 0) the slowest rank's seconds per pass and the bytes all ranks received per pass, "
+                                      "averaged over warm-up + timed passes (the callbacks do not know which pass they serve)",
+                     "rccl_selftest": preflight}
     if os.environ.get("BENCH_NO_TIMING"):                   # diagnostic: the pass time without the per-kernel events (no JSON line)
         if rank == 0:
             print(f"[bench] no kernel events: {dt / args.steps * 1e3:.1f} ms per step", file=sys.stderr)
@@ -896,6 +948,22 @@ def main():
                        "input_generation_s": round(t_gen, 1), "rank0_sizes": info},
             "roofline": roof, "cpu_baseline": cb, "size_check": size, "ref_cut": ref_cut, "t_e2e": e2e,
         }
+        if multi is not None:
+            # one model domain per rank is the only place sharding changes bytes: stream bytes per base here over the committed one-GPU run's
+            one = None
+            for r_ in (6, 5):
+                p1 = os.path.join(ROOT, "profiles", f"r0{r_}_bench_50Gbases_default.json")
+                if os.path.exists(p1):
+                    try:
+                        j1 = json.loads(open(p1).read().strip().splitlines()[-1])
+                        one = {"stream_bytes_per_base": j1["config"]["stream_bytes_per_base"], "source": os.path.basename(p1), "workload": j1["config"]["workload"][:60]}
+                        break
+                    except Exception:
+                        pass
+            here = (total_dna + total_qual) / max(total_bases, 1)
+            multi["domain_loss_vs_one_rank"] = {"value": here / one["stream_bytes_per_base"] if one else None, "stream_bytes_per_base": round(here, 4), "one_rank": one,
+                                                "what": "stream bytes per base of this run / of the committed 1-GPU run of the same recipe (meaningful at the same --bases only)"}
+            line["multi_gpu"] = multi
         print(json.dumps(line))
     else:
         shard.free()

@@ -765,26 +765,26 @@ extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* read
 		if (B.pe + pr_bits + bits_for((r1 - r0) * 2 * c) > 64) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_anchor_candidates: a read and its candidates are too long for 64-bit match keys");
 		const uint32_t nb = r1 - r0;
 		const uint32_t table_x4 = 8;                                          // table slots per m-mer, in quarters (8 = load 0.5; denser tables were slower: longer probe chains)
+		// EVERYTHING of the batch on the side stream (round 6: sizes and offsets ran on the main stream, in front of the match pass of the batch
+		// before — its two waits for scan totals and the allocation of the tables, 6 ms of host work, were a gap on the lane's main queue per
+		// batch): the caller queues the match pass of the current batch first and prepares this one while it runs
+		LaunchOn on(ctx, ctx->side);                                             // (launches, scans + timing events on the side stream)
+		B.sync.s = ctx->side;
 		DevBuf<uint32_t> tsize, nsize, err; DEV_ALLOC(ctx, tsize, nb); DEV_ALLOC(ctx, nsize, nb); DEV_ALLOC(ctx, err, 1); DEV_ALLOC(ctx, B.n_distinct, nb);
-		HIP_TRY(ctx, hipMemsetAsync(err.p, 0, 4, ctx->stream));
+		HIP_TRY(ctx, hipMemsetAsync(err.p, 0, 4, ctx->side));
 		LAUNCH(ctx, k_table_sizes, grid_for(nb, 256), 256, (const uint32_t*)reads->lens.p, (const uint8_t*)reads->has_n.p, d_cand_n, r0, r1, m, table_x4, tsize.p, nsize.p, err.p);
 		DEV_ALLOC(ctx, B.toff, (uint64_t)nb + 1); DEV_ALLOC(ctx, B.noff, (uint64_t)nb + 1);
 		uint64_t tsum = 0;
 		CL_TRY(dev_exclusive_scan_u64(ctx, tsize.p, B.toff.p, nb, &tsum));
-		CL_TRY(dev_exclusive_scan_u64(ctx, nsize.p, B.noff.p, nb, &B.nsum));
-		uint32_t herr = 0; HIP_TRY(ctx, hipMemcpy(&herr, err.p, 4, hipMemcpyDeviceToHost));
+		CL_TRY(dev_exclusive_scan_u64(ctx, nsize.p, B.noff.p, nb, &B.nsum));      // (waits for the side stream: sizes, offsets and err are complete)
+		uint32_t herr = 0; HIP_TRY(ctx, hipMemcpyAsync(&herr, err.p, 4, hipMemcpyDeviceToHost, ctx->side)); HIP_TRY(ctx, hipStreamSynchronize(ctx->side));
 		DEV_ALLOC(ctx, B.slots, tsum); DEV_ALLOC(ctx, B.next, B.nsum); DEV_ALLOC(ctx, B.bins, B.nsum); DEV_ALLOC(ctx, B.err, 1);
-		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                         // offsets complete before the side stream reads them
-		B.sync.s = ctx->side;
 		HIP_TRY(ctx, hipMemsetAsync(B.n_distinct.p, 0, (uint64_t)nb * 4, ctx->side));
 		HIP_TRY(ctx, hipMemsetAsync(B.err.p, 0, 4, ctx->side));                  // (the slots are written region by region, all of them)
 		EncTable T{ B.slots.p, B.toff.p, B.next.p, B.noff.p };
-		{
-			LaunchOn on(ctx, ctx->side);                                          // (launch + timing events on the side stream)
-			LAUNCHB(ctx, B.nsum * (0.25 + 16.0) /* 2 bits in, two 8-byte slots out per m-mer */, k_table_insert, nb, INS_T, A, r0, r1, m, T, B.n_distinct.p, B.bins.p, B.err.p);
-		}
+		LAUNCHB(ctx, B.nsum * (0.25 + 16.0) /* 2 bits in, two 8-byte slots out per m-mer */, k_table_insert, nb, INS_T, A, r0, r1, m, T, B.n_distinct.p, B.bins.p, B.err.p);
 		HIP_TRY(ctx, hipGetLastError());
-		return CL_OK;
+		return CL_OK;                                                            // (the temporaries above were read by kernels the waits above saw end)
 	};
 	std::unique_ptr<TableBatch> cur, nxt;
 	if (nr) CL_TRY(prepare(0, cur));
@@ -797,7 +797,6 @@ extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* read
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->side));                           // this batch's tables are built
 		cur->sync.s = nullptr;
 		{ uint32_t herr = 0; HIP_TRY(ctx, hipMemcpy(&herr, cur->err.p, 4, hipMemcpyDeviceToHost)); if (herr) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_anchor_candidates: a region of an m-mer table overflowed"); }
-		if (r1 < nr) CL_TRY(prepare(r1, nxt));
 		DevBuf<uint32_t>& n_distinct = cur->n_distinct;
 		EncTable T{ cur->slots.p, cur->toff.p, cur->next.p, cur->noff.p };
 		DevBuf<uint32_t> pair_cnt; DEV_ALLOC(ctx, pair_cnt, (uint64_t)n_tasks + 1);
@@ -813,6 +812,8 @@ extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* read
 			HIP_TRY(ctx, hipGetLastError());
 			unsigned long long h_np2[2] = { 0, 0 };
 			HIP_TRY(ctx, hipMemcpyAsync(h_np2, d_np.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+			// while the match pass runs: the next batch's table sizes, offsets, allocations and its table build, all on the side stream
+			if (r1 < nr && !nxt) CL_TRY(prepare(r1, nxt));
 			HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 			const unsigned long long h_np = h_np2[0];
 			n_pairs = h_np;

@@ -95,7 +95,29 @@ struct Chunk {
 		if (with_quals) { uint8_t* nq = get(nc); if (n) memcpy(nq, quals, n); give(quals); quals = nq; }
 		cap = nc;
 	}
-	void clear() { n = 0; off.assign(1, 0); packs.assign(1, 0); pack_acc = 0; parts.assign(1, 0); part_acc = 0; }
+	// the range of the quality bytes, when whoever filled the chunk has looked (the indexed reader's copy threads do, while the bytes pass
+	// through their caches: the check used to be one thread's loop over a gigabyte per chunk, on the thread that feeds the GPU)
+	uint8_t qlo = 255, qhi = 0; bool q_range = false;
+	void clear() { n = 0; off.assign(1, 0); packs.assign(1, 0); pack_acc = 0; parts.assign(1, 0); part_acc = 0; qlo = 255; qhi = 0; q_range = false; }
+	// (Phred+33 0..95: anything else would index past the coder's tables) — false: the input is refused
+	bool quals_in_range(int threads = 8)
+	{
+		if (!quals || !n) return true;
+		if (!q_range)
+		{
+			const int T = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)threads, n >> 22));
+			std::vector<uint8_t> lo(T, 255), hi(T, 0); std::vector<std::thread> th;
+			for (int i = 0; i < T; ++i) th.emplace_back([&, i]() {
+				uint8_t a = 255, b = 0; const uint8_t* q = quals;
+				for (uint64_t x = n * (uint64_t)i / T, e = n * (uint64_t)(i + 1) / T; x < e; ++x) { a = q[x] < a ? q[x] : a; b = q[x] > b ? q[x] : b; }
+				lo[i] = a; hi[i] = b;
+			});
+			for (auto& t : th) t.join();
+			for (int i = 0; i < T; ++i) { qlo = std::min(qlo, lo[i]); qhi = std::max(qhi, hi[i]); }
+			q_range = true;
+		}
+		return qlo >= 33 && qhi <= 33 + 95;
+	}
 	void release() { give(bases); give(quals); bases = quals = nullptr; cap = 0; }
 };
 struct Reader {
@@ -267,15 +289,25 @@ struct Reader {
 		if (ch.off.size() <= 1) return false;
 		{ const uint64_t total = ch.n; ch.n = 0; ch.reserve(total + 1, true); ch.n = total; }     // (nothing to carry over: the buffers are filled below)
 		const size_t cnt = rec_pos - first; const int T = (int)std::min<size_t>((size_t)threads, std::max<size_t>(1, cnt / 256));
-		std::vector<std::thread> th;
+		std::vector<std::thread> th; std::vector<uint8_t> qmin(T, 255), qmax(T, 0);
 		for (int i = 0; i < T; ++i) th.emplace_back([&, i]() {
 			// (equal shares of the chunk's bytes: the offsets are ascending)
 			const uint64_t lo_b = ch.n * (uint64_t)i / T, hi_b = ch.n * (uint64_t)(i + 1) / T;
 			size_t lo = (size_t)(std::lower_bound(ch.off.begin(), ch.off.end() - 1, lo_b) - ch.off.begin());
 			size_t hi = i + 1 == T ? cnt : (size_t)(std::lower_bound(ch.off.begin(), ch.off.end() - 1, hi_b) - ch.off.begin());
-			for (size_t x = lo; x < hi; ++x) { const Rec& r = recs[first + x]; memcpy(ch.bases + ch.off[x], r.seq, r.len); memcpy(ch.quals + ch.off[x], r.qual, r.len); }
+			uint8_t a = 255, b = 0;
+			for (size_t x = lo; x < hi; ++x)
+			{
+				const Rec& r = recs[first + x];
+				memcpy(ch.bases + ch.off[x], r.seq, r.len); memcpy(ch.quals + ch.off[x], r.qual, r.len);
+				const uint8_t* q = (const uint8_t*)r.qual;                           // (the range of the quality bytes while they are in this core's cache)
+				for (uint32_t y = 0; y < r.len; ++y) { a = q[y] < a ? q[y] : a; b = q[y] > b ? q[y] : b; }
+			}
+			qmin[i] = a; qmax[i] = b;
 		});
 		for (auto& t : th) t.join();
+		for (int i = 0; i < T; ++i) { ch.qlo = std::min(ch.qlo, qmin[i]); ch.qhi = std::max(ch.qhi, qmax[i]); }
+		ch.q_range = true;
 		return true;
 	}
 	// pack / part bookkeeping of one more read of `len` symbols: a pack closes once its reads (with one guard byte each) reach 4 Mi
@@ -704,11 +736,7 @@ static int run_compress_multi(const Options& O, const Preset& P, const QDef& qd,
 			B.finish_bounds(host);
 			fill(c0, i);
 			DevChunk dc; dc.n_reads = (uint32_t)(host.off.size() - 1); dc.n_bases = host.n; dc.packs = host.packs; dc.parts = host.parts;
-			if (with_qual)
-			{
-				uint8_t lo = 255, hi8 = 0; for (uint64_t x = 0; x < host.n; ++x) { lo = host.quals[x] < lo ? host.quals[x] : lo; hi8 = host.quals[x] > hi8 ? host.quals[x] : hi8; }
-				if (host.n && (lo < 33 || hi8 > 33 + 95)) die("quality values outside '!'..'~'+1 (Phred+33, 0..95) are not supported");
-			}
+			if (with_qual && !host.quals_in_range()) die("quality values outside '!'..'~'+1 (Phred+33, 0..95) are not supported");
 			upload_chunk(dc);
 			ck(ctx, cl_compressor_count_add(cmp, dc.reads), "pass 1");
 			if (O.stream_input) free_chunk(dc);                                 // (--stream-input: a chunk leaves HBM after each pass, as in the single-GPU path)
@@ -1074,6 +1102,7 @@ int run_compress(int argc, char** argv)
 	// where a loader thread keeps a window of chunks resident ahead of the coders) — the reference reads its file twice for the same
 	// reason (compression.cpp:432,547-561).
 	std::vector<DevChunk> chunks; Chunk hostbuf[2];
+	double t_wait_parser = 0, t_check = 0, t_upload = 0, t_scan = 0;               // (-v: where this thread's time of a pass over the input went)
 	auto for_each_chunk = [&](const std::function<void(Chunk&)>& fn) {
 		std::mutex pmu; std::condition_variable pcv; int filled[2] = { 0, 0 };      // 0 free, 1 full, 2 end of input
 		std::thread parser([&]() {
@@ -1088,7 +1117,9 @@ int run_compress(int argc, char** argv)
 		});
 		for (int hi = 0;; hi ^= 1)
 		{
+			const auto tw = std::chrono::steady_clock::now();
 			{ std::unique_lock<std::mutex> l(pmu); pcv.wait(l, [&]() { return filled[hi] != 0; }); }
+			t_wait_parser += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
 			if (filled[hi] == 2) break;
 			fn(hostbuf[hi]);
 			{ std::lock_guard<std::mutex> l(pmu); filled[hi] = 0; }
@@ -1118,18 +1149,20 @@ int run_compress(int argc, char** argv)
 	};
 	for_each_chunk([&](Chunk& host) {
 		DevChunk dc; dc.n_reads = (uint32_t)(host.off.size() - 1); dc.n_bases = host.n; dc.packs = host.packs; dc.parts = host.parts;
-		if (with_qual)
-		{	// quality bytes outside 33..128 would index past the coder's tables: the input is rejected, not coded (qualities are Phred+33)
-			uint8_t lo = 255, hi8 = 0; const uint8_t* qv = host.quals;
-			for (uint64_t i = 0; i < host.n; ++i) { lo = qv[i] < lo ? qv[i] : lo; hi8 = qv[i] > hi8 ? qv[i] : hi8; }
-			if (host.n && (lo < 33 || hi8 > 33 + 95)) die("quality values outside '!'..'~'+1 (Phred+33, 0..95) are not supported");
-		}
+		// quality bytes outside 33..128 would index past the coder's tables: the input is rejected, not coded (qualities are Phred+33)
+		auto t0 = std::chrono::steady_clock::now();
+		auto lapse = [&](double& acc) { const auto t = std::chrono::steady_clock::now(); acc += std::chrono::duration<double>(t - t0).count(); t0 = t; };
+		if (with_qual && !host.quals_in_range()) die("quality values outside '!'..'~'+1 (Phred+33, 0..95) are not supported");
+		lapse(t_check);
 		upload_chunk(ctx, host, dc);
+		lapse(t_upload);
 		ck(ctx, cl_compressor_count_add(cmp, dc.reads), "pass 1");
+		lapse(t_scan);
 		if (O.stream_input) free_chunk(dc);
 		chunks.push_back(std::move(dc));
 	});
 	lap("input parsed, uploaded and scanned (pass 1)");        // (the pinned staging of a resident input is used once more: pass 2 receives its parts in it)
+	if (O.verbose) fprintf(stderr, "# pass 1, this thread: %.2f s waiting for the parser, %.2f s quality range, %.2f s upload + packing, %.2f s k-mer scan\n", t_wait_parser, t_check, t_upload, t_scan);
 	const uint32_t n = (uint32_t)R.n_reads; const uint64_t total = R.n_bases;
 	if (!n) die("no reads in " + O.in);
 	// the header stream on a host thread, next to the GPU path (CEntrComprHeaders, entr_header.cpp:23-45)

@@ -965,6 +965,12 @@ struct DnaGroupPrep {
 	std::vector<uint32_t> rank, plen_r;                                           // part -> place (descending length); lengths by place
 	DevBuf<uint64_t> d_gbase; DevBuf<uint32_t> d_plen;
 	DevBuf<uint32_t> sidx, seg;
+	// the model-independent half of the long context runs (round 6: made with the rest of the preparation — rounds 3-5 found the runs, sorted
+	// them on the host and took their class histograms between the two model kernels of the coding thread, two host round trips and
+	// k_long_hist on the chain every chunk waits for): per alphabet class (<= 8 / <= 32 symbols) the runs in key order with their places in the
+	// step / group / epoch arrays, and the class prefixes per 64-symbol step and per 64-step group
+	struct LongPrep { uint32_t n_runs = 0; uint64_t steps = 0, groups = 0, eps = 0; DevBuf<LongRun> runs; DevBuf<uint32_t> step_pfx, group_pfx; } lp[2];
+	bool long_ready = false;
 };
 struct DnaWalked {
 	const uint8_t* d_es = nullptr; uint32_t n_reads = 0;                       // identity of the batch
@@ -1135,6 +1141,60 @@ cl_status dna_walk(cl_ctx* ctx, cl_dna_coder* D, const cl_reads* refs, const uin
 } // namespace
 
 namespace {
+// The model-independent half of the long runs of a sorted group: which context runs are long (k_long_find), their order and places (host:
+// a few hundred records), class histograms per step and group (k_long_hist, k_long_groups).  On the context of whoever prepares the group.
+template<typename K>
+cl_status dna_long_prepare(cl_ctx* ctx, cl_dna_coder* D, const K* gkey, uint64_t n_syms, DnaGroupPrep& G)
+{
+	const FamTab& f = D->ft;
+	const uint32_t RUN_CAP = (uint32_t)std::max<uint64_t>(4096, n_syms / f.long_run + 2);   // (a long run holds at least long_run symbols: never more runs than this)
+	DevBuf<LongRun> runs; DEV_ALLOC(ctx, runs, 2 * RUN_CAP);
+	DevBuf<uint32_t> n_runs; DEV_ALLOC(ctx, n_runs, 2);
+	HIP_TRY(ctx, hipMemsetAsync(n_runs.p, 0, 8, ctx->stream));
+	LAUNCH_NAMED(ctx, "k_long_find", (k_long_find<K>), grid_for(G.n_seg, 256), 256, (const uint32_t*)G.seg.p, (uint32_t)G.n_seg, gkey, (const FamTab*)D->d_ft.p, runs.p, RUN_CAP, n_runs.p);
+	uint32_t nlr2[2] = { 0, 0 };
+	HIP_TRY(ctx, hipMemcpyAsync(nlr2, n_runs.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	if (nlr2[0] > RUN_CAP || nlr2[1] > RUN_CAP) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_dna_encode: more than 4096 long context runs in one group");
+	for (int which = 0; which < 2; ++which)
+	{
+		DnaGroupPrep::LongPrep& L = G.lp[which];
+		const uint32_t nlr = nlr2[which], NS = which ? 32 : 8;
+		L.n_runs = nlr; L.steps = L.groups = L.eps = 0;
+		if (!nlr) continue;
+		std::vector<LongRun> h(nlr);
+		HIP_TRY(ctx, hipMemcpy(h.data(), runs.p + (uint64_t)which * RUN_CAP, nlr * sizeof(LongRun), hipMemcpyDeviceToHost));
+		std::sort(h.begin(), h.end(), [](const LongRun& a, const LongRun& b) { return a.s < b.s; });
+		for (auto& r : h)
+		{
+			const uint64_t Ln = r.e - r.s, ns = (Ln + 63) / 64, ngp = (ns + 63) / 64;
+			const uint64_t half = f.max_total[r.fam] / 2 / f.adder[r.fam];
+			r.step0 = L.steps; r.group0 = L.groups; r.epoch0 = L.eps; r.epoch_cap = (uint32_t)(Ln / (half > 80 ? half - 40 : 1) + 8);
+			L.steps += ns; L.groups += ngp; L.eps += r.epoch_cap;
+		}
+		DEV_ALLOC(ctx, L.runs, nlr);
+		HIP_TRY(ctx, hipMemcpyAsync(L.runs.p, h.data(), nlr * sizeof(LongRun), hipMemcpyHostToDevice, ctx->stream));
+		DEV_ALLOC(ctx, L.step_pfx, (L.steps + 1) * NS); DEV_ALLOC(ctx, L.group_pfx, (L.groups + 1) * NS);
+		const LongRun* cr = L.runs.p;
+		if (which == 0)
+		{
+			LAUNCHB_NAMED(ctx, "k_long_hist<8>", L.steps * 64.0 * sizeof(K), (k_long_hist<8, K>), grid_for(L.groups * 64, 256), 256, cr, nlr, L.groups, gkey, L.step_pfx.p, L.group_pfx.p);
+			LAUNCH(ctx, (k_long_groups<8>), nlr, 64, cr, nlr, L.group_pfx.p);
+		}
+		else
+		{
+			LAUNCHB_NAMED(ctx, "k_long_hist<32>", L.steps * 64.0 * sizeof(K), (k_long_hist<32, K>), grid_for(L.groups * 64, 256), 256, cr, nlr, L.groups, gkey, L.step_pfx.p, L.group_pfx.p);
+			LAUNCH(ctx, (k_long_groups<32>), nlr, 64, cr, nlr, L.group_pfx.p);
+		}
+		HIP_TRY(ctx, hipGetLastError());
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                           // (the upload above reads `h`)
+	}
+	G.long_ready = true;
+	return CL_OK;
+}
+} // namespace
+
+namespace {
 // The model-independent half of a group of parts starting at part p0 (as many parts as the 31-bit symbol indices and the memory
 // for the triples allow): layout, triple slots, stable sort of (key, slot) by (family, context), context runs.
 cl_status dna_group_prepare(cl_ctx* ctx, cl_dna_coder* D, DnaWalked& W, uint32_t p0, const uint32_t* h_part_bounds, uint32_t n_parts, DnaGroupPrep& G)
@@ -1192,12 +1252,14 @@ cl_status dna_group_prepare(cl_ctx* ctx, cl_dna_coder* D, DnaWalked& W, uint32_t
 			if (s0 == 0 && W.key32.n == n_syms) CL_TRY(dev_sort_keys32_pairs_swap(ctx, W.key32, G.sidx, n_syms, 8, 8 + cbits));
 			else CL_TRY(dev_sort_keys32_pairs(ctx, W.key32.p + s0, G.sidx.p, n_syms, 8, 8 + cbits));
 			CL_TRY(dev_run_starts_u32(ctx, W.key32.p + s0, n_syms, 8, G.seg.p, seg_cap, &G.n_seg));
+			CL_TRY(dna_long_prepare<uint32_t>(ctx, D, W.key32.p + s0, n_syms, G));
 		}
 		else
 		{
 			if (s0 == 0 && W.key.n == n_syms) CL_TRY(dev_sort_pairs_swap(ctx, W.key, G.sidx, n_syms, 8, 8 + cbits));
 			else CL_TRY(dev_sort_pairs(ctx, W.key.p + s0, G.sidx.p, n_syms, 8, 8 + cbits));
 			CL_TRY(dev_run_starts_u64(ctx, W.key.p + s0, n_syms, 8, G.seg.p, seg_cap, &G.n_seg));
+			CL_TRY(dna_long_prepare<uint64_t>(ctx, D, W.key.p + s0, n_syms, G));
 		}
 	}
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                             // (the uploads above read host vectors of this frame)
@@ -1285,7 +1347,6 @@ namespace {
 cl_status dna_evolve_batch(cl_ctx* ctx, cl_dna_coder* D, const cl_reads* refs, const uint8_t* d_es, const uint64_t* d_es_off, const uint32_t* d_es_ntuples, uint32_t n_reads,
                            const uint32_t* h_part_bounds, uint32_t n_parts, std::unique_ptr<DnaWalked> Wp, uint32_t prev_types, uint32_t read_id, DnaEvolved& E)
 {
-	const FamTab& f = D->ft;
 	const uint64_t* inv_tab = nullptr;
 	CL_TRY(cl_inv_table(ctx, &inv_tab));
 	// (groups sorted ahead hold for the part bounds they were made for; the keys are sorted in place, so with other bounds the walk is redone)
@@ -1314,62 +1375,37 @@ cl_status dna_evolve_batch(cl_ctx* ctx, cl_dna_coder* D, const cl_reads* refs, c
 		{
 			DevBuf<uint32_t>& sidx = GP->sidx; DevBuf<uint32_t>& seg = GP->seg; const uint64_t n_seg = GP->n_seg;
 			// this group's keys, sorted: the model kernels for the key width of the batch
+			// the model half: short runs by a wave each, then the long ones — their rescale chains and every symbol's triple from the class
+			// prefixes the preparation made (no host round trip in between: sizes and places are known)
 			auto models = [&](auto* gkey) -> cl_status {
 				typedef std::remove_cv_t<std::remove_pointer_t<decltype(gkey)>> K;
 				LAUNCHB_NAMED(ctx, "k_dna_evolve", n_syms * (12.0 + sizeof(K)), (k_dna_evolve<K>), grid_for(n_seg, 4), 256, (const FamTab*)D->d_ft.p, (const K*)gkey, (const uint32_t*)sidx.p, (const uint32_t*)seg.p,
 					(uint32_t)n_seg, D->state.p, trip.p);
 				HIP_TRY(ctx, hipGetLastError());
-				// long runs of the models with up to 32 symbols (k_dna_evolve skipped them)
-				const uint32_t RUN_CAP = (uint32_t)std::max<uint64_t>(4096, n_syms / f.long_run + 2);   // (a long run holds at least long_run symbols: never more runs than this)
-				DevBuf<LongRun> runs; DEV_ALLOC(ctx, runs, 2 * RUN_CAP);
-				DevBuf<uint32_t> n_runs; DEV_ALLOC(ctx, n_runs, 2);
-				HIP_TRY(ctx, hipMemsetAsync(n_runs.p, 0, 8, ctx->stream));
-				LAUNCH_NAMED(ctx, "k_long_find", (k_long_find<K>), grid_for(n_seg, 256), 256, (const uint32_t*)seg.p, (uint32_t)n_seg, (const K*)gkey, (const FamTab*)D->d_ft.p, runs.p, RUN_CAP, n_runs.p);
-				uint32_t nlr2[2] = { 0, 0 };
-				HIP_TRY(ctx, hipMemcpyAsync(nlr2, n_runs.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-				HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-				if (nlr2[0] > RUN_CAP || nlr2[1] > RUN_CAP) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_dna_encode: more than 4096 long context runs in one group");
 				for (int which = 0; which < 2; ++which)
 				{
-					const uint32_t nlr = nlr2[which], NS = which ? 32 : 8;
+					DnaGroupPrep::LongPrep& L = GP->lp[which];
+					const uint32_t nlr = L.n_runs, NS = which ? 32 : 8;
 					if (!nlr) continue;
-					LongRun* d_runs = runs.p + (uint64_t)which * RUN_CAP;
-					std::vector<LongRun> h(nlr);
-					HIP_TRY(ctx, hipMemcpy(h.data(), d_runs, nlr * sizeof(LongRun), hipMemcpyDeviceToHost));
-					std::sort(h.begin(), h.end(), [](const LongRun& a, const LongRun& b) { return a.s < b.s; });
-					uint64_t steps = 0, groups = 0, eps = 0;
-					for (auto& r : h)
-					{
-						const uint64_t L = r.e - r.s, ns = (L + 63) / 64, ngp = (ns + 63) / 64;
-						const uint64_t half = f.max_total[r.fam] / 2 / f.adder[r.fam];
-						r.step0 = steps; r.group0 = groups; r.epoch0 = eps; r.epoch_cap = (uint32_t)(L / (half > 80 ? half - 40 : 1) + 8);
-						steps += ns; groups += ngp; eps += r.epoch_cap;
-					}
-					HIP_TRY(ctx, hipMemcpyAsync(d_runs, h.data(), nlr * sizeof(LongRun), hipMemcpyHostToDevice, ctx->stream));
-					DevBuf<uint32_t> step_pfx, group_pfx, d_ne, group_epoch; DevBuf<uint32_t> epochs;
-					DEV_ALLOC(ctx, step_pfx, (steps + 1) * NS); DEV_ALLOC(ctx, group_pfx, (groups + 1) * NS); DEV_ALLOC(ctx, d_ne, nlr); DEV_ALLOC(ctx, group_epoch, groups + 1);
-					DEV_ALLOC(ctx, epochs, (eps + 1) * (2 + 2 * NS));
-					const LongRun* cr = d_runs;
+					DevBuf<uint32_t> d_ne, group_epoch, epochs;
+					DEV_ALLOC(ctx, d_ne, nlr); DEV_ALLOC(ctx, group_epoch, L.groups + 1); DEV_ALLOC(ctx, epochs, (L.eps + 1) * (2 + 2 * NS));
+					const LongRun* cr = L.runs.p; const uint64_t steps = L.steps;
 					if (which == 0)
 					{
-						LAUNCHB_NAMED(ctx, "k_long_hist<8>", steps * 64.0 * sizeof(K), (k_long_hist<8, K>), grid_for(groups * 64, 256), 256, cr, nlr, groups, (const K*)gkey, step_pfx.p, group_pfx.p);
-						LAUNCH(ctx, (k_long_groups<8>), nlr, 64, cr, nlr, group_pfx.p);
-						LAUNCH_NAMED(ctx, "k_long_epochs<8>", (k_long_epochs<8, K>), nlr, 64, (const FamTab*)D->d_ft.p, cr, nlr, (const K*)gkey, (const uint32_t*)step_pfx.p, (const uint32_t*)group_pfx.p,
+						LAUNCH_NAMED(ctx, "k_long_epochs<8>", (k_long_epochs<8, K>), nlr, 64, (const FamTab*)D->d_ft.p, cr, nlr, (const K*)gkey, (const uint32_t*)L.step_pfx.p, (const uint32_t*)L.group_pfx.p,
 							D->state.p, (EpochRec<8>*)epochs.p, d_ne.p, group_epoch.p, err.p);
 						LAUNCHB_NAMED(ctx, "k_long_apply<8>", steps * 64 * (12.0 + sizeof(K)), (k_long_apply<8, K>), grid_for(steps * 64, 256), 256, cr, nlr, steps, (const K*)gkey, (const uint32_t*)sidx.p,
-							(const uint32_t*)step_pfx.p, (const uint32_t*)group_pfx.p, (const EpochRec<8>*)epochs.p, (const uint32_t*)d_ne.p, (const uint32_t*)group_epoch.p, (const FamTab*)D->d_ft.p, trip.p);
+							(const uint32_t*)L.step_pfx.p, (const uint32_t*)L.group_pfx.p, (const EpochRec<8>*)epochs.p, (const uint32_t*)d_ne.p, (const uint32_t*)group_epoch.p, (const FamTab*)D->d_ft.p, trip.p);
 					}
 					else
 					{
-						LAUNCHB_NAMED(ctx, "k_long_hist<32>", steps * 64.0 * sizeof(K), (k_long_hist<32, K>), grid_for(groups * 64, 256), 256, cr, nlr, groups, (const K*)gkey, step_pfx.p, group_pfx.p);
-						LAUNCH(ctx, (k_long_groups<32>), nlr, 64, cr, nlr, group_pfx.p);
-						LAUNCH_NAMED(ctx, "k_long_epochs<32>", (k_long_epochs<32, K>), nlr, 64, (const FamTab*)D->d_ft.p, cr, nlr, (const K*)gkey, (const uint32_t*)step_pfx.p, (const uint32_t*)group_pfx.p,
+						LAUNCH_NAMED(ctx, "k_long_epochs<32>", (k_long_epochs<32, K>), nlr, 64, (const FamTab*)D->d_ft.p, cr, nlr, (const K*)gkey, (const uint32_t*)L.step_pfx.p, (const uint32_t*)L.group_pfx.p,
 							D->state.p, (EpochRec<32>*)epochs.p, d_ne.p, group_epoch.p, err.p);
 						LAUNCHB_NAMED(ctx, "k_long_apply<32>", steps * 64 * (12.0 + sizeof(K)), (k_long_apply<32, K>), grid_for(steps * 64, 256), 256, cr, nlr, steps, (const K*)gkey, (const uint32_t*)sidx.p,
-							(const uint32_t*)step_pfx.p, (const uint32_t*)group_pfx.p, (const EpochRec<32>*)epochs.p, (const uint32_t*)d_ne.p, (const uint32_t*)group_epoch.p, (const FamTab*)D->d_ft.p, trip.p);
+							(const uint32_t*)L.step_pfx.p, (const uint32_t*)L.group_pfx.p, (const EpochRec<32>*)epochs.p, (const uint32_t*)d_ne.p, (const uint32_t*)group_epoch.p, (const FamTab*)D->d_ft.p, trip.p);
 					}
 					HIP_TRY(ctx, hipGetLastError());
-					HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+					HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                       // (the temporaries above go back to the pool)
 				}
 				return CL_OK;
 			};

@@ -213,12 +213,16 @@ __global__ __launch_bounds__(256) void k_evolve_small(const uint32_t* __restrict
 	for (uint32_t a = 0; a < A; ++a) st[a] = state[(uint64_t)c * (A + 1) + a];
 	tot = state[(uint64_t)c * (A + 1) + A];
 	const uint32_t smask = (1u << sym_bits) - 1;
+	// (the step after this one is asked for before this one's triples go out: a wave's steps are a chain of load -> rank -> scatter, and
+	// the scattered stores are what the memory system takes slowest)
+	uint32_t nkey = s + lane < e ? skey[s + lane] : 0u, nval = s + lane < e ? sval[s + lane] : 0u;
 	for (uint32_t j0 = s; j0 < e; j0 += 64)
 	{
 		const uint32_t j = j0 + lane;
 		const bool valid = j < e;
-		const uint32_t sym = valid ? (skey[j] & smask) : 0xffu;
-		const uint32_t dst = valid ? sval[j] : 0u;
+		const uint32_t sym = valid ? (nkey & smask) : 0xffu;
+		const uint32_t dst = valid ? nval : 0u;
+		{ const uint32_t jn = j + 64; const bool vn = jn < e; nkey = vn ? skey[jn] : 0u; nval = vn ? sval[jn] : 0u; }
 		uint64_t m[A];
 #pragma unroll
 		for (uint32_t a = 0; a < A; ++a) m[a] = __ballot(valid && sym == a);

@@ -116,6 +116,11 @@ class TorchExchange:
         self.host_mem = device is None or torch.device(device).type == "cpu"     # CPU suite: pointers are host pointers
         self.err = None
         self.bytes_moved = 0                                                       # payload bytes this rank received (diagnostic)
+        # one record per callback: (phase, collective, seconds, bytes received from the other ranks).  `phase` is set by the driver before
+        # the library call that makes the exchange ("kmers": cl_compressor_count_finish, "refs": cl_compressor_refs_finish), so that a
+        # multi-GPU run can say where its time between the GPUs went
+        self.phase = ""
+        self.log = []
         self._cbs = (_N._EXCH_GATHER_HOST(self._gather_host), _N._EXCH_A2AV(self._all_to_all_v), _N._EXCH_GATHERV(self._all_gather_v))
         self.c_struct = _N.Exchange(None, self.rank, self.world, *self._cbs)
 
@@ -135,9 +140,12 @@ class TorchExchange:
                 return [x.view(dt) for x in t], [[c // w for c in cs] for cs in counts]
         return list(t), [list(cs) for cs in counts]
 
-    def _guard(self, fn):
+    def _guard(self, fn, op=""):
+        import time as _t
+        t0, b0 = _t.perf_counter(), self.bytes_moved
         try:
             fn()
+            self.log.append((self.phase, op, _t.perf_counter() - t0, self.bytes_moved - b0))
             return 0
         except Exception as e:                      # surfaces as CL_E_HIP from the library call; the caller re-raises self.err
             self.err = e
@@ -152,7 +160,7 @@ class TorchExchange:
             dist.all_gather(parts, mine.to(dev))
             res = torch.cat(parts).cpu().numpy().view(_np.uint64)
             _np.ctypeslib.as_array(out, (int(n) * self.world,))[:] = res
-        return self._guard(run)
+        return self._guard(run, "all_gather_host")
 
     def _all_to_all_v(self, user, d_send, h_send, d_recv, h_recv):
         def run():
@@ -169,7 +177,7 @@ class TorchExchange:
             if not self.host_mem:
                 torch.cuda.synchronize()
             self.bytes_moved += sum(rb) - rb[self.rank]
-        return self._guard(run)
+        return self._guard(run, "all_to_all_v")
 
     def _all_gather_v(self, user, d_send, send_bytes, d_recv, h_recv):
         def run():
@@ -200,7 +208,17 @@ class TorchExchange:
                 if not self.host_mem:
                     torch.cuda.synchronize()
             self.bytes_moved += sum(rb) - rb[self.rank]
-        return self._guard(run)
+        return self._guard(run, "all_gather_v")
+
+    def summary(self):
+        """Seconds, bytes received and calls per (phase, collective) since the log was last cleared."""
+        out = {}
+        for ph, op, s_, b in self.log:
+            e = out.setdefault(f"{ph or 'other'}.{op}", {"seconds": 0.0, "bytes_received": 0, "calls": 0})
+            e["seconds"] += s_; e["bytes_received"] += int(b); e["calls"] += 1
+        for e in out.values():
+            e["seconds"] = round(e["seconds"], 4)
+        return out
 
 
 def gather_to_root(t: torch.Tensor, root: int = 0):

@@ -280,3 +280,13 @@ def test_bench_launches_its_own_ranks(tmp_path):
     line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["parts_digest_stable"]
     assert line["config"]["parallelism"].startswith("reads sharded x2")
+    # what makes a first run on N GPUs readable (round 6): the RCCL self-test as a preflight, every rank's own step times and sizes, seconds
+    # and bytes per exchange, the price of one model domain per rank
+    m = line["multi_gpu"]
+    assert m["process_group_ranks"] == 2 and m["backend"] == "gloo" and m["ranks_share_gpus"] is True
+    assert m["rccl_selftest"]["rc"] == 0, m["rccl_selftest"]
+    assert [r["rank"] for r in m["per_rank"]] == [0, 1] and all(len(r["step_s"]) == 1 and r["bases"] > 0 and r["dna_bytes"] > 0 for r in m["per_rank"])
+    ex = m["exchange_s"]
+    assert ex["kmers.all_to_all_v"]["bytes_received_all_ranks_per_step"] > 0 and ex["kmers.all_gather_v"]["calls_per_step"] >= 1
+    assert ex["refs.all_gather_v"]["bytes_received_all_ranks_per_step"] > 0 and "parts.gather_to_root" in ex
+    assert "domain_loss_vs_one_rank" in m and m["domain_loss_vs_one_rank"]["stream_bytes_per_base"] > 0

@@ -1,28 +1,29 @@
-// Differential test of k_range_code (csrc/rc_dev.hpp) against a plain host loop of the reference's interval arithmetic
-// (sub_rc.h:72-100,203-210) on random triples: sizes and bytes of every part.  Debugging aid:
+// Differential test of k_range_code (csrc/rc_dev.hpp) against the ORACLE's interval coder (oracle/rc.h: orc_rce_start / _encode / _end, the
+// restatement of sub_rc.h:72-100,203-210 that the CPU suite pins to the reference's golden streams) on random triples: sizes and bytes of
+// every part.  Test infrastructure: the oracle is the checker here, nothing of it is linked into the library.  Debugging aid:
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iinclude tests/tools/rc_kernel_test.hip -o /tmp/rc_test && /tmp/rc_test
 #include "../../colord_amd/csrc/rc_dev.hpp"
+extern "C" {
+#include "../../oracle/rc.h"
+}
 #include <cstdio>
 #include <random>
 #include <vector>
 
 static std::vector<uint8_t> host_code(const std::vector<triple_t>& sy, bool dbg = false)
 {
-	const uint64_t TOP = 0x00ffffffffffffULL, MASK = 0xff00000000000000ULL;
-	uint64_t low = 0, range = MASK; std::vector<uint8_t> out;
+	orc_bytes ob{ nullptr, 0, 0 }; orc_rce e; e.out = &ob;
+	orc_rce_start(&e);
 	for (const triple_t& t : sy)
 	{
 		const uint32_t tot = (uint32_t)(t & 0x1fffff), freq = (uint32_t)((t >> 21) & 0x1fffff), cum = (uint32_t)(t >> 42);
-		range /= tot; low += range * cum; range *= freq;
-		uint32_t nb = 0;
-		while (range <= TOP)
-		{
-			if ((low ^ (low + range)) & MASK) { uint64_t r = low; range = (r | TOP) - r; }
-			out.push_back((uint8_t)(low >> 56)); low <<= 8; range <<= 8; ++nb;
-		}
-		if (dbg && (&t - sy.data()) < 40) printf("host %zu: tot %u freq %u cum %u nb %u n_out %zu low %016llx range %016llx\n", (size_t)(&t - sy.data()), tot, freq, cum, nb, out.size() - nb, (unsigned long long)low, (unsigned long long)range);
+		const size_t before = ob.n;
+		orc_rce_encode(&e, freq, cum, tot);
+		if (dbg && (&t - sy.data()) < 40) printf("oracle %zu: tot %u freq %u cum %u nb %zu n_out %zu low %016llx range %016llx\n", (size_t)(&t - sy.data()), tot, freq, cum, ob.n - before, before, (unsigned long long)e.low, (unsigned long long)e.range);
 	}
-	for (int i = 0; i < 8; ++i) { out.push_back((uint8_t)(low >> 56)); low <<= 8; }
+	orc_rce_end(&e);
+	std::vector<uint8_t> out(ob.p, ob.p + ob.n);
+	free(ob.p);
 	return out;
 }
 
@@ -77,6 +78,6 @@ int main()
 			for (uint64_t i = out_off[p] + e.size(); i < out_off[p + 1]; ++i) if (out[i] != 0xAA) { if (bad++ < 10) printf("form %d part %u: wrote beyond its size (offset %llu of size %zu)\n", form, p, (unsigned long long)(i - out_off[p]), e.size()); break; }
 		}
 	}
-	printf(bad ? "FAILED: %d parts\n" : "ok: %u parts equal the host coder, nothing written beyond a part's size\n", bad ? bad : np);
+	printf(bad ? "FAILED: %d parts\n" : "ok: %u parts equal the oracle's coder (oracle/rc.h), nothing written beyond a part's size\n", bad ? bad : np);
 	return bad ? 1 : 0;
 }
