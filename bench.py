@@ -629,7 +629,7 @@ def multi_gpu_cli_leg(rank: int, world: int, args, k: int, a: int):
 
 def load_traffic(kernel: str):
     """HBM bytes per launch of `kernel` from the newest committed PMC passes (tools/pmc_traffic.py -> profiles/r0N_traffic.json)."""
-    path = next((p for p in (os.path.join(ROOT, "profiles", f"r0{r}_traffic.json") for r in (5, 4, 3)) if os.path.exists(p)), None)
+    path = next((p for p in (os.path.join(ROOT, "profiles", f"r0{r}_traffic.json") for r in (6, 5, 4, 3)) if os.path.exists(p)), None)
     if path is None:
         return None, None
     t = json.load(open(path))

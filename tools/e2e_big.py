@@ -25,4 +25,4 @@ with tempfile.TemporaryDirectory(dir=base_dir) as tmp:
         r = subprocess.run([cli, "compress-ont", "-v", "-k", "25", "-a", "22", "--part-symbols", "65536"] + extra + [fq, os.path.join(tmp, "a.colord")], capture_output=True, text=True)
         dt = time.time() - t0
         print(f"{name}: exit {r.returncode}, {dt:.2f} s = {nb / dt / 1e9:.3f} Gbases/s, archive {os.path.getsize(os.path.join(tmp, 'a.colord')) if r.returncode == 0 else 0} bytes", flush=True)
-        print("\n".join(l for l in r.stderr.splitlines() if l.startswith("[") or l.startswith("colord_hip"))[-1500:], flush=True)
+        print("\n".join(l for l in r.stderr.splitlines() if l.startswith(("[", "colord_hip", "# pass")))[-1500:], flush=True)
