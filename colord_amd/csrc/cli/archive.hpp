@@ -16,14 +16,18 @@ struct ArchiveWriter {
 	struct Stream { std::string name; std::vector<Part> parts; };
 	FILE* f = nullptr; uint64_t off = 0; std::vector<Stream> streams;
 	static void varint(std::vector<uint8_t>& v, uint64_t x) { int n = 0; for (uint64_t t = x; t; t >>= 8) ++n; v.push_back((uint8_t)n); for (int i = n - 1; i >= 0; --i) v.push_back((uint8_t)(x >> (8 * i))); }
-	void open(const std::string& path) { f = fopen(path.c_str(), "wb"); if (!f) die("cannot open file: " + path); }
+	std::vector<char> iobuf;
+	// (a large stream buffer: with the bench's 64-Ki parts an archive is half a million parts of 10-20 KB, each of which went to the kernel as a
+	// write of its own through stdio's 4-KB buffer — the writer thread of `colord_hip` could not keep up with the coders at 20 Gbases)
+	void open(const std::string& path) { f = fopen(path.c_str(), "wb"); if (!f) die("cannot open file: " + path); iobuf.resize(32u << 20); setvbuf(f, iobuf.data(), _IOFBF, iobuf.size()); }
 	int reg(const std::string& n) { streams.push_back(Stream{ n, {} }); return (int)streams.size() - 1; }
 	void add(int s, const uint8_t* p, uint64_t n, uint64_t meta)
 	{
-		std::vector<uint8_t> h; varint(h, meta);
+		uint8_t h[9]; size_t hn = 0;                                          // varint(meta)
+		{ int nb = 0; for (uint64_t t = meta; t; t >>= 8) ++nb; h[hn++] = (uint8_t)nb; for (int i = nb - 1; i >= 0; --i) h[hn++] = (uint8_t)(meta >> (8 * i)); }
 		streams[s].parts.push_back(Part{ off, n });
-		if (fwrite(h.data(), 1, h.size(), f) != h.size() || (n && fwrite(p, 1, n, f) != n)) die("cannot write the archive (disk full?)");
-		off += h.size() + n;
+		if (fwrite(h, 1, hn, f) != hn || (n && fwrite(p, 1, n, f) != n)) die("cannot write the archive (disk full?)");
+		off += hn + n;
 	}
 	void close()
 	{

@@ -1127,14 +1127,18 @@ int run_compress(int argc, char** argv)
 		}
 		parser.join();
 	};
+	// (the 1-byte-per-base form cl_reads_pack reads is needed only during the call: ONE staging buffer per calling thread, kept — a
+	// hipMalloc + hipFree per chunk were two device-wide synchronisations in front of every chunk's k-mer scan)
+	struct BaseStage { uint8_t* p = nullptr; uint64_t cap = 0; ~BaseStage() { if (p) (void)hipFree(p); } };
+	BaseStage stage_main, stage_loader;
 	auto upload_chunk = [&](cl_ctx* uc, const Chunk& host, DevChunk& dc) {
-		uint8_t* d_bases = nullptr;
-		hipck(hipMalloc((void**)&d_bases, host.n + 1), "hipMalloc"); hipck(hipMalloc((void**)&dc.d_off, host.off.size() * 8), "hipMalloc");
-		hipck(hipMemcpy(d_bases, host.bases, host.n, hipMemcpyHostToDevice), "hipMemcpy");
+		BaseStage& bs = uc == ctx ? stage_main : stage_loader;
+		if (host.n + 1 > bs.cap) { if (bs.p) hipck(hipFree(bs.p), "hipFree"); bs.cap = host.n + host.n / 8 + 4096; hipck(hipMalloc((void**)&bs.p, bs.cap), "hipMalloc"); }
+		hipck(hipMalloc((void**)&dc.d_off, host.off.size() * 8), "hipMalloc");
+		hipck(hipMemcpy(bs.p, host.bases, host.n, hipMemcpyHostToDevice), "hipMemcpy");
 		hipck(hipMemcpy(dc.d_off, host.off.data(), host.off.size() * 8, hipMemcpyHostToDevice), "hipMemcpy");
 		if (with_qual) { hipck(hipMalloc((void**)&dc.d_quals, host.n + 1), "hipMalloc (the input does not fit this GPU's memory: --stream-input keeps only a window of it resident)"); hipck(hipMemcpy(dc.d_quals, host.quals, host.n, hipMemcpyHostToDevice), "hipMemcpy"); }
-		ck(uc, cl_reads_pack(uc, d_bases, dc.d_off, dc.n_reads, 1, &dc.reads), "input");        // "Only ACGTN symbols supported inside a read"
-		hipck(hipFree(d_bases), "hipFree");
+		ck(uc, cl_reads_pack(uc, bs.p, dc.d_off, dc.n_reads, 1, &dc.reads), "input");        // "Only ACGTN symbols supported inside a read"
 	};
 	auto free_chunk = [&](DevChunk& dc) {
 		if (dc.reads) cl_reads_free(dc.reads);
