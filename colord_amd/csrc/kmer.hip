@@ -498,20 +498,34 @@ __global__ __launch_bounds__(256) void k_key_hist(const uint64_t* __restrict__ k
 	__syncthreads();
 	for (uint32_t i = threadIdx.x; i < PART_BINS; i += 256) if (sh[i]) atomicAdd(&bins[i], (unsigned long long)sh[i]);
 }
-// keys whose bin lies in [b0, b1) are appended to out (any order: they are sorted next)
+// keys whose bin lies in [b0, b1) are appended to out (any order: they are sorted next).  A block takes 4096 keys and ONE place in the
+// output (round 6: a block of 256 keys — 16 M returning atomics on one word per launch of the 50-Gbase pass, and one word takes ~88 per
+// microsecond, MI355X_MICROARCH.md `dequeue`: 195 ms per launch where the 33 GB it reads are 10 ms; four launches per pass, all of them
+// in pass 1, which nothing overlaps).
+constexpr uint32_t GATHER_ITEMS = 16;
 __global__ __launch_bounds__(256) void k_key_gather(const uint64_t* __restrict__ keys, uint64_t n, uint32_t shift, uint32_t b0, uint32_t b1,
                                                     uint64_t* __restrict__ out, unsigned long long* __restrict__ counter)
 {
 	__shared__ uint32_t sh[4];
 	__shared__ unsigned long long sbase;
-	const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-	uint64_t key = 0; uint32_t take = 0;
-	if (i < n) { key = keys[i]; const uint32_t b = (uint32_t)(key >> shift) & (PART_BINS - 1); take = b >= b0 && b < b1; }
+	const uint64_t base = (uint64_t)blockIdx.x * (256 * GATHER_ITEMS) + threadIdx.x;
+	uint64_t key[GATHER_ITEMS]; uint32_t mask = 0, mine = 0;
+#pragma unroll
+	for (uint32_t j = 0; j < GATHER_ITEMS; ++j)
+	{
+		const uint64_t i = base + (uint64_t)j * 256;
+		key[j] = i < n ? keys[i] : 0;
+		const uint32_t b = (uint32_t)(key[j] >> shift) & (PART_BINS - 1);
+		const uint32_t take = i < n && b >= b0 && b < b1;
+		mask |= take << j; mine += take;
+	}
 	uint32_t total;
-	const uint32_t ex = block_excl_scan_256(take, sh, &total);
+	const uint32_t ex = block_excl_scan_256(mine, sh, &total);
 	if (threadIdx.x == 0) sbase = total ? atomicAdd(counter, (unsigned long long)total) : 0ULL;
 	__syncthreads();
-	if (take) out[sbase + ex] = key;
+	uint64_t at = sbase + ex;
+#pragma unroll
+	for (uint32_t j = 0; j < GATHER_ITEMS; ++j) if ((mask >> j) & 1u) out[at++] = key[j];
 }
 struct CountPiece { DevBuf<uint64_t> keys; DevBuf<uint32_t> counts; uint64_t n = 0; };
 } // namespace
@@ -534,7 +548,7 @@ cl_status cl_key_gather(cl_ctx* ctx, const uint64_t* d_kmers, uint64_t n, uint32
 {
 	DevBuf<unsigned long long> counter; DEV_ALLOC(ctx, counter, 1);
 	HIP_TRY(ctx, hipMemsetAsync(counter.p, 0, 8, ctx->stream));
-	if (n) LAUNCHB(ctx, n * 8.0 + expect * 8.0, k_key_gather, grid_for(n, 256), 256, d_kmers, n, cl_part_shift(k), b0, b1, d_out, counter.p);
+	if (n) LAUNCHB(ctx, n * 8.0 + expect * 8.0, k_key_gather, grid_for(n, 256 * GATHER_ITEMS), 256, d_kmers, n, cl_part_shift(k), b0, b1, d_out, counter.p);
 	HIP_TRY(ctx, hipGetLastError());
 	unsigned long long got = 0;
 	HIP_TRY(ctx, hipMemcpyAsync(&got, counter.p, 8, hipMemcpyDeviceToHost, ctx->stream));

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void k_qual_symbols(const QualCfg* __restrict_
                                                      const uint64_t* __restrict__ qoff, const uint8_t* __restrict__ flags,
                                                      uint32_t r0, uint32_t r1, uint64_t q0, TripLayoutDev lay,
                                                      uint32_t* __restrict__ key, uint32_t* __restrict__ sidx_out,
-                                                     uint32_t* __restrict__ bkey, uint32_t* __restrict__ bsidx)
+                                                     uint32_t* __restrict__ bkey, uint32_t* __restrict__ bsidx, uint32_t* __restrict__ bad)
 {
 	__shared__ QualCfg cfg;
 	for (uint32_t i = threadIdx.x; i < sizeof(QualCfg) / 4; i += blockDim.x) ((uint32_t*)&cfg)[i] = ((const uint32_t*)cfgp)[i];
@@ -110,6 +110,9 @@ __global__ __launch_bounds__(256) void k_qual_symbols(const QualCfg* __restrict_
 	const uint64_t s_read = (per_base ? (qb - q0) : 0) + (uint64_t)(r - r0) * navg;
 	const uint64_t k_read = qb - q0;
 	const uint32_t part = part_of_read(lay, r);
+	// (every quality byte passes through here once: the range check — Phred+33 0..95, anything else would index past the 96-entry maps — rides
+	// along; rounds 1-5 made a pass of its own over the qualities for it, k_qual_check: 1 byte per base of the 3.2 the whole path must move)
+	bool out_of_range = false;
 
 	if (navg)
 	{	// per-read averages: integer sums are exact, so sum/cnt in double equals the reference's accumulation
@@ -117,7 +120,8 @@ __global__ __launch_bounds__(256) void k_qual_symbols(const QualCfg* __restrict_
 		for (uint32_t i = lane; i < len; i += 64)
 		{
 			uint32_t q = quals[qb + i] - 33u;
-			uint32_t b = cfg.mode == QM_AVERAGE ? 0u : cfg.map_fwd[q];
+			out_of_range |= q > 95u;
+			uint32_t b = cfg.mode == QM_AVERAGE ? 0u : cfg.map_fwd[q > 95u ? 0u : q];
 #pragma unroll
 			for (uint32_t t = 0; t < 5; ++t) if (b == t) { sum[t] += q; cnt[t] += 1; }
 		}
@@ -147,12 +151,13 @@ __global__ __launch_bounds__(256) void k_qual_symbols(const QualCfg* __restrict_
 			}
 		}
 	}
-	if (cfg.mode == QM_AVERAGE || cfg.mode == QM_NONE) return;
+	if (cfg.mode == QM_AVERAGE || cfg.mode == QM_NONE) { if (__ballot(out_of_range) && lane == 0) atomicOr(bad, 1u); return; }
 
 	const uint32_t sym_mask = (1u << cfg.bits_per_sym) - 1;
 	for (uint32_t i = lane; i < len; i += 64)
 	{
 		uint32_t qv = quals[qb + i] - 33u;
+		if (qv > 95u) { out_of_range = true; qv = 0; }
 		uint32_t sym = cfg.map_fwd[qv];
 		// history: context values of positions i-1 .. i-n (missing = all ones)
 		uint32_t hist = 0;
@@ -161,7 +166,8 @@ __global__ __launch_bounds__(256) void k_qual_symbols(const QualCfg* __restrict_
 			uint32_t v = sym_mask;
 			if (i >= t)
 			{
-				uint32_t s = cfg.map_fwd[quals[qb + i - t] - 33u];
+				const uint32_t qp = quals[qb + i - t] - 33u;                          // (checked at its own position)
+				uint32_t s = cfg.map_fwd[qp > 95u ? 0u : qp];
 				v = cfg.mode == QM_ORIGINAL ? cfg.quant[s] : s;
 			}
 			hist |= (v & sym_mask) << ((t - 1) * cfg.bits_per_sym);
@@ -181,6 +187,7 @@ __global__ __launch_bounds__(256) void k_qual_symbols(const QualCfg* __restrict_
 		key[k_read + i] = (ctx << cfg.sym_bits) | sym;
 		sidx_out[k_read + i] = trip_index(lay, part, s_read + navg + i);
 	}
+	if (__ballot(out_of_range) && lane == 0) atomicOr(bad, 1u);
 }
 
 // ---- Q3: run bounds of every context in the sorted key array --------------------------------------
@@ -430,28 +437,6 @@ extern "C" void cl_qual_coder_free(cl_qual_coder* q) { delete q; }
 
 // CEntrComprQuals::Compress for a batch of whole parts (entr_qual.h:100-135).  Models persist across calls.
 namespace {
-__global__ __launch_bounds__(256) void k_qual_check(const uint8_t* __restrict__ q, uint64_t n, uint32_t* __restrict__ bad)
-{	// every byte in '!' .. '!' + 95; sixteen bytes per load (a byte per lane was 26 ms per Gbase: 64-byte requests)
-	const uint64_t head = n < 16 ? n : ((16 - ((uint64_t)(size_t)q & 15)) & 15);    // bytes before the first 16-byte boundary
-	const uint64_t n16 = (n - head) / 16, tail0 = head + n16 * 16;
-	bool b = false;
-	const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x, stride = (uint64_t)gridDim.x * 256;
-	const uint4* v = (const uint4*)(q + head);
-	for (uint64_t i = t; i < n16; i += stride)
-	{
-		const uint4 w = v[i];
-		const uint32_t x[4] = { w.x, w.y, w.z, w.w };
-#pragma unroll
-		for (int k = 0; k < 4; ++k)
-#pragma unroll
-			for (int s = 0; s < 32; s += 8) b |= (((x[k] >> s) & 0xffu) - 33u) > 95u;
-	}
-	if (t < head) b |= ((uint32_t)q[t] - 33u) > 95u;
-	if (tail0 + t < n && t < 16) b |= ((uint32_t)q[tail0 + t] - 33u) > 95u;
-	if (__ballot(b) && (threadIdx.x & 63) == 0) atomicOr(bad, 1u);
-}
-} // namespace
-namespace {
 cl_status qual_prepare(cl_ctx* ctx, cl_qual_coder* Q, const cl_reads* R, const uint8_t* d_quals, const uint64_t* d_qual_off,
                        const uint8_t* d_flags, const uint32_t* h_part_bounds, uint32_t n_parts, QualPrepared& P)
 {
@@ -467,17 +452,18 @@ cl_status qual_prepare(cl_ctx* ctx, cl_qual_coder* Q, const cl_reads* R, const u
 		HIP_TRY(ctx, hipMemcpyAsync(qo.data(), d_qo.p, ((uint64_t)n_parts + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	}
-	{	// quality bytes index the 96-entry maps: anything outside Phred+33 0..95 is refused, not coded (the reference would read past its tables)
-		DevBuf<uint32_t> bad; DEV_ALLOC(ctx, bad, 1);
-		HIP_TRY(ctx, hipMemsetAsync(bad.p, 0, 4, ctx->stream));
-		const uint64_t nq = qo[n_parts] - qo[0];
-		if (nq) LAUNCHB(ctx, (double)nq, k_qual_check, (uint32_t)std::min<uint64_t>(8192, grid_for(nq, 256 * 16)), 256, d_quals + qo[0], nq, bad.p);
-		HIP_TRY(ctx, hipGetLastError());
+	// quality bytes index the 96-entry maps: anything outside Phred+33 0..95 is refused, not coded (the reference would read past its
+	// tables).  k_qual_symbols looks at every byte anyway and reports here.  (Mode `none` codes nothing and never comes here: as in the
+	// reference, whatever its quality bytes are is ignored.)
+	DevBuf<uint32_t> bad; DEV_ALLOC(ctx, bad, 1);
+	HIP_TRY(ctx, hipMemsetAsync(bad.p, 0, 4, ctx->stream));
+	auto refuse_bad = [&]() -> cl_status {
 		uint32_t h_bad = 0;
 		HIP_TRY(ctx, hipMemcpyAsync(&h_bad, bad.p, 4, hipMemcpyDeviceToHost, ctx->stream));
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 		if (h_bad) return cl_fail(ctx, CL_E_INVALID, "cl_qual_encode: quality byte outside '!'..'~'+1 (Phred+33 values 0..95)");
-	}
+		return CL_OK;
+	};
 	// process groups of parts so that one group's symbol stream stays below 2^31
 	// One group of parts = one sort + one range-coding launch.  The per-part interval chain is latency bound (its
 	// duration is set by the longest part, not by the number of parts), so groups are made as large as 32-bit
@@ -532,7 +518,7 @@ cl_status qual_prepare(cl_ctx* ctx, cl_qual_coder* Q, const cl_reads* R, const u
 		DEV_ALLOC(ctx, bkey, n_byte); DEV_ALLOC(ctx, bsidx, n_byte);
 		if (r1 > r0)
 			LAUNCHB(ctx, n_base * (1.0 + 0.25 + 8.0) + n_byte * 8.0, k_qual_symbols, grid_for(r1 - r0, 4), 256, (const QualCfg*)Q->d_cfg.p, (const uint64_t*)R->packed.p, (const uint64_t*)R->word_off.p,
-				d_quals, d_qual_off, d_flags, r0, r1, qo[p0], lay, key.p, sidx.p, bkey.p, bsidx.p);
+				d_quals, d_qual_off, d_flags, r0, r1, qo[p0], lay, key.p, sidx.p, bkey.p, bsidx.p, bad.p);
 		HIP_TRY(ctx, hipGetLastError());
 		const uint32_t total_ctx_bits = c.ctx_bits + c.base_bits + (c.level > 1 ? 2 : 0);
 		if (per_base && n_base)
@@ -553,7 +539,7 @@ cl_status qual_prepare(cl_ctx* ctx, cl_qual_coder* Q, const cl_reads* R, const u
 			LAUNCH(ctx, k_seg_bounds, grid_for(n_byte, 256), 256, (const uint32_t*)bkey.p, n_byte, 8u, G.bss.p, G.bse.p);
 			HIP_TRY(ctx, hipGetLastError());
 		}
-		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                         // (the uploads above read host vectors of this frame)
+		CL_TRY(refuse_bad());                                                    // (waits for the stream: the uploads above read host vectors of this frame)
 		P.groups.push_back(std::move(Gp));
 		p0 = p1;
 	}

@@ -101,3 +101,30 @@ def test_rescale_epochs_hot_context(ctx):
     bounds = np.array([0, 2, len(lens)], dtype=np.int64)
     for mode in (0, 2, 3, 5):
         assert gpu_encode(ctx, rs, mode, 0, 1, bounds) == oracle_encode(rs, mode, 0, 1, bounds), mode
+
+
+@pytest.mark.parametrize("mode", [0, 2, 5, 7])
+def test_quality_bytes_outside_phred33_are_refused(ctx, mode):
+    """A quality byte outside '!' .. '!' + 95 would index past the coder's 96-entry maps (the reference reads past its tables): the call
+    fails, before any model changes — the same coder then codes the clean input as a fresh one does.  (The check rides along in
+    k_qual_symbols; mode `none` codes nothing and ignores the bytes, as the reference does.)"""
+    from colord_amd._native import ColordHipError
+    g = golden("s6m_ont")
+    rs = g.reads
+    d = O.QUAL_DEFAULTS[mode]
+    bounds = np.array([0, rs.n_reads // 2, rs.n_reads], dtype=np.int64)
+    reads = ctx.pack_readset(rs)
+    qoff = torch.from_numpy(rs.offsets).to(ctx.device)
+    good = torch.from_numpy(rs.quals).to(ctx.device)
+    qc = ctx.qual_coder(mode, 0, 1, d[0], d[1])
+    for pos, val in ((int(rs.offsets[rs.n_reads // 3]) + 5, 31), (int(rs.offsets[-1]) - 1, 33 + 96), (0, 200)):
+        bad = good.clone(); bad[pos] = val
+        with pytest.raises(ColordHipError, match="quality byte outside"):
+            qc.encode(reads, bad, qoff, bounds)
+    out, sizes = qc.encode(reads, good, qoff, bounds)
+    raw = out.cpu().numpy().tobytes()
+    got, o = [], 0
+    for s in sizes:
+        got.append(raw[o:o + s]); o += s
+    qc.free(); reads.free()
+    assert got == gpu_encode(ctx, rs, mode, 0, 1, bounds)
