@@ -158,6 +158,25 @@ __global__ __launch_bounds__(256) void k_top_candidates(const uint64_t* __restri
 }
 } // namespace
 
+// Internal (stream.hip): d_bounds[i] (n + 1 entries) = ref_base + the number of accepted reads before read i — the reference reads a read of
+// the chunk may be coded against —, *n_accepted = the accepted reads of the chunk.  (The first half of cl_index_entries_of on its own: the
+// streaming compressor lists the k-mers of the ACCEPTED reads only, a tenth of a chunk in sparse mode, not of every read.)
+cl_status cl_ref_bounds(cl_ctx* ctx, const uint8_t* d_accept, uint32_t n, uint32_t ref_base, uint32_t* d_bounds, uint32_t* n_accepted)
+{
+	if (!ctx || !d_accept || !d_bounds) return cl_fail(ctx, CL_E_INVALID, "cl_ref_bounds: null argument");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	uint64_t n_refs = 0;
+	if (n) LAUNCH(ctx, k_flags_from_bytes, grid_for(n, 256), 256, d_accept, n, d_bounds);
+	HIP_TRY(ctx, hipGetLastError());
+	CL_TRY(dev_exclusive_scan_u32(ctx, d_bounds, n, &n_refs));
+	{ const uint32_t t = (uint32_t)n_refs; HIP_TRY(ctx, hipMemcpyAsync(d_bounds + n, &t, 4, hipMemcpyHostToDevice, ctx->stream)); HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); }
+	if (ref_base) LAUNCH(ctx, k_add_const, grid_for((uint64_t)n + 1, 256), 256, d_bounds, (uint64_t)n + 1, ref_base);
+	HIP_TRY(ctx, hipGetLastError());
+	if (n_accepted) *n_accepted = (uint32_t)n_refs;
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return CL_OK;
+}
+
 // (id, ref) pairs of the accepted reads of `lists`, in read order; ref = ref_base + rank among accepted
 extern "C" cl_status cl_index_entries_of(cl_ctx* ctx, const cl_kmer_lists* L, const uint8_t* d_accept, uint32_t ref_base,
                                          uint32_t* d_ids, uint32_t* d_refs, uint64_t cap, uint64_t* n_out,

@@ -49,6 +49,9 @@ uint32_t cl_part_shift(uint32_t k);
 cl_status cl_key_histogram(cl_ctx* ctx, const uint64_t* d_kmers, uint64_t n, uint32_t k, std::vector<uint64_t>& h_bins);
 cl_status cl_key_gather(cl_ctx* ctx, const uint64_t* d_kmers, uint64_t n, uint32_t k, uint32_t b0, uint32_t b1, uint64_t* d_out, uint64_t expect);
 
+// graph.hip: reference reads before each read of a chunk (the first half of cl_index_entries_of on its own)
+cl_status cl_ref_bounds(cl_ctx* ctx, const uint8_t* d_accept, uint32_t n, uint32_t ref_base, uint32_t* d_bounds, uint32_t* n_accepted);
+
 // the DNA coder's state-independent half ahead of time (dna.hip): stream.hip walks the NEXT chunk's tuples from the hook that
 // cl_dna_encode calls before it waits for its last interval coding
 #include <functional>

@@ -398,23 +398,32 @@ extern "C" cl_status cl_compressor_refs_add(cl_compressor* c, const cl_reads* ch
 		HIP_TRY(ctx, hipGetLastError());
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	}
-	cl_kmer_lists* lists = nullptr;
-	CL_TRY(cl_accepted_kmers(ctx, c->kset, chunk, c->P.k, c->P.f, &lists));
-	std::unique_ptr<cl_kmer_lists, void (*)(cl_kmer_lists*)> lg(lists, cl_kmer_lists_free);
+	// the chunk's reference reads first (a tenth of its reads with the sparse acceptor), THEIR accepted k-mers only: rounds 2-5 listed the
+	// k-mers of every read of the chunk here and kept those of the accepted ones — 50 scans of a gigabase in a pass that nothing overlaps
 	c->bounds.emplace_back();
 	DEV_ALLOC(ctx, c->bounds.back(), (uint64_t)n + 1);
-	uint64_t n_sel = 0; uint32_t n_acc = 0;
-	cl_status s = cl_index_entries_of(ctx, lists, accept.p, c->n_refs_local, nullptr, nullptr, 0, &n_sel, c->bounds.back().p, &n_acc);
-	if (s != CL_OK && s != CL_E_CAPACITY) return s;
-	if (n_sel)
-	{
-		CL_TRY(c->pair_ids.reserve(ctx, c->pair_ids.n + n_sel)); CL_TRY(c->pair_refs.reserve(ctx, c->pair_refs.n + n_sel));
-		CL_TRY(cl_index_entries_of(ctx, lists, accept.p, c->n_refs_local, c->pair_ids.buf.p + c->pair_ids.n, c->pair_refs.buf.p + c->pair_refs.n, n_sel, &n_sel, nullptr, nullptr));
-		c->pair_ids.n += n_sel; c->pair_refs.n += n_sel;
-	}
+	uint32_t n_acc = 0;
+	CL_TRY(cl_ref_bounds(ctx, accept.p, n, c->n_refs_local, c->bounds.back().p, &n_acc));
 	cl_reads* piece = nullptr;
 	CL_TRY(cl_reads_select(ctx, chunk, accept.p, &piece));
 	c->ref_pieces.push_back(piece);
+	if (n_acc)
+	{
+		cl_kmer_lists* lists = nullptr;
+		CL_TRY(cl_accepted_kmers(ctx, c->kset, piece, c->P.k, c->P.f, &lists));
+		std::unique_ptr<cl_kmer_lists, void (*)(cl_kmer_lists*)> lg(lists, cl_kmer_lists_free);
+		DevBuf<uint8_t> all; DEV_ALLOC(ctx, all, n_acc);
+		HIP_TRY(ctx, hipMemsetAsync(all.p, 1, n_acc, ctx->stream));            // (every read of the piece is a reference read: ref = base + its index)
+		uint64_t n_sel = 0;
+		cl_status s = cl_index_entries_of(ctx, lists, all.p, c->n_refs_local, nullptr, nullptr, 0, &n_sel, nullptr, nullptr);
+		if (s != CL_OK && s != CL_E_CAPACITY) return s;
+		if (n_sel)
+		{
+			CL_TRY(c->pair_ids.reserve(ctx, c->pair_ids.n + n_sel)); CL_TRY(c->pair_refs.reserve(ctx, c->pair_refs.n + n_sel));
+			CL_TRY(cl_index_entries_of(ctx, lists, all.p, c->n_refs_local, c->pair_ids.buf.p + c->pair_ids.n, c->pair_refs.buf.p + c->pair_refs.n, n_sel, &n_sel, nullptr, nullptr));
+			c->pair_ids.n += n_sel; c->pair_refs.n += n_sel;
+		}
+	}
 	c->n_refs_local += n_acc;
 	c->refs_reads_seen += n; ++c->refs_chunk;
 	return CL_OK;

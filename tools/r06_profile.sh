@@ -8,6 +8,7 @@ KT=$(find /tmp/st -name "*kernel_trace.csv" | head -1); KS=$(find /tmp/st -name 
 cp $KS gpurun_out/$T/kernel_stats.csv
 python tools/queue_busy.py $KT > gpurun_out/$T/queue_busy.txt 2>&1
 python tools/window_dump.py $KT 8.0 1.2 0.5 > gpurun_out/$T/window.txt 2>&1
+python tools/window_dump.py $KT 0.0 1.8 0.3 > gpurun_out/$T/window_start.txt 2>&1   # passes 1 and 2a: what runs before the first chunk's stage A
 python tools/lane_gaps.py $KT > gpurun_out/$T/lane_gaps.txt 2>&1
 python tools/copy_top.py $KT > gpurun_out/$T/copy_top.txt 2>&1
 python - $KT > gpurun_out/$T/kernel_minmax.txt <<'PY'
