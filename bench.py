@@ -763,11 +763,13 @@ def main():
         qctx.acc.clear()
     # K steps, each bracketed by barrier + synchronize on both sides; between two brackets (never inside one) the pass that just
     # ended is digested part by part where the step left it: `parts_digest_stable` = every timed pass gave the same bytes
-    info, dt, step_s, digests = None, 0.0, [], []
+    info, dt, step_s, own_s, digests = None, 0.0, [], [], []
     for _ in range(args.steps):
         sync()
         t0 = time.perf_counter()
         info = step()
+        torch.cuda.synchronize()
+        own_s.append(time.perf_counter() - t0)               # this rank's own work (before the closing barrier: the imbalance between ranks shows here)
         sync()
         step_s.append(time.perf_counter() - t0)
         dt += step_s[-1]
@@ -797,7 +799,7 @@ def main():
     if world > 1:
         # what a first run on N GPUs needs to be read: every rank's own step times, bases and stream bytes, and where its time between the
         # GPUs went (seconds / bytes received per exchange of the timed passes), gathered to rank 0
-        mine = {"rank": rank, "device": int(local), "step_s": [round(x, 3) for x in step_s], "bases": int(shard.n_bases), "reads": int(shard.n_reads),
+        mine = {"rank": rank, "device": int(local), "step_s": [round(x, 3) for x in step_s], "own_step_s": [round(x, 3) for x in own_s], "bases": int(shard.n_bases), "reads": int(shard.n_reads),
                 "dna_bytes": int(info["dna_bytes"]), "qual_bytes": int(info["qual_bytes"]), "input_generation_s": round(t_gen, 1),
                 "exchange": exchange.summary() if exchange is not None else None, "exchange_bytes_received": int(exchange.bytes_moved) if exchange is not None else 0}
         allr = [None] * world

@@ -285,7 +285,7 @@ def test_bench_launches_its_own_ranks(tmp_path):
     m = line["multi_gpu"]
     assert m["process_group_ranks"] == 2 and m["backend"] == "gloo" and m["ranks_share_gpus"] is True
     assert m["rccl_selftest"]["rc"] == 0, m["rccl_selftest"]
-    assert [r["rank"] for r in m["per_rank"]] == [0, 1] and all(len(r["step_s"]) == 1 and r["bases"] > 0 and r["dna_bytes"] > 0 for r in m["per_rank"])
+    assert [r["rank"] for r in m["per_rank"]] == [0, 1] and all(len(r["step_s"]) == 1 and len(r["own_step_s"]) == 1 and r["own_step_s"][0] <= r["step_s"][0] + 1e-3 and r["bases"] > 0 and r["dna_bytes"] > 0 for r in m["per_rank"])
     ex = m["exchange_s"]
     assert ex["kmers.all_to_all_v"]["bytes_received_all_ranks_per_step"] > 0 and ex["kmers.all_gather_v"]["calls_per_step"] >= 1
     assert ex["refs.all_gather_v"]["bytes_received_all_ranks_per_step"] > 0 and "parts.gather_to_root" in ex
