@@ -578,7 +578,8 @@ def e2e_cli(bases: float, coverage: float, k: int, a: int, part_symbols: int, gp
                 multi = ["--gpus", str(gpus), "--gpu-list", ",".join(str(x) for x in gl), "--transport", "rccl" if len(set(gl)) == len(gl) else "host"]
                 if name == "ref_cut":
                     continue
-            cmd = [ours, "compress-ont", "-v", "-k", str(k), "-a", str(a), "--part-symbols", str(ps)] + multi + [fq, os.path.join(tmp, "e2e.colord")]
+            arc = os.path.join(tmp, f"e2e_{name}.colord")      # (a new file per run: replacing a multi-GB file makes close() wait for its blocks — ext4's replace-via-truncate rule, 0.8 s at 20 Gbases)
+            cmd = [ours, "compress-ont", "-v", "-k", str(k), "-a", str(a), "--part-symbols", str(ps)] + multi + [fq, arc]
             time.sleep(8.0)                                 # the driver clears what the process before gave back (this one's pools, the run before) while the next one starts:
             t0 = time.time()                                # measured 5.2-5.3 s after a pause against 5.5-6.8 s back to back (profiles/r05_e2e_pause_5Gbases.txt)
             try:
@@ -591,7 +592,8 @@ def e2e_cli(bases: float, coverage: float, k: int, a: int, part_symbols: int, gp
                 out[name] = {"error": (r.stderr or r.stdout)[-300:]}
                 continue
             phases = [l.strip() for l in r.stderr.splitlines() if l.strip().startswith("[")][-12:]
-            out[name] = {"value": n_bases / dt / 1e9, "unit": "Gbases/s", "seconds": round(dt, 2), "part_symbols": ps, "archive_bytes": os.path.getsize(os.path.join(tmp, "e2e.colord")), "phases": phases}
+            out[name] = {"value": n_bases / dt / 1e9, "unit": "Gbases/s", "seconds": round(dt, 2), "part_symbols": ps, "archive_bytes": os.path.getsize(arc), "phases": phases}
+            os.remove(arc)
         first = out.get("headline_cut") or {}
         res = {"value": first.get("value"), "unit": "Gbases/s", "seconds": first.get("seconds"), "bases": n_bases, "fastq_bytes": os.path.getsize(fq), "fastq_written_in_s": round(t_gen, 1),
                "what": f"colord_hip compress-ont -k {k} -a {a} --part-symbols N" + (f" --gpus {gpus}" if gpus > 1 else "") + " file -> archive, whole process (mapped file indexed by several threads, chunks filled by parallel copies into "

@@ -94,13 +94,14 @@ constexpr uint32_t NIL = 0xffffffffu;
 
 // ---- A1: table sizes; one wave per read inserts every position --------------------------------------------
 __global__ void k_table_sizes(const uint32_t* __restrict__ lens, const uint8_t* __restrict__ has_n, const uint32_t* __restrict__ ncand,
-                              uint32_t r0, uint32_t r1, uint32_t m, uint32_t x4, uint32_t* __restrict__ tsize, uint32_t* __restrict__ nsize, uint32_t* __restrict__ err)
+                              uint32_t r0, uint32_t r1, uint32_t m, uint32_t x4, uint32_t lds_max_n, uint32_t* __restrict__ tsize, uint32_t* __restrict__ nsize, uint32_t* __restrict__ err)
 {
 	uint32_t r = r0 + blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= r1) return;
 	uint32_t len = lens[r];
 	bool active = ncand[r] > 0 && !has_n[r] && len >= m;
 	uint32_t n = active ? len - m + 1 : 0;
+	if (n <= lds_max_n) n = 0;                                             // its table lives in LDS for the length of one block (k_match_lds): nothing of it in HBM
 	uint32_t t = 0;
 	if (n) { t = 16; while (t < 2 * n + n / 2 && t < REGION_SLOTS) t <<= 1; if (t >= REGION_SLOTS) t = (uint32_t)(((uint64_t)n * x4 / 4 + REGION_SLOTS - 1) / REGION_SLOTS * REGION_SLOTS); }
 	tsize[r - r0] = t; nsize[r - r0] = n;
@@ -329,6 +330,166 @@ __global__ __launch_bounds__(256) void k_match(Arena A, Arena R, EncTable T, Tas
 				if ((p >> 31) == fs) pairs[o++] = kf | pos;
 				if ((p >> 31) == rs_) pairs[o++] = kr | pos;
 			}
+		}
+	}
+	flush();
+}
+// ---- A1-A3 for reads whose table fits in LDS: built, counted and probed by ONE block, nothing of it ever in HBM ----
+// (north_star: "LDS-staged hash-bucket probes".  Built, parity-tested against the tables in HBM and the oracle, measured, and left OFF: see
+// cl_anchor_candidates_hifi below.)  Since only the SET of (read position, reference position) pairs matters up to the sort,
+// the table is a multiset: every position of the read takes a slot of its own in the probe sequence of its canonical m-mer (linear
+// probing, load 2/3), a slot is the position alone — 16 bits — and whether it holds the probing m-mer is decided on the read itself, which
+// sits in LDS beside it (2 bits a base).  No keys, no chains, no tags: 3 bytes of table + 1/4 byte of read per base, so a read of 24 k bases
+// with a 32-KB blocked Bloom filter in front (the same one-word three-bit filter as k_match: a miss — nearly every probe — costs one LDS
+// word) takes 112 KB.  The number of distinct m-mers (the read-level decision, encoder.cpp:1069-1078) = the positions that are the first
+// with their m-mer: a second pass of look-ups.  Per base: 2 bits of the read and 2 bits per candidate from HBM, 8 bytes per pair out.
+template<uint32_t MAXN> struct LdsGeom { static constexpr uint32_t SLOTS = ((MAXN + MAXN / 2) + 17) & ~1u, WORDS = (MAXN + 27 + 31) / 32 + 2; };
+__device__ inline uint32_t lds_table_slots(uint32_t n) { const uint32_t s = (n + n / 2 + 1) & ~1u; return s < 16 ? 16 : s; }
+template<uint32_t MAXN, uint32_t FW, uint32_t NT, uint32_t WAVES_PER_SIMD>
+__global__ __launch_bounds__(NT, WAVES_PER_SIMD) void k_match_lds(Arena A, Arena R, TaskCfg cfg, uint32_t min_n, const uint8_t* __restrict__ has_n,
+                                                 const uint32_t* __restrict__ cand_refs, const uint32_t* __restrict__ cand_n, uint32_t* __restrict__ n_distinct, uint32_t n_reads,
+                                                 unsigned long long* __restrict__ n_pairs, uint64_t cap, uint64_t* __restrict__ pairs, uint32_t dbg)
+{
+	static_assert(MAXN <= 65535 && (FW & (FW - 1)) == 0 && NT % 64 == 0, "positions are 16-bit links; 0xffff is the empty slot");
+	constexpr uint32_t NW = NT / 64, LSTAGE = 64;
+	__shared__ unsigned long long filt[FW];
+	__shared__ uint64_t rd[LdsGeom<MAXN>::WORDS];                        // the read, 32 bases a word as in the arena
+	__shared__ uint32_t slots32[LdsGeom<MAXN>::SLOTS / 2];               // two 16-bit slots a word (LDS atomics are 32-bit)
+	__shared__ uint64_t stage_all[NW][LSTAGE];
+	__shared__ uint32_t s_distinct;
+	const uint32_t rl = blockIdx.x;
+	if (rl >= n_reads) return;
+	const uint32_t r = cfg.r0 + rl, m = cfg.m;
+	const uint32_t elen = A.lens[r];
+	const uint32_t n_slots = cand_n[r] < cfg.c ? cand_n[r] : cfg.c;
+	if (n_slots == 0 || has_n[r] || elen < m) return;
+	const uint32_t n = elen - m + 1;
+	if (n <= min_n || n > MAXN) return;                                    // (another class's, or k_table_insert + k_match's)
+	const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const uint32_t S = lds_table_slots(n);
+	const uint16_t* slot16 = (const uint16_t*)slots32;
+	{
+		const uint64_t* src = A.packed + A.word_off[r];
+		const uint32_t nw = (elen + 31) / 32 + 1;                              // (+ the word after the last: mmer_of takes two)
+		for (uint32_t i = threadIdx.x; i < nw; i += NT) rd[i] = src[i];
+		for (uint32_t i = threadIdx.x; i < FW; i += NT) filt[i] = 0;
+		for (uint32_t i = threadIdx.x; i < S / 2; i += NT) slots32[i] = 0xffffffffu;
+		if (threadIdx.x == 0) s_distinct = 0;
+	}
+	__syncthreads();
+	if (dbg == 1) return;
+	auto own = [&](uint32_t p) -> uint64_t { return mmer_of(rd[p >> 5], rd[(p >> 5) + 1], p, m); };
+	auto step = [&](uint32_t off) -> uint32_t { return off + 1 == S ? 0u : off + 1; };
+	{	// Insertion.  Every position with the same m-mer sits in the run of occupied slots that starts at the m-mer's own slot, and a position
+		// walks over every slot in front of the one it takes: of two equal m-mers exactly one — the one further along — sees the other.  So
+		// the distinct m-mers of the read (encoder.cpp:1069-1078) = the positions that met no equal on their way, counted here
+		uint32_t fresh = 0;
+		for (uint32_t p = threadIdx.x; p < n; p += NT)
+		{
+			const uint64_t xf = own(p), xr = revcomp_m(xf, m), hash = hash_mm(xf < xr ? xf : xr);
+			atomicOr(&filt[(uint32_t)(hash >> 46) & (FW - 1)], (unsigned long long)filt_mask(hash));
+			bool dup = false;
+			for (uint32_t off = table_slot(hash, S);;)
+			{
+				uint32_t* w = &slots32[off >> 1]; const uint32_t sh = (off & 1) * 16;
+				const uint32_t old = *(volatile uint32_t*)w, q = (old >> sh) & 0xffffu;
+				if (q != 0xffffu) { if (!dup && own(q) == xf) dup = true; off = step(off); continue; }
+				if (atomicCAS(w, old, (old & ~(0xffffu << sh)) | (p << sh)) == old) break;   // (else: the word changed — maybe only its other half: look again)
+			}
+			fresh += dup ? 0u : 1u;
+		}
+		fresh = wave_sum(fresh);
+		if (lane == 0 && fresh) atomicAdd(&s_distinct, fresh);
+	}
+	__syncthreads();
+	const uint32_t nd = s_distinct;
+	if (threadIdx.x == 0) n_distinct[rl] = nd;
+	if (dbg == 2) return;
+	if ((double)nd < cfg.frac_min * (double)elen && !((double)nd > cfg.frac_always * (double)elen)) return;
+	uint64_t* stage = stage_all[wv]; uint32_t fill = 0;
+	auto flush = [&]() {
+		if (!fill) return;
+		unsigned long long base = 0;
+		if (lane == 0) base = atomicAdd(n_pairs, (unsigned long long)fill);
+		base = ((unsigned long long)__shfl((int)(base >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)base, 0, 64);
+		if (base + fill <= cap) for (uint32_t i = lane; i < fill; i += 64) pairs[base + i] = stage[i];
+		fill = 0;
+	};
+	// y: the m-mer at q of the reference as stored; z: the one at nq - 1 - q of its reverse complement.  A position of the read that has y is
+	// a hit of the forward analysis, one that has z of the reverse one (a palindrome: of both).  The first two hits stay in registers
+	struct Look { uint64_t y, z; uint32_t h0, cnt, nh, hp0, hp1, hf0, hf1; };
+	auto look = [&](bool live, uint32_t q, uint64_t hi, uint64_t lo) -> Look {
+		Look L{ 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+		if (!live) return L;
+		L.y = mmer_of(hi, lo, q, m); L.z = revcomp_m(L.y, m);
+		const uint64_t hash = hash_mm(L.y < L.z ? L.y : L.z), fm = filt_mask(hash);
+		if ((filt[(uint32_t)(hash >> 46) & (FW - 1)] & fm) != fm || dbg == 3) return L;
+		L.h0 = table_slot(hash, S);
+		for (uint32_t off = L.h0;; off = step(off))
+		{
+			const uint32_t p = slot16[off];
+			if (p == 0xffffu) break;
+			const uint64_t xf = own(p);
+			const uint32_t f = (xf == L.y ? 1u : 0u) | (xf == L.z ? 2u : 0u);
+			if (!f) continue;
+			if (L.nh == 0) { L.hp0 = p; L.hf0 = f; } else if (L.nh == 1) { L.hp1 = p; L.hf1 = f; }
+			++L.nh; L.cnt += (f & 1) + (f >> 1);
+		}
+		return L;
+	};
+	for (uint32_t slot = 0; slot < n_slots; ++slot)
+	{
+		const uint32_t id = cand_refs[(uint64_t)r * cfg.c + slot], rlen = R.lens[id];
+		if (rlen < m) continue;
+		const uint64_t* rw = R.packed + R.word_off[id];
+		const uint32_t nq = rlen - m + 1, sl = rl * cfg.c + slot;
+		const uint32_t PR = cfg.pr; const uint32_t pr_mask = (1u << PR) - 1;
+		const uint64_t key_rev = (uint64_t)(2 * sl) << (cfg.pe + PR), key_fwd = (uint64_t)(2 * sl + 1) << (cfg.pe + PR);
+		if (threadIdx.x == 0) atomicAdd(n_pairs + 2, (unsigned long long)nq);
+		// A wave takes 128 consecutive positions a step, a lane the positions q and q + 64 (two independent look-ups in flight: their LDS
+		// reads overlap) out of four consecutive words of the reference, which are loaded a step ahead
+		const uint32_t last_w = (rlen + 31) / 32;                              // (the word after the read's last exists in the arena)
+		auto words = [&](uint32_t q, uint64_t (&w)[4]) {
+			const uint32_t b = q >> 5;
+#pragma unroll
+			for (uint32_t i = 0; i < 4; ++i) w[i] = (q < nq && b + i <= last_w) ? rw[b + i] : 0;
+		};
+		uint64_t w[4], w1[4];
+		words(wv * 128 + lane, w);
+		for (uint32_t q0 = wv * 128; q0 < nq; q0 += 2 * NT)
+		{
+			const uint32_t qa = q0 + lane, qb = qa + 64;
+			words(qa + 2 * NT, w1);
+			const Look La = look(qa < nq, qa, w[0], w[1]), Lb = look(qb < nq, qb, w[2], w[3]);
+#pragma unroll
+			for (uint32_t i = 0; i < 4; ++i) w[i] = w1[i];
+			const uint32_t cnt = La.cnt + Lb.cnt;
+			if (!__any(cnt != 0)) continue;
+			const uint32_t incl = wave_incl_scan(cnt), tot = __shfl(incl, 63, 64);
+			auto put = [&](auto* dst, uint64_t o) {
+				auto all_of = [&](const Look& L, uint32_t q) {
+					if (!L.cnt) return;
+					const uint64_t kf = key_fwd | (uint64_t)(~q & pr_mask), kr = key_rev | (uint64_t)(~(nq - 1 - q) & pr_mask);
+					auto one = [&](uint32_t p, uint32_t f) { const uint64_t pos = (uint64_t)p << PR; if (f & 1) dst[o++] = kf | pos; if (f & 2) dst[o++] = kr | pos; };
+					if (L.nh <= 2) { one(L.hp0, L.hf0); if (L.nh > 1) one(L.hp1, L.hf1); return; }
+					for (uint32_t off = L.h0;; off = step(off))                   // (a repeated m-mer: walk its run again)
+					{
+						const uint32_t p = slot16[off];
+						if (p == 0xffffu) break;
+						const uint64_t xf = own(p);
+						const uint32_t f = (xf == L.y ? 1u : 0u) | (xf == L.z ? 2u : 0u);
+						if (f) one(p, f);
+					}
+				};
+				all_of(La, qa); all_of(Lb, qb);
+			};
+			if (fill + tot > LSTAGE) flush();
+			if (tot <= LSTAGE) { put(stage, (uint64_t)(fill + incl - cnt)); fill += tot; continue; }
+			unsigned long long base = 0;                                       // more hits in one step than the stage holds: straight to the array
+			if (lane == 0) base = atomicAdd(n_pairs, (unsigned long long)tot);
+			base = ((unsigned long long)__shfl((int)(base >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)base, 0, 64);
+			if (base + tot > cap) continue;
+			put(pairs, (uint64_t)(base + incl - cnt));
 		}
 	}
 	flush();
@@ -749,6 +910,15 @@ extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* read
 		struct SideSync { hipStream_t s = nullptr; ~SideSync() { if (s) (void)hipStreamSynchronize(s); } } sync;   // destroyed first
 	};
 	HIP_TRY(ctx, cl_side_stream(ctx, ctx->side));
+	// COLORD_HIP_ANCHORS_LDS=12288 | 24576: reads of up to that many m-mers keep their table in LDS (k_match_lds, two size classes).  OFF by
+	// default — measured (round 6, profiles/r06_l_*): alone on the device the two classes take 14 + 25 ms per Gbase for the 61 % of the bases
+	// whose tables k_table_insert + k_match make and probe in 6.7 + 15 ms (the probes that reach a table are few: the Bloom filter in LDS stops
+	// 99 % of the misses in both forms), and in the pipeline a block that wants 63 / 118 KB of a CU's LDS waits for it: 104 / 214 ms per chunk,
+	// 21.5 s per pass against 17.0
+	constexpr uint32_t LDS_N_A = 12288, LDS_N_B = 24576, LDS_NT = 1024;
+	uint32_t lds_max_n = 0;
+	if (const char* e = getenv("COLORD_HIP_ANCHORS_LDS")) lds_max_n = atoi(e) <= 0 ? 0u : (uint32_t)atoi(e) <= LDS_N_A ? LDS_N_A : LDS_N_B;
+	const uint32_t lds_dbg = getenv("COLORD_HIP_LDS_DBG") ? (uint32_t)atoi(getenv("COLORD_HIP_LDS_DBG")) : 0u;
 	auto prepare = [&](uint32_t r0, std::unique_ptr<TableBatch>& out) -> cl_status {
 		out = std::make_unique<TableBatch>();
 		TableBatch& B = *out;
@@ -772,7 +942,7 @@ extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* read
 		B.sync.s = ctx->side;
 		DevBuf<uint32_t> tsize, nsize, err; DEV_ALLOC(ctx, tsize, nb); DEV_ALLOC(ctx, nsize, nb); DEV_ALLOC(ctx, err, 1); DEV_ALLOC(ctx, B.n_distinct, nb);
 		HIP_TRY(ctx, hipMemsetAsync(err.p, 0, 4, ctx->side));
-		LAUNCH(ctx, k_table_sizes, grid_for(nb, 256), 256, (const uint32_t*)reads->lens.p, (const uint8_t*)reads->has_n.p, d_cand_n, r0, r1, m, table_x4, tsize.p, nsize.p, err.p);
+		LAUNCH(ctx, k_table_sizes, grid_for(nb, 256), 256, (const uint32_t*)reads->lens.p, (const uint8_t*)reads->has_n.p, d_cand_n, r0, r1, m, table_x4, lds_max_n, tsize.p, nsize.p, err.p);
 		DEV_ALLOC(ctx, B.toff, (uint64_t)nb + 1); DEV_ALLOC(ctx, B.noff, (uint64_t)nb + 1);
 		uint64_t tsum = 0;
 		CL_TRY(dev_exclusive_scan_u64(ctx, tsize.p, B.toff.p, nb, &tsum));
@@ -801,13 +971,19 @@ extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* read
 		EncTable T{ cur->slots.p, cur->toff.p, cur->next.p, cur->noff.p };
 		DevBuf<uint32_t> pair_cnt; DEV_ALLOC(ctx, pair_cnt, (uint64_t)n_tasks + 1);
 		DevBuf<uint64_t> pair_off; DEV_ALLOC(ctx, pair_off, (uint64_t)n_tasks + 1);
-		DevBuf<unsigned long long> d_np; DEV_ALLOC(ctx, d_np, 2);           // match pairs, probes
+		DevBuf<unsigned long long> d_np; DEV_ALLOC(ctx, d_np, 4);           // match pairs, probes (tables in HBM), probes (tables in LDS)
 		DevBuf<uint64_t> pairs;
 		uint64_t n_pairs = 0;
 		for (uint64_t cap = (uint64_t)(pairs_per_base * 1.25 * (double)acc) + (1u << 20);;)
 		{	// one pass when the room guessed from the batches before suffices, else a second with the counted size
 			DEV_ALLOC(ctx, pairs, cap);
-			HIP_TRY(ctx, hipMemsetAsync(d_np.p, 0, 16, ctx->stream));
+			HIP_TRY(ctx, hipMemsetAsync(d_np.p, 0, 32, ctx->stream));
+			if (lds_max_n)
+			{
+				LAUNCH_NAMED(ctx, "k_match_lds<12288>", (k_match_lds<LDS_N_A, 2048, LDS_NT, 8>), nb, LDS_NT, A, R, cfg, 0u, (const uint8_t*)reads->has_n.p, d_cand_refs, d_cand_n, n_distinct.p, nb, d_np.p, cap, pairs.p, lds_dbg);
+				if (lds_max_n > LDS_N_A)
+					LAUNCH_NAMED(ctx, "k_match_lds<24576>", (k_match_lds<LDS_N_B, 4096, LDS_NT, 4>), nb, LDS_NT, A, R, cfg, LDS_N_A, (const uint8_t*)reads->has_n.p, d_cand_refs, d_cand_n, n_distinct.p, nb, d_np.p, cap, pairs.p, lds_dbg);
+			}
 			LAUNCHB(ctx, 0.0, k_match, nb, 256, A, R, T, cfg, d_cand_refs, d_cand_n, (const uint32_t*)n_distinct.p, nb, d_np.p, cap, pairs.p);
 			HIP_TRY(ctx, hipGetLastError());
 			unsigned long long h_np2[2] = { 0, 0 };

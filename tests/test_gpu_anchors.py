@@ -61,3 +61,74 @@ def test_anchor_candidates_equal_oracle(ctx, cfg):
         n_with += len(exp) > 0
     assert n_with > (10 if cfg != "c2_hifi_org" else 2)      # the D.melanogaster fixture has 3 coded reads
     anc.free(); refs.free(); reads.free()
+
+
+def _anchor_arrays(ctx, reads, refs, crefs, cnt, a):
+    anc = ctx.anchor_candidates(reads, refs, crefs, cnt, a)
+    out = (anc.n_cands().cpu().numpy().copy(), anc.cands().cpu().numpy().copy(), anc.cand_offsets().cpu().numpy().copy(), anc.data().cpu().numpy().copy())
+    anc.free()
+    return out
+
+
+@pytest.mark.parametrize("cfg", ["s6m_ont", "s3m_ont_n_ratio", "s5m_hifi", "s6m_ont_k25"])
+def test_anchor_candidates_tables_in_lds_equal_oracle(ctx, cfg, monkeypatch):
+    """The golden reads are short enough for every m-mer table to live in LDS: with COLORD_HIP_ANCHORS_LDS=24576 all of them go through
+    k_match_lds (off by default: DESIGN.md 10) instead of k_table_insert + k_match, and the oracle judges that form too."""
+    monkeypatch.setenv("COLORD_HIP_ANCHORS_LDS", "24576")
+    test_anchor_candidates_equal_oracle(ctx, cfg)
+
+
+def test_anchor_tables_in_lds_equal_tables_in_hbm(ctx, monkeypatch):
+    """Reads either side of both LDS class bounds (12 288 and 24 576 m-mers), a read whose m-mers repeat thousands of times (runs of
+    equal m-mers in the table, more hits in a wave step than the staging holds, the "too many matches" veto) and one with an N:
+    candidates and anchors with the tables in LDS (both classes; the small class only) == with every table in HBM, which the oracle
+    judges on the goldens."""
+    from colord_amd.fastq import ReadSet
+    rng = np.random.default_rng(5)
+    a, c = 16, 5
+    comp = np.array([3, 2, 1, 0], np.uint8)
+    genome = rng.integers(0, 4, 150_000, dtype=np.uint8)
+    unit = rng.integers(0, 4, 37, dtype=np.uint8)
+    genome[60_000:68_000] = np.resize(unit, 8000)                            # a tandem repeat: 37 distinct m-mers, ~200 times each
+    genome[90_000:93_000] = 0                                                # and a homopolymer
+
+    def noisy(s):
+        r = rng.random(len(s))
+        s = s.copy()
+        sub = (r >= 0.02) & (r < 0.05)
+        s[sub] = (s[sub] + rng.integers(1, 4, int(sub.sum()))) % 4
+        s = s[r >= 0.02]
+        ins = np.nonzero(rng.random(len(s)) < 0.02)[0]
+        return np.insert(s, ins, rng.integers(0, 4, len(ins)).astype(np.uint8))
+
+    lens = [300, 15, 16, 17, 2500, 12_000, 12_287 + a - 1, 12_288 + a - 1, 12_289 + a - 1, 12_600, 20_000, 24_576 + a - 1, 24_577 + a - 1, 30_000, 70_000,
+            9000, 23_000, 40_000]
+    starts = [int(rng.integers(0, 50_000)) for _ in lens[:-3]] + [58_000, 55_000, 50_000]        # the last three cover the repeat (and the homopolymer)
+    seqs = []
+    for ln, st in zip(lens, starts):
+        s = noisy(genome[st:st + ln + ln // 20 + 8])[:ln]
+        assert len(s) == ln
+        seqs.append(comp[s[::-1]].copy() if rng.random() < 0.5 else s)
+    for ln, st in ((21_000, 40_000), (64_000, 30_000), (8000, 59_000), (26_000, 52_000)):      # a second cover: candidates of every class with every class
+        seqs.append(noisy(genome[st:st + ln]))
+    seqs.append(seqs[10].copy()); seqs[-1][5000] = 4                          # a read with N: no candidates looked at
+    n = len(seqs)
+    ln = np.array([len(s) for s in seqs], np.int64)
+    rs = ReadSet(np.concatenate(seqs), np.concatenate([[0], np.cumsum(ln)]).astype(np.int64), None, [], [False] * n, False)
+    reads = ctx.pack_readset(rs)
+    accept = np.ones(n, np.uint8); accept[-1] = 0
+    refs = ctx.select_reads(reads, torch.from_numpy(accept).to(ctx.device))
+    cand = np.zeros((n, c), np.int32); cn = np.zeros(n, np.int32)
+    for i in range(1, n):
+        pool = rng.permutation(min(i, n - 1))[:c]
+        cn[i] = len(pool); cand[i, :cn[i]] = pool
+    crefs, cnt = torch.from_numpy(cand).to(ctx.device), torch.from_numpy(cn).to(ctx.device)
+    monkeypatch.delenv("COLORD_HIP_ANCHORS_LDS", raising=False)
+    want = _anchor_arrays(ctx, reads, refs, crefs, cnt, a)
+    assert want[0].sum() >= 20 and want[3].size > 3000                        # candidates kept, anchors found
+    for setting in ("24576", "12288"):
+        monkeypatch.setenv("COLORD_HIP_ANCHORS_LDS", setting)
+        got = _anchor_arrays(ctx, reads, refs, crefs, cnt, a)
+        for w, g_, name in zip(want, got, ("n_cands", "cands", "offsets", "anchors")):
+            assert np.array_equal(w, g_), f"{name} differ with COLORD_HIP_ANCHORS_LDS={setting}"
+    refs.free(); reads.free()

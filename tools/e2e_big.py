@@ -19,10 +19,20 @@ with tempfile.TemporaryDirectory(dir=base_dir) as tmp:
     fq = os.path.join(tmp, "in.fastq")
     t0 = time.time(); nb = ontsim.write_fastq(t, fq); os.sync()
     print(f"fastq: {nb} bases, {os.path.getsize(fq)} bytes, written in {time.time() - t0:.1f} s", flush=True)
-    for name, extra in (("resident", []), ("stream-input", ["--stream-input"])):
+    runs = [("resident", [], {}), ("stream-input", ["--stream-input"], {})]
+    if os.environ.get("E2E_RUNS"):                        # e.g. E2E_RUNS="pread:COLORD_HIP_COPY_PREAD=1;t64:--parse-threads=64": name:ENV=v,--flag=v,...
+        runs = []
+        for spec in os.environ["E2E_RUNS"].split(";"):
+            name, _, rest = spec.partition(":")
+            items = [x for x in rest.split(",") if x]
+            extra = [y for x in items if x.startswith("--") for y in x.split("=", 1)]
+            runs.append((name, extra, dict(x.split("=", 1) for x in items if not x.startswith("--"))))
+    for name, extra, env in runs:
         time.sleep(8.0)
         t0 = time.time()
-        r = subprocess.run([cli, "compress-ont", "-v", "-k", "25", "-a", "22", "--part-symbols", "65536"] + extra + [fq, os.path.join(tmp, "a.colord")], capture_output=True, text=True)
+        r = subprocess.run([cli, "compress-ont", "-v", "-k", "25", "-a", "22", "--part-symbols", "65536"] + extra + [fq, os.path.join(tmp, f"{name}.colord")], capture_output=True, text=True, env=dict(os.environ, **env))
         dt = time.time() - t0
-        print(f"{name}: exit {r.returncode}, {dt:.2f} s = {nb / dt / 1e9:.3f} Gbases/s, archive {os.path.getsize(os.path.join(tmp, 'a.colord')) if r.returncode == 0 else 0} bytes", flush=True)
+        print(f"{name}: exit {r.returncode}, {dt:.2f} s = {nb / dt / 1e9:.3f} Gbases/s, archive {os.path.getsize(os.path.join(tmp, name + '.colord')) if r.returncode == 0 else 0} bytes", flush=True)
+        if os.path.exists(os.path.join(tmp, name + ".colord")):
+            os.remove(os.path.join(tmp, name + ".colord"))          # (every run writes a NEW file: replacing one of 8 GB made close() wait 0.8 s for its blocks — ext4's replace-via-truncate rule)
         print("\n".join(l for l in r.stderr.splitlines() if l.startswith(("[", "colord_hip", "# pass")))[-1500:], flush=True)
