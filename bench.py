@@ -68,7 +68,7 @@ def parse():
                     help="wall-clock budget of the whole process (the driver stops a run after 1800 s).  If (steps + warmup) passes over --bases "
                          "cannot finish inside it — estimated up front at 1.1 Gbases/s/GPU, then checked against the first warm-up pass — the input "
                          "is cut to a prefix of the file that can, and `config.workload` says so")
-    ap.add_argument("--e2e-bases", type=float, default=1.0e10, help="bases of the FASTQ the command-line compressor is timed on, file to archive (T_e2e); 0: skip")
+    ap.add_argument("--e2e-bases", type=float, default=2.0e10, help="bases of the FASTQ the command-line compressor is timed on, file to archive (T_e2e); 0: skip")
     ap.add_argument("--no-qual", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ref-cut", action="store_true", help="skip the extra pass with the reference's 4-Mi-symbol coder parts (the byte-identical mode)")

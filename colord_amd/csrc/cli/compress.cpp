@@ -484,6 +484,23 @@ void code_headers(const Reader& R, uint32_t n, int header_mode, std::vector<std:
 	}
 	cl_id_coder_free(idc);
 }
+// Device buffers of chunks that come and go (--stream-input, one or several ranks): kept and handed out again instead of a hipMalloc + hipFree
+// per chunk — hipFree waits for the WHOLE device, i.e. for the lanes and the preparation working ahead on the chunks after.
+struct DevCache {
+	std::vector<std::pair<void*, uint64_t>> idle; std::mutex mu;
+	void* get(uint64_t bytes, uint64_t& cap)
+	{
+		std::lock_guard<std::mutex> l(mu);
+		size_t best = idle.size();
+		for (size_t i = 0; i < idle.size(); ++i) if (idle[i].second >= bytes && (best == idle.size() || idle[i].second < idle[best].second)) best = i;
+		if (best != idle.size()) { void* p = idle[best].first; cap = idle[best].second; idle.erase(idle.begin() + (long)best); return p; }
+		void* p = nullptr; cap = bytes + bytes / 8 + 4096;                       // (a little room: the chunks are alike, not equal)
+		if (hipMalloc(&p, cap) != hipSuccess) { (void)hipGetLastError(); cap = bytes; if (hipMalloc(&p, cap) != hipSuccess) { (void)hipGetLastError(); return nullptr; } }
+		return p;
+	}
+	void put(void* p, uint64_t cap) { std::lock_guard<std::mutex> l(mu); if (p) idle.emplace_back(p, cap); }
+	void clear() { std::lock_guard<std::mutex> l(mu); for (auto& x : idle) (void)hipFree(x.first); idle.clear(); }
+};
 struct DevChunk { cl_reads* reads = nullptr; uint8_t* d_quals = nullptr; uint64_t* d_off = nullptr; std::vector<uint32_t> packs, parts; uint64_t n_bases = 0; uint32_t n_reads = 0; uint64_t quals_cap = 0, off_cap = 0; };
 } // namespace
 
@@ -707,20 +724,7 @@ static int run_compress_multi(const Options& O, const Preset& P, const QDef& qd,
 		// pass) and freed after each: its buffers come from and go back to a small per-rank cache — round 5 made a hipMalloc and a hipFree per
 		// buffer and chunk, and hipFree waits for the WHOLE device: every announce stalled the lanes and preparation threads of all ranks on
 		// the GPU.  (Resident input: every buffer is asked for once.)
-		struct DevCache {
-			std::vector<std::pair<void*, uint64_t>> idle;
-			void* get(uint64_t bytes, uint64_t& cap)
-			{
-				size_t best = idle.size();
-				for (size_t i = 0; i < idle.size(); ++i) if (idle[i].second >= bytes && (best == idle.size() || idle[i].second < idle[best].second)) best = i;
-				if (best != idle.size()) { void* p = idle[best].first; cap = idle[best].second; idle.erase(idle.begin() + (long)best); return p; }
-				void* p = nullptr; cap = bytes + bytes / 8 + 4096;                       // (a little room: the chunks of a rank are alike, not equal)
-				if (hipMalloc(&p, cap) != hipSuccess) { (void)hipGetLastError(); cap = bytes; if (hipMalloc(&p, cap) != hipSuccess) { (void)hipGetLastError(); return nullptr; } }
-				return p;
-			}
-			void put(void* p, uint64_t cap) { if (p) idle.emplace_back(p, cap); }
-			void clear() { for (auto& x : idle) (void)hipFree(x.first); idle.clear(); }
-		} dcache;
+		DevCache dcache;
 		uint8_t* d_bases_stage = nullptr; uint64_t bases_stage_cap = 0;          // (the 1-byte-per-base form cl_reads_pack reads: needed only during the call)
 		auto upload_chunk = [&](DevChunk& dc) {
 			if (host.n + 1 > bases_stage_cap) { if (d_bases_stage) hipck(hipFree(d_bases_stage), "hipFree"); d_bases_stage = (uint8_t*)dcache.get(host.n + 1, bases_stage_cap); if (!d_bases_stage) die("hipMalloc"); }
@@ -1153,12 +1157,20 @@ int run_compress(int argc, char** argv)
 	// (the 1-byte-per-base form cl_reads_pack reads is needed only during the call: ONE staging buffer per calling thread, kept — a
 	// hipMalloc + hipFree per chunk were two device-wide synchronisations in front of every chunk's k-mer scan)
 	struct BaseStage { uint8_t* p = nullptr; uint64_t cap = 0; hipStream_t s[2] = { nullptr, nullptr }; ~BaseStage() { if (p) (void)hipFree(p); for (hipStream_t x : s) if (x) (void)hipStreamDestroy(x); } };
-	BaseStage stage_main, stage_loader;
+	BaseStage stage_main, stage_loader; DevCache dcache;
 	auto upload_chunk = [&](cl_ctx* uc, const Chunk& host, DevChunk& dc) {
 		BaseStage& bs = uc == ctx ? stage_main : stage_loader;
 		if (host.n + 1 > bs.cap) { if (bs.p) hipck(hipFree(bs.p), "hipFree"); bs.cap = host.n + host.n / 8 + 4096; hipck(hipMalloc((void**)&bs.p, bs.cap), "hipMalloc"); }
-		hipck(hipMalloc((void**)&dc.d_off, host.off.size() * 8), "hipMalloc");
-		if (with_qual) hipck(hipMalloc((void**)&dc.d_quals, host.n + 1), "hipMalloc (the input does not fit this GPU's memory: --stream-input keeps only a window of it resident)");
+		if (O.stream_input)
+		{	// (the window's buffers go round: DevCache)
+			dc.d_off = (uint64_t*)dcache.get(host.off.size() * 8, dc.off_cap); if (with_qual) dc.d_quals = (uint8_t*)dcache.get(host.n + 1, dc.quals_cap);
+			if (!dc.d_off || (with_qual && !dc.d_quals)) die("out of device memory for a chunk of the input");
+		}
+		else
+		{
+			hipck(hipMalloc((void**)&dc.d_off, host.off.size() * 8), "hipMalloc");
+			if (with_qual) hipck(hipMalloc((void**)&dc.d_quals, host.n + 1), "hipMalloc (the input does not fit this GPU's memory: --stream-input keeps only a window of it resident)");
+		}
 		// bases and qualities on a stream each (two copy engines side by side; one after the other they took 91 ms per 2 GB)
 		if (!bs.s[0]) for (int i = 0; i < 2; ++i) hipck(hipStreamCreateWithFlags(&bs.s[i], hipStreamNonBlocking), "hipStreamCreate");
 		hipck(hipMemcpyAsync(bs.p, host.bases, host.n, hipMemcpyHostToDevice, bs.s[0]), "hipMemcpyAsync");
@@ -1169,8 +1181,8 @@ int run_compress(int argc, char** argv)
 	};
 	auto free_chunk = [&](DevChunk& dc) {
 		if (dc.reads) cl_reads_free(dc.reads);
-		if (dc.d_quals) (void)hipFree(dc.d_quals);
-		if (dc.d_off) (void)hipFree(dc.d_off);
+		if (O.stream_input) { dcache.put(dc.d_quals, dc.quals_cap); dcache.put(dc.d_off, dc.off_cap); }
+		else { if (dc.d_quals) (void)hipFree(dc.d_quals); if (dc.d_off) (void)hipFree(dc.d_off); }
 		dc.reads = nullptr; dc.d_quals = nullptr; dc.d_off = nullptr;
 	};
 	// a later pass must see the chunks of the first
