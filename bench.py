@@ -569,6 +569,17 @@ def e2e_cli(bases: float, coverage: float, k: int, a: int, part_symbols: int, gp
         os.sync()                                           # (the input's own write-back is not part of what is timed: without this the timed command's output waits behind 10 GB of dirty pages)
         t_gen = time.time() - t0
         out = {}
+        if gpus == 1:
+            # One UNTIMED run of the same command first (as the timed passes have their warm-up passes): the first GPU process on a device that has
+            # idled — here: while the FASTQ was written — runs 1.4-1.5 x slower, every kernel and copy of it: 13.0-15.1 s against 9.6-10.4 s for the
+            # runs after it at 20 Gbases (profiles/r06_e2e_20Gbases.txt; a 1.3-s run on 0.5 Gbases in front was enough on one box and not on another)
+            warm = os.path.join(tmp, "e2e_warm.colord")
+            try:
+                subprocess.run([ours, "compress-ont", "-k", str(k), "-a", str(a), "--part-symbols", str(part_symbols), fq, warm], capture_output=True, text=True, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                pass
+            if os.path.exists(warm):
+                os.remove(warm)
         for name, ps in (("headline_cut", part_symbols), ("ref_cut", 1 << 22)):
             if name == "ref_cut" and ps == part_symbols:
                 continue
@@ -591,7 +602,7 @@ def e2e_cli(bases: float, coverage: float, k: int, a: int, part_symbols: int, gp
             if r.returncode != 0:
                 out[name] = {"error": (r.stderr or r.stdout)[-300:]}
                 continue
-            phases = [l.strip() for l in r.stderr.splitlines() if l.strip().startswith("[")][-12:]
+            phases = [l.strip() for l in r.stderr.splitlines() if l.strip().startswith(("[", "# "))][-16:]
             out[name] = {"value": n_bases / dt / 1e9, "unit": "Gbases/s", "seconds": round(dt, 2), "part_symbols": ps, "archive_bytes": os.path.getsize(arc), "phases": phases}
             os.remove(arc)
         first = out.get("headline_cut") or {}
@@ -599,7 +610,10 @@ def e2e_cli(bases: float, coverage: float, k: int, a: int, part_symbols: int, gp
                "what": f"colord_hip compress-ont -k {k} -a {a} --part-symbols N" + (f" --gpus {gpus}" if gpus > 1 else "") + " file -> archive, whole process (mapped file indexed by several threads, chunks filled by parallel copies into "
                        f"pinned double buffers); `value` is with the headline's part cut ({part_symbols}), `ref_cut` with the reference's 4194304 (byte-identical archive). "
                        f"INPUT STATE: the FASTQ was written by this process just before, `sync`ed, and is PAGE-CACHE RESIDENT when the timed command starts (a warm-file number, "
-                       f"not a cold-disk one); an 8-s pause precedes the timed command (the driver's clean-up of the memory the process before gave back is not part of it)"
+                       f"not a cold-disk one); an 8-s pause precedes the timed command (the driver's clean-up of the memory the process before gave back is not part of it). "
+                       f"PROTOCOL (round 6): at N = 1 this leg runs FIRST, before this process has touched the GPU — behind the timed passes, with this process's HIP context alive "
+                       f"and device memory of its pools not yet back with the driver, the same command took 37-51 s instead of 10 (profiles/r06_n_*) — and ONE UNTIMED run of "
+                       f"the same command precedes the timed one (the first GPU process on a device that idled while the FASTQ was written runs 1.4-1.5 x slower)"
                        + ("; the C++ host: one rank thread per GPU, exchanges over RCCL (or host-staged), each rank writes its own parts" if gpus > 1 else "")}
         res.update(out)
         return res
@@ -699,16 +713,25 @@ def main():
                 preflight = {"command": f"colord_hip rccl-selftest --gpus {n_self}", "rc": None, "seconds": round(time.time() - t0, 2), "error": repr(e)[:300]}
         dist.barrier()
 
+    # N = 1: the command-line leg (T_e2e) FIRST, while this process has not touched the GPU (see `t_e2e.what`)
+    e2e_first = None
+    if world == 1 and args.e2e_bases > 0 and not args.no_cpu_baseline:
+        k_, a_ = kmer_anchor_len(float(args.bases))
+        k_, a_ = (args.k or k_), (args.a or a_)
+        try:
+            e2e_first = e2e_cli(args.e2e_bases, args.coverage, k_, a_, args.pack_symbols)
+        except Exception as e:
+            e2e_first = {"error": repr(e)[:400]}
     ctx = Context(local, timing=not os.environ.get("BENCH_NO_TIMING"))
     qctx = Context(local, timing=not os.environ.get("BENCH_NO_TIMING")) if not os.environ.get("BENCH_NO_OVERLAP") else None
     bases = float(args.bases)
-    # what the passes may take: the deadline minus what is spent already, the CPU-baseline / size-check leg (~2 min) and a margin
-    reserve_s = (150.0 if (world == 1 and not args.no_cpu_baseline) else 30.0) + 30.0
+    # what the passes may take: the deadline minus what is spent already, the CPU-baseline / size-check leg (~1.5 min) and a margin
+    reserve_s = (100.0 if (world == 1 and not args.no_cpu_baseline) else 30.0) + 30.0
     pass_budget_s = max(10.0, args.deadline_s - (time.time() - T_PROCESS_START) - reserve_s - bases / 5e9)
-    est_s = (args.steps + args.warmup) * bases / (1.1e9 * world)
+    est_s = (args.steps + args.warmup) * bases / (2.0e9 * world)             # (25 s a pass of 50 Gbases on one GPU: measured 17-18)
     reduced = False
     if est_s > pass_budget_s:
-        bases = max(1e8, pass_budget_s * 1.1e9 * world / (args.steps + args.warmup))
+        bases = max(1e8, pass_budget_s * 2.0e9 * world / (args.steps + args.warmup))
         reduced = True
     genome_len = max(1_000_000, int(bases / args.coverage))
     table = ontsim.ReadTable(seed=1, genome_len=genome_len, target_bases=int(bases))        # the same table on every rank
@@ -918,10 +941,7 @@ def main():
             if qctx is not None:
                 qctx.close()
             torch.cuda.empty_cache()
-            try:
-                e2e = e2e_cli(args.e2e_bases, args.coverage, k, a, args.pack_symbols)
-            except Exception as e:
-                e2e = {"error": repr(e)[:400]}
+            e2e = e2e_first                                  # (measured at the start of the process)
             ctx = Context(local)
             qctx = Context(local) if qctx is not None else None
         value = total_bases * args.steps / dt / 1e9

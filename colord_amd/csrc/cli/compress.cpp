@@ -1166,11 +1166,21 @@ int run_compress(int argc, char** argv)
 			if (with_qual) hipck(hipMalloc((void**)&dc.d_quals, host.n + 1), "hipMalloc (the input does not fit this GPU's memory: --stream-input keeps only a window of it resident)");
 		}
 		// bases and qualities on a stream each (two copy engines side by side; one after the other they took 91 ms per 2 GB)
-		if (!bs.s[0]) for (int i = 0; i < 2; ++i) hipck(hipStreamCreateWithFlags(&bs.s[i], hipStreamNonBlocking), "hipStreamCreate");
-		hipck(hipMemcpyAsync(bs.p, host.bases, host.n, hipMemcpyHostToDevice, bs.s[0]), "hipMemcpyAsync");
-		if (with_qual) hipck(hipMemcpyAsync(dc.d_quals, host.quals, host.n, hipMemcpyHostToDevice, bs.s[1]), "hipMemcpyAsync");
-		hipck(hipMemcpy(dc.d_off, host.off.data(), host.off.size() * 8, hipMemcpyHostToDevice), "hipMemcpy");
-		hipck(hipStreamSynchronize(bs.s[0]), "hipMemcpyAsync"); hipck(hipStreamSynchronize(bs.s[1]), "hipMemcpyAsync");
+		static const bool two_engines = !getenv("COLORD_HIP_UPLOAD_ONE_ENGINE");
+		if (two_engines)
+		{
+			if (!bs.s[0]) for (int i = 0; i < 2; ++i) hipck(hipStreamCreateWithFlags(&bs.s[i], hipStreamNonBlocking), "hipStreamCreate");
+			hipck(hipMemcpyAsync(bs.p, host.bases, host.n, hipMemcpyHostToDevice, bs.s[0]), "hipMemcpyAsync");
+			if (with_qual) hipck(hipMemcpyAsync(dc.d_quals, host.quals, host.n, hipMemcpyHostToDevice, bs.s[1]), "hipMemcpyAsync");
+			hipck(hipMemcpy(dc.d_off, host.off.data(), host.off.size() * 8, hipMemcpyHostToDevice), "hipMemcpy");
+			hipck(hipStreamSynchronize(bs.s[0]), "hipMemcpyAsync"); hipck(hipStreamSynchronize(bs.s[1]), "hipMemcpyAsync");
+		}
+		else
+		{
+			hipck(hipMemcpy(bs.p, host.bases, host.n, hipMemcpyHostToDevice), "hipMemcpy");
+			if (with_qual) hipck(hipMemcpy(dc.d_quals, host.quals, host.n, hipMemcpyHostToDevice), "hipMemcpy");
+			hipck(hipMemcpy(dc.d_off, host.off.data(), host.off.size() * 8, hipMemcpyHostToDevice), "hipMemcpy");
+		}
 		ck(uc, cl_reads_pack(uc, bs.p, dc.d_off, dc.n_reads, 1, &dc.reads), "input");        // "Only ACGTN symbols supported inside a read"
 	};
 	auto free_chunk = [&](DevChunk& dc) {
@@ -1355,7 +1365,12 @@ int run_compress(int argc, char** argv)
 					ck(ctx, cl_compressor_prepare_parts(cmp, x.reads, x.packs.data(), (uint32_t)x.packs.size() - 1, x.parts.data(), (uint32_t)x.parts.size() - 1, x.d_quals, x.d_off), "look-ahead");
 				}
 			}
-			if (ci == 0) lap("pass 2 set up, chunks announced");
+			if (ci == 0)
+			{
+				lap("pass 2 set up, chunks announced");
+				size_t fr = 0, tot = 0;
+				if (O.verbose && hipMemGetInfo(&fr, &tot) == hipSuccess) fprintf(stderr, "# device memory before the first chunk of pass 2: %.1f of %.1f GB free\n", fr / 1e9, tot / 1e9);
+			}
 			const uint32_t np = (uint32_t)dc.parts.size() - 1;
 			std::vector<uint64_t> dsz(np), qsz(np); cl_compress_info info{};
 			const int b = (int)(ci & 1);
@@ -1382,6 +1397,7 @@ int run_compress(int argc, char** argv)
 		ocv.notify_all();
 		const auto tj = std::chrono::steady_clock::now();
 		writer.join();
+		{ size_t fr = 0, tot = 0; if (O.verbose && hipMemGetInfo(&fr, &tot) == hipSuccess) fprintf(stderr, "# device memory after pass 2: %.1f of %.1f GB free\n", fr / 1e9, tot / 1e9); }
 		if (O.verbose) fprintf(stderr, "# pass 2, this thread: %.2f s in the encode calls, %.2f s waiting for the writer to hand a buffer set back, %.2f s for its last parts; the writer: %.2f s adding parts to the archive\n",
 			t_encode, t_wait_writer, std::chrono::duration<double>(std::chrono::steady_clock::now() - tj).count(), t_writer);
 		if (!oerr.empty()) { (void)remove(O.out.c_str()); die(oerr + " (no archive was written)"); }     // (what is on disk is half a file: it goes with the error)

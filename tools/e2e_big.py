@@ -14,11 +14,39 @@ print(f"{base_dir}: {free / 1e9:.0f} GB free; need {2.6 * bases / 1e9:.0f} GB", 
 if free < 2.6 * bases:
     bases = max(1e9, free / 2.6 * 0.9)
     print(f"reduced to {bases / 1e9:.1f} Gbases", flush=True)
+if os.environ.get("E2E_PARENT_GPU"):                 # this process holds an (idle) HIP context while the command line runs, as bench.py does
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+    import torch
+    from colord_amd.device import Context
+    ctxs = [Context(0) for _ in range(int(os.environ["E2E_PARENT_GPU"]))]
+    x = torch.zeros(1 << 20, device="cuda"); torch.cuda.synchronize()
+    codes, off, _ = ontsim.device_reads(ontsim.ReadTable(seed=3, genome_len=1_000_000, target_bases=20_000_000), ctxs[0].device, 0, 100, with_quals=False)
+    r = ctxs[0].pack_reads(codes, off); km = ctxs[0].kmer_scan(r, 25, 12); torch.cuda.synchronize()
+    r.free(); del km, codes, off, x
+    for c in ctxs:
+        c.close()
+    torch.cuda.empty_cache()
+    nq = int(os.environ.get("E2E_PARENT_QUEUES", "0"))            # ... and that many of its own streams have seen work (hardware queues made, now idle)
+    keep = [torch.cuda.Stream() for _ in range(nq)]
+    for st in keep:
+        with torch.cuda.stream(st):
+            torch.zeros(1024, device="cuda").add_(1)
+    hold = [torch.empty(1 << 30, dtype=torch.uint8, device="cuda").fill_(1) for _ in range(int(os.environ.get("E2E_PARENT_HOLD_GB", "0")))]   # ... and it keeps that many GiB of HBM
+    torch.cuda.synchronize()
+    print(f"parent: holds {len(hold)} GiB of device memory", flush=True)
+    print(f"parent: HIP context alive, idle ({len(ctxs)} contexts made and closed, {nq} streams used once and kept)", flush=True)
 t = ontsim.ReadTable(seed=41, genome_len=max(1_000_000, int(bases / 16.7)), target_bases=int(bases))
 with tempfile.TemporaryDirectory(dir=base_dir) as tmp:
     fq = os.path.join(tmp, "in.fastq")
     t0 = time.time(); nb = ontsim.write_fastq(t, fq); os.sync()
     print(f"fastq: {nb} bases, {os.path.getsize(fq)} bytes, written in {time.time() - t0:.1f} s", flush=True)
+    if os.environ.get("E2E_TINY_FIRST"):                  # a throw-away run of the command on a small sample first (is it the first GPU process that is slow, whatever its size?)
+        tb = float(os.environ["E2E_TINY_FIRST"])
+        tfq = os.path.join(tmp, "tiny.fastq")
+        ontsim.write_fastq(ontsim.ReadTable(seed=42, genome_len=max(1_000_000, int(tb / 16.7)), target_bases=int(tb)), tfq)
+        t0 = time.time()
+        r = subprocess.run([cli, "compress-ont", "-k", "25", "-a", "22", "--part-symbols", "65536", tfq, os.path.join(tmp, "tiny.colord")], capture_output=True, text=True)
+        print(f"tiny first run ({tb / 1e9:.2f} Gbases): exit {r.returncode}, {time.time() - t0:.2f} s", flush=True)
     runs = [("resident", [], {}), ("stream-input", ["--stream-input"], {})]
     if os.environ.get("E2E_RUNS"):                        # e.g. E2E_RUNS="pread:COLORD_HIP_COPY_PREAD=1;t64:--parse-threads=64": name:ENV=v,--flag=v,...
         runs = []
