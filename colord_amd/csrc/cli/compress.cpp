@@ -1392,6 +1392,7 @@ int run_compress(int argc, char** argv)
 			// (a resident chunk stays where it is until the pass is over: hipFree waits for the whole device — the lanes and the preparation
 			// working ahead on the next chunks — and nobody needs the room)
 			if (O.stream_input) { { std::lock_guard<std::mutex> l(lmu); done_upto = ci + 1; } lcv.notify_all(); }     // (the loader frees it)
+			else { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr < (48ull << 30)) free_chunk(dc); }   // (... unless the device is nearly full: the pools of the chunks to come take what this one held)
 		}
 		{ std::lock_guard<std::mutex> l(omu); odone = true; }
 		ocv.notify_all();
