@@ -195,14 +195,20 @@ struct TaskCfg { uint32_t r0, r1, c, m; uint32_t pe, pr; double frac_always, fra
 constexpr uint32_t FILT_WORDS = 2048, STAGE = 128;
 __device__ inline uint32_t filt_word(uint64_t hash) { return (uint32_t)(hash >> 46) & (FILT_WORDS - 1); }
 __device__ inline uint64_t filt_mask(uint64_t hash) { return (1ull << ((hash >> 40) & 63)) | (1ull << ((hash >> 34) & 63)) | (1ull << ((hash >> 28) & 63)); }
+// A LONG read is matched by several blocks, each for a SEGMENT of its positions (round 6): the filter of a block holds the m-mers of its
+// segment only — 131 072 bits take the 3 bits a position of ~16 k positions (0.6-2.4 % of the misses pass) but are 3/4 full for a read of
+// 60 k, where 42 % passed and went to the table in HBM: reads above 24 576 m-mers, 39 % of the bases, took 65 % of this kernel's time — and
+// the hits it emits are those whose read position lies in its segment (the table and its chains are the read's: a walk skips the others).
+// Every pair comes out exactly once; the reference is hashed once per segment (ALU the kernel has to spare).
+__device__ __host__ inline uint32_t match_segments(uint32_t n, uint32_t seg_n) { return (seg_n == 0 || n <= seg_n + seg_n / 2) ? 1u : (n + seg_n - 1) / seg_n; }
 __global__ __launch_bounds__(256) void k_match(Arena A, Arena R, EncTable T, TaskCfg cfg, const uint32_t* __restrict__ cand_refs, const uint32_t* __restrict__ cand_n,
-                                              const uint32_t* __restrict__ n_distinct, uint32_t n_reads,
+                                              const uint32_t* __restrict__ n_distinct, const uint2* __restrict__ work /* (read of the batch, segment) */, uint32_t n_work, uint32_t seg_n,
                                               unsigned long long* __restrict__ n_pairs, uint64_t cap, uint64_t* __restrict__ pairs)
 {
 	__shared__ unsigned long long filt[FILT_WORDS];
 	__shared__ uint64_t stage_all[4][STAGE];                          // per wave: pairs on their way out
-	const uint32_t rl = blockIdx.x;
-	if (rl >= n_reads) return;
+	if (blockIdx.x >= n_work) return;
+	const uint32_t rl = work[blockIdx.x].x, seg = work[blockIdx.x].y;
 	const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	const uint32_t r = cfg.r0 + rl;
 	const uint64_t t0 = T.toff[rl]; const uint32_t tsz = (uint32_t)(T.toff[rl + 1] - t0);
@@ -213,9 +219,13 @@ __global__ __launch_bounds__(256) void k_match(Arena A, Arena R, EncTable T, Tas
 	if ((double)n_distinct[rl] < cfg.frac_min * (double)elen && !((double)n_distinct[rl] > cfg.frac_always * (double)elen)) return;
 	for (uint32_t i = threadIdx.x; i < FILT_WORDS; i += 256) filt[i] = 0;
 	__syncthreads();
+	uint32_t p_lo, p_hi;
 	{
 		const uint64_t ewb = A.word_off[r]; const uint32_t n = elen - cfg.m + 1;       // tsz != 0: elen >= m
-		for (uint32_t p = threadIdx.x; p < n; p += 256)
+		const uint32_t nseg = match_segments(n, seg_n);
+		if (seg >= nseg) return;                                                        // (never: the host lists the segments by the same rule)
+		p_lo = (uint32_t)((uint64_t)n * seg / nseg); p_hi = (uint32_t)((uint64_t)n * (seg + 1) / nseg);
+		for (uint32_t p = p_lo + threadIdx.x; p < p_hi; p += 256)
 		{
 			const uint64_t xf = mmer_at(A, ewb, p, cfg.m), xr = revcomp_m(xf, cfg.m);
 			const uint64_t hash = hash_mm(xf < xr ? xf : xr);
@@ -244,7 +254,7 @@ __global__ __launch_bounds__(256) void k_match(Arena A, Arena R, EncTable T, Tas
 		const uint32_t nq = rlen - cfg.m + 1, sl = rl * cfg.c + slot;
 		const uint32_t PR = cfg.pr; const uint32_t pr_mask = (1u << PR) - 1;
 		const uint64_t key_rev = (uint64_t)(2 * sl) << (cfg.pe + PR), key_fwd = (uint64_t)(2 * sl + 1) << (cfg.pe + PR);
-		if (threadIdx.x == 0) atomicAdd(n_pairs + 1, (unsigned long long)nq);      // probes, for the achieved-bandwidth report
+		if (threadIdx.x == 0 && seg == 0) atomicAdd(n_pairs + 1, (unsigned long long)nq);      // probes, for the achieved-bandwidth report
 		// Two steps are in flight: the reference words of step i + 2 are being loaded and the table slot of step i + 1 is being
 		// probed (first slot of its probe sequence: at load 0.5 nearly every look-up ends there) while the hits of step i walk
 		// their chains — one memory latency per step instead of three in a row (words, slot, chain).
@@ -299,7 +309,8 @@ __global__ __launch_bounds__(256) void k_match(Arena A, Arena R, EncTable T, Tas
 					h = (h & ~rmask) | ((h + 1) & rmask);
 					sl8 = T.slots[t0 + h];
 				}
-				for (uint32_t p = head; p != NIL; p = T.next[n0 + (p & LINK_POS)]) cnt += (uint32_t)((p >> 31) == fs) + (uint32_t)((p >> 31) == rs_);
+				for (uint32_t p = head; p != NIL; p = T.next[n0 + (p & LINK_POS)])
+					if ((p & LINK_POS) >= p_lo && (p & LINK_POS) < p_hi) cnt += (uint32_t)((p >> 31) == fs) + (uint32_t)((p >> 31) == rs_);
 			}
 			cur = nxt; hi1 = hi2; lo1 = lo2;
 			if (!__any(cnt != 0)) continue;
@@ -311,6 +322,7 @@ __global__ __launch_bounds__(256) void k_match(Arena A, Arena R, EncTable T, Tas
 				uint32_t o = fill + incl - cnt;
 				for (uint32_t p = head; p != NIL; p = T.next[n0 + (p & LINK_POS)])
 				{
+					if ((p & LINK_POS) < p_lo || (p & LINK_POS) >= p_hi) continue;
 					const uint64_t pos = (uint64_t)(p & LINK_POS) << PR;
 					if ((p >> 31) == fs) stage[o++] = kf | pos;
 					if ((p >> 31) == rs_) stage[o++] = kr | pos;
@@ -326,6 +338,7 @@ __global__ __launch_bounds__(256) void k_match(Arena A, Arena R, EncTable T, Tas
 			uint64_t o = base + incl - cnt;
 			for (uint32_t p = head; p != NIL; p = T.next[n0 + (p & LINK_POS)])
 			{
+				if ((p & LINK_POS) < p_lo || (p & LINK_POS) >= p_hi) continue;
 				const uint64_t pos = (uint64_t)(p & LINK_POS) << PR;
 				if ((p >> 31) == fs) pairs[o++] = kf | pos;
 				if ((p >> 31) == rs_) pairs[o++] = kr | pos;
@@ -907,6 +920,7 @@ extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* read
 	struct TableBatch {
 		uint32_t r0 = 0, r1 = 0, pe = 1; uint64_t acc = 0, nsum = 0;
 		DevBuf<uint32_t> n_distinct, next, err; DevBuf<uint64_t> toff, noff; DevBuf<EncSlot> slots; DevBuf<uint2> bins;
+		std::vector<uint2> h_work; DevBuf<uint2> work;                           // k_match's blocks: (read of the batch, segment of its positions)
 		struct SideSync { hipStream_t s = nullptr; ~SideSync() { if (s) (void)hipStreamSynchronize(s); } } sync;   // destroyed first
 	};
 	HIP_TRY(ctx, cl_side_stream(ctx, ctx->side));
@@ -918,6 +932,8 @@ extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* read
 	constexpr uint32_t LDS_N_A = 12288, LDS_N_B = 24576, LDS_NT = 1024;
 	uint32_t lds_max_n = 0;
 	if (const char* e = getenv("COLORD_HIP_ANCHORS_LDS")) lds_max_n = atoi(e) <= 0 ? 0u : (uint32_t)atoi(e) <= LDS_N_A ? LDS_N_A : LDS_N_B;
+	// reads above 1.5 x this many m-mers are matched segment by segment (k_match); COLORD_HIP_MATCH_SEG=0: one block per read whatever its length
+	const uint32_t match_seg = getenv("COLORD_HIP_MATCH_SEG") ? (uint32_t)std::max(0, atoi(getenv("COLORD_HIP_MATCH_SEG"))) : 16384u;
 	const uint32_t lds_dbg = getenv("COLORD_HIP_LDS_DBG") ? (uint32_t)atoi(getenv("COLORD_HIP_LDS_DBG")) : 0u;
 	auto prepare = [&](uint32_t r0, std::unique_ptr<TableBatch>& out) -> cl_status {
 		out = std::make_unique<TableBatch>();
@@ -932,6 +948,8 @@ extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* read
 			mx = std::max(mx, h_len[r1]); acc += h_len[r1]; ++r1;
 		}
 		B.r0 = r0; B.r1 = r1; B.acc = acc; B.pe = bits_for(mx);
+		for (uint32_t r = r0; r < r1; ++r)
+			for (uint32_t sg = 0, ns = match_segments(h_len[r] >= m ? h_len[r] - m + 1 : 0, match_seg); sg < ns; ++sg) B.h_work.push_back(make_uint2(r - r0, sg));
 		if (B.pe + pr_bits + bits_for((r1 - r0) * 2 * c) > 64) return cl_fail(ctx, CL_E_UNSUPPORTED, "cl_anchor_candidates: a read and its candidates are too long for 64-bit match keys");
 		const uint32_t nb = r1 - r0;
 		const uint32_t table_x4 = 8;                                          // table slots per m-mer, in quarters (8 = load 0.5; denser tables were slower: longer probe chains)
@@ -949,6 +967,8 @@ extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* read
 		CL_TRY(dev_exclusive_scan_u64(ctx, nsize.p, B.noff.p, nb, &B.nsum));      // (waits for the side stream: sizes, offsets and err are complete)
 		uint32_t herr = 0; HIP_TRY(ctx, hipMemcpyAsync(&herr, err.p, 4, hipMemcpyDeviceToHost, ctx->side)); HIP_TRY(ctx, hipStreamSynchronize(ctx->side));
 		DEV_ALLOC(ctx, B.slots, tsum); DEV_ALLOC(ctx, B.next, B.nsum); DEV_ALLOC(ctx, B.bins, B.nsum); DEV_ALLOC(ctx, B.err, 1);
+		DEV_ALLOC(ctx, B.work, B.h_work.size() + 1);
+		if (!B.h_work.empty()) HIP_TRY(ctx, hipMemcpyAsync(B.work.p, B.h_work.data(), B.h_work.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->side));   // (h_work lives as long as the batch)
 		HIP_TRY(ctx, hipMemsetAsync(B.n_distinct.p, 0, (uint64_t)nb * 4, ctx->side));
 		HIP_TRY(ctx, hipMemsetAsync(B.err.p, 0, 4, ctx->side));                  // (the slots are written region by region, all of them)
 		EncTable T{ B.slots.p, B.toff.p, B.next.p, B.noff.p };
@@ -984,7 +1004,7 @@ extern "C" cl_status cl_anchor_candidates_hifi(cl_ctx* ctx, const cl_reads* read
 				if (lds_max_n > LDS_N_A)
 					LAUNCH_NAMED(ctx, "k_match_lds<24576>", (k_match_lds<LDS_N_B, 4096, LDS_NT, 4>), nb, LDS_NT, A, R, cfg, LDS_N_A, (const uint8_t*)reads->has_n.p, d_cand_refs, d_cand_n, n_distinct.p, nb, d_np.p, cap, pairs.p, lds_dbg);
 			}
-			LAUNCHB(ctx, 0.0, k_match, nb, 256, A, R, T, cfg, d_cand_refs, d_cand_n, (const uint32_t*)n_distinct.p, nb, d_np.p, cap, pairs.p);
+			LAUNCHB(ctx, 0.0, k_match, (uint32_t)cur->h_work.size(), 256, A, R, T, cfg, d_cand_refs, d_cand_n, (const uint32_t*)n_distinct.p, (const uint2*)cur->work.p, (uint32_t)cur->h_work.size(), match_seg, d_np.p, cap, pairs.p);
 			HIP_TRY(ctx, hipGetLastError());
 			unsigned long long h_np2[2] = { 0, 0 };
 			HIP_TRY(ctx, hipMemcpyAsync(h_np2, d_np.p, 16, hipMemcpyDeviceToHost, ctx->stream));

@@ -79,10 +79,11 @@ def test_anchor_candidates_tables_in_lds_equal_oracle(ctx, cfg, monkeypatch):
 
 
 def test_anchor_tables_in_lds_equal_tables_in_hbm(ctx, monkeypatch):
-    """Reads either side of both LDS class bounds (12 288 and 24 576 m-mers), a read whose m-mers repeat thousands of times (runs of
-    equal m-mers in the table, more hits in a wave step than the staging holds, the "too many matches" veto) and one with an N:
-    candidates and anchors with the tables in LDS (both classes; the small class only) == with every table in HBM, which the oracle
-    judges on the goldens."""
+    """Reads either side of both LDS class bounds (12 288 and 24 576 m-mers) and of the segment rule of k_match, a read whose m-mers
+    repeat thousands of times (runs of equal m-mers in the table, more hits in a wave step than the staging holds, the "too many
+    matches" veto) and one with an N: candidates and anchors with long reads matched by segments (three segment sizes) and with the
+    tables in LDS (both classes; the small class only) == with every table in HBM and one block per read, which the oracle judges on the
+    goldens and the reference's bytes on the bench's sample."""
     from colord_amd.fastq import ReadSet
     rng = np.random.default_rng(5)
     a, c = 16, 5
@@ -124,11 +125,16 @@ def test_anchor_tables_in_lds_equal_tables_in_hbm(ctx, monkeypatch):
         cn[i] = len(pool); cand[i, :cn[i]] = pool
     crefs, cnt = torch.from_numpy(cand).to(ctx.device), torch.from_numpy(cn).to(ctx.device)
     monkeypatch.delenv("COLORD_HIP_ANCHORS_LDS", raising=False)
+    monkeypatch.setenv("COLORD_HIP_MATCH_SEG", "0")                           # one k_match block per read whatever its length: the form of rounds 1-5
     want = _anchor_arrays(ctx, reads, refs, crefs, cnt, a)
     assert want[0].sum() >= 20 and want[3].size > 3000                        # candidates kept, anchors found
-    for setting in ("24576", "12288"):
-        monkeypatch.setenv("COLORD_HIP_ANCHORS_LDS", setting)
+    # long reads matched segment by segment (default: 16 384 positions a block; 1000 / 77: many segments for every read but the shortest),
+    # and the tables in LDS (with the default segments for the reads above the classes)
+    for name_, setting in (("COLORD_HIP_MATCH_SEG", None), ("COLORD_HIP_MATCH_SEG", "1000"), ("COLORD_HIP_MATCH_SEG", "77"), ("COLORD_HIP_ANCHORS_LDS", "24576"), ("COLORD_HIP_ANCHORS_LDS", "12288")):
+        monkeypatch.delenv("COLORD_HIP_ANCHORS_LDS", raising=False); monkeypatch.delenv("COLORD_HIP_MATCH_SEG", raising=False)
+        if setting is not None:
+            monkeypatch.setenv(name_, setting)
         got = _anchor_arrays(ctx, reads, refs, crefs, cnt, a)
         for w, g_, name in zip(want, got, ("n_cands", "cands", "offsets", "anchors")):
-            assert np.array_equal(w, g_), f"{name} differ with COLORD_HIP_ANCHORS_LDS={setting}"
+            assert np.array_equal(w, g_), f"{name} differ with {name_}={setting}"
     refs.free(); reads.free()

@@ -37,5 +37,6 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
 else:
     bases = sys.argv[1] if len(sys.argv) > 1 else "1e9"
     for v in (sys.argv[2:] or ["0", "12288", "24576"]):
-        print("COLORD_HIP_ANCHORS_LDS =", v, flush=True)
-        subprocess.run([sys.executable, __file__, "child", bases], env=dict(os.environ, COLORD_HIP_ANCHORS_LDS=v))
+        print("COLORD_HIP_ANCHORS_LDS =", v, flush=True)                   # (or NAME=value: any other switch, e.g. COLORD_HIP_MATCH_SEG=0)
+        extra = dict([v.split("=", 1)]) if "=" in v else {"COLORD_HIP_ANCHORS_LDS": v}
+        subprocess.run([sys.executable, __file__, "child", bases], env=dict(os.environ, **extra))
